@@ -1,0 +1,88 @@
+/* ORACLE (test infrastructure).  Game dispatch: mirrors the <G>Game adaptors (splendor/SplendorGame.py:16-60,
+ * santorini/SantoriniGame.py:16-60): every Game.py call = Board.copy_state + one Board method. */
+#include <string.h>
+#include "azg_oracle.h"
+
+void splendor_valid_moves(const azo_game*, const int8_t*, int, uint8_t*);
+int  splendor_make_move(const azo_game*, int8_t*, int, int, int64_t, azo_rng*);
+void splendor_game_ended(const azo_game*, const int8_t*, int, float*);
+void splendor_swap_players(const azo_game*, int8_t*, int);
+int  splendor_get_round(const azo_game*, const int8_t*);
+int  splendor_get_score(const azo_game*, const int8_t*, int);
+void splendor_init_board(const azo_game*, int8_t*, azo_rng*);
+int  splendor_symmetries(const azo_game*, const int8_t*, const float*, const uint8_t*, int8_t*, float*, uint8_t*, int);
+
+void santorini_valid_moves(const azo_game*, const int8_t*, int, uint8_t*);
+int  santorini_make_move(const azo_game*, int8_t*, int, int, int64_t, azo_rng*);
+void santorini_game_ended(const azo_game*, const int8_t*, int, float*);
+void santorini_swap_players(const azo_game*, int8_t*, int);
+int  santorini_get_round(const azo_game*, const int8_t*);
+int  santorini_get_score(const azo_game*, const int8_t*, int);
+void santorini_init_board(const azo_game*, int8_t*, azo_rng*);
+int  santorini_symmetries(const azo_game*, const int8_t*, const float*, const uint8_t*, int8_t*, float*, uint8_t*, int);
+
+int azo_game_init(azo_game* g, int game_id, int variant) {
+    memset(g, 0, sizeof(*g));
+    g->id = game_id;
+    g->variant = variant;
+    if (game_id == AZO_SPLENDOR) {
+        int n = variant ? variant : 2;
+        if (n < 2 || n > 4) return -1;
+        g->variant = n;
+        g->P = n;
+        g->rows = 32 + 10 * n + n * n;      /* observation_size, SplendorLogicNumba.py:90-92 */
+        g->cols = 7;
+        g->S = g->rows * g->cols;
+        g->A = 81;
+        return 0;
+    }
+    if (game_id == AZO_SANTORINI) {
+        int gods = variant ? variant : 11;
+        if (gods != 1 && gods != 11) return -1;
+        g->variant = gods;
+        g->P = 2;
+        g->rows = 25; g->cols = 3;          /* (5,5,3) SantoriniLogicNumba.py:13-15 */
+        g->S = 75;
+        g->A = gods * 2 * 9 * 9;            /* :17-19 */
+        return 0;
+    }
+    return -1;
+}
+
+void azo_valid_moves(const azo_game* g, const int8_t* s, int p, uint8_t* out) {
+    if (g->id == AZO_SPLENDOR) splendor_valid_moves(g, s, p, out);
+    else santorini_valid_moves(g, s, p, out);
+}
+int azo_make_move(const azo_game* g, int8_t* s, int mv, int p, int64_t seed, azo_rng* rng) {
+    return g->id == AZO_SPLENDOR ? splendor_make_move(g, s, mv, p, seed, rng) : santorini_make_move(g, s, mv, p, seed, rng);
+}
+void azo_game_ended(const azo_game* g, const int8_t* s, int np, float* out) {
+    if (g->id == AZO_SPLENDOR) splendor_game_ended(g, s, np, out);
+    else santorini_game_ended(g, s, np, out);
+}
+void azo_swap_players(const azo_game* g, int8_t* s, int k) {
+    if (g->id == AZO_SPLENDOR) splendor_swap_players(g, s, k);
+    else santorini_swap_players(g, s, k);
+}
+int azo_get_round(const azo_game* g, const int8_t* s) {
+    return g->id == AZO_SPLENDOR ? splendor_get_round(g, s) : santorini_get_round(g, s);
+}
+int azo_get_score(const azo_game* g, const int8_t* s, int p) {
+    return g->id == AZO_SPLENDOR ? splendor_get_score(g, s, p) : santorini_get_score(g, s, p);
+}
+void azo_init_board(const azo_game* g, int8_t* s, azo_rng* rng) {
+    if (g->id == AZO_SPLENDOR) splendor_init_board(g, s, rng);
+    else santorini_init_board(g, s, rng);
+}
+void azo_canonical(const azo_game* g, const int8_t* s, int player, int8_t* out) {
+    /* getCanonicalForm: SplendorGame.py:42-48, SantoriniGame.py:42-48 */
+    if (out != s) memcpy(out, s, (size_t)g->S);
+    if (player != 0) azo_swap_players(g, out, player);
+}
+int azo_symmetries(const azo_game* g, const int8_t* s, const float* pi, const uint8_t* valids, int8_t* os, float* op,
+                   uint8_t* ov, int max_sym) {
+    return g->id == AZO_SPLENDOR ? splendor_symmetries(g, s, pi, valids, os, op, ov, max_sym)
+                                 : santorini_symmetries(g, s, pi, valids, os, op, ov, max_sym);
+}
+
+const char* azo_version(void) { return "azg-oracle r1"; }

@@ -1,0 +1,123 @@
+"""Pins the CPU oracle (oracle/*.c) against golden vectors produced by the REFERENCE (tools/gen_golden.py) and against
+the RNG-free known answers of SURVEY.md Appendix C.  CPU-only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import azg_oracle as O
+
+VARIANTS = {
+    'splendor2': (O.SPLENDOR, 2), 'splendor3': (O.SPLENDOR, 3), 'splendor4': (O.SPLENDOR, 4),
+    'santorini1': (O.SANTORINI, 1), 'santorini11': (O.SANTORINI, 11),
+}
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize('variant', list(VARIANTS))
+def test_env_transitions(golden_dir, variant):
+    """G1: valid-move masks, next states, next player, game_ended, score, round, canonical form -- bit exact."""
+    d = load(golden_dir, 'env_%s.npz' % variant)
+    g = O.OracleGame(*VARIANTS[variant])
+    assert g.S == d['state'].shape[1] and g.A == int(d['A']) and g.P == int(d['P'])
+    n = len(d['state'])
+    assert n > 100
+    n_seed0 = 0
+    for i in range(n):
+        st, pl = d['state'][i], int(d['player'][i])
+        valid = g.getValidMoves(st, pl)
+        assert np.array_equal(np.packbits(valid.astype(np.uint8)), d['valid'][i]), (variant, i)
+        seed = int(d['seed'][i])
+        rng = g.rng(injected=d['uniforms'][i]) if seed == 0 else None
+        n_seed0 += seed == 0
+        nb, npl = g.getNextState(st, pl, int(d['action'][i]), random_seed=seed, rng=rng)
+        assert np.array_equal(nb, d['next_state'][i]), (variant, i, seed)
+        assert npl == int(d['next_player'][i])
+        assert np.array_equal(g.getGameEnded(nb, npl), d['ended'][i]), (variant, i)
+        assert [g.getScore(nb, p) for p in range(g.P)] == list(d['score'][i])
+        assert g.getRound(nb) == int(d['round'][i])
+        assert np.array_equal(g.getCanonicalForm(nb, npl), d['canonical'][i])
+    assert n_seed0 > 10
+
+
+@pytest.mark.parametrize('variant', list(VARIANTS))
+def test_symmetries(golden_dir, variant):
+    d = load(golden_dir, 'sym_%s.npz' % variant)
+    g = O.OracleGame(*VARIANTS[variant])
+    for i in range(len(d['state'])):
+        syms = g.getSymmetries(d['state'][i], d['pi'][i], d['valid'][i], max_sym=24)
+        assert len(syms) == int(d['count'][i])
+        for k, (s, p, v) in enumerate(syms):
+            assert np.array_equal(s.reshape(-1), d['out_state'][i][k]), (variant, i, k)
+            assert np.array_equal(p, d['out_pi'][i][k]), (variant, i, k)
+            assert np.array_equal(v.astype(np.uint8), d['out_valid'][i][k]), (variant, i, k)
+
+
+def oracle_tree_digest(mc, game):
+    h = hashlib.sha256()
+    keys = mc.keys()
+    order = sorted(range(len(keys)), key=lambda i: keys[i].tobytes())
+    for i in order:
+        nd = mc.node(keys[i])
+        h.update(keys[i].tobytes())
+        h.update(nd['Es'].tobytes())
+        if nd['has_policy']:
+            h.update(np.int64(nd['Ns']).tobytes())
+            h.update(nd['Nsa'].tobytes())
+            h.update(nd['Qsa'].tobytes())
+            h.update(nd['Ps'].tobytes())
+            h.update(np.float32(nd['Qs']).tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8)
+
+
+MCTS_VARIANTS = ['splendor2', 'splendor4', 'santorini1', 'santorini11']
+
+
+@pytest.mark.parametrize('typing', ['numpy2', 'numba'])
+@pytest.mark.parametrize('variant', MCTS_VARIANTS)
+def test_mcts_traces(golden_dir, variant, typing):
+    """G3: whole-tree parity (every node's Ns, Nsa, Qsa, Ps, Qs bit-exact through a SHA-256 digest)."""
+    d = load(golden_dir, 'mcts_%s_%s.npz' % (variant, typing))
+    g = O.OracleGame(*VARIANTS[variant])
+    for i in range(len(d['case_sims'])):
+        args = O.make_args(numMCTSSims=int(d['case_sims'][i]), cpuct=float(d['case_cpuct'][i]),
+                           fpu=float(d['case_fpu'][i]), universes=int(d['case_universes'][i]),
+                           forced_playouts=bool(d['case_forced'][i]), numpy2_scalar_typing=(typing == 'numpy2'))
+        mc = O.OracleMCTS(g, args)
+        probs, q, full = mc.getActionProb(d['case_root'][i], temp=1, force_full_search=True)
+        nd = mc.node(d['case_root'][i])
+        assert nd['Ns'] == int(d['case_Ns'][i]), (variant, i)
+        assert np.array_equal(nd['Nsa'], d['case_Nsa'][i]), (variant, i)
+        assert np.array_equal(nd['Qsa'], d['case_Qsa'][i]), (variant, i)
+        assert nd['Qs'] == d['case_Qs'][i]
+        assert np.array_equal(nd['Ps'], d['case_Ps'][i])
+        assert mc.num_nodes() == int(d['case_nodes'][i])
+        assert np.array_equal(probs, d['case_probs'][i])
+        assert np.array_equal(q, d['case_q'][i])
+        assert np.array_equal(oracle_tree_digest(mc, g), d['case_digest'][i]), (variant, i)
+
+
+@pytest.mark.parametrize('typing', ['numpy2', 'numba'])
+@pytest.mark.parametrize('variant', MCTS_VARIANTS)
+def test_mcts_sequence_tree_reuse(golden_dir, variant, typing):
+    """G3 sequence: tree reuse across moves, fast (non-full) searches, periodic clean-up (MCTS.py:86-91)."""
+    d = load(golden_dir, 'mcts_%s_%s.npz' % (variant, typing))
+    g = O.OracleGame(*VARIANTS[variant])
+    from tools_args import MCTS_ARGS
+    kw = dict(MCTS_ARGS[variant])
+    args = O.make_args(numMCTSSims=int(d['seq_sims']), no_mem_optim=False, prob_fullMCTS=0.0,
+                       numpy2_scalar_typing=(typing == 'numpy2'), **kw)
+    mc = O.OracleMCTS(g, args)
+    for i in range(len(d['seq_action'])):
+        probs, q, full = mc.getActionProb(d['seq_canon'][i], temp=1, force_full_search=(i % 3 != 2), u_full=0.5)
+        nd = mc.node(d['seq_canon'][i])
+        assert int(full) == int(d['seq_full'][i])
+        assert nd['Ns'] == int(d['seq_Ns'][i]), (variant, i)
+        assert np.array_equal(nd['Nsa'], d['seq_Nsa'][i]), (variant, i)
+        assert np.array_equal(probs, d['seq_probs'][i])
+        assert mc.num_nodes() == int(d['seq_nodes'][i]), (variant, i)
+        assert np.array_equal(oracle_tree_digest(mc, g), d['seq_digest'][i]), (variant, i)
