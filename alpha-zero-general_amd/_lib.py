@@ -1,0 +1,93 @@
+"""ctypes loader for libazg_hip.so (the C-ABI declared in include/azg.h).
+
+Fails loudly when the HIP extension is missing: there is NO CPU / eager fallback anywhere in this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libazg_hip.so')
+
+SPLENDOR, SANTORINI = 0, 1
+
+
+class ForestCfg(C.Structure):
+    _fields_ = [('game', C.c_int), ('variant', C.c_int), ('n_trees', C.c_int), ('node_capacity', C.c_int),
+                ('row_capacity_bytes', C.c_int), ('numMCTSSims', C.c_int), ('cpuct', C.c_double), ('fpu', C.c_double),
+                ('universes', C.c_int), ('prob_fullMCTS', C.c_double), ('ratio_fullMCTS', C.c_int),
+                ('forced_playouts', C.c_int), ('dirichletAlpha', C.c_double), ('temperature', C.c_double * 3),
+                ('tempThreshold', C.c_double), ('rng_seed', C.c_uint64), ('stream0', C.c_uint64),
+                ('max_examples', C.c_int)]
+
+
+class SelfplayStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ('plies', 'games', 'sims', 'levels', 'expansions', 'sum_valid_visited',
+                                          'terminal_hits', 'examples', 'gc_runs', 'max_nodes', 'errors',
+                                          'sum_depth_at_expand')]
+
+
+class AzgError(RuntimeError):
+    pass
+
+
+_lib = None
+
+EXPORTS = [
+    'azg_last_error', 'azg_version', 'azg_device_count', 'azg_set_device', 'azg_game_info', 'azg_env_valid_moves',
+    'azg_env_next_state', 'azg_env_game_ended', 'azg_env_canonical', 'azg_env_init_boards', 'azg_forest_create',
+    'azg_forest_destroy', 'azg_forest_device_bytes', 'azg_forest_reset', 'azg_forest_begin_search',
+    'azg_forest_select', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
+    'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_selfplay_start', 'azg_selfplay_advance',
+    'azg_selfplay_stats_get', 'azg_selfplay_drain_examples', 'azg_forest_last_kernel_ms', 'azg_forest_enable_timing',
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AzgError('HIP extension %s is missing: run `python __graft_entry__.py build` (hipcc, gfx950). '
+                       'There is no CPU fallback.' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, u64, dbl = C.c_void_p, C.c_int, C.c_uint64, C.c_double
+    ip = C.POINTER(C.c_int)
+    L.azg_last_error.restype = C.c_char_p
+    L.azg_version.restype = C.c_char_p
+    L.azg_game_info.argtypes = [i, i, ip, ip, ip, ip, ip]
+    L.azg_env_valid_moves.argtypes = [i, i, vp, vp, i, vp, vp]
+    L.azg_env_next_state.argtypes = [i, i, vp, vp, vp, vp, i, vp, vp, u64, u64, vp, vp]
+    L.azg_env_game_ended.argtypes = [i, i, vp, vp, i, vp, vp, vp, vp]
+    L.azg_env_canonical.argtypes = [i, i, vp, vp, i, vp, vp]
+    L.azg_env_init_boards.argtypes = [i, i, i, vp, u64, u64, vp, vp]
+    L.azg_forest_create.argtypes = [C.POINTER(ForestCfg), C.POINTER(vp)]
+    L.azg_forest_destroy.argtypes = [vp]
+    L.azg_forest_device_bytes.restype = C.c_size_t
+    L.azg_forest_device_bytes.argtypes = [vp]
+    L.azg_forest_reset.argtypes = [vp, vp]
+    L.azg_forest_begin_search.argtypes = [vp, vp, vp, vp]
+    L.azg_forest_select.argtypes = [vp, vp, vp, vp, vp, i, vp]
+    L.azg_forest_expand_backup.argtypes = [vp, vp, vp, vp, i, vp]
+    L.azg_forest_active.argtypes = [vp, ip]
+    L.azg_forest_action_probs.argtypes = [vp, dbl, vp, vp, vp, vp]
+    L.azg_forest_root_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.azg_forest_dump_tree.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.azg_selfplay_start.argtypes = [vp, vp, vp]
+    L.azg_selfplay_advance.argtypes = [vp, vp]
+    L.azg_selfplay_stats_get.argtypes = [vp, C.POINTER(SelfplayStats)]
+    L.azg_selfplay_drain_examples.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, ip, vp]
+    L.azg_forest_last_kernel_ms.argtypes = [vp, i, C.POINTER(dbl), C.POINTER(u64)]
+    L.azg_forest_enable_timing.argtypes = [vp, i]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise AzgError(lib().azg_last_error().decode())
+    return rc
+
+
+def game_info(game, variant):
+    S, A, P, rows, cols = (C.c_int() for _ in range(5))
+    check(lib().azg_game_info(game, variant, C.byref(S), C.byref(A), C.byref(P), C.byref(rows), C.byref(cols)))
+    return S.value, A.value, P.value, rows.value, cols.value

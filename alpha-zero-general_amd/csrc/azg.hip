@@ -1,0 +1,434 @@
+// azg.hip -- C-ABI (include/azg.h) of the MI355X self-play engine: host-side launch code for the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared azg.hip -o libazg_hip.so
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/azg.h"
+#include "game_splendor.cuh"
+#include "game_santorini.cuh"
+#include "selfplay.cuh"
+
+using namespace azg;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return -1; }
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
+
+extern "C" const char* azg_last_error(void) { return g_err.c_str(); }
+extern "C" const char* azg_version(void) { return "azg-hip r1 (gfx950)"; }
+extern "C" int azg_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
+
+// ---- game dispatch --------------------------------------------------------------------------------------------------
+#define AZG_DISPATCH(game, variant, ...)                                                         \
+    do {                                                                                           \
+        if ((game) == AZG_SPLENDOR && (variant) == 2) { using G = SplendorDev<2>; __VA_ARGS__; }          \
+        else if ((game) == AZG_SPLENDOR && (variant) == 3) { using G = SplendorDev<3>; __VA_ARGS__; }     \
+        else if ((game) == AZG_SPLENDOR && (variant) == 4) { using G = SplendorDev<4>; __VA_ARGS__; }     \
+        else if ((game) == AZG_SANTORINI && (variant) == 1) { using G = SantoriniDev<1>; __VA_ARGS__; }   \
+        else if ((game) == AZG_SANTORINI && (variant) == 11) { using G = SantoriniDev<11>; __VA_ARGS__; } \
+        else return fail("unsupported game/variant");                                              \
+    } while (0)
+
+static int norm_variant(int game, int variant) {
+    if (game == AZG_SPLENDOR) return variant ? variant : 2;
+    if (game == AZG_SANTORINI) return variant ? variant : 11;
+    return variant;
+}
+
+extern "C" int azg_game_info(int game, int variant, int* S, int* A, int* P, int* rows, int* cols) {
+    variant = norm_variant(game, variant);
+    AZG_DISPATCH(game, variant, {
+        if (S) *S = G::S;
+        if (A) *A = G::A;
+        if (P) *P = G::P;
+        if (rows) *rows = G::ROWS;
+        if (cols) *cols = G::COLS;
+    });
+    return 0;
+}
+
+// ---- env kernels ----------------------------------------------------------------------------------------------------
+extern "C" int azg_env_valid_moves(int game, int variant, const int8_t* states, const int32_t* players, int n,
+                                   uint8_t* out, void* stream) {
+    if (n <= 0) return 0;
+    variant = norm_variant(game, variant);
+    AZG_DISPATCH(game, variant, k_env_valid_moves<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(states, players, n, out));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_env_next_state(int game, int variant, const int8_t* states, const int32_t* players,
+                                  const int32_t* actions, const int64_t* seeds, int n, int8_t* out_states,
+                                  int32_t* out_next, uint64_t rng_seed, uint64_t stream0, uint64_t* counters,
+                                  void* stream) {
+    if (n <= 0) return 0;
+    variant = norm_variant(game, variant);
+    AZG_DISPATCH(game, variant,
+                 k_env_next_state<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(states, players,
+                                     actions, (const int64_t*)seeds, n, out_states, out_next, rng_seed, stream0,
+                                     counters));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_env_game_ended(int game, int variant, const int8_t* states, const int32_t* next_players, int n,
+                                  float* out_ended, int32_t* out_scores, int32_t* out_round, void* stream) {
+    if (n <= 0) return 0;
+    variant = norm_variant(game, variant);
+    AZG_DISPATCH(game, variant, k_env_game_ended<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(states, next_players, n, out_ended, out_scores, out_round));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_env_canonical(int game, int variant, const int8_t* states, const int32_t* players, int n,
+                                 int8_t* out_states, void* stream) {
+    if (n <= 0) return 0;
+    variant = norm_variant(game, variant);
+    AZG_DISPATCH(game, variant, k_env_canonical<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(states, players, n, out_states));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_env_init_boards(int game, int variant, int n, int8_t* out_states, uint64_t rng_seed,
+                                   uint64_t stream0, uint64_t* out_counters, void* stream) {
+    if (n <= 0) return 0;
+    variant = norm_variant(game, variant);
+    AZG_DISPATCH(game, variant, k_env_init_boards<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(n,
+                                                    out_states, rng_seed, stream0, out_counters));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- forest ---------------------------------------------------------------------------------------------------------
+struct azg_forest {
+    azg_forest_cfg cfg;
+    ForestDev dev;
+    int S, SP, A, P;
+    size_t bytes;
+    std::vector<void*> allocs;
+    // timing
+    bool timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+    size_t ev_used[2];
+    double ms_total[2];
+    uint64_t launches[2];
+};
+
+template <class T>
+static int dalloc(azg_forest* f, T** p, size_t count) {
+    size_t b = count * sizeof(T);
+    if (b == 0) b = 16;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, b);
+    if (e != hipSuccess) return fail(std::string("hipMalloc(") + std::to_string(b) + "): " + hipGetErrorString(e));
+    f->allocs.push_back(q);
+    f->bytes += b;
+    *p = (T*)q;
+    return 0;
+}
+
+extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
+    if (!cfg || !out) return fail("null argument");
+    azg_forest* f = new azg_forest();
+    f->cfg = *cfg;
+    f->cfg.variant = norm_variant(cfg->game, cfg->variant);
+    f->bytes = 0;
+    f->timing = false;
+    f->ev_used[0] = f->ev_used[1] = 0;
+    f->ms_total[0] = f->ms_total[1] = 0;
+    f->launches[0] = f->launches[1] = 0;
+    int game = f->cfg.game, variant = f->cfg.variant;
+    AZG_DISPATCH(game, variant, { f->S = G::S; f->SP = G::SP; f->A = G::A; f->P = G::P; });
+    if (cfg->n_trees <= 0 || cfg->node_capacity < 16) { delete f; return fail("bad n_trees / node_capacity"); }
+    if (cfg->node_capacity > (1 << AZG_IDX_BITS) - 2) { delete f; return fail("node_capacity too large"); }
+    if (cfg->universes < 0 || cfg->universes > AZG_MAX_UNIVERSES) { delete f; return fail("universes out of range"); }
+    ForestDev& D = f->dev;
+    memset(&D, 0, sizeof(D));
+    D.T = cfg->n_trees;
+    D.cap = cfg->node_capacity;
+    int ht = 64;
+    while (ht < 2 * D.cap) ht <<= 1;
+    D.HT = ht;
+    D.U = cfg->universes > 0 ? cfg->universes : 1;
+    size_t heap_bytes = cfg->row_capacity_bytes > 0
+                            ? (size_t)cfg->row_capacity_bytes
+                            : (size_t)D.cap * RowLayout(f->A < 56 ? f->A : 56, D.U).total;
+    heap_bytes = (heap_bytes + 15) / 16 * 16;
+    D.heap_units = (uint32_t)(heap_bytes / 16);
+    D.universes = cfg->universes;
+    D.numMCTSSims = cfg->numMCTSSims;
+    D.ratio_fullMCTS = cfg->ratio_fullMCTS > 0 ? cfg->ratio_fullMCTS : 1;
+    D.forced_playouts = cfg->forced_playouts;
+    D.cpuct = cfg->cpuct; D.fpu = cfg->fpu; D.prob_fullMCTS = cfg->prob_fullMCTS;
+    D.dirichletAlpha = cfg->dirichletAlpha;
+    D.temp_begin = cfg->temperature[0]; D.temp_end = cfg->temperature[1]; D.temp_root = cfg->temperature[2];
+    D.tempThreshold = cfg->tempThreshold;
+    D.rng_seed = cfg->rng_seed; D.stream0 = cfg->stream0;
+    D.max_examples = cfg->max_examples > 0 ? cfg->max_examples : 0;
+    D.max_rec = f->cfg.game == AZG_SPLENDOR ? 64 * f->P + 8 : 256;
+    const size_t T = D.T;
+    int rc = 0;
+    rc |= dalloc(f, &D.hdr, T);
+    rc |= dalloc(f, &D.node_hdr, T * D.cap);
+    rc |= dalloc(f, &D.node_state, T * D.cap * f->SP);
+    rc |= dalloc(f, &D.heap, T * heap_bytes);
+    rc |= dalloc(f, &D.htab, T * D.HT);
+    rc |= dalloc(f, &D.path, T * AZG_MAXD);
+    rc |= dalloc(f, &D.root_state, T * f->SP);
+    rc |= dalloc(f, &D.board, T * f->SP);
+    if (D.max_examples > 0) {
+        const size_t R = T * D.max_rec, E = D.max_examples;
+        rc |= dalloc(f, &D.rec_board, R * f->S);
+        rc |= dalloc(f, &D.rec_pi, R * f->A);
+        rc |= dalloc(f, &D.rec_valid, R * f->A);
+        rc |= dalloc(f, &D.rec_q, R * f->P);
+        rc |= dalloc(f, &D.rec_player, R);
+        rc |= dalloc(f, &D.rec_ply, R);
+        rc |= dalloc(f, &D.ex_board, E * f->S);
+        rc |= dalloc(f, &D.ex_pi, E * f->A);
+        rc |= dalloc(f, &D.ex_z, E * f->P);
+        rc |= dalloc(f, &D.ex_valid, E * f->A);
+        rc |= dalloc(f, &D.ex_q, E * f->P);
+        rc |= dalloc(f, &D.ex_meta, E * 4);
+    }
+    rc |= dalloc(f, &D.ex_count, 2);
+    if (rc) { azg_forest_destroy(f); return -1; }
+    hipError_t e = hipMemset(D.hdr, 0, T * sizeof(TreeHdr));
+    if (e == hipSuccess) e = hipMemset(D.ex_count, 0, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(D.root_state, 0, T * f->SP);
+    if (e == hipSuccess) e = hipMemset(D.board, 0, T * f->SP);
+    if (e != hipSuccess) { azg_forest_destroy(f); return fail(hipGetErrorString(e)); }
+    *out = f;
+    return azg_forest_reset(f, nullptr);
+}
+
+extern "C" int azg_forest_destroy(azg_forest* f) {
+    if (!f) return 0;
+    for (void* p : f->allocs) (void)hipFree(p);
+    for (int k = 0; k < 2; k++)
+        for (auto& pr : f->ev[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    delete f;
+    return 0;
+}
+
+extern "C" size_t azg_forest_device_bytes(const azg_forest* f) { return f ? f->bytes : 0; }
+
+#define FDISPATCH(f, ...) AZG_DISPATCH((f)->cfg.game, (f)->cfg.variant, __VA_ARGS__)
+
+extern "C" int azg_forest_reset(azg_forest* f, void* stream) {
+    if (!f) return fail("null forest");
+    FDISPATCH(f, k_forest_reset<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_forest_begin_search(azg_forest* f, const int8_t* roots, const uint8_t* full, void* stream) {
+    if (!f || !roots) return fail("null argument");
+    FDISPATCH(f, k_begin_search<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, roots,
+                                     full));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static void ev_begin(azg_forest* f, int which, hipStream_t s) {
+    if (!f->timing) return;
+    if (f->ev_used[which] >= f->ev[which].size()) return;
+    (void)hipEventRecord(f->ev[which][f->ev_used[which]].first, s);
+}
+static void ev_end(azg_forest* f, int which, hipStream_t s) {
+    if (!f->timing) return;
+    if (f->ev_used[which] >= f->ev[which].size()) return;
+    (void)hipEventRecord(f->ev[which][f->ev_used[which]].second, s);
+    f->ev_used[which]++;
+}
+
+extern "C" int azg_forest_select(azg_forest* f, int8_t* leaf_states, uint8_t* leaf_valid, uint8_t* needs_eval,
+                                 const double* root_noise, int noise_stride, void* stream) {
+    if (!f || !leaf_states || !leaf_valid || !needs_eval) return fail("null argument");
+    ev_begin(f, 0, (hipStream_t)stream);
+    FDISPATCH(f, k_select<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, leaf_states,
+                                     leaf_valid, needs_eval, root_noise, noise_stride));
+    ev_end(f, 0, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_forest_expand_backup(azg_forest* f, const float* pi, const float* v, const double* root_noise,
+                                        int noise_stride, void* stream) {
+    if (!f || !pi || !v) return fail("null argument");
+    ev_begin(f, 1, (hipStream_t)stream);
+    FDISPATCH(f, k_expand_backup<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, pi,
+                                     v, root_noise, noise_stride));
+    ev_end(f, 1, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_forest_active(azg_forest* f, int* n_active) {
+    if (!f || !n_active) return fail("null argument");
+    std::vector<TreeHdr> h(f->dev.T);
+    HIPCHK(hipMemcpy(h.data(), f->dev.hdr, sizeof(TreeHdr) * h.size(), hipMemcpyDeviceToHost));
+    int n = 0;
+    uint32_t err = 0;
+    for (auto& x : h) { n += (x.status == ST_SEARCHING || x.status == ST_WAIT_NN); err |= x.err; }
+    *n_active = n;
+    if (err) return fail("forest error flags: " + std::to_string(err) +
+                         " (1=node overflow 2=row-heap overflow 4=depth overflow 16/32=example overflow)");
+    return 0;
+}
+
+extern "C" int azg_forest_action_probs(azg_forest* f, double temp, double* probs, float* q, uint8_t* is_full,
+                                       void* stream) {
+    if (!f) return fail("null forest");
+    FDISPATCH(f, k_action_probs<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, temp,
+                                     probs, q, is_full));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_forest_root_stats(azg_forest* f, int32_t* Ns, float* Qs, int32_t* Nsa, double* Qsa, float* Ps,
+                                     int32_t* n_nodes, void* stream) {
+    if (!f) return fail("null forest");
+    FDISPATCH(f, k_root_stats<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, Ns, Qs,
+                                     Nsa, Qsa, Ps, n_nodes));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8_t* states, int32_t* Ns, float* Qs,
+                                    float* Es, int32_t* Nsa, double* Qsa, float* Ps, uint8_t* has_policy) {
+    if (!f || tree < 0 || tree >= f->dev.T) return fail("bad tree index");
+    HIPCHK(hipDeviceSynchronize());
+    const ForestDev& D = f->dev;
+    TreeHdr H;
+    HIPCHK(hipMemcpy(&H, D.hdr + tree, sizeof(H), hipMemcpyDeviceToHost));
+    const int n = (int)H.n_nodes;
+    if (n > max_nodes) return n;
+    std::vector<NodeHdr> nh(n);
+    std::vector<int8_t> st((size_t)n * f->SP);
+    const size_t heap_bytes = (size_t)D.heap_units * 16;
+    std::vector<uint8_t> hp((size_t)H.heap_top * 16);
+    if (n) {
+        HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)tree * D.cap, sizeof(NodeHdr) * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(st.data(), D.node_state + (size_t)tree * D.cap * f->SP, (size_t)n * f->SP, hipMemcpyDeviceToHost));
+    }
+    if (!hp.empty()) HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)tree * heap_bytes, hp.size(), hipMemcpyDeviceToHost));
+    const int A = f->A, P = f->P, S = f->S;
+    for (int i = 0; i < n; i++) {
+        memcpy(states + (size_t)i * S, st.data() + (size_t)i * f->SP, S);
+        Ns[i] = (int32_t)nh[i].Ns;
+        Qs[i] = nh[i].Qs;
+        for (int p = 0; p < P; p++) Es[(size_t)i * P + p] = nh[i].Es[p];
+        has_policy[i] = (nh[i].flags & NF_EXPANDED) ? 1 : 0;
+        for (int a = 0; a < A; a++) { Nsa[(size_t)i * A + a] = 0; Qsa[(size_t)i * A + a] = AZG_NANQ; Ps[(size_t)i * A + a] = 0.f; }
+        if (has_policy[i]) {
+            RowLayout L(nh[i].nv, D.U);
+            const uint8_t* row = hp.data() + (size_t)nh[i].row_off * 16;
+            const uint16_t* ids = (const uint16_t*)(row + L.offI);
+            for (int j = 0; j < nh[i].nv; j++) {
+                int a = ids[j];
+                Nsa[(size_t)i * A + a] = (int32_t)((const uint32_t*)(row + L.offN))[j];
+                Qsa[(size_t)i * A + a] = ((const double*)(row + L.offQ))[j];
+                Ps[(size_t)i * A + a] = ((const float*)row)[j];
+            }
+        }
+    }
+    return n;
+}
+
+// ---- self-play ------------------------------------------------------------------------------------------------------
+extern "C" int azg_selfplay_start(azg_forest* f, const int8_t* init_boards, void* stream) {
+    if (!f) return fail("null forest");
+    if (f->dev.max_examples <= 0) return fail("forest created with max_examples == 0");
+    HIPCHK(hipMemsetAsync(f->dev.ex_count, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream));
+    FDISPATCH(f, k_selfplay_start<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev,
+                                     init_boards));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_selfplay_advance(azg_forest* f, void* stream) {
+    if (!f) return fail("null forest");
+    FDISPATCH(f, k_selfplay_advance<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out) {
+    if (!f || !out) return fail("null argument");
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<TreeHdr> h(f->dev.T);
+    HIPCHK(hipMemcpy(h.data(), f->dev.hdr, sizeof(TreeHdr) * h.size(), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    for (auto& x : h) {
+        out->plies += x.c_plies; out->games += x.games_done; out->sims += x.c_sims; out->levels += x.c_levels;
+        out->expansions += x.c_exp; out->sum_valid_visited += x.c_sumvalid; out->terminal_hits += x.c_term;
+        out->examples += x.c_examples; out->gc_runs += x.gc_runs; out->errors |= x.err;
+        out->sum_depth_at_expand += x.c_depth;
+        if (x.max_nodes_seen > out->max_nodes) out->max_nodes = x.max_nodes_seen;
+    }
+    return 0;
+}
+
+extern "C" int azg_selfplay_drain_examples(azg_forest* f, int max_records, int8_t* boards, float* pi, float* z,
+                                           uint8_t* valids, float* q, int32_t* meta, int* n_out, void* stream) {
+    if (!f || !n_out) return fail("null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipStreamSynchronize(s));
+    unsigned long long cnt[2];
+    HIPCHK(hipMemcpy(cnt, f->dev.ex_count, sizeof(cnt), hipMemcpyDeviceToHost));
+    size_t n = cnt[0] < (unsigned long long)f->dev.max_examples ? (size_t)cnt[0] : (size_t)f->dev.max_examples;
+    if ((size_t)max_records < n) n = (size_t)max_records;
+    const ForestDev& D = f->dev;
+    if (n) {
+        if (boards) HIPCHK(hipMemcpyAsync(boards, D.ex_board, n * f->S, hipMemcpyDeviceToDevice, s));
+        if (pi) HIPCHK(hipMemcpyAsync(pi, D.ex_pi, n * f->A * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (z) HIPCHK(hipMemcpyAsync(z, D.ex_z, n * f->P * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (valids) HIPCHK(hipMemcpyAsync(valids, D.ex_valid, n * f->A, hipMemcpyDeviceToDevice, s));
+        if (q) HIPCHK(hipMemcpyAsync(q, D.ex_q, n * f->P * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (meta) HIPCHK(hipMemcpyAsync(meta, D.ex_meta, n * 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipMemsetAsync(D.ex_count, 0, 2 * sizeof(unsigned long long), s));
+    HIPCHK(hipStreamSynchronize(s));
+    *n_out = (int)n;
+    return 0;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------------------------
+extern "C" int azg_forest_enable_timing(azg_forest* f, int enable) {
+    if (!f) return fail("null forest");
+    if (enable) {
+        for (int k = 0; k < 2; k++) {
+            while (f->ev[k].size() < 4096) {
+                hipEvent_t a, b;
+                HIPCHK(hipEventCreate(&a));
+                HIPCHK(hipEventCreate(&b));
+                f->ev[k].push_back({a, b});
+            }
+            f->ev_used[k] = 0;
+            f->ms_total[k] = 0;
+            f->launches[k] = 0;
+        }
+    }
+    f->timing = enable != 0;
+    return 0;
+}
+
+extern "C" int azg_forest_last_kernel_ms(azg_forest* f, int which, double* avg_ms, uint64_t* launches) {
+    if (!f || which < 0 || which > 1) return fail("bad argument");
+    HIPCHK(hipDeviceSynchronize());
+    for (size_t i = 0; i < f->ev_used[which]; i++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, f->ev[which][i].first, f->ev[which][i].second));
+        f->ms_total[which] += ms;
+        f->launches[which]++;
+    }
+    f->ev_used[which] = 0;
+    if (avg_ms) *avg_ms = f->launches[which] ? f->ms_total[which] / (double)f->launches[which] : 0.0;
+    if (launches) *launches = f->launches[which];
+    return 0;
+}

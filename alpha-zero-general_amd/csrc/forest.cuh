@@ -1,0 +1,317 @@
+// forest.cuh -- struct-of-arrays MCTS forest in HBM, one 64-lane wavefront per tree.
+//
+// What the reference does (MCTS.py): nodes_data is a dict keyed by board.tobytes() holding dense per-action arrays
+// (Ps f32[A], Qsa f64[A], Nsa i64[A]); every simulation re-plays the env step at every level and re-hashes the child
+// state to find the next node (MCTS.py:125-126,164-175).
+//
+// What this engine keeps in HBM per tree (all private to the tree's wavefront, so no atomics and no cross-workgroup
+// visibility protocol are needed inside a launch):
+//   NodeHdr[cap]         48 B     64-bit state hash, row offset, #valid, round, flags, Ns (u32), Qs (f32), Es (f32[P])
+//   state[cap][SP]       int8     the node's canonical state = the dict KEY of the reference (full-key verified)
+//   row heap             bytes    per expanded node, VALID-ACTION-COMPACTED rows, 16-B aligned sections:
+//                                   P f32[nv] | N u32[nv] | Q f64[nv] | child u32[nv*U] | action id u16[nv]
+//   htab[HT]             u32      open-addressing table: (10-bit tag | 22-bit node id), probed 64 slots per wave load
+//   path[MAXD]           8 B      the descent of the pending simulation (node, row index, next_player, roll prefix)
+//
+// child[j*U+u] caches the node reached through valid action j in universe u (u = sim index mod universes, the
+// reference's seeded-chance mechanism MCTS.py:14,63).  It is pure memoisation of the reference's "replay env step +
+// dict lookup": the child of (state, action, seed) is a deterministic function, node identity stays the full state
+// (transpositions are found through the hash table exactly like the dict), and nodes are only ever dropped when they
+// are unreachable (round < root round), so a cached id can never differ from what the lookup would return.
+//
+// Numerics follow the shipped (Numba-typed) reference: UCB in f64 with f32 operands widened (MCTS.py:210-230),
+// Qsa running mean in f64, Qs in f32 scalar arithmetic (MCTS.py:178-181), no FMA contraction (-ffp-contract=off).
+#pragma once
+#include "azg_common.cuh"
+
+namespace azg {
+
+enum : uint32_t { ST_IDLE = 0, ST_SEARCHING = 1, ST_WAIT_NN = 2, ST_DONE = 3 };
+enum : uint8_t { NF_TERMINAL = 1, NF_EXPANDED = 2 };
+enum : uint32_t {
+    ERR_NODE_OVERFLOW = 1, ERR_HEAP_OVERFLOW = 2, ERR_DEPTH_OVERFLOW = 4, ERR_BAD_STATE = 8, ERR_EXAMPLE_OVERFLOW = 16,
+    ERR_REC_OVERFLOW = 32
+};
+
+#define AZG_MAXD 256
+#define AZG_IDX_BITS 22
+#define AZG_IDX_MASK ((1u << AZG_IDX_BITS) - 1u)
+#define AZG_CHILD_IDX_MASK 0x3FFFFFFFu
+
+struct __attribute__((aligned(16))) NodeHdr {
+    uint64_t hash;
+    uint32_t row_off;      // 16-byte units into the tree's heap; AZG_NONE for terminal nodes
+    uint16_t nv;
+    uint8_t round;
+    uint8_t flags;
+    uint32_t Ns;
+    float Qs;
+    float Es[AZG_MAX_PLAYERS_DEV];
+    uint32_t pad[2];
+};
+
+struct __attribute__((aligned(16))) TreeHdr {
+    uint32_t n_nodes, heap_top, root, status;
+    uint32_t sim_idx, n_sims, is_full, forced;
+    uint32_t pending_leaf, path_len, ply, cur_player;
+    uint64_t rng_counter;
+    uint32_t err, root_round;
+    uint32_t leaf_is_root, games_done, step, n_rec;
+    uint32_t max_nodes_seen, gc_runs, pad0, pad1;
+    uint64_t c_sims, c_levels, c_exp, c_sumvalid, c_term, c_depth, c_plies, c_examples;
+};
+
+struct PathEnt {
+    uint32_t node;
+    uint16_t j;
+    uint8_t np;        // next_player of this edge
+    uint8_t pre;       // sum of np over the entries above this one (mod P)
+};
+
+struct ForestDev {
+    int T, cap, HT, U;                 // trees, nodes per tree, hash slots per tree (pow2), child slots per action
+    uint32_t heap_units;               // 16-byte units per tree heap
+    int universes, numMCTSSims, ratio_fullMCTS, forced_playouts;
+    double cpuct, fpu, prob_fullMCTS, dirichletAlpha, temp_begin, temp_end, temp_root, tempThreshold;
+    uint64_t rng_seed, stream0;
+    int max_examples, max_rec;
+    TreeHdr* hdr;
+    NodeHdr* node_hdr;
+    int8_t* node_state;
+    uint8_t* heap;
+    uint32_t* htab;
+    PathEnt* path;
+    int8_t* root_state;
+    int8_t* board;
+    // per-game record buffers (self-play): [T][max_rec]
+    int8_t* rec_board; float* rec_pi; uint8_t* rec_valid; float* rec_q; uint8_t* rec_player; uint16_t* rec_ply;
+    // example ring
+    int8_t* ex_board; float* ex_pi; float* ex_z; uint8_t* ex_valid; float* ex_q;
+    int32_t* ex_meta;                  // [max_examples][4] = (global game stream, game index on that stream, ply, player)
+    unsigned long long* ex_count;      // [0] = records written (may exceed capacity => dropped), [1] = dropped
+};
+
+__device__ __constant__ long long AZG_MAGIC_SEEDS[8] = {31416, 1, 14142, 42, 27183, 2, 16180, 7};   // MCTS.py:14
+
+__host__ __device__ __forceinline__ uint32_t align16u(uint32_t x) { return (x + 15u) & ~15u; }
+
+struct RowLayout {
+    uint32_t offN, offQ, offC, offI, total;   // bytes; P at 0
+    __host__ __device__ RowLayout(int nv, int U) {
+        uint32_t szP = align16u(4u * nv);
+        offN = szP;
+        offQ = offN + szP;
+        offC = offQ + align16u(8u * nv);
+        offI = offC + align16u(4u * nv * U);
+        total = offI + align16u(2u * nv);
+    }
+};
+
+// NumPy's pairwise float32 summation order (np.sum called by `normalise`, MCTS.py:250-253) for n <= 128 elements,
+// executed by lanes 0..7 over an LDS array; every lane returns the sum.
+__device__ __forceinline__ float np_sum_block_f32(const float* a, int n) {
+    int l = lane_id();
+    float res;
+    if (n < 8) {
+        res = 0.f;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    int lim = n - (n % 8);
+    float r = 0.f;
+    if (l < 8) {
+        r = a[l];
+        for (int i = 8 + l; i < lim; i += 8) r += a[i];
+    }
+    float r1 = __shfl_xor(r, 1, 64);
+    float s2 = (l & 1) ? (r1 + r) : (r + r1);          // lanes 0,1 -> r0+r1 ; 2,3 -> r2+r3 ...
+    float s2o = __shfl_xor(s2, 2, 64);
+    float s4 = (l & 2) ? (s2o + s2) : (s2 + s2o);      // (r0+r1)+(r2+r3)
+    float s4o = __shfl_xor(s4, 4, 64);
+    float s8 = (l & 4) ? (s4o + s4) : (s4 + s4o);
+    res = __shfl(s8, 0, 64);
+    for (int i = lim; i < n; i++) res += a[i];
+    return res;
+}
+
+// full pairwise recursion (n > 128 splits in halves rounded down to a multiple of 8)
+__device__ inline float np_sum_f32(const float* a, int n) {
+    if (n <= 128) return np_sum_block_f32(a, n);
+    // iterative traversal of the recursion tree with an explicit stack (depth <= 8 for n <= 32768)
+    int st_off[12], st_n[12], st_state[12];
+    float st_acc[12];
+    int sp = 0;
+    st_off[0] = 0; st_n[0] = n; st_state[0] = 0; st_acc[0] = 0.f;
+    float ret = 0.f;
+    while (sp >= 0) {
+        int off = st_off[sp], len = st_n[sp];
+        if (len <= 128) { ret = np_sum_block_f32(a + off, len); sp--; continue; }
+        int n2 = len / 2; n2 -= n2 % 8;
+        if (st_state[sp] == 0) {            // descend left
+            st_state[sp] = 1;
+            sp++; st_off[sp] = off; st_n[sp] = n2; st_state[sp] = 0;
+        } else if (st_state[sp] == 1) {     // left done -> descend right
+            st_acc[sp] = ret; st_state[sp] = 2;
+            sp++; st_off[sp] = off + n2; st_n[sp] = len - n2; st_state[sp] = 0;
+        } else {                            // both done
+            ret = st_acc[sp] + ret; sp--;
+        }
+    }
+    return ret;
+}
+
+template <class G>
+struct Forest {
+    static constexpr int S = G::S, SP = G::SP, A = G::A, P = G::P, AW = G::AW;
+    static constexpr int SPW = SP / 4;
+
+    struct Smem {
+        __attribute__((aligned(16))) int8_t st[SP];
+        __attribute__((aligned(16))) int8_t tmp[SP];
+        __attribute__((aligned(16))) uint64_t mask[AW];
+        __attribute__((aligned(16))) PathEnt path[AZG_MAXD];
+    };
+
+    // ---- addressing ----
+    __device__ static __forceinline__ NodeHdr* nhdr(const ForestDev& F, int t, uint32_t id) {
+        return F.node_hdr + (size_t)t * F.cap + id;
+    }
+    __device__ static __forceinline__ int8_t* nstate(const ForestDev& F, int t, uint32_t id) {
+        return F.node_state + ((size_t)t * F.cap + id) * SP;
+    }
+    __device__ static __forceinline__ uint8_t* heap(const ForestDev& F, int t) {
+        return F.heap + (size_t)t * F.heap_units * 16u;
+    }
+    __device__ static __forceinline__ uint32_t* htab(const ForestDev& F, int t) { return F.htab + (size_t)t * F.HT; }
+
+    __device__ static __forceinline__ void load_state(int8_t* lds, const int8_t* g_padded) {
+        const uint32_t* src = (const uint32_t*)g_padded;
+        uint32_t* dst = (uint32_t*)lds;
+        for (int i = lane_id(); i < SPW; i += 64) dst[i] = src[i];
+        wave_sync();
+    }
+    __device__ static __forceinline__ void store_state(int8_t* g_padded, const int8_t* lds) {
+        const uint32_t* src = (const uint32_t*)lds;
+        uint32_t* dst = (uint32_t*)g_padded;
+        for (int i = lane_id(); i < SPW; i += 64) dst[i] = src[i];
+    }
+    // unpadded S-byte state (API buffers) -> LDS with zero tail
+    __device__ static __forceinline__ void load_state_unpadded(int8_t* lds, const int8_t* g) {
+        for (int i = lane_id(); i < SP; i += 64) lds[i] = i < S ? g[i] : (int8_t)0;
+        wave_sync();
+    }
+    __device__ static __forceinline__ void store_state_unpadded(int8_t* g, const int8_t* lds) {
+        for (int i = lane_id(); i < S; i += 64) g[i] = lds[i];
+    }
+
+    __device__ static __forceinline__ uint32_t tag_of(uint64_t h) { return (uint32_t)(h >> 54); }   // 10 bits
+
+    // Find the node whose key equals the state in LDS.  Also returns the first free slot met (for insertion).
+    __device__ static uint32_t probe(const ForestDev& F, int t, const int8_t* st_lds, uint64_t h, uint32_t* free_slot) {
+        const uint32_t* tab = htab(F, t);
+        const uint32_t maskHT = (uint32_t)F.HT - 1u;
+        uint32_t slot0 = (uint32_t)h & maskHT;
+        const uint32_t tg = tag_of(h);
+        const uint32_t* my = (const uint32_t*)st_lds;
+        for (int round = 0; round < F.HT / 64 + 1; round++) {
+            uint32_t slot = (slot0 + (uint32_t)round * 64u + (uint32_t)lane_id()) & maskHT;
+            uint32_t e = tab[slot];
+            uint64_t emp = __ballot(e == AZG_NONE);
+            uint64_t mat = __ballot(e != AZG_NONE && (e >> AZG_IDX_BITS) == tg);
+            int fe = emp ? first_lane(emp) : 64;
+            if (fe < 64) mat &= (fe == 0) ? 0ull : (~0ull >> (64 - fe));
+            while (mat) {
+                int src = first_lane(mat);
+                mat &= mat - 1;
+                uint32_t id = __shfl(e, src, 64) & AZG_IDX_MASK;
+                if (nhdr(F, t, id)->hash != h) continue;
+                const uint32_t* other = (const uint32_t*)nstate(F, t, id);
+                bool eq = true;
+                for (int i = lane_id(); i < SPW; i += 64) eq = eq && (other[i] == my[i]);
+                if (__all(eq)) return id;
+            }
+            if (fe < 64) {
+                *free_slot = (slot0 + (uint32_t)round * 64u + (uint32_t)fe) & maskHT;
+                return AZG_NONE;
+            }
+        }
+        *free_slot = AZG_NONE;
+        return AZG_NONE;
+    }
+
+    // Allocate a node for the state in LDS, write key + hash, insert in the table.  Returns AZG_NONE on overflow.
+    __device__ static uint32_t create_node(const ForestDev& F, int t, TreeHdr& H, const int8_t* st_lds, uint64_t h,
+                                           uint32_t free_slot) {
+        if (H.n_nodes >= (uint32_t)F.cap || free_slot == AZG_NONE) { H.err |= ERR_NODE_OVERFLOW; return AZG_NONE; }
+        uint32_t id = H.n_nodes++;
+        store_state(nstate(F, t, id), st_lds);
+        if (lane_id() == 0) {
+            nhdr(F, t, id)->hash = h;
+            htab(F, t)[free_slot] = (tag_of(h) << AZG_IDX_BITS) | id;
+        }
+        return id;
+    }
+
+    // Lane-parallel value backup along the recorded path (MCTS.py:176-183 unwound): level d belongs to lane d.
+    __device__ static void backup(const ForestDev& F, int t, const PathEnt* path, int depth, const float* v) {
+        if (depth == 0) return;
+        int tot = 0;
+        {
+            const PathEnt last = path[depth - 1];
+            tot = (last.pre + last.np) % P;
+        }
+        uint8_t* hp = heap(F, t);
+        for (int base = 0; base < depth; base += 64) {
+            int d = base + lane_id();
+            if (d < depth) {
+                PathEnt e = path[d];
+                int roll = ((tot - e.pre) % P + P) % P;            // sum of next_player over levels >= d
+                float v0 = v[((0 - roll) % P + P) % P];             // np.roll(v, n)[0] = v[(-n) mod P]
+                NodeHdr* nh = nhdr(F, t, e.node);
+                RowLayout L(nh->nv, F.U);
+                uint8_t* row = hp + (size_t)nh->row_off * 16u;
+                uint32_t* Nrow = (uint32_t*)(row + L.offN);
+                double* Qrow = (double*)(row + L.offQ);
+                uint32_t n = Nrow[e.j];
+                double q = Qrow[e.j];
+                Qrow[e.j] = ((double)n * q + (double)v0) / (double)(n + 1u);
+                uint32_t ns = nh->Ns;
+                float tq = (float)(ns + 1u) * nh->Qs;
+                tq = tq + v0;
+                nh->Qs = tq / (float)(ns + 2u);
+                Nrow[e.j] = n + 1u;
+                nh->Ns = ns + 1u;
+            }
+        }
+    }
+
+    // softmax(Ps, T) + applyDirNoise + normalise on a DENSE policy in LDS (MCTS.py:147-150,156-160,187-197,255-261)
+    __device__ static void root_noise_dense(float* dense, const uint64_t* mask, double temp_root, const double* noise) {
+        int l = lane_id();
+        if (temp_root != 1.0) {
+            // Numba typing: float32 array ** float64 -> float64 array, normalised in f64, cast to f32
+            double s = 0.0;
+            for (int i = l; i < A; i += 64) s += pow((double)dense[i], 1.0 / temp_root);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) s += shfl_xor_f64(s, m);
+            for (int i = l; i < A; i += 64) dense[i] = (float)(pow((double)dense[i], 1.0 / temp_root) / s);
+            wave_sync();
+        }
+        // dir_values are indexed by the rank of the valid action
+        for (int i = l; i < A; i += 64) {
+            uint64_t w = mask[i >> 6];
+            if ((w >> (i & 63)) & 1) {
+                int rank = __popcll(w & ((1ull << (i & 63)) - 1ull));
+                for (int k = 0; k < (i >> 6); k++) rank += __popcll(mask[k]);
+                float a = 0.75f * dense[i];
+                dense[i] = (float)((double)a + 0.25 * noise[rank]);
+            }
+        }
+        wave_sync();
+        float s = np_sum_f32(dense, A);
+        for (int i = l; i < A; i += 64) dense[i] = dense[i] / s;
+        wave_sync();
+    }
+};
+
+}  // namespace azg

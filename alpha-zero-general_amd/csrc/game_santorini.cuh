@@ -1,0 +1,316 @@
+// game_santorini.cuh -- Santorini 5x5 (NB_GODS = 1: no gods, 11: basic gods) env step for one wavefront.
+//
+// Semantics follow santorini/SantoriniLogicNumba.py `Board` + SantoriniConstants.py (lines cited).  State bytes are the
+// reference's int8[5][5][3] interleaved (workers, levels, gods_power).  The reference enumerates valid moves with nested
+// worker x move x build loops per god (:125-432); here every lane evaluates the SAME rules as a predicate of ONE
+// action id (worker, power, move_dir, build_dir), 64 actions per pass, and the passes' ballots are the mask words.
+#pragma once
+#include "azg_common.cuh"
+
+namespace azg {
+
+template <int NB>
+struct SantoriniDev {
+    static constexpr int P = 2;
+    static constexpr int ROWS = 25, COLS = 3;
+    static constexpr int S = 75;
+    static constexpr int SP = 80;
+    static constexpr int A = NB * 2 * 81;                    // action_size :17-19
+    static constexpr int AW = (A + 63) / 64;
+    enum { NO_GOD = 0, APOLLO, MINOTAUR, ATLAS, HEPHAESTUS, ARTEMIS, DEMETER, HERMES, PAN, ATHENA, PROMETHEUS };
+    static constexpr int NO_MOVE = 4, NO_BUILD = 4, MAX_ITER_FOR_HERMES = 5;
+
+    __device__ static __forceinline__ int W(const int8_t* st, int pos) { return st[pos * 3]; }
+    __device__ static __forceinline__ int LV(const int8_t* st, int pos) { return st[pos * 3 + 1]; }
+    __device__ static __forceinline__ int GP(const int8_t* st, int i) { return st[i * 3 + 2]; }
+
+    struct Pos { int y, x; };
+    __device__ static __forceinline__ Pos dir(Pos p, int d) { return Pos{p.y + d / 3 - 1, p.x + d % 3 - 1}; }   // :56-70
+    __device__ static __forceinline__ bool in_grid(Pos p) { return p.y >= 0 && p.y < 5 && p.x >= 0 && p.x < 5; }
+    __device__ static __forceinline__ int idx(Pos p) { return p.y * 5 + p.x; }
+
+    __device__ static Pos worker_pos(const int8_t* st, int id) {                                   // :667-673
+        int f = 0;
+#pragma unroll
+        for (int i = 24; i >= 0; i--) f = (W(st, i) == id) ? i : f;
+        return Pos{f / 5, f % 5};
+    }
+
+    __device__ static bool able_to_move(const int8_t* st, Pos old, Pos np, int player, bool no_climb, bool swap,
+                                        bool push) {                                               // :675-716
+        if (old.y == np.y && old.x == np.x) return true;
+        if (!in_grid(np)) return false;
+        const int w = W(st, idx(np));
+        if (w != 0) {
+            const bool is_opp = player == 0 ? (w == -1 || w == -2) : (w == 1 || w == 2);
+            if ((swap || push) && is_opp) {
+                if (push) {
+                    Pos pp{2 * np.y - old.y, 2 * np.x - old.x};                                    // :52-53
+                    if (!in_grid(pp)) return false;
+                    if (W(st, idx(pp)) != 0) return false;
+                    if (LV(st, idx(pp)) > 3) return false;
+                }
+            } else return false;
+        }
+        const int nl = LV(st, idx(np));
+        if (nl > 3) return false;
+        return !(nl > LV(st, idx(old)) + (no_climb ? 0 : 1));
+    }
+
+    __device__ static bool able_to_build(const int8_t* st, Pos p, int ignore, bool two_levels, bool dome) {   // :718-729
+        if (!in_grid(p)) return false;
+        const int w = W(st, idx(p));
+        if (!(w == 0 || w == ignore)) return false;
+        return !(LV(st, idx(p)) >= (two_levels ? 2 : (dome ? 3 : 4)));
+    }
+
+    __device__ static __forceinline__ int owned_god(const int8_t* st, int player) {
+        int god = -1;
+#pragma unroll
+        for (int k = PROMETHEUS; k >= 0; k--) god = (GP(st, k + NB * player) > 0) ? k : god;      // first of the elif chain
+        return god;
+    }
+
+    // Board.valid_moves (:125-432) as a predicate of one action
+    __device__ static bool valid_action(const int8_t* st, int a, int player, int god, bool opp_athena) {
+        const int worker = a / (NB * 81);
+        int rem = a - worker * NB * 81;
+        const int power = rem / 81; rem -= power * 81;
+        const int md = rem / 9, bd = rem - md * 9;
+        if (god < 0) return false;
+        if (power != NO_GOD && power != god) return false;
+        const int wid = (worker + 1) * (player == 0 ? 1 : -1);
+        const Pos old = worker_pos(st, wid);
+        const Pos np = dir(old, md);
+        const Pos bp = dir(np, bd);
+        switch (god) {
+        case NO_GOD: case PAN: case ATHENA: {
+            if (power != NO_GOD || md == NO_MOVE || bd == NO_BUILD) return false;
+            const bool nc = god == ATHENA ? false : opp_athena;                                    // :383
+            return able_to_move(st, old, np, player, nc, false, false) && able_to_build(st, bp, wid, false, false);
+        }
+        case APOLLO: case MINOTAUR: {                                                               // :154-198
+            if (md == NO_MOVE || bd == NO_BUILD) return false;
+            bool use_power = false;
+            if (!able_to_move(st, old, np, player, opp_athena, false, false)) {
+                if (!able_to_move(st, old, np, player, opp_athena, god == APOLLO, god == MINOTAUR)) return false;
+                use_power = true;
+            }
+            if (power != (use_power ? god : (int)NO_GOD)) return false;
+            return able_to_build(st, bp, wid, false, false);
+        }
+        case ATLAS: case HEPHAESTUS: {                                                              // :200-239
+            if (md == NO_MOVE || bd == NO_BUILD) return false;
+            if (!able_to_move(st, old, np, player, opp_athena, false, false)) return false;
+            if (power == NO_GOD) return able_to_build(st, bp, wid, false, false);
+            return able_to_build(st, bp, wid, god == HEPHAESTUS, god == ATLAS);
+        }
+        case ARTEMIS: {                                                                             // :242-281
+            const int avoid = GP(st, ARTEMIS + NB * player) % 64 - 1;
+            if (md == NO_MOVE) return false;
+            if (avoid < 0) {
+                if (!able_to_move(st, old, np, player, opp_athena, false, false)) return false;
+                if (bd == NO_BUILD) return power == ARTEMIS;
+                return power == NO_GOD && able_to_build(st, bp, wid, false, false);
+            }
+            if (worker != avoid / 9 || power != NO_GOD || md == avoid % 9 || bd == NO_BUILD) return false;
+            return able_to_move(st, old, np, player, opp_athena, false, false) && able_to_build(st, bp, wid, false, false);
+        }
+        case DEMETER: {                                                                             // :284-318
+            const int avoid = GP(st, DEMETER + NB * player) % 64 - 1;
+            if (avoid < 0) {
+                if (power != DEMETER || md == NO_MOVE || bd == NO_BUILD) return false;
+                return able_to_move(st, old, np, player, opp_athena, false, false) &&
+                       able_to_build(st, bp, wid, false, false);
+            }
+            if (worker != avoid / 9 || power != NO_GOD || md != NO_MOVE) return false;
+            if (bd == NO_BUILD) return true;                                                        // cancel 2nd turn
+            if (bd == avoid % 9) return false;
+            return able_to_build(st, dir(old, bd), wid, false, false);
+        }
+        case HERMES: {                                                                              // :321-351
+            const int nb_prev = GP(st, HERMES + NB * player) % 64;
+            if (power == NO_GOD && md == NO_MOVE)
+                return bd != NO_BUILD && able_to_build(st, dir(old, bd), wid, false, false);
+            if (power == HERMES)
+                return md != NO_MOVE && bd == NO_BUILD && nb_prev < MAX_ITER_FOR_HERMES &&
+                       able_to_move(st, old, np, player, opp_athena, false, false) &&
+                       LV(st, idx(np)) == LV(st, idx(old));
+            // classic turn
+            return md != NO_MOVE && bd != NO_BUILD && nb_prev == 0 &&
+                   able_to_move(st, old, np, player, opp_athena, false, false) &&
+                   able_to_build(st, bp, wid, false, false);
+        }
+        case PROMETHEUS: {                                                                          // :392-428
+            const int v = GP(st, PROMETHEUS + NB * player) % 64 - 1;
+            const int prev = v < 0 ? -1 : v / 9;
+            if (bd == NO_BUILD) return false;
+            if (prev < 0) {
+                const bool use_power = md == NO_MOVE;
+                if (power != (use_power ? (int)PROMETHEUS : (int)NO_GOD)) return false;
+                return able_to_move(st, old, np, player, opp_athena, false, false) &&
+                       able_to_build(st, bp, wid, false, false);
+            }
+            if (worker != prev || power != NO_GOD || md == NO_MOVE) return false;
+            return able_to_move(st, old, np, player, true, false, false) && able_to_build(st, bp, wid, false, false);
+        }
+        }
+        return false;
+    }
+
+    __device__ static void valid_mask(const int8_t* st, int player, uint64_t* mask_lds) {
+        const int l = lane_id();
+        const int god = owned_god(st, player);
+        const bool opp_athena = GP(st, ATHENA + NB * ((player + 1) % 2)) > 64;                      // :133
+        for (int k = 0; k < AW; k++) {
+            const int a = k * 64 + l;
+            const uint64_t m = __ballot(a < A && valid_action(st, a < A ? a : 0, player, god, opp_athena));
+            if (l == 0) mask_lds[k] = m;
+        }
+    }
+
+    // Board.make_move :434-550 -- lane 0 only
+    __device__ static int make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
+        (void)seed; (void)rng;
+        const int worker = move / (NB * 81);
+        int rem = move - worker * NB * 81;
+        const int power = rem / 81; rem -= power * 81;
+        const int md = rem / 9, bd = rem - md * 9;
+        const int wid = (worker + 1) * (player == 0 ? 1 : -1);
+        const Pos old = worker_pos(st, wid);
+        const Pos np = dir(old, md);
+        const int io = idx(old) * 3, in = idx(np) * 3;
+        bool opp_next = true;
+        switch (power) {
+        case NO_GOD: {
+            const int old_level = st[io + 1];
+            st[io] = 0; st[in] = (int8_t)wid;
+            if (bd != NO_BUILD) st[idx(dir(np, bd)) * 3 + 1] += 1;
+            if (GP(st, PAN + NB * player) > 0) {
+                if (st[in + 1] <= old_level - 2) st[(PAN + NB * player) * 3 + 2] = 65;
+            } else if (GP(st, ATHENA + NB * player) > 0) {
+                st[(ATHENA + NB * player) * 3 + 2] = (int8_t)(64 + (st[in + 1] > old_level ? 1 : 0));
+            } else {
+                for (int i = player * NB; i < (player + 1) * NB; i++)
+                    if (st[i * 3 + 2] > 64) st[i * 3 + 2] = 64;
+            }
+            break; }
+        case APOLLO: {
+            const int8_t a = st[io], b = st[in];
+            st[io] = b; st[in] = a;
+            st[idx(dir(np, bd)) * 3 + 1] += 1;
+            break; }
+        case MINOTAUR: {
+            const Pos pp{2 * np.y - old.y, 2 * np.x - old.x};
+            const int8_t a = st[io], b = st[in];
+            st[io] = 0; st[in] = a; st[idx(pp) * 3] = b;
+            st[idx(dir(np, bd)) * 3 + 1] += 1;
+            break; }
+        case ATLAS:
+            st[io] = 0; st[in] = (int8_t)wid;
+            st[idx(dir(np, bd)) * 3 + 1] = 4;
+            break;
+        case HEPHAESTUS:
+            st[io] = 0; st[in] = (int8_t)wid;
+            st[idx(dir(np, bd)) * 3 + 1] += 2;
+            break;
+        case ARTEMIS:
+            st[io] = 0; st[in] = (int8_t)wid;
+            st[(ARTEMIS + NB * player) * 3 + 2] = (int8_t)(64 + (worker * 9 + (8 - md) + 1));
+            opp_next = false;
+            break;
+        case DEMETER:
+            st[io] = 0; st[in] = (int8_t)wid;
+            st[idx(dir(np, bd)) * 3 + 1] += 1;
+            st[(DEMETER + NB * player) * 3 + 2] = (int8_t)(64 + (worker * 9 + bd + 1));
+            opp_next = false;
+            break;
+        case HERMES:
+            st[io] = 0; st[in] = (int8_t)wid;
+            st[(HERMES + NB * player) * 3 + 2] += 1;
+            opp_next = false;
+            break;
+        case PROMETHEUS:
+            st[idx(dir(old, bd)) * 3 + 1] += 1;
+            st[(PROMETHEUS + NB * player) * 3 + 2] = (int8_t)(64 + (worker * 9 + 1));
+            opp_next = false;
+            break;
+        default: break;
+        }
+        if (st[2 * NB * 3 + 2] < 127) st[2 * NB * 3 + 2] += 1;                                      // :544-545
+        return opp_next ? 1 - player : player;
+    }
+
+    __device__ static __forceinline__ int get_round(const int8_t* st) { return GP(st, 2 * NB); }   // :655-656
+
+    __device__ static int get_score(const int8_t* st, int player) {                                 // :84-97
+        int hi = 0;
+#pragma unroll
+        for (int i = 0; i < 25; i++) {
+            const int w = W(st, i), lv = LV(st, i);
+            hi = ((player == 0 ? w > 0 : w < 0) && lv > hi) ? lv : hi;
+        }
+        return hi;
+    }
+
+    // Board.check_end_game(next_player) :552-565 -- wave-cooperative (needs the valid-move scan)
+    __device__ static bool game_ended(const int8_t* st, int next_player, float* out, uint64_t* mask_scratch) {
+        (void)mask_scratch;
+        out[0] = out[1] = 0.f;
+        if (get_score(st, 0) == 3 || GP(st, PAN + NB * 0) > 64) { out[0] = 1.f; out[1] = -1.f; return true; }
+        if (get_score(st, 1) == 3 || GP(st, PAN + NB * 1) > 64) { out[0] = -1.f; out[1] = 1.f; return true; }
+        const int l = lane_id();
+        const int god = owned_god(st, next_player);
+        const bool opp_athena = GP(st, ATHENA + NB * ((next_player + 1) % 2)) > 64;
+        bool any = false;
+        for (int k = 0; k < AW && !any; k++) {
+            const int a = k * 64 + l;
+            any = __ballot(a < A && valid_action(st, a < A ? a : 0, next_player, god, opp_athena)) != 0ull;
+        }
+        if (!any) {
+            if (next_player == 0) { out[0] = -1.f; out[1] = 1.f; }
+            else { out[0] = 1.f; out[1] = -1.f; }
+            return true;
+        }
+        return false;
+    }
+
+    // Board.swap_players :567-576
+    __device__ static void swap_players(int8_t* st, int8_t* tmp, int k) {
+        if (k != 1) return;
+        const int l = lane_id();
+        if (l < 2 * NB) tmp[l] = st[l * 3 + 2];
+        wave_sync();
+        if (l < 25) st[l * 3] = (int8_t)(-st[l * 3]);
+        if (l < 2 * NB) st[l * 3 + 2] = tmp[(l + NB) % (2 * NB)];
+        wave_sync();
+    }
+
+    // init_game :99-120 with INIT_METHOD == 1 -- lane 0; state zeroed by the caller
+    __device__ static void init_board(int8_t* st, Rng& rng) {
+        int cells[25];
+        for (int i = 0; i < 25; i++) cells[i] = i;
+        const int wl[4] = {1, -1, 2, -2};
+        for (int i = 0; i < 4; i++) {
+            int j = i + (int)(rng.u01() * (25 - i));
+            j = j > 24 ? 24 : j;
+            const int t = cells[i]; cells[i] = cells[j]; cells[j] = t;
+            st[cells[i] * 3] = (int8_t)wl[i];
+        }
+        int g0 = NO_GOD, g1 = NO_GOD;
+        if (NB > 1) {
+            int gods[10];
+            for (int i = 0; i < NB - 1; i++) gods[i] = i;
+            for (int i = 0; i < 2; i++) {
+                int j = i + (int)(rng.u01() * (NB - 1 - i));
+                j = j > NB - 2 ? NB - 2 : j;
+                const int t = gods[i]; gods[i] = gods[j]; gods[j] = t;
+            }
+            g0 = gods[0] + 1; g1 = gods[1] + 1;
+        }
+        st[(g0 + NB * 0) * 3 + 2] = 64;
+        st[(g1 + NB * 1) * 3 + 2] = 64;
+    }
+};
+
+}  // namespace azg

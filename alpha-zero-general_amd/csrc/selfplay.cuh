@@ -1,0 +1,294 @@
+// selfplay.cuh -- Coach.executeEpisode (Coach.py:37-84) as a per-tree device state machine.
+// Each tree plays its own game: when its search finishes it samples the move, records the example, plays the move
+// (true-random chance via the RNG contract), detects the end of the game, emits the finished game's examples to the
+// on-device ring, restarts, canonicalises the new root and begins the next search -- no host involvement, so trees
+// run out of phase and the leaf batch for the net stays full.
+#pragma once
+#include "kernels.cuh"
+
+namespace azg {
+
+// temp_for_selfplay (Coach.py:266-271)
+__device__ __forceinline__ double temp_for_selfplay(const ForestDev& F, int n) {
+    const double tb = F.temp_begin, te = F.temp_end, hl = F.tempThreshold;
+    if (hl < 0) return (n > -hl) ? te : tb;
+    return te + (tb - te) * pow(0.5, (double)n / hl);
+}
+
+// Drop every node that can no longer be reached: round < root_round (the move counter is part of the state, so such
+// states cannot recur).  Equivalent to -- and stricter in memory than -- the reference's lazy clean-up MCTS.py:86-91,
+// which removes nodes with round < r-5 every >20 rounds.  In-place sliding compaction by the tree's own wave:
+//   pass 1  old id -> new id map (stored in the hash-table memory, rebuilt afterwards)
+//   pass 2  slide headers / states / rows down, rewrite cached child ids through the map
+//   pass 3  clear + re-insert the hash table
+template <class G>
+__device__ void gc_tree(const ForestDev& F, int t, TreeHdr& H, int min_round) {
+    using FR = Forest<G>;
+    const int l = lane_id();
+    uint32_t* map = FR::htab(F, t);          // HT >= 2*cap entries
+    uint8_t* hp = FR::heap(F, t);
+    const uint32_t n = H.n_nodes;
+    // pass 1
+    uint32_t kept = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        uint32_t i = base + l;
+        bool keep = false;
+        if (i < n) {
+            const NodeHdr* nh = FR::nhdr(F, t, i);
+            keep = (int)nh->round >= min_round || i == H.root;
+        }
+        uint64_t b = __ballot(keep);
+        uint32_t rank = (uint32_t)__popcll(b & ((1ull << l) - 1ull));
+        if (i < n) map[i] = keep ? kept + rank : AZG_NONE;
+        kept += (uint32_t)__popcll(b);
+    }
+    __threadfence_block();
+    wave_sync();
+    // pass 2 (sequential over nodes, wave-parallel inside a node; dst <= src so forward copies are safe)
+    uint32_t heap_top = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t ni = map[i];
+        if (ni == AZG_NONE) continue;
+        NodeHdr nh = *FR::nhdr(F, t, i);
+        const bool has_row = nh.row_off != AZG_NONE;
+        const RowLayout L(nh.nv, F.U);
+        const uint32_t units = has_row ? L.total / 16u : 0u;
+        if (has_row) {
+            const uint4* src = (const uint4*)(hp + (size_t)nh.row_off * 16u);
+            uint4* dst = (uint4*)(hp + (size_t)heap_top * 16u);
+            const uint32_t c0 = L.offC / 16u, c1 = L.offI / 16u;     // child section in 16-byte units
+            for (uint32_t base = 0; base < units; base += 64) {
+                uint32_t k = base + l;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (k < units) {
+                    v = src[k];
+                    if (k >= c0 && k < c1) {
+                        uint32_t* w = (uint32_t*)&v;
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (w[q] != AZG_NONE) {
+                                uint32_t m = map[w[q] & AZG_CHILD_IDX_MASK];
+                                w[q] = (m == AZG_NONE) ? AZG_NONE : ((w[q] & ~AZG_CHILD_IDX_MASK) | m);
+                            }
+                    }
+                }
+                wave_sync();                       // every lane has read its chunk before anyone overwrites it
+                if (k < units) dst[k] = v;
+            }
+            nh.row_off = heap_top;
+        }
+        if (ni != i) {
+            const uint32_t* ssrc = (const uint32_t*)FR::nstate(F, t, i);
+            uint32_t* sdst = (uint32_t*)FR::nstate(F, t, ni);
+            for (int k = l; k < FR::SPW; k += 64) sdst[k] = ssrc[k];
+        }
+        if (l == 0) *FR::nhdr(F, t, ni) = nh;
+        heap_top += units;
+        wave_sync();
+    }
+    if (H.root != AZG_NONE) H.root = map[H.root];
+    // pass 3
+    wave_sync();
+    uint32_t* tab = FR::htab(F, t);
+    for (int i = l; i < F.HT; i += 64) tab[i] = AZG_NONE;
+    wave_sync();
+    const uint32_t maskHT = (uint32_t)F.HT - 1u;
+    if (l == 0) {
+        for (uint32_t i = 0; i < kept; i++) {
+            const uint64_t h = FR::nhdr(F, t, i)->hash;
+            uint32_t s = (uint32_t)h & maskHT;
+            while (tab[s] != AZG_NONE) s = (s + 1u) & maskHT;
+            tab[s] = (FR::tag_of(h) << AZG_IDX_BITS) | i;
+        }
+    }
+    wave_sync();
+    H.n_nodes = kept;
+    H.heap_top = heap_top;
+    H.gc_runs++;
+}
+
+template <class G>
+__device__ void reset_tree(const ForestDev& F, int t, TreeHdr& H) {
+    uint32_t* tab = Forest<G>::htab(F, t);
+    for (int i = lane_id(); i < F.HT; i += 64) tab[i] = AZG_NONE;
+    H.n_nodes = 0; H.heap_top = 0; H.root = AZG_NONE;
+    wave_sync();
+}
+
+// new game on this tree: Board.init_game (or a supplied board), player 0 to move
+template <class G>
+__device__ void start_game(const ForestDev& F, int t, TreeHdr& H, typename Forest<G>::Smem& sm, Rng& rng,
+                           const int8_t* init_board) {
+    using FR = Forest<G>;
+    reset_tree<G>(F, t, H);
+    if (init_board) FR::load_state_unpadded(sm.st, init_board);
+    else {
+        for (int i = lane_id(); i < G::SP; i += 64) sm.st[i] = 0;
+        wave_sync();
+        if (lane_id() == 0) G::init_board(sm.st, rng);
+        rng.counter = bcast_u64(rng.counter, 0);
+        wave_sync();
+    }
+    FR::store_state(F.board + (size_t)t * G::SP, sm.st);
+    H.cur_player = 0; H.ply = 0; H.step = 0; H.n_rec = 0;
+}
+
+template <class G>
+__global__ __launch_bounds__(64) void k_selfplay_start(ForestDev F, const int8_t* init_boards) {
+    using FR = Forest<G>;
+    __shared__ typename FR::Smem sm;
+    const int t = blockIdx.x;
+    TreeHdr H = F.hdr[t];
+    Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, 0ull};
+    H.err = 0; H.games_done = 0; H.gc_runs = 0; H.max_nodes_seen = 0;
+    H.c_sims = H.c_levels = H.c_exp = H.c_sumvalid = H.c_term = H.c_depth = H.c_plies = H.c_examples = 0;
+    start_game<G>(F, t, H, sm, rng, init_boards ? init_boards + (size_t)t * G::S : nullptr);
+    // board is canonical for player 0 (Coach.py:61 with curPlayer == 0)
+    const double u_full = rng.u01();
+    begin_search_from_lds<G>(F, t, H, sm, u_full < F.prob_fullMCTS);
+    H.rng_counter = rng.counter;
+    if (lane_id() == 0) F.hdr[t] = H;
+}
+
+template <class G>
+__global__ __launch_bounds__(64) void k_selfplay_advance(ForestDev F) {
+    using FR = Forest<G>;
+    __shared__ typename FR::Smem sm;
+    __shared__ int cnt[G::A];
+    __shared__ double w[G::A];
+    const int t = blockIdx.x;
+    const int l = lane_id();
+    TreeHdr H = F.hdr[t];
+    if (H.status != ST_DONE) return;
+    if (H.err) return;                         // tree is parked; the host reads the error flag
+    Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, H.rng_counter};
+    float q[G::P];
+#pragma unroll
+    for (int p = 0; p < G::P; p++) q[p] = 0.f;
+    root_counts<G>(F, t, H, cnt, q);
+    // ---- pi with temp = 1 (MCTS.py:100-103), then random_pick with the self-play temperature (Coach.py:62-63) ----
+    long long tot = 0;
+    for (int a = 0; a < G::A; a++) tot += cnt[a];
+    const double T = temp_for_selfplay(F, (int)H.step + 1);
+    const double u_pick = rng.u01();
+    for (int a = l; a < G::A; a += 64) {
+        double p = tot > 0 ? (double)cnt[a] / (double)tot : 0.0;
+        w[a] = (T == 0.0) ? p : pow(p, 1.0 / T);
+    }
+    wave_sync();
+    int action = 0;
+    if (l == 0) {
+        if (T == 0.0) {                                                    // uniform among the maxima (Coach.py:279-282)
+            double mx = -1.0; int nb = 0;
+            for (int a = 0; a < G::A; a++) mx = w[a] > mx ? w[a] : mx;
+            for (int a = 0; a < G::A; a++) nb += w[a] == mx;
+            int k = (int)(u_pick * nb); k = k >= nb ? nb - 1 : k;
+            for (int a = 0; a < G::A; a++) if (w[a] == mx) { if (k-- == 0) { action = a; break; } }
+        } else {
+            double s = 0.0;
+            for (int a = 0; a < G::A; a++) s += w[a];
+            double tot2 = 0.0;
+            for (int a = 0; a < G::A; a++) tot2 += w[a] / s;
+            double cdf = 0.0; int pick = -1, last = 0;
+            for (int a = 0; a < G::A; a++) {
+                double pa = w[a] / s;
+                cdf += pa;
+                if (pa > 0) last = a;
+                if (cdf / tot2 > u_pick) { pick = a; break; }
+            }
+            action = pick < 0 ? last : pick;
+        }
+    }
+    action = __shfl(action, 0, 64);
+    // ---- record the example on full searches (Coach.py:65-69; symmetries are applied by the consumer) ----
+    if (H.is_full) {
+        if (H.n_rec < (uint32_t)F.max_rec) {
+            const size_t r = (size_t)t * F.max_rec + H.n_rec;
+            const int8_t* rs = F.root_state + (size_t)t * G::SP;
+            for (int i = l; i < G::S; i += 64) F.rec_board[r * G::S + i] = rs[i];
+            for (int a = l; a < G::A; a += 64) {
+                F.rec_pi[r * G::A + a] = (float)(tot > 0 ? (double)cnt[a] / (double)tot : 0.0);
+                F.rec_valid[r * G::A + a] = 0;
+            }
+            wave_sync();
+            if (H.root != AZG_NONE) {
+                const NodeHdr nh = *FR::nhdr(F, t, H.root);
+                if (nh.flags & NF_EXPANDED) {
+                    const RowLayout L(nh.nv, F.U);
+                    const uint16_t* ids = (const uint16_t*)(FR::heap(F, t) + (size_t)nh.row_off * 16u + L.offI);
+                    for (int j = l; j < nh.nv; j += 64) F.rec_valid[r * G::A + ids[j]] = 1;
+                }
+            }
+            if (l == 0) {
+                for (int p = 0; p < G::P; p++) F.rec_q[r * G::P + p] = q[p];
+                F.rec_player[r] = (uint8_t)H.cur_player;
+                F.rec_ply[r] = (uint16_t)H.ply;
+            }
+            H.n_rec++;
+        } else H.err |= ERR_REC_OVERFLOW;
+    }
+    // ---- play the move for real: random_seed = 0 (Coach.py:71) ----
+    FR::load_state(sm.st, F.board + (size_t)t * G::SP);
+    int np = 0;
+    if (l == 0) np = G::make_move(sm.st, action, (int)H.cur_player, 0ll, rng);
+    np = __shfl(np, 0, 64);
+    rng.counter = bcast_u64(rng.counter, 0);
+    wave_sync();
+    H.c_plies++;
+    float es[G::P];
+    const bool ended = G::game_ended(sm.st, np, es, sm.mask);                                  // Coach.py:73
+    if (ended) {
+        // z = np.roll(r, -player) (Coach.py:76-82): z[i] = r[(i + player) mod P]
+        unsigned long long base = 0;
+        if (l == 0) base = atomicAdd(F.ex_count, (unsigned long long)H.n_rec);
+        base = bcast_u64(base, 0);
+        for (uint32_t k = 0; k < H.n_rec; k++) {
+            const size_t r = (size_t)t * F.max_rec + k;
+            const unsigned long long dst = base + k;
+            if (dst >= (unsigned long long)F.max_examples) { if (l == 0) atomicAdd(F.ex_count + 1, 1ull); continue; }
+            for (int i = l; i < G::S; i += 64) F.ex_board[dst * G::S + i] = F.rec_board[r * G::S + i];
+            for (int a = l; a < G::A; a += 64) {
+                F.ex_pi[dst * G::A + a] = F.rec_pi[r * G::A + a];
+                F.ex_valid[dst * G::A + a] = F.rec_valid[r * G::A + a];
+            }
+            if (l == 0) {
+                const int pl = F.rec_player[r];
+                for (int p = 0; p < G::P; p++) {
+                    F.ex_z[dst * G::P + p] = es[(p + pl) % G::P];
+                    F.ex_q[dst * G::P + p] = F.rec_q[r * G::P + p];
+                }
+                F.ex_meta[dst * 4 + 0] = (int32_t)(F.stream0 + (uint64_t)t);
+                F.ex_meta[dst * 4 + 1] = (int32_t)H.games_done;
+                F.ex_meta[dst * 4 + 2] = (int32_t)F.rec_ply[r];
+                F.ex_meta[dst * 4 + 3] = pl;
+            }
+        }
+        H.c_examples += H.n_rec;
+        H.games_done++;
+        start_game<G>(F, t, H, sm, rng, nullptr);
+    } else {
+        FR::store_state(F.board + (size_t)t * G::SP, sm.st);
+        H.cur_player = (uint32_t)np;
+        H.ply++;
+        H.step++;
+        if (np != 0) G::swap_players(sm.st, sm.tmp, np);                                      // Coach.py:61
+    }
+    // ---- memory reclamation, then the next search ----
+    const int new_round = G::get_round(sm.st);
+    if (!ended && (H.n_nodes + (uint32_t)F.numMCTSSims + 8u > (uint32_t)F.cap ||
+                   H.heap_top + (uint32_t)(F.numMCTSSims + 8) * (RowLayout(G::A < 96 ? G::A : 96, F.U).total / 16u) >
+                       F.heap_units)) {
+        // locate the new root first so that GC can keep it
+        uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
+        uint32_t free_slot;
+        H.root = FR::probe(F, t, sm.st, h, &free_slot);
+        gc_tree<G>(F, t, H, new_round);
+    }
+    const double u_full = rng.u01();                                                           // MCTS.py:58
+    begin_search_from_lds<G>(F, t, H, sm, u_full < F.prob_fullMCTS);
+    H.rng_counter = rng.counter;
+    if (H.n_nodes > H.max_nodes_seen) H.max_nodes_seen = H.n_nodes;
+    if (l == 0) F.hdr[t] = H;
+}
+
+}  // namespace azg

@@ -1,0 +1,171 @@
+"""Thin Python handle on an `azg_forest` (include/azg.h).  torch is used only for device buffers and streams."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ForestCfg, SelfplayStats, check, lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Forest:
+    """T independent search trees on one GPU.  args: the reference's `args` object (dotdict or namespace) with
+    numMCTSSims, cpuct, fpu, universes, prob_fullMCTS, ratio_fullMCTS, forced_playouts, dirichletAlpha, temperature,
+    tempThreshold (main.py:120-156, pit.py:49-57)."""
+
+    def __init__(self, game_id, variant, n_trees, args, node_capacity=4096, max_examples=0, rng_seed=0, stream0=0,
+                 device='cuda:0', row_capacity_bytes=0):
+        if not torch.cuda.is_available():
+            raise _lib.AzgError('no GPU visible: the engine has no CPU fallback')
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.S, self.A, self.P, self.rows, self.cols = _lib.game_info(game_id, variant)
+        g = lambda k, d: getattr(args, k, d) if not isinstance(args, dict) else args.get(k, d)  # noqa: E731
+        cfg = ForestCfg()
+        cfg.game, cfg.variant, cfg.n_trees = game_id, variant, n_trees
+        cfg.node_capacity, cfg.row_capacity_bytes = node_capacity, row_capacity_bytes
+        cfg.numMCTSSims = int(g('numMCTSSims', 800))
+        cfg.cpuct, cfg.fpu = float(g('cpuct', 1.0)), float(g('fpu', 0.0))
+        cfg.universes = int(g('universes', 1))
+        cfg.prob_fullMCTS = float(g('prob_fullMCTS', 1.0))
+        cfg.ratio_fullMCTS = int(g('ratio_fullMCTS', 5))
+        cfg.forced_playouts = int(bool(g('forced_playouts', True)))
+        cfg.dirichletAlpha = float(g('dirichletAlpha', 0.0))
+        temp = list(g('temperature', [1.0, 1.0, 1.0]))
+        temp = temp + [1.0] * (3 - len(temp))        # pretrained checkpoints embed only 2 entries
+        for i in range(3):
+            cfg.temperature[i] = float(temp[i])
+        cfg.tempThreshold = float(g('tempThreshold', 10))
+        cfg.rng_seed, cfg.stream0, cfg.max_examples = rng_seed, stream0, max_examples
+        self.cfg = cfg
+        self.T = n_trees
+        h = C.c_void_p()
+        check(lib().azg_forest_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        dev = self.device
+        self.leaf_states = torch.zeros((n_trees, self.S), dtype=torch.int8, device=dev)
+        self.leaf_valid = torch.zeros((n_trees, self.A), dtype=torch.uint8, device=dev)
+        self.needs_eval = torch.zeros((n_trees,), dtype=torch.uint8, device=dev)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            lib().azg_forest_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self):
+        return lib().azg_forest_device_bytes(self.h)
+
+    def board_shape(self):
+        return (5, 5, 3) if self.cfg.game == _lib.SANTORINI else (self.rows, self.cols)
+
+    def reset(self):
+        check(lib().azg_forest_reset(self.h, _stream()))
+
+    def begin_search(self, roots, full=None):
+        roots = roots.reshape(self.T, self.S).contiguous()
+        assert roots.dtype == torch.int8 and roots.is_cuda
+        self._keep = (roots, full)
+        check(lib().azg_forest_begin_search(self.h, _ptr(roots), _ptr(full), _stream()))
+
+    def select(self, noise=None):
+        check(lib().azg_forest_select(self.h, _ptr(self.leaf_states), _ptr(self.leaf_valid), _ptr(self.needs_eval),
+                                      _ptr(noise), 0 if noise is None else noise.shape[1], _stream()))
+
+    def expand_backup(self, pi, v, noise=None):
+        assert pi.dtype == torch.float32 and v.dtype == torch.float32 and pi.is_contiguous() and v.is_contiguous()
+        assert pi.shape == (self.T, self.A) and v.shape == (self.T, self.P)
+        check(lib().azg_forest_expand_backup(self.h, _ptr(pi), _ptr(v), _ptr(noise),
+                                             0 if noise is None else noise.shape[1], _stream()))
+
+    def active(self):
+        n = C.c_int()
+        check(lib().azg_forest_active(self.h, C.byref(n)))
+        return n.value
+
+    def action_probs(self, temp=1.0):
+        probs = torch.empty((self.T, self.A), dtype=torch.float64, device=self.device)
+        q = torch.empty((self.T, self.P), dtype=torch.float32, device=self.device)
+        full = torch.empty((self.T,), dtype=torch.uint8, device=self.device)
+        check(lib().azg_forest_action_probs(self.h, float(temp), _ptr(probs), _ptr(q), _ptr(full), _stream()))
+        return probs, q, full
+
+    def root_stats(self):
+        d = self.device
+        Ns = torch.empty((self.T,), dtype=torch.int32, device=d)
+        Qs = torch.empty((self.T,), dtype=torch.float32, device=d)
+        Nsa = torch.empty((self.T, self.A), dtype=torch.int32, device=d)
+        Qsa = torch.empty((self.T, self.A), dtype=torch.float64, device=d)
+        Ps = torch.empty((self.T, self.A), dtype=torch.float32, device=d)
+        nn = torch.empty((self.T,), dtype=torch.int32, device=d)
+        check(lib().azg_forest_root_stats(self.h, _ptr(Ns), _ptr(Qs), _ptr(Nsa), _ptr(Qsa), _ptr(Ps), _ptr(nn),
+                                          _stream()))
+        return dict(Ns=Ns, Qs=Qs, Nsa=Nsa, Qsa=Qsa, Ps=Ps, n_nodes=nn)
+
+    def dump_tree(self, tree, max_nodes=None):
+        max_nodes = max_nodes or self.cfg.node_capacity
+        S, A, P = self.S, self.A, self.P
+        states = np.zeros((max_nodes, S), dtype=np.int8)
+        Ns = np.zeros(max_nodes, dtype=np.int32)
+        Qs = np.zeros(max_nodes, dtype=np.float32)
+        Es = np.zeros((max_nodes, P), dtype=np.float32)
+        Nsa = np.zeros((max_nodes, A), dtype=np.int32)
+        Qsa = np.zeros((max_nodes, A), dtype=np.float64)
+        Ps = np.zeros((max_nodes, A), dtype=np.float32)
+        hp = np.zeros(max_nodes, dtype=np.uint8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        n = check(lib().azg_forest_dump_tree(self.h, tree, max_nodes, p(states), p(Ns), p(Qs), p(Es), p(Nsa), p(Qsa),
+                                             p(Ps), p(hp)))
+        return dict(n=n, states=states[:n], Ns=Ns[:n], Qs=Qs[:n], Es=Es[:n], Nsa=Nsa[:n], Qsa=Qsa[:n], Ps=Ps[:n],
+                    has_policy=hp[:n].astype(bool))
+
+    # ---- self-play ----
+    def selfplay_start(self, init_boards=None):
+        ib = None if init_boards is None else init_boards.reshape(self.T, self.S).contiguous()
+        self._keep_ib = ib
+        check(lib().azg_selfplay_start(self.h, _ptr(ib), _stream()))
+
+    def selfplay_advance(self):
+        check(lib().azg_selfplay_advance(self.h, _stream()))
+
+    def stats(self):
+        s = SelfplayStats()
+        check(lib().azg_selfplay_stats_get(self.h, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in SelfplayStats._fields_}
+
+    def drain_examples(self, max_records=None):
+        max_records = max_records or self.cfg.max_examples
+        d = self.device
+        boards = torch.empty((max_records, self.S), dtype=torch.int8, device=d)
+        pi = torch.empty((max_records, self.A), dtype=torch.float32, device=d)
+        z = torch.empty((max_records, self.P), dtype=torch.float32, device=d)
+        valids = torch.empty((max_records, self.A), dtype=torch.uint8, device=d)
+        q = torch.empty((max_records, self.P), dtype=torch.float32, device=d)
+        meta = torch.empty((max_records, 4), dtype=torch.int32, device=d)
+        n = C.c_int()
+        check(lib().azg_selfplay_drain_examples(self.h, max_records, _ptr(boards), _ptr(pi), _ptr(z), _ptr(valids),
+                                                _ptr(q), _ptr(meta), C.byref(n), _stream()))
+        n = n.value
+        return boards[:n], pi[:n], z[:n], valids[:n], q[:n], meta[:n]
+
+    def enable_timing(self, on=True):
+        check(lib().azg_forest_enable_timing(self.h, int(on)))
+
+    def kernel_ms(self, which):
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib().azg_forest_last_kernel_ms(self.h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

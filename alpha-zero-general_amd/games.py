@@ -1,0 +1,143 @@
+"""Game.py-compatible env plugins backed by the batched HIP env kernels (azg_env_* in include/azg.h).
+
+Same method names, argument meaning and return types as the reference's adaptors (splendor/SplendorGame.py:16-60,
+santorini/SantoriniGame.py:16-60, Game.py:14-162).  Every method also has a `*_batch` twin that takes and returns
+torch CUDA tensors for n boards at once -- that is the form the engine itself uses."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HipGame:
+    GAME_ID = None
+
+    def __init__(self, variant, device='cuda:0', rng_seed=0):
+        if not torch.cuda.is_available():
+            raise _lib.AzgError('no GPU visible: the engine has no CPU fallback')
+        self.variant = variant
+        self.device = torch.device(device)
+        self.S, self.A, self.P, self.rows, self.cols = _lib.game_info(self.GAME_ID, variant)
+        self.num_players = self.P
+        self.rng_seed = rng_seed
+        self._stream_ctr = 0
+        self._draw = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    # ---- batch API (torch CUDA tensors) ----
+    def valid_moves_batch(self, boards, players):
+        n = boards.shape[0]
+        out = torch.empty((n, self.A), dtype=torch.uint8, device=self.device)
+        check(lib().azg_env_valid_moves(self.GAME_ID, self.variant, _ptr(boards), _ptr(players), n, _ptr(out),
+                                        _stream()))
+        return out
+
+    def next_state_batch(self, boards, players, actions, seeds, stream0=0, counters=None):
+        n = boards.shape[0]
+        out = torch.empty((n, self.S), dtype=torch.int8, device=self.device)
+        nxt = torch.empty((n,), dtype=torch.int32, device=self.device)
+        check(lib().azg_env_next_state(self.GAME_ID, self.variant, _ptr(boards), _ptr(players), _ptr(actions),
+                                       _ptr(seeds), n, _ptr(out), _ptr(nxt), self.rng_seed, stream0, _ptr(counters),
+                                       _stream()))
+        return out, nxt
+
+    def game_ended_batch(self, boards, next_players):
+        n = boards.shape[0]
+        ended = torch.empty((n, self.P), dtype=torch.float32, device=self.device)
+        scores = torch.empty((n, self.P), dtype=torch.int32, device=self.device)
+        rnd = torch.empty((n,), dtype=torch.int32, device=self.device)
+        check(lib().azg_env_game_ended(self.GAME_ID, self.variant, _ptr(boards), _ptr(next_players), n, _ptr(ended),
+                                       _ptr(scores), _ptr(rnd), _stream()))
+        return ended, scores, rnd
+
+    def canonical_batch(self, boards, players):
+        n = boards.shape[0]
+        out = torch.empty((n, self.S), dtype=torch.int8, device=self.device)
+        check(lib().azg_env_canonical(self.GAME_ID, self.variant, _ptr(boards), _ptr(players), n, _ptr(out), _stream()))
+        return out
+
+    def init_boards_batch(self, n, stream0=0):
+        out = torch.empty((n, self.S), dtype=torch.int8, device=self.device)
+        check(lib().azg_env_init_boards(self.GAME_ID, self.variant, n, _ptr(out), self.rng_seed, stream0, None,
+                                        _stream()))
+        return out
+
+    # ---- Game.py API (numpy in / numpy out, one board) ----
+    def _dev(self, board):
+        return torch.from_numpy(np.ascontiguousarray(board, dtype=np.int8).reshape(1, self.S)).to(self.device)
+
+    def _i32(self, v):
+        return torch.tensor([int(v)], dtype=torch.int32, device=self.device)
+
+    def getBoardSize(self):
+        return (5, 5, 3) if self.GAME_ID == _lib.SANTORINI else (self.rows, self.cols)
+
+    def getActionSize(self):
+        return self.A
+
+    def getNumberOfPlayers(self):
+        return self.P
+
+    def getInitBoard(self):
+        self._stream_ctr += 1
+        return self.init_boards_batch(1, stream0=self._stream_ctr)[0].cpu().numpy().reshape(self.getBoardSize())
+
+    def getNextState(self, board, player, action, random_seed=0):
+        seeds = torch.tensor([int(random_seed)], dtype=torch.int64, device=self.device)
+        self._stream_ctr += 1
+        out, nxt = self.next_state_batch(self._dev(board), self._i32(player), self._i32(action), seeds,
+                                         stream0=(1 << 40) + self._stream_ctr)
+        return out[0].cpu().numpy().reshape(self.getBoardSize()), int(nxt[0].item())
+
+    def getValidMoves(self, board, player):
+        return self.valid_moves_batch(self._dev(board), self._i32(player))[0].cpu().numpy().astype(bool)
+
+    def getGameEnded(self, board, next_player):
+        return self.game_ended_batch(self._dev(board), self._i32(next_player))[0][0].cpu().numpy()
+
+    def getScore(self, board, player):
+        return int(self.game_ended_batch(self._dev(board), self._i32(0))[1][0, player].item())
+
+    def getRound(self, board):
+        return int(self.game_ended_batch(self._dev(board), self._i32(0))[2][0].item())
+
+    def getCanonicalForm(self, board, player):
+        if player == 0:
+            return board
+        return self.canonical_batch(self._dev(board), self._i32(player))[0].cpu().numpy().reshape(self.getBoardSize())
+
+    def stringRepresentation(self, board):
+        return np.ascontiguousarray(board, dtype=np.int8).tobytes()
+
+
+class SplendorGame(HipGame):
+    GAME_ID = _lib.SPLENDOR
+
+    def __init__(self, num_players=2, **kw):
+        super().__init__(num_players, **kw)
+
+
+class SantoriniGame(HipGame):
+    GAME_ID = _lib.SANTORINI
+
+    def __init__(self, nb_gods=11, **kw):
+        super().__init__(nb_gods, **kw)
+
+
+def import_game(name, **kw):
+    """GameSwitcher.import_game equivalent (GameSwitcher.py:15-24) for the games on the hot path."""
+    if name == 'splendor':
+        return SplendorGame(**kw)
+    if name == 'santorini':
+        return SantoriniGame(**kw)
+    raise ValueError('game %r is not on the accelerated path' % name)

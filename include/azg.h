@@ -1,0 +1,156 @@
+/* azg.h -- C-ABI of the MI355X-native batched self-play engine (libazg_hip.so).
+ *
+ * The reference (cestpasphoto/alpha-zero-general) is 100% Python and has NO FFI; its boundary for this path is duck
+ * typing.  This header is the C boundary a binding for the reference would call: every entry point
+ * names the reference interface it replaces (file:line under the reference root).  The Python host side in
+ * alpha-zero-general_amd/ mirrors Game.py / MCTS.py / Coach.py on top of exactly these functions through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; azg_last_error() gives the message (thread-local).
+ *   - `*_dev` pointers are DEVICE pointers (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void*
+ *     (NULL = default stream).  Kernels are enqueued on that stream and the call returns without synchronising, so
+ *     they can be captured in a HIP graph.  Functions without a stream argument synchronise the device.
+ *   - states are int8, C-contiguous, byte-identical to the reference's board.tobytes()
+ *     (splendor/SplendorLogicNumba.py:207-219, santorini/SantoriniLogicNumba.py:658-665).
+ *   - no callbacks into the host language; one host thread per forest handle.
+ *
+ * RNG contract (shared with oracle/rng.c):
+ *     mix64(x): x^=x>>30; x*=0xBF58476D1CE4E5B9; x^=x>>27; x*=0x94D049BB133111EB; x^=x>>31
+ *     raw(seed, stream, counter) = mix64(mix64(mix64(seed ^ 0x9E3779B97F4A7C15) + stream) + counter)
+ *     u01 = (raw >> 11) * 2^-53;   stream = global game index, counter = per-game draw count.
+ *   Per ply a self-play game draws: u_full (MCTS.py:58), u_pick (Coach.py:289-292), then whatever
+ *   make_move(random_seed=0) consumes (SplendorLogicNumba.py:311-315).
+ */
+#ifndef AZG_H
+#define AZG_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { AZG_SPLENDOR = 0, AZG_SANTORINI = 1 };
+#define AZG_MAX_PLAYERS 4
+#define AZG_MAX_UNIVERSES 8
+
+const char* azg_last_error(void);
+const char* azg_version(void);
+int azg_device_count(void);
+int azg_set_device(int device);
+
+/* GameSwitcher.import_game + Game.getBoardSize/getActionSize/getNumberOfPlayers (GameSwitcher.py:15-24, Game.py:27-42).
+   variant: Splendor = NUMBER_PLAYERS (2..4, splendor/SplendorGame.py:9); Santorini = NB_GODS (1 or 11,
+   santorini/SantoriniConstants.py:19). */
+int azg_game_info(int game, int variant, int* state_bytes, int* action_size, int* num_players, int* rows, int* cols);
+
+/* ---- batched env step (one wavefront per state) ------------------------------------------------------------------
+   Replace the per-call <G>Game adaptor methods (splendor/SplendorGame.py:28-48, santorini/SantoriniGame.py:28-48). */
+/* Game.getValidMoves(board, player) -> bool[A]            out_valid_dev: u8[n][A] */
+int azg_env_valid_moves(int game, int variant, const int8_t* states_dev, const int32_t* players_dev, int n,
+                        uint8_t* out_valid_dev, void* stream);
+/* Game.getNextState(board, player, action, random_seed) -> (board', next_player).  random_seed==0 draws from the RNG
+   contract with (rng_seed, stream = stream0 + i, counter = counters_dev[i]) and advances counters_dev[i]. */
+int azg_env_next_state(int game, int variant, const int8_t* states_dev, const int32_t* players_dev,
+                       const int32_t* actions_dev, const int64_t* random_seeds_dev, int n, int8_t* out_states_dev,
+                       int32_t* out_next_players_dev, uint64_t rng_seed, uint64_t stream0, uint64_t* counters_dev,
+                       void* stream);
+/* Game.getGameEnded(board, next_player) -> f32[P] ; getScore -> i32[P] ; getRound -> i32 */
+int azg_env_game_ended(int game, int variant, const int8_t* states_dev, const int32_t* next_players_dev, int n,
+                       float* out_ended_dev, int32_t* out_scores_dev, int32_t* out_round_dev, void* stream);
+/* Game.getCanonicalForm(board, player) */
+int azg_env_canonical(int game, int variant, const int8_t* states_dev, const int32_t* players_dev, int n,
+                      int8_t* out_states_dev, void* stream);
+/* Game.getInitBoard() for n games (Board.init_game); RNG contract with stream = stream0 + i, counter from 0;
+   out_counters_dev (optional) receives the number of draws consumed. */
+int azg_env_init_boards(int game, int variant, int n, int8_t* out_states_dev, uint64_t rng_seed, uint64_t stream0,
+                        uint64_t* out_counters_dev, void* stream);
+
+/* ---- forest: T independent MCTS trees, one wavefront per tree ----------------------------------------------------
+   Replaces MCTS (MCTS.py:19-261) for a batch of trees and, in self-play mode, Coach.executeEpisode (Coach.py:37-84). */
+typedef struct azg_forest_cfg {
+    int game, variant;
+    int n_trees;                 /* concurrent games on this GPU */
+    int node_capacity;           /* nodes per tree (arena); GC keeps it bounded in self-play */
+    int row_capacity_bytes;      /* per-tree row heap; 0 = auto */
+    /* args.* of the reference (main.py:120-156, pit.py:49-57) */
+    int numMCTSSims;
+    double cpuct, fpu;
+    int universes;
+    double prob_fullMCTS;
+    int ratio_fullMCTS;
+    int forced_playouts;
+    double dirichletAlpha;       /* 0 = no root noise; noise samples are supplied by the caller (torch Dirichlet) */
+    double temperature[3];       /* [begin, end, root-softmax] (Coach.py:266-271, MCTS.py:148) */
+    double tempThreshold;
+    uint64_t rng_seed;
+    uint64_t stream0;            /* global index of tree 0 (rank * n_trees in multi-GPU runs) */
+    int max_examples;            /* capacity of the on-device example ring (self-play mode) */
+} azg_forest_cfg;
+
+typedef struct azg_forest azg_forest;
+
+int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out);           /* MCTS.__init__ MCTS.py:24-47 */
+int azg_forest_destroy(azg_forest* f);
+size_t azg_forest_device_bytes(const azg_forest* f);
+
+/* MCTS.reset_all_search_trees (MCTS.py:199-203) */
+int azg_forest_reset(azg_forest* f, void* stream);
+
+/* --- host-driven mode: the pieces of MCTS.getActionProb (MCTS.py:49-103) --- */
+/* begin a search on every tree: canonical roots int8[T][S]; full_dev u8[T] (1 = full search) or NULL (all full).
+   The tree is reused if the root state is already a node (MCTS.py:125-126). */
+int azg_forest_begin_search(azg_forest* f, const int8_t* roots_dev, const uint8_t* full_dev, void* stream);
+/* one lock-step round, part 1: every tree runs simulations until it needs the net (one leaf per tree) or has finished
+   its numMCTSSims.  Writes the leaf batch for NeuralNet.predict (NeuralNet.py:32-43):
+   leaf_states int8[T][S], leaf_valid u8[T][A], needs_eval u8[T].   MCTS.search :105-175 */
+int azg_forest_select(azg_forest* f, int8_t* leaf_states_dev, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev,
+                      const double* root_noise_dev /* f64[T][noise_stride] or NULL */, int noise_stride, void* stream);
+/* part 2: store (Ps, v) on the pending leaves and back the values up (MCTS.py:147-154,176-183).
+   pi f32[T][A] are PROBABILITIES (exp of the net's log-softmax, GenericNNetWrapper.py:107,119), v f32[T][P]. */
+int azg_forest_expand_backup(azg_forest* f, const float* pi_dev, const float* v_dev, const double* root_noise_dev,
+                             int noise_stride, void* stream);
+/* number of trees that still have simulations to run (synchronises) */
+int azg_forest_active(azg_forest* f, int* n_active);
+/* MCTS.getActionProb epilogue (:67-103): probs f64[T][A] for temperature temp_dev f64[T] (or scalar temp if NULL),
+   q f32[T][P], is_full u8[T].  Any output may be NULL. */
+int azg_forest_action_probs(azg_forest* f, double temp, double* probs_dev, float* q_dev, uint8_t* is_full_dev,
+                            void* stream);
+/* root statistics for parity checks: Ns i32[T], Qs f32[T], Nsa i32[T][A], Qsa f64[T][A] (sentinel -42 where unvisited),
+   Ps f32[T][A], n_nodes i32[T] */
+int azg_forest_root_stats(azg_forest* f, int32_t* Ns_dev, float* Qs_dev, int32_t* Nsa_dev, double* Qsa_dev,
+                          float* Ps_dev, int32_t* n_nodes_dev, void* stream);
+/* whole-tree dump of one tree to HOST memory for parity tests (synchronises): for every node: state[S], flags,
+   Ns, Qs, Es[P], and dense Nsa/Qsa/Ps[A].  Returns node count; arrays sized for max_nodes. */
+int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8_t* states, int32_t* Ns, float* Qs, float* Es,
+                         int32_t* Nsa, double* Qsa, float* Ps, uint8_t* has_policy);
+
+/* --- self-play mode: Coach.executeEpisode on device (Coach.py:37-84) --- */
+/* start one game per tree (Board.init_game or the given init boards int8[T][S]) */
+int azg_selfplay_start(azg_forest* f, const int8_t* init_boards_dev /* or NULL */, void* stream);
+/* to be called once per round after expand_backup: trees whose search finished sample the move
+   (Coach.py:63,278-292), record the example (Coach.py:65-69), play it (Coach.py:71), detect the end (Coach.py:73-82),
+   restart finished games, re-root and begin the next search -- all on device. */
+int azg_selfplay_advance(azg_forest* f, void* stream);
+/* counters (synchronises): plies executed, games finished, simulations run, examples stored, error flags */
+typedef struct azg_selfplay_stats {
+    uint64_t plies, games, sims, levels, expansions, sum_valid_visited, terminal_hits, examples, gc_runs, max_nodes,
+        errors, sum_depth_at_expand;
+} azg_selfplay_stats;
+int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out);
+/* drain finished-game examples: (board int8[S], pi f32[A], z f32[P], valids u8[A], q f32[P]) per record
+   (Coach.py:76-82).  Returns count copied (<= max_records), device->device on `stream` then synchronises. */
+int azg_selfplay_drain_examples(azg_forest* f, int max_records, int8_t* boards_dev, float* pi_dev, float* z_dev,
+                                uint8_t* valids_dev, float* q_dev, int32_t* meta_dev /* i32[n][4] = (global game
+                                stream, game index on it, ply, player) or NULL */, int* n_out, void* stream);
+
+/* ---- measurement helpers ---- */
+/* time `iters` back-to-back launches of kernel `which` (0 = select, 1 = expand_backup) with hipEvents on `stream`
+   (state is mutated like normal rounds); returns average milliseconds per launch. */
+int azg_forest_last_kernel_ms(azg_forest* f, int which, double* avg_ms, uint64_t* launches);
+int azg_forest_enable_timing(azg_forest* f, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,24 @@
+"""Integer hash-net of SURVEY.md Appendix C.3 as a batched torch module (bit-reproducible on any backend): the
+deterministic NeuralNet.predict used on both sides of the MCTS parity tests."""
+import torch
+
+
+class HashNetTorch:
+    def __init__(self, P):
+        self.P = P
+
+    def predict_batch(self, boards, valids):
+        T = boards.shape[0]
+        flat = boards.reshape(T, -1).to(torch.int64)
+        idx = torch.arange(1, flat.shape[1] + 1, dtype=torch.int64, device=flat.device)
+        s = (flat * idx).sum(dim=1)
+        h = torch.remainder(s * 2654435761, 1 << 32)
+        v0 = (h.to(torch.float64) / 2147483648.0 - 1.0).to(torch.float32)
+        others = (-v0 / float(self.P - 1)).to(torch.float32)
+        v = torch.stack([v0] + [others] * (self.P - 1), dim=1)
+        A = valids.shape[1]
+        a = torch.arange(A, dtype=torch.int64, device=flat.device)
+        w = valids.to(torch.int64) * (1 + torch.remainder(torch.remainder((h >> 8)[:, None] + 2654435761 * a[None, :],
+                                                                          1 << 32), 13))
+        pi = (w.to(torch.float64) / w.sum(dim=1, keepdim=True).to(torch.float64)).to(torch.float32)
+        return pi.contiguous(), v.contiguous()

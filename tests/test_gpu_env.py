@@ -1,0 +1,96 @@
+"""GPU parity: batched HIP env kernels (through the C-ABI) vs the reference's golden vectors and the pinned oracle.
+Bit-exact for valid-move masks, next states, next player, game_ended, scores, round, canonical form."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
+            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11)}
+
+
+def make_game(variant):
+    import torch
+    from azg_amd import games
+    name, v = VARIANTS[variant]
+    assert torch.cuda.is_available()
+    return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
+
+
+@pytest.mark.parametrize('variant', list(VARIANTS))
+def test_env_vs_golden(golden_dir, variant):
+    import torch
+    d = np.load(os.path.join(golden_dir, 'env_%s.npz' % variant))
+    g = make_game(variant)
+    dev = g.device
+    n = len(d['state'])
+    st = torch.from_numpy(d['state']).to(dev)
+    pl = torch.from_numpy(d['player'].astype(np.int32)).to(dev)
+    valid = g.valid_moves_batch(st, pl).cpu().numpy()
+    exp_valid = np.unpackbits(d['valid'], axis=1)[:, :g.A]
+    assert np.array_equal(valid, exp_valid)
+    seeds = torch.from_numpy(d['seed'].astype(np.int64)).to(dev)
+    act = torch.from_numpy(d['action'].astype(np.int32)).to(dev)
+    nxt_state, nxt_pl = g.next_state_batch(st, pl, act, seeds)
+    det = d['seed'] != 0
+    assert det.sum() > 50
+    assert np.array_equal(nxt_state.cpu().numpy()[det], d['next_state'][det])
+    assert np.array_equal(nxt_pl.cpu().numpy(), d['next_player'].astype(np.int32))
+    ns = torch.from_numpy(d['next_state']).to(dev)
+    npl = torch.from_numpy(d['next_player'].astype(np.int32)).to(dev)
+    ended, scores, rnd = g.game_ended_batch(ns, npl)
+    assert np.array_equal(ended.cpu().numpy(), d['ended'])
+    assert np.array_equal(scores.cpu().numpy(), d['score'].astype(np.int32))
+    assert np.array_equal(rnd.cpu().numpy(), d['round'].astype(np.int32))
+    canon = g.canonical_batch(ns, npl)
+    assert np.array_equal(canon.cpu().numpy(), d['canonical'])
+
+
+@pytest.mark.parametrize('variant', ['splendor2', 'splendor4', 'santorini11'])
+def test_true_random_moves_and_init_vs_oracle(golden_dir, variant):
+    """random_seed == 0 (Coach.py:71) and Board.init_game consume the shared counter-based RNG exactly like the oracle."""
+    import torch
+    import azg_oracle as O
+    d = np.load(os.path.join(golden_dir, 'env_%s.npz' % variant))
+    g = make_game(variant)
+    name, v = VARIANTS[variant]
+    og = O.OracleGame(O.SPLENDOR if name == 'splendor' else O.SANTORINI, v)
+    dev = g.device
+    n = min(len(d['state']), 400)
+    st = torch.from_numpy(d['state'][:n]).to(dev)
+    pl = torch.from_numpy(d['player'][:n].astype(np.int32)).to(dev)
+    act = torch.from_numpy(d['action'][:n].astype(np.int32)).to(dev)
+    seeds = torch.zeros(n, dtype=torch.int64, device=dev)
+    counters = torch.arange(n, dtype=torch.int64, device=dev) * 3
+    g.rng_seed = 1234
+    out, nxt = g.next_state_batch(st, pl, act, seeds, stream0=77, counters=counters)
+    out = out.cpu().numpy()
+    cnt = counters.cpu().numpy()
+    for i in range(n):
+        rng = og.rng(seed=1234, stream=77 + i)
+        rng.counter = 3 * i
+        exp, enp = og.getNextState(d['state'][i], int(d['player'][i]), int(d['action'][i]), 0, rng)
+        assert np.array_equal(out[i], exp.reshape(-1)), (variant, i)
+        assert int(cnt[i]) == rng.counter
+    boards = g.init_boards_batch(64, stream0=5).cpu().numpy()
+    for i in range(64):
+        exp = og.getInitBoard(og.rng(seed=1234, stream=5 + i)).reshape(-1)
+        assert np.array_equal(boards[i], exp), (variant, i)
+
+
+def test_game_py_surface():
+    """The Game.py-shaped single-board methods (what main.py / pit.py / Arena call) work end to end."""
+    g = make_game('splendor2')
+    b = g.getInitBoard()
+    assert b.shape == (56, 7) and b.dtype == np.int8
+    v = g.getValidMoves(b, 0)
+    assert v.dtype == bool and v.shape == (81,) and v[80]
+    a = int(np.flatnonzero(v)[0])
+    nb, npl = g.getNextState(b, 0, a, random_seed=31416)
+    assert npl == 1 and g.getRound(nb) == 1
+    assert not g.getGameEnded(nb, npl).any()
+    c = g.getCanonicalForm(nb, npl)
+    assert c.shape == b.shape
+    assert g.stringRepresentation(b) == b.tobytes()

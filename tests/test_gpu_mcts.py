@@ -1,0 +1,124 @@
+"""GPU parity: HIP forest (select / expand_backup / action_probs through the C-ABI) vs the reference's MCTS golden
+traces (Numba operand typing) and, node by node, vs the pinned oracle.  N exact; Q compared bit-exactly (tolerance of
+the task: 1e-5)."""
+import os
+
+import numpy as np
+import pytest
+
+from tools_args import MCTS_ARGS
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {'splendor2': ('splendor', 2), 'splendor4': ('splendor', 4), 'santorini1': ('santorini', 1),
+            'santorini11': ('santorini', 11)}
+
+
+class Args(dict):
+    __getattr__ = dict.get
+
+
+def make(variant):
+    from azg_amd import games
+    name, v = VARIANTS[variant]
+    return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
+
+
+@pytest.mark.parametrize('variant', list(VARIANTS))
+def test_mcts_traces_vs_golden(golden_dir, variant):
+    import torch
+    from azg_amd.mcts import BatchedMCTS
+    from hashnet import HashNetTorch
+    d = np.load(os.path.join(golden_dir, 'mcts_%s_numba.npz' % variant))
+    g = make(variant)
+    n_cases = len(d['case_sims'])
+    # group the cases by identical args so that each group runs as one batched forest
+    keys = {}
+    for i in range(n_cases):
+        k = (int(d['case_sims'][i]), float(d['case_cpuct'][i]), float(d['case_fpu'][i]), int(d['case_universes'][i]),
+             int(d['case_forced'][i]))
+        keys.setdefault(k, []).append(i)
+    for (sims, cpuct, fpu, uni, forced), idxs in keys.items():
+        args = Args(numMCTSSims=sims, cpuct=cpuct, fpu=fpu, universes=uni, forced_playouts=bool(forced),
+                    prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1, 1, 1])
+        T = len(idxs)
+        m = BatchedMCTS(g, HashNetTorch(g.P), args, T, node_capacity=sims + 64)
+        roots = torch.from_numpy(d['case_root'][idxs]).to(g.device)
+        probs, q, full = m.getActionProb(roots, temp=1, force_full_search=True)
+        rs = m.forest.root_stats()
+        for k, i in enumerate(idxs):
+            assert int(rs['Ns'][k]) == int(d['case_Ns'][i]), (variant, i)
+            assert np.array_equal(rs['Nsa'][k].cpu().numpy(), d['case_Nsa'][i].astype(np.int32)), (variant, i)
+            assert np.allclose(rs['Qsa'][k].cpu().numpy(), d['case_Qsa'][i], rtol=0, atol=1e-5)
+            assert np.array_equal(rs['Qsa'][k].cpu().numpy(), d['case_Qsa'][i]), 'Qsa not bit-exact'
+            assert float(rs['Qs'][k]) == float(d['case_Qs'][i])
+            assert int(rs['n_nodes'][k]) == int(d['case_nodes'][i])
+            assert np.array_equal(probs[k].cpu().numpy(), d['case_probs'][i])
+            assert np.array_equal(q[k].cpu().numpy(), d['case_q'][i])
+            # Ps of valid actions
+            va = d['case_Ps'][i] > 0
+            assert np.array_equal(rs['Ps'][k].cpu().numpy()[va], d['case_Ps'][i][va])
+        m.forest.close()
+
+
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini11'])
+def test_whole_tree_vs_oracle(variant):
+    """Every node of the HIP tree equals the oracle's node with the same state key (Ns, Qs, Nsa, Qsa, Ps, Es)."""
+    import torch
+    import azg_oracle as O
+    from azg_amd.mcts import BatchedMCTS
+    from hashnet import HashNetTorch
+    g = make(variant)
+    name, v = VARIANTS[variant]
+    og = O.OracleGame(O.SPLENDOR if name == 'splendor' else O.SANTORINI, v)
+    kw = dict(MCTS_ARGS[variant])
+    sims = 400
+    T = 8
+    roots = np.stack([og.getInitBoard(og.rng(seed=9, stream=i)).reshape(-1) for i in range(T)])
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1, 1, 1], **kw)
+    m = BatchedMCTS(g, HashNetTorch(g.P), args, T, node_capacity=sims + 64)
+    m.getActionProb(torch.from_numpy(roots).to(g.device), temp=1, force_full_search=True)
+    for t in range(T):
+        om = O.OracleMCTS(og, O.make_args(numMCTSSims=sims, **kw))
+        om.getActionProb(roots[t], temp=1, force_full_search=True)
+        tree = m.forest.dump_tree(t)
+        assert tree['n'] == om.num_nodes()
+        for i in range(tree['n']):
+            nd = om.node(tree['states'][i])
+            assert nd is not None
+            assert np.array_equal(nd['Es'], tree['Es'][i])
+            assert nd['has_policy'] == bool(tree['has_policy'][i])
+            if nd['has_policy']:
+                assert nd['Ns'] == int(tree['Ns'][i])
+                assert nd['Qs'] == tree['Qs'][i]
+                assert np.array_equal(nd['Nsa'].astype(np.int32), tree['Nsa'][i])
+                assert np.array_equal(nd['Qsa'], tree['Qsa'][i])
+                va = nd['Nsa'] >= 0
+                vmask = og.getValidMoves(tree['states'][i], 0)
+                assert np.array_equal(nd['Ps'][vmask], tree['Ps'][i][vmask])
+    m.forest.close()
+
+
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini1'])
+def test_tree_reuse_sequence_vs_golden(golden_dir, variant):
+    """Multi-move sequence of the golden set: tree reuse across moves and fast (non-full) searches."""
+    import torch
+    from azg_amd.mcts import BatchedMCTS
+    from hashnet import HashNetTorch
+    d = np.load(os.path.join(golden_dir, 'mcts_%s_numba.npz' % variant))
+    g = make(variant)
+    kw = dict(MCTS_ARGS[variant])
+    sims = int(d['seq_sims'])
+    args = Args(numMCTSSims=sims, prob_fullMCTS=0.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1, 1, 1], **kw)
+    n = len(d['seq_action'])
+    m = BatchedMCTS(g, HashNetTorch(g.P), args, 1, node_capacity=sims * n + 64)
+    for i in range(n):
+        root = torch.from_numpy(d['seq_canon'][i:i + 1]).to(g.device)
+        full = torch.tensor([1 if i % 3 != 2 else 0], dtype=torch.uint8, device=g.device)
+        probs, q, is_full = m.getActionProb(root, temp=1, full=full)
+        rs = m.forest.root_stats()
+        assert int(is_full[0]) == int(d['seq_full'][i])
+        assert int(rs['Ns'][0]) == int(d['seq_Ns'][i]), (variant, i)
+        assert np.array_equal(rs['Nsa'][0].cpu().numpy(), d['seq_Nsa'][i].astype(np.int32)), (variant, i)
+        assert np.array_equal(probs[0].cpu().numpy(), d['seq_probs'][i]), (variant, i)
+    m.forest.close()

@@ -1,0 +1,102 @@
+"""GPU parity: device-resident self-play (Coach.executeEpisode on the forest) vs the oracle's episode with the same
+counter-based RNG stream and the deterministic hash-net: same moves, same examples (board, pi, z, q)."""
+import numpy as np
+import pytest
+
+from tools_args import MCTS_ARGS
+
+pytestmark = pytest.mark.gpu
+
+
+class Args(dict):
+    __getattr__ = dict.get
+
+
+@pytest.mark.parametrize('variant,prob_full', [('splendor2', 1.0), ('splendor2', 0.5), ('santorini1', 1.0)])
+def test_selfplay_first_games_vs_oracle(variant, prob_full):
+    import torch
+    import azg_oracle as O
+    from azg_amd import games
+    from azg_amd.forest import Forest
+    from hashnet import HashNetTorch
+    name, v = ('splendor', 2) if variant == 'splendor2' else ('santorini', 1)
+    g = games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
+    og = O.OracleGame(O.SPLENDOR if name == 'splendor' else O.SANTORINI, v)
+    kw = dict(MCTS_ARGS[variant])
+    sims, T, seed, stream0 = 40, 16, 4242, 1000
+    temp = [1.25, 0.8, 1.0]
+    args = Args(numMCTSSims=sims, prob_fullMCTS=prob_full, ratio_fullMCTS=5, dirichletAlpha=0, temperature=temp,
+                tempThreshold=6, **kw)
+    f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=2048, max_examples=T * 300, rng_seed=seed,
+               stream0=stream0)
+    net = HashNetTorch(g.P)
+    f.selfplay_start()
+    shape = f.board_shape()
+    for rnd in range(200000):
+        f.select()
+        pi, vv = net.predict_batch(f.leaf_states.view((T,) + shape), f.leaf_valid.bool())
+        f.expand_backup(pi, vv)
+        f.selfplay_advance()
+        if rnd % 256 == 255:
+            st = f.stats()
+            assert st['errors'] == 0
+            if st['games'] >= 2 * T:
+                break
+    boards, pis, zs, valids, qs, meta = [x.cpu().numpy() for x in f.drain_examples()]
+    assert len(boards) > 0
+    for t in range(T):
+        o = O.run_episode(og, O.make_args(numMCTSSims=sims, prob_fullMCTS=prob_full, **kw), None, seed=seed,
+                          stream=stream0 + t, temp=(temp[0], temp[1]), tempThreshold=6.0)
+        sel = np.flatnonzero((meta[:, 0] == stream0 + t) & (meta[:, 1] == 0))
+        sel = sel[np.argsort(meta[sel, 2])]
+        full_plies = np.flatnonzero(o['full'])
+        assert len(sel) == len(full_plies), (t, len(sel), len(full_plies))
+        for k, ply in zip(sel, full_plies):
+            assert meta[k, 2] == ply and meta[k, 3] == o['player'][ply]
+            assert np.array_equal(boards[k], o['canonical'][ply]), (t, ply)
+            assert np.array_equal(pis[k], o['pi'][ply].astype(np.float32)), (t, ply)
+            assert np.array_equal(qs[k], o['q'][ply])
+            assert np.array_equal(zs[k], np.roll(o['result'], -int(o['player'][ply])))
+            assert np.array_equal(valids[k].astype(bool), og.getValidMoves(o['canonical'][ply], 0))
+    f.close()
+
+
+def test_selfplay_gc_keeps_results(tmp_path):
+    """A node arena too small for a whole game forces the round-based compaction; results must not change."""
+    import torch
+    import azg_oracle as O
+    from azg_amd import games
+    from azg_amd.forest import Forest
+    from hashnet import HashNetTorch
+    g = games.SplendorGame(2)
+    og = O.OracleGame(O.SPLENDOR, 2)
+    kw = dict(MCTS_ARGS['splendor2'])
+    sims, T, seed, stream0 = 60, 8, 7, 50
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1.0, 1.0, 1.0],
+                tempThreshold=6, **kw)
+    f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=400, max_examples=T * 200, rng_seed=seed, stream0=stream0)
+    net = HashNetTorch(g.P)
+    f.selfplay_start()
+    for rnd in range(200000):
+        f.select()
+        pi, vv = net.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid.bool())
+        f.expand_backup(pi, vv)
+        f.selfplay_advance()
+        if rnd % 256 == 255:
+            st = f.stats()
+            assert st['errors'] == 0, st
+            if st['games'] >= T:
+                break
+    st = f.stats()
+    assert st['gc_runs'] > 0
+    boards, pis, zs, valids, qs, meta = [x.cpu().numpy() for x in f.drain_examples()]
+    for t in range(T):
+        o = O.run_episode(og, O.make_args(numMCTSSims=sims, **kw), None, seed=seed, stream=stream0 + t,
+                          temp=(1.0, 1.0), tempThreshold=6.0)
+        sel = np.flatnonzero((meta[:, 0] == stream0 + t) & (meta[:, 1] == 0))
+        sel = sel[np.argsort(meta[sel, 2])]
+        assert len(sel) == o['plies']
+        for k, ply in zip(sel, range(o['plies'])):
+            assert np.array_equal(boards[k], o['canonical'][ply]), (t, ply)
+            assert np.array_equal(pis[k], o['pi'][ply].astype(np.float32)), (t, ply)
+    f.close()
