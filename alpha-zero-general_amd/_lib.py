@@ -36,7 +36,7 @@ EXPORTS = [
     'azg_env_next_state', 'azg_env_game_ended', 'azg_env_canonical', 'azg_env_init_boards', 'azg_forest_create',
     'azg_forest_destroy', 'azg_forest_device_bytes', 'azg_forest_reset', 'azg_forest_begin_search',
     'azg_forest_select', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
-    'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_selfplay_start', 'azg_selfplay_advance',
+    'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_forest_validate', 'azg_selfplay_start', 'azg_selfplay_advance',
     'azg_selfplay_stats_get', 'azg_selfplay_drain_examples', 'azg_forest_last_kernel_ms', 'azg_forest_enable_timing',
 ]
 
@@ -71,6 +71,7 @@ def lib():
     L.azg_forest_action_probs.argtypes = [vp, dbl, vp, vp, vp, vp]
     L.azg_forest_root_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.azg_forest_dump_tree.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.azg_forest_validate.argtypes = [vp, i]
     L.azg_selfplay_start.argtypes = [vp, vp, vp]
     L.azg_selfplay_advance.argtypes = [vp, vp]
     L.azg_selfplay_stats_get.argtypes = [vp, C.POINTER(SelfplayStats)]

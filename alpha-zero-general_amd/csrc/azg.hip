@@ -156,7 +156,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     D.U = cfg->universes > 0 ? cfg->universes : 1;
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
-                            : (size_t)D.cap * RowLayout(f->A < 56 ? f->A : 56, D.U).total;
+                            : (size_t)D.cap * RowLayout(f->A <= 200 ? (f->A < 64 ? f->A : 64) : 128, D.U).total;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     D.heap_units = (uint32_t)(heap_bytes / 16);
     D.universes = cfg->universes;
@@ -340,6 +340,55 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
     return n;
 }
 
+
+// Structural validation of every tree on the HOST (debug / tests): returns the number of violated invariants.
+extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
+    if (!f) return fail("null forest");
+    HIPCHK(hipDeviceSynchronize());
+    const ForestDev& D = f->dev;
+    const size_t heap_bytes = (size_t)D.heap_units * 16;
+    int bad = 0;
+    std::vector<NodeHdr> nh(D.cap);
+    std::vector<uint8_t> hp(heap_bytes);
+    std::vector<uint32_t> tab(D.HT);
+    for (int t = 0; t < D.T; t++) {
+        TreeHdr H;
+        HIPCHK(hipMemcpy(&H, D.hdr + t, sizeof(H), hipMemcpyDeviceToHost));
+        const uint32_t n = H.n_nodes;
+        if (n > (uint32_t)D.cap || H.heap_top > D.heap_units) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d n=%u heap_top=%u\n", t, n, H.heap_top); continue; }
+        if (H.root != AZG_NONE && H.root >= n) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d root=%u n=%u\n", t, H.root, n); }
+        HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)t * D.cap, sizeof(NodeHdr) * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)t * heap_bytes, (size_t)H.heap_top * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tab.data(), D.htab + (size_t)t * D.HT, sizeof(uint32_t) * D.HT, hipMemcpyDeviceToHost));
+        uint32_t expect_off = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (nh[i].flags & NF_TERMINAL) continue;
+            RowLayout L(nh[i].nv, D.U);
+            if (nh[i].row_off != expect_off) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d node=%u row_off=%u expect=%u nv=%u flags=%u\n", t, i, nh[i].row_off, expect_off, nh[i].nv, nh[i].flags); }
+            expect_off = nh[i].row_off + L.total / 16u;
+            if (expect_off > H.heap_top) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d node=%u row end %u > heap_top %u (n=%u root=%u gc=%u status=%u sim=%u err=%u ply=%u)\n", t, i, expect_off, H.heap_top, n, H.root, H.gc_runs, H.status, H.sim_idx, H.err, H.ply); break; }
+            if (!(nh[i].flags & NF_EXPANDED)) continue;
+            const uint8_t* row = hp.data() + (size_t)nh[i].row_off * 16;
+            const uint32_t* c = (const uint32_t*)(row + L.offC);
+            const uint16_t* ids = (const uint16_t*)(row + L.offI);
+            for (int j = 0; j < nh[i].nv * D.U; j++)
+                if (c[j] != AZG_NONE && (c[j] & AZG_CHILD_IDX_MASK) >= n) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d node=%u child[%d]=%08x n=%u\n", t, i, j, c[j], n); }
+            for (int j = 0; j < nh[i].nv; j++)
+                if (ids[j] >= f->A || (j && ids[j] <= ids[j - 1])) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d node=%u ids[%d]=%u\n", t, i, j, ids[j]); break; }
+        }
+        uint32_t cnt = 0;
+        for (int k = 0; k < D.HT; k++)
+            if (tab[k] != AZG_NONE) {
+                cnt++;
+                uint32_t id = tab[k] & AZG_IDX_MASK;
+                if (id >= n) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d htab[%d]=%08x n=%u\n", t, k, tab[k], n); }
+                else if ((uint32_t)(nh[id].hash >> 54) != (tab[k] >> AZG_IDX_BITS)) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d htab tag mismatch id=%u\n", t, id); }
+            }
+        if (cnt != n) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d htab entries %u != n %u\n", t, cnt, n); }
+    }
+    return bad;
+}
+
 // ---- self-play ------------------------------------------------------------------------------------------------------
 extern "C" int azg_selfplay_start(azg_forest* f, const int8_t* init_boards, void* stream) {
     if (!f) return fail("null forest");
@@ -370,6 +419,7 @@ extern "C" int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out) {
         out->examples += x.c_examples; out->gc_runs += x.gc_runs; out->errors |= x.err;
         out->sum_depth_at_expand += x.c_depth;
         if (x.max_nodes_seen > out->max_nodes) out->max_nodes = x.max_nodes_seen;
+        if (x.err & ERR_BAD_STATE) fprintf(stderr, "[azg] tree err=%u pad0=%u pad1=%u n_nodes=%u heap_top=%u\n", x.err, x.pad0, x.pad1, x.n_nodes, x.heap_top);
     }
     return 0;
 }

@@ -33,6 +33,9 @@ struct Rng {
     }
 };
 
+__device__ __forceinline__ uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);

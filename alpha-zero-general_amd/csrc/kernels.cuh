@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* 
     double* Qrow = (double*)(row + L.offQ);
     uint32_t* crow = (uint32_t*)(row + L.offC);
     for (int j = l; j < nv; j += 64) { Nrow[j] = 0u; Qrow[j] = AZG_NANQ; }                       // :40-41,152
-    for (int j = l; j < nv * F.U; j += 64) crow[j] = AZG_NONE;
+    for (int j = l; j < (int)((L.offI - L.offC) / 4u); j += 64) crow[j] = AZG_NONE;     // whole aligned section
     float v[G::P];
 #pragma unroll
     for (int p = 0; p < G::P; p++) v[p] = vin[(size_t)t * G::P + p];

@@ -15,6 +15,14 @@ __device__ __forceinline__ double temp_for_selfplay(const ForestDev& F, int n) {
     return te + (tb - te) * pow(0.5, (double)n / hl);
 }
 
+__device__ __forceinline__ uint32_t remap_child(const uint32_t* map, uint32_t w, bool in_range, uint32_t n) {
+    if (!in_range || w == AZG_NONE) return w;
+    const uint32_t idx = w & AZG_CHILD_IDX_MASK;
+    if (idx >= n) return AZG_NONE;
+    const uint32_t m = map[idx];
+    return (m == AZG_NONE) ? AZG_NONE : ((w & ~AZG_CHILD_IDX_MASK) | m);
+}
+
 // Drop every node that can no longer be reached: round < root_round (the move counter is part of the state, so such
 // states cannot recur).  Equivalent to -- and stricter in memory than -- the reference's lazy clean-up MCTS.py:86-91,
 // which removes nodes with round < r-5 every >20 rounds.  In-place sliding compaction by the tree's own wave:
@@ -44,48 +52,55 @@ __device__ void gc_tree(const ForestDev& F, int t, TreeHdr& H, int min_round) {
     }
     __threadfence_block();
     wave_sync();
-    // pass 2 (sequential over nodes, wave-parallel inside a node; dst <= src so forward copies are safe)
+    // pass 2 (sequential over nodes, wave-parallel inside a node; dst <= src so forward copies are safe).
+    // Every control value is made explicitly wave-uniform (readfirstlane) so that the barriers below sit in
+    // provably uniform control flow.
     uint32_t heap_top = 0;
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t ni = map[i];
-        if (ni == AZG_NONE) continue;
-        NodeHdr nh = *FR::nhdr(F, t, i);
-        const bool has_row = nh.row_off != AZG_NONE;
-        const RowLayout L(nh.nv, F.U);
-        const uint32_t units = has_row ? L.total / 16u : 0u;
-        if (has_row) {
-            const uint4* src = (const uint4*)(hp + (size_t)nh.row_off * 16u);
-            uint4* dst = (uint4*)(hp + (size_t)heap_top * 16u);
-            const uint32_t c0 = L.offC / 16u, c1 = L.offI / 16u;     // child section in 16-byte units
-            for (uint32_t base = 0; base < units; base += 64) {
-                uint32_t k = base + l;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (k < units) {
-                    v = src[k];
-                    if (k >= c0 && k < c1) {
-                        uint32_t* w = (uint32_t*)&v;
-#pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            if (w[q] != AZG_NONE) {
-                                uint32_t m = map[w[q] & AZG_CHILD_IDX_MASK];
-                                w[q] = (m == AZG_NONE) ? AZG_NONE : ((w[q] & ~AZG_CHILD_IDX_MASK) | m);
-                            }
+        const uint32_t ni = uni_u32(map[i]);
+        if (ni != AZG_NONE) {
+            NodeHdr nh = *FR::nhdr(F, t, i);
+            const uint32_t old_off = uni_u32(nh.row_off);
+            const uint32_t nv = uni_u32((uint32_t)nh.nv);
+            const bool has_row = old_off != AZG_NONE;
+            const RowLayout L((int)nv, F.U);
+            const uint32_t units = has_row ? L.total / 16u : 0u;
+            if (has_row) {
+                const uint4* src = (const uint4*)(hp + (size_t)old_off * 16u);
+                uint4* dst = (uint4*)(hp + (size_t)heap_top * 16u);
+                const uint32_t c0 = L.offC / 16u, c1 = L.offI / 16u;     // child section in 16-byte units
+                const uint32_t n_child = nv * (uint32_t)F.U;
+                for (uint32_t base = 0; base < units; base += 64) {
+                    const uint32_t k = base + (uint32_t)l;
+                    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+                    if (k < units) {
+                        const uint4 v = src[k];
+                        w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
+                        if (k >= c0 && k < c1) {
+                            const uint32_t e = (k - c0) * 4u;
+                            w0 = remap_child(map, w0, e + 0u < n_child, n);
+                            w1 = remap_child(map, w1, e + 1u < n_child, n);
+                            w2 = remap_child(map, w2, e + 2u < n_child, n);
+                            w3 = remap_child(map, w3, e + 3u < n_child, n);
+                        }
                     }
+                    wave_sync();                   // every lane has read its chunk before anyone overwrites it
+                    if (k < units) dst[k] = make_uint4(w0, w1, w2, w3);
+                    wave_sync();
                 }
-                wave_sync();                       // every lane has read its chunk before anyone overwrites it
-                if (k < units) dst[k] = v;
+                nh.row_off = heap_top;
             }
-            nh.row_off = heap_top;
+            if (ni != i) {
+                const uint32_t* ssrc = (const uint32_t*)FR::nstate(F, t, i);
+                uint32_t* sdst = (uint32_t*)FR::nstate(F, t, ni);
+                for (int k = l; k < FR::SPW; k += 64) sdst[k] = ssrc[k];
+            }
+            if (l == 0) *FR::nhdr(F, t, ni) = nh;
+            heap_top += units;
         }
-        if (ni != i) {
-            const uint32_t* ssrc = (const uint32_t*)FR::nstate(F, t, i);
-            uint32_t* sdst = (uint32_t*)FR::nstate(F, t, ni);
-            for (int k = l; k < FR::SPW; k += 64) sdst[k] = ssrc[k];
-        }
-        if (l == 0) *FR::nhdr(F, t, ni) = nh;
-        heap_top += units;
         wave_sync();
     }
+    heap_top = uni_u32(heap_top);
     if (H.root != AZG_NONE) H.root = map[H.root];
     // pass 3
     wave_sync();

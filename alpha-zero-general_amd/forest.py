@@ -133,6 +133,9 @@ class Forest:
         return dict(n=n, states=states[:n], Ns=Ns[:n], Qs=Qs[:n], Es=Es[:n], Nsa=Nsa[:n], Qsa=Qsa[:n], Ps=Ps[:n],
                     has_policy=hp[:n].astype(bool))
 
+    def validate(self, verbose=True):
+        return check(lib().azg_forest_validate(self.h, int(verbose)))
+
     # ---- self-play ----
     def selfplay_start(self, init_boards=None):
         ib = None if init_boards is None else init_boards.reshape(self.T, self.S).contiguous()

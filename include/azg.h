@@ -125,6 +125,9 @@ int azg_forest_root_stats(azg_forest* f, int32_t* Ns_dev, float* Qs_dev, int32_t
 int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8_t* states, int32_t* Ns, float* Qs, float* Es,
                          int32_t* Nsa, double* Qsa, float* Ps, uint8_t* has_policy);
 
+/* debug / tests: check the structural invariants of every tree on the host; returns the number of violations */
+int azg_forest_validate(azg_forest* f, int verbose);
+
 /* --- self-play mode: Coach.executeEpisode on device (Coach.py:37-84) --- */
 /* start one game per tree (Board.init_game or the given init boards int8[T][S]) */
 int azg_selfplay_start(azg_forest* f, const int8_t* init_boards_dev /* or NULL */, void* stream);

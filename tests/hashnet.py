@@ -14,7 +14,7 @@ class HashNetTorch:
         s = (flat * idx).sum(dim=1)
         h = torch.remainder(s * 2654435761, 1 << 32)
         v0 = (h.to(torch.float64) / 2147483648.0 - 1.0).to(torch.float32)
-        others = (-v0 / float(self.P - 1)).to(torch.float32)
+        others = (-v0.to(torch.float64) / float(self.P - 1)).to(torch.float32)   # f64 divide: torch's f32 scalar divide multiplies by a reciprocal
         v = torch.stack([v0] + [others] * (self.P - 1), dim=1)
         A = valids.shape[1]
         a = torch.arange(A, dtype=torch.int64, device=flat.device)
