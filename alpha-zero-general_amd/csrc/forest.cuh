@@ -285,8 +285,12 @@ struct Forest {
         }
     }
 
-    // softmax(Ps, T) + applyDirNoise + normalise on a DENSE policy in LDS (MCTS.py:147-150,156-160,187-197,255-261)
-    __device__ static void root_noise_dense(float* dense, const uint64_t* mask, double temp_root, const double* noise) {
+    // softmax(Ps, T) + applyDirNoise + normalise on a DENSE policy in LDS (MCTS.py:147-150,156-160,187-197,255-261).
+    // `noise` holds, for this tree, either a Dirichlet sample over the valid actions (normalised == true; parity tests
+    // inject the reference's sample) or iid Gamma(alpha, 1) variates that are normalised over the first n_valid
+    // entries here (Dirichlet(alpha) == normalised Gammas; rng.dirichlet MCTS.py:189).
+    __device__ static void root_noise_dense(float* dense, const uint64_t* mask, double temp_root, const double* noise,
+                                            bool normalised) {
         int l = lane_id();
         if (temp_root != 1.0) {
             // Numba typing: float32 array ** float64 -> float64 array, normalised in f64, cast to f32
@@ -297,6 +301,17 @@ struct Forest {
             for (int i = l; i < A; i += 64) dense[i] = (float)(pow((double)dense[i], 1.0 / temp_root) / s);
             wave_sync();
         }
+        int nv = 0;
+#pragma unroll
+        for (int k = 0; k < AW; k++) nv += __popcll(mask[k]);
+        double gsum = 1.0;
+        if (!normalised) {
+            gsum = 0.0;
+            for (int r = l; r < nv; r += 64) gsum += noise[r];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) gsum += shfl_xor_f64(gsum, m);
+            if (!(gsum > 0.0)) gsum = 1.0;
+        }
         // dir_values are indexed by the rank of the valid action
         for (int i = l; i < A; i += 64) {
             uint64_t w = mask[i >> 6];
@@ -304,7 +319,8 @@ struct Forest {
                 int rank = __popcll(w & ((1ull << (i & 63)) - 1ull));
                 for (int k = 0; k < (i >> 6); k++) rank += __popcll(mask[k]);
                 float a = 0.75f * dense[i];
-                dense[i] = (float)((double)a + 0.25 * noise[rank]);
+                double d = normalised ? noise[rank] : noise[rank] / gsum;
+                dense[i] = (float)((double)a + 0.25 * d);
             }
         }
         wave_sync();

@@ -173,7 +173,7 @@ __device__ int pick_action(const ForestDev& F, int t, const NodeHdr& nh, const u
 // Apply root Dirichlet noise to the existing root row (MCTS.py:156-160): scatter to dense, transform, gather back.
 template <class G>
 __device__ void noise_existing_root(const ForestDev& F, uint8_t* row, const RowLayout& L, int nv, float* dense,
-                                    uint64_t* mask, const double* noise) {
+                                    uint64_t* mask, const double* noise, bool normalised) {
     float* Prow = (float*)row;
     const uint16_t* ids = (const uint16_t*)(row + L.offI);
     for (int i = lane_id(); i < G::A; i += 64) dense[i] = 0.f;
@@ -183,7 +183,7 @@ __device__ void noise_existing_root(const ForestDev& F, uint8_t* row, const RowL
     if (lane_id() == 0)
         for (int j = 0; j < nv; j++) mask[ids[j] >> 6] |= 1ull << (ids[j] & 63);
     wave_sync();
-    Forest<G>::root_noise_dense(dense, mask, F.temp_root, noise);
+    Forest<G>::root_noise_dense(dense, mask, F.temp_root, noise, normalised);
     for (int j = lane_id(); j < nv; j += 64) Prow[j] = dense[ids[j]];
 }
 
@@ -247,7 +247,8 @@ __global__ __launch_bounds__(64) void k_select(ForestDev F, int8_t* leaf_states,
             const RowLayout L(nh.nv, F.U);
             uint8_t* row = hp + (size_t)nh.row_off * 16u;
             if (depth == 0 && dir_now)
-                noise_existing_root<G>(F, row, L, nh.nv, dense, sm.mask, root_noise + (size_t)t * noise_stride);
+                noise_existing_root<G>(F, row, L, nh.nv, dense, sm.mask,
+                                       root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride), noise_stride < 0);
             const int j = pick_action<G>(F, t, nh, row, L, depth == 0 && H.forced, H.sim_idx);
             H.c_levels++;
             H.c_sumvalid += nh.nv;
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* 
         if (l == 0)
             for (int j = 0; j < nv; j++) mask[ids[j] >> 6] |= 1ull << (ids[j] & 63);
         wave_sync();
-        FR::root_noise_dense(dense, mask, F.temp_root, root_noise + (size_t)t * noise_stride);
+        FR::root_noise_dense(dense, mask, F.temp_root, root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride),
+                             noise_stride < 0);
         float* Prow = (float*)row;
         for (int j = l; j < nv; j += 64) Prow[j] = dense[ids[j]];
     } else {

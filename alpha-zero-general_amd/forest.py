@@ -82,15 +82,22 @@ class Forest:
         self._keep = (roots, full)
         check(lib().azg_forest_begin_search(self.h, _ptr(roots), _ptr(full), _stream()))
 
-    def select(self, noise=None):
-        check(lib().azg_forest_select(self.h, _ptr(self.leaf_states), _ptr(self.leaf_valid), _ptr(self.needs_eval),
-                                      _ptr(noise), 0 if noise is None else noise.shape[1], _stream()))
+    @staticmethod
+    def _stride(noise, normalised):
+        if noise is None:
+            return 0
+        assert noise.dtype == torch.float64 and noise.is_contiguous()
+        return -noise.shape[1] if normalised else noise.shape[1]
 
-    def expand_backup(self, pi, v, noise=None):
+    def select(self, noise=None, normalised=False):
+        check(lib().azg_forest_select(self.h, _ptr(self.leaf_states), _ptr(self.leaf_valid), _ptr(self.needs_eval),
+                                      _ptr(noise), self._stride(noise, normalised), _stream()))
+
+    def expand_backup(self, pi, v, noise=None, normalised=False):
         assert pi.dtype == torch.float32 and v.dtype == torch.float32 and pi.is_contiguous() and v.is_contiguous()
         assert pi.shape == (self.T, self.A) and v.shape == (self.T, self.P)
-        check(lib().azg_forest_expand_backup(self.h, _ptr(pi), _ptr(v), _ptr(noise),
-                                             0 if noise is None else noise.shape[1], _stream()))
+        check(lib().azg_forest_expand_backup(self.h, _ptr(pi), _ptr(v), _ptr(noise), self._stride(noise, normalised),
+                                             _stream()))
 
     def active(self):
         n = C.c_int()

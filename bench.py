@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play env-steps/sec @ numMCTSSims=800, Splendor-2p, T concurrent games per MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by torch.distributed.run, one rank per GPU).
+A "step" is one lock-step round of the hot path over the batch of T games:
+    select (HIP) -> NeuralNet.predict_batch (PyTorch-ROCm) -> expand_backup (HIP) -> selfplay_advance (HIP)
+i.e. one MCTS simulation for every concurrent game, incl. the env steps, root noise, move sampling and example
+recording that fall into that round.  Every ply is a full numMCTSSims search (prob_fullMCTS=1).
+value = env-steps/sec = (simulations completed in the timed region / numMCTSSims) / seconds, summed over ranks; the
+integer number of plies that completed inside the region is reported next to it.
+
+Extra objects on the JSON line: "roofline" (select+backup kernels, HIP events on the launch stream, algorithmic bytes
+from live engine counters, SURVEY.md §8d formula) and "cpu_baseline" (the C oracle + PyTorch-CPU net on one host core,
+bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+class Args(dict):
+    __getattr__ = dict.get
+
+
+# MCTS / self-play settings embedded in the reference's splendor/pretrained_2players.pt
+SPLENDOR2_ARGS = dict(numMCTSSims=800, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, dirichletAlpha=0.3,
+                      temperature=[1.25, 0.8, 1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0)
+WEIGHTS = os.path.join(ROOT, 'tests', 'golden', 'weights_splendor2_v80.npz')
+HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes_per_sim(S, A, P, d, vbar, e):
+    """B_sim = d*(ceil(A/8) + 12*v + 8 + S + 16) + e*(S + ceil(A/8) + 12*v + 8 + 4A + 4P)"""
+    mask = (A + 7) // 8
+    return d * (mask + 12.0 * vbar + 8 + S + 16) + e * (S + mask + 12.0 * vbar + 8 + 4 * A + 4 * P)
+
+
+def cpu_baseline(sims, seconds=15.0, n_par=8):
+    """The oracle (C restatement of MCTS.py + SplendorLogicNumba, pinned against the reference) with the PyTorch-CPU net,
+    one host thread, leaves batched over n_par games like --parallel-inferences 8 (Coach.py:117-144)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import azg_oracle as O
+    from azg_amd.nnet import SplendorV80
+    torch.set_num_threads(1)
+    og = O.OracleGame(O.SPLENDOR, 2)
+    net = SplendorV80.from_npz(WEIGHTS, device='cpu') if os.path.exists(WEIGHTS) else SplendorV80.random_init(device='cpu')
+    kw = dict(cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True)
+    trees = [O.OracleMCTS(og, O.make_args(numMCTSSims=sims, **kw)) for _ in range(n_par)]
+    boards = [og.getInitBoard(og.rng(seed=99, stream=i)) for i in range(n_par)]
+    players = [0] * n_par
+    rngs = [og.rng(seed=99, stream=1000 + i) for i in range(n_par)]
+    for i, t in enumerate(trees):
+        t.search_begin(og.getCanonicalForm(boards[i], players[i]).reshape(-1), True)
+    plies = 0
+    sims_done = 0
+    t0 = time.perf_counter()
+    lb = np.zeros((n_par, og.S), dtype=np.int8)
+    lv = np.zeros((n_par, og.A), dtype=np.uint8)
+    while time.perf_counter() - t0 < seconds:
+        need = []
+        for i, t in enumerate(trees):
+            while True:
+                if t.search_done():
+                    probs, q, _ = t.search_end(1.0)
+                    a = int(np.argmax(probs))
+                    boards[i], players[i] = og.getNextState(boards[i], players[i], a, 0, rngs[i])
+                    plies += 1
+                    if og.getGameEnded(boards[i], players[i]).any():
+                        boards[i], players[i] = og.getInitBoard(rngs[i]), 0
+                        t = trees[i] = O.OracleMCTS(og, O.make_args(numMCTSSims=sims, **kw))
+                    t.search_begin(og.getCanonicalForm(boards[i], players[i]).reshape(-1), True)
+                r = t.sim_begin()
+                sims_done += 1
+                if r == 1:
+                    b, v = t.leaf()
+                    lb[i], lv[i] = b, v
+                    need.append(i)
+                    break
+        pi, vv = net.predict_batch(torch.from_numpy(lb), torch.from_numpy(lv))
+        pi, vv = pi.numpy(), vv.numpy()
+        for i in need:
+            trees[i].sim_finish(pi[i], vv[i])
+    dt = time.perf_counter() - t0
+    return dict(value=sims_done / sims / dt, unit='env-steps/sec', cores=1, kind='port',
+                sample='%d concurrent games, %.0f s wall, %d sims (=%d plies completed) of the same Splendor-2p/800-sim '
+                       'workload; C oracle tree+env, PyTorch-CPU V80 net batched over %d leaves, 1 thread'
+                       % (n_par, dt, sims_done, plies, n_par),
+                sims_per_sec=sims_done / dt, host_cores_available=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=1700)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--games', type=int, default=4096, help='concurrent games per GPU')
+    ap.add_argument('--sims', type=int, default=800)
+    ap.add_argument('--node-capacity', type=int, default=0)
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--net-dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--roofline-rounds', type=int, default=300)
+    ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'r01_traffic.json'))
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    assert world == a.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
+    torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
+
+    from azg_amd import games
+    from azg_amd.nnet import SplendorV80
+    from azg_amd.selfplay import SelfPlayEngine, gather_examples
+
+    T = a.games
+    margs = Args(SPLENDOR2_ARGS)
+    margs['numMCTSSims'] = a.sims
+    game = games.SplendorGame(2, device=dev)
+    dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[a.net_dtype]
+    pretrained = os.path.exists(WEIGHTS)
+    net = SplendorV80.from_npz(WEIGHTS, device=dev, dtype=dtype) if pretrained else \
+        SplendorV80.random_init(device=dev, dtype=dtype)
+    cap = a.node_capacity or max(2048, 10 * a.sims + 512)
+    eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
+                         stream0=rank * T, use_graph=not a.no_graph)
+    eng.start()
+    eng.run(a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    s0 = eng.stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(a.steps)
+    ex = eng.drain_examples()
+    n_local_examples = int(ex[0].shape[0])
+    if world > 1:
+        ex = gather_examples(list(ex))           # the one RCCL collective of the path (episode-end example gather)
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    s1 = eng.stats()
+    dt = t1 - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    d_sims = s1['sims'] - s0['sims']
+    d_plies = s1['plies'] - s0['plies']
+    loc = torch.tensor([d_sims, d_plies, s1['errors'], s1['games'] - s0['games'], n_local_examples], dtype=torch.int64,
+                       device=dev)
+    if world > 1:
+        dist.all_reduce(loc, op=dist.ReduceOp.SUM)
+    tot_sims, tot_plies, errs, tot_games, tot_examples = [int(x) for x in loc.tolist()]
+    value = tot_sims / a.sims / dt
+
+    # ---- roofline segment: eager rounds with HIP events around the select / expand_backup launches ----
+    roof = None
+    f = eng.forest
+    r0 = eng.stats()
+    f.enable_timing(True)
+    for _ in range(a.roofline_rounds):
+        eng._round()
+    torch.cuda.synchronize()
+    ms_sel, n_sel = f.kernel_ms(0)
+    ms_exp, n_exp = f.kernel_ms(1)
+    f.enable_timing(False)
+    r1 = eng.stats()
+    rs = r1['sims'] - r0['sims']
+    if rs > 0 and n_sel > 0:
+        d = (r1['levels'] - r0['levels']) / rs
+        e = (r1['expansions'] - r0['expansions']) / rs
+        vbar = (r1['sum_valid_visited'] - r0['sum_valid_visited']) / max(1, r1['levels'] - r0['levels'])
+        b_sim = algorithmic_bytes_per_sim(f.S, f.A, f.P, d, vbar, e)
+        sims_per_launch = rs / n_sel
+        bytes_per_launch = b_sim * sims_per_launch
+        pair_ms = ms_sel + ms_exp
+        achieved = bytes_per_launch / (pair_ms * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(a.traffic_json):
+            try:
+                tj = json.load(open(a.traffic_json))
+                if tj.get('games') == T and tj.get('sims') == a.sims:
+                    traffic = tj.get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        roof = dict(bound='hbm', kernels=['k_select', 'k_expand_backup'], achieved=achieved, peak=HBM_PEAK_GBS,
+                    unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                    bytes_per_sim=b_sim, sims_per_launch=sims_per_launch, bytes_per_launch=bytes_per_launch,
+                    select_ms=ms_sel, expand_backup_ms=ms_exp, launches=int(n_sel),
+                    d_levels_per_sim=d, v_valid_per_level=vbar, e_expansions_per_sim=e)
+
+    out = dict(metric='self-play env-steps/sec @ numMCTSSims=%d, Splendor-2p' % a.sims, value=value,
+               unit='env-steps/sec', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
+               higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
+               data='synthetic (Board.init_game boards from the counter RNG; net weights: %s)'
+                    % ('reference pretrained_2players.pt converted' if pretrained else 'random-init V80'),
+               config=dict(workload='Splendor 2p, numMCTSSims=%d, %d concurrent self-play games per GPU, V80 net %s, '
+                                    'args of pretrained_2players.pt (cpuct 0.8 fpu 0.0593 universes 3 forced playouts '
+                                    'dirichlet 0.3), every ply a full search' % (a.sims, T, a.net_dtype),
+                           games_per_gpu=T, parallelism='games sharded x%d, 1 RCCL example all_gather at episode end'
+                                                        % world if world > 1 else 'single GPU',
+                           hip_graph=eng.graph is not None),
+               sims_per_sec=tot_sims / dt, plies_completed=tot_plies, games_finished=tot_games,
+               examples_gathered=tot_examples if world == 1 else int(ex[0].shape[0]), engine_errors=errs,
+               forest_bytes_per_gpu=f.device_bytes, max_nodes_per_tree=s1['max_nodes'], gc_runs=s1['gc_runs'])
+    if roof:
+        out['roofline'] = roof
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(a.sims, a.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -105,7 +105,11 @@ int azg_forest_begin_search(azg_forest* f, const int8_t* roots_dev, const uint8_
    its numMCTSSims.  Writes the leaf batch for NeuralNet.predict (NeuralNet.py:32-43):
    leaf_states int8[T][S], leaf_valid u8[T][A], needs_eval u8[T].   MCTS.search :105-175 */
 int azg_forest_select(azg_forest* f, int8_t* leaf_states_dev, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev,
-                      const double* root_noise_dev /* f64[T][noise_stride] or NULL */, int noise_stride, void* stream);
+                      const double* root_noise_dev /* f64[T][|noise_stride|] or NULL */, int noise_stride, void* stream);
+/* root noise (MCTS.py:64,187-197): applied on simulation 0 of full searches when root_noise_dev != NULL.
+   noise_stride > 0: rows hold iid Gamma(dirichletAlpha,1) variates, normalised on device over the root's n_valid
+   first entries (== rng.dirichlet([alpha]*n_valid)); noise_stride < 0: rows already hold a Dirichlet sample over the
+   valid actions (parity tests inject the reference's own sample), stride = -noise_stride. */
 /* part 2: store (Ps, v) on the pending leaves and back the values up (MCTS.py:147-154,176-183).
    pi f32[T][A] are PROBABILITIES (exp of the net's log-softmax, GenericNNetWrapper.py:107,119), v f32[T][P]. */
 int azg_forest_expand_backup(azg_forest* f, const float* pi_dev, const float* v_dev, const double* root_noise_dev,
