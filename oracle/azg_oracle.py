@@ -64,6 +64,7 @@ def lib():
         L.azo_get_round.argtypes = [C.POINTER(Game), i8p]
         L.azo_get_score.argtypes = [C.POINTER(Game), i8p, C.c_int]
         L.azo_init_board.argtypes = [C.POINTER(Game), i8p, C.POINTER(Rng)]
+        L.azo_known_start.argtypes = [C.POINTER(Game), i8p, C.c_int, C.c_int]
         L.azo_canonical.argtypes = [C.POINTER(Game), i8p, C.c_int, i8p]
         L.azo_symmetries.argtypes = [C.POINTER(Game), i8p, f32p, u8p, i8p, f32p, u8p, C.c_int]
         L.azo_rng_u01.restype = C.c_double
@@ -154,6 +155,11 @@ class OracleGame:
         st = np.zeros(self.S, dtype=np.int8)
         lib().azo_init_board(C.byref(self.g), _p(st), C.byref(rng))
         return st.reshape(self.shape)
+
+    def known_start(self, a=0, b=0):
+        st = np.zeros(self.S, dtype=np.int8)
+        lib().azo_known_start(C.byref(self.g), _p(st), a, b)
+        return st
 
     def getValidMoves(self, board, player):
         b = np.ascontiguousarray(board, dtype=np.int8)

@@ -85,4 +85,11 @@ int azo_symmetries(const azo_game* g, const int8_t* s, const float* pi, const ui
                                  : santorini_symmetries(g, s, pi, valids, os, op, ov, max_sym);
 }
 
+void splendor_known_start(const azo_game*, int8_t*);
+void santorini_known_start(const azo_game*, int8_t*, int, int);
+void azo_known_start(const azo_game* g, int8_t* s, int a, int b) {
+    if (g->id == AZO_SPLENDOR) splendor_known_start(g, s);
+    else santorini_known_start(g, s, a, b);
+}
+
 const char* azo_version(void) { return "azg-oracle r1"; }

@@ -475,3 +475,12 @@ int santorini_symmetries(const azo_game* g, const int8_t* st, const float* pi, c
     k++;
     return k;
 }
+
+/* RNG-free start state of SURVEY.md Appendix C.1: the INIT_METHOD == 0 layout (:105-106) with gods g0 / g1 */
+void santorini_known_start(const azo_game* g, int8_t* st, int g0, int g1) {
+    const int NB = g->variant;
+    memset(st, 0, 75);
+    W(st, 2 * 5 + 1) = 1; W(st, 2 * 5 + 3) = 2; W(st, 1 * 5 + 2) = -1; W(st, 3 * 5 + 2) = -2;
+    GP(st, g0 + NB * 0) = 64;
+    GP(st, g1 + NB * 1) = 64;
+}

@@ -356,3 +356,23 @@ int splendor_symmetries(const azo_game* g, const int8_t* st, const float* pi, co
 #undef EMIT_BASE
     return k;
 }
+
+/* RNG-free start state of SURVEY.md Appendix C.1 (built through the Board API, bypassing init_game's RNG) */
+void splendor_known_start(const azo_game* g, int8_t* st) {
+    int n = g->P;
+    memset(st, 0, (size_t)g->S);
+    int8_t* bank = ROW(st, 0);
+    int gems_in_play = n == 2 ? 4 : (n == 3 ? 5 : 7);
+    for (int c = 0; c < 5; c++) bank[c] = (int8_t)gems_in_play;
+    bank[GOLD] = 5;
+    for (int t = 0; t < 3; t++) {
+        int len = SPL_DECK_LEN[t];
+        for (int c = 0; c < 5; c++) {
+            ROW(st, 25 + 2 * t)[c] = (int8_t)len;
+            ROW(st, 26 + 2 * t)[c] = (int8_t)(uint8_t)(0xFF00u >> len);
+        }
+    }
+    for (int t = 0; t < 3; t++)
+        for (int i = 0; i < 4; i++) fill_new_card(st, t, i, 31416, NULL);
+    for (int i = 0; i < n + 1; i++) memcpy(ROW(st, 31 + i), SPL_NOBLES[i], COLS);
+}

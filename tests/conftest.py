@@ -9,7 +9,7 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+GOLDEN = os.environ.get('AZG_GOLDEN_DIR', os.path.join(ROOT, 'tests', 'golden'))
 
 
 def pytest_configure(config):

@@ -1,0 +1,78 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/azg.h declares (no compute without a GPU);
+the product fails loudly without a GPU; the multi-GPU example gather works (world_size 2, gloo)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from azg_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, 'include', 'azg.h')).read()
+    declared = set(re.findall(r'\b(azg_[a-z_0-9]+)\s*\(', hdr))
+    assert len(declared) >= 25
+    for sym in sorted(declared):
+        assert hasattr(L, sym), 'libazg_hip.so does not export %s' % sym
+    assert set(_lib.EXPORTS) <= declared
+    assert b'gfx950' in L.azg_version()
+    S, A, P, rows, cols = _lib.game_info(_lib.SPLENDOR, 2)
+    assert (S, A, P, rows, cols) == (392, 81, 2, 56, 7)
+    assert _lib.game_info(_lib.SPLENDOR, 4)[0] == 616
+    assert _lib.game_info(_lib.SANTORINI, 11)[:3] == (75, 1782, 2)
+    assert _lib.game_info(_lib.SANTORINI, 1)[:3] == (75, 162, 2)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_product_fails_loudly_without_gpu():
+    from azg_amd import games, _lib
+    with pytest.raises(_lib.AzgError):
+        games.SplendorGame(2)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'alpha-zero-general_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.cuh', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'azg_oracle' not in src and 'libazg_oracle' not in src, f
+
+
+WORKER = r'''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from azg_amd.selfplay import gather_examples
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+n = 3 + 2 * rank                                   # ragged: rank 0 has 3 records, rank 1 has 5
+boards = torch.full((n, 392), rank + 1, dtype=torch.int8)
+pi = torch.arange(n * 81, dtype=torch.float32).reshape(n, 81) + 1000 * rank
+z = torch.full((n, 2), float(rank))
+out = gather_examples([boards, pi, z])
+assert out[0].shape == (8, 392) and out[1].shape == (8, 81) and out[2].shape == (8, 2)
+assert (out[0][:3] == 1).all() and (out[0][3:] == 2).all()
+assert torch.equal(out[1][3:], torch.arange(5 * 81, dtype=torch.float32).reshape(5, 81) + 1000)
+empty = gather_examples([torch.zeros((0 if rank == 0 else 2, 4), dtype=torch.float32)])
+assert empty[0].shape == (2, 4)
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_example_gather_world2_gloo(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29641')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29641', str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'rank 0 ok' in r.stdout + r.stderr and 'rank 1 ok' in r.stdout + r.stderr
