@@ -10,6 +10,7 @@
 #include "game_splendor.cuh"
 #include "game_santorini.cuh"
 #include "selfplay.cuh"
+#include "nn_kernels.cuh"
 
 using namespace azg;
 
@@ -480,5 +481,134 @@ extern "C" int azg_forest_last_kernel_ms(azg_forest* f, int which, double* avg_m
     f->ev_used[which] = 0;
     if (avg_ms) *avg_ms = f->launches[which] ? f->ms_total[which] / (double)f->launches[which] : 0.0;
     if (launches) *launches = f->launches[which];
+    return 0;
+}
+
+// ---- policy/value net building blocks (NeuralNet.predict, GenericNNetWrapper.py:94-120; V80: SplendorNNet.py:262-283) ----
+template <int NT, int KSPLIT, int NCH>
+static int launch_linear(const float* A, int lda, const float* Wp, const float* bias, const float* R, int ldr,
+                         const float* rowscale, int rpg, float* out, int ldc, int M, int K, int Kp, int N, int act,
+                         hipStream_t s) {
+    constexpr int NP = NT * 16;
+    const int tiles = (M + 15) / 16;
+    size_t lds;
+    int grid;
+    if (KSPLIT) {
+        lds = (size_t)4 * NT * 4 * 64 * sizeof(float);
+        grid = tiles;
+    } else {
+        lds = (size_t)Kp * NP * sizeof(float);
+        grid = (tiles + 3) / 4;
+        if (grid > 512) grid = 512;
+    }
+    if (lds > 160 * 1024) return fail("azg_nn_linear: weight tile exceeds LDS");
+    static bool attr_done = false;
+    if (lds > 64 * 1024 && !attr_done) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_linear<NT, KSPLIT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    k_linear<NT, KSPLIT, NCH><<<dim3(grid), dim3(256), lds, s>>>(A, lda, Wp, bias, R, ldr, rowscale, rpg, out, ldc, M, K, Kp,
+                                                                  N, act);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_nn_linear(const float* A, int lda, const float* Wp, int Kp, int NP, const float* bias, const float* R,
+                             int ldr, const float* rowscale, int rows_per_group, float* out, int ldc, int M, int K, int N,
+                             int act, int ksplit, void* stream) {
+    if (!A || !Wp || !out || M <= 0) return fail("azg_nn_linear: null/empty argument");
+    if (K % 4 || lda % 4 || Kp % 16 || Kp < K || NP % 16 || NP < N || (rowscale && rows_per_group <= 0))
+        return fail("azg_nn_linear: K, lda multiples of 4; Wp padded to [Kp % 16 == 0][NP % 16 == 0]");
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = NP / 16;
+    const int chunks = Kp / 16;
+    const int per_wave = ksplit ? (chunks + 3) / 4 : chunks;
+    const int nch = per_wave <= 2 ? 2 : (per_wave <= 4 ? 4 : (per_wave <= 7 ? 7 : (per_wave <= 11 ? 11 : 0)));
+    if (!nch) return fail("azg_nn_linear: K too long for this variant (K <= 176, or <= 704 with ksplit)");
+#define ARGS A, lda, Wp, bias, R, ldr, rowscale, rows_per_group, out, ldc, M, K, Kp, N, act, s
+#define LIN_N(NTV, KS)                                                                     \
+    switch (nch) {                                                                         \
+        case 2: return launch_linear<NTV, KS, 2>(ARGS);                                    \
+        case 4: return launch_linear<NTV, KS, 4>(ARGS);                                    \
+        case 7: return launch_linear<NTV, KS, 7>(ARGS);                                    \
+        default: return launch_linear<NTV, KS, 11>(ARGS);                                  \
+    }
+#define LIN(NTV) do { if (ksplit) { LIN_N(NTV, 1) } else { LIN_N(NTV, 0) } } while (0)
+    switch (nt) {
+        case 1: LIN(1);
+        case 4: LIN(4);
+        case 6: LIN(6);
+        case 11: LIN(11);
+        default: return fail("azg_nn_linear: NP/16 must be 1, 4, 6 or 11");
+    }
+#undef LIN
+#undef LIN_N
+#undef ARGS
+}
+
+template <int NCH>
+static int launch_linear_ws(const float* A, int lda, const float* Wp, int NP, const float* biasp, const float* R, int ldr,
+                            const float* rowscale, int rpg, float* out, int ldc, int M, int K, int N, int act,
+                            hipStream_t s) {
+    const int tiles = (M + 15) / 16;
+    const int col_groups = ((N + 15) / 16 + 3) / 4;
+    // enough workgroups to fill the chip (~2048 waves), but several row tiles per wave so the weight fragment and the
+    // software prefetch are amortised
+    int tiles_per_wg = (tiles * col_groups + 2047) / 2048;
+    if (tiles_per_wg < 1) tiles_per_wg = 1;
+    const int gx = (tiles + tiles_per_wg - 1) / tiles_per_wg;
+    k_linear_ws<NCH><<<dim3(gx, col_groups), dim3(256), 0, s>>>(A, lda, Wp, NP, biasp, R, ldr, rowscale, rpg, out, ldc, M, K, N,
+                                                                act, tiles_per_wg);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_nn_linear_ws(const float* A, int lda, const float* Wp, int Kp, int NP, const float* bias_padded,
+                                const float* R, int ldr, const float* rowscale, int rows_per_group, float* out, int ldc,
+                                int M, int K, int N, int act, void* stream) {
+    if (!A || !Wp || !out || M <= 0) return fail("azg_nn_linear_ws: null/empty argument");
+    if (K % 4 || lda % 4 || ldc % 4 || (R && ldr % 4) || Kp % 16 || Kp < K || NP % 16 || NP < N ||
+        (rowscale && rows_per_group <= 0))
+        return fail("azg_nn_linear_ws: K, lda, ldc, ldr multiples of 4; Wp padded to [Kp % 16 == 0][NP % 16 == 0]");
+    hipStream_t s = (hipStream_t)stream;
+#define WS(NCHV) return launch_linear_ws<NCHV>(A, lda, Wp, NP, bias_padded, R, ldr, rowscale, rows_per_group, out, ldc, M, K, N, act, s)
+    switch (Kp / 16) {
+        case 1: WS(1);
+        case 3: WS(3);
+        case 4: WS(4);
+        case 6: WS(6);
+        case 11: WS(11);
+        case 25: WS(25);
+        default: return fail("azg_nn_linear_ws: Kp/16 must be 1, 3, 4, 6, 11 or 25");
+    }
+#undef WS
+}
+
+extern "C" int azg_nn_dw_pool(float* H, int ldh, const float* Wd, const float* sd, const float* bd, float* pooled, int B,
+                              int E, int act, int pool_max, void* stream) {
+    if (!H || !Wd || !pooled || B <= 0) return fail("azg_nn_dw_pool: null/empty argument");
+    const long long total = (long long)B * E;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    k_dw_pool<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(H, ldh, Wd, sd, bd, pooled, B, E, act, pool_max);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_nn_board_to_x(const int8_t* boards, float* x, int B, int C, void* stream) {
+    if (!boards || !x || B <= 0) return fail("azg_nn_board_to_x: null/empty argument");
+    const long long total = (long long)B * 7 * C;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    k_board_to_x<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(boards, x, B, C);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_nn_heads_out(const float* logits, int ldl, const uint8_t* valid, const float* vhid, int ldv,
+                                const float* Wv2, const float* bv2, float* pi, float* v, int B, int A, int P,
+                                void* stream) {
+    if (!logits || !valid || !pi || !v || B <= 0) return fail("azg_nn_heads_out: null/empty argument");
+    if (A > 256 || P > 4) return fail("azg_nn_heads_out: A <= 256, P <= 4");
+    k_heads_out<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(logits, ldl, valid, vhid, ldv, Wv2, bv2, pi, v, B, A, P);
+    HIPCHK(hipGetLastError());
     return 0;
 }

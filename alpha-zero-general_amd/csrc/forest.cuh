@@ -91,6 +91,19 @@ struct ForestDev {
     unsigned long long* ex_count;      // [0] = records written (may exceed capacity => dropped), [1] = dropped
 };
 
+// Load a header through the vector path but keep every word wave-uniform (SGPR): the tree / node headers drive the
+// control flow of the whole wave, so they should not occupy 64 lanes' worth of VGPRs.
+template <class T>
+__device__ __forceinline__ T load_uniform(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "word-sized struct");
+    T out;
+    const uint32_t* s = (const uint32_t*)p;
+    uint32_t* d = (uint32_t*)&out;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); k++) d[k] = uni_u32(s[k]);
+    return out;
+}
+
 __device__ __constant__ long long AZG_MAGIC_SEEDS[8] = {31416, 1, 14142, 42, 27183, 2, 16180, 7};   // MCTS.py:14
 
 __host__ __device__ __forceinline__ uint32_t align16u(uint32_t x) { return (x + 15u) & ~15u; }
@@ -158,6 +171,27 @@ __device__ inline float np_sum_f32(const float* a, int n) {
         }
     }
     return ret;
+}
+
+// Gamma(alpha, 1) variate from a counter-based uniform stream (Marsaglia-Tsang squeeze; alpha < 1 via the
+// U^(1/alpha) boost).  Deterministic in (key, ctr): the same call returns the same variate, so callers may recompute
+// instead of storing.  Used for the root Dirichlet noise (rng.dirichlet([alpha]*n_valid) == normalised Gammas,
+// MCTS.py:187-192) when the caller supplies no noise tensor.
+__device__ inline double gamma_variate(double alpha, uint64_t key, uint64_t ctr) {
+    auto u01 = [&](uint64_t k) { return ((double)(mix64(key + k) >> 11) + 0.5) * (1.0 / 9007199254740992.0); };
+    const double a = alpha < 1.0 ? alpha + 1.0 : alpha;
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double g = d;
+    for (int it = 0; it < 8; it++) {
+        const double u1 = u01(ctr + 4 * it), u2 = u01(ctr + 4 * it + 1), u3 = u01(ctr + 4 * it + 2);
+        const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        if (log(u3) < 0.5 * x * x + d - d * v + d * log(v)) { g = d * v; break; }
+    }
+    if (alpha < 1.0) g *= pow(u01(ctr + 3), 1.0 / alpha);
+    return g;
 }
 
 template <class G>
@@ -290,7 +324,7 @@ struct Forest {
     // inject the reference's sample) or iid Gamma(alpha, 1) variates that are normalised over the first n_valid
     // entries here (Dirichlet(alpha) == normalised Gammas; rng.dirichlet MCTS.py:189).
     __device__ static void root_noise_dense(float* dense, const uint64_t* mask, double temp_root, const double* noise,
-                                            bool normalised) {
+                                            bool normalised, double alpha = 0.0, uint64_t gkey = 0, uint64_t gctr = 0) {
         int l = lane_id();
         if (temp_root != 1.0) {
             // Numba typing: float32 array ** float64 -> float64 array, normalised in f64, cast to f32
@@ -304,10 +338,11 @@ struct Forest {
         int nv = 0;
 #pragma unroll
         for (int k = 0; k < AW; k++) nv += __popcll(mask[k]);
+        if (noise == nullptr && alpha < 0.0) alpha = 10.0 / (double)nv;            // automatic value MCTS.py:190-192
         double gsum = 1.0;
         if (!normalised) {
             gsum = 0.0;
-            for (int r = l; r < nv; r += 64) gsum += noise[r];
+            for (int r = l; r < nv; r += 64) gsum += noise ? noise[r] : gamma_variate(alpha, gkey, gctr + ((uint64_t)r << 6));
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) gsum += shfl_xor_f64(gsum, m);
             if (!(gsum > 0.0)) gsum = 1.0;
@@ -319,7 +354,8 @@ struct Forest {
                 int rank = __popcll(w & ((1ull << (i & 63)) - 1ull));
                 for (int k = 0; k < (i >> 6); k++) rank += __popcll(mask[k]);
                 float a = 0.75f * dense[i];
-                double d = normalised ? noise[rank] : noise[rank] / gsum;
+                double d = normalised ? noise[rank]
+                                      : (noise ? noise[rank] : gamma_variate(alpha, gkey, gctr + ((uint64_t)rank << 6))) / gsum;
                 dense[i] = (float)((double)a + 0.25 * d);
             }
         }

@@ -155,7 +155,7 @@ __device__ int pick_action(const ForestDev& F, int t, const NodeHdr& nh, const u
         if (forced) {                                                     // :218-220 first deficient action wins
             double thr = sqrt(0.5 * (double)p * (double)n_iter);
             uint64_t def = __ballot(act && ((long long)n < (long long)thr));
-            if (def) return base + first_lane(def);
+            if (def) return uni_i32(base + first_lane(def));
         }
         double u;
         if (q != AZG_NANQ) u = q + F.cpuct * (double)p * sqrtNs / (double)(1u + n);      // :223
@@ -167,13 +167,14 @@ __device__ int pick_action(const ForestDev& F, int t, const NodeHdr& nh, const u
         best_j = take ? jj : best_j;
     }
     wave_argmax_f64(best_u, best_j);
-    return best_j;
+    return uni_i32(best_j);
 }
 
 // Apply root Dirichlet noise to the existing root row (MCTS.py:156-160): scatter to dense, transform, gather back.
 template <class G>
 __device__ void noise_existing_root(const ForestDev& F, uint8_t* row, const RowLayout& L, int nv, float* dense,
-                                    uint64_t* mask, const double* noise, bool normalised) {
+                                    uint64_t* mask, const double* noise, bool normalised, double alpha, uint64_t gkey,
+                                    uint64_t gctr) {
     float* Prow = (float*)row;
     const uint16_t* ids = (const uint16_t*)(row + L.offI);
     for (int i = lane_id(); i < G::A; i += 64) dense[i] = 0.f;
@@ -183,20 +184,20 @@ __device__ void noise_existing_root(const ForestDev& F, uint8_t* row, const RowL
     if (lane_id() == 0)
         for (int j = 0; j < nv; j++) mask[ids[j] >> 6] |= 1ull << (ids[j] & 63);
     wave_sync();
-    Forest<G>::root_noise_dense(dense, mask, F.temp_root, noise, normalised);
+    Forest<G>::root_noise_dense(dense, mask, F.temp_root, noise, normalised, alpha, gkey, gctr);
     for (int j = lane_id(); j < nv; j += 64) Prow[j] = dense[ids[j]];
 }
 
 // One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
 template <class G>
-__global__ __launch_bounds__(64) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
+__global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
                                                uint8_t* needs_eval, const double* root_noise, int noise_stride) {
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
     __shared__ __attribute__((aligned(16))) float dense[G::A];
     const int t = blockIdx.x;
     const int l = lane_id();
-    TreeHdr H = F.hdr[t];
+    TreeHdr H = load_uniform(&F.hdr[t]);
     if (H.status != ST_SEARCHING) {
         if (l == 0) needs_eval[t] = 0;
         return;
@@ -209,7 +210,9 @@ __global__ __launch_bounds__(64) void k_select(ForestDev F, int8_t* leaf_states,
         if (H.err) { H.status = ST_DONE; break; }
         const int uidx = F.universes > 0 ? (int)(H.sim_idx % (uint32_t)F.universes) : 0;
         const long long seed = F.universes > 0 ? AZG_MAGIC_SEEDS[uidx] : -1ll;                 // MCTS.py:63
-        const bool dir_now = (H.sim_idx == 0 && H.is_full && root_noise != nullptr);           // MCTS.py:64
+        // MCTS.py:64 -- noise source: caller tensor, or the engine's own Gamma sampler (root_noise == NULL, stride == -1)
+        const bool gen_noise = (root_noise == nullptr && noise_stride == -1 && F.dirichletAlpha != 0.0);
+        const bool dir_now = (H.sim_idx == 0 && H.is_full && (root_noise != nullptr || gen_noise));
         H.c_sims++;
         uint32_t node = H.root;
         int depth = 0;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(64) void k_select(ForestDev F, int8_t* leaf_states,
             }
         }
         while (!have_leaf) {
-            const NodeHdr nh = *FR::nhdr(F, t, node);
+            const NodeHdr nh = load_uniform(FR::nhdr(F, t, node));
             if (nh.flags & NF_TERMINAL) {                                                       // MCTS.py:136-138
                 H.c_term++;
                 float v[G::P];
@@ -248,21 +251,25 @@ __global__ __launch_bounds__(64) void k_select(ForestDev F, int8_t* leaf_states,
             uint8_t* row = hp + (size_t)nh.row_off * 16u;
             if (depth == 0 && dir_now)
                 noise_existing_root<G>(F, row, L, nh.nv, dense, sm.mask,
-                                       root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride), noise_stride < 0);
+                                       root_noise ? root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride)
+                                                  : nullptr,
+                                       root_noise != nullptr && noise_stride < 0, F.dirichletAlpha,
+                                       mix64(mix64(F.rng_seed ^ 0xA5A5A5A55A5A5A5AULL) + F.stream0 + (uint64_t)t),
+                                       H.c_sims << 20);
             const int j = pick_action<G>(F, t, nh, row, L, depth == 0 && H.forced, H.sim_idx);
             H.c_levels++;
             H.c_sumvalid += nh.nv;
             const uint16_t* ids = (const uint16_t*)(row + L.offI);
             uint32_t* crow = (uint32_t*)(row + L.offC);
-            const int a = ids[j];
-            uint32_t child = crow[j * F.U + uidx];
+            const int a = (int)uni_u32(ids[j]);
+            uint32_t child = uni_u32(crow[j * F.U + uidx]);
             if (depth >= AZG_MAXD - 1) { H.err |= ERR_DEPTH_OVERFLOW; H.sim_idx = H.n_sims; break; }
             if (child == AZG_NONE) {
                 // frontier edge: replay the env step from the parent's state (MCTS.py:233-248) and look the child up
                 FR::load_state(sm.st, FR::nstate(F, t, node));
                 int np = 0;
                 if (l == 0) np = G::make_move(sm.st, a, 0, seed, no_rng);
-                np = __shfl(np, 0, 64);
+                np = uni_i32(np);
                 wave_sync();
                 if (np != 0) G::swap_players(sm.st, sm.tmp, np);
                 uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* 
     __shared__ __attribute__((aligned(16))) PathEnt path[AZG_MAXD];
     const int t = blockIdx.x;
     const int l = lane_id();
-    TreeHdr H = F.hdr[t];
+    TreeHdr H = load_uniform(&F.hdr[t]);
     if (H.status != ST_WAIT_NN) return;
     const uint32_t leaf = H.pending_leaf;
     NodeHdr* nhp = FR::nhdr(F, t, leaf);
@@ -369,15 +376,18 @@ __global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* 
     const PathEnt* gp = F.path + (size_t)t * AZG_MAXD;
     for (int d = l; d < depth; d += 64) path[d] = gp[d];
     wave_sync();
-    const bool dir_now = (H.leaf_is_root && H.sim_idx == 0 && H.is_full && root_noise != nullptr);
+    const bool gen_noise = (root_noise == nullptr && noise_stride == -1 && F.dirichletAlpha != 0.0);
+    const bool dir_now = (H.leaf_is_root && H.sim_idx == 0 && H.is_full && (root_noise != nullptr || gen_noise));
     if (dir_now) {                                                                               // MCTS.py:147-149
         if (l < G::AW) mask[l] = 0ull;
         wave_sync();
         if (l == 0)
             for (int j = 0; j < nv; j++) mask[ids[j] >> 6] |= 1ull << (ids[j] & 63);
         wave_sync();
-        FR::root_noise_dense(dense, mask, F.temp_root, root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride),
-                             noise_stride < 0);
+        FR::root_noise_dense(dense, mask, F.temp_root,
+                             root_noise ? root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride) : nullptr,
+                             root_noise != nullptr && noise_stride < 0, F.dirichletAlpha,
+                             mix64(mix64(F.rng_seed ^ 0xA5A5A5A55A5A5A5AULL) + F.stream0 + (uint64_t)t), H.c_sims << 20);
         float* Prow = (float*)row;
         for (int j = l; j < nv; j += 64) Prow[j] = dense[ids[j]];
     } else {

@@ -1,0 +1,303 @@
+// nn_kernels.cuh -- fp32 policy/value net building blocks for gfx950 (the only MFMA work on the self-play path).
+//
+// The reference evaluates the net with ONNX Runtime / torch on the CPU, one leaf at a time or 8 at a time
+// (GenericNNetWrapper.py:94-157).  Here one lock-step round evaluates T leaves at once; the V80 network
+// (splendor/SplendorNNet.py:262-283,397-440) is a chain of *skinny* GEMMs (M = 7*T rows, K,N in {56,168,392,81}) plus
+// per-(sample,channel) glue, so instead of library GEMM calls (which pick poor tiles for K = 56) there are three kernels (+ a layout kernel):
+//
+//   k_linear      out = act(A' @ W + bias) (+ R)      MFMA v_mfma_f32_16x16x4_f32 (exact f32, == an fmaf chain), weights
+//                                                      resident in LDS, A fragments straight from HBM as float4;
+//                                                      A' = A optionally scaled per (sample,k) -- this fuses the
+//                                                      SqueezeExcitation multiply into the project GEMM's operand
+//   k_dw_pool     depthwise Linear(7->7) over the token axis + folded BN + activation + SE squeeze (avg / max)
+//                 (the two SE fully-connected layers E -> Q -> E are two more k_linear launches, hardsigmoid epilogue)
+//   k_heads_out   masked softmax of the policy logits (exp(log_softmax), GenericNNetWrapper.py:107) and the value tail
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace azg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_HSIGMOID = 3 };
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    if (act == ACT_RELU) return x > 0.f ? x : 0.f;
+    if (act == ACT_HSWISH) { float t = fminf(fmaxf(x + 3.f, 0.f), 6.f); return x * t / 6.f; }
+    if (act == ACT_HSIGMOID) return fminf(fmaxf(x + 3.f, 0.f), 6.f) / 6.f;
+    return x;
+}
+__device__ __forceinline__ float hardsigmoid(float x) { return fminf(fmaxf(x + 3.f, 0.f), 6.f) / 6.f; }
+
+// out[M][N] = act(A'[M][K] @ W + bias[N]) (+ R[M][N]);  A'[r][k] = A[r][k] * rowscale[r / rpg][k] if rowscale.
+//
+// W is pre-padded by the host to Wp[Kp][NP] (Kp = K rounded up to 16, NP = 16*NT, zero padding) so that staging and
+// fragment reads need no bounds logic.  MFMA 16x16x4 f32: lane l supplies A[row = l&15][k'] and B[k'][col = l&15] for the
+// k' of its lane group g = l>>4.  The reduction order over K is free as long as A and B agree, so group g takes
+// k' = 16*s + 4*g + j (j = 0..3) of K-chunk s: every lane then reads ONE float4 of its A row per chunk straight from
+// global memory (16 rows x 64 contiguous bytes per wave instruction) and A never goes through LDS.
+//   KSPLIT == 0 (tall M): Wp resident in LDS, each wave walks its own 16-row tiles, no barrier in the tile loop.
+//   KSPLIT == 1 (M ~ T, long K: the flatten->Linear heads): one 16-row tile per workgroup, the 4 waves split the K
+//               chunks, B fragments come straight from L2, partial sums are reduced through LDS.
+template <int NT, int KSPLIT, int NCH>
+__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
+                                                const float* __restrict__ bias, const float* __restrict__ R, int ldr,
+                                                const float* __restrict__ rowscale, int rpg, float* __restrict__ out,
+                                                int ldc, int M, int K, int Kp, int N, int act) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NP = NT * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int n_chunks = Kp >> 4;
+    const int n_tiles = (M + 15) / 16;
+    if (!KSPLIT) {
+        // async global->LDS DMA (global_load_lds_dwordx4): 1 KiB per wave instruction, destination = uniform base +
+        // lane*16, all requests in flight at once (Kp*NP*4 is a multiple of 1 KiB because Kp and NP are multiples of 16)
+        const int n_kb = (Kp * NP) >> 8;
+        for (int c = wave; c < n_kb; c += 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (size_t)c * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(smem + (size_t)c * 256), 16, 0, 0);
+        __syncthreads();
+    }
+    const int tile_step = KSPLIT ? gridDim.x : gridDim.x * 4;
+    for (int tile = KSPLIT ? blockIdx.x : blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_step) {
+        const int row = tile * 16 + r16;
+        const bool row_ok = row < M;
+        const float* arow = A + (size_t)(row_ok ? row : 0) * lda;
+        const float* srow = rowscale ? rowscale + (size_t)((row_ok ? row : 0) / rpg) * K : nullptr;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // all A chunks of this tile are requested up front (NCH float4 per lane) so the HBM latency is paid once
+        float4 av[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int s = KSPLIT ? wave + 4 * c : c;
+            const int k0 = 16 * s + 4 * g;
+            av[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok && s < n_chunks && k0 < K) av[c] = *(const float4*)(arow + k0);
+        }
+        if (srow) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int s = KSPLIT ? wave + 4 * c : c;
+                const int k0 = 16 * s + 4 * g;
+                if (row_ok && s < n_chunks && k0 < K) {
+                    const float4 sc = *(const float4*)(srow + k0);
+                    av[c].x *= sc.x; av[c].y *= sc.y; av[c].z *= sc.z; av[c].w *= sc.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int s = KSPLIT ? wave + 4 * c : c;
+            if (s < n_chunks) {
+                const int k0 = 16 * s + 4 * g;
+                const float* wb = (KSPLIT ? Wp : smem) + (size_t)k0 * NP + r16;
+                const float a4[4] = {av[c].x, av[c].y, av[c].z, av[c].w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], wb[j * NP + nt * 16], acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        if (KSPLIT) {
+            // reduce the 4 waves' partial tiles through LDS: red[wave][nt][reg][lane]
+            __syncthreads();
+            float* red = smem;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[((wave * NT + nt) * 4 + r) * 64 + lane] = acc[nt][r];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        acc[nt][r] = ((red[((0 * NT + nt) * 4 + r) * 64 + lane] + red[((1 * NT + nt) * 4 + r) * 64 + lane]) +
+                                      red[((2 * NT + nt) * 4 + r) * 64 + lane]) + red[((3 * NT + nt) * 4 + r) * 64 + lane];
+            }
+        }
+        if (!KSPLIT || wave == 0) {
+            // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                const int col = nt * 16 + r16;
+                if (col < N) {
+                    const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int orow = tile * 16 + g * 4 + r;
+                        if (orow < M) {
+                            float v = act_apply(acc[nt][r] + b, act);
+                            if (R) v += R[(size_t)orow * ldr + col];
+                            out[(size_t)orow * ldc + col] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Weight-stationary variant (the one the net uses): out^T = W^T @ A'^T.  The WEIGHT tile is the MFMA "A" operand and
+// lives in registers for the whole kernel (NCH*4 VGPRs per lane for one 16-column tile), activations are the "B" operand:
+// lane (g = l>>4, r = l&15) reads ONE float4 of activation row `tile*16 + r` per 16-wide K chunk straight from HBM/L2.
+// No LDS, no barrier; the C/D layout (i = 4*g + reg -> output column, j = r -> row) leaves every lane with 4 CONSECUTIVE
+// output columns of its row, so bias / activation / residual / store are float4-wide.  A workgroup's 4 waves take 4
+// different column tiles of the same row tiles (activation re-reads hit L1); grid.y covers the remaining column tiles.
+// The next row tile's activations (and residual) are requested before the current tile's MFMAs (software prefetch).
+template <int NCH>
+__global__ __launch_bounds__(256) void k_linear_ws(const float* __restrict__ A, int lda, const float* __restrict__ Wp,
+                                                   int NP, const float* __restrict__ biasp, const float* __restrict__ R,
+                                                   int ldr, const float* __restrict__ rowscale, int rpg,
+                                                   float* __restrict__ out, int ldc, int M, int K, int N, int act,
+                                                   int tiles_per_wg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int nt = blockIdx.y * 4 + wave;
+    if (nt * 16 >= N) return;
+    float w[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[c][j] = Wp[(size_t)(16 * c + 4 * g + j) * NP + nt * 16 + r16];
+    const int col0 = nt * 16 + 4 * g;
+    const float4 b4 = biasp ? *(const float4*)(biasp + col0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n_tiles = (M + 15) / 16;
+    const int t_begin = blockIdx.x * tiles_per_wg;
+    const int t_end = min(n_tiles, t_begin + tiles_per_wg);
+    float4 a_nxt[NCH];
+    float4 r_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int tile) {
+        const int row = tile * 16 + r16;
+        const bool ok = row < M;
+        const float* arow = A + (size_t)(ok ? row : 0) * lda;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int k0 = 16 * c + 4 * g;
+            a_nxt[c] = (ok && k0 < K) ? *(const float4*)(arow + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (rowscale) {
+            const float* srow = rowscale + (size_t)((ok ? row : 0) / rpg) * K;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int k0 = 16 * c + 4 * g;
+                if (ok && k0 < K) {
+                    const float4 sc = *(const float4*)(srow + k0);
+                    a_nxt[c].x *= sc.x; a_nxt[c].y *= sc.y; a_nxt[c].z *= sc.z; a_nxt[c].w *= sc.w;
+                }
+            }
+        }
+        if (R) r_nxt = (ok && col0 + 3 < ((N + 3) & ~3)) ? *(const float4*)(R + (size_t)row * ldr + col0)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (t_begin < t_end) fetch(t_begin);
+    for (int tile = t_begin; tile < t_end; tile++) {
+        float4 a_cur[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) a_cur[c] = a_nxt[c];
+        const float4 r_cur = r_nxt;
+        if (tile + 1 < t_end) fetch(tile + 1);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][0], a_cur[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][1], a_cur[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][2], a_cur[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][3], a_cur[c].w, acc, 0, 0, 0);
+        }
+        const int row = tile * 16 + r16;
+        if (row < M) {
+            float4 v;
+            v.x = act_apply(acc[0] + b4.x, act) + r_cur.x;
+            v.y = act_apply(acc[1] + b4.y, act) + r_cur.y;
+            v.z = act_apply(acc[2] + b4.z, act) + r_cur.z;
+            v.w = act_apply(acc[3] + b4.w, act) + r_cur.w;
+            float* o = out + (size_t)row * ldc + col0;
+            if (col0 + 3 < N) *(float4*)o = v;
+            else {
+                if (col0 + 0 < N) o[0] = v.x;
+                if (col0 + 1 < N) o[1] = v.y;
+                if (col0 + 2 < N) o[2] = v.z;
+            }
+        }
+    }
+}
+
+// H[b*7 + m][c] <- act( sd[c] * sum_l Wd[m][l] * H[b*7 + l][c] + bd[c] );  pooled[b][c] = mean_m / max_m of the result
+// (LinearNormActivation depthwise + SqueezeExcitation1d pooling, SplendorNNet.py:148-187).  One (sample, channel) per
+// thread, channel-fastest => coalesced; wide grid for memory-level parallelism (2 x 19 MB of traffic at T = 4096).
+__global__ __launch_bounds__(256) void k_dw_pool(float* __restrict__ H, int ldh, const float* __restrict__ Wd,
+                                                 const float* __restrict__ sd, const float* __restrict__ bd,
+                                                 float* __restrict__ pooled, int B, int E, int act, int pool_max) {
+    __shared__ float w[49];
+    if (threadIdx.x < 49) w[threadIdx.x] = Wd[threadIdx.x];
+    __syncthreads();
+    const long long total = (long long)B * E;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / E), c = (int)(i - (long long)b * E);
+        float* base = H + (size_t)b * 7 * ldh + c;
+        float in[7];
+#pragma unroll
+        for (int l = 0; l < 7; l++) in[l] = base[(size_t)l * ldh];
+        const float s = sd[c], bb = bd[c];
+        float pool = pool_max ? -INFINITY : 0.f;
+#pragma unroll
+        for (int m = 0; m < 7; m++) {
+            float a = 0.f;
+#pragma unroll
+            for (int l = 0; l < 7; l++) a += w[m * 7 + l] * in[l];
+            a = act_apply(a * s + bb, act);
+            base[(size_t)m * ldh] = a;
+            pool = pool_max ? fmaxf(pool, a) : pool + a;
+        }
+        pooled[(size_t)b * E + c] = pool_max ? pool : pool / 7.f;
+    }
+}
+
+// boards int8 [B][C][7] (reference layout) -> x f32 [B][7][C] (channels-last)
+__global__ __launch_bounds__(256) void k_board_to_x(const int8_t* __restrict__ boards, float* __restrict__ x, int B, int C) {
+    const long long total = (long long)B * 7 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / (7 * C)), rem = (int)(i - (long long)b * 7 * C), l = rem / C, c = rem - l * C;
+        x[i] = (float)boards[(size_t)b * 7 * C + c * 7 + l];
+    }
+}
+
+// pi[b] = softmax(where(valid, logits, -1e8)) ; v[b] = tanh(relu(vhid[b]) @ Wv2 + bv2)      one wave per sample
+__global__ __launch_bounds__(64) void k_heads_out(const float* __restrict__ logits, int ldl,
+                                                  const uint8_t* __restrict__ valid, const float* __restrict__ vhid,
+                                                  int ldv, const float* __restrict__ Wv2, const float* __restrict__ bv2,
+                                                  float* __restrict__ pi, float* __restrict__ v, int B, int A, int P) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    if (b >= B) return;
+    float x[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int a = l + 64 * k;
+        x[k] = -INFINITY;
+        if (a < A) { x[k] = valid[(size_t)b * A + a] ? logits[(size_t)b * ldl + a] : -1e8f; mx = fmaxf(mx, x[k]); }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x[k] = (l + 64 * k < A) ? expf(x[k] - mx) : 0.f; s += x[k]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (l + 64 * k < A) pi[(size_t)b * A + l + 64 * k] = x[k] / s;
+    if (l < P) {
+        float a = bv2[l];
+        for (int j = 0; j < P; j++) { float hj = vhid[(size_t)b * ldv + j]; a += (hj > 0.f ? hj : 0.f) * Wv2[j * P + l]; }
+        v[(size_t)b * P + l] = tanhf(a);
+    }
+}
+
+}  // namespace azg

@@ -166,14 +166,14 @@ __global__ __launch_bounds__(64) void k_selfplay_start(ForestDev F, const int8_t
 }
 
 template <class G>
-__global__ __launch_bounds__(64) void k_selfplay_advance(ForestDev F) {
+__global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
     __shared__ int cnt[G::A];
     __shared__ double w[G::A];
     const int t = blockIdx.x;
     const int l = lane_id();
-    TreeHdr H = F.hdr[t];
+    TreeHdr H = load_uniform(&F.hdr[t]);
     if (H.status != ST_DONE) return;
     if (H.err) return;                         // tree is parked; the host reads the error flag
     Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, H.rng_counter};

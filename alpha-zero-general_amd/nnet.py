@@ -87,15 +87,18 @@ class SplendorV80:
                 setattr(blk, name, getattr(blk, name).to(self.device, dtype))
         return self
 
-    @staticmethod
-    def from_npz(path, **kw):
+    @classmethod
+    def from_npz(cls, path, **kw):
         z = np.load(path)
-        sd = {k[3:]: z[k] for k in z.files if k.startswith('sd/')}
-        return SplendorV80(sd, **kw)
+        return cls({k[3:]: z[k] for k in z.files if k.startswith('sd/')}, **kw)
+
+    @classmethod
+    def random_init(cls, num_players=2, seed=0, **kw):
+        """random weights of the V80 architecture (for runs without a checkpoint)"""
+        return cls(cls.random_state_dict(num_players, seed), num_players=num_players, **kw)
 
     @staticmethod
-    def random_init(num_players=2, seed=0, **kw):
-        """random weights of the V80 architecture (for runs without a checkpoint)"""
+    def random_state_dict(num_players=2, seed=0):
         g = torch.Generator().manual_seed(seed)
         C, E, Q = 32 + 10 * num_players + num_players * num_players, 0, 0
         E = 3 * C
@@ -120,7 +123,7 @@ class SplendorV80:
         block('trunk.0'); block('output_layers_PI.0'); block('output_layers_V.0')
         lin('output_layers_PI.2', 81, 7 * C); lin('output_layers_PI.4', 81, 81)
         lin('output_layers_V.2', num_players, 7 * C); lin('output_layers_V.4', num_players, num_players)
-        return SplendorV80(sd, num_players=num_players, **kw)
+        return sd
 
     @torch.no_grad()
     def forward(self, boards, valids):
@@ -145,3 +148,117 @@ class SplendorV80:
         va = torch.from_numpy(np.asarray(valid_actions).astype(np.bool_))[None].to(self.device)
         pi, v = self.forward(b, va)
         return pi[0].cpu().numpy(), v[0].cpu().numpy()
+
+
+class SplendorV80Hip(SplendorV80):
+    """Same network, same weights, evaluated by the engine's own gfx950 kernels (azg_nn_* in include/azg.h) instead of
+    ~70 torch ops: 9 skinny fp32 MFMA GEMMs (k_linear, with bias / activation / residual / SE-scale fused), 3
+    depthwise+BN+act+pool kernels, 3 SE kernels, one layout kernel and one softmax/value kernel per leaf batch."""
+
+    def __init__(self, state_dict, num_players=2, device='cuda:0', max_batch=4096):
+        super().__init__(state_dict, num_players=num_players, device=device, dtype=torch.float32)
+        from . import _lib
+        self._lib = _lib
+        self.C = self.nb_vect
+        self.E = 3 * self.C
+        self.Q = self.trunk.W1.shape[1]
+        self.weight_stationary = True
+        self._bias_pad = {}
+        self._prepare()
+        self._alloc(max_batch)
+
+    def _alloc(self, B):
+        d, f = self.device, torch.float32
+        self.maxB = B
+        self.x0 = torch.empty((B * 7, self.C), dtype=f, device=d)
+        self.x1 = torch.empty((B * 7, self.C), dtype=f, device=d)
+        self.x2 = torch.empty((B * 7, self.C), dtype=f, device=d)
+        self.xh = torch.empty((B * 7, self.C), dtype=f, device=d)
+        self.h = torch.empty((B * 7, self.E), dtype=f, device=d)
+        self.pooled = torch.empty((B, self.E), dtype=f, device=d)
+        self.sc = torch.empty((B, self.E), dtype=f, device=d)
+        self.se_h = torch.zeros((B, 48), dtype=f, device=d)        # Q = 40 used, zero-padded to a multiple of 16 for K
+        self.hid_pi = torch.zeros((B, 96), dtype=f, device=d)      # 81 used, zero-padded to a multiple of 4 for K
+        self.logits = torch.empty((B, 96), dtype=f, device=d)
+        self.hid_v = torch.zeros((B, 16), dtype=f, device=d)
+        self.pi = torch.empty((B, self.A), dtype=f, device=d)
+        self.v = torch.empty((B, self.P), dtype=f, device=d)
+
+    def _stream(self):
+        import ctypes as C
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _pad_w(W):
+        """[K][N] -> zero-padded [Kp][NP], Kp multiple of 16, NP/16 in {1,4,6,11} (k_linear's LDS / fragment layout)"""
+        K, N = W.shape
+        Kp = (K + 15) // 16 * 16
+        nt = (N + 15) // 16
+        nt = 1 if nt <= 1 else 4 if nt <= 4 else 6 if nt <= 6 else 11
+        out = torch.zeros((Kp, nt * 16), dtype=torch.float32, device=W.device)
+        out[:K, :N] = W
+        return out.contiguous()
+
+    def _prepare(self):
+        self.pW0 = self._pad_w(self.W0)
+        for blk in (self.trunk, self.head_pi, self.head_v):
+            blk.pWe, blk.pWp = self._pad_w(blk.We), self._pad_w(blk.Wp)
+            blk.pW1, blk.pW2 = self._pad_w(blk.W1), self._pad_w(blk.W2)
+        self.pWpi1, self.pWpi2 = self._pad_w(self.Wpi1), self._pad_w(self.Wpi2)
+        self.pWv1 = self._pad_w(self.Wv1)
+
+    def _linear(self, A, lda, Wp, bias, out, ldc, M, K, N, act=0, R=None, ldr=0, rowscale=None, rpg=0, ksplit=0):
+        import ctypes as C
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        if self.weight_stationary:
+            bp = None
+            if bias is not None:
+                key = bias.data_ptr()
+                bp = self._bias_pad.get(key)
+                if bp is None:
+                    bp = torch.zeros(Wp.shape[1], dtype=torch.float32, device=bias.device)
+                    bp[:bias.numel()] = bias
+                    self._bias_pad[key] = bp
+            self._lib.check(self._lib.lib().azg_nn_linear_ws(p(A), lda, p(Wp), Wp.shape[0], Wp.shape[1], p(bp), p(R), ldr,
+                                                             p(rowscale), rpg, p(out), ldc, M, K, N, act, self._stream()))
+            return
+        self._lib.check(self._lib.lib().azg_nn_linear(p(A), lda, p(Wp), Wp.shape[0], Wp.shape[1], p(bias), p(R), ldr,
+                                                      p(rowscale), rpg, p(out), ldc, M, K, N, act, ksplit,
+                                                      self._stream()))
+
+    def _block(self, blk, xin, xout, B):
+        import ctypes as C
+        L = self._lib.lib()
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        act = 2 if blk.use_hs else 1
+        M = B * 7
+        self._linear(xin, self.C, blk.pWe, blk.be, self.h, self.E, M, self.C, self.E, act=act)           # expand+BN+act
+        self._lib.check(L.azg_nn_dw_pool(p(self.h), self.E, p(blk.Wd), p(blk.sd), p(blk.bd), p(self.pooled), B, self.E,
+                                         act, 0 if blk.setype == 'avg' else 1, self._stream()))           # depthwise+BN+act+squeeze
+        self._linear(self.pooled, self.E, blk.pW1, blk.b1, self.se_h, 48, B, self.E, self.Q, act=1, ksplit=1)   # SE fc1+ReLU
+        self._linear(self.se_h, 48, blk.pW2, blk.b2, self.sc, self.E, B, 48, self.E, act=3, ksplit=1)            # SE fc2+Hardsigmoid
+        self._linear(self.h, self.E, blk.pWp, blk.bp, xout, self.C, M, self.E, self.C, act=0, R=xin, ldr=self.C,
+                     rowscale=self.sc, rpg=7)                                                             # SE*h @ Wp + BN + residual
+
+    @torch.no_grad()
+    def forward(self, boards, valids):
+        import ctypes as C
+        B = boards.shape[0]
+        if B > self.maxB:
+            self._alloc(B)
+        L = self._lib.lib()
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        boards = boards.reshape(B, -1)
+        assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda
+        valids = valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)
+        self._lib.check(L.azg_nn_board_to_x(p(boards), p(self.x0), B, self.C, self._stream()))
+        self._linear(self.x0, self.C, self.pW0, self.b0, self.x1, self.C, B * 7, self.C, self.C)           # first_layer
+        self._block(self.trunk, self.x1, self.x2, B)
+        self._block(self.head_pi, self.x2, self.xh, B)
+        self._linear(self.xh, 7 * self.C, self.pWpi1, self.bpi1, self.hid_pi, 96, B, 7 * self.C, self.A, act=1, ksplit=1)
+        self._linear(self.hid_pi, 96, self.pWpi2, self.bpi2, self.logits, 96, B, 96, self.A, ksplit=1)
+        self._block(self.head_v, self.x2, self.xh, B)
+        self._linear(self.xh, 7 * self.C, self.pWv1, self.bv1, self.hid_v, 16, B, 7 * self.C, self.P, ksplit=1)
+        self._lib.check(L.azg_nn_heads_out(p(self.logits), 96, p(valids), p(self.hid_v), 16, p(self.Wv2), p(self.bv2),
+                                           p(self.pi), p(self.v), B, self.A, self.P, self._stream()))
+        return self.pi[:B], self.v[:B]

@@ -22,14 +22,9 @@ class SelfPlayEngine:
         self.alpha = float(get('dirichletAlpha', 0.0)) if dirichlet is None else float(dirichlet)
         self.shape = (n_games,) + tuple(self.forest.board_shape())
         dev = self.forest.device
-        self.noise = None
-        if self.alpha > 0:
-            # Coach passes dirichlet_noise=(dirichletAlpha != 0) (Coach.py:31,96): Gamma(alpha,1) variates, normalised over
-            # the root's valid actions on device (== rng.dirichlet([alpha]*n_valid), MCTS.py:189)
-            self._alpha_t = torch.full((n_games, self.forest.A), self.alpha, dtype=torch.float64, device=dev)
-            self.noise = torch._standard_gamma(self._alpha_t)
-        elif self.alpha < 0:
-            raise NotImplementedError('automatic dirichletAlpha (10/n_valid) is not wired into the device sampler yet')
+        # Coach passes dirichlet_noise=(dirichletAlpha != 0) (Coach.py:31,96).  The Gamma variates of
+        # rng.dirichlet([alpha]*n_valid) (MCTS.py:187-192) are drawn on device by the engine's own sampler.
+        self.device_noise = self.alpha != 0.0
         self.use_graph = use_graph
         self.graph = None
         self.rounds = 0
@@ -41,12 +36,10 @@ class SelfPlayEngine:
 
     def _round(self):
         f = self.forest
-        if self.noise is not None:
-            self.noise.copy_(torch._standard_gamma(self._alpha_t))
-        f.select(self.noise)
+        f.select(device_noise=self.device_noise)
         pi, v = self.nnet.predict_batch(f.leaf_states.view(self.shape), f.leaf_valid)
         self._pi, self._v = pi, v
-        f.expand_backup(pi, v, self.noise)
+        f.expand_backup(pi, v, device_noise=self.device_noise)
         f.selfplay_advance()
 
     def capture(self):

@@ -105,6 +105,7 @@ def main():
     ap.add_argument('--node-capacity', type=int, default=0)
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--net-dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
+    ap.add_argument('--net', default='hip', choices=['hip', 'torch'], help='hip: engine MFMA kernels; torch: PyTorch-ROCm ops')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--roofline-rounds', type=int, default=300)
@@ -124,7 +125,7 @@ def main():
     dev = 'cuda:%d' % local_rank
 
     from azg_amd import games
-    from azg_amd.nnet import SplendorV80
+    from azg_amd.nnet import SplendorV80, SplendorV80Hip
     from azg_amd.selfplay import SelfPlayEngine, gather_examples
 
     T = a.games
@@ -133,8 +134,13 @@ def main():
     game = games.SplendorGame(2, device=dev)
     dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[a.net_dtype]
     pretrained = os.path.exists(WEIGHTS)
-    net = SplendorV80.from_npz(WEIGHTS, device=dev, dtype=dtype) if pretrained else \
-        SplendorV80.random_init(device=dev, dtype=dtype)
+    if a.net == 'hip':
+        assert a.net_dtype == 'fp32'
+        net = SplendorV80Hip.from_npz(WEIGHTS, device=dev, max_batch=T) if pretrained else \
+            SplendorV80Hip.random_init(device=dev, max_batch=T)
+    else:
+        net = SplendorV80.from_npz(WEIGHTS, device=dev, dtype=dtype) if pretrained else \
+            SplendorV80.random_init(device=dev, dtype=dtype)
     cap = a.node_capacity or max(2048, 10 * a.sims + 512)
     eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
                          stream0=rank * T, use_graph=not a.no_graph)
@@ -210,9 +216,9 @@ def main():
                higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
                data='synthetic (Board.init_game boards from the counter RNG; net weights: %s)'
                     % ('reference pretrained_2players.pt converted' if pretrained else 'random-init V80'),
-               config=dict(workload='Splendor 2p, numMCTSSims=%d, %d concurrent self-play games per GPU, V80 net %s, '
+               config=dict(workload='Splendor 2p, numMCTSSims=%d, %d concurrent self-play games per GPU, V80 net %s (%s), '
                                     'args of pretrained_2players.pt (cpuct 0.8 fpu 0.0593 universes 3 forced playouts '
-                                    'dirichlet 0.3), every ply a full search' % (a.sims, T, a.net_dtype),
+                                    'dirichlet 0.3), every ply a full search' % (a.sims, T, a.net_dtype, 'engine MFMA-f32 kernels' if a.net == 'hip' else 'PyTorch-ROCm ops'),
                            games_per_gpu=T, parallelism='games sharded x%d, 1 RCCL example all_gather at episode end'
                                                         % world if world > 1 else 'single GPU',
                            hip_graph=eng.graph is not None),

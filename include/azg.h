@@ -109,7 +109,9 @@ int azg_forest_select(azg_forest* f, int8_t* leaf_states_dev, uint8_t* leaf_vali
 /* root noise (MCTS.py:64,187-197): applied on simulation 0 of full searches when root_noise_dev != NULL.
    noise_stride > 0: rows hold iid Gamma(dirichletAlpha,1) variates, normalised on device over the root's n_valid
    first entries (== rng.dirichlet([alpha]*n_valid)); noise_stride < 0: rows already hold a Dirichlet sample over the
-   valid actions (parity tests inject the reference's own sample), stride = -noise_stride. */
+   valid actions (parity tests inject the reference's own sample), stride = -noise_stride.
+   root_noise_dev == NULL with noise_stride == -1: the engine draws the Gamma variates itself (counter-based stream keyed
+   by rng_seed / game stream / simulation count; cfg.dirichletAlpha > 0, or < 0 for the automatic 10/n_valid). */
 /* part 2: store (Ps, v) on the pending leaves and back the values up (MCTS.py:147-154,176-183).
    pi f32[T][A] are PROBABILITIES (exp of the net's log-softmax, GenericNNetWrapper.py:107,119), v f32[T][P]. */
 int azg_forest_expand_backup(azg_forest* f, const float* pi_dev, const float* v_dev, const double* root_noise_dev,
@@ -150,6 +152,33 @@ int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out);
 int azg_selfplay_drain_examples(azg_forest* f, int max_records, int8_t* boards_dev, float* pi_dev, float* z_dev,
                                 uint8_t* valids_dev, float* q_dev, int32_t* meta_dev /* i32[n][4] = (global game
                                 stream, game index on it, ply, player) or NULL */, int* n_out, void* stream);
+
+/* ---- policy/value net building blocks: NeuralNet.predict for a whole leaf batch (NeuralNet.py:32-43,
+   GenericNNetWrapper.py:94-120; V80 network splendor/SplendorNNet.py:148-202,262-283,397-440), fp32 ----
+   out[M][N] = act(A'[M][K] @ W + bias) (+ R);  A' = A * rowscale[row / rows_per_group][k] when rowscale != NULL (fuses the
+   SqueezeExcitation multiply into the project GEMM).  Wp is the weight pre-padded with zeros to [Kp][NP], Kp = K rounded
+   up to 16, NP/16 in {1,4,6,11}.  act: 0 none, 1 ReLU, 2 Hardswish, 3 Hardsigmoid.  K, lda % 4 == 0.  ksplit = 1 selects the variant for
+   M ~ batch and long K (flatten->Linear heads).  MFMA v_mfma_f32_16x16x4_f32 (exact f32 == an fmaf chain). */
+int azg_nn_linear(const float* A_dev, int lda, const float* Wp_dev, int Kp, int NP, const float* bias_dev,
+                  const float* R_dev, int ldr, const float* rowscale_dev, int rows_per_group, float* out_dev, int ldc,
+                  int M, int K, int N, int act, int ksplit, void* stream);
+/* Same contract, weight-stationary kernel (weights in registers as the MFMA A operand, activations streamed as float4,
+   float4 epilogue, no LDS): the variant the V80 forward uses for every layer.  bias_padded: NP floats (zero padded) or
+   NULL; ldc (and ldr) % 4 == 0; Kp/16 in {1,3,4,6,11,25}. */
+int azg_nn_linear_ws(const float* A_dev, int lda, const float* Wp_dev, int Kp, int NP, const float* bias_padded_dev,
+                     const float* R_dev, int ldr, const float* rowscale_dev, int rows_per_group, float* out_dev, int ldc,
+                     int M, int K, int N, int act, void* stream);
+/* depthwise Linear(7->7) over the token axis + folded BatchNorm + activation, in place on H[B*7][ldh], and the SE squeeze
+   pooled[B][E] (mean or max over the 7 tokens)  (SplendorNNet.py:148-187).  The SE excitation
+   hardsigmoid(relu(pooled @ W1 + b1) @ W2 + b2) is two azg_nn_linear calls (act 1, then act 3 = Hardsigmoid). */
+int azg_nn_dw_pool(float* H_dev, int ldh, const float* Wd_dev /*[7][7] out,in*/, const float* bn_scale_dev,
+                   const float* bn_bias_dev, float* pooled_dev, int B, int E, int act, int pool_max, void* stream);
+/* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
+int azg_nn_board_to_x(const int8_t* boards_dev, float* x_dev, int B, int C, void* stream);
+/* pi = softmax(where(valid, logits, -1e8)) (== exp(log_softmax), GenericNNetWrapper.py:107); v = tanh(relu(vhid) @ Wv2 + bv2) */
+int azg_nn_heads_out(const float* logits_dev, int ldl, const uint8_t* valid_dev, const float* vhid_dev, int ldv,
+                     const float* Wv2_dev, const float* bv2_dev, float* pi_dev, float* v_dev, int B, int A, int P,
+                     void* stream);
 
 /* ---- measurement helpers ---- */
 /* time `iters` back-to-back launches of kernel `which` (0 = select, 1 = expand_backup) with hipEvents on `stream`

@@ -122,3 +122,95 @@ def test_tree_reuse_sequence_vs_golden(golden_dir, variant):
         assert np.array_equal(rs['Nsa'][0].cpu().numpy(), d['seq_Nsa'][i].astype(np.int32)), (variant, i)
         assert np.array_equal(probs[0].cpu().numpy(), d['seq_probs'][i]), (variant, i)
     m.forest.close()
+
+
+@pytest.mark.parametrize('temp_root', [1.0, 1.1])
+def test_root_dirichlet_noise_injected_vs_oracle(temp_root):
+    """applyDirNoise (MCTS.py:187-197) with the SAME Dirichlet sample injected on both sides: new root (noise at
+    expansion, :147-149) and, on a second search from the same root, an existing root (:156-160)."""
+    import torch
+    import azg_oracle as O
+    from azg_amd import games
+    from azg_amd.forest import Forest
+    from hashnet import HashNetTorch
+    g = games.SplendorGame(2)
+    og = O.OracleGame(O.SPLENDOR, 2)
+    kw = dict(MCTS_ARGS['splendor2'])
+    sims, T = 120, 6
+    rng = np.random.default_rng(5)
+    roots = np.stack([og.getInitBoard(og.rng(seed=21, stream=i)).reshape(-1) for i in range(T)])
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3,
+                temperature=[1.0, 1.0, temp_root], **kw)
+    f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=1024)
+    net = HashNetTorch(2)
+    oracles = [O.OracleMCTS(og, O.make_args(numMCTSSims=sims, dirichletAlpha=0.3, temperature=(1.0, 1.0, temp_root), **kw),
+                            dirichlet_noise=True) for _ in range(T)]
+    for rep in range(2):
+        noise = np.zeros((T, g.A), dtype=np.float64)
+        samples = []
+        for t in range(T):
+            nv = int(og.getValidMoves(roots[t], 0).sum())
+            s = rng.dirichlet([0.3] * nv)
+            noise[t, :nv] = s
+            samples.append(s)
+        nz = torch.from_numpy(noise).to(g.device)
+        f.begin_search(torch.from_numpy(roots).to(g.device))
+        while True:
+            f.select(nz, normalised=True)
+            if not bool(f.needs_eval.any().item()):
+                if f.active() == 0:
+                    break
+                continue
+            pi, v = net.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid.bool())
+            f.expand_backup(pi, v, nz, normalised=True)
+        rs = f.root_stats()
+        for t in range(T):
+            oracles[t].getActionProb(roots[t], temp=1, force_full_search=True, dir_noise=samples[t])
+            nd = oracles[t].node(roots[t])
+            va = og.getValidMoves(roots[t], 0)
+            ps = rs['Ps'][t].cpu().numpy()
+            if temp_root == 1.0:
+                assert np.array_equal(ps[va], nd['Ps'][va]), (rep, t)
+                assert np.array_equal(rs['Nsa'][t].cpu().numpy(), nd['Nsa'].astype(np.int32)), (rep, t)
+                assert np.array_equal(rs['Qsa'][t].cpu().numpy(), nd['Qsa'])
+            else:   # pow() in f64 on device vs libm: last-ulp differences allowed
+                assert np.allclose(ps[va], nd['Ps'][va], rtol=1e-6, atol=1e-9), (rep, t)
+    f.close()
+
+
+def test_device_dirichlet_sampler_statistics():
+    """The engine's own Gamma sampler (no noise tensor): the noised root prior is a proper distribution that differs from
+    the clean prior with the moments of 0.75*P + 0.25*Dir(alpha) (mean of the Dirichlet part = 1/n_valid)."""
+    import torch
+    import azg_oracle as O
+    from azg_amd import games
+    from azg_amd.forest import Forest
+    from hashnet import HashNetTorch
+    g = games.SplendorGame(2)
+    og = O.OracleGame(O.SPLENDOR, 2)
+    kw = dict(MCTS_ARGS['splendor2'])
+    T = 512
+    root = og.getInitBoard(og.rng(seed=3, stream=0)).reshape(-1)
+    roots = torch.from_numpy(np.tile(root, (T, 1))).to(g.device)
+    net = HashNetTorch(2)
+    res = {}
+    for alpha in (0.0, 0.3):
+        args = Args(numMCTSSims=1, prob_fullMCTS=1.0, dirichletAlpha=alpha, temperature=[1.0, 1.0, 1.0], **kw)
+        f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=64, rng_seed=11)
+        f.begin_search(roots)
+        f.select(device_noise=True)
+        pi, v = net.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid.bool())
+        f.expand_backup(pi, v, device_noise=True)
+        res[alpha] = f.root_stats()['Ps'].cpu().numpy().astype(np.float64)
+        f.close()
+    clean, noisy = res[0.0], res[0.3]
+    va = og.getValidMoves(root, 0)
+    nv = int(va.sum())
+    assert np.allclose(noisy.sum(axis=1), 1.0, atol=1e-5) and np.all(noisy[:, ~va] == 0)
+    d = (noisy[:, va] - 0.75 * clean[:, va]) / 0.25           # the Dirichlet part per tree
+    assert np.all(d > -1e-6) and np.allclose(d.sum(axis=1), 1.0, atol=1e-4)
+    assert abs(d.mean() - 1.0 / nv) < 1e-3
+    # Var of a Dirichlet(alpha) marginal: (1/n)(1-1/n)/(n*alpha+1)
+    expect_var = (1.0 / nv) * (1 - 1.0 / nv) / (nv * 0.3 + 1)
+    assert abs(d.var() - expect_var) / expect_var < 0.15
+    assert len({tuple(np.round(x, 6)) for x in d[:32]}) == 32      # different trees, different samples

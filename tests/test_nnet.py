@@ -24,3 +24,24 @@ def test_v80_forward_cpu():
 @pytest.mark.gpu
 def test_v80_forward_gpu():
     _check('cuda:0')
+
+
+@pytest.mark.gpu
+def test_v80_hip_kernels_forward_gpu():
+    """The engine's own gfx950 net kernels (MFMA f32 skinny GEMMs + fused glue) vs the reference model's outputs."""
+    from azg_amd.nnet import SplendorV80Hip, SplendorV80
+    root = os.path.join(os.path.dirname(__file__), 'golden')
+    net = SplendorV80Hip.from_npz(os.path.join(root, 'weights_splendor2_v80.npz'), device='cuda:0', max_batch=512)
+    d = np.load(os.path.join(root, 'netfwd_splendor2_v80.npz'))
+    boards = torch.from_numpy(d['boards']).cuda()
+    masks = torch.from_numpy(d['masks']).cuda()
+    pi, v = net.predict_batch(boards, masks)
+    assert np.allclose(pi.cpu().numpy(), d['pi'], atol=1e-5, rtol=0)
+    assert np.allclose(v.cpu().numpy(), d['v'], atol=1e-5, rtol=0)
+    assert np.all(pi.cpu().numpy()[d['masks'] == 0] == 0)
+    # ragged batch sizes (not a multiple of the 64-row GEMM tile / 8-sample SE group)
+    ref = SplendorV80.from_npz(os.path.join(root, 'weights_splendor2_v80.npz'), device='cuda:0')
+    for n in (1, 7, 65, 200):
+        p1, v1 = net.predict_batch(boards[:n].contiguous(), masks[:n].contiguous())
+        p2, v2 = ref.predict_batch(boards[:n], masks[:n])
+        assert torch.allclose(p1, p2, atol=1e-5, rtol=0) and torch.allclose(v1, v2, atol=1e-5, rtol=0)
