@@ -594,6 +594,33 @@ extern "C" int azg_nn_dw_pool(float* H, int ldh, const float* Wd, const float* s
     return 0;
 }
 
+extern "C" int azg_nn_v80_block(const float* xin, float* xout, const float* const* w /* 11 device pointers */, int B,
+                                int act, int pool_max, void* stream) {
+    if (!xin || !xout || !w || B <= 0) return fail("azg_nn_v80_block: null/empty argument");
+    V80BlockW W{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10]};
+    constexpr size_t lds = (size_t)(112 * 60 + 112 * 172 + 2 * 16 * 172 + 16 * 52 + 64) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (B + 15) / 16;
+    static bool attr[4] = {false, false, false, false};
+#define BLK(A_, P_, IDX)                                                                                              \
+    do {                                                                                                              \
+        if (!attr[IDX]) {                                                                                             \
+            HIPCHK(hipFuncSetAttribute((const void*)k_v80_block<A_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                       160 * 1024));                                                                  \
+            attr[IDX] = true;                                                                                         \
+        }                                                                                                             \
+        k_v80_block<A_, P_><<<dim3(grid), dim3(768), lds, s>>>(xin, xout, W, B);                                      \
+    } while (0)
+    if (act == 1 && !pool_max) BLK(1, 0, 0);
+    else if (act == 1 && pool_max) BLK(1, 1, 1);
+    else if (act == 2 && !pool_max) BLK(2, 0, 2);
+    else if (act == 2 && pool_max) BLK(2, 1, 3);
+    else return fail("azg_nn_v80_block: act must be 1 (ReLU) or 2 (Hardswish)");
+#undef BLK
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int azg_nn_board_to_x(const int8_t* boards, float* x, int B, int C, void* stream) {
     if (!boards || !x || B <= 0) return fail("azg_nn_board_to_x: null/empty argument");
     const long long total = (long long)B * 7 * C;

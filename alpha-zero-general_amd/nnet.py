@@ -163,6 +163,7 @@ class SplendorV80Hip(SplendorV80):
         self.E = 3 * self.C
         self.Q = self.trunk.W1.shape[1]
         self.weight_stationary = True
+        self.fused_blocks = True
         self._bias_pad = {}
         self._prepare()
         self._alloc(max_batch)
@@ -194,7 +195,6 @@ class SplendorV80Hip(SplendorV80):
         K, N = W.shape
         Kp = (K + 15) // 16 * 16
         nt = (N + 15) // 16
-        nt = 1 if nt <= 1 else 4 if nt <= 4 else 6 if nt <= 6 else 11
         out = torch.zeros((Kp, nt * 16), dtype=torch.float32, device=W.device)
         out[:K, :N] = W
         return out.contiguous()
@@ -206,6 +206,8 @@ class SplendorV80Hip(SplendorV80):
             blk.pW1, blk.pW2 = self._pad_w(blk.W1), self._pad_w(blk.W2)
         self.pWpi1, self.pWpi2 = self._pad_w(self.Wpi1), self._pad_w(self.Wpi2)
         self.pWv1 = self._pad_w(self.Wv1)
+        for blk in (self.trunk, self.head_pi, self.head_v):
+            self._block_ptrs(blk)
 
     def _linear(self, A, lda, Wp, bias, out, ldc, M, K, N, act=0, R=None, ldr=0, rowscale=None, rpg=0, ksplit=0):
         import ctypes as C
@@ -226,9 +228,26 @@ class SplendorV80Hip(SplendorV80):
                                                       p(rowscale), rpg, p(out), ldc, M, K, N, act, ksplit,
                                                       self._stream()))
 
+    def _block_ptrs(self, blk):
+        import ctypes as C
+
+        def pad1(v, n):
+            out = torch.zeros(n, dtype=torch.float32, device=v.device)
+            out[:v.numel()] = v
+            return out
+        blk._keep = [blk.pWe, pad1(blk.be, 176), blk.Wd.contiguous(), blk.sd.contiguous(), blk.bd.contiguous(), blk.pW1,
+                     pad1(blk.b1, 48), blk.pW2, pad1(blk.b2, 176), blk.pWp, pad1(blk.bp, 64)]
+        assert tuple(blk.pWe.shape) == (64, 176) and tuple(blk.pW1.shape) == (176, 48)
+        assert tuple(blk.pW2.shape) == (48, 176) and tuple(blk.pWp.shape) == (176, 64)
+        blk.ptrs = (C.c_void_p * 11)(*[t.data_ptr() for t in blk._keep])
+
     def _block(self, blk, xin, xout, B):
         import ctypes as C
         L = self._lib.lib()
+        if self.fused_blocks:
+            self._lib.check(L.azg_nn_v80_block(C.c_void_p(xin.data_ptr()), C.c_void_p(xout.data_ptr()), blk.ptrs, B,
+                                               2 if blk.use_hs else 1, 0 if blk.setype == 'avg' else 1, self._stream()))
+            return
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         act = 2 if blk.use_hs else 1
         M = B * 7

@@ -173,6 +173,12 @@ int azg_nn_linear_ws(const float* A_dev, int lda, const float* Wp_dev, int Kp, i
    hardsigmoid(relu(pooled @ W1 + b1) @ W2 + b2) is two azg_nn_linear calls (act 1, then act 3 = Hardsigmoid). */
 int azg_nn_dw_pool(float* H_dev, int ldh, const float* Wd_dev /*[7][7] out,in*/, const float* bn_scale_dev,
                    const float* bn_bias_dev, float* pooled_dev, int B, int E, int act, int pool_max, void* stream);
+/* One fused InvertedResidual1d block of the V80 net (SplendorNNet.py:189-202: expand + depthwise + SE + project +
+   residual) for x[B*7][56] -> out[B*7][56]; the 168-wide expanded activations stay in LDS.  w = 11 HOST-array device
+   pointers {We[64][176], be[176], Wd[7][7], bn_scale[168], bn_bias[168], W1[176][48], b1[48], W2[48][176], b2[176],
+   Wp[176][64], bp[64]} (zero padded, BatchNorm folded).  act 1 ReLU / 2 Hardswish; pool_max 0 mean / 1 max. */
+int azg_nn_v80_block(const float* xin_dev, float* xout_dev, const float* const* w, int B, int act, int pool_max,
+                     void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
 int azg_nn_board_to_x(const int8_t* boards_dev, float* x_dev, int B, int C, void* stream);
 /* pi = softmax(where(valid, logits, -1e8)) (== exp(log_softmax), GenericNNetWrapper.py:107); v = tanh(relu(vhid) @ Wv2 + bv2) */
