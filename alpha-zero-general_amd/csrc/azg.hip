@@ -157,13 +157,14 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     D.U = cfg->universes > 0 ? cfg->universes : 1;
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
-                            : (size_t)D.cap * RowLayout(f->A <= 200 ? (f->A < 64 ? f->A : 64) : 128, D.U).total;
+                            : (size_t)D.cap * RecLayout(f->A <= 200 ? (f->A < 64 ? f->A : 64) : 128, D.U).total + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     D.heap_units = (uint32_t)(heap_bytes / 16);
     D.universes = cfg->universes;
     D.numMCTSSims = cfg->numMCTSSims;
     D.ratio_fullMCTS = cfg->ratio_fullMCTS > 0 ? cfg->ratio_fullMCTS : 1;
     D.forced_playouts = cfg->forced_playouts;
+    D.level_budget = cfg->level_budget;
     D.cpuct = cfg->cpuct; D.fpu = cfg->fpu; D.prob_fullMCTS = cfg->prob_fullMCTS;
     D.dirichletAlpha = cfg->dirichletAlpha;
     D.temp_begin = cfg->temperature[0]; D.temp_end = cfg->temperature[1]; D.temp_root = cfg->temperature[2];
@@ -250,9 +251,11 @@ static void ev_end(azg_forest* f, int which, hipStream_t s) {
 extern "C" int azg_forest_select(azg_forest* f, int8_t* leaf_states, uint8_t* leaf_valid, uint8_t* needs_eval,
                                  const double* root_noise, int noise_stride, void* stream) {
     if (!f || !leaf_states || !leaf_valid || !needs_eval) return fail("null argument");
+    if (f->cfg.dirichletAlpha != 0.0 && (root_noise || noise_stride == -1))
+        FDISPATCH(f, k_root_noise<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, root_noise, noise_stride));
     ev_begin(f, 0, (hipStream_t)stream);
     FDISPATCH(f, k_select<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, leaf_states,
-                                     leaf_valid, needs_eval, root_noise, noise_stride));
+                                     leaf_valid, needs_eval));
     ev_end(f, 0, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -263,7 +266,7 @@ extern "C" int azg_forest_expand_backup(azg_forest* f, const float* pi, const fl
     if (!f || !pi || !v) return fail("null argument");
     ev_begin(f, 1, (hipStream_t)stream);
     FDISPATCH(f, k_expand_backup<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, pi,
-                                     v, root_noise, noise_stride));
+                                     v, (root_noise || noise_stride == -1) ? 1 : 0));
     ev_end(f, 1, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -321,26 +324,27 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
     const int A = f->A, P = f->P, S = f->S;
     for (int i = 0; i < n; i++) {
         memcpy(states + (size_t)i * S, st.data() + (size_t)i * f->SP, S);
-        Ns[i] = (int32_t)nh[i].Ns;
-        Qs[i] = nh[i].Qs;
-        for (int p = 0; p < P; p++) Es[(size_t)i * P + p] = nh[i].Es[p];
-        has_policy[i] = (nh[i].flags & NF_EXPANDED) ? 1 : 0;
+        const uint8_t* rec = hp.data() + (size_t)nh[i].rec_off * 16;
+        const RecHdr* rh = (const RecHdr*)rec;
+        Ns[i] = (int32_t)rh->Ns;
+        Qs[i] = rh->Qs;
+        for (int p = 0; p < P; p++) Es[(size_t)i * P + p] = rh->Es[p];
+        has_policy[i] = (rh->flags & NF_EXPANDED) ? 1 : 0;
         for (int a = 0; a < A; a++) { Nsa[(size_t)i * A + a] = 0; Qsa[(size_t)i * A + a] = AZG_NANQ; Ps[(size_t)i * A + a] = 0.f; }
         if (has_policy[i]) {
-            RowLayout L(nh[i].nv, D.U);
-            const uint8_t* row = hp.data() + (size_t)nh[i].row_off * 16;
-            const uint16_t* ids = (const uint16_t*)(row + L.offI);
-            for (int j = 0; j < nh[i].nv; j++) {
-                int a = ids[j];
-                Nsa[(size_t)i * A + a] = (int32_t)((const uint32_t*)(row + L.offN))[j];
-                Qsa[(size_t)i * A + a] = ((const double*)(row + L.offQ))[j];
-                Ps[(size_t)i * A + a] = ((const float*)row)[j];
+            RecLayout L(rh->nv, D.U);
+            const uint16_t* ids = (const uint16_t*)(rec + L.offI);
+            for (int j = 0; j < rh->nv; j++) {
+                const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
+                const int a = ids[j];
+                Nsa[(size_t)i * A + a] = (int32_t)*(const uint32_t*)(ent + AZG_E_N);
+                Qsa[(size_t)i * A + a] = *(const double*)(ent + AZG_E_Q);
+                Ps[(size_t)i * A + a] = *(const float*)(ent + AZG_E_P);
             }
         }
     }
     return n;
 }
-
 
 // Structural validation of every tree on the HOST (debug / tests): returns the number of violated invariants.
 extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
@@ -352,41 +356,54 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
     std::vector<NodeHdr> nh(D.cap);
     std::vector<uint8_t> hp(heap_bytes);
     std::vector<uint32_t> tab(D.HT);
+#define VBAD(...) do { bad++; if (verbose) fprintf(stderr, __VA_ARGS__); } while (0)
     for (int t = 0; t < D.T; t++) {
         TreeHdr H;
         HIPCHK(hipMemcpy(&H, D.hdr + t, sizeof(H), hipMemcpyDeviceToHost));
         const uint32_t n = H.n_nodes;
-        if (n > (uint32_t)D.cap || H.heap_top > D.heap_units) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d n=%u heap_top=%u\n", t, n, H.heap_top); continue; }
-        if (H.root != AZG_NONE && H.root >= n) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d root=%u n=%u\n", t, H.root, n); }
+        if (n > (uint32_t)D.cap || H.heap_top > D.heap_units) { VBAD("[validate] t=%d n=%u heap_top=%u\n", t, n, H.heap_top); continue; }
+        if (H.root != AZG_NONE && H.root >= n) VBAD("[validate] t=%d root=%u n=%u\n", t, H.root, n);
         HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)t * D.cap, sizeof(NodeHdr) * n, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)t * heap_bytes, (size_t)H.heap_top * 16, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(tab.data(), D.htab + (size_t)t * D.HT, sizeof(uint32_t) * D.HT, hipMemcpyDeviceToHost));
+        if (H.root != AZG_NONE && H.root < n && nh[H.root].rec_off != H.root_rec)
+            VBAD("[validate] t=%d root_rec=%u but node %u has rec_off=%u\n", t, H.root_rec, H.root, nh[H.root].rec_off);
         uint32_t expect_off = 0;
         for (uint32_t i = 0; i < n; i++) {
-            if (nh[i].flags & NF_TERMINAL) continue;
-            RowLayout L(nh[i].nv, D.U);
-            if (nh[i].row_off != expect_off) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d node=%u row_off=%u expect=%u nv=%u flags=%u\n", t, i, nh[i].row_off, expect_off, nh[i].nv, nh[i].flags); }
-            expect_off = nh[i].row_off + L.total / 16u;
-            if (expect_off > H.heap_top) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d node=%u row end %u > heap_top %u (n=%u root=%u gc=%u status=%u sim=%u err=%u ply=%u)\n", t, i, expect_off, H.heap_top, n, H.root, H.gc_runs, H.status, H.sim_idx, H.err, H.ply); break; }
-            if (!(nh[i].flags & NF_EXPANDED)) continue;
-            const uint8_t* row = hp.data() + (size_t)nh[i].row_off * 16;
-            const uint32_t* c = (const uint32_t*)(row + L.offC);
-            const uint16_t* ids = (const uint16_t*)(row + L.offI);
-            for (int j = 0; j < nh[i].nv * D.U; j++)
-                if (c[j] != AZG_NONE && (c[j] & AZG_CHILD_IDX_MASK) >= n) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d node=%u child[%d]=%08x n=%u\n", t, i, j, c[j], n); }
-            for (int j = 0; j < nh[i].nv; j++)
-                if (ids[j] >= f->A || (j && ids[j] <= ids[j - 1])) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d node=%u ids[%d]=%u\n", t, i, j, ids[j]); break; }
+            RecLayout L(nh[i].nv, D.U);
+            if (nh[i].rec_off != expect_off) VBAD("[validate] t=%d node=%u rec_off=%u expect=%u nv=%u flags=%u\n", t, i, nh[i].rec_off, expect_off, nh[i].nv, nh[i].flags);
+            expect_off = nh[i].rec_off + L.total / 16u;
+            if (expect_off > H.heap_top) { VBAD("[validate] t=%d node=%u record end %u > heap_top %u (n=%u gc=%u)\n", t, i, expect_off, H.heap_top, n, H.gc_runs); break; }
+            const uint8_t* rec = hp.data() + (size_t)nh[i].rec_off * 16;
+            const RecHdr* rh = (const RecHdr*)rec;
+            if (rh->node_id != i || rh->nv != nh[i].nv || rh->round != nh[i].round)
+                VBAD("[validate] t=%d node=%u header mismatch (rec node_id=%u nv=%u)\n", t, i, rh->node_id, rh->nv);
+            if (!(rh->flags & NF_EXPANDED)) continue;
+            const uint16_t* ids = (const uint16_t*)(rec + L.offI);
+            for (int j = 0; j < rh->nv; j++) {
+                const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
+                for (int u = 0; u < D.U; u++) {
+                    const uint32_t c = *(const uint32_t*)(ent + AZG_E_C + 4 * u);
+                    if (c == AZG_NONE) continue;
+                    const uint32_t cr = c & AZG_CHILD_IDX_MASK;
+                    if (cr >= H.heap_top) { VBAD("[validate] t=%d node=%u child[%d][%d]=%08x beyond heap\n", t, i, j, u, c); continue; }
+                    const RecHdr* ch = (const RecHdr*)(hp.data() + (size_t)cr * 16);
+                    if (ch->node_id >= n || nh[ch->node_id].rec_off != cr) VBAD("[validate] t=%d node=%u child[%d][%d] -> bad record %u\n", t, i, j, u, cr);
+                }
+                if (ids[j] >= f->A || (j && ids[j] <= ids[j - 1])) { VBAD("[validate] t=%d node=%u ids[%d]=%u\n", t, i, j, ids[j]); break; }
+            }
         }
         uint32_t cnt = 0;
         for (int k = 0; k < D.HT; k++)
             if (tab[k] != AZG_NONE) {
                 cnt++;
-                uint32_t id = tab[k] & AZG_IDX_MASK;
-                if (id >= n) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d htab[%d]=%08x n=%u\n", t, k, tab[k], n); }
-                else if ((uint32_t)(nh[id].hash >> 54) != (tab[k] >> AZG_IDX_BITS)) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d htab tag mismatch id=%u\n", t, id); }
+                const uint32_t id = tab[k] & AZG_IDX_MASK;
+                if (id >= n) VBAD("[validate] t=%d htab[%d]=%08x n=%u\n", t, k, tab[k], n);
+                else if ((uint32_t)(nh[id].hash >> 54) != (tab[k] >> AZG_IDX_BITS)) VBAD("[validate] t=%d htab tag mismatch id=%u\n", t, id);
             }
-        if (cnt != n) { bad++; if (verbose) fprintf(stderr, "[validate] t=%d htab entries %u != n %u\n", t, cnt, n); }
+        if (cnt != n) VBAD("[validate] t=%d htab entries %u != n %u\n", t, cnt, n);
     }
+#undef VBAD
     return bad;
 }
 
@@ -419,8 +436,8 @@ extern "C" int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out) {
         out->expansions += x.c_exp; out->sum_valid_visited += x.c_sumvalid; out->terminal_hits += x.c_term;
         out->examples += x.c_examples; out->gc_runs += x.gc_runs; out->errors |= x.err;
         out->sum_depth_at_expand += x.c_depth;
+        out->cyc_select += x.cyc_select; out->cyc_levels += x.cyc_levels; out->cyc_edge += x.cyc_edge; out->cyc_leaf += x.cyc_leaf;
         if (x.max_nodes_seen > out->max_nodes) out->max_nodes = x.max_nodes_seen;
-        if (x.err & ERR_BAD_STATE) fprintf(stderr, "[azg] tree err=%u pad0=%u pad1=%u n_nodes=%u heap_top=%u\n", x.err, x.pad0, x.pad1, x.n_nodes, x.heap_top);
     }
     return 0;
 }

@@ -6,14 +6,19 @@
 //
 // What this engine keeps in HBM per tree (all private to the tree's wavefront, so no atomics and no cross-workgroup
 // visibility protocol are needed inside a launch):
-//   NodeHdr[cap]         48 B     64-bit state hash, row offset, #valid, round, flags, Ns (u32), Qs (f32), Es (f32[P])
+//   record heap          bytes    one contiguous, 16-B aligned RECORD per node -- everything a descent level touches:
+//                                   RecHdr 32 B  { Ns u32, Qs f32, node id, n_valid, flags, round, Es f32[4] }
+//                                   entry[nv]    VALID-ACTION-COMPACTED, fixed stride ES = 16 + 4U (rounded to 8):
+//                                                { P f32, N u32, Q f64, child u32[U] }
+//                                   action id u16[nv]
+//                                 entry j of a record sits at a position that does not depend on n_valid, so a wave
+//                                 requests the header and every lane's entry in ONE round trip per level
+//   NodeHdr[cap]         16 B     cold: 64-bit state hash, record offset, n_valid, round, flags (probe / GC / dumps)
 //   state[cap][SP]       int8     the node's canonical state = the dict KEY of the reference (full-key verified)
-//   row heap             bytes    per expanded node, VALID-ACTION-COMPACTED rows, 16-B aligned sections:
-//                                   P f32[nv] | N u32[nv] | Q f64[nv] | child u32[nv*U] | action id u16[nv]
 //   htab[HT]             u32      open-addressing table: (10-bit tag | 22-bit node id), probed 64 slots per wave load
-//   path[MAXD]           8 B      the descent of the pending simulation (node, row index, next_player, roll prefix)
+//   path[MAXD]           8 B      the descent of the pending simulation (record, entry index, next_player, roll prefix)
 //
-// child[j*U+u] caches the node reached through valid action j in universe u (u = sim index mod universes, the
+// child[u] of entry j caches the RECORD OFFSET (| next_player << 30) of the node reached through valid action j in universe u (u = sim index mod universes, the
 // reference's seeded-chance mechanism MCTS.py:14,63).  It is pure memoisation of the reference's "replay env step +
 // dict lookup": the child of (state, action, seed) is a deterministic function, node identity stays the full state
 // (transpositions are found through the hash table exactly like the dict), and nodes are only ever dropped when they
@@ -38,31 +43,40 @@ enum : uint32_t {
 #define AZG_IDX_MASK ((1u << AZG_IDX_BITS) - 1u)
 #define AZG_CHILD_IDX_MASK 0x3FFFFFFFu
 
-struct __attribute__((aligned(16))) NodeHdr {
+struct __attribute__((aligned(16))) NodeHdr {          // cold per-node data
     uint64_t hash;
-    uint32_t row_off;      // 16-byte units into the tree's heap; AZG_NONE for terminal nodes
+    uint32_t rec_off;      // 16-byte units into the tree's record heap
     uint16_t nv;
     uint8_t round;
     uint8_t flags;
+};
+
+struct __attribute__((aligned(16))) RecHdr {           // first 32 bytes of every record
     uint32_t Ns;
     float Qs;
+    uint32_t node_id;
+    uint16_t nv;
+    uint8_t flags;
+    uint8_t round;
     float Es[AZG_MAX_PLAYERS_DEV];
-    uint32_t pad[2];
 };
 
 struct __attribute__((aligned(16))) TreeHdr {
-    uint32_t n_nodes, heap_top, root, status;
+    uint32_t n_nodes, heap_top, root, status;          // root = node id of the search root (AZG_NONE: not a node yet)
     uint32_t sim_idx, n_sims, is_full, forced;
     uint32_t pending_leaf, path_len, ply, cur_player;
     uint64_t rng_counter;
     uint32_t err, root_round;
     uint32_t leaf_is_root, games_done, step, n_rec;
-    uint32_t max_nodes_seen, gc_runs, pad0, pad1;
+    uint32_t mid_sim, cur_rec, cur_depth, cur_pre;     // a descent paused by the per-launch level budget
+    uint32_t max_nodes_seen, gc_runs, root_rec, noise_pending;   // root_rec = record offset of the root;
+                                                                 // noise_pending: root Dirichlet noise still to apply
     uint64_t c_sims, c_levels, c_exp, c_sumvalid, c_term, c_depth, c_plies, c_examples;
+    uint64_t cyc_select, cyc_levels, cyc_edge, cyc_leaf;   // shader-clock cycles spent in k_select and its phases
 };
 
 struct PathEnt {
-    uint32_t node;
+    uint32_t rec;      // record offset (16-byte units)
     uint16_t j;
     uint8_t np;        // next_player of this edge
     uint8_t pre;       // sum of np over the entries above this one (mod P)
@@ -72,6 +86,7 @@ struct ForestDev {
     int T, cap, HT, U;                 // trees, nodes per tree, hash slots per tree (pow2), child slots per action
     uint32_t heap_units;               // 16-byte units per tree heap
     int universes, numMCTSSims, ratio_fullMCTS, forced_playouts;
+    int level_budget;                  // max descent levels per tree per k_select launch (0 = unlimited)
     double cpuct, fpu, prob_fullMCTS, dirichletAlpha, temp_begin, temp_end, temp_root, tempThreshold;
     uint64_t rng_seed, stream0;
     int max_examples, max_rec;
@@ -108,17 +123,21 @@ __device__ __constant__ long long AZG_MAGIC_SEEDS[8] = {31416, 1, 14142, 42, 271
 
 __host__ __device__ __forceinline__ uint32_t align16u(uint32_t x) { return (x + 15u) & ~15u; }
 
-struct RowLayout {
-    uint32_t offN, offQ, offC, offI, total;   // bytes; P at 0
-    __host__ __device__ RowLayout(int nv, int U) {
-        uint32_t szP = align16u(4u * nv);
-        offN = szP;
-        offQ = offN + szP;
-        offC = offQ + align16u(8u * nv);
-        offI = offC + align16u(4u * nv * U);
-        total = offI + align16u(2u * nv);
+// record geometry: RecHdr | entry[nv] (stride ES) | action ids u16[nv]
+#define AZG_REC_HDR 32u
+__host__ __device__ __forceinline__ uint32_t entry_stride(int U) { return (16u + 4u * (uint32_t)U + 7u) & ~7u; }
+struct RecLayout {
+    uint32_t ES, offI, total;   // bytes
+    __host__ __device__ RecLayout(int nv, int U) {
+        ES = entry_stride(U);
+        offI = AZG_REC_HDR + align16u((uint32_t)nv * ES);
+        total = offI + align16u(2u * (uint32_t)nv);
     }
 };
+#define AZG_E_P 0u
+#define AZG_E_N 4u
+#define AZG_E_Q 8u
+#define AZG_E_C 16u
 
 // NumPy's pairwise float32 summation order (np.sum called by `normalise`, MCTS.py:250-253) for n <= 128 elements,
 // executed by lanes 0..7 over an LDS array; every lane returns the sum.
@@ -217,6 +236,9 @@ struct Forest {
         return F.heap + (size_t)t * F.heap_units * 16u;
     }
     __device__ static __forceinline__ uint32_t* htab(const ForestDev& F, int t) { return F.htab + (size_t)t * F.HT; }
+    __device__ static __forceinline__ uint8_t* rec_ptr(const ForestDev& F, int t, uint32_t rec_off) {
+        return heap(F, t) + (size_t)rec_off * 16u;
+    }
 
     __device__ static __forceinline__ void load_state(int8_t* lds, const int8_t* g_padded) {
         const uint32_t* src = (const uint32_t*)g_padded;
@@ -274,7 +296,8 @@ struct Forest {
     }
 
     // Allocate a node for the state in LDS, write key + hash, insert in the table.  Returns AZG_NONE on overflow.
-    __device__ static uint32_t create_node(const ForestDev& F, int t, TreeHdr& H, const int8_t* st_lds, uint64_t h,
+    template <class HS>
+    __device__ static uint32_t create_node(const ForestDev& F, int t, HS& H, const int8_t* st_lds, uint64_t h,
                                            uint32_t free_slot) {
         if (H.n_nodes >= (uint32_t)F.cap || free_slot == AZG_NONE) { H.err |= ERR_NODE_OVERFLOW; return AZG_NONE; }
         uint32_t id = H.n_nodes++;
@@ -295,26 +318,25 @@ struct Forest {
             tot = (last.pre + last.np) % P;
         }
         uint8_t* hp = heap(F, t);
+        const uint32_t ES = entry_stride(F.U);
         for (int base = 0; base < depth; base += 64) {
             int d = base + lane_id();
             if (d < depth) {
                 PathEnt e = path[d];
                 int roll = ((tot - e.pre) % P + P) % P;            // sum of next_player over levels >= d
                 float v0 = v[((0 - roll) % P + P) % P];             // np.roll(v, n)[0] = v[(-n) mod P]
-                NodeHdr* nh = nhdr(F, t, e.node);
-                RowLayout L(nh->nv, F.U);
-                uint8_t* row = hp + (size_t)nh->row_off * 16u;
-                uint32_t* Nrow = (uint32_t*)(row + L.offN);
-                double* Qrow = (double*)(row + L.offQ);
-                uint32_t n = Nrow[e.j];
-                double q = Qrow[e.j];
-                Qrow[e.j] = ((double)n * q + (double)v0) / (double)(n + 1u);
-                uint32_t ns = nh->Ns;
-                float tq = (float)(ns + 1u) * nh->Qs;
+                uint8_t* rec = hp + (size_t)e.rec * 16u;
+                RecHdr* rh = (RecHdr*)rec;
+                uint8_t* ent = rec + AZG_REC_HDR + (size_t)e.j * ES;
+                uint32_t n = *(uint32_t*)(ent + AZG_E_N);
+                double q = *(double*)(ent + AZG_E_Q);
+                *(double*)(ent + AZG_E_Q) = ((double)n * q + (double)v0) / (double)(n + 1u);
+                uint32_t ns = rh->Ns;
+                float tq = (float)(ns + 1u) * rh->Qs;
                 tq = tq + v0;
-                nh->Qs = tq / (float)(ns + 2u);
-                Nrow[e.j] = n + 1u;
-                nh->Ns = ns + 1u;
+                rh->Qs = tq / (float)(ns + 2u);
+                *(uint32_t*)(ent + AZG_E_N) = n + 1u;
+                rh->Ns = ns + 1u;
             }
         }
     }

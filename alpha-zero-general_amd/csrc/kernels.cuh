@@ -100,8 +100,8 @@ __global__ __launch_bounds__(64) void k_forest_reset(ForestDev F) {
     for (int i = lane_id(); i < F.HT; i += 64) tab[i] = AZG_NONE;
     if (lane_id() == 0) {
         TreeHdr* H = &F.hdr[t];
-        H->n_nodes = 0; H->heap_top = 0; H->root = AZG_NONE; H->status = ST_IDLE;
-        H->sim_idx = 0; H->n_sims = 0; H->pending_leaf = AZG_NONE; H->path_len = 0;
+        H->n_nodes = 0; H->heap_top = 0; H->root = AZG_NONE; H->root_rec = AZG_NONE; H->status = ST_IDLE;
+        H->sim_idx = 0; H->n_sims = 0; H->pending_leaf = AZG_NONE; H->path_len = 0; H->mid_sim = 0;
     }
 }
 
@@ -113,6 +113,7 @@ __device__ void begin_search_from_lds(const ForestDev& F, int t, TreeHdr& H, typ
     uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
     uint32_t free_slot;
     H.root = FR::probe(F, t, sm.st, h, &free_slot);
+    H.root_rec = H.root == AZG_NONE ? AZG_NONE : uni_u32(FR::nhdr(F, t, H.root)->rec_off);
     H.root_round = (uint32_t)G::get_round(sm.st);
     H.is_full = full ? 1u : 0u;
     H.n_sims = (uint32_t)(full ? F.numMCTSSims : F.numMCTSSims / F.ratio_fullMCTS);
@@ -120,6 +121,9 @@ __device__ void begin_search_from_lds(const ForestDev& F, int t, TreeHdr& H, typ
     H.sim_idx = 0;
     H.status = ST_SEARCHING;
     H.pending_leaf = AZG_NONE;
+    H.mid_sim = 0;
+    // MCTS.py:64,156-160: an EXISTING root gets its noise before simulation 0 (applied by k_root_noise)
+    H.noise_pending = (full && F.dirichletAlpha != 0.0 && H.root_rec != AZG_NONE) ? 1u : 0u;
 }
 
 template <class G>
@@ -127,203 +131,98 @@ __global__ __launch_bounds__(64) void k_begin_search(ForestDev F, const int8_t* 
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
     int t = blockIdx.x;
-    TreeHdr H = F.hdr[t];
+    TreeHdr H = load_uniform(&F.hdr[t]);
     FR::load_state_unpadded(sm.st, roots + (size_t)t * G::S);
     begin_search_from_lds<G>(F, t, H, sm, full ? full[t] != 0 : true);
     if (lane_id() == 0) F.hdr[t] = H;
 }
 
-// pick_highest_UCB (MCTS.py:210-230) over the compact row of `node`; returns row index j (wave-uniform).
+// Root Dirichlet noise (MCTS.py:64,147-149,156-160,187-197) as its own small kernel so that the f64 pow/log/cos of the
+// Gamma sampler never weigh on the registers of the descent kernel.  It runs right before k_select and touches only trees
+// with noise_pending != 0: an existing root at the start of a full search (entries hold the normalised prior), or a root
+// that was expanded by simulation 0 (k_expand_backup left the RAW net output in the entries).  Both get the reference's
+// sequence softmax(T) -> 0.75*P + 0.25*Dir -> normalise.
 template <class G>
-__device__ int pick_action(const ForestDev& F, int t, const NodeHdr& nh, const uint8_t* row, const RowLayout& L,
-                           bool forced, uint32_t n_iter) {
-    const int nv = nh.nv;
-    const float* Prow = (const float*)row;
-    const uint32_t* Nrow = (const uint32_t*)(row + L.offN);
-    const double* Qrow = (const double*)(row + L.offQ);
-    const double sqrtNs = sqrt((double)nh.Ns);
-    const double sqrtNsEps = sqrt((double)nh.Ns + AZG_EPS);
-    const double fpu_init = F.fpu > 0 ? (double)nh.Qs - F.fpu : F.fpu;
-    double best_u = -INFINITY;
-    int best_j = 0x7FFFFFFF;
-    for (int base = 0; base < nv; base += 64) {
-        int j = base + lane_id();
-        bool act = j < nv;
-        float p = act ? Prow[j] : 0.f;
-        uint32_t n = act ? Nrow[j] : 0u;
-        double q = act ? Qrow[j] : AZG_NANQ;
-        if (forced) {                                                     // :218-220 first deficient action wins
-            double thr = sqrt(0.5 * (double)p * (double)n_iter);
-            uint64_t def = __ballot(act && ((long long)n < (long long)thr));
-            if (def) return uni_i32(base + first_lane(def));
-        }
-        double u;
-        if (q != AZG_NANQ) u = q + F.cpuct * (double)p * sqrtNs / (double)(1u + n);      // :223
-        else u = fpu_init + F.cpuct * (double)p * sqrtNsEps;                            // :225
-        if (!act) u = -INFINITY;
-        int jj = act ? j : 0x7FFFFFFF;
-        bool take = (u > best_u) || (u == best_u && jj < best_j);
-        best_u = take ? u : best_u;
-        best_j = take ? jj : best_j;
-    }
-    wave_argmax_f64(best_u, best_j);
-    return uni_i32(best_j);
-}
-
-// Apply root Dirichlet noise to the existing root row (MCTS.py:156-160): scatter to dense, transform, gather back.
-template <class G>
-__device__ void noise_existing_root(const ForestDev& F, uint8_t* row, const RowLayout& L, int nv, float* dense,
-                                    uint64_t* mask, const double* noise, bool normalised, double alpha, uint64_t gkey,
-                                    uint64_t gctr) {
-    float* Prow = (float*)row;
-    const uint16_t* ids = (const uint16_t*)(row + L.offI);
-    for (int i = lane_id(); i < G::A; i += 64) dense[i] = 0.f;
-    if (lane_id() < G::AW) mask[lane_id()] = 0ull;
-    wave_sync();
-    for (int j = lane_id(); j < nv; j += 64) dense[ids[j]] = Prow[j];
-    if (lane_id() == 0)
-        for (int j = 0; j < nv; j++) mask[ids[j] >> 6] |= 1ull << (ids[j] & 63);
-    wave_sync();
-    Forest<G>::root_noise_dense(dense, mask, F.temp_root, noise, normalised, alpha, gkey, gctr);
-    for (int j = lane_id(); j < nv; j += 64) Prow[j] = dense[ids[j]];
-}
-
-// One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
-template <class G>
-__global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
-                                               uint8_t* needs_eval, const double* root_noise, int noise_stride) {
+__global__ __launch_bounds__(64) void k_root_noise(ForestDev F, const double* root_noise, int noise_stride) {
     using FR = Forest<G>;
-    __shared__ typename FR::Smem sm;
     __shared__ __attribute__((aligned(16))) float dense[G::A];
+    __shared__ __attribute__((aligned(16))) uint64_t mask[G::AW];
     const int t = blockIdx.x;
     const int l = lane_id();
-    TreeHdr H = load_uniform(&F.hdr[t]);
-    if (H.status != ST_SEARCHING) {
-        if (l == 0) needs_eval[t] = 0;
-        return;
-    }
-    uint8_t* hp = FR::heap(F, t);
-    bool need_nn = false;
-    Rng no_rng{0, 0, 0};
-    while (true) {
-        if (H.sim_idx >= H.n_sims) { H.status = ST_DONE; break; }
-        if (H.err) { H.status = ST_DONE; break; }
-        const int uidx = F.universes > 0 ? (int)(H.sim_idx % (uint32_t)F.universes) : 0;
-        const long long seed = F.universes > 0 ? AZG_MAGIC_SEEDS[uidx] : -1ll;                 // MCTS.py:63
-        // MCTS.py:64 -- noise source: caller tensor, or the engine's own Gamma sampler (root_noise == NULL, stride == -1)
-        const bool gen_noise = (root_noise == nullptr && noise_stride == -1 && F.dirichletAlpha != 0.0);
-        const bool dir_now = (H.sim_idx == 0 && H.is_full && (root_noise != nullptr || gen_noise));
-        H.c_sims++;
-        uint32_t node = H.root;
-        int depth = 0;
-        int pre = 0;
-        bool have_leaf = false;
-        H.leaf_is_root = 0;
-        if (node == AZG_NONE) {
-            // the root itself is not a node yet: it is the leaf of this simulation (MCTS.py:140-154)
-            FR::load_state(sm.st, F.root_state + (size_t)t * G::SP);
-            uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
-            uint32_t free_slot;
-            uint32_t found = FR::probe(F, t, sm.st, h, &free_slot);
-            if (found == AZG_NONE) {
-                node = FR::create_node(F, t, H, sm.st, h, free_slot);
-                if (node == AZG_NONE) continue;
-                H.root = node;
-                H.leaf_is_root = 1;
-                have_leaf = true;
-            } else {
-                node = found;
-                H.root = node;
-            }
-        }
-        while (!have_leaf) {
-            const NodeHdr nh = load_uniform(FR::nhdr(F, t, node));
-            if (nh.flags & NF_TERMINAL) {                                                       // MCTS.py:136-138
-                H.c_term++;
-                float v[G::P];
-#pragma unroll
-                for (int p = 0; p < G::P; p++) v[p] = nh.Es[p];
-                FR::backup(F, t, sm.path, depth, v);
-                H.sim_idx++;
-                break;
-            }
-            const RowLayout L(nh.nv, F.U);
-            uint8_t* row = hp + (size_t)nh.row_off * 16u;
-            if (depth == 0 && dir_now)
-                noise_existing_root<G>(F, row, L, nh.nv, dense, sm.mask,
-                                       root_noise ? root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride)
-                                                  : nullptr,
-                                       root_noise != nullptr && noise_stride < 0, F.dirichletAlpha,
-                                       mix64(mix64(F.rng_seed ^ 0xA5A5A5A55A5A5A5AULL) + F.stream0 + (uint64_t)t),
-                                       H.c_sims << 20);
-            const int j = pick_action<G>(F, t, nh, row, L, depth == 0 && H.forced, H.sim_idx);
-            H.c_levels++;
-            H.c_sumvalid += nh.nv;
-            const uint16_t* ids = (const uint16_t*)(row + L.offI);
-            uint32_t* crow = (uint32_t*)(row + L.offC);
-            const int a = (int)uni_u32(ids[j]);
-            uint32_t child = uni_u32(crow[j * F.U + uidx]);
-            if (depth >= AZG_MAXD - 1) { H.err |= ERR_DEPTH_OVERFLOW; H.sim_idx = H.n_sims; break; }
-            if (child == AZG_NONE) {
-                // frontier edge: replay the env step from the parent's state (MCTS.py:233-248) and look the child up
-                FR::load_state(sm.st, FR::nstate(F, t, node));
-                int np = 0;
-                if (l == 0) np = G::make_move(sm.st, a, 0, seed, no_rng);
-                np = uni_i32(np);
-                wave_sync();
-                if (np != 0) G::swap_players(sm.st, sm.tmp, np);
-                uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
-                uint32_t free_slot;
-                uint32_t found = FR::probe(F, t, sm.st, h, &free_slot);
-                if (found == AZG_NONE) {
-                    found = FR::create_node(F, t, H, sm.st, h, free_slot);
-                    if (found == AZG_NONE) { H.sim_idx = H.n_sims; break; }
-                    have_leaf = true;
-                }
-                child = found | ((uint32_t)np << 30);
-                if (l == 0) crow[j * F.U + uidx] = child;
-            }
-            const int np = (int)(child >> 30);
-            if (l == 0) {
-                PathEnt e; e.node = node; e.j = (uint16_t)j; e.np = (uint8_t)np; e.pre = (uint8_t)pre;
-                sm.path[depth] = e;
-            }
-            wave_sync();
-            pre = (pre + np) % G::P;
-            depth++;
-            node = child & AZG_CHILD_IDX_MASK;
-        }
-        if (!have_leaf) continue;
-        // ---- new node `node`, its state is in sm.st: terminal test, valid moves, queue for the net ----
-        float es[G::P];
-        const bool ended = G::game_ended(sm.st, 0, es, sm.mask);                                 // MCTS.py:131
-        NodeHdr* nhp = FR::nhdr(F, t, node);
-        if (ended) {
-            if (l == 0) {
-                nhp->row_off = AZG_NONE; nhp->nv = 0; nhp->round = (uint8_t)G::get_round(sm.st);
-                nhp->flags = NF_TERMINAL; nhp->Ns = 0; nhp->Qs = 0.f;
-#pragma unroll
-                for (int p = 0; p < G::P; p++) nhp->Es[p] = es[p];
-            }
-            H.c_term++;
-            FR::backup(F, t, sm.path, depth, es);
-            H.sim_idx++;
-            continue;
-        }
+    const uint32_t pending = uni_u32(F.hdr[t].noise_pending);
+    if (!pending) return;
+    const uint32_t root_rec = uni_u32(F.hdr[t].root_rec);
+    if (root_rec == AZG_NONE) return;
+    uint8_t* rec = FR::rec_ptr(F, t, root_rec);
+    const RecHdr rh = load_uniform((const RecHdr*)rec);
+    if (!(rh.flags & NF_EXPANDED)) return;
+    const int nv = rh.nv;
+    const RecLayout L(nv, F.U);
+    const uint16_t* ids = (const uint16_t*)(rec + L.offI);
+    for (int i = l; i < G::A; i += 64) dense[i] = 0.f;
+    if (l < G::AW) mask[l] = 0ull;
+    wave_sync();
+    for (int j = l; j < nv; j += 64) dense[ids[j]] = *(const float*)(rec + AZG_REC_HDR + (size_t)j * L.ES + AZG_E_P);
+    if (l == 0)
+        for (int j = 0; j < nv; j++) mask[ids[j] >> 6] |= 1ull << (ids[j] & 63);
+    wave_sync();
+    const double* nz = root_noise ? root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride) : nullptr;
+    const uint64_t c_sims = F.hdr[t].c_sims;
+    FR::root_noise_dense(dense, mask, F.temp_root, nz, root_noise != nullptr && noise_stride < 0, F.dirichletAlpha,
+                         mix64(mix64(F.rng_seed ^ 0xA5A5A5A55A5A5A5AULL) + F.stream0 + (uint64_t)t), c_sims << 20);
+    for (int j = l; j < nv; j += 64) *(float*)(rec + AZG_REC_HDR + (size_t)j * L.ES + AZG_E_P) = dense[ids[j]];
+    if (l == 0) F.hdr[t].noise_pending = 0u;
+}
+
+// PUCT score of one entry (pick_highest_UCB body, MCTS.py:222-225), f64 with the Numba operand typing.
+__device__ __forceinline__ double ucb_score(float p, uint32_t n, double q, double cpuct, double sqrtNs, double sqrtNsEps,
+                                            double fpu_init) {
+    if (q != AZG_NANQ) return q + cpuct * (double)p * sqrtNs / (double)(1u + n);
+    return fpu_init + cpuct * (double)p * sqrtNsEps;
+}
+
+// Frontier edge / new root: the state of a node that is not in the tree yet is in sm.st.  Creates the node and its record,
+// runs the terminal test and the valid-move scan (MCTS.py:127-142).  Returns the record offset (AZG_NONE on overflow);
+// *terminal tells whether the new node ended the game (then es[] holds Es).  For a non-terminal leaf the canonical state and
+// valid mask are written to the net's leaf batch.
+template <class G, class HS>
+__device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H, typename Forest<G>::Smem& sm,
+                                             uint64_t h, uint32_t free_slot, int8_t* leaf_states, uint8_t* leaf_valid,
+                                             bool* terminal, float* es) {
+    using FR = Forest<G>;
+    const int l = lane_id();
+    const uint32_t id = FR::create_node(F, t, H, sm.st, h, free_slot);
+    if (id == AZG_NONE) return AZG_NONE;
+    const bool ended = G::game_ended(sm.st, 0, es, sm.mask);                                     // MCTS.py:131
+    int nv = 0;
+    if (!ended) {
         G::valid_mask(sm.st, 0, sm.mask);                                                        // MCTS.py:142
         wave_sync();
-        int nv = 0;
 #pragma unroll
         for (int k = 0; k < G::AW; k++) nv += __popcll(sm.mask[k]);
-        const RowLayout L(nv, F.U);
-        if (H.heap_top + L.total / 16u > F.heap_units) { H.err |= ERR_HEAP_OVERFLOW; H.sim_idx = H.n_sims; continue; }
-        const uint32_t row_off = H.heap_top;
-        H.heap_top += L.total / 16u;
-        uint8_t* row = hp + (size_t)row_off * 16u;
-        uint16_t* ids = (uint16_t*)(row + L.offI);
+    }
+    const RecLayout L(nv, F.U);
+    // 256 units (4 KB) of slack: a level's speculative entry loads may reach 64 entries past a short record
+    if (H.heap_top + L.total / 16u + 256u > F.heap_units) { H.err |= ERR_HEAP_OVERFLOW; return AZG_NONE; }
+    const uint32_t rec_off = H.heap_top;
+    H.heap_top += L.total / 16u;
+    uint8_t* rec = FR::rec_ptr(F, t, rec_off);
+    const uint8_t round = (uint8_t)G::get_round(sm.st);
+    if (l == 0) {
+        RecHdr rh;
+        rh.Ns = 0; rh.Qs = 0.f; rh.node_id = id; rh.nv = (uint16_t)nv; rh.flags = ended ? NF_TERMINAL : 0; rh.round = round;
+#pragma unroll
+        for (int p = 0; p < AZG_MAX_PLAYERS_DEV; p++) rh.Es[p] = (ended && p < G::P) ? es[p] : 0.f;
+        *(RecHdr*)rec = rh;
+        NodeHdr* nh = FR::nhdr(F, t, id);
+        nh->rec_off = rec_off; nh->nv = (uint16_t)nv; nh->round = round; nh->flags = rh.flags;
+    }
+    *terminal = ended;
+    if (!ended) {
+        uint16_t* ids = (uint16_t*)(rec + L.offI);
         for (int a = l; a < G::A; a += 64) {
-            uint64_t w = sm.mask[a >> 6];
-            bool v = (w >> (a & 63)) & 1;
+            const uint64_t w = sm.mask[a >> 6];
+            const bool v = (w >> (a & 63)) & 1;
             if (v) {
                 int rank = __popcll(w & ((1ull << (a & 63)) - 1ull));
                 for (int k = 0; k < (a >> 6); k++) rank += __popcll(sm.mask[k]);
@@ -331,79 +230,303 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
             }
             leaf_valid[(size_t)t * G::A + a] = (uint8_t)v;
         }
-        if (l == 0) {
-            nhp->row_off = row_off; nhp->nv = (uint16_t)nv; nhp->round = (uint8_t)G::get_round(sm.st);
-            nhp->flags = 0; nhp->Ns = 0; nhp->Qs = 0.f;
-#pragma unroll
-            for (int p = 0; p < G::P; p++) nhp->Es[p] = 0.f;
-        }
         FR::store_state_unpadded(leaf_states + (size_t)t * G::S, sm.st);
+    }
+    return rec_off;
+}
+
+// Resolve the child of (parent record, entry j, universe): replay the env step from the parent's state
+// (get_next_best_action_and_canonical_state, MCTS.py:233-248), look the state up, create it if new.
+// Returns child slot value (record offset | next_player << 30) or AZG_NONE on overflow.
+template <class G, class HS>
+__device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& H, typename Forest<G>::Smem& sm,
+                                              uint32_t parent_node, int a, long long seed, int8_t* leaf_states,
+                                              uint8_t* leaf_valid, bool* is_new, bool* terminal, float* es) {
+    using FR = Forest<G>;
+    FR::load_state(sm.st, FR::nstate(F, t, parent_node));
+    int np = 0;
+    Rng no_rng{0, 0, 0};
+    if (lane_id() == 0) np = G::make_move(sm.st, a, 0, seed, no_rng);
+    np = uni_i32(np);
+    wave_sync();
+    if (np != 0) G::swap_players(sm.st, sm.tmp, np);
+    const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
+    uint32_t free_slot;
+    const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot);
+    uint32_t crec;
+    *is_new = false;
+    if (found != AZG_NONE) crec = uni_u32(FR::nhdr(F, t, found)->rec_off);
+    else {
+        const long long t_l = clock64();
+        crec = create_leaf<G, HS>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, terminal, es);
+        H.cyc_leaf += (uint32_t)(clock64() - t_l);
+        if (crec == AZG_NONE) return AZG_NONE;
+        *is_new = true;
+    }
+    return crec | ((uint32_t)np << 30);
+}
+
+// The fields of TreeHdr that k_select keeps live (wave-uniform => SGPRs).  Loading the whole 200-byte header into
+// registers made the kernel spill to scratch; the cold fields are read-modify-written by lane 0 at the end instead.
+struct SelState {
+    uint32_t n_nodes, heap_top, root, root_rec, sim_idx, n_sims, is_full, forced, err, leaf_is_root, mid_sim, cur_rec,
+        cur_depth, cur_pre, status, pending_leaf, path_len, cyc_leaf;
+};
+
+// One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
+template <class G>
+__global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
+                                                  uint8_t* needs_eval) {
+    using FR = Forest<G>;
+    __shared__ typename FR::Smem sm;
+    const int t = blockIdx.x;
+    const int l = lane_id();
+    TreeHdr* Hp = &F.hdr[t];
+    if (uni_u32(Hp->status) != ST_SEARCHING) {
+        if (l == 0) needs_eval[t] = 0;
+        return;
+    }
+    SelState H;
+    H.n_nodes = uni_u32(Hp->n_nodes); H.heap_top = uni_u32(Hp->heap_top); H.root = uni_u32(Hp->root);
+    H.root_rec = uni_u32(Hp->root_rec); H.sim_idx = uni_u32(Hp->sim_idx); H.n_sims = uni_u32(Hp->n_sims);
+    H.is_full = uni_u32(Hp->is_full); H.forced = uni_u32(Hp->forced); H.err = uni_u32(Hp->err);
+    H.leaf_is_root = uni_u32(Hp->leaf_is_root); H.mid_sim = uni_u32(Hp->mid_sim); H.cur_rec = uni_u32(Hp->cur_rec);
+    H.cur_depth = uni_u32(Hp->cur_depth); H.cur_pre = uni_u32(Hp->cur_pre);
+    H.status = ST_SEARCHING; H.pending_leaf = AZG_NONE; H.path_len = 0; H.cyc_leaf = 0;
+    uint8_t* hp = FR::heap(F, t);
+    const uint32_t ES = entry_stride(F.U);
+    bool need_nn = false;
+    uint32_t c_sims = 0, c_levels = 0, c_sumvalid = 0, c_term = 0, levels_this_launch = 0;
+    const long long t_start = clock64();
+    long long cyc_levels = 0, cyc_edge = 0;
+    while (true) {
+        if (H.sim_idx >= H.n_sims || H.err) { H.status = ST_DONE; break; }
+        const int uidx = F.universes > 0 ? (int)(H.sim_idx % (uint32_t)F.universes) : 0;
+        const long long seed = F.universes > 0 ? AZG_MAGIC_SEEDS[uidx] : -1ll;                 // MCTS.py:63
+        int depth = 0, pre = 0;
+        bool have_leaf = false, leaf_terminal = false;
+        float es[G::P];
+        uint32_t rec;
+        if (H.mid_sim) {
+            // resume a descent that the level budget paused in an earlier launch
+            H.mid_sim = 0;
+            rec = H.cur_rec; depth = (int)H.cur_depth; pre = (int)H.cur_pre;
+            const PathEnt* gp0 = F.path + (size_t)t * AZG_MAXD;
+            for (int d = l; d < depth; d += 64) sm.path[d] = gp0[d];
+            wave_sync();
+        } else {
+            c_sims++;
+            H.leaf_is_root = 0;
+            rec = H.root_rec;
+            if (rec == AZG_NONE) {
+                // the root itself is not a node yet: it is the leaf of this simulation (MCTS.py:140-154)
+                FR::load_state(sm.st, F.root_state + (size_t)t * G::SP);
+                const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
+                uint32_t free_slot;
+                const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot);
+                if (found == AZG_NONE) {
+                    rec = create_leaf<G, SelState>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, &leaf_terminal, es);
+                    if (rec == AZG_NONE) continue;
+                    H.root = uni_u32(((const RecHdr*)(hp + (size_t)rec * 16u))->node_id);
+                    H.root_rec = rec;
+                    H.leaf_is_root = 1;
+                    have_leaf = true;
+                } else {
+                    H.root = found;
+                    rec = H.root_rec = uni_u32(FR::nhdr(F, t, found)->rec_off);
+                }
+            }
+        }
+        bool paused = false;
+        while (!have_leaf) {
+            if (F.level_budget > 0 && levels_this_launch >= (uint32_t)F.level_budget) {
+                // time slice: park the descent, resume next launch (the tree contributes no leaf this round)
+                PathEnt* gp0 = F.path + (size_t)t * AZG_MAXD;
+                for (int d = l; d < depth; d += 64) gp0[d] = sm.path[d];
+                H.mid_sim = 1; H.cur_rec = rec; H.cur_depth = (uint32_t)depth; H.cur_pre = (uint32_t)pre;
+                paused = true;
+                break;
+            }
+            levels_this_launch++;
+            const long long t_lvl = clock64();
+            // ---- one level: header + this lane's entry requested together (entry position is independent of nv) ----
+            const uint8_t* rp = hp + (size_t)rec * 16u;
+            const uint8_t* ent = rp + AZG_REC_HDR + (size_t)l * ES;
+            const uint2 pn = *(const uint2*)(ent + AZG_E_P);
+            const double q0 = *(const double*)(ent + AZG_E_Q);
+            const uint32_t ch0 = *(const uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)uidx);
+            const RecHdr rh = load_uniform((const RecHdr*)rp);
+            if (rh.flags & NF_TERMINAL) {                                                       // MCTS.py:136-138
+                c_term++;
+                float v[G::P];
+#pragma unroll
+                for (int p = 0; p < G::P; p++) v[p] = rh.Es[p];
+                FR::backup(F, t, sm.path, depth, v);
+                H.sim_idx++;
+                break;
+            }
+            const int nv = rh.nv;
+            // ---- pick_highest_UCB (MCTS.py:210-230) ----
+            const bool forced = depth == 0 && H.forced;
+            const double sqrtNs = sqrt((double)rh.Ns);
+            const double sqrtNsEps = sqrt((double)rh.Ns + AZG_EPS);
+            const double fpu_init = F.fpu > 0 ? (double)rh.Qs - F.fpu : F.fpu;
+            int j = -1;
+            uint32_t child = AZG_NONE;
+            {
+                float p = __uint_as_float(pn.x);
+                uint32_t n = pn.y;
+                double q = q0;
+                const bool act = l < nv;
+                double best_u = -INFINITY;
+                int best_j = 0x7FFFFFFF;
+                uint32_t best_ch = AZG_NONE;
+                for (int base = 0; base < nv; base += 64) {
+                    uint32_t chv = ch0;
+                    bool a_ok = act;
+                    if (base > 0) {
+                        const int jj = base + l;
+                        a_ok = jj < nv;
+                        const uint8_t* e2 = rp + AZG_REC_HDR + (size_t)(a_ok ? jj : 0) * ES;
+                        p = *(const float*)(e2 + AZG_E_P);
+                        n = *(const uint32_t*)(e2 + AZG_E_N);
+                        q = *(const double*)(e2 + AZG_E_Q);
+                        chv = *(const uint32_t*)(e2 + AZG_E_C + 4u * (uint32_t)uidx);
+                    }
+                    if (forced) {                                                 // :218-220 first deficient action wins
+                        const double thr = sqrt(0.5 * (double)p * (double)H.sim_idx);
+                        const uint64_t def = __ballot(a_ok && ((long long)n < (long long)thr));
+                        if (def) {
+                            const int src = first_lane(def);
+                            j = base + src;
+                            child = uni_u32(__shfl(chv, src, 64));
+                            break;
+                        }
+                    }
+                    double u = ucb_score(p, n, q, F.cpuct, sqrtNs, sqrtNsEps, fpu_init);
+                    if (!a_ok) u = -INFINITY;
+                    const int jj = a_ok ? base + l : 0x7FFFFFFF;
+                    const bool take = (u > best_u) || (u == best_u && jj < best_j);
+                    best_u = take ? u : best_u;
+                    best_j = take ? jj : best_j;
+                    best_ch = take ? chv : best_ch;
+                }
+                if (j < 0) {
+                    // wave arg-max, lowest index on ties (== ascending scan with strict '>', MCTS.py:216-228): reduce the
+                    // f64 maximum, then the FIRST lane (lowest entry index of its chunk) holding it wins; across chunks the
+                    // per-lane running best already prefers the earlier chunk on ties.
+                    double mx = best_u;
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) { const double o = shfl_xor_f64(mx, m); mx = o > mx ? o : mx; }
+                    const uint64_t hit = __ballot(best_u == mx && best_j != 0x7FFFFFFF);
+                    // several lanes can tie with different chunks' indices only when nv > 64: pick the lowest index
+                    int src = first_lane(hit);
+                    if (nv > 64) {
+                        int cand = (best_u == mx) ? best_j : 0x7FFFFFFF;
+#pragma unroll
+                        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(cand, m, 64); cand = o < cand ? o : cand; }
+                        src = cand & 63;
+                    }
+                    j = uni_i32(__shfl(best_j, src, 64));
+                    child = uni_u32(__shfl(best_ch, src, 64));
+                }
+            }
+            c_levels++;
+            c_sumvalid += (uint32_t)nv;
+            cyc_levels += clock64() - t_lvl;
+            if (depth >= AZG_MAXD - 1) { H.err |= ERR_DEPTH_OVERFLOW; H.sim_idx = H.n_sims; break; }
+            if (child == AZG_NONE) {
+                const RecLayout L(nv, F.U);
+                const int a = (int)uni_u32(((const uint16_t*)(rp + L.offI))[j]);
+                bool is_new = false;
+                const long long t_e = clock64();
+                child = resolve_edge<G, SelState>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es);
+                cyc_edge += clock64() - t_e;
+                if (child == AZG_NONE) { H.sim_idx = H.n_sims; break; }
+                if (l == 0) *(uint32_t*)((uint8_t*)rp + AZG_REC_HDR + (size_t)j * ES + AZG_E_C + 4u * (uint32_t)uidx) = child;
+                have_leaf = is_new;
+            }
+            const int np = (int)(child >> 30);
+            if (l == 0) {
+                PathEnt e; e.rec = rec; e.j = (uint16_t)j; e.np = (uint8_t)np; e.pre = (uint8_t)pre;
+                sm.path[depth] = e;
+            }
+            wave_sync();
+            pre = (pre + np) % G::P;
+            depth++;
+            rec = child & AZG_CHILD_IDX_MASK;
+        }
+        if (paused) break;
+        if (!have_leaf) continue;
+        if (leaf_terminal) {                                                                      // MCTS.py:132-135
+            c_term++;
+            FR::backup(F, t, sm.path, depth, es);
+            H.sim_idx++;
+            continue;
+        }
         PathEnt* gp = F.path + (size_t)t * AZG_MAXD;
         for (int d = l; d < depth; d += 64) gp[d] = sm.path[d];
-        H.pending_leaf = node;
+        H.pending_leaf = rec;
         H.path_len = (uint32_t)depth;
         H.status = ST_WAIT_NN;
         need_nn = true;
         break;
     }
-    if (H.n_nodes > H.max_nodes_seen) H.max_nodes_seen = H.n_nodes;
     if (l == 0) {
-        F.hdr[t] = H;
+        Hp->n_nodes = H.n_nodes; Hp->heap_top = H.heap_top; Hp->root = H.root; Hp->root_rec = H.root_rec;
+        Hp->sim_idx = H.sim_idx; Hp->err = H.err; Hp->leaf_is_root = H.leaf_is_root; Hp->mid_sim = H.mid_sim;
+        Hp->cur_rec = H.cur_rec; Hp->cur_depth = H.cur_depth; Hp->cur_pre = H.cur_pre; Hp->status = H.status;
+        Hp->pending_leaf = H.pending_leaf; Hp->path_len = H.path_len;
+        if (H.n_nodes > Hp->max_nodes_seen) Hp->max_nodes_seen = H.n_nodes;
+        Hp->c_sims += c_sims; Hp->c_levels += c_levels; Hp->c_sumvalid += c_sumvalid; Hp->c_term += c_term;
+        Hp->cyc_select += (uint64_t)(clock64() - t_start); Hp->cyc_levels += (uint64_t)cyc_levels;
+        Hp->cyc_edge += (uint64_t)cyc_edge; Hp->cyc_leaf += (uint64_t)H.cyc_leaf;
         needs_eval[t] = need_nn ? 1 : 0;
     }
 }
 
 // One lock-step round, part 2: store (Ps, v) on the pending leaf and back up (MCTS.py:144-154,176-183).
 template <class G>
-__global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* pi, const float* vin,
-                                                      const double* root_noise, int noise_stride) {
+__global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* pi, const float* vin, int noise_enabled) {
     using FR = Forest<G>;
     __shared__ __attribute__((aligned(16))) float dense[G::A];
-    __shared__ __attribute__((aligned(16))) uint64_t mask[G::AW];
     __shared__ __attribute__((aligned(16))) PathEnt path[AZG_MAXD];
     const int t = blockIdx.x;
     const int l = lane_id();
-    TreeHdr H = load_uniform(&F.hdr[t]);
-    if (H.status != ST_WAIT_NN) return;
-    const uint32_t leaf = H.pending_leaf;
-    NodeHdr* nhp = FR::nhdr(F, t, leaf);
-    const int nv = nhp->nv;
-    const RowLayout L(nv, F.U);
-    uint8_t* row = FR::heap(F, t) + (size_t)nhp->row_off * 16u;
-    const uint16_t* ids = (const uint16_t*)(row + L.offI);
+    if (uni_u32(F.hdr[t].status) != ST_WAIT_NN) return;
+    struct { uint32_t pending_leaf, path_len, leaf_is_root, sim_idx, is_full; uint64_t c_exp, c_depth; } H;
+    H.pending_leaf = uni_u32(F.hdr[t].pending_leaf); H.path_len = uni_u32(F.hdr[t].path_len);
+    H.leaf_is_root = uni_u32(F.hdr[t].leaf_is_root); H.sim_idx = uni_u32(F.hdr[t].sim_idx); H.is_full = uni_u32(F.hdr[t].is_full);
+    H.c_exp = F.hdr[t].c_exp; H.c_depth = F.hdr[t].c_depth;
+    uint8_t* rec = FR::rec_ptr(F, t, H.pending_leaf);
+    RecHdr* rhp = (RecHdr*)rec;
+    const int nv = (int)uni_u32((uint32_t)rhp->nv);
+    const RecLayout L(nv, F.U);
+    const uint16_t* ids = (const uint16_t*)(rec + L.offI);
     for (int i = l; i < G::A; i += 64) dense[i] = pi[(size_t)t * G::A + i];
     const int depth = (int)H.path_len;
     const PathEnt* gp = F.path + (size_t)t * AZG_MAXD;
     for (int d = l; d < depth; d += 64) path[d] = gp[d];
     wave_sync();
-    const bool gen_noise = (root_noise == nullptr && noise_stride == -1 && F.dirichletAlpha != 0.0);
-    const bool dir_now = (H.leaf_is_root && H.sim_idx == 0 && H.is_full && (root_noise != nullptr || gen_noise));
-    if (dir_now) {                                                                               // MCTS.py:147-149
-        if (l < G::AW) mask[l] = 0ull;
-        wave_sync();
-        if (l == 0)
-            for (int j = 0; j < nv; j++) mask[ids[j] >> 6] |= 1ull << (ids[j] & 63);
-        wave_sync();
-        FR::root_noise_dense(dense, mask, F.temp_root,
-                             root_noise ? root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride) : nullptr,
-                             root_noise != nullptr && noise_stride < 0, F.dirichletAlpha,
-                             mix64(mix64(F.rng_seed ^ 0xA5A5A5A55A5A5A5AULL) + F.stream0 + (uint64_t)t), H.c_sims << 20);
-        float* Prow = (float*)row;
-        for (int j = l; j < nv; j += 64) Prow[j] = dense[ids[j]];
-    } else {
-        const float s = np_sum_f32(dense, G::A);                                                 // normalise :150,250-253
-        float* Prow = (float*)row;
-        for (int j = l; j < nv; j += 64) Prow[j] = dense[ids[j]] / s;
+    // a root expanded by simulation 0 of a full search gets root noise (MCTS.py:147-149): keep the RAW net output in the
+    // entries and let k_root_noise do softmax -> noise -> normalise; every other leaf is normalised here (:150,250-253)
+    const bool dir_now = (noise_enabled && H.leaf_is_root && H.sim_idx == 0 && H.is_full && F.dirichletAlpha != 0.0);
+    float s = 1.f;
+    if (!dir_now) s = np_sum_f32(dense, G::A);
+    for (int j = l; j < nv; j += 64) {                                                           // :40-41,150-152
+        uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
+        *(float*)(ent + AZG_E_P) = dir_now ? dense[ids[j]] : dense[ids[j]] / s;
+        *(uint32_t*)(ent + AZG_E_N) = 0u;
+        *(double*)(ent + AZG_E_Q) = AZG_NANQ;
+        for (int u = 0; u < F.U; u++) *(uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)u) = AZG_NONE;
     }
-    uint32_t* Nrow = (uint32_t*)(row + L.offN);
-    double* Qrow = (double*)(row + L.offQ);
-    uint32_t* crow = (uint32_t*)(row + L.offC);
-    for (int j = l; j < nv; j += 64) { Nrow[j] = 0u; Qrow[j] = AZG_NANQ; }                       // :40-41,152
-    for (int j = l; j < (int)((L.offI - L.offC) / 4u); j += 64) crow[j] = AZG_NONE;     // whole aligned section
     float v[G::P];
 #pragma unroll
     for (int p = 0; p < G::P; p++) v[p] = vin[(size_t)t * G::P + p];
-    if (l == 0) { nhp->Ns = 0; nhp->Qs = v[0]; nhp->flags = NF_EXPANDED; }                        // :152-153
+    if (l == 0) {                                                                                // :152-153
+        rhp->Ns = 0; rhp->Qs = v[0]; rhp->flags = NF_EXPANDED;
+        FR::nhdr(F, t, rhp->node_id)->flags = NF_EXPANDED;
+    }
     FR::backup(F, t, path, depth, v);                                                            // leaf returns v :154
     if (l == 0) {
         TreeHdr* Hp = &F.hdr[t];
@@ -412,6 +535,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* 
         Hp->pending_leaf = AZG_NONE;
         Hp->c_exp = H.c_exp + 1;
         Hp->c_depth = H.c_depth + (uint64_t)depth;
+        if (dir_now) Hp->noise_pending = 2u;
     }
 }
 
@@ -423,25 +547,27 @@ __device__ bool root_counts(const ForestDev& F, int t, const TreeHdr& H, int* cn
     const int l = lane_id();
     for (int i = l; i < G::A; i += 64) cnt[i] = 0;
     wave_sync();
-    if (H.root == AZG_NONE) return false;
-    const NodeHdr nh = *FR::nhdr(F, t, H.root);
-    const float q0 = nh.Qs;                                                                      // :71-72
+    if (H.root_rec == AZG_NONE) return false;
+    const uint8_t* rec = FR::rec_ptr(F, t, H.root_rec);
+    const RecHdr rh = load_uniform((const RecHdr*)rec);
+    const float q0 = rh.Qs;                                                                      // :71-72
 #pragma unroll
     for (int p = 0; p < G::P; p++) q[p] = p == 0 ? q0 : -q0 / (float)(G::P - 1);
-    if (!(nh.flags & NF_EXPANDED)) return false;
-    const RowLayout L(nh.nv, F.U);
-    const uint8_t* row = FR::heap(F, t) + (size_t)nh.row_off * 16u;
-    const float* Prow = (const float*)row;
-    const uint32_t* Nrow = (const uint32_t*)(row + L.offN);
-    const uint16_t* ids = (const uint16_t*)(row + L.offI);
+    if (!(rh.flags & NF_EXPANDED)) return false;
+    const RecLayout L(rh.nv, F.U);
+    const uint16_t* ids = (const uint16_t*)(rec + L.offI);
     int best = 0;
-    for (int j = l; j < nh.nv; j += 64) { int n = (int)Nrow[j]; best = n > best ? n : best; }
+    for (int j = l; j < rh.nv; j += 64) {
+        int n = (int)*(const uint32_t*)(rec + AZG_REC_HDR + (size_t)j * L.ES + AZG_E_N);
+        best = n > best ? n : best;
+    }
     best = wave_max_i32(best);
-    for (int j = l; j < nh.nv; j += 64) {
-        int c = (int)Nrow[j];
+    for (int j = l; j < rh.nv; j += 64) {
+        const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
+        int c = (int)*(const uint32_t*)(ent + AZG_E_N);
         if (H.forced) {                                                                          // :75-80
             if (c != best) {
-                float tq = (0.5f * Prow[j]) * (float)H.n_sims;       // plain-Python NumPy scalar typing (see oracle)
+                float tq = (0.5f * *(const float*)(ent + AZG_E_P)) * (float)H.n_sims;   // plain-Python NumPy scalar typing
                 c = c - (int)sqrt((double)tq);
             }
             c = c > 1 ? c : 0;
@@ -458,7 +584,7 @@ __global__ __launch_bounds__(64) void k_action_probs(ForestDev F, double temp, d
     __shared__ int cnt[G::A];
     const int t = blockIdx.x;
     const int l = lane_id();
-    const TreeHdr H = F.hdr[t];
+    const TreeHdr H = load_uniform(&F.hdr[t]);
     float q[G::P];
 #pragma unroll
     for (int p = 0; p < G::P; p++) q[p] = 0.f;
@@ -487,26 +613,27 @@ __global__ __launch_bounds__(64) void k_root_stats(ForestDev F, int32_t* Ns, flo
     using FR = Forest<G>;
     const int t = blockIdx.x;
     const int l = lane_id();
-    const TreeHdr H = F.hdr[t];
+    const TreeHdr H = load_uniform(&F.hdr[t]);
     if (n_nodes && l == 0) n_nodes[t] = (int32_t)H.n_nodes;
     for (int a = l; a < G::A; a += 64) {
         if (Nsa) Nsa[(size_t)t * G::A + a] = 0;
         if (Qsa) Qsa[(size_t)t * G::A + a] = AZG_NANQ;
         if (Ps) Ps[(size_t)t * G::A + a] = 0.f;
     }
-    if (H.root == AZG_NONE) { if (l == 0) { if (Ns) Ns[t] = -1; if (Qs) Qs[t] = 0.f; } return; }
-    const NodeHdr nh = *FR::nhdr(F, t, H.root);
-    if (l == 0) { if (Ns) Ns[t] = (int32_t)nh.Ns; if (Qs) Qs[t] = nh.Qs; }
-    if (!(nh.flags & NF_EXPANDED)) return;
+    if (H.root_rec == AZG_NONE) { if (l == 0) { if (Ns) Ns[t] = -1; if (Qs) Qs[t] = 0.f; } return; }
+    const uint8_t* rec = FR::rec_ptr(F, t, H.root_rec);
+    const RecHdr rh = load_uniform((const RecHdr*)rec);
+    if (l == 0) { if (Ns) Ns[t] = (int32_t)rh.Ns; if (Qs) Qs[t] = rh.Qs; }
+    if (!(rh.flags & NF_EXPANDED)) return;
     __syncthreads();
-    const RowLayout L(nh.nv, F.U);
-    const uint8_t* row = FR::heap(F, t) + (size_t)nh.row_off * 16u;
-    const uint16_t* ids = (const uint16_t*)(row + L.offI);
-    for (int j = l; j < nh.nv; j += 64) {
-        int a = ids[j];
-        if (Nsa) Nsa[(size_t)t * G::A + a] = (int32_t)((const uint32_t*)(row + L.offN))[j];
-        if (Qsa) Qsa[(size_t)t * G::A + a] = ((const double*)(row + L.offQ))[j];
-        if (Ps) Ps[(size_t)t * G::A + a] = ((const float*)row)[j];
+    const RecLayout L(rh.nv, F.U);
+    const uint16_t* ids = (const uint16_t*)(rec + L.offI);
+    for (int j = l; j < rh.nv; j += 64) {
+        const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
+        const int a = ids[j];
+        if (Nsa) Nsa[(size_t)t * G::A + a] = (int32_t)*(const uint32_t*)(ent + AZG_E_N);
+        if (Qsa) Qsa[(size_t)t * G::A + a] = *(const double*)(ent + AZG_E_Q);
+        if (Ps) Ps[(size_t)t * G::A + a] = *(const float*)(ent + AZG_E_P);
     }
 }
 

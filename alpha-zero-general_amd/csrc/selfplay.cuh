@@ -15,95 +15,105 @@ __device__ __forceinline__ double temp_for_selfplay(const ForestDev& F, int n) {
     return te + (tb - te) * pow(0.5, (double)n / hl);
 }
 
-__device__ __forceinline__ uint32_t remap_child(const uint32_t* map, uint32_t w, bool in_range, uint32_t n) {
-    if (!in_range || w == AZG_NONE) return w;
-    const uint32_t idx = w & AZG_CHILD_IDX_MASK;
-    if (idx >= n) return AZG_NONE;
-    const uint32_t m = map[idx];
-    return (m == AZG_NONE) ? AZG_NONE : ((w & ~AZG_CHILD_IDX_MASK) | m);
-}
-
 // Drop every node that can no longer be reached: round < root_round (the move counter is part of the state, so such
 // states cannot recur).  Equivalent to -- and stricter in memory than -- the reference's lazy clean-up MCTS.py:86-91,
 // which removes nodes with round < r-5 every >20 rounds.  In-place sliding compaction by the tree's own wave:
-//   pass 1  old id -> new id map (stored in the hash-table memory, rebuilt afterwards)
-//   pass 2  slide headers / states / rows down, rewrite cached child ids through the map
-//   pass 3  clear + re-insert the hash table
+//   pass 1  per node: keep?, new node id, new record offset (wave prefix sums); both maps live in the hash-table memory
+//   pass 2  rewrite the child slots of every kept record (old record offset -> child's node id -> new record offset)
+//   pass 3  slide records / states / cold headers down (dst <= src, forward copies), fix RecHdr.node_id
+//   pass 4  clear + re-insert the hash table
+// Every control value is made explicitly wave-uniform (readfirstlane) so the barriers sit in uniform control flow.
 template <class G>
-__device__ void gc_tree(const ForestDev& F, int t, TreeHdr& H, int min_round) {
+__device__ __noinline__ void gc_tree(const ForestDev& F, int t, TreeHdr& H, int min_round) {
     using FR = Forest<G>;
     const int l = lane_id();
-    uint32_t* map = FR::htab(F, t);          // HT >= 2*cap entries
+    uint32_t* map_id = FR::htab(F, t);               // [cap]   (HT >= 2*cap)
+    uint32_t* map_rec = map_id + F.cap;              // [cap]
     uint8_t* hp = FR::heap(F, t);
     const uint32_t n = H.n_nodes;
+    const uint32_t ES = entry_stride(F.U);
     // pass 1
-    uint32_t kept = 0;
+    uint32_t kept = 0, top = 0;
     for (uint32_t base = 0; base < n; base += 64) {
-        uint32_t i = base + l;
+        const uint32_t i = base + l;
         bool keep = false;
+        uint32_t units = 0;
         if (i < n) {
             const NodeHdr* nh = FR::nhdr(F, t, i);
             keep = (int)nh->round >= min_round || i == H.root;
+            units = RecLayout(nh->nv, F.U).total / 16u;
         }
-        uint64_t b = __ballot(keep);
-        uint32_t rank = (uint32_t)__popcll(b & ((1ull << l) - 1ull));
-        if (i < n) map[i] = keep ? kept + rank : AZG_NONE;
+        const uint64_t b = __ballot(keep);
+        const uint32_t rank = (uint32_t)__popcll(b & ((1ull << l) - 1ull));
+        uint32_t incl = keep ? units : 0u;           // inclusive prefix sum of kept record sizes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (l >= d) incl += o;
+        }
+        if (i < n) {
+            map_id[i] = keep ? kept + rank : AZG_NONE;
+            map_rec[i] = keep ? top + incl - units : AZG_NONE;
+        }
         kept += (uint32_t)__popcll(b);
+        top += uni_u32(__shfl(incl, 63, 64));
     }
-    __threadfence_block();
     wave_sync();
-    // pass 2 (sequential over nodes, wave-parallel inside a node; dst <= src so forward copies are safe).
-    // Every control value is made explicitly wave-uniform (readfirstlane) so that the barriers below sit in
-    // provably uniform control flow.
-    uint32_t heap_top = 0;
+    // pass 2: child slots (records are still at their old places, so a child's node id can be read from its header)
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t ni = uni_u32(map[i]);
+        if (uni_u32(map_id[i]) == AZG_NONE) continue;
+        const NodeHdr nh = *FR::nhdr(F, t, i);
+        const uint32_t nv = uni_u32((uint32_t)nh.nv);
+        if (!(uni_u32((uint32_t)nh.flags) & NF_EXPANDED)) continue;
+        uint8_t* rec = hp + (size_t)uni_u32(nh.rec_off) * 16u;
+        const uint32_t slots = nv * (uint32_t)F.U;
+        for (uint32_t k = l; k < slots; k += 64) {
+            uint32_t* sp = (uint32_t*)(rec + AZG_REC_HDR + (size_t)(k / (uint32_t)F.U) * ES + AZG_E_C + 4u * (k % (uint32_t)F.U));
+            const uint32_t c = *sp;
+            if (c != AZG_NONE) {
+                const uint32_t cid = ((const RecHdr*)(hp + (size_t)(c & AZG_CHILD_IDX_MASK) * 16u))->node_id;
+                const uint32_t nr = cid < n ? map_rec[cid] : AZG_NONE;
+                *sp = nr == AZG_NONE ? AZG_NONE : ((c & ~AZG_CHILD_IDX_MASK) | nr);
+            }
+        }
+    }
+    wave_sync();
+    // pass 3: slide (ascending node order == ascending record order)
+    uint32_t new_root = AZG_NONE, new_root_rec = AZG_NONE;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t ni = uni_u32(map_id[i]);
         if (ni != AZG_NONE) {
             NodeHdr nh = *FR::nhdr(F, t, i);
-            const uint32_t old_off = uni_u32(nh.row_off);
-            const uint32_t nv = uni_u32((uint32_t)nh.nv);
-            const bool has_row = old_off != AZG_NONE;
-            const RowLayout L((int)nv, F.U);
-            const uint32_t units = has_row ? L.total / 16u : 0u;
-            if (has_row) {
+            const uint32_t old_off = uni_u32(nh.rec_off);
+            const uint32_t new_off = uni_u32(map_rec[i]);
+            const uint32_t units = RecLayout((int)uni_u32((uint32_t)nh.nv), F.U).total / 16u;
+            if (new_off != old_off) {
                 const uint4* src = (const uint4*)(hp + (size_t)old_off * 16u);
-                uint4* dst = (uint4*)(hp + (size_t)heap_top * 16u);
-                const uint32_t c0 = L.offC / 16u, c1 = L.offI / 16u;     // child section in 16-byte units
-                const uint32_t n_child = nv * (uint32_t)F.U;
+                uint4* dst = (uint4*)(hp + (size_t)new_off * 16u);
                 for (uint32_t base = 0; base < units; base += 64) {
                     const uint32_t k = base + (uint32_t)l;
-                    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-                    if (k < units) {
-                        const uint4 v = src[k];
-                        w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
-                        if (k >= c0 && k < c1) {
-                            const uint32_t e = (k - c0) * 4u;
-                            w0 = remap_child(map, w0, e + 0u < n_child, n);
-                            w1 = remap_child(map, w1, e + 1u < n_child, n);
-                            w2 = remap_child(map, w2, e + 2u < n_child, n);
-                            w3 = remap_child(map, w3, e + 3u < n_child, n);
-                        }
-                    }
-                    wave_sync();                   // every lane has read its chunk before anyone overwrites it
-                    if (k < units) dst[k] = make_uint4(w0, w1, w2, w3);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (k < units) v = src[k];
+                    wave_sync();                       // every lane has read its chunk before anyone overwrites it
+                    if (k < units) dst[k] = v;
                     wave_sync();
                 }
-                nh.row_off = heap_top;
             }
+            if (l == 0) ((RecHdr*)(hp + (size_t)new_off * 16u))->node_id = ni;
             if (ni != i) {
                 const uint32_t* ssrc = (const uint32_t*)FR::nstate(F, t, i);
                 uint32_t* sdst = (uint32_t*)FR::nstate(F, t, ni);
                 for (int k = l; k < FR::SPW; k += 64) sdst[k] = ssrc[k];
             }
+            nh.rec_off = new_off;
             if (l == 0) *FR::nhdr(F, t, ni) = nh;
-            heap_top += units;
+            if (i == H.root) { new_root = ni; new_root_rec = new_off; }
         }
         wave_sync();
     }
-    heap_top = uni_u32(heap_top);
-    if (H.root != AZG_NONE) H.root = map[H.root];
-    // pass 3
-    wave_sync();
+    H.root = new_root;
+    H.root_rec = new_root_rec;
+    // pass 4
     uint32_t* tab = FR::htab(F, t);
     for (int i = l; i < F.HT; i += 64) tab[i] = AZG_NONE;
     wave_sync();
@@ -118,7 +128,7 @@ __device__ void gc_tree(const ForestDev& F, int t, TreeHdr& H, int min_round) {
     }
     wave_sync();
     H.n_nodes = kept;
-    H.heap_top = heap_top;
+    H.heap_top = uni_u32(top);
     H.gc_runs++;
 }
 
@@ -126,7 +136,7 @@ template <class G>
 __device__ void reset_tree(const ForestDev& F, int t, TreeHdr& H) {
     uint32_t* tab = Forest<G>::htab(F, t);
     for (int i = lane_id(); i < F.HT; i += 64) tab[i] = AZG_NONE;
-    H.n_nodes = 0; H.heap_top = 0; H.root = AZG_NONE;
+    H.n_nodes = 0; H.heap_top = 0; H.root = AZG_NONE; H.root_rec = AZG_NONE;
     wave_sync();
 }
 
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(64) void k_selfplay_start(ForestDev F, const int8_t
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
     const int t = blockIdx.x;
-    TreeHdr H = F.hdr[t];
+    TreeHdr H = load_uniform(&F.hdr[t]);
     Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, 0ull};
     H.err = 0; H.games_done = 0; H.gc_runs = 0; H.max_nodes_seen = 0;
     H.c_sims = H.c_levels = H.c_exp = H.c_sumvalid = H.c_term = H.c_depth = H.c_plies = H.c_examples = 0;
@@ -173,8 +183,8 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     __shared__ double w[G::A];
     const int t = blockIdx.x;
     const int l = lane_id();
+    if (uni_u32(F.hdr[t].status) != ST_DONE) return;
     TreeHdr H = load_uniform(&F.hdr[t]);
-    if (H.status != ST_DONE) return;
     if (H.err) return;                         // tree is parked; the host reads the error flag
     Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, H.rng_counter};
     float q[G::P];
@@ -226,12 +236,12 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
                 F.rec_valid[r * G::A + a] = 0;
             }
             wave_sync();
-            if (H.root != AZG_NONE) {
-                const NodeHdr nh = *FR::nhdr(F, t, H.root);
-                if (nh.flags & NF_EXPANDED) {
-                    const RowLayout L(nh.nv, F.U);
-                    const uint16_t* ids = (const uint16_t*)(FR::heap(F, t) + (size_t)nh.row_off * 16u + L.offI);
-                    for (int j = l; j < nh.nv; j += 64) F.rec_valid[r * G::A + ids[j]] = 1;
+            if (H.root_rec != AZG_NONE) {
+                const uint8_t* rrec = FR::rec_ptr(F, t, H.root_rec);
+                const RecHdr rh = load_uniform((const RecHdr*)rrec);
+                if (rh.flags & NF_EXPANDED) {
+                    const uint16_t* ids = (const uint16_t*)(rrec + RecLayout(rh.nv, F.U).offI);
+                    for (int j = l; j < rh.nv; j += 64) F.rec_valid[r * G::A + ids[j]] = 1;
                 }
             }
             if (l == 0) {
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     // ---- memory reclamation, then the next search ----
     const int new_round = G::get_round(sm.st);
     if (!ended && (H.n_nodes + (uint32_t)F.numMCTSSims + 8u > (uint32_t)F.cap ||
-                   H.heap_top + (uint32_t)(F.numMCTSSims + 8) * (RowLayout(G::A < 96 ? G::A : 96, F.U).total / 16u) >
+                   H.heap_top + (uint32_t)(F.numMCTSSims + 8) * (RecLayout(G::A < 96 ? G::A : 96, F.U).total / 16u) + 256u >
                        F.heap_units)) {
         // locate the new root first so that GC can keep it
         uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);

@@ -185,6 +185,13 @@ class SplendorV80Hip(SplendorV80):
         self.pi = torch.empty((B, self.A), dtype=f, device=d)
         self.v = torch.empty((B, self.P), dtype=f, device=d)
 
+    def clone_buffers(self):
+        """a second evaluator sharing the (read-only) weights but with its own activation buffers (concurrent streams)"""
+        import copy
+        other = copy.copy(self)
+        other._alloc(self.maxB)
+        return other
+
     def _stream(self):
         import ctypes as C
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,46 +1,89 @@
 """Coach.executeEpisodes on the engine (Coach.py:86-148): T games per GPU, device-resident episode state machines, one
 batched NeuralNet.predict per lock-step round.  The reference time-slices N game threads on one core around a lock ring
 to build inference batches of N (Coach.py:117-144); here every round is
-    select (HIP) -> predict_batch (PyTorch-ROCm, MFMA GEMMs) -> expand_backup (HIP) -> selfplay_advance (HIP)
-with no host decision in the loop, so it can be captured once in a HIP graph and replayed."""
+    select (HIP) -> predict_batch (MFMA net kernels) -> expand_backup (HIP) -> selfplay_advance (HIP)
+with no host decision in the loop, so it is captured once in a HIP graph and replayed.
+
+The descent kernel is a latency chain (few waves, each waiting on dependent loads) while the net is throughput bound, so
+the games are split into `groups` independent forests whose rounds are skewed by one stage and run on separate HIP
+streams inside the same graph: while group 0 descends its trees, group 1's leaves are in the net, and vice versa."""
 import torch
 
 from .forest import Forest
 
 
+class _Group:
+    def __init__(self, forest, net, shape, device_noise):
+        self.f, self.net, self.shape, self.device_noise = forest, net, shape, device_noise
+
+    def select(self):
+        self.f.select(device_noise=self.device_noise)
+
+    def predict_expand_advance(self):
+        f = self.f
+        pi, v = self.net.predict_batch(f.leaf_states.view(self.shape), f.leaf_valid)
+        f.expand_backup(pi, v, device_noise=self.device_noise)
+        f.selfplay_advance()
+
+
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
-                 use_graph=True, dirichlet=None):
-        self.game, self.nnet, self.args = game, nnet, args
+                 use_graph=True, dirichlet=None, level_budget=0, groups=1):
+        self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
         cap = node_capacity or max(1024, 8 * sims)
-        self.T = n_games
-        self.forest = Forest(game.GAME_ID, game.variant, n_games, args, node_capacity=cap,
-                             max_examples=max_examples or n_games * 64, rng_seed=rng_seed, stream0=stream0,
-                             device=str(game.device))
-        self.alpha = float(get('dirichletAlpha', 0.0)) if dirichlet is None else float(dirichlet)
-        self.shape = (n_games,) + tuple(self.forest.board_shape())
-        dev = self.forest.device
+        assert n_games % groups == 0
+        self.T, self.G = n_games, groups
+        Tg = n_games // groups
+        alpha = float(get('dirichletAlpha', 0.0)) if dirichlet is None else float(dirichlet)
         # Coach passes dirichlet_noise=(dirichletAlpha != 0) (Coach.py:31,96).  The Gamma variates of
         # rng.dirichlet([alpha]*n_valid) (MCTS.py:187-192) are drawn on device by the engine's own sampler.
-        self.device_noise = self.alpha != 0.0
+        nets = nnet if isinstance(nnet, (list, tuple)) else [nnet] + [nnet.clone_buffers() for _ in range(groups - 1)]
+        self.groups = []
+        for g in range(groups):
+            f = Forest(game.GAME_ID, game.variant, Tg, args, node_capacity=cap,
+                       max_examples=(max_examples or n_games * 64) // groups, rng_seed=rng_seed,
+                       stream0=stream0 + g * Tg, device=str(game.device), level_budget=level_budget)
+            self.groups.append(_Group(f, nets[g], (Tg,) + tuple(f.board_shape()), alpha != 0.0))
+        self.forest = self.groups[0].f
+        self.nnet = nets[0]
         self.use_graph = use_graph
         self.graph = None
         self.rounds = 0
-        self._pi = self._v = None
+        self._streams = [torch.cuda.Stream() for _ in range(groups)] if groups > 1 else None
 
     def start(self, init_boards=None):
-        self.forest.selfplay_start(init_boards)
+        Tg = self.T // self.G
+        for g, grp in enumerate(self.groups):
+            grp.f.selfplay_start(None if init_boards is None else init_boards[g * Tg:(g + 1) * Tg])
+        torch.cuda.synchronize()
+        # pipeline prologue: odd groups enter the steady state one stage ahead (their leaves are already selected)
+        for g, grp in enumerate(self.groups):
+            if g % 2 == 1:
+                grp.select()
         torch.cuda.synchronize()
 
     def _round(self):
-        f = self.forest
-        f.select(device_noise=self.device_noise)
-        pi, v = self.nnet.predict_batch(f.leaf_states.view(self.shape), f.leaf_valid)
-        self._pi, self._v = pi, v
-        f.expand_backup(pi, v, device_noise=self.device_noise)
-        f.selfplay_advance()
+        """one round of every group; group g's stage order is rotated by g (software-pipeline skew)"""
+        if self.G == 1:
+            grp = self.groups[0]
+            grp.select()
+            grp.predict_expand_advance()
+            return
+        cur = torch.cuda.current_stream()
+        for g, grp in enumerate(self.groups):
+            s = self._streams[g]
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                if g % 2 == 0:
+                    grp.select()
+                    grp.predict_expand_advance()
+                else:
+                    grp.predict_expand_advance()
+                    grp.select()
+        for s in self._streams:
+            cur.wait_stream(s)
 
     def capture(self):
         """Capture one round in a HIP graph (after a few eager warm-up rounds on a side stream)."""
@@ -69,12 +112,25 @@ class SelfPlayEngine:
         self.rounds += rounds
 
     def stats(self):
-        return self.forest.stats()
+        tot = None
+        for grp in self.groups:
+            s = grp.f.stats()
+            if tot is None:
+                tot = dict(s)
+            else:
+                for k, v in s.items():
+                    tot[k] = max(tot[k], v) if k == 'max_nodes' else (tot[k] | v if k == 'errors' else tot[k] + v)
+        return tot
+
+    @property
+    def device_bytes(self):
+        return sum(grp.f.device_bytes for grp in self.groups)
 
     def drain_examples(self):
         """-> (boards int8[n,S], pi f32[n,A], z f32[n,P], valids u8[n,A], q f32[n,P], meta i32[n,4]) of finished games
         (Coach.py:76-82 record layout, un-augmented; symmetries are applied by the consumer)."""
-        return self.forest.drain_examples()
+        parts = [grp.f.drain_examples() for grp in self.groups]
+        return tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(6))
 
 
 def gather_examples(tensors, group=None):

@@ -104,6 +104,8 @@ def main():
     ap.add_argument('--sims', type=int, default=800)
     ap.add_argument('--node-capacity', type=int, default=0)
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--groups', type=int, default=1, help='independent forests with skewed rounds on separate streams')
+    ap.add_argument('--level-budget', type=int, default=0, help='max descent levels per tree per select launch (0 = unlimited)')
     ap.add_argument('--net-dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--net', default='hip', choices=['hip', 'torch'], help='hip: engine MFMA kernels; torch: PyTorch-ROCm ops')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -136,14 +138,14 @@ def main():
     pretrained = os.path.exists(WEIGHTS)
     if a.net == 'hip':
         assert a.net_dtype == 'fp32'
-        net = SplendorV80Hip.from_npz(WEIGHTS, device=dev, max_batch=T) if pretrained else \
-            SplendorV80Hip.random_init(device=dev, max_batch=T)
+        net = SplendorV80Hip.from_npz(WEIGHTS, device=dev, max_batch=T // a.groups) if pretrained else \
+            SplendorV80Hip.random_init(device=dev, max_batch=T // a.groups)
     else:
         net = SplendorV80.from_npz(WEIGHTS, device=dev, dtype=dtype) if pretrained else \
             SplendorV80.random_init(device=dev, dtype=dtype)
     cap = a.node_capacity or max(2048, 10 * a.sims + 512)
     eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
-                         stream0=rank * T, use_graph=not a.no_graph)
+                         stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups)
     eng.start()
     eng.run(a.warmup)
     torch.cuda.synchronize()
@@ -193,6 +195,7 @@ def main():
         e = (r1['expansions'] - r0['expansions']) / rs
         vbar = (r1['sum_valid_visited'] - r0['sum_valid_visited']) / max(1, r1['levels'] - r0['levels'])
         b_sim = algorithmic_bytes_per_sim(f.S, f.A, f.P, d, vbar, e)
+        rs = rs / a.groups          # the timed launches are group 0's (T/groups trees each)
         sims_per_launch = rs / n_sel
         bytes_per_launch = b_sim * sims_per_launch
         pair_ms = ms_sel + ms_exp
@@ -224,7 +227,7 @@ def main():
                            hip_graph=eng.graph is not None),
                sims_per_sec=tot_sims / dt, plies_completed=tot_plies, games_finished=tot_games,
                examples_gathered=tot_examples if world == 1 else int(ex[0].shape[0]), engine_errors=errs,
-               forest_bytes_per_gpu=f.device_bytes, max_nodes_per_tree=s1['max_nodes'], gc_runs=s1['gc_runs'])
+               forest_bytes_per_gpu=eng.device_bytes, groups=a.groups, max_nodes_per_tree=s1['max_nodes'], gc_runs=s1['gc_runs'])
     if roof:
         out['roofline'] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -86,6 +86,8 @@ typedef struct azg_forest_cfg {
     uint64_t rng_seed;
     uint64_t stream0;            /* global index of tree 0 (rank * n_trees in multi-GPU runs) */
     int max_examples;            /* capacity of the on-device example ring (self-play mode) */
+    int level_budget;            /* max descent levels per tree per azg_forest_select launch; a deeper simulation is parked
+                                    and resumed by the next launch (0 = unlimited).  Pure scheduling: results identical. */
 } azg_forest_cfg;
 
 typedef struct azg_forest azg_forest;
@@ -144,7 +146,9 @@ int azg_selfplay_advance(azg_forest* f, void* stream);
 /* counters (synchronises): plies executed, games finished, simulations run, examples stored, error flags */
 typedef struct azg_selfplay_stats {
     uint64_t plies, games, sims, levels, expansions, sum_valid_visited, terminal_hits, examples, gc_runs, max_nodes,
-        errors, sum_depth_at_expand;
+        errors, sum_depth_at_expand,
+        cyc_select, cyc_levels, cyc_edge, cyc_leaf;   /* shader-clock cycles summed over trees: whole k_select, descent levels,
+                                                         frontier edge resolution (incl. leaf creation), leaf creation */
 } azg_selfplay_stats;
 int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out);
 /* drain finished-game examples: (board int8[S], pi f32[A], z f32[P], valids u8[A], q f32[P]) per record

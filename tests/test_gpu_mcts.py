@@ -195,12 +195,13 @@ def test_device_dirichlet_sampler_statistics():
     net = HashNetTorch(2)
     res = {}
     for alpha in (0.0, 0.3):
-        args = Args(numMCTSSims=1, prob_fullMCTS=1.0, dirichletAlpha=alpha, temperature=[1.0, 1.0, 1.0], **kw)
+        args = Args(numMCTSSims=4, prob_fullMCTS=1.0, dirichletAlpha=alpha, temperature=[1.0, 1.0, 1.0], **kw)
         f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=64, rng_seed=11)
         f.begin_search(roots)
         f.select(device_noise=True)
         pi, v = net.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid.bool())
         f.expand_backup(pi, v, device_noise=True)
+        f.select(device_noise=True)        # k_root_noise runs at the head of the next select
         res[alpha] = f.root_stats()['Ps'].cpu().numpy().astype(np.float64)
         f.close()
     clean, noisy = res[0.0], res[0.3]
@@ -214,3 +215,28 @@ def test_device_dirichlet_sampler_statistics():
     expect_var = (1.0 / nv) * (1 - 1.0 / nv) / (nv * 0.3 + 1)
     assert abs(d.var() - expect_var) / expect_var < 0.15
     assert len({tuple(np.round(x, 6)) for x in d[:32]}) == 32      # different trees, different samples
+
+
+@pytest.mark.parametrize('budget', [1, 3])
+def test_level_budget_is_pure_scheduling(golden_dir, budget):
+    """A per-launch level budget (descents parked and resumed across launches) must not change any statistic."""
+    import torch
+    from azg_amd.mcts import BatchedMCTS
+    from hashnet import HashNetTorch
+    d = np.load(os.path.join(golden_dir, 'mcts_splendor2_numba.npz'))
+    g = make('splendor2')
+    idxs = [i for i in range(len(d['case_sims'])) if int(d['case_sims'][i]) == 200 and int(d['case_universes'][i]) == 3
+            and int(d['case_forced'][i]) == 1 and abs(float(d['case_fpu'][i]) - 0.0593) < 1e-9]
+    assert len(idxs) >= 2
+    args = Args(numMCTSSims=200, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, prob_fullMCTS=1.0,
+                ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1, 1, 1])
+    m = BatchedMCTS(g, HashNetTorch(g.P), args, len(idxs), node_capacity=512, level_budget=budget)
+    probs, q, _ = m.getActionProb(torch.from_numpy(d['case_root'][idxs]).to(g.device), temp=1, force_full_search=True)
+    rs = m.forest.root_stats()
+    for k, i in enumerate(idxs):
+        assert np.array_equal(rs['Nsa'][k].cpu().numpy(), d['case_Nsa'][i].astype(np.int32))
+        assert np.array_equal(rs['Qsa'][k].cpu().numpy(), d['case_Qsa'][i])
+        assert np.array_equal(probs[k].cpu().numpy(), d['case_probs'][i])
+        assert int(rs['n_nodes'][k]) == int(d['case_nodes'][i])
+    assert m.forest.validate() == 0
+    m.forest.close()

@@ -1,0 +1,19 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+import torch
+from azg_amd import games
+from azg_amd.nnet import SplendorV80Hip
+from azg_amd.selfplay import SelfPlayEngine
+class Args(dict): __getattr__ = dict.get
+a = Args(numMCTSSims=800, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, dirichletAlpha=0.3, temperature=[1.25,0.8,1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0)
+g = games.SplendorGame(2)
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=T)
+e = SelfPlayEngine(g, net, a, T, node_capacity=8512, max_examples=T*160, use_graph=False)
+e.start(); e.run(1200)
+s0 = e.stats(); e.run(300); s1 = e.stats()
+d = {k: s1[k]-s0[k] for k in s0}
+n = 300 * T
+print('per tree-launch cycles: select', d['cyc_select']/n, 'levels', d['cyc_levels']/n, 'edge', d['cyc_edge']/n, 'leaf', d['cyc_leaf']/n)
+print('levels/launch', d['levels']/n, 'sims/launch', d['sims']/n, 'cycles per level', d['cyc_levels']/max(1,d['levels']))
