@@ -131,7 +131,7 @@ class OracleGame:
             raise ValueError('bad game/variant')
         self.S, self.A, self.P = self.g.S, self.g.A, self.g.P
         self.num_players = self.P
-        self.shape = (self.g.rows, self.g.cols) if game_id != SANTORINI else (5, 5, 3)
+        self.shape = (self.g.rows, self.g.cols) if game_id != SANTORINI else (5, 5, 3)   # Azul: (23, 6)
 
     def getBoardSize(self):
         return self.shape

@@ -10,7 +10,7 @@ import azg_oracle as O
 
 VARIANTS = {
     'splendor2': (O.SPLENDOR, 2), 'splendor3': (O.SPLENDOR, 3), 'splendor4': (O.SPLENDOR, 4),
-    'santorini1': (O.SANTORINI, 1), 'santorini11': (O.SANTORINI, 11),
+    'santorini1': (O.SANTORINI, 1), 'santorini11': (O.SANTORINI, 11), 'azul': (O.AZUL, 0),
 }
 
 
@@ -49,7 +49,7 @@ def test_symmetries(golden_dir, variant):
     d = load(golden_dir, 'sym_%s.npz' % variant)
     g = O.OracleGame(*VARIANTS[variant])
     for i in range(len(d['state'])):
-        syms = g.getSymmetries(d['state'][i], d['pi'][i], d['valid'][i], max_sym=24)
+        syms = g.getSymmetries(d['state'][i], d['pi'][i], d['valid'][i], max_sym=128)
         assert len(syms) == int(d['count'][i])
         for k, (s, p, v) in enumerate(syms):
             assert np.array_equal(s.reshape(-1), d['out_state'][i][k]), (variant, i, k)
@@ -74,7 +74,7 @@ def oracle_tree_digest(mc, game):
     return np.frombuffer(h.digest(), dtype=np.uint8)
 
 
-MCTS_VARIANTS = ['splendor2', 'splendor4', 'santorini1', 'santorini11']
+MCTS_VARIANTS = ['splendor2', 'splendor4', 'santorini1', 'santorini11', 'azul']
 
 
 @pytest.mark.parametrize('typing', ['numpy2', 'numba'])

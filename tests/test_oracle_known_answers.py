@@ -43,6 +43,7 @@ C2 = [
     ((O.SANTORINI, 11), (7, 10), None, 54, 2669, [7, 23, 50, 849, 75, 63, 947, 73], '05a8796c6ae75459', 'd553c04776663f4d', [-1, 1]),
     ((O.SANTORINI, 11), (3, 9), None, 46, 2106, [7, 23, 65, 75, 80, 944, 250, 3], '174d42d233374269', 'c2e5b7f81bd4c1f7', [-1, 1]),
     ((O.SANTORINI, 11), (8, 4), None, 23, 2035, [7, 23, 65, 75, 80, 891, 907, 916], '32d0d9278fa27e47', '40fbfce53c2f7f3e', [1, -1]),
+    ((O.AZUL, 0), (0, 0), 'd1e0bbcd4c4277f0', 63, 1435, [33, 16, 73, 106, 150, 140, 20, 1], 'ac77a8d87f636d12', '62a229650d22c744', [1, -1]),
 ]
 
 
@@ -64,6 +65,7 @@ C3 = [
     ((O.SANTORINI, 1), (0, 0), dict(cpuct=1.1, fpu=0.03, universes=0), 25, 25, 24, -0.17132920026779175, '1b51c44b02553a62', 1),
     ((O.SANTORINI, 1), (0, 0), dict(cpuct=1.1, fpu=0.03, universes=0), 800, 800, 799, -0.018680008128285408, 'f6a86e2b69d5f887', 31),
     ((O.SANTORINI, 11), (1, 5), dict(cpuct=1.1, fpu=0.03, universes=0), 800, 800, 799, 0.0020819352939724922, '5bb85ebbe5d154c8', 37),
+    ((O.AZUL, 0), (0, 0), dict(cpuct=0.5, fpu=0.05, universes=1), 800, 800, 799, -0.01931973174214363, 'f0e32ed35ac9f702', 32),
 ]
 
 

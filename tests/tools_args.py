@@ -5,4 +5,5 @@ MCTS_ARGS = {
     'splendor4': dict(cpuct=0.8, fpu=0.1, universes=3, forced_playouts=True),
     'santorini1': dict(cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True),
     'santorini11': dict(cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True),
+    'azul': dict(cpuct=0.5, fpu=0.05, universes=1, forced_playouts=True),
 }

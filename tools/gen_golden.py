@@ -34,6 +34,7 @@ VARIANTS = {
     'splendor4': (dict(splendor_players=4), 'SplendorGame', 'SplendorGame'),
     'santorini1': (dict(santorini_gods=1), 'SantoriniGame', 'SantoriniGame'),
     'santorini11': (dict(santorini_gods=11), 'SantoriniGame', 'SantoriniGame'),
+    'azul': (dict(), 'AzulGame', 'AzulGame'),
 }
 
 MCTS_ARGS = {
@@ -42,6 +43,7 @@ MCTS_ARGS = {
     'splendor4': dict(cpuct=0.8, fpu=0.1, universes=3, forced_playouts=True),
     'santorini1': dict(cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True),
     'santorini11': dict(cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True),
+    'azul': dict(cpuct=0.5, fpu=0.05, universes=1, forced_playouts=True),
 }
 
 
@@ -97,7 +99,8 @@ def gen_env(name, n_traj, rng, max_plies=400):
                 seed = -1
             else:
                 seed = H.MAGIC_SEEDS[int(rng.integers(8))]
-            us = [float(x) for x in rng.random(4)]
+            nu = 24 if name == 'azul' else 4       # Azul's new-round refill draws up to 20 tiles
+            us = [float(x) for x in rng.random(nu)]
             with _PatchedRandom() as pr:
                 pr.queue = list(us)
                 nb, npl = game.getNextState(board, player, a, random_seed=seed)
@@ -115,7 +118,7 @@ def gen_env(name, n_traj, rng, max_plies=400):
             rec['score'].append([int(game.getScore(nb, p)) for p in range(P)])
             rec['round'].append(int(game.getRound(nb)))
             rec['canonical'].append(game.getCanonicalForm(nb, npl).reshape(-1).copy())
-            rec['uniforms'].append((used + [0.5] * 4)[:4])
+            rec['uniforms'].append((used + [0.5] * nu)[:nu])
             rec['traj'].append(t)
             board, player = nb, npl
             if ended.any():
@@ -218,7 +221,7 @@ def gen_sym(name, env, game, rng, n):
         syms = game.getSymmetries(st, pi, va)
         states.append(st.reshape(-1)); pis.append(pi); valids.append(va.astype(np.uint8))
         counts.append(len(syms))
-        pad = 24 - len(syms)
+        pad = (128 if len(syms) > 24 else 24) - len(syms)
         o_states.append(np.array([s[0].reshape(-1) for s in syms] + [np.zeros(st.size, np.int8)] * pad, dtype=np.int8))
         o_pi.append(np.array([s[1] for s in syms] + [np.zeros(A, np.float32)] * pad, dtype=np.float32))
         o_valid.append(np.array([np.asarray(s[2]).astype(np.uint8) for s in syms] + [np.zeros(A, np.uint8)] * pad))
@@ -242,7 +245,7 @@ def main():
         env, m, game = gen_env(name, n_traj, rng)
         np.savez_compressed(os.path.join(outdir, 'env_%s.npz' % name), **env)
         print(name, 'env transitions', len(env['state']))
-        sym = gen_sym(name, env, game, rng, 40 if big else 6)
+        sym = gen_sym(name, env, game, rng, (40 if big else 6) if name != 'azul' else (6 if big else 2))
         np.savez_compressed(os.path.join(outdir, 'sym_%s.npz' % name), **sym)
         if name in ('splendor3',):
             H.cleanup()

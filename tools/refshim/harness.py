@@ -10,7 +10,8 @@ What it does (SURVEY.md §8c recipe):
   * variants that are source-level constants in the reference (NUMBER_PLAYERS, NB_GODS, INIT_METHOD) are
     produced by editing a TEMP COPY of the reference tree (never the repo, never /root/reference);
   * patches splendor.SplendorLogicNumba.my_packbits to wrap uint8->int8 like Numba's silent int8 store
-    (NumPy 2 raises OverflowError for 255 -> int8);
+    (NumPy 2 raises OverflowError for 255 -> int8); widens azul's np_factory_symmetries table to int64 (Numba widens
+    `30*(p+1)`, NumPy 2 overflows it in int8);
   * optional "numba typing" emulation for MCTS.pick_highest_UCB: Numba promotes float32 operands to
     float64 when mixed with float64 (cpuct, fpu are float64), while NumPy-2 scalar arithmetic in
     pure-Python mode keeps `python_float * np.float32` in float32.  `numba_typing=True` calls the
@@ -87,6 +88,9 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     try:
         mods['AzulGame'] = importlib.import_module('azul.AzulGame')
         mods['AzulLogicNumba'] = importlib.import_module('azul.AzulLogicNumba')
+        # Numba widens int8 * int64 in `30*(p+1)` (AzulLogicNumba.py:320); NumPy>=2 keeps python_int*np.int8 in int8 and
+        # overflows for p >= 4.  Same values, wider dtype:
+        mods['AzulLogicNumba'].np_factory_symmetries = mods['AzulLogicNumba'].np_factory_symmetries.astype(np.int64)
     except Exception as e:  # pragma: no cover
         mods['AzulGame'] = None
         mods['azul_error'] = e
