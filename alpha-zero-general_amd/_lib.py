@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libazg_hip.so')
 
-SPLENDOR, SANTORINI = 0, 1
+SPLENDOR, SANTORINI, AZUL = 0, 1, 2
 
 
 class ForestCfg(C.Structure):

@@ -134,10 +134,19 @@ class SantoriniGame(HipGame):
         super().__init__(nb_gods, **kw)
 
 
+class AzulGame(HipGame):
+    GAME_ID = _lib.AZUL
+
+    def __init__(self, **kw):
+        super().__init__(2, **kw)
+
+
 def import_game(name, **kw):
     """GameSwitcher.import_game equivalent (GameSwitcher.py:15-24) for the games on the hot path."""
     if name == 'splendor':
         return SplendorGame(**kw)
     if name == 'santorini':
         return SantoriniGame(**kw)
+    if name == 'azul':
+        return AzulGame(**kw)
     raise ValueError('game %r is not on the accelerated path' % name)

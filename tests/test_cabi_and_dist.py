@@ -27,6 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert _lib.game_info(_lib.SPLENDOR, 4)[0] == 616
     assert _lib.game_info(_lib.SANTORINI, 11)[:3] == (75, 1782, 2)
     assert _lib.game_info(_lib.SANTORINI, 1)[:3] == (75, 162, 2)
+    assert _lib.game_info(_lib.AZUL, 0) == (138, 180, 2, 23, 6)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')

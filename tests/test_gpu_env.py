@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
-            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11)}
+            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0)}
 
 
 def make_game(variant):
@@ -16,6 +16,8 @@ def make_game(variant):
     from azg_amd import games
     name, v = VARIANTS[variant]
     assert torch.cuda.is_available()
+    if name == 'azul':
+        return games.AzulGame()
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
 
 
@@ -48,7 +50,7 @@ def test_env_vs_golden(golden_dir, variant):
     assert np.array_equal(canon.cpu().numpy(), d['canonical'])
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'splendor4', 'santorini11'])
+@pytest.mark.parametrize('variant', ['splendor2', 'splendor4', 'santorini11', 'azul'])
 def test_true_random_moves_and_init_vs_oracle(golden_dir, variant):
     """random_seed == 0 (Coach.py:71) and Board.init_game consume the shared counter-based RNG exactly like the oracle."""
     import torch
@@ -56,7 +58,7 @@ def test_true_random_moves_and_init_vs_oracle(golden_dir, variant):
     d = np.load(os.path.join(golden_dir, 'env_%s.npz' % variant))
     g = make_game(variant)
     name, v = VARIANTS[variant]
-    og = O.OracleGame(O.SPLENDOR if name == 'splendor' else O.SANTORINI, v)
+    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL}[name], v)
     dev = g.device
     n = min(len(d['state']), 400)
     st = torch.from_numpy(d['state'][:n]).to(dev)
@@ -64,6 +66,7 @@ def test_true_random_moves_and_init_vs_oracle(golden_dir, variant):
     act = torch.from_numpy(d['action'][:n].astype(np.int32)).to(dev)
     seeds = torch.zeros(n, dtype=torch.int64, device=dev)
     counters = torch.arange(n, dtype=torch.int64, device=dev) * 3
+    step = 3
     g.rng_seed = 1234
     out, nxt = g.next_state_batch(st, pl, act, seeds, stream0=77, counters=counters)
     out = out.cpu().numpy()

@@ -11,7 +11,7 @@ from tools_args import MCTS_ARGS
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {'splendor2': ('splendor', 2), 'splendor4': ('splendor', 4), 'santorini1': ('santorini', 1),
-            'santorini11': ('santorini', 11)}
+            'santorini11': ('santorini', 11), 'azul': ('azul', 0)}
 
 
 class Args(dict):
@@ -21,6 +21,8 @@ class Args(dict):
 def make(variant):
     from azg_amd import games
     name, v = VARIANTS[variant]
+    if name == 'azul':
+        return games.AzulGame()
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
 
 
@@ -61,7 +63,7 @@ def test_mcts_traces_vs_golden(golden_dir, variant):
         m.forest.close()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'santorini11'])
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini11', 'azul'])
 def test_whole_tree_vs_oracle(variant):
     """Every node of the HIP tree equals the oracle's node with the same state key (Ns, Qs, Nsa, Qsa, Ps, Es)."""
     import torch
@@ -70,7 +72,7 @@ def test_whole_tree_vs_oracle(variant):
     from hashnet import HashNetTorch
     g = make(variant)
     name, v = VARIANTS[variant]
-    og = O.OracleGame(O.SPLENDOR if name == 'splendor' else O.SANTORINI, v)
+    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL}[name], v)
     kw = dict(MCTS_ARGS[variant])
     sims = 400
     T = 8
@@ -99,7 +101,7 @@ def test_whole_tree_vs_oracle(variant):
     m.forest.close()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'santorini1'])
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini1', 'azul'])
 def test_tree_reuse_sequence_vs_golden(golden_dir, variant):
     """Multi-move sequence of the golden set: tree reuse across moves and fast (non-full) searches."""
     import torch
