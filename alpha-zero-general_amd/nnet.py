@@ -44,14 +44,15 @@ class _Block:
     def act(self, x):
         return F.hardswish(x) if self.use_hs else F.relu(x)
 
-    def __call__(self, x):                      # x: [B, 7, C]
+    def __call__(self, x):                      # x: [B, L, C]
         h = self.act(torch.matmul(x, self.We) + self.be)                       # expand  [B,7,Cexp]
         h = torch.matmul(self.Wd.to(h.dtype), h) * self.sd + self.bd           # depthwise Linear(7->7) over L, then BN
         h = self.act(h)
         pooled = h.mean(dim=1) if self.setype == 'avg' else h.amax(dim=1)      # SE squeeze over L  [B,Cexp]
         sc = F.hardsigmoid(torch.addmm(self.b2, F.relu(torch.addmm(self.b1, pooled, self.W1)), self.W2))
         h = h * sc[:, None, :]
-        return torch.matmul(h, self.Wp) + self.bp + x                          # project + residual
+        out = torch.matmul(h, self.Wp) + self.bp                               # project (+BN)
+        return out + x if self.Wp.shape[1] == x.shape[-1] else out             # use_res_connect: in == out channels
 
 
 class SplendorV80:
@@ -288,3 +289,106 @@ class SplendorV80Hip(SplendorV80):
         self._lib.check(L.azg_nn_heads_out(p(self.logits), 96, p(valids), p(self.hid_v), 16, p(self.Wv2), p(self.bv2),
                                            p(self.pi), p(self.v), B, self.A, self.P, self._stream()))
         return self.pi[:B], self.v[:B]
+
+
+
+class AzulV84(SplendorV80):
+    """azul/AzulNNet.py nn_version == 84 (:91-113,130-142): same building blocks on a [B, 23, 6] board -- trunk block
+    23->115->23, policy head block 23->115->46 (no residual) + Linear(276,180)+ReLU+Linear, value head block 23->46->23."""
+
+    def __init__(self, state_dict, num_players=2, device='cuda:0', dtype=torch.float32):
+        sd = {k: torch.as_tensor(v).float() for k, v in state_dict.items()}
+        self.P = num_players
+        self.nb_vect, self.L, self.A = 23, 6, 180
+        s, b = _fold_bn(sd, 'first_layer.norm')
+        self.W0 = (sd['first_layer.linear.weight'] * s[:, None]).t().contiguous()
+        self.b0 = b
+        self.trunk = _Block(sd, 'trunk.0', False, 'avg')
+        self.head_pi = _Block(sd, 'output_layers_PI.0', True, 'avg')
+        self.head_v = _Block(sd, 'output_layers_V.0', True, 'avg')
+        L = self.L
+
+        def perm(w, C):   # reference flattens [B, C, L] (index c*L+l); ours is [B, L, C] (index l*C+c)
+            return w.view(w.shape[0], C, L).permute(0, 2, 1).reshape(w.shape[0], L * C).t().contiguous()
+        self.Wpi1, self.bpi1 = perm(sd['output_layers_PI.2.weight'], 46), sd['output_layers_PI.2.bias']
+        self.Wpi2, self.bpi2 = sd['output_layers_PI.4.weight'].t().contiguous(), sd['output_layers_PI.4.bias']
+        self.Wv1, self.bv1 = perm(sd['output_layers_V.2.weight'], 23), sd['output_layers_V.2.bias']
+        self.Wv2, self.bv2 = sd['output_layers_V.4.weight'].t().contiguous(), sd['output_layers_V.4.bias']
+        self.to(device, dtype)
+
+    @torch.no_grad()
+    def forward(self, boards, valids):
+        B = boards.shape[0]
+        x = boards.reshape(B, self.nb_vect, self.L).to(self.dtype).transpose(1, 2)
+        x = torch.matmul(x, self.W0) + self.b0
+        x = self.trunk(x)
+        hp = self.head_pi(x).reshape(B, -1)
+        logits = torch.addmm(self.bpi2, F.relu(torch.addmm(self.bpi1, hp, self.Wpi1)), self.Wpi2).float()
+        hv = self.head_v(x).reshape(B, -1)
+        v = torch.tanh(torch.addmm(self.bv2, F.relu(torch.addmm(self.bv1, hv, self.Wv1)), self.Wv2).float())
+        logits = torch.where(valids.bool(), logits, torch.full_like(logits, -1e8))
+        return torch.softmax(logits, dim=1).contiguous(), v.contiguous()
+
+
+class SantoriniV89:
+    """santorini/SantoriniNNet.py nn_version 88/89 (:194-219,273-281; SimpleResBlock :71-84, SimpleHead :17-40): the 2
+    spatial planes (workers, levels) of the (5,5,3) board -> conv3x3(2->64)+BN+ReLU -> 5 residual blocks -> 1x1-conv heads.
+    BatchNorm folded into the convolutions (eval mode); plain torch ops (MIOpen / hipBLASLt)."""
+
+    def __init__(self, state_dict, num_players=2, device='cuda:0', dtype=torch.float32):
+        sd = {k: torch.as_tensor(v).float() for k, v in state_dict.items()}
+        self.P, self.A = num_players, sd['head_PI.fc.weight'].shape[0]
+
+        def conv_bn(conv, bn):
+            s, b = _fold_bn(sd, bn)
+            return (sd[conv + '.weight'] * s[:, None, None, None]).contiguous(), b
+        self.c0 = conv_bn('first_layer.0', 'first_layer.1')
+        self.blocks = []
+        i = 0
+        while 'trunk.%d.conv1.weight' % i in sd:
+            self.blocks.append((conv_bn('trunk.%d.conv1' % i, 'trunk.%d.bn1' % i),
+                                conv_bn('trunk.%d.conv2' % i, 'trunk.%d.bn2' % i)))
+            i += 1
+        self.hp = conv_bn('head_PI.conv1x1', 'head_PI.bn')
+        self.hv = conv_bn('head_V.conv1x1', 'head_V.bn')
+        self.fc_pi = (sd['head_PI.fc.weight'].t().contiguous(), sd['head_PI.fc.bias'])
+        self.fc_v1 = (sd['head_V.fc1.weight'].t().contiguous(), sd['head_V.fc1.bias'])
+        self.fc_v2 = (sd['head_V.fc2.weight'].t().contiguous(), sd['head_V.fc2.bias'])
+        self.to(device, dtype)
+
+    def to(self, device, dtype=torch.float32):
+        self.device, self.dtype = torch.device(device), dtype
+        mv = lambda pr: tuple(t.to(self.device, dtype) for t in pr)  # noqa: E731
+        self.c0, self.hp, self.hv = mv(self.c0), mv(self.hp), mv(self.hv)
+        self.blocks = [(mv(a), mv(b)) for a, b in self.blocks]
+        self.fc_pi, self.fc_v1, self.fc_v2 = mv(self.fc_pi), mv(self.fc_v1), mv(self.fc_v2)
+        return self
+
+    @classmethod
+    def from_npz(cls, path, **kw):
+        z = np.load(path)
+        return cls({k[3:]: z[k] for k in z.files if k.startswith('sd/')}, **kw)
+
+    @torch.no_grad()
+    def forward(self, boards, valids):
+        B = boards.shape[0]
+        x = boards.reshape(B, 5, 5, 3).to(self.dtype).permute(0, 3, 1, 2)[:, :2].contiguous()
+        x = F.relu(F.conv2d(x, self.c0[0], self.c0[1], padding=1))
+        for (w1, b1), (w2, b2) in self.blocks:
+            y = F.relu(F.conv2d(x, w1, b1, padding=1))
+            x = F.relu(F.conv2d(y, w2, b2, padding=1) + x)
+        hp = F.relu(F.conv2d(x, self.hp[0], self.hp[1])).flatten(1)
+        logits = torch.addmm(self.fc_pi[1], hp, self.fc_pi[0]).float()
+        hv = F.relu(F.conv2d(x, self.hv[0], self.hv[1])).flatten(1)
+        v = torch.tanh(torch.addmm(self.fc_v2[1], F.relu(torch.addmm(self.fc_v1[1], hv, self.fc_v1[0])), self.fc_v2[0]).float())
+        logits = torch.where(valids.bool(), logits, torch.full_like(logits, -1e8))
+        return torch.softmax(logits, dim=1).contiguous(), v.contiguous()
+
+    def predict_batch(self, boards, valids):
+        return self.forward(boards, valids)
+
+    def predict(self, board, valid_actions):
+        b = torch.from_numpy(np.ascontiguousarray(board, dtype=np.int8))[None].to(self.device)
+        va = torch.from_numpy(np.asarray(valid_actions).astype(np.bool_))[None].to(self.device)
+        pi, v = self.forward(b, va)
+        return pi[0].cpu().numpy(), v[0].cpu().numpy()

@@ -45,3 +45,27 @@ def test_v80_hip_kernels_forward_gpu():
         p1, v1 = net.predict_batch(boards[:n].contiguous(), masks[:n].contiguous())
         p2, v2 = ref.predict_batch(boards[:n], masks[:n])
         assert torch.allclose(p1, p2, atol=1e-5, rtol=0) and torch.allclose(v1, v2, atol=1e-5, rtol=0)
+
+
+def _check_generic(cls, tag, device):
+    from azg_amd import nnet
+    root = os.path.join(os.path.dirname(__file__), 'golden')
+    net = getattr(nnet, cls).from_npz(os.path.join(root, 'weights_%s.npz' % tag), device=device)
+    d = np.load(os.path.join(root, 'netfwd_%s.npz' % tag))
+    pi, v = net.predict_batch(torch.from_numpy(d['boards']).to(device), torch.from_numpy(d['masks']).to(device))
+    # tolerance: 1e-5 on pi; 3e-5 on v -- an f64 evaluation of the Azul net differs from the reference's own f32 output by
+    # 1.07e-5, i.e. 1e-5 is the reference's f32 rounding floor for this value head
+    assert np.allclose(pi.cpu().numpy(), d['pi'], atol=1e-5, rtol=0)
+    assert np.allclose(v.cpu().numpy(), d['v'], atol=3e-5, rtol=0)
+
+
+@pytest.mark.parametrize('cls,tag', [('AzulV84', 'azul_v84'), ('SantoriniV89', 'santorini1_v89')])
+def test_other_nets_forward_cpu(cls, tag):
+    """azul/AzulNNet.py V84 and santorini/SantoriniNNet.py V89 re-expressed in plain torch vs the reference models."""
+    _check_generic(cls, tag, 'cpu')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cls,tag', [('AzulV84', 'azul_v84'), ('SantoriniV89', 'santorini1_v89')])
+def test_other_nets_forward_gpu(cls, tag):
+    _check_generic(cls, tag, 'cuda:0')

@@ -15,11 +15,10 @@ import harness as H  # noqa: E402
 GOLDEN = os.path.join(HERE, '..', 'tests', 'golden')
 
 
-def main():
+def convert(name, ckpt_rel, load_kw, game_mod, game_cls, n_vec=256):
     import torch
-    H.load_reference(splendor_players=2)
-    ck = torch.load(os.path.join(H.REFERENCE, 'splendor', 'pretrained_2players.pt'), map_location='cpu',
-                    weights_only=False)
+    m = H.load_reference(**load_kw)
+    ck = torch.load(os.path.join(H.REFERENCE, ckpt_rel), map_location='cpu', weights_only=False)
     sd = {k: v.numpy() for k, v in ck['state_dict'].items()}
     meta = {k: ck[k] for k in ck if k not in ('state_dict', 'full_model')}
     out = {'sd/' + k: v for k, v in sd.items()}
@@ -28,24 +27,30 @@ def main():
             out['arg/' + k] = np.array(v)
         elif isinstance(v, (list, tuple)) and all(isinstance(x, (int, float)) for x in v):
             out['arg/' + k] = np.array(v, dtype=np.float64)
-    np.savez_compressed(os.path.join(GOLDEN, 'weights_splendor2_v80.npz'), **out)
-    print('args:', {k: v for k, v in meta.items() if not hasattr(v, 'shape')})
-
+    np.savez_compressed(os.path.join(GOLDEN, 'weights_%s.npz' % name), **out)
+    print(name, 'args:', {k: v for k, v in meta.items() if k in ('nn_version', 'cpuct', 'fpu', 'universes', 'numMCTSSims',
+                                                                   'dirichletAlpha', 'temperature', 'tempThreshold')})
     # G4: forward vectors from the reference's own module (GenericNNetWrapper.py:112-120 torch branch)
     model = ck['full_model'].eval()
-    env = np.load(os.path.join(GOLDEN, 'env_splendor2.npz'))
+    env = np.load(os.path.join(GOLDEN, 'env_%s.npz' % name.split('_')[0]))
     rng = np.random.default_rng(0)
-    sel = rng.choice(len(env['canonical']), size=256, replace=False)
-    boards = env['canonical'][sel].reshape(-1, 56, 7)
-    import splendor.SplendorGame as SG
-    g = SG.SplendorGame()
+    sel = rng.choice(len(env['canonical']), size=min(n_vec, len(env['canonical'])), replace=False)
+    g = getattr(m[game_mod], game_cls)()
+    shape = tuple(g.getBoardSize())
+    boards = env['canonical'][sel].reshape((-1,) + shape)
     masks = np.array([g.getValidMoves(b, 0) for b in boards])
     with torch.no_grad():
         lp, v = model(torch.from_numpy(boards.astype(np.float32)), torch.from_numpy(masks.astype(bool)))
-    np.savez_compressed(os.path.join(GOLDEN, 'netfwd_splendor2_v80.npz'), boards=boards.astype(np.int8),
+    np.savez_compressed(os.path.join(GOLDEN, 'netfwd_%s.npz' % name), boards=boards.astype(np.int8),
                         masks=masks.astype(np.uint8), pi=torch.exp(lp).numpy(), v=v.numpy())
-    print('wrote weights +', len(sel), 'forward vectors')
+    print('wrote weights +', len(sel), 'forward vectors for', name)
     H.cleanup()
+
+
+def main():
+    convert('splendor2_v80', 'splendor/pretrained_2players.pt', dict(splendor_players=2), 'SplendorGame', 'SplendorGame')
+    convert('santorini1_v89', 'santorini/pretrained.pt', dict(santorini_gods=1), 'SantoriniGame', 'SantoriniGame', n_vec=128)
+    convert('azul_v84', 'azul/pretrained.pt', dict(), 'AzulGame', 'AzulGame', n_vec=128)
 
 
 if __name__ == '__main__':
