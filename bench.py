@@ -31,6 +31,15 @@ class Args(dict):
 SPLENDOR2_ARGS = dict(numMCTSSims=800, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, dirichletAlpha=0.3,
                       temperature=[1.25, 0.8, 1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0)
 WEIGHTS = os.path.join(ROOT, 'tests', 'golden', 'weights_splendor2_v80.npz')
+# other hot-path games (parity-test configs of BASELINE.json; selectable with --game, not the default bench line)
+OTHER_GAMES = {
+    'santorini1': dict(args=dict(numMCTSSims=800, cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True, dirichletAlpha=0.2,
+                                 temperature=[1.25, 0.8, 1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0),
+                       weights='weights_santorini1_v89.npz', net='SantoriniV89', label='Santorini no-gods (NB_GODS=1), V89 net'),
+    'azul': dict(args=dict(numMCTSSims=800, cpuct=0.5, fpu=0.05, universes=1, forced_playouts=True, dirichletAlpha=-1,
+                           temperature=[1.25, 0.8, 1.0], tempThreshold=10, ratio_fullMCTS=5, prob_fullMCTS=1.0),
+                 weights='weights_azul_v84.npz', net='AzulV84', label='Azul 2p, V84 net'),
+}
 HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -101,6 +110,7 @@ def main():
     ap.add_argument('--steps', type=int, default=1700)
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--games', type=int, default=4096, help='concurrent games per GPU')
+    ap.add_argument('--game', default='splendor2', choices=['splendor2', 'santorini1', 'azul'])
     ap.add_argument('--sims', type=int, default=800)
     ap.add_argument('--node-capacity', type=int, default=0)
     ap.add_argument('--no-graph', action='store_true')
@@ -133,10 +143,24 @@ def main():
     T = a.games
     margs = Args(SPLENDOR2_ARGS)
     margs['numMCTSSims'] = a.sims
-    game = games.SplendorGame(2, device=dev)
     dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[a.net_dtype]
     pretrained = os.path.exists(WEIGHTS)
-    if a.net == 'hip':
+    label = 'Splendor 2p'
+    if a.game != 'splendor2':
+        from azg_amd import nnet as _nn
+        og = OTHER_GAMES[a.game]
+        margs = Args(og['args'])
+        margs['numMCTSSims'] = a.sims
+        game = games.SantoriniGame(1, device=dev) if a.game == 'santorini1' else games.AzulGame(device=dev)
+        net = getattr(_nn, og['net']).from_npz(os.path.join(ROOT, 'tests', 'golden', og['weights']), device=dev, dtype=dtype)
+        a.net = 'torch'
+        label = og['label']
+        pretrained = True
+    else:
+        game = games.SplendorGame(2, device=dev)
+    if a.game != 'splendor2':
+        pass
+    elif a.net == 'hip':
         assert a.net_dtype == 'fp32'
         net = SplendorV80Hip.from_npz(WEIGHTS, device=dev, max_batch=T // a.groups) if pretrained else \
             SplendorV80Hip.random_init(device=dev, max_batch=T // a.groups)
@@ -214,14 +238,15 @@ def main():
                     select_ms=ms_sel, expand_backup_ms=ms_exp, launches=int(n_sel),
                     d_levels_per_sim=d, v_valid_per_level=vbar, e_expansions_per_sim=e)
 
-    out = dict(metric='self-play env-steps/sec @ numMCTSSims=%d, Splendor-2p' % a.sims, value=value,
+    out = dict(metric='self-play env-steps/sec @ numMCTSSims=%d, %s' % (a.sims, 'Splendor-2p' if a.game == 'splendor2' else label), value=value,
                unit='env-steps/sec', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
                higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
                data='synthetic (Board.init_game boards from the counter RNG; net weights: %s)'
                     % ('reference pretrained_2players.pt converted' if pretrained else 'random-init V80'),
-               config=dict(workload='Splendor 2p, numMCTSSims=%d, %d concurrent self-play games per GPU, V80 net %s (%s), '
-                                    'args of pretrained_2players.pt (cpuct 0.8 fpu 0.0593 universes 3 forced playouts '
-                                    'dirichlet 0.3), every ply a full search' % (a.sims, T, a.net_dtype, 'engine MFMA-f32 kernels' if a.net == 'hip' else 'PyTorch-ROCm ops'),
+               config=dict(workload=('Splendor 2p, numMCTSSims=%d, %d concurrent self-play games per GPU, V80 net %s (%s), '
+                                     'args of pretrained_2players.pt (cpuct 0.8 fpu 0.0593 universes 3 forced playouts '
+                                     'dirichlet 0.3), every ply a full search' % (a.sims, T, a.net_dtype, 'engine MFMA-f32 kernels' if a.net == 'hip' else 'PyTorch-ROCm ops'))
+                           if a.game == 'splendor2' else '%s, numMCTSSims=%d, %d concurrent self-play games per GPU, MCTS args of the pretrained checkpoint, every ply a full search' % (label, a.sims, T),
                            games_per_gpu=T, parallelism='games sharded x%d, 1 RCCL example all_gather at episode end'
                                                         % world if world > 1 else 'single GPU',
                            hip_graph=eng.graph is not None),
@@ -230,7 +255,7 @@ def main():
                forest_bytes_per_gpu=eng.device_bytes, groups=a.groups, max_nodes_per_tree=s1['max_nodes'], gc_runs=s1['gc_runs'])
     if roof:
         out['roofline'] = roof
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.game == 'splendor2':
         out['cpu_baseline'] = cpu_baseline(a.sims, a.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
