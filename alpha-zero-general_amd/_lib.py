@@ -22,7 +22,8 @@ class ForestCfg(C.Structure):
 class SelfplayStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ('plies', 'games', 'sims', 'levels', 'expansions', 'sum_valid_visited',
                                           'terminal_hits', 'examples', 'gc_runs', 'max_nodes', 'errors',
-                                          'sum_depth_at_expand', 'cyc_select', 'cyc_levels', 'cyc_edge', 'cyc_leaf')]
+                                          'sum_depth_at_expand', 'cyc_select', 'cyc_levels', 'cyc_edge', 'cyc_leaf')] + [
+                                          ('cyc_seg', C.c_uint64 * 4)]
 
 
 class AzgError(RuntimeError):
@@ -37,7 +38,7 @@ EXPORTS = [
     'azg_forest_destroy', 'azg_forest_device_bytes', 'azg_forest_reset', 'azg_forest_begin_search',
     'azg_forest_select', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
     'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_forest_validate', 'azg_selfplay_start', 'azg_selfplay_advance',
-    'azg_selfplay_stats_get', 'azg_selfplay_drain_examples', 'azg_forest_last_kernel_ms', 'azg_forest_enable_timing', 'azg_nn_linear', 'azg_nn_linear_ws', 'azg_nn_dw_pool', 'azg_nn_v80_block',
+    'azg_selfplay_stats_get', 'azg_selfplay_drain_examples', 'azg_forest_last_kernel_ms', 'azg_forest_enable_timing', 'azg_nn_linear', 'azg_nn_linear_ws', 'azg_nn_dw_pool', 'azg_nn_v80_block', 'azg_nn_v80_forward',
     'azg_nn_board_to_x', 'azg_nn_heads_out',
 ]
 
@@ -82,6 +83,7 @@ def lib():
     L.azg_nn_linear.argtypes = [vp, i, vp, i, i, vp, vp, i, vp, i, vp, i, i, i, i, i, i, vp]
     L.azg_nn_linear_ws.argtypes = [vp, i, vp, i, i, vp, vp, i, vp, i, vp, i, i, i, i, i, vp]
     L.azg_nn_v80_block.argtypes = [vp, vp, vp, i, i, i, vp]
+    L.azg_nn_v80_forward.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp]
     L.azg_nn_dw_pool.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, vp]
     L.azg_nn_board_to_x.argtypes = [vp, vp, i, i, vp]
     L.azg_nn_heads_out.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, i, i, i, vp]

@@ -331,12 +331,12 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
         const RecHdr* rh = (const RecHdr*)rec;
         Ns[i] = (int32_t)rh->Ns;
         Qs[i] = rh->Qs;
-        for (int p = 0; p < P; p++) Es[(size_t)i * P + p] = rh->Es[p];
+        for (int p = 0; p < P; p++) Es[(size_t)i * P + p] = (rh->flags & NF_TERMINAL) ? rh->Es[p] : 0.f;
         has_policy[i] = (rh->flags & NF_EXPANDED) ? 1 : 0;
         for (int a = 0; a < A; a++) { Nsa[(size_t)i * A + a] = 0; Qsa[(size_t)i * A + a] = AZG_NANQ; Ps[(size_t)i * A + a] = 0.f; }
         if (has_policy[i]) {
             RecLayout L(rh->nv, D.U);
-            const uint16_t* ids = (const uint16_t*)(rec + L.offI);
+            const RecIds ids(rec, f->dev.U);
             for (int j = 0; j < rh->nv; j++) {
                 const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
                 const int a = ids[j];
@@ -382,7 +382,7 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
             if (rh->node_id != i || rh->nv != nh[i].nv || rh->round != nh[i].round)
                 VBAD("[validate] t=%d node=%u header mismatch (rec node_id=%u nv=%u)\n", t, i, rh->node_id, rh->nv);
             if (!(rh->flags & NF_EXPANDED)) continue;
-            const uint16_t* ids = (const uint16_t*)(rec + L.offI);
+            const RecIds ids(rec, f->dev.U);
             for (int j = 0; j < rh->nv; j++) {
                 const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
                 for (int u = 0; u < D.U; u++) {
@@ -440,6 +440,7 @@ extern "C" int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out) {
         out->examples += x.c_examples; out->gc_runs += x.gc_runs; out->errors |= x.err;
         out->sum_depth_at_expand += x.c_depth;
         out->cyc_select += x.cyc_select; out->cyc_levels += x.cyc_levels; out->cyc_edge += x.cyc_edge; out->cyc_leaf += x.cyc_leaf;
+        for (int k = 0; k < 4; k++) out->cyc_seg[k] += x.cyc_seg[k];
         if (x.max_nodes_seen > out->max_nodes) out->max_nodes = x.max_nodes_seen;
     }
     return 0;
@@ -614,30 +615,50 @@ extern "C" int azg_nn_dw_pool(float* H, int ldh, const float* Wd, const float* s
     return 0;
 }
 
+static constexpr size_t V80_LDS = (size_t)(112 * 60 + 112 * 172 + 2 * 16 * 172 + 16 * 52 + 64) * sizeof(float);
+
+template <int A_, int P_, int M_>
+static int launch_v80(const float* xin, float* xout, const V80BlockW& W, int B, const int8_t* boards, const V80NetW& N,
+                      const uint8_t* valid, float* pi, float* v, int P, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_v80_block<A_, P_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        attr = true;
+    }
+    k_v80_block<A_, P_, M_><<<dim3((B + 15) / 16), dim3(768), V80_LDS, s>>>(xin, xout, W, B, boards, N, valid, pi, v, P);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int azg_nn_v80_block(const float* xin, float* xout, const float* const* w /* 11 device pointers */, int B,
                                 int act, int pool_max, void* stream) {
     if (!xin || !xout || !w || B <= 0) return fail("azg_nn_v80_block: null/empty argument");
     V80BlockW W{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10]};
-    constexpr size_t lds = (size_t)(112 * 60 + 112 * 172 + 2 * 16 * 172 + 16 * 52 + 64) * sizeof(float);
+    V80NetW N{};
     hipStream_t s = (hipStream_t)stream;
-    const int grid = (B + 15) / 16;
-    static bool attr[4] = {false, false, false, false};
-#define BLK(A_, P_, IDX)                                                                                              \
-    do {                                                                                                              \
-        if (!attr[IDX]) {                                                                                             \
-            HIPCHK(hipFuncSetAttribute((const void*)k_v80_block<A_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                       160 * 1024));                                                                  \
-            attr[IDX] = true;                                                                                         \
-        }                                                                                                             \
-        k_v80_block<A_, P_><<<dim3(grid), dim3(768), lds, s>>>(xin, xout, W, B);                                      \
-    } while (0)
-    if (act == 1 && !pool_max) BLK(1, 0, 0);
-    else if (act == 1 && pool_max) BLK(1, 1, 1);
-    else if (act == 2 && !pool_max) BLK(2, 0, 2);
-    else if (act == 2 && pool_max) BLK(2, 1, 3);
-    else return fail("azg_nn_v80_block: act must be 1 (ReLU) or 2 (Hardswish)");
-#undef BLK
-    HIPCHK(hipGetLastError());
+    if (act == 1 && !pool_max) return launch_v80<1, 0, 0>(xin, xout, W, B, nullptr, N, nullptr, nullptr, nullptr, 0, s);
+    if (act == 1 && pool_max) return launch_v80<1, 1, 0>(xin, xout, W, B, nullptr, N, nullptr, nullptr, nullptr, 0, s);
+    if (act == 2 && !pool_max) return launch_v80<2, 0, 0>(xin, xout, W, B, nullptr, N, nullptr, nullptr, nullptr, 0, s);
+    if (act == 2 && pool_max) return launch_v80<2, 1, 0>(xin, xout, W, B, nullptr, N, nullptr, nullptr, nullptr, 0, s);
+    return fail("azg_nn_v80_block: act must be 1 (ReLU) or 2 (Hardswish)");
+}
+
+extern "C" int azg_nn_v80_forward(const int8_t* boards, const uint8_t* valid, const float* const* w /* 43 */, int B,
+                                  int P, float* x_trunk, float* pi, float* v, void* stream) {
+    if (!boards || !valid || !w || !x_trunk || !pi || !v || B <= 0) return fail("azg_nn_v80_forward: null/empty argument");
+    if (P < 2 || P > 4) return fail("azg_nn_v80_forward: 2 <= P <= 4");
+    V80BlockW Wt{w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12]};
+    V80BlockW Wp{w[13], w[14], w[15], w[16], w[17], w[18], w[19], w[20], w[21], w[22], w[23]};
+    V80BlockW Wv{w[24], w[25], w[26], w[27], w[28], w[29], w[30], w[31], w[32], w[33], w[34]};
+    V80NetW N0{w[0], w[1], nullptr, nullptr, nullptr, nullptr};
+    V80NetW Np{nullptr, nullptr, w[35], w[36], w[37], w[38]};
+    V80NetW Nv{nullptr, nullptr, w[39], w[40], w[41], w[42]};
+    hipStream_t s = (hipStream_t)stream;
+    // V80 geometry (SplendorNNet.py:262-283): trunk ReLU + mean-SE, both heads Hardswish + max-SE
+    if (launch_v80<1, 0, 1>(nullptr, x_trunk, Wt, B, boards, N0, nullptr, nullptr, nullptr, P, s)) return -1;
+    if (launch_v80<2, 1, 2>(x_trunk, nullptr, Wp, B, nullptr, Np, valid, pi, nullptr, P, s)) return -1;
+    if (launch_v80<2, 1, 3>(x_trunk, nullptr, Wv, B, nullptr, Nv, nullptr, nullptr, v, P, s)) return -1;
     return 0;
 }
 

@@ -53,10 +53,47 @@ __device__ __forceinline__ double bcast_f64(double v, int src) {
     return __longlong_as_double((long long)bcast_u64((uint64_t)__double_as_longlong(v), src));
 }
 
+// ---- DPP cross-lane moves (VALU data path, no LDS crossbar round trip like ds_bpermute) ----
+// dpp_ctrl: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140,
+// row_bcast15 = 0x142 (lane 15 of each row -> next row), row_bcast31 = 0x143 (lane 31 -> rows 2,3)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
+    return ((uint64_t)dpp_u32<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32) | dpp_u32<CTRL, ROW_MASK>((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+}
+// wave-wide reduction with a commutative, associative, idempotent-on-self-free op (each lane is combined exactly once):
+// 4 butterfly steps inside each row of 16, then two row broadcasts; the result is read from lane 63 (wave-uniform).
+#define AZG_DPP_REDUCE_U64(v, OP)                                                   \
+    do {                                                                            \
+        uint64_t o_;                                                                \
+        o_ = dpp_u64<0xB1>(v); v = OP(v, o_);                                       \
+        o_ = dpp_u64<0x4E>(v); v = OP(v, o_);                                       \
+        o_ = dpp_u64<0x141>(v); v = OP(v, o_);                                      \
+        o_ = dpp_u64<0x140>(v); v = OP(v, o_);                                      \
+    } while (0)
+
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
-    return v;
+#define AZG_OP_ADD(a, b) ((a) + (b))
+    AZG_DPP_REDUCE_U64(v, AZG_OP_ADD);                 // every lane of a row holds its row's sum
+#undef AZG_OP_ADD
+    return readlane_u64(v, 0) + readlane_u64(v, 16) + readlane_u64(v, 32) + readlane_u64(v, 48);
+}
+// maximum of an f64 over the wave (no NaNs expected; -inf for idle lanes), wave-uniform result
+__device__ __forceinline__ double wave_max_f64(double x) {
+    uint64_t v = (uint64_t)__double_as_longlong(x);
+#define AZG_OP_FMAX(a, b) ((uint64_t)__double_as_longlong(fmax(__longlong_as_double((long long)(a)), __longlong_as_double((long long)(b)))))
+    AZG_DPP_REDUCE_U64(v, AZG_OP_FMAX);
+#undef AZG_OP_FMAX
+    const double a = __longlong_as_double((long long)readlane_u64(v, 0)), b = __longlong_as_double((long long)readlane_u64(v, 16));
+    const double c = __longlong_as_double((long long)readlane_u64(v, 32)), d = __longlong_as_double((long long)readlane_u64(v, 48));
+    return fmax(fmax(a, b), fmax(c, d));
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll

@@ -8,9 +8,8 @@
 // visibility protocol are needed inside a launch):
 //   record heap          bytes    one contiguous, 16-B aligned RECORD per node -- everything a descent level touches:
 //                                   RecHdr 32 B  { Ns u32, Qs f32, node id, n_valid, flags, round, Es f32[4] }
-//                                   entry[nv]    VALID-ACTION-COMPACTED, fixed stride ES = 16 + 4U (rounded to 8):
-//                                                { P f32, N u32, Q f64, child u32[U] }
-//                                   action id u16[nv]
+//                                   entry[nv]    VALID-ACTION-COMPACTED, fixed stride ES = 18 + 4U (rounded to 8):
+//                                                { P f32, N u32, Q f64, child u32[U], action id u16 }
 //                                 entry j of a record sits at a position that does not depend on n_valid, so a wave
 //                                 requests the header and every lane's entry in ONE round trip per level
 //   NodeHdr[cap]         16 B     cold: 64-bit state hash, record offset, n_valid, round, flags (probe / GC / dumps)
@@ -58,7 +57,10 @@ struct __attribute__((aligned(16))) RecHdr {           // first 32 bytes of ever
     uint16_t nv;
     uint8_t flags;
     uint8_t round;
-    float Es[AZG_MAX_PLAYERS_DEV];
+    union {
+        float Es[AZG_MAX_PLAYERS_DEV];     // terminal node: game result (MCTS.py:131-135)
+        double sq[2];                      // otherwise: sqrt(Ns), sqrt(Ns + EPS) -- kept by the backup so that a descent
+    };                                     // level does not recompute two f64 square roots (MCTS.py:213-214)
 };
 
 struct __attribute__((aligned(16))) TreeHdr {
@@ -72,7 +74,7 @@ struct __attribute__((aligned(16))) TreeHdr {
     uint32_t max_nodes_seen, gc_runs, root_rec, noise_pending;   // root_rec = record offset of the root;
                                                                  // noise_pending: root Dirichlet noise still to apply
     uint64_t c_sims, c_levels, c_exp, c_sumvalid, c_term, c_depth, c_plies, c_examples;
-    uint64_t cyc_select, cyc_levels, cyc_edge, cyc_leaf;   // shader-clock cycles spent in k_select and its phases
+    uint64_t cyc_select, cyc_levels, cyc_edge, cyc_leaf, cyc_seg[4];   // shader-clock cycles spent in k_select and its phases
 };
 
 struct PathEnt {
@@ -123,21 +125,27 @@ __device__ __constant__ long long AZG_MAGIC_SEEDS[8] = {31416, 1, 14142, 42, 271
 
 __host__ __device__ __forceinline__ uint32_t align16u(uint32_t x) { return (x + 15u) & ~15u; }
 
-// record geometry: RecHdr | entry[nv] (stride ES) | action ids u16[nv]
+// record geometry: RecHdr | entry[nv] (stride ES); entry = { P f32, N u32, Q f64, child u32[U], action id u16 }
 #define AZG_REC_HDR 32u
-__host__ __device__ __forceinline__ uint32_t entry_stride(int U) { return (16u + 4u * (uint32_t)U + 7u) & ~7u; }
+__host__ __device__ __forceinline__ uint32_t entry_stride(int U) { return (18u + 4u * (uint32_t)U + 7u) & ~7u; }
 struct RecLayout {
-    uint32_t ES, offI, total;   // bytes
+    uint32_t ES, total;   // bytes
     __host__ __device__ RecLayout(int nv, int U) {
         ES = entry_stride(U);
-        offI = AZG_REC_HDR + align16u((uint32_t)nv * ES);
-        total = offI + align16u(2u * (uint32_t)nv);
+        total = AZG_REC_HDR + align16u((uint32_t)nv * ES);
     }
 };
 #define AZG_E_P 0u
 #define AZG_E_N 4u
 #define AZG_E_Q 8u
 #define AZG_E_C 16u
+#define AZG_E_ID(U) (16u + 4u * (uint32_t)(U))
+// read-only view of a record's action ids (ids[j] = action of valid-action-compacted entry j)
+struct RecIds {
+    const uint8_t* base; uint32_t ES;
+    __host__ __device__ RecIds(const uint8_t* rec, int U) : base(rec + AZG_REC_HDR + AZG_E_ID(U)), ES(entry_stride(U)) {}
+    __host__ __device__ __forceinline__ uint16_t operator[](int j) const { return *(const uint16_t*)(base + (size_t)j * ES); }
+};
 
 // NumPy's pairwise float32 summation order (np.sum called by `normalise`, MCTS.py:250-253) for n <= 128 elements,
 // executed by lanes 0..7 over an LDS array; every lane returns the sum.
@@ -262,8 +270,10 @@ struct Forest {
 
     __device__ static __forceinline__ uint32_t tag_of(uint64_t h) { return (uint32_t)(h >> 54); }   // 10 bits
 
-    // Find the node whose key equals the state in LDS.  Also returns the first free slot met (for insertion).
-    __device__ static uint32_t probe(const ForestDev& F, int t, const int8_t* st_lds, uint64_t h, uint32_t* free_slot) {
+    // Find the node whose key equals the state in LDS (*found_rec = its record offset).  Also returns the first free slot
+    // met (for insertion).
+    __device__ static uint32_t probe(const ForestDev& F, int t, const int8_t* st_lds, uint64_t h, uint32_t* free_slot,
+                                     uint32_t* found_rec) {
         const uint32_t* tab = htab(F, t);
         const uint32_t maskHT = (uint32_t)F.HT - 1u;
         uint32_t slot0 = (uint32_t)h & maskHT;
@@ -279,12 +289,14 @@ struct Forest {
             while (mat) {
                 int src = first_lane(mat);
                 mat &= mat - 1;
-                uint32_t id = __shfl(e, src, 64) & AZG_IDX_MASK;
-                if (nhdr(F, t, id)->hash != h) continue;
+                const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)e, src) & AZG_IDX_MASK;
+                // hash check and full-key compare requested together (one round trip; tag collisions are rare)
                 const uint32_t* other = (const uint32_t*)nstate(F, t, id);
                 bool eq = true;
                 for (int i = lane_id(); i < SPW; i += 64) eq = eq && (other[i] == my[i]);
-                if (__all(eq)) return id;
+                const NodeHdr nh = load_uniform(nhdr(F, t, id));
+                if (nh.hash != h) continue;
+                if (__all(eq)) { *found_rec = nh.rec_off; return id; }
             }
             if (fe < 64) {
                 *free_slot = (slot0 + (uint32_t)round * 64u + (uint32_t)fe) & maskHT;
@@ -337,6 +349,8 @@ struct Forest {
                 rh->Qs = tq / (float)(ns + 2u);
                 *(uint32_t*)(ent + AZG_E_N) = n + 1u;
                 rh->Ns = ns + 1u;
+                rh->sq[0] = sqrt((double)(ns + 1u));
+                rh->sq[1] = sqrt((double)(ns + 1u) + AZG_EPS);
             }
         }
     }

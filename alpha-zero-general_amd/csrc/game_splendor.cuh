@@ -1,8 +1,8 @@
 // game_splendor.cuh -- Splendor (2-4 players) env step for one wavefront, state staged in LDS.
 //
 // Semantics follow splendor/SplendorLogicNumba.py `Board` (line numbers cited); the byte layout of the state is the
-// reference's int8[(32+10n+n*n)][7] (copy_state :207-219).  valid_mask() is lane-parallel (one action per lane, two
-// passes for the 81 actions); make_move() is branchy integer work on ~400 LDS bytes and runs on lane 0.
+// reference's int8[(32+10n+n*n)][7] (copy_state :207-219).  valid_mask() is lane-parallel and branch-free (one action per lane, two
+// ballots for the 81 actions); make_move() is branchy integer work on ~400 LDS bytes and runs on lane 0.
 #pragma once
 #include "azg_common.cuh"
 #include "splendor_tables.h"
@@ -40,53 +40,62 @@ struct SplendorDev {
         return s;
     }
 
-    // Board.valid_moves restricted to ONE action (:180-188 and the _valid_* helpers)
-    __device__ static bool valid_action(const int8_t* st, int a, int player) {
-        const int8_t* bank = row(st, 0);
-        const int8_t* gems = row(st, R_GEMS + player);
-        const int8_t* cards = row(st, R_PCARDS + player);
-        if (a < 12) {                                                      // _valid_buy :359-368
-            const int8_t* cost = row(st, 1 + 2 * a);
-            return missing(cost, gems, cards) <= gems[GOLD] && sum5(cost) != 0;
-        }
-        if (a < 27) {                                                      // _valid_reserve :375-380
-            int i = a - 12;
-            bool empty_slot = sum5(row(st, R_RES + 6 * player + 5)) == 0;
-            const int8_t* src = i < 12 ? row(st, 1 + 2 * i) : row(st, 25 + 2 * (i - 12));
-            return empty_slot && sum5(src) != 0;
-        }
-        if (a < 30) {                                                      // _valid_buy_reserve :402-412
-            const int8_t* cost = row(st, R_RES + 6 * player + 2 * (a - 27));
-            return missing(cost, gems, cards) <= gems[GOLD] && sum5(cost) != 0;
-        }
-        if (a < 55) {                                                      // _valid_get_gems :422-427
-            int i = a - 30, k = 0;
-            bool ok = true;
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                int8_t g = SPL_GEMS3[i][c];
-                ok = ok && ((int8_t)(bank[c] - g) >= 0);
-                k += g;
-            }
-            return ok && (sum7(gems) + k <= 10);
-        }
-        if (a < 60) return bank[a - 55] >= 4 && sum7(gems) + 2 <= 10;      // _valid_get_gems_identical :429-434
-        if (a < 75) {                                                      // _valid_give_gems :446-449
-            int i = a - 60;
-            bool ok = true;
-#pragma unroll
-            for (int c = 0; c < 5; c++) ok = ok && ((int8_t)(gems[c] - SPL_GEMS2[i][c]) >= 0);
-            return ok;
-        }
-        if (a < 80) return gems[a - 75] >= 2;                              // _valid_give_gems_identical :451-453
-        return a == 80;                                                    // pass :187
-    }
-
-    // wave-cooperative: one action per lane, two passes; lane 0 writes the AW mask words to LDS (caller syncs)
+    // Board.valid_moves :180-188, wave-cooperative and branch-free: lane l answers action l (first ballot) and action
+    // 64+l (second ballot).  The player's rows are wave-uniform bytes; only the 30 card actions read a per-lane row.
+    // Lane 0 writes the AW mask words (caller syncs).
     __device__ static __forceinline__ void valid_mask(const int8_t* st, int player, uint64_t* mask_lds) {
-        int l = lane_id();
-        uint64_t m0 = __ballot(valid_action(st, l, player));
-        uint64_t m1 = __ballot((l + 64 < A) && valid_action(st, l + 64 < A ? l + 64 : 80, player));
+        const int l = lane_id();
+        const int8_t* bankp = row(st, 0);
+        const int8_t* gemsp = row(st, R_GEMS + player);
+        const int8_t* cardsp = row(st, R_PCARDS + player);
+        const int8_t* lastres = row(st, R_RES + 6 * player + 5);
+        int bank[5], gems[7], cards[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) { bank[c] = bankp[c]; cards[c] = cardsp[c]; }
+#pragma unroll
+        for (int c = 0; c < 7; c++) gems[c] = gemsp[c];
+        const bool empty_slot = sum5(lastres) == 0;                                   // :376
+        const int r = l < 12 ? 1 + 2 * l : l < 24 ? 1 + 2 * (l - 12) : l < 27 ? 25 + 2 * (l - 24)
+                    : l < 30 ? R_RES + 6 * player + 2 * (l - 27) : 0;
+        const int8_t* cr = row(st, r);
+        int cost[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) cost[c] = cr[c];
+        int gsum = 0;
+#pragma unroll
+        for (int c = 0; c < 7; c++) gsum += gems[c];
+        int miss = 0, csum = 0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const int8_t d = (int8_t)((int8_t)(cost[c] - gems[c]) - cards[c]);        // int8 wrap :363
+            miss += d > 0 ? d : 0;
+            csum += cost[c];
+        }
+        const bool nz = csum != 0;
+        const bool ok_buy = miss <= gems[GOLD] && nz;                                 // :359-368, :402-412
+        const bool ok_res = empty_slot && nz;                                         // :375-380
+        constexpr uint32_t g3[5] = SPL_GEMS3_COL_INIT, g2[5] = SPL_GEMS2_COL_INIT;   // bit i of gN[c] = table[i][c]
+        const int i3 = (l - 30) & 31;                                                 // lanes 30..54
+        const int ig = (l >= 60 ? l - 60 : l + 4) & 15;                               // lanes 60..63 (a=l) and 0..10 (a=64+l)
+        bool ok3 = true, okg = true;
+        int k3 = 0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const int t3 = (int)((g3[c] >> i3) & 1u), t2 = (int)((g2[c] >> ig) & 1u);
+            ok3 = ok3 && ((int8_t)(bank[c] - t3) >= 0);                               // :422-427
+            okg = okg && ((int8_t)(gems[c] - t2) >= 0);                               // :446-449
+            k3 += t3;
+        }
+        ok3 = ok3 && (gsum + k3 <= 10);
+        const int cs = l - 55, cg = l - 11;                                           // identical-gem colours
+        int bank_cs = bank[0], gems_cg = gems[0];
+#pragma unroll
+        for (int c = 1; c < 5; c++) { bank_cs = cs == c ? bank[c] : bank_cs; gems_cg = cg == c ? gems[c] : gems_cg; }
+        const bool ok_same = bank_cs >= 4 && gsum + 2 <= 10;                          // :429-434
+        const bool v0 = l < 12 ? ok_buy : l < 27 ? ok_res : l < 30 ? ok_buy : l < 55 ? ok3 : l < 60 ? ok_same : okg;
+        const bool v1 = l < 11 ? okg : l < 16 ? gems_cg >= 2 : l == 16;               // :451-453, pass :187
+        const uint64_t m0 = __ballot(v0);
+        const uint64_t m1 = __ballot(v1);
         if (l == 0) { mask_lds[0] = m0; mask_lds[1] = m1; }
     }
 

@@ -112,8 +112,9 @@ __device__ void begin_search_from_lds(const ForestDev& F, int t, TreeHdr& H, typ
     FR::store_state(F.root_state + (size_t)t * G::SP, sm.st);
     uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
     uint32_t free_slot;
-    H.root = FR::probe(F, t, sm.st, h, &free_slot);
-    H.root_rec = H.root == AZG_NONE ? AZG_NONE : uni_u32(FR::nhdr(F, t, H.root)->rec_off);
+    uint32_t found_rec = AZG_NONE;
+    H.root = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
+    H.root_rec = H.root == AZG_NONE ? AZG_NONE : found_rec;
     H.root_round = (uint32_t)G::get_round(sm.st);
     H.is_full = full ? 1u : 0u;
     H.n_sims = (uint32_t)(full ? F.numMCTSSims : F.numMCTSSims / F.ratio_fullMCTS);
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(64) void k_root_noise(ForestDev F, const double* ro
     if (!(rh.flags & NF_EXPANDED)) return;
     const int nv = rh.nv;
     const RecLayout L(nv, F.U);
-    const uint16_t* ids = (const uint16_t*)(rec + L.offI);
+    const RecIds ids(rec, F.U);
     for (int i = l; i < G::A; i += 64) dense[i] = 0.f;
     if (l < G::AW) mask[l] = 0ull;
     wave_sync();
@@ -191,9 +192,18 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
                                              bool* terminal, float* es) {
     using FR = Forest<G>;
     const int l = lane_id();
+#ifdef AZG_LEAF_SPLIT
+    long long q0 = clock64();
+#endif
     const uint32_t id = FR::create_node(F, t, H, sm.st, h, free_slot);
     if (id == AZG_NONE) return AZG_NONE;
+#ifdef AZG_LEAF_SPLIT
+    long long q1 = clock64(); H.cyc_seg[0] += (uint32_t)(q1 - q0);
+#endif
     const bool ended = G::game_ended(sm.st, 0, es, sm.mask);                                     // MCTS.py:131
+#ifdef AZG_LEAF_SPLIT
+    q0 = clock64(); H.cyc_seg[1] += (uint32_t)(q0 - q1);
+#endif
     int nv = 0;
     if (!ended) {
         G::valid_mask(sm.st, 0, sm.mask);                                                        // MCTS.py:142
@@ -201,6 +211,9 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
 #pragma unroll
         for (int k = 0; k < G::AW; k++) nv += __popcll(sm.mask[k]);
     }
+#ifdef AZG_LEAF_SPLIT
+    q1 = clock64(); H.cyc_seg[2] += (uint32_t)(q1 - q0);
+#endif
     const RecLayout L(nv, F.U);
     // 256 units (4 KB) of slack: a level's speculative entry loads may reach 64 entries past a short record
     if (H.heap_top + L.total / 16u + 256u > F.heap_units) { H.err |= ERR_HEAP_OVERFLOW; return AZG_NONE; }
@@ -213,25 +226,28 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
         rh.Ns = 0; rh.Qs = 0.f; rh.node_id = id; rh.nv = (uint16_t)nv; rh.flags = ended ? NF_TERMINAL : 0; rh.round = round;
 #pragma unroll
         for (int p = 0; p < AZG_MAX_PLAYERS_DEV; p++) rh.Es[p] = (ended && p < G::P) ? es[p] : 0.f;
+        if (!ended) { rh.sq[0] = 0.0; rh.sq[1] = sqrt(0.0 + AZG_EPS); }
         *(RecHdr*)rec = rh;
         NodeHdr* nh = FR::nhdr(F, t, id);
         nh->rec_off = rec_off; nh->nv = (uint16_t)nv; nh->round = round; nh->flags = rh.flags;
     }
     *terminal = ended;
     if (!ended) {
-        uint16_t* ids = (uint16_t*)(rec + L.offI);
         for (int a = l; a < G::A; a += 64) {
             const uint64_t w = sm.mask[a >> 6];
             const bool v = (w >> (a & 63)) & 1;
             if (v) {
                 int rank = __popcll(w & ((1ull << (a & 63)) - 1ull));
                 for (int k = 0; k < (a >> 6); k++) rank += __popcll(sm.mask[k]);
-                ids[rank] = (uint16_t)a;
+                *(uint16_t*)(rec + AZG_REC_HDR + (size_t)rank * L.ES + AZG_E_ID(F.U)) = (uint16_t)a;
             }
             leaf_valid[(size_t)t * G::A + a] = (uint8_t)v;
         }
         FR::store_state_unpadded(leaf_states + (size_t)t * G::S, sm.st);
     }
+#ifdef AZG_LEAF_SPLIT
+    q0 = clock64(); H.cyc_seg[3] += (uint32_t)(q0 - q1);
+#endif
     return rec_off;
 }
 
@@ -243,19 +259,30 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
                                               uint32_t parent_node, int a, long long seed, int8_t* leaf_states,
                                               uint8_t* leaf_valid, bool* is_new, bool* terminal, float* es) {
     using FR = Forest<G>;
+#ifdef AZG_LEAF_SPLIT
+#define AZG_SEG(k, d)
+#else
+#define AZG_SEG(k, d) H.cyc_seg[k] += (uint32_t)(d)
+#endif
+    long long c0 = clock64();
     FR::load_state(sm.st, FR::nstate(F, t, parent_node));
+    long long c1 = clock64(); AZG_SEG(0, c1 - c0);
     int np = 0;
     Rng no_rng{0, 0, 0};
     if (lane_id() == 0) np = G::make_move(sm.st, a, 0, seed, no_rng);
     np = uni_i32(np);
     wave_sync();
+    c0 = clock64(); AZG_SEG(1, c0 - c1);
     if (np != 0) G::swap_players(sm.st, sm.tmp, np);
     const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
+    c1 = clock64(); AZG_SEG(2, c1 - c0);
     uint32_t free_slot;
-    const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot);
+    uint32_t found_rec = AZG_NONE;
+    const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
+    c0 = clock64(); AZG_SEG(3, c0 - c1);
     uint32_t crec;
     *is_new = false;
-    if (found != AZG_NONE) crec = uni_u32(FR::nhdr(F, t, found)->rec_off);
+    if (found != AZG_NONE) crec = found_rec;
     else {
         const long long t_l = clock64();
         crec = create_leaf<G, HS>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, terminal, es);
@@ -266,11 +293,15 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
     return crec | ((uint32_t)np << 30);
 }
 
+__device__ __forceinline__ void stat_add(uint64_t* p, uint64_t v) {
+    __hip_atomic_fetch_add((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The fields of TreeHdr that k_select keeps live (wave-uniform => SGPRs).  Loading the whole 200-byte header into
 // registers made the kernel spill to scratch; the cold fields are read-modify-written by lane 0 at the end instead.
 struct SelState {
     uint32_t n_nodes, heap_top, root, root_rec, sim_idx, n_sims, is_full, forced, err, leaf_is_root, mid_sim, cur_rec,
-        cur_depth, cur_pre, status, pending_leaf, path_len, cyc_leaf;
+        cur_depth, cur_pre, status, pending_leaf, path_len, cyc_leaf, cyc_seg[4];
 };
 
 // One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
@@ -293,6 +324,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
     H.leaf_is_root = uni_u32(Hp->leaf_is_root); H.mid_sim = uni_u32(Hp->mid_sim); H.cur_rec = uni_u32(Hp->cur_rec);
     H.cur_depth = uni_u32(Hp->cur_depth); H.cur_pre = uni_u32(Hp->cur_pre);
     H.status = ST_SEARCHING; H.pending_leaf = AZG_NONE; H.path_len = 0; H.cyc_leaf = 0;
+    H.cyc_seg[0] = H.cyc_seg[1] = H.cyc_seg[2] = H.cyc_seg[3] = 0;
     uint8_t* hp = FR::heap(F, t);
     const uint32_t ES = entry_stride(F.U);
     bool need_nn = false;
@@ -323,7 +355,8 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                 FR::load_state(sm.st, F.root_state + (size_t)t * G::SP);
                 const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
                 uint32_t free_slot;
-                const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot);
+                uint32_t found_rec = AZG_NONE;
+                const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
                 if (found == AZG_NONE) {
                     rec = create_leaf<G, SelState>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, &leaf_terminal, es);
                     if (rec == AZG_NONE) continue;
@@ -333,7 +366,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                     have_leaf = true;
                 } else {
                     H.root = found;
-                    rec = H.root_rec = uni_u32(FR::nhdr(F, t, found)->rec_off);
+                    rec = H.root_rec = found_rec;
                 }
             }
         }
@@ -355,6 +388,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
             const uint2 pn = *(const uint2*)(ent + AZG_E_P);
             const double q0 = *(const double*)(ent + AZG_E_Q);
             const uint32_t ch0 = *(const uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)uidx);
+            const uint32_t id0 = *(const uint16_t*)(ent + AZG_E_ID(F.U));
             const RecHdr rh = load_uniform((const RecHdr*)rp);
             if (rh.flags & NF_TERMINAL) {                                                       // MCTS.py:136-138
                 c_term++;
@@ -368,10 +402,9 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
             const int nv = rh.nv;
             // ---- pick_highest_UCB (MCTS.py:210-230) ----
             const bool forced = depth == 0 && H.forced;
-            const double sqrtNs = sqrt((double)rh.Ns);
-            const double sqrtNsEps = sqrt((double)rh.Ns + AZG_EPS);
+            const double sqrtNs = rh.sq[0], sqrtNsEps = rh.sq[1];        // == sqrt(Ns), sqrt(Ns + EPS): see RecHdr
             const double fpu_init = F.fpu > 0 ? (double)rh.Qs - F.fpu : F.fpu;
-            int j = -1;
+            int j = -1, a_sel = 0;
             uint32_t child = AZG_NONE;
             {
                 float p = __uint_as_float(pn.x);
@@ -380,9 +413,9 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                 const bool act = l < nv;
                 double best_u = -INFINITY;
                 int best_j = 0x7FFFFFFF;
-                uint32_t best_ch = AZG_NONE;
+                uint32_t best_ch = AZG_NONE, best_id = 0;
                 for (int base = 0; base < nv; base += 64) {
-                    uint32_t chv = ch0;
+                    uint32_t chv = ch0, idv = id0;
                     bool a_ok = act;
                     if (base > 0) {
                         const int jj = base + l;
@@ -392,6 +425,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                         n = *(const uint32_t*)(e2 + AZG_E_N);
                         q = *(const double*)(e2 + AZG_E_Q);
                         chv = *(const uint32_t*)(e2 + AZG_E_C + 4u * (uint32_t)uidx);
+                        idv = *(const uint16_t*)(e2 + AZG_E_ID(F.U));
                     }
                     if (forced) {                                                 // :218-220 first deficient action wins
                         const double thr = sqrt(0.5 * (double)p * (double)H.sim_idx);
@@ -399,7 +433,8 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                         if (def) {
                             const int src = first_lane(def);
                             j = base + src;
-                            child = uni_u32(__shfl(chv, src, 64));
+                            child = (uint32_t)__builtin_amdgcn_readlane((int)chv, src);
+                            a_sel = __builtin_amdgcn_readlane((int)idv, src);
                             break;
                         }
                     }
@@ -410,14 +445,13 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                     best_u = take ? u : best_u;
                     best_j = take ? jj : best_j;
                     best_ch = take ? chv : best_ch;
+                    best_id = take ? idv : best_id;
                 }
                 if (j < 0) {
                     // wave arg-max, lowest index on ties (== ascending scan with strict '>', MCTS.py:216-228): reduce the
                     // f64 maximum, then the FIRST lane (lowest entry index of its chunk) holding it wins; across chunks the
                     // per-lane running best already prefers the earlier chunk on ties.
-                    double mx = best_u;
-#pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1) { const double o = shfl_xor_f64(mx, m); mx = o > mx ? o : mx; }
+                    const double mx = wave_max_f64(best_u);
                     const uint64_t hit = __ballot(best_u == mx && best_j != 0x7FFFFFFF);
                     // several lanes can tie with different chunks' indices only when nv > 64: pick the lowest index
                     int src = first_lane(hit);
@@ -425,10 +459,11 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                         int cand = (best_u == mx) ? best_j : 0x7FFFFFFF;
 #pragma unroll
                         for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(cand, m, 64); cand = o < cand ? o : cand; }
-                        src = cand & 63;
+                        src = uni_i32(cand) & 63;
                     }
-                    j = uni_i32(__shfl(best_j, src, 64));
-                    child = uni_u32(__shfl(best_ch, src, 64));
+                    j = __builtin_amdgcn_readlane(best_j, src);
+                    child = (uint32_t)__builtin_amdgcn_readlane((int)best_ch, src);
+                    a_sel = __builtin_amdgcn_readlane((int)best_id, src);
                 }
             }
             c_levels++;
@@ -436,8 +471,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
             cyc_levels += clock64() - t_lvl;
             if (depth >= AZG_MAXD - 1) { H.err |= ERR_DEPTH_OVERFLOW; H.sim_idx = H.n_sims; break; }
             if (child == AZG_NONE) {
-                const RecLayout L(nv, F.U);
-                const int a = (int)uni_u32(((const uint16_t*)(rp + L.offI))[j]);
+                const int a = a_sel;
                 bool is_new = false;
                 const long long t_e = clock64();
                 child = resolve_edge<G, SelState>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es);
@@ -477,10 +511,13 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
         Hp->sim_idx = H.sim_idx; Hp->err = H.err; Hp->leaf_is_root = H.leaf_is_root; Hp->mid_sim = H.mid_sim;
         Hp->cur_rec = H.cur_rec; Hp->cur_depth = H.cur_depth; Hp->cur_pre = H.cur_pre; Hp->status = H.status;
         Hp->pending_leaf = H.pending_leaf; Hp->path_len = H.path_len;
-        if (H.n_nodes > Hp->max_nodes_seen) Hp->max_nodes_seen = H.n_nodes;
-        Hp->c_sims += c_sims; Hp->c_levels += c_levels; Hp->c_sumvalid += c_sumvalid; Hp->c_term += c_term;
-        Hp->cyc_select += (uint64_t)(clock64() - t_start); Hp->cyc_levels += (uint64_t)cyc_levels;
-        Hp->cyc_edge += (uint64_t)cyc_edge; Hp->cyc_leaf += (uint64_t)H.cyc_leaf;
+        // statistics: no-return atomics, so the wave does not wait for a read-modify-write round trip before it retires
+        atomicMax(&Hp->max_nodes_seen, H.n_nodes);
+        stat_add(&Hp->c_sims, c_sims); stat_add(&Hp->c_levels, c_levels); stat_add(&Hp->c_sumvalid, c_sumvalid);
+        stat_add(&Hp->c_term, c_term);
+        stat_add(&Hp->cyc_select, (uint64_t)(clock64() - t_start)); stat_add(&Hp->cyc_levels, (uint64_t)cyc_levels);
+        stat_add(&Hp->cyc_edge, (uint64_t)cyc_edge); stat_add(&Hp->cyc_leaf, (uint64_t)H.cyc_leaf);
+        for (int k = 0; k < 4; k++) stat_add(&Hp->cyc_seg[k], (uint64_t)H.cyc_seg[k]);
         needs_eval[t] = need_nn ? 1 : 0;
     }
 }
@@ -502,7 +539,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* 
     RecHdr* rhp = (RecHdr*)rec;
     const int nv = (int)uni_u32((uint32_t)rhp->nv);
     const RecLayout L(nv, F.U);
-    const uint16_t* ids = (const uint16_t*)(rec + L.offI);
+    const RecIds ids(rec, F.U);
     for (int i = l; i < G::A; i += 64) dense[i] = pi[(size_t)t * G::A + i];
     const int depth = (int)H.path_len;
     const PathEnt* gp = F.path + (size_t)t * AZG_MAXD;
@@ -555,7 +592,7 @@ __device__ bool root_counts(const ForestDev& F, int t, const TreeHdr& H, int* cn
     for (int p = 0; p < G::P; p++) q[p] = p == 0 ? q0 : -q0 / (float)(G::P - 1);
     if (!(rh.flags & NF_EXPANDED)) return false;
     const RecLayout L(rh.nv, F.U);
-    const uint16_t* ids = (const uint16_t*)(rec + L.offI);
+    const RecIds ids(rec, F.U);
     int best = 0;
     for (int j = l; j < rh.nv; j += 64) {
         int n = (int)*(const uint32_t*)(rec + AZG_REC_HDR + (size_t)j * L.ES + AZG_E_N);
@@ -627,7 +664,7 @@ __global__ __launch_bounds__(64) void k_root_stats(ForestDev F, int32_t* Ns, flo
     if (!(rh.flags & NF_EXPANDED)) return;
     __syncthreads();
     const RecLayout L(rh.nv, F.U);
-    const uint16_t* ids = (const uint16_t*)(rec + L.offI);
+    const RecIds ids(rec, F.U);
     for (int j = l; j < rh.nv; j += 64) {
         const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
         const int a = ids[j];

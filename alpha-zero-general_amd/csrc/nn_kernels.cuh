@@ -276,11 +276,24 @@ __global__ __launch_bounds__(256) void k_dw_pool(float* __restrict__ H, int ldh,
 struct V80BlockW {
     const float *We, *be, *Wd, *sd, *bd, *W1, *b1, *W2, *b2, *Wp, *bp;     // be/b1/b2/bp zero-padded to the padded widths
 };
+// What the whole-net fusion hangs onto the three blocks (k_v80_block MODE 1..3):
+//   MODE 1 (trunk):       boards int8 [B][56][7] -> f32 tile (layout change in LDS) -> first_layer Linear(56,56)+BN
+//                         (SplendorNNet.py:397-401) -> block -> xout in HBM
+//   MODE 2 (policy head): block -> Flatten -> Linear(392,81)+ReLU -> Linear(81,81) -> masked softmax -> pi in HBM
+//   MODE 3 (value head):  block -> Flatten -> Linear(392,P)+ReLU -> Linear(P,P) -> tanh -> v in HBM   (:414-440)
+// The block output tile stays in LDS (in place of x, row stride 60), so the flatten index of the head weights is
+// k = l*60 + c (rows with c >= 56 are zero): Wh1 is [432][96] (policy) / [432][16] (value), zero padded.
+struct V80NetW {
+    const float *W0, *b0;                  // first layer [64][64], [64]
+    const float *Wh1, *bh1, *Wh2, *bh2;    // policy: [432][96], [96], [96][96], [96];  value: [432][16], [16], [P][P], [P]
+};
 
-template <int ACT, int POOLMAX>
+template <int ACT, int POOLMAX, int MODE>
 __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin, float* __restrict__ xout, V80BlockW W,
-                                                   int B) {
-    constexpr int C = 56, E = 168, NS = 16, ROWS = NS * 7, XS = 60, HS = 172, QS = 52;
+                                                   int B, const int8_t* __restrict__ boards, V80NetW N,
+                                                   const uint8_t* __restrict__ valid, float* __restrict__ pi_out,
+                                                   float* __restrict__ v_out, int P) {
+    constexpr int C = 56, E = 168, NS = 16, ROWS = NS * 7, XS = 60, HS = 172, QS = 52, FK = 7 * XS /* 420 */, A = 81;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;                    // [ROWS][XS]
     float* H = X + ROWS * XS;           // [ROWS][HS]
@@ -292,6 +305,49 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
     const int g = lane >> 4, r16 = lane & 15;
     const int b0 = blockIdx.x * NS;
     const int nrows = min(ROWS, (B - b0) * 7);
+    const int nt_p = wave & 3;
+
+    if (MODE == 1) {
+        // ---- P0': board tile (int8, [s][c][l]) -> X0[s*7+l][c] f32 (aliases H), then first layer -> X ----
+        float w0r[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) w0r[c][j] = N.W0[(16 * c + 4 * g + j) * 64 + nt_p * 16 + r16];
+        const float4 b04 = *(const float4*)(N.b0 + nt_p * 16 + 4 * g);
+        float* X0 = H;
+        const int nb = min(NS, B - b0);
+        const uint32_t* bsrc = (const uint32_t*)(boards + (size_t)b0 * (7 * C));
+        for (int i = tid; i < NS * (7 * C / 4); i += 768) {
+            const int s = i / (7 * C / 4), d = i - s * (7 * C / 4);
+            const uint32_t v = s < nb ? bsrc[i] : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int idx = 4 * d + q, c = idx / 7, l = idx - c * 7;
+                X0[(s * 7 + l) * XS + c] = (float)(int8_t)(v >> (8 * q));
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int rt = wave >> 2; rt < 7; rt += 3) {
+            const float* xr = X0 + (rt * 16 + r16) * XS + 4 * g;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (16 * c + 4 * g < C) a = *(const float4*)(xr + 16 * c);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c][0], a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c][1], a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c][2], a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c][3], a.w, acc, 0, 0, 0);
+            }
+            const int col0 = nt_p * 16 + 4 * g;
+            if (col0 < XS)            // columns 56..59 get 0 (zero-padded W0 / b0)
+                *(float4*)(X + (rt * 16 + r16) * XS + col0) =
+                    make_float4(acc[0] + b04.x, acc[1] + b04.y, acc[2] + b04.z, acc[3] + b04.w);
+        }
+        __syncthreads();
+    }
 
     // ---- weight fragments -> registers (L2 hits; issued before the x tile arrives) ----
     float we[4][4], w2r[3][4], w1r[11][4], wpr[11][4];
@@ -309,7 +365,6 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
     for (int c = 0; c < 11; c++)
 #pragma unroll
         for (int j = 0; j < 4; j++) w1r[c][j] = W.W1[(16 * c + 4 * g + j) * 48 + nt_1 * 16 + r16];
-    const int nt_p = wave & 3;
 #pragma unroll
     for (int c = 0; c < 11; c++)
 #pragma unroll
@@ -320,12 +375,14 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
     const float4 bp4 = *(const float4*)(W.bp + nt_p * 16 + 4 * g);
     if (tid < 49) WD[tid] = W.Wd[tid];
 
-    // ---- P0: x tile -> LDS (contiguous rows, float4) ----
-    for (int i = tid; i < ROWS * (C / 4); i += 768) {
-        const int row = i / (C / 4), c4 = i - row * (C / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nrows) v = *(const float4*)(xin + ((size_t)b0 * 7 + row) * C + 4 * c4);
-        *(float4*)(X + row * XS + 4 * c4) = v;
+    if (MODE != 1) {
+        // ---- P0: x tile -> LDS (contiguous rows, float4); pad columns 56..59 zeroed ----
+        for (int i = tid; i < ROWS * (XS / 4); i += 768) {
+            const int row = i / (XS / 4), c4 = i - row * (XS / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nrows && c4 < C / 4) v = *(const float4*)(xin + ((size_t)b0 * 7 + row) * C + 4 * c4);
+            *(float4*)(X + row * XS + 4 * c4) = v;
+        }
     }
     __syncthreads();
 
@@ -419,7 +476,7 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
     }
     __syncthreads();
 
-    // ---- P5: project (SE-scaled operand) + BN + residual -> HBM ----
+    // ---- P5: project (SE-scaled operand) + BN + residual -> HBM (MODE 0/1) or in place of x in LDS (MODE 2/3) ----
 #pragma unroll 1
     for (int rt = wave >> 2; rt < 7; rt += 3) {
         const int row = rt * 16 + r16;
@@ -440,12 +497,138 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c][3], a.w, acc, 0, 0, 0);
         }
         const int col0 = nt_p * 16 + 4 * g;
-        if (row < nrows && col0 < C) {
+        if (MODE >= 2) {
+            if (col0 < XS) {          // each element is read (residual) and overwritten by the same lane
+                float* xp = X + row * XS + col0;
+                const float4 xr = *(const float4*)xp;
+                *(float4*)xp = make_float4(acc[0] + bp4.x + xr.x, acc[1] + bp4.y + xr.y, acc[2] + bp4.z + xr.z,
+                                           acc[3] + bp4.w + xr.w);
+            }
+        } else if (row < nrows && col0 < C) {
             const float4 xr = *(const float4*)(X + row * XS + col0);
             float4 v;
             v.x = acc[0] + bp4.x + xr.x; v.y = acc[1] + bp4.y + xr.y;
             v.z = acc[2] + bp4.z + xr.z; v.w = acc[3] + bp4.w + xr.w;
             *(float4*)(xout + ((size_t)b0 * 7 + row) * C + col0) = v;
+        }
+    }
+
+    if (MODE == 2) {
+        // ---- policy head tail on the block output O = X viewed as [16][420] ----
+        constexpr int LS = 100;
+        float* RED = H;                      // [2][16][LS]   K-halves of the first Linear
+        float* HID = RED + 2 * 16 * LS;      // [16][LS]
+        float* LG = HID + 16 * LS;           // [16][LS]
+        const int nt = wave % 6, half = wave / 6;
+        const int c_beg = half * 14, n_c = half ? 13 : 14;          // 27 K chunks of 16 (432 >= 420)
+        float wr[14][4];
+#pragma unroll
+        for (int cc = 0; cc < 14; cc++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                wr[cc][j] = cc < n_c ? N.Wh1[(size_t)(16 * (c_beg + cc) + 4 * g + j) * 96 + nt * 16 + r16] : 0.f;
+        __syncthreads();                     // O complete, H free
+        {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < 14; cc++) {
+                const int k0 = 16 * (c_beg + cc) + 4 * g;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cc < n_c && k0 < FK) a = *(const float4*)(X + r16 * FK + k0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc][0], a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc][1], a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc][2], a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc][3], a.w, acc, 0, 0, 0);
+            }
+            *(float4*)(RED + (half * 16 + r16) * LS + nt * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        float w2h[6][4];
+        if (wave < 6) {
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) w2h[c][j] = N.Wh2[(16 * c + 4 * g + j) * 96 + wave * 16 + r16];
+        }
+        __syncthreads();
+        if (tid < 16 * 24) {
+            const int s = tid / 24, col = 4 * (tid - s * 24);
+            const float4 p0 = *(const float4*)(RED + s * LS + col), p1 = *(const float4*)(RED + (16 + s) * LS + col);
+            const float4 bb = *(const float4*)(N.bh1 + col);
+            *(float4*)(HID + s * LS + col) = make_float4(fmaxf(p0.x + p1.x + bb.x, 0.f), fmaxf(p0.y + p1.y + bb.y, 0.f),
+                                                         fmaxf(p0.z + p1.z + bb.z, 0.f), fmaxf(p0.w + p1.w + bb.w, 0.f));
+        }
+        __syncthreads();
+        if (wave < 6) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const float4 a = *(const float4*)(HID + r16 * LS + 16 * c + 4 * g);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c][0], a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c][1], a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c][2], a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c][3], a.w, acc, 0, 0, 0);
+            }
+            const float4 bb = *(const float4*)(N.bh2 + wave * 16 + 4 * g);
+            *(float4*)(LG + r16 * LS + wave * 16 + 4 * g) =
+                make_float4(acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+        }
+        __syncthreads();
+        // masked softmax == exp(log_softmax(where(valid, logits, -1e8))) (GenericNNetWrapper.py:105-107), one wave per sample
+        for (int s = wave; s < NS; s += 12) {
+            const int b = b0 + s;
+            if (b >= B) continue;
+            const int a1 = lane + 64;
+            float x0 = valid[(size_t)b * A + lane] ? LG[s * LS + lane] : -1e8f;
+            float x1 = a1 < A ? (valid[(size_t)b * A + a1] ? LG[s * LS + a1] : -1e8f) : -INFINITY;
+            float mx = fmaxf(x0, x1);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+            x0 = expf(x0 - mx);
+            x1 = a1 < A ? expf(x1 - mx) : 0.f;
+            float sum = x0 + x1;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+            pi_out[(size_t)b * A + lane] = x0 / sum;
+            if (a1 < A) pi_out[(size_t)b * A + a1] = x1 / sum;
+        }
+    }
+
+    if (MODE == 3) {
+        // ---- value head tail: Linear(392,P) -> ReLU -> Linear(P,P) -> tanh ----
+        float* RED = H;                      // [12][16][16]
+        __syncthreads();
+        {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                const int c = wave + 12 * cc;
+                const int k0 = 16 * c + 4 * g;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                float w4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (c < 27) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) w4[j] = N.Wh1[(size_t)(k0 + j) * 16 + r16];
+                    if (k0 < FK) a = *(const float4*)(X + r16 * FK + k0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[0], a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[1], a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[2], a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[3], a.w, acc, 0, 0, 0);
+            }
+            *(float4*)(RED + (wave * 16 + r16) * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        __syncthreads();
+        if (tid < NS * P) {
+            const int s = tid / P, p = tid - s * P, b = b0 + s;
+            if (b < B) {
+                float a = N.bh2[p];
+                for (int j = 0; j < P; j++) {
+                    float h = N.bh1[j];
+                    for (int w = 0; w < 12; w++) h += RED[(w * 16 + s) * 16 + j];
+                    a += fmaxf(h, 0.f) * N.Wh2[j * P + p];
+                }
+                v_out[(size_t)b * P + p] = tanhf(a);
+            }
         }
     }
 }

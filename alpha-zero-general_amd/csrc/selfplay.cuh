@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
                 const uint8_t* rrec = FR::rec_ptr(F, t, H.root_rec);
                 const RecHdr rh = load_uniform((const RecHdr*)rrec);
                 if (rh.flags & NF_EXPANDED) {
-                    const uint16_t* ids = (const uint16_t*)(rrec + RecLayout(rh.nv, F.U).offI);
+                    const RecIds ids(rrec, F.U);
                     for (int j = l; j < rh.nv; j += 64) F.rec_valid[r * G::A + ids[j]] = 1;
                 }
             }
@@ -306,7 +306,8 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
         // locate the new root first so that GC can keep it
         uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
         uint32_t free_slot;
-        H.root = FR::probe(F, t, sm.st, h, &free_slot);
+        uint32_t found_rec = AZG_NONE;
+        H.root = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
         gc_tree<G>(F, t, H, new_round);
     }
     const double u_full = rng.u01();                                                           // MCTS.py:58

@@ -158,7 +158,7 @@ class Forest:
     def stats(self):
         s = SelfplayStats()
         check(lib().azg_selfplay_stats_get(self.h, C.byref(s)))
-        return {n: int(getattr(s, n)) for n, _ in SelfplayStats._fields_}
+        return {n: (list(getattr(s, n)) if n == 'cyc_seg' else int(getattr(s, n))) for n, _ in SelfplayStats._fields_}
 
     def drain_examples(self, max_records=None):
         max_records = max_records or self.cfg.max_examples

@@ -165,6 +165,7 @@ class SplendorV80Hip(SplendorV80):
         self.Q = self.trunk.W1.shape[1]
         self.weight_stationary = True
         self.fused_blocks = True
+        self.fused_net = True          # whole forward in 3 launches (azg_nn_v80_forward)
         self._bias_pad = {}
         self._prepare()
         self._alloc(max_batch)
@@ -216,6 +217,33 @@ class SplendorV80Hip(SplendorV80):
         self.pWv1 = self._pad_w(self.Wv1)
         for blk in (self.trunk, self.head_pi, self.head_v):
             self._block_ptrs(blk)
+        self._net_ptrs()
+
+    def _net_ptrs(self):
+        """device pointer table of azg_nn_v80_forward (include/azg.h): first layer, 3 blocks, head Linears re-indexed to the
+        in-LDS flatten k = l*60 + c"""
+        import ctypes as C
+        assert (self.trunk.use_hs, self.trunk.setype) == (False, 'avg')
+        assert (self.head_pi.use_hs, self.head_pi.setype) == (True, 'max') and (self.head_v.use_hs, self.head_v.setype) == (True, 'max')
+        assert self.C == 56 and self.A == 81
+        d, f = self.device, torch.float32
+
+        def pad(t, shape):
+            out = torch.zeros(shape, dtype=f, device=d)
+            out[tuple(slice(0, n) for n in t.shape)] = t
+            return out.contiguous()
+
+        def flat60(Wf, ncols):        # [7*56][N] (k = l*56 + c) -> [432][ncols] (k = l*60 + c)
+            N = Wf.shape[1]
+            out = torch.zeros((432, ncols), dtype=f, device=d)
+            out[:420].view(7, 60, ncols)[:, :56, :N] = Wf.view(7, 56, N)
+            return out.contiguous()
+        head = [flat60(self.Wpi1, 96), pad(self.bpi1, (96,)), pad(self.Wpi2, (96, 96)), pad(self.bpi2, (96,)),
+                flat60(self.Wv1, 16), pad(self.bv1, (16,)), self.Wv2.contiguous(), self.bv2.contiguous()]
+        first = [pad(self.W0, (64, 64)), pad(self.b0, (64,))]
+        self._net_keep = first + self.trunk._keep + self.head_pi._keep + self.head_v._keep + head
+        assert len(self._net_keep) == 43
+        self.net_ptrs = (C.c_void_p * 43)(*[t.data_ptr() for t in self._net_keep])
 
     def _linear(self, A, lda, Wp, bias, out, ldc, M, K, N, act=0, R=None, ldr=0, rowscale=None, rpg=0, ksplit=0):
         import ctypes as C
@@ -278,6 +306,10 @@ class SplendorV80Hip(SplendorV80):
         boards = boards.reshape(B, -1)
         assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda
         valids = valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)
+        if self.fused_net:
+            self._lib.check(L.azg_nn_v80_forward(p(boards), p(valids), self.net_ptrs, B, self.P, p(self.x2), p(self.pi),
+                                                 p(self.v), self._stream()))
+            return self.pi[:B], self.v[:B]
         self._lib.check(L.azg_nn_board_to_x(p(boards), p(self.x0), B, self.C, self._stream()))
         self._linear(self.x0, self.C, self.pW0, self.b0, self.x1, self.C, B * 7, self.C, self.C)           # first_layer
         self._block(self.trunk, self.x1, self.x2, B)

@@ -119,7 +119,8 @@ class SelfPlayEngine:
                 tot = dict(s)
             else:
                 for k, v in s.items():
-                    tot[k] = max(tot[k], v) if k == 'max_nodes' else (tot[k] | v if k == 'errors' else tot[k] + v)
+                    tot[k] = (max(tot[k], v) if k == 'max_nodes' else tot[k] | v if k == 'errors' else
+                              [a + b for a, b in zip(tot[k], v)] if k == 'cyc_seg' else tot[k] + v)
         return tot
 
     @property

@@ -147,8 +147,10 @@ int azg_selfplay_advance(azg_forest* f, void* stream);
 typedef struct azg_selfplay_stats {
     uint64_t plies, games, sims, levels, expansions, sum_valid_visited, terminal_hits, examples, gc_runs, max_nodes,
         errors, sum_depth_at_expand,
-        cyc_select, cyc_levels, cyc_edge, cyc_leaf;   /* shader-clock cycles summed over trees: whole k_select, descent levels,
+        cyc_select, cyc_levels, cyc_edge, cyc_leaf,   /* shader-clock cycles summed over trees: whole k_select, descent levels,
                                                          frontier edge resolution (incl. leaf creation), leaf creation */
+        cyc_seg[4];                                   /* frontier edge split: parent-state load, env step, canonical form +
+                                                         hash, table probe */
 } azg_selfplay_stats;
 int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out);
 /* drain finished-game examples: (board int8[S], pi f32[A], z f32[P], valids u8[A], q f32[P]) per record
@@ -183,6 +185,15 @@ int azg_nn_dw_pool(float* H_dev, int ldh, const float* Wd_dev /*[7][7] out,in*/,
    Wp[176][64], bp[64]} (zero padded, BatchNorm folded).  act 1 ReLU / 2 Hardswish; pool_max 0 mean / 1 max. */
 int azg_nn_v80_block(const float* xin_dev, float* xout_dev, const float* const* w, int B, int act, int pool_max,
                      void* stream);
+/* The whole V80 forward (NeuralNet.predict for a leaf batch, SplendorNNet.py:397-440 / GenericNNetWrapper.py:94-110) in
+   three launches: boards int8[B][56][7] -> first_layer + trunk block -> x_trunk (workspace f32 [B*7][56]); policy head
+   block + Flatten + Linear + ReLU + Linear + masked softmax -> pi f32[B][81]; value head block + Flatten + Linear +
+   ReLU + Linear + tanh -> v f32[B][P].  w = 43 device pointers: {W0[64][64], b0[64]}, 3 x the 11 block tensors of
+   azg_nn_v80_block (trunk, policy head, value head), {Wpi1[432][96], bpi1[96], Wpi2[96][96], bpi2[96]},
+   {Wv1[432][16], bv1[16], Wv2[P][P], bv2[P]}; the flatten index of Wpi1 / Wv1 rows is k = l*60 + c (c < 56), zero
+   padded.  Fixed to the V80 activations (trunk ReLU + mean squeeze, heads Hardswish + max squeeze). */
+int azg_nn_v80_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int B, int P,
+                       float* x_trunk_dev, float* pi_dev, float* v_dev, void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
 int azg_nn_board_to_x(const int8_t* boards_dev, float* x_dev, int B, int C, void* stream);
 /* pi = softmax(where(valid, logits, -1e8)) (== exp(log_softmax), GenericNNetWrapper.py:107); v = tanh(relu(vhid) @ Wv2 + bv2) */

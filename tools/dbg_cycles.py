@@ -13,7 +13,10 @@ net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2
 e = SelfPlayEngine(g, net, a, T, node_capacity=8512, max_examples=T*160, use_graph=False)
 e.start(); e.run(1200)
 s0 = e.stats(); e.run(300); s1 = e.stats()
-d = {k: s1[k]-s0[k] for k in s0}
+seg = [s1['cyc_seg'][k]-s0['cyc_seg'][k] for k in range(4)]
+d = {k: s1[k]-s0[k] for k in s0 if k != 'cyc_seg'}
 n = 300 * T
 print('per tree-launch cycles: select', d['cyc_select']/n, 'levels', d['cyc_levels']/n, 'edge', d['cyc_edge']/n, 'leaf', d['cyc_leaf']/n)
 print('levels/launch', d['levels']/n, 'sims/launch', d['sims']/n, 'cycles per level', d['cyc_levels']/max(1,d['levels']))
+print('edge split per tree-launch: load_state %.0f make_move %.0f canon+hash %.0f probe %.0f' % tuple(x/n for x in seg))
+print('expansions/launch', d['expansions']/n, 'terminal', d['terminal_hits']/n)
