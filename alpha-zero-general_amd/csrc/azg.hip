@@ -256,9 +256,10 @@ extern "C" int azg_forest_select(azg_forest* f, int8_t* leaf_states, uint8_t* le
     if (!f || !leaf_states || !leaf_valid || !needs_eval) return fail("null argument");
     if (f->cfg.dirichletAlpha != 0.0 && (root_noise || noise_stride == -1))
         FDISPATCH(f, k_root_noise<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, root_noise, noise_stride));
+    const int wait_noise = (f->cfg.dirichletAlpha != 0.0 && !root_noise && noise_stride == -2) ? 1 : 0;
     ev_begin(f, 0, (hipStream_t)stream);
     FDISPATCH(f, k_select<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, leaf_states,
-                                     leaf_valid, needs_eval));
+                                     leaf_valid, needs_eval, wait_noise));
     ev_end(f, 0, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -269,7 +270,7 @@ extern "C" int azg_forest_expand_backup(azg_forest* f, const float* pi, const fl
     if (!f || !pi || !v) return fail("null argument");
     ev_begin(f, 1, (hipStream_t)stream);
     FDISPATCH(f, k_expand_backup<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, pi,
-                                     v, (root_noise || noise_stride == -1) ? 1 : 0));
+                                     v, (root_noise || noise_stride == -1 || noise_stride == -2) ? 1 : 0));
     ev_end(f, 1, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;

@@ -143,20 +143,17 @@ __global__ __launch_bounds__(64) void k_begin_search(ForestDev F, const int8_t* 
 // with noise_pending != 0: an existing root at the start of a full search (entries hold the normalised prior), or a root
 // that was expanded by simulation 0 (k_expand_backup left the RAW net output in the entries).  Both get the reference's
 // sequence softmax(T) -> 0.75*P + 0.25*Dir -> normalise.
+// Applies the noise to the root record `root_rec` of tree t (all lanes must call); returns false when there is nothing to do.
 template <class G>
-__global__ __launch_bounds__(64) void k_root_noise(ForestDev F, const double* root_noise, int noise_stride) {
+__device__ __forceinline__ bool root_noise_tree(const ForestDev& F, int t, uint32_t root_rec, uint64_t c_sims,
+                                                const double* root_noise, int noise_stride, float* dense /*LDS [A]*/,
+                                                uint64_t* mask /*LDS [AW]*/) {
     using FR = Forest<G>;
-    __shared__ __attribute__((aligned(16))) float dense[G::A];
-    __shared__ __attribute__((aligned(16))) uint64_t mask[G::AW];
-    const int t = blockIdx.x;
     const int l = lane_id();
-    const uint32_t pending = uni_u32(F.hdr[t].noise_pending);
-    if (!pending) return;
-    const uint32_t root_rec = uni_u32(F.hdr[t].root_rec);
-    if (root_rec == AZG_NONE) return;
+    if (root_rec == AZG_NONE) return false;
     uint8_t* rec = FR::rec_ptr(F, t, root_rec);
     const RecHdr rh = load_uniform((const RecHdr*)rec);
-    if (!(rh.flags & NF_EXPANDED)) return;
+    if (!(rh.flags & NF_EXPANDED)) return false;
     const int nv = rh.nv;
     const RecLayout L(nv, F.U);
     const RecIds ids(rec, F.U);
@@ -168,11 +165,22 @@ __global__ __launch_bounds__(64) void k_root_noise(ForestDev F, const double* ro
         for (int j = 0; j < nv; j++) mask[ids[j] >> 6] |= 1ull << (ids[j] & 63);
     wave_sync();
     const double* nz = root_noise ? root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride) : nullptr;
-    const uint64_t c_sims = F.hdr[t].c_sims;
     FR::root_noise_dense(dense, mask, F.temp_root, nz, root_noise != nullptr && noise_stride < 0, F.dirichletAlpha,
                          mix64(mix64(F.rng_seed ^ 0xA5A5A5A55A5A5A5AULL) + F.stream0 + (uint64_t)t), c_sims << 20);
     for (int j = l; j < nv; j += 64) *(float*)(rec + AZG_REC_HDR + (size_t)j * L.ES + AZG_E_P) = dense[ids[j]];
-    if (l == 0) F.hdr[t].noise_pending = 0u;
+    return true;
+}
+
+template <class G>
+__global__ __launch_bounds__(64) void k_root_noise(ForestDev F, const double* root_noise, int noise_stride) {
+    __shared__ __attribute__((aligned(16))) float dense[G::A];
+    __shared__ __attribute__((aligned(16))) uint64_t mask[G::AW];
+    const int t = blockIdx.x;
+    if (!uni_u32(F.hdr[t].noise_pending)) return;
+    const uint32_t root_rec = uni_u32(F.hdr[t].root_rec);
+    const uint64_t c_sims = F.hdr[t].c_sims;
+    if (root_noise_tree<G>(F, t, root_rec, c_sims, root_noise, noise_stride, dense, mask) && lane_id() == 0)
+        F.hdr[t].noise_pending = 0u;
 }
 
 // PUCT score of one entry (pick_highest_UCB body, MCTS.py:222-225), f64 with the Numba operand typing.
@@ -307,13 +315,14 @@ struct SelState {
 // One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
 template <class G>
 __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
-                                                  uint8_t* needs_eval) {
+                                                  uint8_t* needs_eval, int wait_noise) {
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
     const int t = blockIdx.x;
     const int l = lane_id();
     TreeHdr* Hp = &F.hdr[t];
-    if (uni_u32(Hp->status) != ST_SEARCHING) {
+    // wait_noise: the root noise is applied by the periodic k_selfplay_advance launch; until then the tree sits out
+    if (uni_u32(Hp->status) != ST_SEARCHING || (wait_noise && uni_u32(Hp->noise_pending))) {
         if (l == 0) needs_eval[t] = 0;
         return;
     }

@@ -181,9 +181,18 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     __shared__ typename FR::Smem sm;
     __shared__ int cnt[G::A];
     __shared__ double w[G::A];
+    __shared__ __attribute__((aligned(16))) float dense[G::A];
     const int t = blockIdx.x;
     const int l = lane_id();
-    if (uni_u32(F.hdr[t].status) != ST_DONE) return;
+    const uint32_t status0 = uni_u32(F.hdr[t].status);
+    if (status0 != ST_DONE) {
+        // nothing to advance; a root expanded by simulation 0 may still be waiting for its Dirichlet noise (MCTS.py:147-149)
+        if (!uni_u32(F.hdr[t].noise_pending) || status0 != ST_SEARCHING) return;
+        const uint32_t root_rec = uni_u32(F.hdr[t].root_rec);
+        const uint64_t c_sims = F.hdr[t].c_sims;
+        if (root_noise_tree<G>(F, t, root_rec, c_sims, nullptr, -1, dense, sm.mask) && l == 0) F.hdr[t].noise_pending = 0u;
+        return;
+    }
     TreeHdr H = load_uniform(&F.hdr[t]);
     if (H.err) return;                         // tree is parked; the host reads the error flag
     Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, H.rng_counter};
@@ -314,6 +323,8 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     begin_search_from_lds<G>(F, t, H, sm, u_full < F.prob_fullMCTS);
     H.rng_counter = rng.counter;
     if (H.n_nodes > H.max_nodes_seen) H.max_nodes_seen = H.n_nodes;
+    // an EXISTING root gets its noise before simulation 0 (MCTS.py:64,156-160)
+    if (H.noise_pending && root_noise_tree<G>(F, t, H.root_rec, H.c_sims, nullptr, -1, dense, sm.mask)) H.noise_pending = 0u;
     if (l == 0) F.hdr[t] = H;
 }
 

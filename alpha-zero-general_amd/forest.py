@@ -90,17 +90,22 @@ class Forest:
         assert noise.dtype == torch.float64 and noise.is_contiguous()
         return -noise.shape[1] if normalised else noise.shape[1]
 
+    def _noise_arg(self, noise, normalised, device_noise):
+        """noise_stride of include/azg.h: device_noise True -> -1 (sampled on device right before each select),
+        'deferred' -> -2 (sampled on device by the next selfplay_advance; trees wait for it)"""
+        if noise is None and device_noise:
+            return -2 if device_noise == 'deferred' else -1
+        return self._stride(noise, normalised)
+
     def select(self, noise=None, normalised=False, device_noise=False):
         check(lib().azg_forest_select(self.h, _ptr(self.leaf_states), _ptr(self.leaf_valid), _ptr(self.needs_eval),
-                                      _ptr(noise), -1 if (device_noise and noise is None) else self._stride(noise, normalised),
-                                      _stream()))
+                                      _ptr(noise), self._noise_arg(noise, normalised, device_noise), _stream()))
 
     def expand_backup(self, pi, v, noise=None, normalised=False, device_noise=False):
         assert pi.dtype == torch.float32 and v.dtype == torch.float32 and pi.is_contiguous() and v.is_contiguous()
         assert pi.shape == (self.T, self.A) and v.shape == (self.T, self.P)
         check(lib().azg_forest_expand_backup(self.h, _ptr(pi), _ptr(v), _ptr(noise),
-                                             -1 if (device_noise and noise is None) else self._stride(noise, normalised),
-                                             _stream()))
+                                             self._noise_arg(noise, normalised, device_noise), _stream()))
 
     def active(self):
         n = C.c_int()

@@ -2,7 +2,10 @@
 batched NeuralNet.predict per lock-step round.  The reference time-slices N game threads on one core around a lock ring
 to build inference batches of N (Coach.py:117-144); here every round is
     select (HIP) -> predict_batch (MFMA net kernels) -> expand_backup (HIP) -> selfplay_advance (HIP)
-with no host decision in the loop, so it is captured once in a HIP graph and replayed.
+with no host decision in the loop, so it is captured once in a HIP graph and replayed.  selfplay_advance only has work
+for a tree once per search (numMCTSSims rounds), so it is launched every `advance_every` rounds: a tree whose search is
+finished (or whose fresh root waits for its Dirichlet noise) sits out up to advance_every-1 rounds -- (advance_every-1) /
+numMCTSSims of its time -- in exchange for one launch less per round; per-tree results do not depend on the cadence.
 
 The descent kernel is a latency chain (few waves, each waiting on dependent loads) while the net is throughput bound, so
 the games are split into `groups` independent forests whose rounds are skewed by one stage and run on separate HIP
@@ -19,22 +22,28 @@ class _Group:
     def select(self):
         self.f.select(device_noise=self.device_noise)
 
-    def predict_expand_advance(self):
+    def predict_expand(self):
         f = self.f
         pi, v = self.net.predict_batch(f.leaf_states.view(self.shape), f.leaf_valid)
         f.expand_backup(pi, v, device_noise=self.device_noise)
-        f.selfplay_advance()
+
+    def predict_expand_advance(self):
+        self.predict_expand()
+        self.f.selfplay_advance()
 
 
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
-                 use_graph=True, dirichlet=None, level_budget=0, groups=1):
+                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None):
         self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
         cap = node_capacity or max(1024, 8 * sims)
         assert n_games % groups == 0
         self.T, self.G = n_games, groups
+        # cadence of the advance launch: idle share (K-1)/numMCTSSims kept under ~1 %
+        self.K = max(1, min(8, sims // 100)) if advance_every is None else int(advance_every)
+        assert self.K == 1 or groups == 1
         Tg = n_games // groups
         alpha = float(get('dirichletAlpha', 0.0)) if dirichlet is None else float(dirichlet)
         # Coach passes dirichlet_noise=(dirichletAlpha != 0) (Coach.py:31,96).  The Gamma variates of
@@ -45,7 +54,7 @@ class SelfPlayEngine:
             f = Forest(game.GAME_ID, game.variant, Tg, args, node_capacity=cap,
                        max_examples=(max_examples or n_games * 64) // groups, rng_seed=rng_seed,
                        stream0=stream0 + g * Tg, device=str(game.device), level_budget=level_budget)
-            self.groups.append(_Group(f, nets[g], (Tg,) + tuple(f.board_shape()), alpha != 0.0))
+            self.groups.append(_Group(f, nets[g], (Tg,) + tuple(f.board_shape()), 'deferred' if alpha != 0.0 else False))
         self.forest = self.groups[0].f
         self.nnet = nets[0]
         self.use_graph = use_graph
@@ -64,12 +73,14 @@ class SelfPlayEngine:
                 grp.select()
         torch.cuda.synchronize()
 
-    def _round(self):
+    def _round(self, advance=True):
         """one round of every group; group g's stage order is rotated by g (software-pipeline skew)"""
         if self.G == 1:
             grp = self.groups[0]
             grp.select()
-            grp.predict_expand_advance()
+            grp.predict_expand()
+            if advance:
+                grp.f.selfplay_advance()
             return
         cur = torch.cuda.current_stream()
         for g, grp in enumerate(self.groups):
@@ -96,19 +107,21 @@ class SelfPlayEngine:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._round()
+            for k in range(self.K):
+                self._round(advance=(k == self.K - 1))
         self.graph = g
-        self.rounds += 4
+        self.rounds += 3 + self.K
 
     def run(self, rounds):
         if self.use_graph and self.graph is None:
             self.capture()
+        done = 0
         if self.graph is not None:
-            for _ in range(rounds):
+            for _ in range(rounds // self.K):
                 self.graph.replay()
-        else:
-            for _ in range(rounds):
-                self._round()
+            done = rounds - rounds % self.K
+        for _ in range(rounds - done):               # remainder (or no graph): eager rounds, advance every round
+            self._round()
         self.rounds += rounds
 
     def stats(self):

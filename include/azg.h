@@ -113,7 +113,10 @@ int azg_forest_select(azg_forest* f, int8_t* leaf_states_dev, uint8_t* leaf_vali
    first entries (== rng.dirichlet([alpha]*n_valid)); noise_stride < 0: rows already hold a Dirichlet sample over the
    valid actions (parity tests inject the reference's own sample), stride = -noise_stride.
    root_noise_dev == NULL with noise_stride == -1: the engine draws the Gamma variates itself (counter-based stream keyed
-   by rng_seed / game stream / simulation count; cfg.dirichletAlpha > 0, or < 0 for the automatic 10/n_valid). */
+   by rng_seed / game stream / simulation count; cfg.dirichletAlpha > 0, or < 0 for the automatic 10/n_valid).
+   root_noise_dev == NULL with noise_stride == -2 (self-play): same device sampler, but run by the next
+   azg_selfplay_advance launch instead of a launch of its own; a tree whose root noise is pending sits out the selects
+   in between (same per-tree event sequence, so results do not depend on how often advance is launched). */
 /* part 2: store (Ps, v) on the pending leaves and back the values up (MCTS.py:147-154,176-183).
    pi f32[T][A] are PROBABILITIES (exp of the net's log-softmax, GenericNNetWrapper.py:107,119), v f32[T][P]. */
 int azg_forest_expand_backup(azg_forest* f, const float* pi_dev, const float* v_dev, const double* root_noise_dev,
@@ -139,7 +142,7 @@ int azg_forest_validate(azg_forest* f, int verbose);
 /* --- self-play mode: Coach.executeEpisode on device (Coach.py:37-84) --- */
 /* start one game per tree (Board.init_game or the given init boards int8[T][S]) */
 int azg_selfplay_start(azg_forest* f, const int8_t* init_boards_dev /* or NULL */, void* stream);
-/* to be called once per round after expand_backup: trees whose search finished sample the move
+/* to be called after expand_backup, every round or every few rounds: trees whose search finished sample the move
    (Coach.py:63,278-292), record the example (Coach.py:65-69), play it (Coach.py:71), detect the end (Coach.py:73-82),
    restart finished games, re-root and begin the next search -- all on device. */
 int azg_selfplay_advance(azg_forest* f, void* stream);

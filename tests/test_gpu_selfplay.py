@@ -100,3 +100,37 @@ def test_selfplay_gc_keeps_results(tmp_path):
             assert np.array_equal(boards[k], o['canonical'][ply]), (t, ply)
             assert np.array_equal(pis[k], o['pi'][ply].astype(np.float32)), (t, ply)
     f.close()
+
+
+def test_advance_cadence_does_not_change_results():
+    """SelfPlayEngine launches selfplay_advance (move sampling, re-rooting, root Dirichlet noise) every `advance_every`
+    rounds; trees wait for it, so the examples of every game must be identical for any cadence (device noise sampler on)."""
+    import torch
+    from azg_amd import games
+    from azg_amd.selfplay import SelfPlayEngine
+    from hashnet import HashNetTorch
+    g = games.SplendorGame(2)
+    args = Args(numMCTSSims=24, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0],
+                tempThreshold=6, **MCTS_ARGS['splendor2'])
+    T = 32
+    res = []
+    for K, graph in ((1, False), (5, True)):
+        e = SelfPlayEngine(g, HashNetTorch(2), args, T, node_capacity=2048, max_examples=T * 400, rng_seed=99, stream0=7,
+                           use_graph=graph, advance_every=K)
+        e.start()
+        for _ in range(400):
+            e.run(40)
+            st = e.stats()
+            assert st['errors'] == 0
+            if st['games'] >= 3 * T:
+                break
+        ex = [x.cpu().numpy() for x in e.drain_examples()]
+        meta = ex[5]
+        keep = np.flatnonzero(meta[:, 1] == 0)                       # first game of every stream (finished in both runs)
+        order = keep[np.lexsort((meta[keep, 2], meta[keep, 0]))]
+        res.append([x[order] for x in ex])
+        for grp in e.groups:
+            grp.f.close()
+    assert len(res[0][0]) == len(res[1][0]) > 0
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
