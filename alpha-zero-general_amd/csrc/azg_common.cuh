@@ -118,13 +118,31 @@ __device__ __forceinline__ void wave_argmax_f64(double& u, int& idx) {
     }
 }
 
-// 64-bit hash of a zero-padded state held in LDS as n_dwords dwords (order-sensitive through the position salt).
+// 64-bit hash of a zero-padded state held in LDS as n_dwords dwords: multilinear sum_i a_i * x_i over Z_2^64 with a
+// distinct odd 32-bit multiplier per position (one v_mad_u64_u32 per dword; two states that differ in a single dword can
+// never collide), reduced over the wave and avalanched once on the wave-uniform result.  Only the table placement and
+// the 10-bit tag depend on it: node identity is always the full state.
 __device__ __forceinline__ uint64_t wave_hash_state(const uint32_t* lds_dwords, int n_dwords) {
     uint64_t acc = 0;
-    for (int i = lane_id(); i < n_dwords; i += 64)
-        acc += mix64((uint64_t)lds_dwords[i] + ((uint64_t)(i + 1) << 32) * 0x9E3779B1ULL + 0x2545F4914F6CDD1DULL * (uint64_t)(i + 1));
+    for (int i = lane_id(); i < n_dwords; i += 64) {
+        const uint32_t a = ((uint32_t)(i + 1) * 0x9E3779B1u) | 1u;
+        acc += (uint64_t)lds_dwords[i] * (uint64_t)a;
+    }
     acc = wave_sum_u64(acc);
     return mix64(acc ^ 0xD6E8FEB86659FD93ULL);
+}
+
+// Env step by lane 0 on the LDS state (games whose make_move is lane-serial): all lanes call, the next player and the
+// RNG counter come back wave-uniform, the LDS state is synchronised.
+template <class G>
+__device__ __forceinline__ int lane0_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
+    int np = 0;
+    if (lane_id() == 0) np = G::make_move(st, move, player, seed, rng);
+    np = __builtin_amdgcn_readfirstlane(np);
+    rng.counter = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rng.counter >> 32)) << 32) |
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rng.counter);
+    __syncthreads();
+    return np;
 }
 
 __device__ __forceinline__ int first_lane(uint64_t ballot) { return __ffsll((unsigned long long)ballot) - 1; }

@@ -189,6 +189,9 @@ struct AzulDev {
             scores[p] = (int8_t)(scores[p] + add);
         }
     }
+    __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
+        return lane0_make_move<AzulDev>(st, move, player, seed, rng);
+    }
 
     // Board.make_move :125-159 -- lane 0 only
     __device__ static int make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {

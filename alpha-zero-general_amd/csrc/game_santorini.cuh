@@ -168,6 +168,9 @@ struct SantoriniDev {
             if (l == 0) mask_lds[k] = m;
         }
     }
+    __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
+        return lane0_make_move<SantoriniDev<NB>>(st, move, player, seed, rng);
+    }
 
     // Board.make_move :434-550 -- lane 0 only
     __device__ static int make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {

@@ -2,7 +2,7 @@
 //
 // Semantics follow splendor/SplendorLogicNumba.py `Board` (line numbers cited); the byte layout of the state is the
 // reference's int8[(32+10n+n*n)][7] (copy_state :207-219).  valid_mask() is lane-parallel and branch-free (one action per lane, two
-// ballots for the 81 actions); make_move() is branchy integer work on ~400 LDS bytes and runs on lane 0.
+// ballots for the 81 actions); wave_make_move() keeps the branchy rule arithmetic on the scalar unit (see below).
 #pragma once
 #include "azg_common.cuh"
 #include "splendor_tables.h"
@@ -167,92 +167,239 @@ struct SplendorDev {
         for (int i = 0; i < 14; i++) dst[i] = got ? card[i] : (int8_t)0;
     }
 
-    __device__ static void buy_card(int8_t* st, const int8_t* c0, const int8_t* c1, int player) {       // :344-357
-        int8_t* bank = row(st, 0);
-        int8_t* gems = row(st, R_GEMS + player);
-        int8_t* cards = row(st, R_PCARDS + player);
-        int miss = missing(c0, gems, cards);
+    // ------------------------------------------------------------------------------------------------------------------
+    // Board.make_move :190-205 for the whole wave.  The env step is wave-uniform, branchy byte arithmetic: run by one lane
+    // it costs a full VALU instruction per byte operation (plus an LDS round trip per access).  Here the state is pulled
+    // into registers (lane i holds dwords i, 64+i, ... of the padded state), rows are fetched with v_readlane into SGPR
+    // pairs (7 packed bytes) and all the rule arithmetic stays on the scalar unit; modified rows go back with
+    // a compare+select.  Only the 14-byte card moves (table -> board slot, board slot -> reserve, reserve shift) are done as
+    // lane-parallel byte copies in LDS after the registers have been stored back.
+    // ------------------------------------------------------------------------------------------------------------------
+    static constexpr int SPW = SP / 4, NW = (SPW + 63) / 64;
+    struct SW {
+        uint32_t w[NW];
+        __device__ __forceinline__ void load(const int8_t* st) {
+#pragma unroll
+            for (int k = 0; k < NW; k++) { const int i = lane_id() + 64 * k; w[k] = i < SPW ? ((const uint32_t*)st)[i] : 0u; }
+        }
+        __device__ __forceinline__ void store(int8_t* st) const {
+#pragma unroll
+            for (int k = 0; k < NW; k++) { const int i = lane_id() + 64 * k; if (i < SPW) ((uint32_t*)st)[i] = w[k]; }
+        }
+        __device__ __forceinline__ uint32_t rd(int d) const {                      // d wave-uniform
+            uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)w[0], d & 63);
+#pragma unroll
+            for (int k = 1; k < NW; k++) {
+                const uint32_t vk = (uint32_t)__builtin_amdgcn_readlane((int)w[k], d & 63);
+                v = (d >> 6) == k ? vk : v;
+            }
+            return v;
+        }
+        __device__ __forceinline__ void wr(int d, uint32_t v) {
+#pragma unroll
+            for (int k = 0; k < NW; k++) w[k] = (lane_id() + 64 * k == d) ? v : w[k];   // v_cmp + v_cndmask (no writelane builtin)
+        }
+        __device__ __forceinline__ uint64_t row(int r) const {                     // 7 bytes of row r, packed little-endian
+            const int o = 7 * r, d = o >> 2, sh = (o & 3) * 8;
+            uint64_t v = (((uint64_t)rd(d + 1) << 32) | rd(d)) >> sh;
+            if (sh > 8) v |= (uint64_t)rd(d + 2) << (64 - sh);
+            return v & 0x00FFFFFFFFFFFFFFull;
+        }
+        __device__ __forceinline__ void set_row(int r, uint64_t v) {
+            const int o = 7 * r, d = o >> 2, sh = (o & 3) * 8;
+            const uint64_t m = 0x00FFFFFFFFFFFFFFull, M = m << sh, V = (v & m) << sh;
+            wr(d, (rd(d) & ~(uint32_t)M) | (uint32_t)V);
+            wr(d + 1, (rd(d + 1) & ~(uint32_t)(M >> 32)) | (uint32_t)(V >> 32));
+            if (sh > 8) wr(d + 2, (rd(d + 2) & ~(uint32_t)(m >> (64 - sh))) | (uint32_t)((v & m) >> (64 - sh)));
+        }
+    };
+    __device__ static __forceinline__ int B(uint64_t row, int c) { return (int)(int8_t)(uint8_t)(row >> (8 * c)); }
+    __device__ static __forceinline__ int UB(uint64_t row, int c) { return (int)(uint8_t)(row >> (8 * c)); }
+    __device__ static __forceinline__ void SETB(uint64_t& row, int c, int v) {
+        row = (row & ~(0xFFull << (8 * c))) | ((uint64_t)(uint8_t)v << (8 * c));
+    }
+    __device__ static __forceinline__ int rsum5(uint64_t r) { return B(r, 0) + B(r, 1) + B(r, 2) + B(r, 3) + B(r, 4); }
+    __device__ static __forceinline__ int rsum7(uint64_t r) { return rsum5(r) + B(r, 5) + B(r, 6); }
+
+    // v mod n for v < 2^22 (exact in f32, quotient estimate off by at most one)
+    __device__ static __forceinline__ uint32_t small_mod(uint32_t v, uint32_t n, float rn) {
+        const uint32_t q = (uint32_t)((float)v * rn);
+        int r = (int)(v - q * n);
+        r = r < 0 ? r + (int)n : r;
+        r = r >= (int)n ? r - (int)n : r;
+        return (uint32_t)r;
+    }
+    // (4594591 * b) mod n with Python floor-mod semantics (:316-323), n <= 40: Horner over 16-bit limbs
+    __device__ static __forceinline__ int draw_mod(long long b, int n) {
+        const float rn = 1.0f / (float)n;
+        const bool neg = b < 0;
+        const uint64_t ub = neg ? (uint64_t)(-b) : (uint64_t)b;
+        uint32_t mb = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) mb = small_mod(mb * 65536u + (uint32_t)((ub >> (16 * k)) & 0xFFFFu), (uint32_t)n, rn);
+        uint32_t ma = small_mod(70u, (uint32_t)n, rn);                              // 4594591 = 70 * 65536 + 7071
+        ma = small_mod(ma * 65536u + 7071u, (uint32_t)n, rn);
+        uint32_t r = small_mod(ma * mb, (uint32_t)n, rn);
+        if (neg && r) r = (uint32_t)n - r;
+        return (int)r;
+    }
+
+    // _get_deck_card :306-336 on the register view: picks (colour, index), updates the deck rows; false = deck empty
+    __device__ static __forceinline__ bool draw_card(SW& s, int tier, long long seed, Rng& rng, int* color_o, int* idx_o) {
+        uint64_t cnt = s.row(25 + 2 * tier), bits = s.row(26 + 2 * tier);
+        const int total = rsum5(cnt);
+        if (total == 0) return false;
+        int color = 0, card_index = 0;
+        if (seed == 0) {                                                   // true random :311-315
+            const double u = rng.u01();
+            double acc = 0.0;
+            int k = 0;
+            for (; k < 5; k++) { acc += (double)B(cnt, k) / (double)total; if (acc > u) break; }
+            if (k >= 5) { for (k = 4; k > 0 && B(cnt, k) == 0; k--) {} }
+            color = k;
+            const uint32_t b = (uint32_t)UB(bits, color);
+            const int nb = __popc(b);
+            const double u2 = rng.u01();
+            acc = 0.0;
+            int idx = -1, last = 0;
+            for (int i = 0; i < 8; i++) {
+                const int set = (b >> (7 - i)) & 1;
+                if (set) last = i;
+                acc += (double)set / (double)nb;
+                if (acc > u2) { idx = i; break; }
+            }
+            card_index = idx < 0 ? last : idx;
+        } else {                                                           // seeded universe draw :316-323
+            int n = 0;
+            long long seedv = 0, pw = 1;
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const uint32_t b = (uint32_t)UB(bits, c);
+                n += __popc(b);
+                seedv += (long long)b * pw;
+                pw *= 32;
+            }
+            int rem = draw_mod(seed + seedv, n);
+            // rem-th candidate in colour-major, MSB-first order
+            for (int c = 0; c < 5; c++) {
+                const uint32_t b = (uint32_t)UB(bits, c);
+                const int pc = __popc(b);
+                if (rem < pc) {
+                    color = c;
+                    for (int i = 0; i < 8; i++)
+                        if ((b >> (7 - i)) & 1) { if (rem == 0) { card_index = i; break; } rem--; }
+                    break;
+                }
+                rem -= pc;
+            }
+        }
+        SETB(bits, color, (int)((uint32_t)UB(bits, color) & ~(0x80u >> card_index)));   // int8 wrap :327
+        SETB(cnt, color, B(cnt, color) - 1);
+        s.set_row(25 + 2 * tier, cnt);
+        s.set_row(26 + 2 * tier, bits);
+        *color_o = color; *idx_o = card_index;
+        return true;
+    }
+
+    // _buy_card :344-357 + _give_nobles_if_earned :465-470 on the register view
+    __device__ static __forceinline__ void buy_card(SW& s, uint64_t& bank, uint64_t& gems, uint64_t c0, uint64_t c1, int player) {
+        uint64_t cards = s.row(R_PCARDS + player);
+        int miss = 0;
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            int8_t need = (int8_t)(c0[c] - cards[c]);
-            need = need < 0 ? (int8_t)0 : need;
-            int8_t paid = need < gems[c] ? need : gems[c];
-            gems[c] -= paid;
-            bank[c] += paid;
+            const int8_t d = (int8_t)((int8_t)(B(c0, c) - B(gems, c)) - B(cards, c));
+            miss += d > 0 ? d : 0;
         }
-        gems[GOLD] = (int8_t)(gems[GOLD] - miss);
-        bank[GOLD] = (int8_t)(bank[GOLD] + miss);
 #pragma unroll
-        for (int c = 0; c < COLS; c++) cards[c] += c1[c];
-        for (int i = 0; i < NN; i++) {                                     // _give_nobles_if_earned :465-470
-            int8_t* noble = row(st, R_NOBLES + i);
-            if (sum5(noble) <= 0) continue;
+        for (int c = 0; c < 5; c++) {
+            int8_t need = (int8_t)(B(c0, c) - B(cards, c));
+            need = need < 0 ? (int8_t)0 : need;
+            const int8_t g = (int8_t)B(gems, c);
+            const int8_t paid = need < g ? need : g;
+            SETB(gems, c, g - paid);
+            SETB(bank, c, B(bank, c) + paid);
+        }
+        SETB(gems, GOLD, B(gems, GOLD) - miss);
+        SETB(bank, GOLD, B(bank, GOLD) + miss);
+#pragma unroll
+        for (int c = 0; c < COLS; c++) SETB(cards, c, B(cards, c) + B(c1, c));
+        s.set_row(R_PCARDS + player, cards);
+        for (int i = 0; i < NN; i++) {
+            const uint64_t noble = s.row(R_NOBLES + i);
+            if (rsum5(noble) <= 0) continue;
             bool ok = true;
 #pragma unroll
-            for (int c = 0; c < 5; c++) ok = ok && cards[c] >= noble[c];
+            for (int c = 0; c < 5; c++) ok = ok && B(cards, c) >= B(noble, c);
             if (ok) {
-                int8_t* dst = row(st, R_PNOB + NN * player + i);
-#pragma unroll
-                for (int c = 0; c < COLS; c++) { dst[c] = noble[c]; noble[c] = 0; }
+                s.set_row(R_PNOB + NN * player + i, noble);
+                s.set_row(R_NOBLES + i, 0ull);
             }
         }
     }
 
-    // Board.make_move :190-205 -- lane 0 only
-    __device__ static int make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
-        int8_t* bank = row(st, 0);
-        int8_t* gems = row(st, R_GEMS + player);
+    // ALL lanes call with wave-uniform arguments; returns the next player; the LDS state is updated and synchronised.
+    __device__ static int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
+        move = uni_i32(move); player = uni_i32(player);
+        seed = (long long)(((uint64_t)uni_u32((uint32_t)((uint64_t)seed >> 32)) << 32) | uni_u32((uint32_t)seed));
+        const int l = lane_id();
+        SW s;
+        s.load(st);
+        uint64_t bank = s.row(0), gems = s.row(R_GEMS + player);
+        const int res = R_RES + 6 * player;
+        int fill_row = -1, fill_tier = 0, fill_color = 0, fill_idx = 0;   // 2-row slot that receives a card (or zeros)
+        bool fill_got = false;
+        int copy_src = -1, copy_dst = 0;                                    // 14-byte move board slot -> reserve slot
+        int shift_i = -1;                                                   // bought reserve slot: close the gap
         if (move < 12) {                                                   // _buy :370-373
-            int8_t c[14];
-            const int8_t* src = row(st, 1 + 2 * move);
-#pragma unroll
-            for (int i = 0; i < 14; i++) c[i] = src[i];
-            buy_card(st, c, c + 7, player);
-            fill_new_card(st, move >> 2, move & 3, seed, rng);
+            buy_card(s, bank, gems, s.row(1 + 2 * move), s.row(2 + 2 * move), player);
+            fill_tier = move >> 2;
+            fill_got = draw_card(s, fill_tier, seed, rng, &fill_color, &fill_idx);
+            fill_row = 1 + 2 * move;
         } else if (move < 27) {                                            // _reserve :382-400
-            int i = move - 12;
-            int8_t* res = row(st, R_RES + 6 * player);
+            const int i = move - 12;
             int slot = 2;
-            for (int s = 2; s >= 0; s--) if (sum5(res + 2 * s * COLS) == 0) slot = s;
-            int8_t* dst = res + 2 * slot * COLS;
+            for (int k = 2; k >= 0; k--) if (rsum5(s.row(res + 2 * k)) == 0) slot = k;
             if (i < 12) {
-                const int8_t* src = row(st, 1 + 2 * i);
-#pragma unroll
-                for (int k = 0; k < 14; k++) dst[k] = src[k];
-                fill_new_card(st, i >> 2, i & 3, seed, rng);
+                copy_src = 1 + 2 * i; copy_dst = res + 2 * slot;
+                fill_tier = i >> 2;
+                fill_got = draw_card(s, fill_tier, seed, rng, &fill_color, &fill_idx);
+                fill_row = 1 + 2 * i;
             } else {
-                int8_t card[14];
-                if (get_deck_card(st, i - 12, seed, rng, card)) {
-#pragma unroll
-                    for (int k = 0; k < 14; k++) dst[k] = card[k];
-                }
+                fill_tier = i - 12;
+                fill_got = draw_card(s, fill_tier, seed, rng, &fill_color, &fill_idx);
+                if (fill_got) fill_row = res + 2 * slot;                    // an empty deck leaves the slot as it is
             }
-            if (bank[GOLD] > 0 && sum7(gems) <= 9) { gems[GOLD] += 1; bank[GOLD] -= 1; }
+            if (B(bank, GOLD) > 0 && rsum7(gems) <= 9) { SETB(gems, GOLD, B(gems, GOLD) + 1); SETB(bank, GOLD, B(bank, GOLD) - 1); }
         } else if (move < 30) {                                            // _buy_reserve :414-420
-            int i = move - 27;
-            int8_t* res = row(st, R_RES + 6 * player);
-            int8_t c[14];
-#pragma unroll
-            for (int k = 0; k < 14; k++) c[k] = res[2 * i * COLS + k];
-            buy_card(st, c, c + 7, player);
-            for (int k = 2 * i * COLS; k < 4 * COLS; k++) res[k] = res[k + 2 * COLS];   // shift towards slot 0
-            for (int k = 4 * COLS; k < 6 * COLS; k++) res[k] = 0;
-        } else if (move < 60) {                                            // _get_gems :436-444
-            int i = move - 30;
+            const int i = move - 27;
+            buy_card(s, bank, gems, s.row(res + 2 * i), s.row(res + 2 * i + 1), player);
+            shift_i = i;
+        } else if (move < 80) {                                            // _get_gems :436-444 / _give_gems :455-463
+            constexpr uint32_t g3[5] = SPL_GEMS3_COL_INIT, g2[5] = SPL_GEMS2_COL_INIT;
+            const bool take = move < 60;
+            const int i = take ? move - 30 : move - 60, nd = take ? 25 : 15;
 #pragma unroll
             for (int c = 0; c < 5; c++) {
-                int8_t k = i < 25 ? SPL_GEMS3[i < 25 ? i : 0][c] : (int8_t)(c == i - 25 ? 2 : 0);
-                bank[c] -= k; gems[c] += k;
-            }
-        } else if (move < 80) {                                            // _give_gems :455-463
-            int i = move - 60;
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                int8_t k = i < 15 ? SPL_GEMS2[i < 15 ? i : 0][c] : (int8_t)(c == i - 15 ? 2 : 0);
-                bank[c] += k; gems[c] -= k;
+                const int k = i < nd ? (int)(((take ? g3[c] : g2[c]) >> (i & 31)) & 1u) : (c == i - nd ? 2 : 0);
+                SETB(bank, c, take ? B(bank, c) - k : B(bank, c) + k);
+                SETB(gems, c, take ? B(gems, c) + k : B(gems, c) - k);
             }
         }
-        bank[PTS] = (int8_t)(bank[PTS] + 1);                               // move counter, int8 wrap :203
+        SETB(bank, PTS, B(bank, PTS) + 1);                                 // move counter, int8 wrap :203
+        s.set_row(0, bank);
+        s.set_row(R_GEMS + player, gems);
+        s.store(st);
+        wave_sync();
+        // ---- 14-byte card moves, lane-parallel in LDS ----
+        if (copy_src >= 0 && l < 14) st[copy_dst * COLS + l] = st[copy_src * COLS + l];
+        if (fill_row >= 0 && l < 14)
+            st[fill_row * COLS + l] = fill_got ? SPL_CARDS[fill_tier][fill_color][fill_idx][l] : (int8_t)0;
+        if (shift_i >= 0 && l < 6 * COLS) {                                // rows res+2i.. <- rows +2, last slot <- 0
+            const int lo = 2 * shift_i * COLS;
+            const int8_t v = (l >= lo && l < 4 * COLS) ? st[res * COLS + l + 2 * COLS] : (int8_t)0;
+            if (l >= lo) st[res * COLS + l] = v;
+        }
+        wave_sync();
         return (player + 1) % NP;
     }
 
@@ -301,7 +448,7 @@ struct SplendorDev {
 
     // Board.swap_players :244-253 -- wave-cooperative, byte-parallel: dst[r] = src[rolled(r)]
     __device__ static void swap_players(int8_t* st, int8_t* tmp, int k) {
-        for (int i = lane_id(); i < S; i += 64) tmp[i] = st[i];
+        for (int i = lane_id() + R_GEMS * COLS; i < S; i += 64) tmp[i] = st[i];      // only the per-player rows move
         wave_sync();
         for (int i = lane_id() + R_GEMS * COLS; i < S; i += 64) {
             int r = i / COLS, c = i - r * COLS, src;

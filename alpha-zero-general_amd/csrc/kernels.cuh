@@ -30,14 +30,12 @@ __global__ __launch_bounds__(64) void k_env_next_state(const int8_t* states, con
     int t = blockIdx.x;
     if (t >= n) return;
     Forest<G>::load_state_unpadded(st, states + (size_t)t * G::S);
-    int np = 0;
+    Rng rng{rng_seed, stream0 + (uint64_t)t, counters ? counters[t] : 0ull};
+    const int np = G::wave_make_move(st, actions[t], players ? players[t] : 0, seeds ? (long long)seeds[t] : 0ll, rng);
     if (lane_id() == 0) {
-        Rng rng{rng_seed, stream0 + (uint64_t)t, counters ? counters[t] : 0ull};
-        np = G::make_move(st, actions[t], players ? players[t] : 0, seeds ? (long long)seeds[t] : 0ll, rng);
         if (counters) counters[t] = rng.counter;
         out_next[t] = np;
     }
-    wave_sync();
     Forest<G>::store_state_unpadded(out_states + (size_t)t * G::S, st);
 }
 
@@ -275,11 +273,8 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
     long long c0 = clock64();
     FR::load_state(sm.st, FR::nstate(F, t, parent_node));
     long long c1 = clock64(); AZG_SEG(0, c1 - c0);
-    int np = 0;
     Rng no_rng{0, 0, 0};
-    if (lane_id() == 0) np = G::make_move(sm.st, a, 0, seed, no_rng);
-    np = uni_i32(np);
-    wave_sync();
+    const int np = G::wave_make_move(sm.st, a, 0, seed, no_rng);
     c0 = clock64(); AZG_SEG(1, c0 - c1);
     if (np != 0) G::swap_players(sm.st, sm.tmp, np);
     const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);

@@ -263,11 +263,7 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     }
     // ---- play the move for real: random_seed = 0 (Coach.py:71) ----
     FR::load_state(sm.st, F.board + (size_t)t * G::SP);
-    int np = 0;
-    if (l == 0) np = G::make_move(sm.st, action, (int)H.cur_player, 0ll, rng);
-    np = __shfl(np, 0, 64);
-    rng.counter = bcast_u64(rng.counter, 0);
-    wave_sync();
+    const int np = G::wave_make_move(sm.st, action, (int)H.cur_player, 0ll, rng);
     H.c_plies++;
     float es[G::P];
     const bool ended = G::game_ended(sm.st, np, es, sm.mask);                                  // Coach.py:73
