@@ -163,6 +163,11 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
                             : (size_t)D.cap * RecLayout(f->A <= 200 ? (f->A < 64 ? f->A : 64) : 128, D.U).total + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     D.heap_units = (uint32_t)(heap_bytes / 16);
+    auto skew = [](size_t bytes) { size_t r = (bytes + 255) / 256 * 256; return ((r >> 8) & 1) ? r : r + 256; };
+    D.s_heap = skew(heap_bytes);
+    D.s_nstate = skew((size_t)D.cap * f->SP);
+    D.s_nhdr = skew((size_t)D.cap * sizeof(NodeHdr)) / sizeof(NodeHdr);
+    D.s_htab = skew((size_t)D.HT * 4) / 4;
     D.universes = cfg->universes;
     D.numMCTSSims = cfg->numMCTSSims;
     D.ratio_fullMCTS = cfg->ratio_fullMCTS > 0 ? cfg->ratio_fullMCTS : 1;
@@ -178,10 +183,10 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     const size_t T = D.T;
     int rc = 0;
     rc |= dalloc(f, &D.hdr, T);
-    rc |= dalloc(f, &D.node_hdr, T * D.cap);
-    rc |= dalloc(f, &D.node_state, T * D.cap * f->SP);
-    rc |= dalloc(f, &D.heap, T * heap_bytes);
-    rc |= dalloc(f, &D.htab, T * D.HT);
+    rc |= dalloc(f, &D.node_hdr, T * D.s_nhdr);
+    rc |= dalloc(f, &D.node_state, T * D.s_nstate);
+    rc |= dalloc(f, &D.heap, T * D.s_heap);
+    rc |= dalloc(f, &D.htab, T * D.s_htab);
     rc |= dalloc(f, &D.path, T * AZG_MAXD);
     rc |= dalloc(f, &D.root_state, T * f->SP);
     rc |= dalloc(f, &D.board, T * f->SP);
@@ -321,10 +326,10 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
     const size_t heap_bytes = (size_t)D.heap_units * 16;
     std::vector<uint8_t> hp((size_t)H.heap_top * 16);
     if (n) {
-        HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)tree * D.cap, sizeof(NodeHdr) * n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(st.data(), D.node_state + (size_t)tree * D.cap * f->SP, (size_t)n * f->SP, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)tree * D.s_nhdr, sizeof(NodeHdr) * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(st.data(), D.node_state + (size_t)tree * D.s_nstate, (size_t)n * f->SP, hipMemcpyDeviceToHost));
     }
-    if (!hp.empty()) HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)tree * heap_bytes, hp.size(), hipMemcpyDeviceToHost));
+    if (!hp.empty()) HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)tree * D.s_heap, hp.size(), hipMemcpyDeviceToHost));
     const int A = f->A, P = f->P, S = f->S;
     for (int i = 0; i < n; i++) {
         memcpy(states + (size_t)i * S, st.data() + (size_t)i * f->SP, S);
@@ -367,9 +372,9 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
         const uint32_t n = H.n_nodes;
         if (n > (uint32_t)D.cap || H.heap_top > D.heap_units) { VBAD("[validate] t=%d n=%u heap_top=%u\n", t, n, H.heap_top); continue; }
         if (H.root != AZG_NONE && H.root >= n) VBAD("[validate] t=%d root=%u n=%u\n", t, H.root, n);
-        HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)t * D.cap, sizeof(NodeHdr) * n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)t * heap_bytes, (size_t)H.heap_top * 16, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(tab.data(), D.htab + (size_t)t * D.HT, sizeof(uint32_t) * D.HT, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)t * D.s_nhdr, sizeof(NodeHdr) * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)t * D.s_heap, (size_t)H.heap_top * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tab.data(), D.htab + (size_t)t * D.s_htab, sizeof(uint32_t) * D.HT, hipMemcpyDeviceToHost));
         if (H.root != AZG_NONE && H.root < n && nh[H.root].rec_off != H.root_rec)
             VBAD("[validate] t=%d root_rec=%u but node %u has rec_off=%u\n", t, H.root_rec, H.root, nh[H.root].rec_off);
         uint32_t expect_off = 0;
@@ -662,6 +667,14 @@ extern "C" int azg_nn_v80_forward(const int8_t* boards, const uint8_t* valid, co
     if (launch_v80<2, 1, 3>(x_trunk, nullptr, Wv, B, nullptr, Nv, nullptr, nullptr, v, P, s)) return -1;
     return 0;
 }
+
+#ifdef AZG_NN_PHASE_TIMES
+extern "C" int azg_nn_debug_phase_times(long long* out /* [4][16] */) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v80_phase), sizeof(long long) * 64));
+    return 0;
+}
+#endif
 
 extern "C" int azg_nn_board_to_x(const int8_t* boards, float* x, int B, int C, void* stream) {
     if (!boards || !x || B <= 0) return fail("azg_nn_board_to_x: null/empty argument");

@@ -87,6 +87,10 @@ struct PathEnt {
 struct ForestDev {
     int T, cap, HT, U;                 // trees, nodes per tree, hash slots per tree (pow2), child slots per action
     uint32_t heap_units;               // 16-byte units per tree heap
+    // per-tree strides: the sizes rounded up to an ODD multiple of 256 B, so that "the same offset in every tree" (root
+    // record, node 0, ...) walks over all HBM channels instead of hitting one (power-of-two strides were ~8 % slower)
+    size_t s_heap, s_nstate;           // bytes
+    size_t s_nhdr, s_htab;             // elements (NodeHdr, u32)
     int universes, numMCTSSims, ratio_fullMCTS, forced_playouts;
     int level_budget;                  // max descent levels per tree per k_select launch (0 = unlimited)
     double cpuct, fpu, prob_fullMCTS, dirichletAlpha, temp_begin, temp_end, temp_root, tempThreshold;
@@ -235,15 +239,15 @@ struct Forest {
 
     // ---- addressing ----
     __device__ static __forceinline__ NodeHdr* nhdr(const ForestDev& F, int t, uint32_t id) {
-        return F.node_hdr + (size_t)t * F.cap + id;
+        return F.node_hdr + (size_t)t * F.s_nhdr + id;
     }
     __device__ static __forceinline__ int8_t* nstate(const ForestDev& F, int t, uint32_t id) {
-        return F.node_state + ((size_t)t * F.cap + id) * SP;
+        return F.node_state + (size_t)t * F.s_nstate + (size_t)id * SP;
     }
     __device__ static __forceinline__ uint8_t* heap(const ForestDev& F, int t) {
-        return F.heap + (size_t)t * F.heap_units * 16u;
+        return F.heap + (size_t)t * F.s_heap;
     }
-    __device__ static __forceinline__ uint32_t* htab(const ForestDev& F, int t) { return F.htab + (size_t)t * F.HT; }
+    __device__ static __forceinline__ uint32_t* htab(const ForestDev& F, int t) { return F.htab + (size_t)t * F.s_htab; }
     __device__ static __forceinline__ uint8_t* rec_ptr(const ForestDev& F, int t, uint32_t rec_off) {
         return heap(F, t) + (size_t)rec_off * 16u;
     }

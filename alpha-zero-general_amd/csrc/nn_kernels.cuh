@@ -16,6 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The net has a tolerance contract (|pi|,|v| within 1e-5 of the reference's fp32 outputs), not a bit-exact one: FMA
+// contraction is allowed in this header (the MCTS / env code keeps -ffp-contract=off).
+#pragma clang fp contract(fast)
+
 namespace azg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -24,11 +28,11 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_HSIGMOID = 3 };
 
 __device__ __forceinline__ float act_apply(float x, int act) {
     if (act == ACT_RELU) return x > 0.f ? x : 0.f;
-    if (act == ACT_HSWISH) { float t = fminf(fmaxf(x + 3.f, 0.f), 6.f); return x * t / 6.f; }
-    if (act == ACT_HSIGMOID) return fminf(fmaxf(x + 3.f, 0.f), 6.f) / 6.f;
+    if (act == ACT_HSWISH) { float t = fminf(fmaxf(x + 3.f, 0.f), 6.f); return x * t * (1.f / 6.f); }
+    if (act == ACT_HSIGMOID) return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
     return x;
 }
-__device__ __forceinline__ float hardsigmoid(float x) { return fminf(fmaxf(x + 3.f, 0.f), 6.f) / 6.f; }
+__device__ __forceinline__ float hardsigmoid(float x) { return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
 
 // out[M][N] = act(A'[M][K] @ W + bias[N]) (+ R[M][N]);  A'[r][k] = A[r][k] * rowscale[r / rpg][k] if rowscale.
 //
@@ -272,7 +276,8 @@ __global__ __launch_bounds__(256) void k_dw_pool(float* __restrict__ H, int ldh,
 //   SE fc1   3 column tiles x 1 row tile         waves 0..2
 //   SE fc2   11 column tiles x 1 row tile        waves 0..10
 //   project  4 column tiles x 7 row tiles        wave w owns column tile w&3 and row tiles {w>>2, (w>>2)+3, (w>>2)+6}
-// Hard-wired to the V80 geometry C = 56, E = 168, Q = 40 (padded weights: We[64][176], W1[176][48], W2[48][176], Wp[176][64]).
+// Hard-wired to the V80 geometry C = 56, E = 168, Q = 40; the zero-padded weights We[64][176], W1[176][48], W2[48][176],
+// Wp[176][64] are passed in MFMA fragment order (FRAG above).
 struct V80BlockW {
     const float *We, *be, *Wd, *sd, *bd, *W1, *b1, *W2, *b2, *Wp, *bp;     // be/b1/b2/bp zero-padded to the padded widths
 };
@@ -286,7 +291,19 @@ struct V80BlockW {
 struct V80NetW {
     const float *W0, *b0;                  // first layer [64][64], [64]
     const float *Wh1, *bh1, *Wh2, *bh2;    // policy: [432][96], [96], [96][96], [96];  value: [432][16], [16], [P][P], [P]
+                                           // (W0, Wh1 and the policy Wh2 in fragment order; the value Wh2 is plain)
 };
+
+// weight operands are stored in MFMA fragment order: frag[tile nt][K chunk c][lane][j] = W[16c + 4*(lane>>4) + j][16nt + (lane&15)],
+// so a wave fetches one chunk of one column tile as a single 1 KiB global_load_dwordx4
+#define FRAG(ptr, NCH, nt, c) (*(const float4*)((ptr) + ((((size_t)(nt) * (NCH) + (c)) * 64 + lane) << 2)))
+
+#ifdef AZG_NN_PHASE_TIMES
+__device__ long long g_v80_phase[4][16];
+#define AZG_PH(k) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_v80_phase[MODE][k] = clock64(); } while (0)
+#else
+#define AZG_PH(k)
+#endif
 
 template <int ACT, int POOLMAX, int MODE>
 __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin, float* __restrict__ xout, V80BlockW W,
@@ -306,25 +323,44 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
     const int b0 = blockIdx.x * NS;
     const int nrows = min(ROWS, (B - b0) * 7);
     const int nt_p = wave & 3;
+    AZG_PH(0);
 
+    float4 we[4], w2r[3], w1r[11], wpr[11];
+    const int nt_e = wave < 11 ? wave : 0, nt_1 = wave < 3 ? wave : 0;
+    auto load_we = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; c++) we[c] = FRAG(W.We, 4, nt_e, c);
+    };
+    auto load_w2_wp = [&]() {
+#pragma unroll
+        for (int c = 0; c < 3; c++) w2r[c] = FRAG(W.W2, 3, nt_e, c);
+#pragma unroll
+        for (int c = 0; c < 11; c++) wpr[c] = FRAG(W.Wp, 11, nt_p, c);
+    };
     if (MODE == 1) {
         // ---- P0': board tile (int8, [s][c][l]) -> X0[s*7+l][c] f32 (aliases H), then first layer -> X ----
-        float w0r[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) w0r[c][j] = N.W0[(16 * c + 4 * g + j) * 64 + nt_p * 16 + r16];
-        const float4 b04 = *(const float4*)(N.b0 + nt_p * 16 + 4 * g);
         float* X0 = H;
         const int nb = min(NS, B - b0);
         const uint32_t* bsrc = (const uint32_t*)(boards + (size_t)b0 * (7 * C));
-        for (int i = tid; i < NS * (7 * C / 4); i += 768) {
-            const int s = i / (7 * C / 4), d = i - s * (7 * C / 4);
-            const uint32_t v = s < nb ? bsrc[i] : 0u;
+        uint32_t bv[3];                                   // the board tile is requested before any weight
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int idx = 4 * d + q, c = idx / 7, l = idx - c * 7;
-                X0[(s * 7 + l) * XS + c] = (float)(int8_t)(v >> (8 * q));
+        for (int k = 0; k < 3; k++) { const int i = tid + 768 * k; bv[k] = (i < NS * (7 * C / 4) && i / (7 * C / 4) < nb) ? bsrc[i] : 0u; }
+        float4 w0r[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) w0r[c] = FRAG(N.W0, 4, nt_p, c);
+        const float4 b04 = *(const float4*)(N.b0 + nt_p * 16 + 4 * g);
+        load_we();                                        // block weights stream in behind the first layer
+        load_w2_wp();
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = tid + 768 * k;
+            if (i < NS * (7 * C / 4)) {
+                const int s = i / (7 * C / 4), d = i - s * (7 * C / 4);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int idx = 4 * d + q, c = idx / 7, l = idx - c * 7;
+                    X0[(s * 7 + l) * XS + c] = (float)(int8_t)(bv[k] >> (8 * q));
+                }
             }
         }
         __syncthreads();
@@ -336,10 +372,10 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
             for (int c = 0; c < 4; c++) {
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (16 * c + 4 * g < C) a = *(const float4*)(xr + 16 * c);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c][0], a.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c][1], a.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c][2], a.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c][3], a.w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c].x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c].y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c].z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c].w, a.w, acc, 0, 0, 0);
             }
             const int col0 = nt_p * 16 + 4 * g;
             if (col0 < XS)            // columns 56..59 get 0 (zero-padded W0 / b0)
@@ -349,42 +385,35 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
         __syncthreads();
     }
 
-    // ---- weight fragments -> registers (L2 hits; issued before the x tile arrives) ----
-    float we[4][4], w2r[3][4], w1r[11][4], wpr[11][4];
-    const int nt_e = wave < 11 ? wave : 0;
+    AZG_PH(1);
+    // ---- x tile requested first (HBM), then the weight fragments (L2) in the order the phases need them: the vmcnt
+    //      counter retires in order, so P0 / P1 only wait for what they use while the rest keeps streaming in ----
+    float4 xv[3];
+    if (MODE != 1) {
 #pragma unroll
-    for (int c = 0; c < 4; c++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) we[c][j] = W.We[(16 * c + 4 * g + j) * 176 + nt_e * 16 + r16];
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) w2r[c][j] = W.W2[(16 * c + 4 * g + j) * 176 + nt_e * 16 + r16];
-    const int nt_1 = wave < 3 ? wave : 0;
-#pragma unroll
-    for (int c = 0; c < 11; c++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) w1r[c][j] = W.W1[(16 * c + 4 * g + j) * 48 + nt_1 * 16 + r16];
-#pragma unroll
-    for (int c = 0; c < 11; c++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) wpr[c][j] = W.Wp[(16 * c + 4 * g + j) * 64 + nt_p * 16 + r16];
+        for (int k = 0; k < 3; k++) {
+            const int i = tid + 768 * k, row = i / (XS / 4), c4 = i - row * (XS / 4);
+            xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < ROWS * (XS / 4) && row < nrows && c4 < C / 4) xv[k] = *(const float4*)(xin + ((size_t)b0 * 7 + row) * C + 4 * c4);
+        }
+    }
+    if (MODE != 1) load_we();
     const float4 be4 = *(const float4*)(W.be + nt_e * 16 + 4 * g);
+    if (tid < 49) WD[tid] = W.Wd[tid];
+    if (MODE != 1) {
+        // ---- P0: x tile -> LDS (contiguous rows, float4); pad columns 56..59 zeroed ----
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = tid + 768 * k, row = i / (XS / 4), c4 = i - row * (XS / 4);
+            if (i < ROWS * (XS / 4)) *(float4*)(X + row * XS + 4 * c4) = xv[k];
+        }
+    }
+    if (MODE != 1) load_w2_wp();
     const float4 b14 = *(const float4*)(W.b1 + nt_1 * 16 + 4 * g);
     const float4 b24 = *(const float4*)(W.b2 + nt_e * 16 + 4 * g);
     const float4 bp4 = *(const float4*)(W.bp + nt_p * 16 + 4 * g);
-    if (tid < 49) WD[tid] = W.Wd[tid];
-
-    if (MODE != 1) {
-        // ---- P0: x tile -> LDS (contiguous rows, float4); pad columns 56..59 zeroed ----
-        for (int i = tid; i < ROWS * (XS / 4); i += 768) {
-            const int row = i / (XS / 4), c4 = i - row * (XS / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nrows && c4 < C / 4) v = *(const float4*)(xin + ((size_t)b0 * 7 + row) * C + 4 * c4);
-            *(float4*)(X + row * XS + 4 * c4) = v;
-        }
-    }
     __syncthreads();
+    AZG_PH(2);
 
     // ---- P1: expand + BN + act -> H ----
     if (wave < 11) {
@@ -396,10 +425,10 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
             for (int c = 0; c < 4; c++) {
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (16 * c + 4 * g < C) a = *(const float4*)(xr + 16 * c);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c][0], a.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c][1], a.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c][2], a.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c][3], a.w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c].x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c].y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c].z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c].w, a.w, acc, 0, 0, 0);
             }
             const int col0 = nt_e * 16 + 4 * g;
             if (col0 < E) {
@@ -411,8 +440,16 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
         }
     }
     __syncthreads();
+    AZG_PH(3);
+    if (wave < 3) {                    // SE fc1 weights: requested now (the expand fragments are dead), they land during P2
+#pragma unroll
+        for (int c = 0; c < 11; c++) w1r[c] = FRAG(W.W1, 11, nt_1, c);
+    }
 
     // ---- P2: depthwise Linear(7->7) over the token axis + BN + act (in place) + SE squeeze ----
+    float wd[49];                      // wave-uniform 7x7 weights -> SGPRs (one LDS broadcast read each, once per wave)
+#pragma unroll
+    for (int k = 0; k < 49; k++) wd[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, WD[k])));
     for (int i = tid; i < NS * E; i += 768) {
         const int s = i / E, c = i - s * E;
         float* base = H + (s * 7) * HS + c;
@@ -425,7 +462,7 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
         for (int m = 0; m < 7; m++) {
             float a = 0.f;
 #pragma unroll
-            for (int l = 0; l < 7; l++) a += WD[m * 7 + l] * in[l];
+            for (int l = 0; l < 7; l++) a += wd[m * 7 + l] * in[l];
             a = act_apply(a * scl + bb, ACT);
             base[m * HS] = a;
             pool = POOLMAX ? fmaxf(pool, a) : pool + a;
@@ -433,6 +470,7 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
         PL[s * HS + c] = POOLMAX ? pool : pool / 7.f;
     }
     __syncthreads();
+    AZG_PH(4);
 
     // ---- P3: SE fc1 + ReLU : SH[16][48] = relu(PL[16][168] @ W1 + b1) ----
     if (wave < 3) {
@@ -442,10 +480,10 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
         for (int c = 0; c < 11; c++) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
             if (16 * c + 4 * g < E) a = *(const float4*)(pr + 16 * c);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c][0], a.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c][1], a.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c][2], a.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c][3], a.w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c].x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c].y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c].z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c].w, a.w, acc, 0, 0, 0);
         }
         float4 v;
         v.x = fmaxf(acc[0] + b14.x, 0.f); v.y = fmaxf(acc[1] + b14.y, 0.f);
@@ -453,6 +491,7 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
         *(float4*)(SH + r16 * QS + nt_1 * 16 + 4 * g) = v;
     }
     __syncthreads();
+    AZG_PH(5);
 
     // ---- P4: SE fc2 + Hardsigmoid : SC[16][168] ----
     if (wave < 11) {
@@ -461,10 +500,10 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float4 a = *(const float4*)(hr + 16 * c);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[c][0], a.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[c][1], a.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[c][2], a.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[c][3], a.w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[c].x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[c].y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[c].z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2r[c].w, a.w, acc, 0, 0, 0);
         }
         const int col0 = nt_e * 16 + 4 * g;
         if (col0 < E) {
@@ -475,6 +514,20 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
         }
     }
     __syncthreads();
+    AZG_PH(6);
+
+    // policy head: the first Linear's weight fragments stream in from L2 while P5 runs (we / w1r / w2r are dead by now)
+    float4 wr[14], w2h[6];
+    const int ht_nt = wave % 6, ht_half = wave / 6;
+    const int ht_beg = ht_half * 14, ht_n = ht_half ? 13 : 14;          // 27 K chunks of 16 (432 >= 420)
+    if (MODE == 2) {
+#pragma unroll
+        for (int cc = 0; cc < 14; cc++) wr[cc] = cc < ht_n ? FRAG(N.Wh1, 27, ht_nt, ht_beg + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave < 6) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) w2h[c] = FRAG(N.Wh2, 6, wave, c);
+        }
+    }
 
     // ---- P5: project (SE-scaled operand) + BN + residual -> HBM (MODE 0/1) or in place of x in LDS (MODE 2/3) ----
 #pragma unroll 1
@@ -491,10 +544,10 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
                 const float4 s4 = *(const float4*)(sr + 16 * c);
                 a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
             }
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c][0], a.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c][1], a.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c][2], a.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c][3], a.w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c].x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c].y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c].z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c].w, a.w, acc, 0, 0, 0);
         }
         const int col0 = nt_p * 16 + 4 * g;
         if (MODE >= 2) {
@@ -513,21 +566,16 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
         }
     }
 
+    AZG_PH(7);
     if (MODE == 2) {
         // ---- policy head tail on the block output O = X viewed as [16][420] ----
         constexpr int LS = 100;
         float* RED = H;                      // [2][16][LS]   K-halves of the first Linear
         float* HID = RED + 2 * 16 * LS;      // [16][LS]
         float* LG = HID + 16 * LS;           // [16][LS]
-        const int nt = wave % 6, half = wave / 6;
-        const int c_beg = half * 14, n_c = half ? 13 : 14;          // 27 K chunks of 16 (432 >= 420)
-        float wr[14][4];
-#pragma unroll
-        for (int cc = 0; cc < 14; cc++)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                wr[cc][j] = cc < n_c ? N.Wh1[(size_t)(16 * (c_beg + cc) + 4 * g + j) * 96 + nt * 16 + r16] : 0.f;
+        const int nt = ht_nt, half = ht_half, c_beg = ht_beg, n_c = ht_n;
         __syncthreads();                     // O complete, H free
+        AZG_PH(8);
         {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -535,19 +583,12 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
                 const int k0 = 16 * (c_beg + cc) + 4 * g;
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (cc < n_c && k0 < FK) a = *(const float4*)(X + r16 * FK + k0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc][0], a.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc][1], a.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc][2], a.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc][3], a.w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc].x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc].y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc].z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc].w, a.w, acc, 0, 0, 0);
             }
             *(float4*)(RED + (half * 16 + r16) * LS + nt * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        }
-        float w2h[6][4];
-        if (wave < 6) {
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) w2h[c][j] = N.Wh2[(16 * c + 4 * g + j) * 96 + wave * 16 + r16];
         }
         __syncthreads();
         if (tid < 16 * 24) {
@@ -563,16 +604,17 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 const float4 a = *(const float4*)(HID + r16 * LS + 16 * c + 4 * g);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c][0], a.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c][1], a.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c][2], a.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c][3], a.w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c].x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c].y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c].z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2h[c].w, a.w, acc, 0, 0, 0);
             }
             const float4 bb = *(const float4*)(N.bh2 + wave * 16 + 4 * g);
             *(float4*)(LG + r16 * LS + wave * 16 + 4 * g) =
                 make_float4(acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
         }
         __syncthreads();
+        AZG_PH(9);
         // masked softmax == exp(log_softmax(where(valid, logits, -1e8))) (GenericNNetWrapper.py:105-107), one wave per sample
         for (int s = wave; s < NS; s += 12) {
             const int b = b0 + s;
@@ -591,6 +633,7 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
             pi_out[(size_t)b * A + lane] = x0 / sum;
             if (a1 < A) pi_out[(size_t)b * A + a1] = x1 / sum;
         }
+        AZG_PH(10);
     }
 
     if (MODE == 3) {
@@ -604,16 +647,15 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
                 const int c = wave + 12 * cc;
                 const int k0 = 16 * c + 4 * g;
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                float w4[4] = {0.f, 0.f, 0.f, 0.f};
+                float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (c < 27) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) w4[j] = N.Wh1[(size_t)(k0 + j) * 16 + r16];
+                    w4 = FRAG(N.Wh1, 27, 0, c);
                     if (k0 < FK) a = *(const float4*)(X + r16 * FK + k0);
                 }
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[0], a.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[1], a.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[2], a.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[3], a.w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, a.w, acc, 0, 0, 0);
             }
             *(float4*)(RED + (wave * 16 + r16) * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
@@ -674,3 +716,5 @@ __global__ __launch_bounds__(64) void k_heads_out(const float* __restrict__ logi
 }
 
 }  // namespace azg
+
+#pragma clang fp contract(off)

@@ -238,9 +238,10 @@ class SplendorV80Hip(SplendorV80):
             out = torch.zeros((432, ncols), dtype=f, device=d)
             out[:420].view(7, 60, ncols)[:, :56, :N] = Wf.view(7, 56, N)
             return out.contiguous()
-        head = [flat60(self.Wpi1, 96), pad(self.bpi1, (96,)), pad(self.Wpi2, (96, 96)), pad(self.bpi2, (96,)),
-                flat60(self.Wv1, 16), pad(self.bv1, (16,)), self.Wv2.contiguous(), self.bv2.contiguous()]
-        first = [pad(self.W0, (64, 64)), pad(self.b0, (64,))]
+        head = [self._frag(flat60(self.Wpi1, 96)), pad(self.bpi1, (96,)), self._frag(pad(self.Wpi2, (96, 96))),
+                pad(self.bpi2, (96,)), self._frag(flat60(self.Wv1, 16)), pad(self.bv1, (16,)), self.Wv2.contiguous(),
+                self.bv2.contiguous()]
+        first = [self._frag(pad(self.W0, (64, 64))), pad(self.b0, (64,))]
         self._net_keep = first + self.trunk._keep + self.head_pi._keep + self.head_v._keep + head
         assert len(self._net_keep) == 43
         self.net_ptrs = (C.c_void_p * 43)(*[t.data_ptr() for t in self._net_keep])
@@ -264,6 +265,14 @@ class SplendorV80Hip(SplendorV80):
                                                       p(rowscale), rpg, p(out), ldc, M, K, N, act, ksplit,
                                                       self._stream()))
 
+    @staticmethod
+    def _frag(Wp):
+        """zero-padded [Kp][NP] -> MFMA fragment order [NP/16][Kp/16][64 lanes][4]:
+        frag[nt][c][lane][j] = Wp[16c + 4*(lane>>4) + j][16nt + (lane&15)]  (FRAG in csrc/nn_kernels.cuh)"""
+        Kp, NP = Wp.shape
+        assert Kp % 16 == 0 and NP % 16 == 0
+        return Wp.view(Kp // 16, 4, 4, NP // 16, 16).permute(3, 0, 1, 4, 2).contiguous().view(-1)
+
     def _block_ptrs(self, blk):
         import ctypes as C
 
@@ -271,8 +280,9 @@ class SplendorV80Hip(SplendorV80):
             out = torch.zeros(n, dtype=torch.float32, device=v.device)
             out[:v.numel()] = v
             return out
-        blk._keep = [blk.pWe, pad1(blk.be, 176), blk.Wd.contiguous(), blk.sd.contiguous(), blk.bd.contiguous(), blk.pW1,
-                     pad1(blk.b1, 48), blk.pW2, pad1(blk.b2, 176), blk.pWp, pad1(blk.bp, 64)]
+        blk._keep = [self._frag(blk.pWe), pad1(blk.be, 176), blk.Wd.contiguous(), blk.sd.contiguous(), blk.bd.contiguous(),
+                     self._frag(blk.pW1), pad1(blk.b1, 48), self._frag(blk.pW2), pad1(blk.b2, 176), self._frag(blk.pWp),
+                     pad1(blk.bp, 64)]
         assert tuple(blk.pWe.shape) == (64, 176) and tuple(blk.pW1.shape) == (176, 48)
         assert tuple(blk.pW2.shape) == (48, 176) and tuple(blk.pWp.shape) == (176, 64)
         blk.ptrs = (C.c_void_p * 11)(*[t.data_ptr() for t in blk._keep])

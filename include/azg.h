@@ -185,7 +185,9 @@ int azg_nn_dw_pool(float* H_dev, int ldh, const float* Wd_dev /*[7][7] out,in*/,
 /* One fused InvertedResidual1d block of the V80 net (SplendorNNet.py:189-202: expand + depthwise + SE + project +
    residual) for x[B*7][56] -> out[B*7][56]; the 168-wide expanded activations stay in LDS.  w = 11 HOST-array device
    pointers {We[64][176], be[176], Wd[7][7], bn_scale[168], bn_bias[168], W1[176][48], b1[48], W2[48][176], b2[176],
-   Wp[176][64], bp[64]} (zero padded, BatchNorm folded).  act 1 ReLU / 2 Hardswish; pool_max 0 mean / 1 max. */
+   Wp[176][64], bp[64]} (zero padded, BatchNorm folded).  The four matrices are stored in MFMA fragment order:
+   frag[n/16][k/16][lane 0..63][j 0..3] = W[16*(k/16) + 4*(lane>>4) + j][16*(n/16) + (lane&15)] (one 1 KiB load per wave and
+   K chunk).  act 1 ReLU / 2 Hardswish; pool_max 0 mean / 1 max. */
 int azg_nn_v80_block(const float* xin_dev, float* xout_dev, const float* const* w, int B, int act, int pool_max,
                      void* stream);
 /* The whole V80 forward (NeuralNet.predict for a leaf batch, SplendorNNet.py:397-440 / GenericNNetWrapper.py:94-110) in
@@ -194,7 +196,7 @@ int azg_nn_v80_block(const float* xin_dev, float* xout_dev, const float* const* 
    ReLU + Linear + tanh -> v f32[B][P].  w = 43 device pointers: {W0[64][64], b0[64]}, 3 x the 11 block tensors of
    azg_nn_v80_block (trunk, policy head, value head), {Wpi1[432][96], bpi1[96], Wpi2[96][96], bpi2[96]},
    {Wv1[432][16], bv1[16], Wv2[P][P], bv2[P]}; the flatten index of Wpi1 / Wv1 rows is k = l*60 + c (c < 56), zero
-   padded.  Fixed to the V80 activations (trunk ReLU + mean squeeze, heads Hardswish + max squeeze). */
+   padded; every matrix except Wv2 is in the fragment order described at azg_nn_v80_block.  Fixed to the V80 activations (trunk ReLU + mean squeeze, heads Hardswish + max squeeze). */
 int azg_nn_v80_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int B, int P,
                        float* x_trunk_dev, float* pi_dev, float* v_dev, void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
