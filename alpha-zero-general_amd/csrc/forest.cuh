@@ -37,6 +37,14 @@ enum : uint32_t {
     ERR_REC_OVERFLOW = 32
 };
 
+// phase cycle counters of k_select (azg_selfplay_stats.cyc_*): compiled in only with -DAZG_CYC_COUNTERS (tools/dbg_cycles.py),
+// each s_memtime read costs the wave an lgkmcnt(0) wait
+#ifdef AZG_CYC_COUNTERS
+#define AZG_CLK() clock64()
+#else
+#define AZG_CLK() 0ll
+#endif
+
 #define AZG_MAXD 256
 #define AZG_IDX_BITS 22
 #define AZG_IDX_MASK ((1u << AZG_IDX_BITS) - 1u)

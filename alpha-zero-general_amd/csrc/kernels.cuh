@@ -125,17 +125,6 @@ __device__ void begin_search_from_lds(const ForestDev& F, int t, TreeHdr& H, typ
     H.noise_pending = (full && F.dirichletAlpha != 0.0 && H.root_rec != AZG_NONE) ? 1u : 0u;
 }
 
-template <class G>
-__global__ __launch_bounds__(64) void k_begin_search(ForestDev F, const int8_t* roots, const uint8_t* full) {
-    using FR = Forest<G>;
-    __shared__ typename FR::Smem sm;
-    int t = blockIdx.x;
-    TreeHdr H = load_uniform(&F.hdr[t]);
-    FR::load_state_unpadded(sm.st, roots + (size_t)t * G::S);
-    begin_search_from_lds<G>(F, t, H, sm, full ? full[t] != 0 : true);
-    if (lane_id() == 0) F.hdr[t] = H;
-}
-
 // Root Dirichlet noise (MCTS.py:64,147-149,156-160,187-197) as its own small kernel so that the f64 pow/log/cos of the
 // Gamma sampler never weigh on the registers of the descent kernel.  It runs right before k_select and touches only trees
 // with noise_pending != 0: an existing root at the start of a full search (entries hold the normalised prior), or a root
@@ -199,16 +188,16 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
     using FR = Forest<G>;
     const int l = lane_id();
 #ifdef AZG_LEAF_SPLIT
-    long long q0 = clock64();
+    long long q0 = AZG_CLK();
 #endif
     const uint32_t id = FR::create_node(F, t, H, sm.st, h, free_slot);
     if (id == AZG_NONE) return AZG_NONE;
 #ifdef AZG_LEAF_SPLIT
-    long long q1 = clock64(); H.cyc_seg[0] += (uint32_t)(q1 - q0);
+    long long q1 = AZG_CLK(); H.cyc_seg[0] += (uint32_t)(q1 - q0);
 #endif
     const bool ended = G::game_ended(sm.st, 0, es, sm.mask);                                     // MCTS.py:131
 #ifdef AZG_LEAF_SPLIT
-    q0 = clock64(); H.cyc_seg[1] += (uint32_t)(q0 - q1);
+    q0 = AZG_CLK(); H.cyc_seg[1] += (uint32_t)(q0 - q1);
 #endif
     int nv = 0;
     if (!ended) {
@@ -218,7 +207,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
         for (int k = 0; k < G::AW; k++) nv += __popcll(sm.mask[k]);
     }
 #ifdef AZG_LEAF_SPLIT
-    q1 = clock64(); H.cyc_seg[2] += (uint32_t)(q1 - q0);
+    q1 = AZG_CLK(); H.cyc_seg[2] += (uint32_t)(q1 - q0);
 #endif
     const RecLayout L(nv, F.U);
     // 256 units (4 KB) of slack: a level's speculative entry loads may reach 64 entries past a short record
@@ -252,7 +241,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
         FR::store_state_unpadded(leaf_states + (size_t)t * G::S, sm.st);
     }
 #ifdef AZG_LEAF_SPLIT
-    q0 = clock64(); H.cyc_seg[3] += (uint32_t)(q0 - q1);
+    q0 = AZG_CLK(); H.cyc_seg[3] += (uint32_t)(q0 - q1);
 #endif
     return rec_off;
 }
@@ -270,26 +259,26 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
 #else
 #define AZG_SEG(k, d) H.cyc_seg[k] += (uint32_t)(d)
 #endif
-    long long c0 = clock64();
+    long long c0 = AZG_CLK();
     FR::load_state(sm.st, FR::nstate(F, t, parent_node));
-    long long c1 = clock64(); AZG_SEG(0, c1 - c0);
+    long long c1 = AZG_CLK(); AZG_SEG(0, c1 - c0);
     Rng no_rng{0, 0, 0};
     const int np = G::wave_make_move(sm.st, a, 0, seed, no_rng);
-    c0 = clock64(); AZG_SEG(1, c0 - c1);
+    c0 = AZG_CLK(); AZG_SEG(1, c0 - c1);
     if (np != 0) G::swap_players(sm.st, sm.tmp, np);
     const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
-    c1 = clock64(); AZG_SEG(2, c1 - c0);
+    c1 = AZG_CLK(); AZG_SEG(2, c1 - c0);
     uint32_t free_slot;
     uint32_t found_rec = AZG_NONE;
     const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
-    c0 = clock64(); AZG_SEG(3, c0 - c1);
+    c0 = AZG_CLK(); AZG_SEG(3, c0 - c1);
     uint32_t crec;
     *is_new = false;
     if (found != AZG_NONE) crec = found_rec;
     else {
-        const long long t_l = clock64();
+        const long long t_l = AZG_CLK();
         crec = create_leaf<G, HS>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, terminal, es);
-        H.cyc_leaf += (uint32_t)(clock64() - t_l);
+        H.cyc_leaf += (uint32_t)(AZG_CLK() - t_l);
         if (crec == AZG_NONE) return AZG_NONE;
         *is_new = true;
     }
@@ -316,24 +305,29 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
     const int t = blockIdx.x;
     const int l = lane_id();
     TreeHdr* Hp = &F.hdr[t];
+    // every hot header field is requested in one go (status included): one memory round trip before the first level
+    SelState H;
+    const uint32_t status0 = Hp->status, pending0 = Hp->noise_pending;
+    H.n_nodes = Hp->n_nodes; H.heap_top = Hp->heap_top; H.root = Hp->root; H.root_rec = Hp->root_rec; H.sim_idx = Hp->sim_idx;
+    H.n_sims = Hp->n_sims; H.is_full = Hp->is_full; H.forced = Hp->forced; H.err = Hp->err; H.leaf_is_root = Hp->leaf_is_root;
+    H.mid_sim = Hp->mid_sim; H.cur_rec = Hp->cur_rec; H.cur_depth = Hp->cur_depth; H.cur_pre = Hp->cur_pre;
     // wait_noise: the root noise is applied by the periodic k_selfplay_advance launch; until then the tree sits out
-    if (uni_u32(Hp->status) != ST_SEARCHING || (wait_noise && uni_u32(Hp->noise_pending))) {
+    if (uni_u32(status0) != ST_SEARCHING || (wait_noise && uni_u32(pending0))) {
         if (l == 0) needs_eval[t] = 0;
         return;
     }
-    SelState H;
-    H.n_nodes = uni_u32(Hp->n_nodes); H.heap_top = uni_u32(Hp->heap_top); H.root = uni_u32(Hp->root);
-    H.root_rec = uni_u32(Hp->root_rec); H.sim_idx = uni_u32(Hp->sim_idx); H.n_sims = uni_u32(Hp->n_sims);
-    H.is_full = uni_u32(Hp->is_full); H.forced = uni_u32(Hp->forced); H.err = uni_u32(Hp->err);
-    H.leaf_is_root = uni_u32(Hp->leaf_is_root); H.mid_sim = uni_u32(Hp->mid_sim); H.cur_rec = uni_u32(Hp->cur_rec);
-    H.cur_depth = uni_u32(Hp->cur_depth); H.cur_pre = uni_u32(Hp->cur_pre);
+    H.n_nodes = uni_u32(H.n_nodes); H.heap_top = uni_u32(H.heap_top); H.root = uni_u32(H.root);
+    H.root_rec = uni_u32(H.root_rec); H.sim_idx = uni_u32(H.sim_idx); H.n_sims = uni_u32(H.n_sims);
+    H.is_full = uni_u32(H.is_full); H.forced = uni_u32(H.forced); H.err = uni_u32(H.err);
+    H.leaf_is_root = uni_u32(H.leaf_is_root); H.mid_sim = uni_u32(H.mid_sim); H.cur_rec = uni_u32(H.cur_rec);
+    H.cur_depth = uni_u32(H.cur_depth); H.cur_pre = uni_u32(H.cur_pre);
     H.status = ST_SEARCHING; H.pending_leaf = AZG_NONE; H.path_len = 0; H.cyc_leaf = 0;
     H.cyc_seg[0] = H.cyc_seg[1] = H.cyc_seg[2] = H.cyc_seg[3] = 0;
     uint8_t* hp = FR::heap(F, t);
     const uint32_t ES = entry_stride(F.U);
     bool need_nn = false;
     uint32_t c_sims = 0, c_levels = 0, c_sumvalid = 0, c_term = 0, levels_this_launch = 0;
-    const long long t_start = clock64();
+    const long long t_start = AZG_CLK();
     long long cyc_levels = 0, cyc_edge = 0;
     while (true) {
         if (H.sim_idx >= H.n_sims || H.err) { H.status = ST_DONE; break; }
@@ -385,7 +379,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                 break;
             }
             levels_this_launch++;
-            const long long t_lvl = clock64();
+            const long long t_lvl = AZG_CLK();
             // ---- one level: header + this lane's entry requested together (entry position is independent of nv) ----
             const uint8_t* rp = hp + (size_t)rec * 16u;
             const uint8_t* ent = rp + AZG_REC_HDR + (size_t)l * ES;
@@ -472,14 +466,14 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
             }
             c_levels++;
             c_sumvalid += (uint32_t)nv;
-            cyc_levels += clock64() - t_lvl;
+            cyc_levels += AZG_CLK() - t_lvl;
             if (depth >= AZG_MAXD - 1) { H.err |= ERR_DEPTH_OVERFLOW; H.sim_idx = H.n_sims; break; }
             if (child == AZG_NONE) {
                 const int a = a_sel;
                 bool is_new = false;
-                const long long t_e = clock64();
+                const long long t_e = AZG_CLK();
                 child = resolve_edge<G, SelState>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es);
-                cyc_edge += clock64() - t_e;
+                cyc_edge += AZG_CLK() - t_e;
                 if (child == AZG_NONE) { H.sim_idx = H.n_sims; break; }
                 if (l == 0) *(uint32_t*)((uint8_t*)rp + AZG_REC_HDR + (size_t)j * ES + AZG_E_C + 4u * (uint32_t)uidx) = child;
                 have_leaf = is_new;
@@ -519,9 +513,13 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
         atomicMax(&Hp->max_nodes_seen, H.n_nodes);
         stat_add(&Hp->c_sims, c_sims); stat_add(&Hp->c_levels, c_levels); stat_add(&Hp->c_sumvalid, c_sumvalid);
         stat_add(&Hp->c_term, c_term);
-        stat_add(&Hp->cyc_select, (uint64_t)(clock64() - t_start)); stat_add(&Hp->cyc_levels, (uint64_t)cyc_levels);
+#ifdef AZG_CYC_COUNTERS
+        stat_add(&Hp->cyc_select, (uint64_t)(AZG_CLK() - t_start)); stat_add(&Hp->cyc_levels, (uint64_t)cyc_levels);
         stat_add(&Hp->cyc_edge, (uint64_t)cyc_edge); stat_add(&Hp->cyc_leaf, (uint64_t)H.cyc_leaf);
         for (int k = 0; k < 4; k++) stat_add(&Hp->cyc_seg[k], (uint64_t)H.cyc_seg[k]);
+#else
+        (void)t_start; (void)cyc_levels; (void)cyc_edge;
+#endif
         needs_eval[t] = need_nn ? 1 : 0;
     }
 }

@@ -175,6 +175,38 @@ __global__ __launch_bounds__(64) void k_selfplay_start(ForestDev F, const int8_t
     if (lane_id() == 0) F.hdr[t] = H;
 }
 
+// Memory reclamation before a search from the canonical state in sm.st: when the arena or the record heap could not take
+// another numMCTSSims nodes, drop everything older than the new root's round (the reference's clean-up deletes nodes with
+// round < r-5 every >20 rounds, MCTS.py:86-91; unreachable nodes never influence a search, so dropping them earlier does
+// not change any result).
+template <class G>
+__device__ __forceinline__ void reclaim_if_short(const ForestDev& F, int t, TreeHdr& H, typename Forest<G>::Smem& sm) {
+    using FR = Forest<G>;
+    if (H.n_nodes + (uint32_t)F.numMCTSSims + 8u > (uint32_t)F.cap ||
+        H.heap_top + (uint32_t)(F.numMCTSSims + 8) * (RecLayout(G::A < 96 ? G::A : 96, F.U).total / 16u) + 256u > F.heap_units) {
+        // locate the new root first so that GC can keep it
+        const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
+        uint32_t free_slot;
+        uint32_t found_rec = AZG_NONE;
+        H.root = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
+        gc_tree<G>(F, t, H, G::get_round(sm.st));
+    }
+}
+
+// MCTS.getActionProb prologue for host-driven searches (azg_forest_begin_search)
+template <class G>
+__global__ __launch_bounds__(64) void k_begin_search(ForestDev F, const int8_t* roots, const uint8_t* full) {
+    using FR = Forest<G>;
+    __shared__ typename FR::Smem sm;
+    const int t = blockIdx.x;
+    TreeHdr H = load_uniform(&F.hdr[t]);
+    FR::load_state_unpadded(sm.st, roots + (size_t)t * G::S);
+    if (H.n_nodes) reclaim_if_short<G>(F, t, H, sm);
+    begin_search_from_lds<G>(F, t, H, sm, full ? full[t] != 0 : true);
+    if (H.n_nodes > H.max_nodes_seen) H.max_nodes_seen = H.n_nodes;
+    if (lane_id() == 0) F.hdr[t] = H;
+}
+
 template <class G>
 __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     using FR = Forest<G>;
@@ -304,17 +336,7 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
         if (np != 0) G::swap_players(sm.st, sm.tmp, np);                                      // Coach.py:61
     }
     // ---- memory reclamation, then the next search ----
-    const int new_round = G::get_round(sm.st);
-    if (!ended && (H.n_nodes + (uint32_t)F.numMCTSSims + 8u > (uint32_t)F.cap ||
-                   H.heap_top + (uint32_t)(F.numMCTSSims + 8) * (RecLayout(G::A < 96 ? G::A : 96, F.U).total / 16u) + 256u >
-                       F.heap_units)) {
-        // locate the new root first so that GC can keep it
-        uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
-        uint32_t free_slot;
-        uint32_t found_rec = AZG_NONE;
-        H.root = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
-        gc_tree<G>(F, t, H, new_round);
-    }
+    if (!ended) reclaim_if_short<G>(F, t, H, sm);
     const double u_full = rng.u01();                                                           // MCTS.py:58
     begin_search_from_lds<G>(F, t, H, sm, u_full < F.prob_fullMCTS);
     H.rng_counter = rng.counter;

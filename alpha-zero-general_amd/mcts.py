@@ -18,7 +18,9 @@ class BatchedMCTS:
         self.game, self.nnet, self.args = game, nnet, args
         self.dirichlet_noise = dirichlet_noise
         sims = int(getattr(args, 'numMCTSSims', 800) if not isinstance(args, dict) else args.get('numMCTSSims', 800))
-        cap = node_capacity or max(64, 4 * sims + 64)
+        # nodes live until the root's round passes theirs (the clean-up before each search, cf. MCTS.py:86-91): a few
+        # plies' worth of simulations
+        cap = node_capacity or max(1024, 10 * sims + 512)
         self.forest = Forest(game.GAME_ID, game.variant, n_trees, args, node_capacity=cap, device=str(game.device),
                              **forest_kw)
         self.T = n_trees

@@ -150,7 +150,7 @@ int azg_selfplay_advance(azg_forest* f, void* stream);
 typedef struct azg_selfplay_stats {
     uint64_t plies, games, sims, levels, expansions, sum_valid_visited, terminal_hits, examples, gc_runs, max_nodes,
         errors, sum_depth_at_expand,
-        cyc_select, cyc_levels, cyc_edge, cyc_leaf,   /* shader-clock cycles summed over trees: whole k_select, descent levels,
+        cyc_select, cyc_levels, cyc_edge, cyc_leaf,   /* (library built with -DAZG_CYC_COUNTERS only, else 0) shader-clock cycles summed over trees: whole k_select, descent levels,
                                                          frontier edge resolution (incl. leaf creation), leaf creation */
         cyc_seg[4];                                   /* frontier edge split: parent-state load, env step, canonical form +
                                                          hash, table probe */

@@ -102,8 +102,10 @@ def test_whole_tree_vs_oracle(variant):
 
 
 @pytest.mark.parametrize('variant', ['splendor2', 'santorini1', 'azul'])
-def test_tree_reuse_sequence_vs_golden(golden_dir, variant):
-    """Multi-move sequence of the golden set: tree reuse across moves and fast (non-full) searches."""
+@pytest.mark.parametrize('small_arena', [False, True])
+def test_tree_reuse_sequence_vs_golden(golden_dir, variant, small_arena):
+    """Multi-move sequence of the golden set: tree reuse across moves and fast (non-full) searches.  With a small arena
+    every search is preceded by the engine's clean-up (the counterpart of MCTS.py:86-91): results must not change."""
     import torch
     from azg_amd.mcts import BatchedMCTS
     from hashnet import HashNetTorch
@@ -113,7 +115,11 @@ def test_tree_reuse_sequence_vs_golden(golden_dir, variant):
     sims = int(d['seq_sims'])
     args = Args(numMCTSSims=sims, prob_fullMCTS=0.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1, 1, 1], **kw)
     n = len(d['seq_action'])
-    m = BatchedMCTS(g, HashNetTorch(g.P), args, 1, node_capacity=sims * n + 64)
+    # round-based clean-up keeps every node that a later transposition could still reach (round >= the root's round), so
+    # the arena must hold a few plies' worth of nodes: tight for Splendor (round == ply counter), half the sequence for
+    # Santorini / Azul (Azul's round only advances every few plies)
+    small_cap = 2 * sims + 72 if variant == 'splendor2' else (sims * n) // 2
+    m = BatchedMCTS(g, HashNetTorch(g.P), args, 1, node_capacity=small_cap if small_arena else (sims * n + 64))
     for i in range(n):
         root = torch.from_numpy(d['seq_canon'][i:i + 1]).to(g.device)
         full = torch.tensor([1 if i % 3 != 2 else 0], dtype=torch.uint8, device=g.device)
@@ -123,6 +129,8 @@ def test_tree_reuse_sequence_vs_golden(golden_dir, variant):
         assert int(rs['Ns'][0]) == int(d['seq_Ns'][i]), (variant, i)
         assert np.array_equal(rs['Nsa'][0].cpu().numpy(), d['seq_Nsa'][i].astype(np.int32)), (variant, i)
         assert np.array_equal(probs[0].cpu().numpy(), d['seq_probs'][i]), (variant, i)
+    if small_arena and variant == 'splendor2':
+        assert m.forest.stats()['gc_runs'] > 0
     m.forest.close()
 
 

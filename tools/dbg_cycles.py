@@ -1,3 +1,4 @@
+"""needs the library built with AZG_DEFINES=AZG_CYC_COUNTERS python alpha-zero-general_amd/build.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
