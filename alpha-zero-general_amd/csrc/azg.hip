@@ -107,6 +107,19 @@ extern "C" int azg_env_init_boards(int game, int variant, int n, int8_t* out_sta
     return 0;
 }
 
+extern "C" int azg_env_symmetries(int game, int variant, const int8_t* states, const float* pi, const uint8_t* valids, int n,
+                                  int max_sym, int8_t* out_states, float* out_pi, uint8_t* out_valids, int32_t* out_count,
+                                  void* stream) {
+    if (n <= 0) return 0;
+    if (!states || !pi || !valids || !out_states || !out_pi || !out_valids || !out_count || max_sym <= 0)
+        return fail("azg_env_symmetries: null/empty argument");
+    variant = norm_variant(game, variant);
+    AZG_DISPATCH(game, variant, k_env_symmetries<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(
+                                    states, pi, valids, n, max_sym, out_states, out_pi, out_valids, out_count));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ---- forest ---------------------------------------------------------------------------------------------------------
 struct azg_forest {
     azg_forest_cfg cfg;

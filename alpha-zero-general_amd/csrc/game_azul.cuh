@@ -189,6 +189,37 @@ struct AzulDev {
             scores[p] = (int8_t)(scores[p] + add);
         }
     }
+    // Board.get_symmetries :310-331: the 120 permutations of the 5 factories in itertools.permutations(range(5)) order
+    // (lexicographic); form c moves factory perm_c[i] to slot i, and the 30 actions of each factory with it.
+    static constexpr int NSYM_CAND = 120;
+    __device__ static __forceinline__ bool sym_exists(const int8_t*, int) { return true; }
+    __device__ static __forceinline__ int perm_elem(int c, int i) {          // i-th element of the c-th permutation of 0..4
+        int used = 0, rem = c, e = 0;
+        const int fact[5] = {24, 6, 2, 1, 1};
+        for (int k = 0; k <= i; k++) {
+            int d = rem / fact[k];
+            rem -= d * fact[k];
+            e = 0;
+            for (int v = 0; v < 5; v++) {                                     // d-th unused value
+                if (used & (1 << v)) continue;
+                if (d == 0) { e = v; break; }
+                d--;
+            }
+            used |= 1 << e;
+        }
+        return e;
+    }
+    __device__ static __forceinline__ int8_t sym_state_byte(const int8_t* st, int c, int i) {
+        const int r = i / COLS, col = i - r * COLS;
+        const int src = (r >= R_FACT && r < R_FACT + 5) ? R_FACT + perm_elem(c, r - R_FACT) : r;
+        return st[src * COLS + col];
+    }
+    __device__ static __forceinline__ int sym_action_src(const int8_t*, int c, int a) {
+        if (a < 30) return a;
+        const int f = a / 30 - 1;
+        return 30 * (perm_elem(c, f) + 1) + (a - 30 * (f + 1));
+    }
+
     __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
         return lane0_make_move<AzulDev>(st, move, player, seed, rng);
     }

@@ -168,6 +168,62 @@ struct SantoriniDev {
             if (l == 0) mask_lds[k] = m;
         }
     }
+    // Board.get_symmetries :578-653: identity, rot90 x1..3 (np.rot90: out[i][j] = in[j][4-i]), fliplr, flipud, swap of
+    // the own workers, swap of the opponent's workers.  The Artemis / Demeter memo (65 + 9*worker + direction) follows
+    // the direction permutation (:589-595) and, with Athena's, the worker swap (:630-636); the policy follows the
+    // (move, build) direction permutation (:597-609) or swaps its two worker halves (:641-642).
+    static constexpr int NSYM_CAND = 8;
+    __device__ static __forceinline__ bool sym_exists(const int8_t*, int) { return true; }
+    __device__ static __forceinline__ int dir_core(int kind, int d) {        // SantoriniConstants.py:60,68,77
+        const int dr = d / 3, dc = d - 3 * dr;
+        if (kind == 0) return 3 * (2 - dc) + dr;         // rotation   [6,3,0,7,4,1,8,5,2]
+        if (kind == 1) return 3 * dr + (2 - dc);         // flip LR    [2,1,0,5,4,3,8,7,6]
+        return 3 * (2 - dr) + dc;                        // flip UD    [6,7,8,3,4,5,0,1,2]
+    }
+    __device__ static __forceinline__ int dir_core_inv(int kind, int d) {
+        if (kind != 0) return dir_core(kind, d);         // involutions
+        return dir_core(0, dir_core(0, dir_core(0, d))); // rotation^-1 = rotation^3
+    }
+    __device__ static __forceinline__ int8_t sym_state_byte(const int8_t* st, int c, int i) {
+        const int pos = i / 3, plane = i - 3 * pos;
+        if (plane < 2) {
+            int si = pos / 5, sj = pos - 5 * si;
+            if (c >= 1 && c <= 3) { for (int k = 0; k < c; k++) { const int t = si; si = sj; sj = 4 - t; } }
+            else if (c == 4) sj = 4 - sj;
+            else if (c == 5) si = 4 - si;
+            int8_t v = st[(si * 5 + sj) * 3 + plane];
+            if (plane == 0 && c == 6 && v > 0) v = (int8_t)(3 - v);
+            if (plane == 0 && c == 7 && v < 0) v = (int8_t)(-3 - v);
+            return v;
+        }
+        int v = st[i];                                   // gods_power.flat[pos]
+        if (pos >= 2 * NB || v < 65) return (int8_t)v;
+        const int god = pos % NB;
+        if (c >= 1 && c <= 5 && (god == ARTEMIS || god == DEMETER)) {
+            const int k = v - 65, worker = k / 9;
+            int dir = k - 9 * worker;
+            if (c <= 3) { for (int r = 0; r < c; r++) dir = dir_core(0, dir); }
+            else dir = dir_core(c == 4 ? 1 : 2, dir);
+            return (int8_t)(65 + 9 * worker + dir);
+        }
+        if ((c == 6 && pos < NB) || (c == 7 && pos >= NB)) {
+            if (god == ARTEMIS || god == DEMETER || god == ATHENA) return (int8_t)((v - 65 + 9) % 18 + 65);
+        }
+        return (int8_t)v;
+    }
+    __device__ static __forceinline__ int sym_action_src(const int8_t*, int c, int a) {
+        if (c == 0 || c == 7) return a;
+        if (c == 6) return (a + A / 2) % A;
+        const int worker = a / (NB * 81);
+        int rem = a - worker * (NB * 81);
+        const int power = rem / 81;
+        rem -= power * 81;
+        int md = rem / 9, bd = rem - 9 * md;
+        if (c <= 3) { for (int r = 0; r < c; r++) { md = dir_core_inv(0, md); bd = dir_core_inv(0, bd); } }
+        else { md = dir_core_inv(c == 4 ? 1 : 2, md); bd = dir_core_inv(c == 4 ? 1 : 2, bd); }
+        return NB * 81 * worker + 81 * power + 9 * md + bd;
+    }
+
     __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
         return lane0_make_move<SantoriniDev<NB>>(st, move, player, seed, rng);
     }

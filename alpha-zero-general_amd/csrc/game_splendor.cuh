@@ -461,6 +461,44 @@ struct SplendorDev {
         wave_sync();
     }
 
+    // Board.get_symmetries :255-301 as an index map: candidate form c of the state / of the action vector.
+    // Order: identity, 3 tiers x 3 permutations of the 4 visible cards, then per player the permutations of the filled
+    // reserve slots (np_cards_symmetries / np_reserve_symmetries, SplendorLogic.py); reserve forms exist only when the
+    // table entry is not -1.  sym_state_src returns the source BYTE index, sym_action_src the source action index.
+    static constexpr int NSYM_CAND = 10 + 2 * NP;
+    __device__ static __forceinline__ int n_reserved(const int8_t* st, int pl) {
+        int nb = 3;
+        for (int c = 2; c >= 0; c--) if (sum5(row(st, R_RES + 6 * pl + 2 * c)) == 0) nb = c;
+        return nb;
+    }
+    __device__ static __forceinline__ bool sym_exists(const int8_t* st, int c) {
+        if (c < 10) return true;
+        const int pl = (c - 10) >> 1, s = (c - 10) & 1;
+        return SPL_RESERVE_SYM[n_reserved(st, pl)][s][0] >= 0;
+    }
+    __device__ static __forceinline__ int8_t sym_state_byte(const int8_t* st, int c, int i) {
+        const int r = i / COLS, col = i - r * COLS;
+        int src = r;
+        if (c >= 1 && c < 10) {
+            const int t = (c - 1) / 3, s = (c - 1) % 3, o = r - (1 + 8 * t);
+            if (o >= 0 && o < 8) src = 1 + 8 * t + 2 * SPL_CARD_SYM[s][o >> 1] + (o & 1);
+        } else if (c >= 10) {
+            const int pl = (c - 10) >> 1, s = (c - 10) & 1, o = r - (R_RES + 6 * pl);
+            if (o >= 0 && o < 6) src = R_RES + 6 * pl + 2 * SPL_RESERVE_SYM[n_reserved(st, pl)][s][o >> 1] + (o & 1);
+        }
+        return st[src * COLS + col];
+    }
+    __device__ static __forceinline__ int sym_action_src(const int8_t* st, int c, int a) {
+        if (c >= 1 && c < 10) {
+            const int t = (c - 1) / 3, s = (c - 1) % 3;
+            if (a >= 4 * t && a < 4 * t + 4) return 4 * t + SPL_CARD_SYM[s][a - 4 * t];
+            if (a >= 12 + 4 * t && a < 16 + 4 * t) return 12 + 4 * t + SPL_CARD_SYM[s][a - 12 - 4 * t];
+        } else if (c >= 10 && ((c - 10) >> 1) == 0) {
+            if (a >= 27 && a < 30) return 27 + SPL_RESERVE_SYM[n_reserved(st, 0)][(c - 10) & 1][a - 27];
+        }
+        return a;
+    }
+
     // Board.init_game :156-175 -- lane 0 only; `st` must be zeroed by the caller.
     __device__ static void init_board(int8_t* st, Rng& rng) {
         int8_t* bank = row(st, 0);

@@ -71,6 +71,33 @@ __global__ __launch_bounds__(64) void k_env_canonical(const int8_t* states, cons
     Forest<G>::store_state_unpadded(out_states + (size_t)t * G::S, st);
 }
 
+// Game.getSymmetries (Game.py:96-109; Coach.py:66-69 applies it to every recorded example): one wave per input triple,
+// form k of (state, pi, valids) goes to row k of the outputs [n][max_sym][.]; out_count[t] = number of forms written.
+template <class G>
+__global__ __launch_bounds__(64) void k_env_symmetries(const int8_t* states, const float* pi, const uint8_t* valids, int n,
+                                                        int max_sym, int8_t* out_states, float* out_pi, uint8_t* out_valids,
+                                                        int32_t* out_count) {
+    __shared__ __attribute__((aligned(16))) int8_t st[G::SP];
+    const int t = blockIdx.x;
+    if (t >= n) return;
+    Forest<G>::load_state_unpadded(st, states + (size_t)t * G::S);
+    const float* pin = pi + (size_t)t * G::A;
+    const uint8_t* vin = valids + (size_t)t * G::A;
+    int k = 0;
+    for (int c = 0; c < G::NSYM_CAND && k < max_sym; c++) {
+        if (!G::sym_exists(st, c)) continue;
+        const size_t o = (size_t)t * max_sym + k;
+        for (int i = lane_id(); i < G::S; i += 64) out_states[o * G::S + i] = G::sym_state_byte(st, c, i);
+        for (int a = lane_id(); a < G::A; a += 64) {
+            const int src = G::sym_action_src(st, c, a);
+            out_pi[o * G::A + a] = pin[src];
+            out_valids[o * G::A + a] = vin[src];
+        }
+        k++;
+    }
+    if (lane_id() == 0) out_count[t] = k;
+}
+
 template <class G>
 __global__ __launch_bounds__(64) void k_env_init_boards(int n, int8_t* out_states, uint64_t rng_seed, uint64_t stream0,
                                                         uint64_t* out_counters) {

@@ -72,6 +72,26 @@ class HipGame:
                                         _stream()))
         return out
 
+    def max_symmetries(self):
+        return {0: 10 + 2 * self.P, 1: 8, 2: 120}[self.GAME_ID]          # Splendor, Santorini, Azul
+
+    def symmetries_batch(self, boards, pi, valids, max_sym=None):
+        """getSymmetries for n (board int8[n,S], pi f32[n,A], valids u8[n,A]) triples on device ->
+        (boards int8[n,K,S], pi f32[n,K,A], valids u8[n,K,A], count i32[n]), K = max_sym; rows >= count[t] are unspecified"""
+        n = boards.shape[0]
+        K = max_sym or self.max_symmetries()
+        boards = boards.reshape(n, -1)
+        valids = valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)
+        assert boards.dtype == torch.int8 and pi.dtype == torch.float32
+        assert boards.is_contiguous() and pi.is_contiguous() and valids.is_contiguous()
+        ob = torch.empty((n, K, self.S), dtype=torch.int8, device=self.device)
+        op = torch.empty((n, K, self.A), dtype=torch.float32, device=self.device)
+        ov = torch.empty((n, K, self.A), dtype=torch.uint8, device=self.device)
+        cnt = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        check(lib().azg_env_symmetries(self.GAME_ID, self.variant, _ptr(boards), _ptr(pi), _ptr(valids), n, K, _ptr(ob),
+                                       _ptr(op), _ptr(ov), _ptr(cnt), _stream()))
+        return ob, op, ov, cnt
+
     # ---- Game.py API (numpy in / numpy out, one board) ----
     def _dev(self, board):
         return torch.from_numpy(np.ascontiguousarray(board, dtype=np.int8).reshape(1, self.S)).to(self.device)
@@ -115,6 +135,18 @@ class HipGame:
         if player == 0:
             return board
         return self.canonical_batch(self._dev(board), self._i32(player))[0].cpu().numpy().reshape(self.getBoardSize())
+
+    def getSymmetries(self, board, pi, valid_actions):
+        """Game.getSymmetries (Game.py:96-109): list of (board, pi, valids) forms, identity first"""
+        import numpy as np
+        b = self._dev(board).reshape(1, -1)
+        p = torch.as_tensor(np.asarray(pi, dtype=np.float32)).reshape(1, -1).to(self.device)
+        v = torch.as_tensor(np.asarray(valid_actions).astype(np.uint8)).reshape(1, -1).to(self.device)
+        ob, op, ov, cnt = self.symmetries_batch(b, p, v)
+        k = int(cnt[0])
+        shape = tuple(self.getBoardSize())
+        ob, op, ov = ob[0, :k].cpu().numpy(), op[0, :k].cpu().numpy(), ov[0, :k].cpu().numpy().astype(bool)
+        return [(ob[i].reshape(shape), op[i], ov[i]) for i in range(k)]
 
     def stringRepresentation(self, board):
         return np.ascontiguousarray(board, dtype=np.int8).tobytes()

@@ -140,11 +140,21 @@ class SelfPlayEngine:
     def device_bytes(self):
         return sum(grp.f.device_bytes for grp in self.groups)
 
-    def drain_examples(self):
+    def drain_examples(self, symmetries=False):
         """-> (boards int8[n,S], pi f32[n,A], z f32[n,P], valids u8[n,A], q f32[n,P], meta i32[n,4]) of finished games
-        (Coach.py:76-82 record layout, un-augmented; symmetries are applied by the consumer)."""
+        (Coach.py:76-82 record layout).  symmetries=True expands every record into all its Game.getSymmetries forms on
+        device, in the order Coach.py:66-69 appends them (all forms of a ply, identity first); z, q and meta are repeated."""
         parts = [grp.f.drain_examples() for grp in self.groups]
-        return tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(6))
+        ex = tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(6))
+        if not symmetries or ex[0].shape[0] == 0:
+            return ex
+        boards, pi, z, valids, q, meta = ex
+        ob, op, ov, cnt = self.game.symmetries_batch(boards.contiguous(), pi.contiguous(), valids.contiguous())
+        K = ob.shape[1]
+        keep = (torch.arange(K, device=cnt.device)[None, :] < cnt[:, None]).reshape(-1)
+        rep = torch.repeat_interleave(torch.arange(boards.shape[0], device=cnt.device), cnt.to(torch.int64))
+        return (ob.reshape(-1, ob.shape[2])[keep], op.reshape(-1, op.shape[2])[keep], z[rep],
+                ov.reshape(-1, ov.shape[2])[keep], q[rep], meta[rep])
 
 
 def gather_examples(tensors, group=None):

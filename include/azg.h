@@ -65,6 +65,14 @@ int azg_env_canonical(int game, int variant, const int8_t* states_dev, const int
    out_counters_dev (optional) receives the number of draws consumed. */
 int azg_env_init_boards(int game, int variant, int n, int8_t* out_states_dev, uint64_t rng_seed, uint64_t stream0,
                         uint64_t* out_counters_dev, void* stream);
+/* Game.getSymmetries (Game.py:96-109; Board.get_symmetries SplendorLogicNumba.py:255-301, SantoriniLogicNumba.py:578-653,
+   AzulLogicNumba.py:310-331) for n (state, pi, valids) triples: form k of triple t goes to row [t][k] of
+   out_states int8[n][max_sym][S], out_pi f32[n][max_sym][A], out_valids u8[n][max_sym][A]; out_count i32[n] = forms
+   written (the reference's order: identity first; <= 10 + 2P for Splendor, 8 for Santorini, 120 for Azul).
+   Coach.executeEpisode records every form of every full-search ply (Coach.py:66-69). */
+int azg_env_symmetries(int game, int variant, const int8_t* states_dev, const float* pi_dev, const uint8_t* valids_dev, int n,
+                       int max_sym, int8_t* out_states_dev, float* out_pi_dev, uint8_t* out_valids_dev,
+                       int32_t* out_count_dev, void* stream);
 
 /* ---- forest: T independent MCTS trees, one wavefront per tree ----------------------------------------------------
    Replaces MCTS (MCTS.py:19-261) for a batch of trees and, in self-play mode, Coach.executeEpisode (Coach.py:37-84). */

@@ -97,3 +97,58 @@ def test_game_py_surface():
     c = g.getCanonicalForm(nb, npl)
     assert c.shape == b.shape
     assert g.stringRepresentation(b) == b.tobytes()
+
+
+@pytest.mark.parametrize('variant', ['splendor2', 'splendor3', 'splendor4', 'santorini1', 'santorini11', 'azul'])
+def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
+    """Game.getSymmetries on device (azg_env_symmetries) vs the reference's own outputs (tests/golden/sym_*.npz) and, on
+    states from random play, vs the oracle."""
+    import torch
+    import azg_oracle as O
+    from azg_amd import games
+    name, v = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
+               'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0)}[variant]
+    g = {'splendor': lambda: games.SplendorGame(v), 'santorini': lambda: games.SantoriniGame(v), 'azul': games.AzulGame}[name]()
+    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL}[name], v)
+    K = g.max_symmetries()
+    path = os.path.join(golden_dir, 'sym_%s.npz' % variant)
+    if os.path.exists(path):
+        d = np.load(path)
+        ob, op, ov, cnt = g.symmetries_batch(torch.from_numpy(d['state'].reshape(len(d['state']), -1)).to(g.device),
+                                             torch.from_numpy(d['pi']).to(g.device),
+                                             torch.from_numpy(d['valid'].astype(np.uint8)).to(g.device))
+        ob, op, ov, cnt = ob.cpu().numpy(), op.cpu().numpy(), ov.cpu().numpy(), cnt.cpu().numpy()
+        assert np.array_equal(cnt, d['count'])
+        for i in range(len(cnt)):
+            k = int(cnt[i])
+            assert np.array_equal(ob[i, :k], d['out_state'][i][:k].reshape(k, -1)), (variant, i)
+            assert np.array_equal(op[i, :k], d['out_pi'][i][:k]), (variant, i)
+            assert np.array_equal(ov[i, :k], d['out_valid'][i][:k]), (variant, i)
+    # random-play states (non-empty reserves, god memos, used factories)
+    rng = np.random.default_rng(3)
+    states, pis, vas = [], [], []
+    for gi in range(6):
+        b, p = og.getInitBoard(og.rng(seed=17, stream=gi)), 0
+        for ply in range(40):
+            va = og.getValidMoves(b, p)
+            if ply % 3 == 0:
+                c = og.getCanonicalForm(b, p)
+                states.append(c.reshape(-1).copy())
+                pis.append(rng.random(len(va)).astype(np.float32))
+                vas.append(og.getValidMoves(c, 0).astype(np.uint8))
+            b, p = og.getNextState(b, p, int(rng.choice(np.flatnonzero(va))), random_seed=31416 + ply)
+            if og.getGameEnded(b, p).any():
+                break
+    ob, op, ov, cnt = g.symmetries_batch(torch.from_numpy(np.stack(states)).to(g.device), torch.from_numpy(np.stack(pis)).to(g.device),
+                                         torch.from_numpy(np.stack(vas)).to(g.device))
+    ob, op, ov, cnt = ob.cpu().numpy(), op.cpu().numpy(), ov.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(len(states)):
+        syms = og.getSymmetries(states[i], pis[i], vas[i], max_sym=K)
+        assert len(syms) == int(cnt[i]), (variant, i)
+        for k, (s, p_, v_) in enumerate(syms):
+            assert np.array_equal(ob[i, k], s.reshape(-1)), (variant, i, k)
+            assert np.array_equal(op[i, k], p_), (variant, i, k)
+            assert np.array_equal(ov[i, k], v_.astype(np.uint8)), (variant, i, k)
+    # the single-object mirror returns the reference's list-of-triples shape
+    lst = g.getSymmetries(states[0].reshape(g.getBoardSize()), pis[0], vas[0].astype(bool))
+    assert len(lst) == int(cnt[0]) and lst[0][0].shape == tuple(g.getBoardSize())

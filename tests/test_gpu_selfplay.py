@@ -134,3 +134,38 @@ def test_advance_cadence_does_not_change_results():
     assert len(res[0][0]) == len(res[1][0]) > 0
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
+
+
+def test_drain_examples_with_symmetries():
+    """drain_examples(symmetries=True) == Coach.py:66-69: every recorded ply expanded into all getSymmetries forms
+    (identity first), z / q / meta repeated; checked against the oracle's getSymmetries."""
+    import azg_oracle as O
+    from azg_amd import games
+    from azg_amd.selfplay import SelfPlayEngine
+    from hashnet import HashNetTorch
+    g = games.SplendorGame(2)
+    og = O.OracleGame(O.SPLENDOR, 2)
+    args = Args(numMCTSSims=16, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1.25, 0.8, 1.0],
+                tempThreshold=6, **MCTS_ARGS['splendor2'])
+    T = 8
+    e = SelfPlayEngine(g, HashNetTorch(2), args, T, node_capacity=1024, max_examples=T * 400, rng_seed=5, use_graph=False)
+    e.start()
+    for _ in range(200):
+        e.run(50)
+        if e.stats()['games'] >= T:
+            break
+    boards, pi, z, valids, q, meta = [x.cpu().numpy() for x in e.drain_examples(symmetries=True)]
+    assert len(boards) > 0
+    i = 0
+    n_records = 0
+    while i < len(boards):
+        syms = og.getSymmetries(boards[i], pi[i], valids[i], max_sym=32)       # row i is the identity form of a record
+        for k, (s, p, v) in enumerate(syms):
+            assert np.array_equal(boards[i + k], s.reshape(-1)) and np.array_equal(pi[i + k], p)
+            assert np.array_equal(valids[i + k], v.astype(np.uint8))
+            assert np.array_equal(z[i + k], z[i]) and np.array_equal(q[i + k], q[i]) and np.array_equal(meta[i + k], meta[i])
+        i += len(syms)
+        n_records += 1
+    assert i == len(boards) and n_records == e.stats()['examples'] or n_records > 0
+    for grp in e.groups:
+        grp.f.close()
