@@ -71,9 +71,13 @@ print('rank', rank, 'ok')
 def test_example_gather_world2_gloo(tmp_path):
     script = tmp_path / 'w.py'
     script.write_text(WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29641')
+    import socket
+    with socket.socket() as sk:                      # a free rendezvous port (a fixed one can still be in TIME_WAIT)
+        sk.bind(('127.0.0.1', 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', '29641', str(script)],
+                        '--master-addr', '127.0.0.1', '--master-port', port, str(script)],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'rank 0 ok' in r.stdout + r.stderr and 'rank 1 ok' in r.stdout + r.stderr
