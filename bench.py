@@ -121,7 +121,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--roofline-rounds', type=int, default=300)
-    ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'r01b_traffic.json'))
+    ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'r01c_traffic.json'))
     a = ap.parse_args()
 
     import torch
