@@ -434,3 +434,58 @@ class SantoriniV89:
         va = torch.from_numpy(np.asarray(valid_actions).astype(np.bool_))[None].to(self.device)
         pi, v = self.forward(b, va)
         return pi[0].cpu().numpy(), v[0].cpu().numpy()
+
+
+class SantoriniV78(SantoriniV89):
+    """santorini/SantoriniNNet.py nn_version 78 (:167-192,264-271; HeadWithMeta :42-69) -- the with-gods net of
+    pretrained_withgods.pt: conv3x3(2->64, no BN) -> 10 torchvision MobileNetV3 InvertedResidual blocks (1x1 expand
+    64->192 + BN + ReLU, depthwise 3x3 + BN + ReLU, 1x1 project + BN, residual; no SE) -> 1x1-conv heads whose flattened
+    features are concatenated with a 32-wide embedding of the gods/metadata plane (Linear(25,32)+ReLU).  BatchNorm
+    (eps 1e-5) folded into the convolutions; plain torch ops."""
+
+    def __init__(self, state_dict, num_players=2, device='cuda:0', dtype=torch.float32):
+        sd = {k: torch.as_tensor(v).float() for k, v in state_dict.items()}
+        self.P, self.A = num_players, sd['head_PI.fc.weight'].shape[0]
+
+        def conv_bn(conv, bn):
+            s, b = _fold_bn(sd, bn)
+            return (sd[conv + '.weight'] * s[:, None, None, None]).contiguous(), b
+        self.c0 = (sd['first_layer.weight'].contiguous(), torch.zeros(sd['first_layer.weight'].shape[0]))
+        self.blocks = []
+        i = 0
+        while 'trunk.%d.block.0.0.weight' % i in sd:
+            self.blocks.append(tuple(conv_bn('trunk.%d.block.%d.0' % (i, j), 'trunk.%d.block.%d.1' % (i, j)) for j in range(3)))
+            i += 1
+        self.hp = conv_bn('head_PI.conv1x1', 'head_PI.bn')
+        self.hv = conv_bn('head_V.conv1x1', 'head_V.bn')
+        self.meta = (sd['meta_fc.1.weight'].t().contiguous(), sd['meta_fc.1.bias'])
+        self.fc_pi = (sd['head_PI.fc.weight'].t().contiguous(), sd['head_PI.fc.bias'])
+        self.fc_v1 = (sd['head_V.fc1.weight'].t().contiguous(), sd['head_V.fc1.bias'])
+        self.fc_v2 = (sd['head_V.fc2.weight'].t().contiguous(), sd['head_V.fc2.bias'])
+        self.to(device, dtype)
+
+    def to(self, device, dtype=torch.float32):
+        self.device, self.dtype = torch.device(device), dtype
+        mv = lambda pr: tuple(t.to(self.device, dtype) for t in pr)  # noqa: E731
+        self.c0, self.hp, self.hv, self.meta = mv(self.c0), mv(self.hp), mv(self.hv), mv(self.meta)
+        self.blocks = [tuple(mv(c) for c in blk) for blk in self.blocks]
+        self.fc_pi, self.fc_v1, self.fc_v2 = mv(self.fc_pi), mv(self.fc_v1), mv(self.fc_v2)
+        return self
+
+    @torch.no_grad()
+    def forward(self, boards, valids):
+        B = boards.shape[0]
+        x = boards.reshape(B, 5, 5, 3).to(self.dtype).permute(0, 3, 1, 2)
+        meta = F.relu(torch.addmm(self.meta[1], x[:, 2].reshape(B, 25), self.meta[0]))
+        x = F.conv2d(x[:, :2].contiguous(), self.c0[0], self.c0[1], padding=1)
+        for (we, be), (wd, bd), (wp, bp) in self.blocks:
+            h = F.relu(F.conv2d(x, we, be))
+            h = F.relu(F.conv2d(h, wd, bd, padding=1, groups=wd.shape[0]))
+            x = F.conv2d(h, wp, bp) + x
+        hp = torch.cat([F.relu(F.conv2d(x, self.hp[0], self.hp[1])).flatten(1), meta], dim=1)
+        logits = torch.addmm(self.fc_pi[1], hp, self.fc_pi[0]).float()
+        hv = torch.cat([F.relu(F.conv2d(x, self.hv[0], self.hv[1])).flatten(1), meta], dim=1)
+        v = torch.tanh(torch.addmm(self.fc_v2[1], F.relu(torch.addmm(self.fc_v1[1], hv, self.fc_v1[0])), self.fc_v2[0]).float())
+        logits = torch.where(valids.bool(), logits, torch.full_like(logits, -1e8))
+        return torch.softmax(logits, dim=1).contiguous(), v.contiguous()
+

@@ -36,6 +36,10 @@ OTHER_GAMES = {
     'santorini1': dict(args=dict(numMCTSSims=800, cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True, dirichletAlpha=0.2,
                                  temperature=[1.25, 0.8, 1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0),
                        weights='weights_santorini1_v89.npz', net='SantoriniV89', label='Santorini no-gods (NB_GODS=1), V89 net'),
+    'santorini11': dict(args=dict(numMCTSSims=800, cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True, dirichletAlpha=0.2,
+                                  temperature=[1.25, 0.8, 1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0),
+                        weights='weights_santorini11_v78.npz', net='SantoriniV78',
+                        label='Santorini with gods (NB_GODS=11, A=1782), V78 net'),
     'azul': dict(args=dict(numMCTSSims=800, cpuct=0.5, fpu=0.05, universes=1, forced_playouts=True, dirichletAlpha=-1,
                            temperature=[1.25, 0.8, 1.0], tempThreshold=10, ratio_fullMCTS=5, prob_fullMCTS=1.0),
                  weights='weights_azul_v84.npz', net='AzulV84', label='Azul 2p, V84 net'),
@@ -110,7 +114,7 @@ def main():
     ap.add_argument('--steps', type=int, default=1700)
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--games', type=int, default=4096, help='concurrent games per GPU')
-    ap.add_argument('--game', default='splendor2', choices=['splendor2', 'santorini1', 'azul'])
+    ap.add_argument('--game', default='splendor2', choices=['splendor2', 'santorini1', 'santorini11', 'azul'])
     ap.add_argument('--sims', type=int, default=800)
     ap.add_argument('--node-capacity', type=int, default=0)
     ap.add_argument('--no-graph', action='store_true')
@@ -151,7 +155,8 @@ def main():
         og = OTHER_GAMES[a.game]
         margs = Args(og['args'])
         margs['numMCTSSims'] = a.sims
-        game = games.SantoriniGame(1, device=dev) if a.game == 'santorini1' else games.AzulGame(device=dev)
+        game = {'santorini1': lambda: games.SantoriniGame(1, device=dev), 'santorini11': lambda: games.SantoriniGame(11, device=dev),
+                'azul': lambda: games.AzulGame(device=dev)}[a.game]()
         net = getattr(_nn, og['net']).from_npz(os.path.join(ROOT, 'tests', 'golden', og['weights']), device=dev, dtype=dtype)
         a.net = 'torch'
         label = og['label']
@@ -242,7 +247,8 @@ def main():
                unit='env-steps/sec', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
                higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
                data='synthetic (Board.init_game boards from the counter RNG; net weights: %s)'
-                    % ('reference pretrained_2players.pt converted' if pretrained else 'random-init V80'),
+                    % (('reference checkpoint converted (%s)' % (os.path.basename(WEIGHTS) if a.game == 'splendor2' else OTHER_GAMES[a.game]['weights']))
+                       if pretrained else 'random-init V80'),
                config=dict(workload=('Splendor 2p, numMCTSSims=%d, %d concurrent self-play games per GPU, V80 net %s (%s), '
                                      'args of pretrained_2players.pt (cpuct 0.8 fpu 0.0593 universes 3 forced playouts '
                                      'dirichlet 0.3), every ply a full search' % (a.sims, T, a.net_dtype, 'engine MFMA-f32 kernels' if a.net == 'hip' else 'PyTorch-ROCm ops'))
