@@ -447,6 +447,18 @@ extern "C" int azg_selfplay_advance(azg_forest* f, void* stream) {
     return 0;
 }
 
+#ifdef AZG_CYC_COUNTERS
+// debug builds only: one 64-bit cycle counter of every tree (which: 0 cyc_select, 1 cyc_levels, 2 cyc_edge, 3 cyc_leaf)
+extern "C" int azg_debug_tree_cycles(azg_forest* f, int which, uint64_t* out /* host [T] */) {
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<TreeHdr> h(f->dev.T);
+    HIPCHK(hipMemcpy(h.data(), f->dev.hdr, sizeof(TreeHdr) * h.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); i++)
+        out[i] = which == 0 ? h[i].cyc_select : which == 1 ? h[i].cyc_levels : which == 2 ? h[i].cyc_edge : h[i].cyc_leaf;
+    return 0;
+}
+#endif
+
 extern "C" int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out) {
     if (!f || !out) return fail("null argument");
     HIPCHK(hipDeviceSynchronize());
