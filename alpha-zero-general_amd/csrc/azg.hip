@@ -127,6 +127,7 @@ struct azg_forest {
     int S, SP, A, P;
     size_t bytes;
     std::vector<void*> allocs;
+    const uint8_t* last_leaf_valid = nullptr;   // valid masks written by the last azg_forest_select (read by expand_backup)
     // timing
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
@@ -275,6 +276,7 @@ extern "C" int azg_forest_select(azg_forest* f, int8_t* leaf_states, uint8_t* le
     if (f->cfg.dirichletAlpha != 0.0 && (root_noise || noise_stride == -1))
         FDISPATCH(f, k_root_noise<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, root_noise, noise_stride));
     const int wait_noise = (f->cfg.dirichletAlpha != 0.0 && !root_noise && noise_stride == -2) ? 1 : 0;
+    f->last_leaf_valid = leaf_valid;
     ev_begin(f, 0, (hipStream_t)stream);
     FDISPATCH(f, k_select<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, leaf_states,
                                      leaf_valid, needs_eval, wait_noise));
@@ -286,9 +288,10 @@ extern "C" int azg_forest_select(azg_forest* f, int8_t* leaf_states, uint8_t* le
 extern "C" int azg_forest_expand_backup(azg_forest* f, const float* pi, const float* v, const double* root_noise,
                                         int noise_stride, void* stream) {
     if (!f || !pi || !v) return fail("null argument");
+    if (!f->last_leaf_valid) return fail("azg_forest_expand_backup: no preceding azg_forest_select");
     ev_begin(f, 1, (hipStream_t)stream);
     FDISPATCH(f, k_expand_backup<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, pi,
-                                     v, (root_noise || noise_stride == -1 || noise_stride == -2) ? 1 : 0));
+                                     v, f->last_leaf_valid, (root_noise || noise_stride == -1 || noise_stride == -2) ? 1 : 0));
     ev_end(f, 1, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;

@@ -79,6 +79,7 @@ struct __attribute__((aligned(16))) TreeHdr {
     uint32_t err, root_round;
     uint32_t leaf_is_root, games_done, step, n_rec;
     uint32_t mid_sim, cur_rec, cur_depth, cur_pre;     // a descent paused by the per-launch level budget
+    uint32_t pending_nv, pending_node, pad0_, pad1_;   // n_valid and node id of pending_leaf (saves k_expand_backup a round trip)
     uint32_t max_nodes_seen, gc_runs, root_rec, noise_pending;   // root_rec = record offset of the root;
                                                                  // noise_pending: root Dirichlet noise still to apply
     uint64_t c_sims, c_levels, c_exp, c_sumvalid, c_term, c_depth, c_plies, c_examples;

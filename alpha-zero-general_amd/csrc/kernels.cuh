@@ -236,6 +236,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
 #ifdef AZG_LEAF_SPLIT
     q1 = AZG_CLK(); H.cyc_seg[2] += (uint32_t)(q1 - q0);
 #endif
+    H.leaf_nv = (uint32_t)nv; H.leaf_node = id;
     const RecLayout L(nv, F.U);
     // 256 units (4 KB) of slack: a level's speculative entry loads may reach 64 entries past a short record
     if (H.heap_top + L.total / 16u + 256u > F.heap_units) { H.err |= ERR_HEAP_OVERFLOW; return AZG_NONE; }
@@ -320,7 +321,7 @@ __device__ __forceinline__ void stat_add(uint64_t* p, uint64_t v) {
 // registers made the kernel spill to scratch; the cold fields are read-modify-written by lane 0 at the end instead.
 struct SelState {
     uint32_t n_nodes, heap_top, root, root_rec, sim_idx, n_sims, is_full, forced, err, leaf_is_root, mid_sim, cur_rec,
-        cur_depth, cur_pre, status, pending_leaf, path_len, cyc_leaf, cyc_seg[4];
+        cur_depth, cur_pre, status, pending_leaf, path_len, leaf_nv, leaf_node, cyc_leaf, cyc_seg[4];
 };
 
 // One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
     H.is_full = uni_u32(H.is_full); H.forced = uni_u32(H.forced); H.err = uni_u32(H.err);
     H.leaf_is_root = uni_u32(H.leaf_is_root); H.mid_sim = uni_u32(H.mid_sim); H.cur_rec = uni_u32(H.cur_rec);
     H.cur_depth = uni_u32(H.cur_depth); H.cur_pre = uni_u32(H.cur_pre);
-    H.status = ST_SEARCHING; H.pending_leaf = AZG_NONE; H.path_len = 0; H.cyc_leaf = 0;
+    H.status = ST_SEARCHING; H.pending_leaf = AZG_NONE; H.path_len = 0; H.cyc_leaf = 0; H.leaf_nv = 0; H.leaf_node = 0;
     H.cyc_seg[0] = H.cyc_seg[1] = H.cyc_seg[2] = H.cyc_seg[3] = 0;
     uint8_t* hp = FR::heap(F, t);
     const uint32_t ES = entry_stride(F.U);
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
         Hp->n_nodes = H.n_nodes; Hp->heap_top = H.heap_top; Hp->root = H.root; Hp->root_rec = H.root_rec;
         Hp->sim_idx = H.sim_idx; Hp->err = H.err; Hp->leaf_is_root = H.leaf_is_root; Hp->mid_sim = H.mid_sim;
         Hp->cur_rec = H.cur_rec; Hp->cur_depth = H.cur_depth; Hp->cur_pre = H.cur_pre; Hp->status = H.status;
-        Hp->pending_leaf = H.pending_leaf; Hp->path_len = H.path_len;
+        Hp->pending_leaf = H.pending_leaf; Hp->path_len = H.path_len; Hp->pending_nv = H.leaf_nv; Hp->pending_node = H.leaf_node;
         // statistics: no-return atomics, so the wave does not wait for a read-modify-write round trip before it retires
         atomicMax(&Hp->max_nodes_seen, H.n_nodes);
         stat_add(&Hp->c_sims, c_sims); stat_add(&Hp->c_levels, c_levels); stat_add(&Hp->c_sumvalid, c_sumvalid);
@@ -553,54 +554,76 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
 
 // One lock-step round, part 2: store (Ps, v) on the pending leaf and back up (MCTS.py:144-154,176-183).
 template <class G>
-__global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* pi, const float* vin, int noise_enabled) {
+__global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* pi, const float* vin, const uint8_t* leaf_valid,
+                                                      int noise_enabled) {
     using FR = Forest<G>;
     __shared__ __attribute__((aligned(16))) float dense[G::A];
     __shared__ __attribute__((aligned(16))) PathEnt path[AZG_MAXD];
     const int t = blockIdx.x;
     const int l = lane_id();
-    if (uni_u32(F.hdr[t].status) != ST_WAIT_NN) return;
-    struct { uint32_t pending_leaf, path_len, leaf_is_root, sim_idx, is_full; uint64_t c_exp, c_depth; } H;
-    H.pending_leaf = uni_u32(F.hdr[t].pending_leaf); H.path_len = uni_u32(F.hdr[t].path_len);
-    H.leaf_is_root = uni_u32(F.hdr[t].leaf_is_root); H.sim_idx = uni_u32(F.hdr[t].sim_idx); H.is_full = uni_u32(F.hdr[t].is_full);
-    H.c_exp = F.hdr[t].c_exp; H.c_depth = F.hdr[t].c_depth;
-    uint8_t* rec = FR::rec_ptr(F, t, H.pending_leaf);
-    RecHdr* rhp = (RecHdr*)rec;
-    const int nv = (int)uni_u32((uint32_t)rhp->nv);
-    const RecLayout L(nv, F.U);
-    const RecIds ids(rec, F.U);
-    for (int i = l; i < G::A; i += 64) dense[i] = pi[(size_t)t * G::A + i];
-    const int depth = (int)H.path_len;
-    const PathEnt* gp = F.path + (size_t)t * AZG_MAXD;
-    for (int d = l; d < depth; d += 64) path[d] = gp[d];
-    wave_sync();
-    // a root expanded by simulation 0 of a full search gets root noise (MCTS.py:147-149): keep the RAW net output in the
-    // entries and let k_root_noise do softmax -> noise -> normalise; every other leaf is normalised here (:150,250-253)
-    const bool dir_now = (noise_enabled && H.leaf_is_root && H.sim_idx == 0 && H.is_full && F.dirichletAlpha != 0.0);
-    float s = 1.f;
-    if (!dir_now) s = np_sum_f32(dense, G::A);
-    for (int j = l; j < nv; j += 64) {                                                           // :40-41,150-152
-        uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
-        *(float*)(ent + AZG_E_P) = dir_now ? dense[ids[j]] : dense[ids[j]] / s;
-        *(uint32_t*)(ent + AZG_E_N) = 0u;
-        *(double*)(ent + AZG_E_Q) = AZG_NANQ;
-        for (int u = 0; u < F.U; u++) *(uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)u) = AZG_NONE;
+    TreeHdr* Hp = &F.hdr[t];
+    // ---- round trip 1: everything whose address does not depend on loaded data (header words, pi, v, the valid mask the
+    //      descent wrote for this leaf, the first 64 path entries) ----
+    const uint32_t status = Hp->status, pending_leaf = Hp->pending_leaf, path_len = Hp->path_len, leaf_is_root = Hp->leaf_is_root,
+                   sim_idx = Hp->sim_idx, is_full = Hp->is_full, pend_nv = Hp->pending_nv, pend_node = Hp->pending_node;
+    constexpr int NA = (G::A + 63) / 64;
+    float pv[NA];
+    uint8_t va[NA];
+#pragma unroll
+    for (int k = 0; k < NA; k++) {
+        const int a = l + 64 * k;
+        pv[k] = a < G::A ? pi[(size_t)t * G::A + a] : 0.f;
+        va[k] = a < G::A ? leaf_valid[(size_t)t * G::A + a] : (uint8_t)0;
     }
     float v[G::P];
 #pragma unroll
     for (int p = 0; p < G::P; p++) v[p] = vin[(size_t)t * G::P + p];
+    const PathEnt* gp = F.path + (size_t)t * AZG_MAXD;
+    const PathEnt pe0 = gp[l];
+    if (uni_u32(status) != ST_WAIT_NN) return;
+    const int depth = (int)uni_u32(path_len);
+    const int nv = (int)uni_u32(pend_nv);
+    const uint32_t sim = uni_u32(sim_idx);
+    uint8_t* rec = FR::rec_ptr(F, t, uni_u32(pending_leaf));
+    RecHdr* rhp = (RecHdr*)rec;
+    const RecLayout L(nv, F.U);
+    path[l] = pe0;
+    for (int d = l + 64; d < depth; d += 64) path[d] = gp[d];
+#pragma unroll
+    for (int k = 0; k < NA; k++) if (l + 64 * k < G::A) dense[l + 64 * k] = pv[k];
+    wave_sync();
+    // a root expanded by simulation 0 of a full search gets root noise (MCTS.py:147-149): keep the RAW net output in the
+    // entries and let the noise step do softmax -> noise -> normalise; every other leaf is normalised here (:150,250-253)
+    const bool dir_now = (noise_enabled && uni_u32(leaf_is_root) && sim == 0 && uni_u32(is_full) && F.dirichletAlpha != 0.0);
+    float s = 1.f;
+    if (!dir_now) s = np_sum_f32(dense, G::A);
+    // entry j belongs to the j-th valid action (the rank of its bit in the leaf's valid mask): no read of the record needed
+    int base_rank = 0;
+#pragma unroll
+    for (int k = 0; k < NA; k++) {                                                               // :40-41,150-152
+        const uint64_t m = __ballot(va[k] != 0);
+        if (va[k]) {
+            const int j = base_rank + __popcll(m & ((1ull << l) - 1ull));
+            uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
+            uint4 e0;
+            e0.x = __float_as_uint(dir_now ? pv[k] : pv[k] / s); e0.y = 0u;                       // P, N = 0
+            e0.z = (uint32_t)__double_as_longlong(AZG_NANQ); e0.w = (uint32_t)((uint64_t)__double_as_longlong(AZG_NANQ) >> 32);
+            *(uint4*)(ent + AZG_E_P) = e0;
+            for (int u = 0; u < F.U; u++) *(uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)u) = AZG_NONE;
+        }
+        base_rank += __popcll(m);
+    }
     if (l == 0) {                                                                                // :152-153
         rhp->Ns = 0; rhp->Qs = v[0]; rhp->flags = NF_EXPANDED;
-        FR::nhdr(F, t, rhp->node_id)->flags = NF_EXPANDED;
+        FR::nhdr(F, t, uni_u32(pend_node))->flags = NF_EXPANDED;
     }
     FR::backup(F, t, path, depth, v);                                                            // leaf returns v :154
     if (l == 0) {
-        TreeHdr* Hp = &F.hdr[t];
-        Hp->sim_idx = H.sim_idx + 1;
+        Hp->sim_idx = sim + 1;
         Hp->status = ST_SEARCHING;
         Hp->pending_leaf = AZG_NONE;
-        Hp->c_exp = H.c_exp + 1;
-        Hp->c_depth = H.c_depth + (uint64_t)depth;
+        stat_add(&Hp->c_exp, 1ull);
+        stat_add(&Hp->c_depth, (uint64_t)depth);
         if (dir_now) Hp->noise_pending = 2u;
     }
 }

@@ -126,7 +126,9 @@ int azg_forest_select(azg_forest* f, int8_t* leaf_states_dev, uint8_t* leaf_vali
    azg_selfplay_advance launch instead of a launch of its own; a tree whose root noise is pending sits out the selects
    in between (same per-tree event sequence, so results do not depend on how often advance is launched). */
 /* part 2: store (Ps, v) on the pending leaves and back the values up (MCTS.py:147-154,176-183).
-   pi f32[T][A] are PROBABILITIES (exp of the net's log-softmax, GenericNNetWrapper.py:107,119), v f32[T][P]. */
+   pi f32[T][A] are PROBABILITIES (exp of the net's log-softmax, GenericNNetWrapper.py:107,119), v f32[T][P].
+   The leaf_valid buffer handed to the preceding azg_forest_select must still hold what that call wrote (the kernel maps
+   entry j of a leaf to its j-th valid action through it). */
 int azg_forest_expand_backup(azg_forest* f, const float* pi_dev, const float* v_dev, const double* root_noise_dev,
                              int noise_stride, void* stream);
 /* number of trees that still have simulations to run (synchronises) */
