@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libazg_hip.so')
+# AZG_LIB: A/B-test another build of the same library (tools/ab_bench.sh); never a different implementation
+LIB_PATH = os.environ.get('AZG_LIB') or os.path.join(HERE, 'libazg_hip.so')
 
 SPLENDOR, SANTORINI, AZUL = 0, 1, 2
 

@@ -220,6 +220,9 @@ struct AzulDev {
         return 30 * (perm_elem(c, f) + 1) + (a - 30 * (f + 1));
     }
 
+    // any move can end the round, whose refill draws tiles with random_seed (setup_new_round :237-255)
+    __device__ static __forceinline__ bool move_uses_seed(int) { return true; }
+
     __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
         return lane0_make_move<AzulDev>(st, move, player, seed, rng);
     }

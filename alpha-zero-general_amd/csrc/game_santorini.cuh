@@ -224,6 +224,9 @@ struct SantoriniDev {
         return NB * 81 * worker + 81 * power + 9 * md + bd;
     }
 
+    // no chance events in Santorini: random_seed is never read by make_move (:434-550)
+    __device__ static __forceinline__ bool move_uses_seed(int) { return false; }
+
     __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
         return lane0_make_move<SantoriniDev<NB>>(st, move, player, seed, rng);
     }

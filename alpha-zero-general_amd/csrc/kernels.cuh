@@ -503,7 +503,12 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                 child = resolve_edge<G, SelState>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es);
                 cyc_edge += AZG_CLK() - t_e;
                 if (child == AZG_NONE) { H.sim_idx = H.n_sims; break; }
-                if (l == 0) *(uint32_t*)((uint8_t*)rp + AZG_REC_HDR + (size_t)j * ES + AZG_E_C + 4u * (uint32_t)uidx) = child;
+                // memoise: this universe's slot -- or every slot when the env step of `a` cannot depend on the seed (the
+                // child of (state, a, seed) is then the same node for all universes; 30 % of the simulations used to
+                // re-resolve such an edge once per universe only to find the node through the hash table)
+                if (G::move_uses_seed(a)) {
+                    if (l == 0) *(uint32_t*)((uint8_t*)rp + AZG_REC_HDR + (size_t)j * ES + AZG_E_C + 4u * (uint32_t)uidx) = child;
+                } else if (l < F.U) *(uint32_t*)((uint8_t*)rp + AZG_REC_HDR + (size_t)j * ES + AZG_E_C + 4u * (uint32_t)l) = child;
                 have_leaf = is_new;
             }
             const int np = (int)(child >> 30);
