@@ -187,6 +187,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     D.ratio_fullMCTS = cfg->ratio_fullMCTS > 0 ? cfg->ratio_fullMCTS : 1;
     D.forced_playouts = cfg->forced_playouts;
     D.level_budget = cfg->level_budget;
+    D.work_budget = cfg->work_budget;
     D.cpuct = cfg->cpuct; D.fpu = cfg->fpu; D.prob_fullMCTS = cfg->prob_fullMCTS;
     D.dirichletAlpha = cfg->dirichletAlpha;
     D.temp_begin = cfg->temperature[0]; D.temp_end = cfg->temperature[1]; D.temp_root = cfg->temperature[2];
@@ -457,7 +458,9 @@ extern "C" int azg_debug_tree_cycles(azg_forest* f, int which, uint64_t* out /* 
     std::vector<TreeHdr> h(f->dev.T);
     HIPCHK(hipMemcpy(h.data(), f->dev.hdr, sizeof(TreeHdr) * h.size(), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < h.size(); i++)
-        out[i] = which == 0 ? h[i].cyc_select : which == 1 ? h[i].cyc_levels : which == 2 ? h[i].cyc_edge : h[i].cyc_leaf;
+        out[i] = which == 0 ? h[i].cyc_select : which == 1 ? h[i].cyc_levels : which == 2 ? h[i].cyc_edge :
+                 which == 3 ? h[i].cyc_leaf : which == 4 ? h[i].c_levels : which == 5 ? h[i].pad0_ : which == 10 ? h[i].pad1_ :
+                 h[i].cyc_seg[which - 6];
     return 0;
 }
 #endif

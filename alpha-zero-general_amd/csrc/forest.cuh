@@ -45,6 +45,7 @@ enum : uint32_t {
 #define AZG_CLK() 0ll
 #endif
 
+#define AZG_EDGE_UNITS 5
 #define AZG_MAXD 256
 #define AZG_IDX_BITS 22
 #define AZG_IDX_MASK ((1u << AZG_IDX_BITS) - 1u)
@@ -102,6 +103,7 @@ struct ForestDev {
     size_t s_nhdr, s_htab;             // elements (NodeHdr, u32)
     int universes, numMCTSSims, ratio_fullMCTS, forced_playouts;
     int level_budget;                  // max descent levels per tree per k_select launch (0 = unlimited)
+    int work_budget;                   // max work units (level = 1, edge resolution = AZG_EDGE_UNITS) per tree per launch
     double cpuct, fpu, prob_fullMCTS, dirichletAlpha, temp_begin, temp_end, temp_root, tempThreshold;
     uint64_t rng_seed, stream0;
     int max_examples, max_rec;

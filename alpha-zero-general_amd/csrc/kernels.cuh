@@ -333,6 +333,9 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
     const int t = blockIdx.x;
     const int l = lane_id();
     TreeHdr* Hp = &F.hdr[t];
+#ifdef AZG_WALL_CAL
+    const uint32_t w_first = (uint32_t)wall_clock64();
+#endif
     // every hot header field is requested in one go (status included): one memory round trip before the first level
     SelState H;
     const uint32_t status0 = Hp->status, pending0 = Hp->noise_pending;
@@ -354,8 +357,11 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
     uint8_t* hp = FR::heap(F, t);
     const uint32_t ES = entry_stride(F.U);
     bool need_nn = false;
-    uint32_t c_sims = 0, c_levels = 0, c_sumvalid = 0, c_term = 0, levels_this_launch = 0;
+    uint32_t c_sims = 0, c_levels = 0, c_sumvalid = 0, c_term = 0, levels_this_launch = 0, edges_this_launch = 0, work_units = 0;
     const long long t_start = AZG_CLK();
+#ifdef AZG_WALL_CAL
+    const long long w_start = wall_clock64();
+#endif
     long long cyc_levels = 0, cyc_edge = 0;
     while (true) {
         if (H.sim_idx >= H.n_sims || H.err) { H.status = ST_DONE; break; }
@@ -396,9 +402,10 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                 }
             }
         }
-        bool paused = false;
+        bool paused = false, park_request = false;
         while (!have_leaf) {
-            if (F.level_budget > 0 && levels_this_launch >= (uint32_t)F.level_budget) {
+            if ((F.level_budget > 0 && levels_this_launch >= (uint32_t)F.level_budget) ||
+                (F.work_budget > 0 && (work_units >= (uint32_t)F.work_budget || park_request))) {
                 // time slice: park the descent, resume next launch (the tree contributes no leaf this round)
                 PathEnt* gp0 = F.path + (size_t)t * AZG_MAXD;
                 for (int d = l; d < depth; d += 64) gp0[d] = sm.path[d];
@@ -407,6 +414,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
                 break;
             }
             levels_this_launch++;
+            work_units++;
             const long long t_lvl = AZG_CLK();
             // ---- one level: header + this lane's entry requested together (entry position is independent of nv) ----
             const uint8_t* rp = hp + (size_t)rec * 16u;
@@ -497,6 +505,12 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
             cyc_levels += AZG_CLK() - t_lvl;
             if (depth >= AZG_MAXD - 1) { H.err |= ERR_DEPTH_OVERFLOW; H.sim_idx = H.n_sims; break; }
             if (child == AZG_NONE) {
+                if (F.work_budget > 0 && edges_this_launch > 0 && work_units + AZG_EDGE_UNITS > (uint32_t)F.work_budget) {
+                    park_request = true;       // re-evaluated (same choice) when the descent resumes; the first edge of a
+                    continue;                  // launch is always resolved, so every launch makes progress
+                }
+                edges_this_launch++;
+                work_units += AZG_EDGE_UNITS;
                 const int a = a_sel;
                 bool is_new = false;
                 const long long t_e = AZG_CLK();
@@ -547,6 +561,12 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
         stat_add(&Hp->c_sims, c_sims); stat_add(&Hp->c_levels, c_levels); stat_add(&Hp->c_sumvalid, c_sumvalid);
         stat_add(&Hp->c_term, c_term);
 #ifdef AZG_CYC_COUNTERS
+#ifndef AZG_WALL_CAL
+        Hp->pad0_ += edges_this_launch;      // debug: frontier-edge resolutions of this tree (tools/dbg_tail.py)
+#endif
+#ifdef AZG_WALL_CAL
+        Hp->pad0_ = w_first; Hp->pad1_ = (uint32_t)wall_clock64(); (void)w_start;   // absolute 100 MHz stamps: wave start / end
+#endif
         stat_add(&Hp->cyc_select, (uint64_t)(AZG_CLK() - t_start)); stat_add(&Hp->cyc_levels, (uint64_t)cyc_levels);
         stat_add(&Hp->cyc_edge, (uint64_t)cyc_edge); stat_add(&Hp->cyc_leaf, (uint64_t)H.cyc_leaf);
         for (int k = 0; k < 4; k++) stat_add(&Hp->cyc_seg[k], (uint64_t)H.cyc_seg[k]);

@@ -34,7 +34,7 @@ class _Group:
 
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
-                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None):
+                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=0):
         self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
@@ -53,7 +53,7 @@ class SelfPlayEngine:
         for g in range(groups):
             f = Forest(game.GAME_ID, game.variant, Tg, args, node_capacity=cap,
                        max_examples=(max_examples or n_games * 64) // groups, rng_seed=rng_seed,
-                       stream0=stream0 + g * Tg, device=str(game.device), level_budget=level_budget)
+                       stream0=stream0 + g * Tg, device=str(game.device), level_budget=level_budget, work_budget=work_budget)
             self.groups.append(_Group(f, nets[g], (Tg,) + tuple(f.board_shape()), 'deferred' if alpha != 0.0 else False))
         self.forest = self.groups[0].f
         self.nnet = nets[0]

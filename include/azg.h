@@ -96,6 +96,10 @@ typedef struct azg_forest_cfg {
     int max_examples;            /* capacity of the on-device example ring (self-play mode) */
     int level_budget;            /* max descent levels per tree per azg_forest_select launch; a deeper simulation is parked
                                     and resumed by the next launch (0 = unlimited).  Pure scheduling: results identical. */
+    int work_budget;             /* cap on the work of one tree in one azg_forest_select launch, in level units (one descent
+                                    level = 1, one frontier-edge resolution = 5; 0 = unlimited): a launch lasts as long as
+                                    its slowest tree, so the few trees with a very deep or transposition-heavy simulation
+                                    are parked at a level boundary and resume in the next launch.  Pure scheduling. */
 } azg_forest_cfg;
 
 typedef struct azg_forest azg_forest;

@@ -227,9 +227,9 @@ def test_device_dirichlet_sampler_statistics():
     assert len({tuple(np.round(x, 6)) for x in d[:32]}) == 32      # different trees, different samples
 
 
-@pytest.mark.parametrize('budget', [1, 3])
+@pytest.mark.parametrize('budget', [dict(level_budget=1), dict(level_budget=3), dict(work_budget=2), dict(work_budget=7)])
 def test_level_budget_is_pure_scheduling(golden_dir, budget):
-    """A per-launch level budget (descents parked and resumed across launches) must not change any statistic."""
+    """A per-launch level / work budget (descents parked and resumed across launches) must not change any statistic."""
     import torch
     from azg_amd.mcts import BatchedMCTS
     from hashnet import HashNetTorch
@@ -240,7 +240,7 @@ def test_level_budget_is_pure_scheduling(golden_dir, budget):
     assert len(idxs) >= 2
     args = Args(numMCTSSims=200, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, prob_fullMCTS=1.0,
                 ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1, 1, 1])
-    m = BatchedMCTS(g, HashNetTorch(g.P), args, len(idxs), node_capacity=512, level_budget=budget)
+    m = BatchedMCTS(g, HashNetTorch(g.P), args, len(idxs), node_capacity=512, **budget)
     probs, q, _ = m.getActionProb(torch.from_numpy(d['case_root'][idxs]).to(g.device), temp=1, force_full_search=True)
     rs = m.forest.root_stats()
     for k, i in enumerate(idxs):
