@@ -693,9 +693,20 @@ extern "C" int azg_nn_v80_forward(const int8_t* boards, const uint8_t* valid, co
     V80NetW Nv{nullptr, nullptr, w[39], w[40], w[41], w[42]};
     hipStream_t s = (hipStream_t)stream;
     // V80 geometry (SplendorNNet.py:262-283): trunk ReLU + mean-SE, both heads Hardswish + max-SE
-    if (launch_v80<1, 0, 1>(nullptr, x_trunk, Wt, B, boards, N0, nullptr, nullptr, nullptr, P, s)) return -1;
-    if (launch_v80<2, 1, 2>(x_trunk, nullptr, Wp, B, nullptr, Np, valid, pi, nullptr, P, s)) return -1;
-    if (launch_v80<2, 1, 3>(x_trunk, nullptr, Wv, B, nullptr, Nv, nullptr, nullptr, v, P, s)) return -1;
+    if (getenv("AZG_NN_THREE_LAUNCHES")) {       // the per-block path (kept for A/B measurements)
+        if (launch_v80<1, 0, 1>(nullptr, x_trunk, Wt, B, boards, N0, nullptr, nullptr, nullptr, P, s)) return -1;
+        if (launch_v80<2, 1, 2>(x_trunk, nullptr, Wp, B, nullptr, Np, valid, pi, nullptr, P, s)) return -1;
+        if (launch_v80<2, 1, 3>(x_trunk, nullptr, Wv, B, nullptr, Nv, nullptr, nullptr, v, P, s)) return -1;
+        return 0;
+    }
+    static bool attr = false;
+    constexpr size_t lds = V80_LDS + (size_t)112 * 60 * sizeof(float);
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_v80_net, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    k_v80_net<<<dim3((B + 15) / 16), dim3(768), lds, s>>>(Wt, Wp, Wv, N0, Np, Nv, boards, valid, B, P, pi, v);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

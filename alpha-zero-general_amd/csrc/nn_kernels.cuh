@@ -305,15 +305,17 @@ __device__ long long g_v80_phase[4][16];
 #define AZG_PH(k)
 #endif
 
-template <int ACT, int POOLMAX, int MODE>
-__global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin, float* __restrict__ xout, V80BlockW W,
-                                                   int B, const int8_t* __restrict__ boards, V80NetW N,
-                                                   const uint8_t* __restrict__ valid, float* __restrict__ pi_out,
-                                                   float* __restrict__ v_out, int P) {
+// The block (+ optional first layer in front, + optional head tail behind) on one 16-sample tile.  X = the tile's [112][60]
+// f32 buffer in LDS, H = the rest of the workgroup's LDS ([112][172] + 2 x [16][172] + [16][52] + 64 floats).
+//   INLDS:  the input tile is already in X (whole-net kernel) instead of xin in HBM
+//   OUTLDS: the block output replaces X in place (always the case for the head MODEs); SAVE: and is copied to xsave
+template <int ACT, int POOLMAX, int MODE, bool INLDS, bool OUTLDS, bool SAVE>
+__device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave, const float* __restrict__ xin,
+                                               float* __restrict__ xout, const V80BlockW& W, int B,
+                                               const int8_t* __restrict__ boards, const V80NetW& N,
+                                               const uint8_t* __restrict__ valid, float* __restrict__ pi_out,
+                                               float* __restrict__ v_out, int P) {
     constexpr int C = 56, E = 168, NS = 16, ROWS = NS * 7, XS = 60, HS = 172, QS = 52, FK = 7 * XS /* 420 */, A = 81;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* X = smem;                    // [ROWS][XS]
-    float* H = X + ROWS * XS;           // [ROWS][HS]
     float* PL = H + ROWS * HS;          // pooled [NS][HS]
     float* SC = PL + NS * HS;           // scales [NS][HS]
     float* SH = SC + NS * HS;           // SE hidden [NS][QS]
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
     // ---- x tile requested first (HBM), then the weight fragments (L2) in the order the phases need them: the vmcnt
     //      counter retires in order, so P0 / P1 only wait for what they use while the rest keeps streaming in ----
     float4 xv[3];
-    if (MODE != 1) {
+    if (MODE != 1 && !INLDS) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int i = tid + 768 * k, row = i / (XS / 4), c4 = i - row * (XS / 4);
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
     if (MODE != 1) load_we();
     const float4 be4 = *(const float4*)(W.be + nt_e * 16 + 4 * g);
     if (tid < 49) WD[tid] = W.Wd[tid];
-    if (MODE != 1) {
+    if (MODE != 1 && !INLDS) {
         // ---- P0: x tile -> LDS (contiguous rows, float4); pad columns 56..59 zeroed ----
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -550,12 +552,14 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c].w, a.w, acc, 0, 0, 0);
         }
         const int col0 = nt_p * 16 + 4 * g;
-        if (MODE >= 2) {
+        if (MODE >= 2 || OUTLDS) {
             if (col0 < XS) {          // each element is read (residual) and overwritten by the same lane
                 float* xp = X + row * XS + col0;
                 const float4 xr = *(const float4*)xp;
-                *(float4*)xp = make_float4(acc[0] + bp4.x + xr.x, acc[1] + bp4.y + xr.y, acc[2] + bp4.z + xr.z,
-                                           acc[3] + bp4.w + xr.w);
+                const float4 o4 = make_float4(acc[0] + bp4.x + xr.x, acc[1] + bp4.y + xr.y, acc[2] + bp4.z + xr.z,
+                                              acc[3] + bp4.w + xr.w);
+                *(float4*)xp = o4;
+                if (SAVE) *(float4*)(xsave + row * XS + col0) = o4;
             }
         } else if (row < nrows && col0 < C) {
             const float4 xr = *(const float4*)(X + row * XS + col0);
@@ -673,6 +677,33 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
             }
         }
     }
+}
+
+template <int ACT, int POOLMAX, int MODE>
+__global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin, float* __restrict__ xout, V80BlockW W,
+                                                   int B, const int8_t* __restrict__ boards, V80NetW N,
+                                                   const uint8_t* __restrict__ valid, float* __restrict__ pi_out,
+                                                   float* __restrict__ v_out, int P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    v80_block_body<ACT, POOLMAX, MODE, false, false, false>(smem, smem + 112 * 60, nullptr, xin, xout, W, B, boards, N, valid,
+                                                           pi_out, v_out, P);
+}
+
+// The whole V80 forward of one 16-sample tile in ONE workgroup pass: first layer + trunk block (its output stays in LDS and
+// is copied to a second tile buffer), policy head block + tail on the first copy, value head block + tail on the second.
+// Nothing but the int8 boards, the valid masks and pi / v crosses HBM; LDS = 2 x [112][60] + the block's 129.5 KB = 156.4 KB.
+__global__ __launch_bounds__(768) void k_v80_net(V80BlockW Wt, V80BlockW Wp, V80BlockW Wv, V80NetW N0, V80NetW Np, V80NetW Nv,
+                                                 const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid, int B,
+                                                 int P, float* __restrict__ pi_out, float* __restrict__ v_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    float* XT = X + 112 * 60;
+    float* H = XT + 112 * 60;
+    v80_block_body<1, 0, 1, false, true, true>(X, H, XT, nullptr, nullptr, Wt, B, boards, N0, nullptr, nullptr, nullptr, P);
+    __syncthreads();
+    v80_block_body<2, 1, 2, true, false, false>(X, H, nullptr, nullptr, nullptr, Wp, B, nullptr, Np, valid, pi_out, nullptr, P);
+    __syncthreads();
+    v80_block_body<2, 1, 3, true, false, false>(XT, H, nullptr, nullptr, nullptr, Wv, B, nullptr, Nv, nullptr, nullptr, v_out, P);
 }
 
 // boards int8 [B][C][7] (reference layout) -> x f32 [B][7][C] (channels-last)

@@ -165,7 +165,7 @@ class SplendorV80Hip(SplendorV80):
         self.Q = self.trunk.W1.shape[1]
         self.weight_stationary = True
         self.fused_blocks = True
-        self.fused_net = True          # whole forward in 3 launches (azg_nn_v80_forward)
+        self.fused_net = True          # whole forward in one launch (azg_nn_v80_forward)
         self._bias_pad = {}
         self._prepare()
         self._alloc(max_batch)

@@ -205,9 +205,10 @@ int azg_nn_dw_pool(float* H_dev, int ldh, const float* Wd_dev /*[7][7] out,in*/,
 int azg_nn_v80_block(const float* xin_dev, float* xout_dev, const float* const* w, int B, int act, int pool_max,
                      void* stream);
 /* The whole V80 forward (NeuralNet.predict for a leaf batch, SplendorNNet.py:397-440 / GenericNNetWrapper.py:94-110) in
-   three launches: boards int8[B][56][7] -> first_layer + trunk block -> x_trunk (workspace f32 [B*7][56]); policy head
-   block + Flatten + Linear + ReLU + Linear + masked softmax -> pi f32[B][81]; value head block + Flatten + Linear +
-   ReLU + Linear + tanh -> v f32[B][P].  w = 43 device pointers: {W0[64][64], b0[64]}, 3 x the 11 block tensors of
+   ONE launch, one workgroup pass per 16 samples: boards int8[B][56][7] -> first_layer + trunk block (output kept in LDS,
+   two copies) -> policy head block + Flatten + Linear + ReLU + Linear + masked softmax -> pi f32[B][81]; value head block
+   + Flatten + Linear + ReLU + Linear + tanh -> v f32[B][P].  x_trunk (f32 [B*7][56]) is only written by the three-launch
+   variant (environment AZG_NN_THREE_LAUNCHES=1, kept for A/B measurements).  w = 43 device pointers: {W0[64][64], b0[64]}, 3 x the 11 block tensors of
    azg_nn_v80_block (trunk, policy head, value head), {Wpi1[432][96], bpi1[96], Wpi2[96][96], bpi2[96]},
    {Wv1[432][16], bv1[16], Wv2[P][P], bv2[P]}; the flatten index of Wpi1 / Wv1 rows is k = l*60 + c (c < 56), zero
    padded; every matrix except Wv2 is in the fragment order described at azg_nn_v80_block.  Fixed to the V80 activations (trunk ReLU + mean squeeze, heads Hardswish + max squeeze). */
