@@ -199,6 +199,10 @@ __global__ __launch_bounds__(64) void k_begin_search(ForestDev F, const int8_t* 
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
     const int t = blockIdx.x;
+    if (full && full[t] == 2) {                    // tree sits this search out (e.g. the other player's turn): keep its contents
+        if (lane_id() == 0) F.hdr[t].status = ST_IDLE;
+        return;
+    }
     TreeHdr H = load_uniform(&F.hdr[t]);
     FR::load_state_unpadded(sm.st, roots + (size_t)t * G::S);
     if (H.n_nodes) reclaim_if_short<G>(F, t, H, sm);

@@ -66,9 +66,11 @@ class HipGame:
         check(lib().azg_env_canonical(self.GAME_ID, self.variant, _ptr(boards), _ptr(players), n, _ptr(out), _stream()))
         return out
 
-    def init_boards_batch(self, n, stream0=0):
+    def init_boards_batch(self, n, stream0=0, counters=None):
+        """Board.init_game for n games on RNG streams stream0..stream0+n-1; `counters` (u64[n] tensor) receives the number
+        of uniforms each stream consumed, so next_state_batch(..., counters=counters) continues the same streams"""
         out = torch.empty((n, self.S), dtype=torch.int8, device=self.device)
-        check(lib().azg_env_init_boards(self.GAME_ID, self.variant, n, _ptr(out), self.rng_seed, stream0, None,
+        check(lib().azg_env_init_boards(self.GAME_ID, self.variant, n, _ptr(out), self.rng_seed, stream0, _ptr(counters),
                                         _stream()))
         return out
 

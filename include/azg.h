@@ -112,7 +112,8 @@ size_t azg_forest_device_bytes(const azg_forest* f);
 int azg_forest_reset(azg_forest* f, void* stream);
 
 /* --- host-driven mode: the pieces of MCTS.getActionProb (MCTS.py:49-103) --- */
-/* begin a search on every tree: canonical roots int8[T][S]; full_dev u8[T] (1 = full search) or NULL (all full).
+/* begin a search on every tree: canonical roots int8[T][S]; full_dev u8[T] (1 = full search, 0 = fast search, 2 = this
+   tree sits the search out and keeps its contents -- e.g. the opponent's turn in an Arena) or NULL (all full).
    The tree is reused if the root state is already a node (MCTS.py:125-126). */
 int azg_forest_begin_search(azg_forest* f, const int8_t* roots_dev, const uint8_t* full_dev, void* stream);
 /* one lock-step round, part 1: every tree runs simulations until it needs the net (one leaf per tree) or has finished
