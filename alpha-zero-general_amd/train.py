@@ -1,0 +1,119 @@
+"""Next-row f1: the trainer side of Coach.learn on PyTorch-ROCm autograd.
+
+`SplendorV80Module` is a trainable nn.Module with the reference's parameter names (splendor/SplendorNNet.py:148-202,
+262-283,397-440), so `state_dict()` round-trips with the reference's checkpoints and with the inference nets of
+azg_amd.nnet (which fold its BatchNorms).  `train()` is GenericNNetWrapper.train (:44-92): AdamW + OneCycleLR,
+loss = KLDiv(pi) + 0.25 * MSE((z + q_weight*q) / (1 + q_weight)) (:179-190), batches sampled without replacement inside a
+batch, `epochs * (len(examples) // batch_size)` steps."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _LinearNormAct(nn.Module):
+    """Linear over the channel axis (or over the token axis when depthwise) of x[B, C, L] + BatchNorm1d(C) + activation"""
+
+    def __init__(self, n_in, n_out, act, depthwise=False, channels=None):
+        super().__init__()
+        self.linear = nn.Linear(n_in, n_out, bias=False)
+        self.norm = nn.BatchNorm1d(channels if depthwise else n_out)
+        self.activation = act() if act is not None else nn.Identity()
+        self.depthwise = depthwise
+
+    def forward(self, x):
+        y = self.linear(x) if self.depthwise else self.linear(x.transpose(1, 2)).transpose(1, 2)
+        return self.activation(self.norm(y))
+
+
+class _SE(nn.Module):
+    def __init__(self, channels, squeeze, setype):
+        super().__init__()
+        self.setype = setype
+        self.fc1, self.fc2 = nn.Linear(channels, squeeze), nn.Linear(squeeze, channels)
+
+    def forward(self, x):
+        s = x.mean(dim=2) if self.setype == 'avg' else x.amax(dim=2)
+        s = F.hardsigmoid(self.fc2(F.relu(self.fc1(s))))
+        return x * s[:, :, None]
+
+
+class _Block(nn.Module):
+    def __init__(self, c, e, use_hs, setype, tokens=7):
+        super().__init__()
+        act = nn.Hardswish if use_hs else nn.ReLU
+        self.expand = _LinearNormAct(c, e, act)
+        self.depthwise = _LinearNormAct(tokens, tokens, act, depthwise=True, channels=e)
+        self.se = _SE(e, max(8, (e // 4 + 4) // 8 * 8), setype)          # _make_divisible(e // 4, 8)
+        self.project = _LinearNormAct(e, c, None)
+
+    def forward(self, x):
+        return self.project(self.se(self.depthwise(self.expand(x)))) + x
+
+
+class SplendorV80Module(nn.Module):
+    version = 80
+
+    def __init__(self, num_players=2, action_size=81, dropout=0.0):
+        super().__init__()
+        self.C = 32 + 10 * num_players + num_players * num_players
+        self.P, self.A, self.dropout = num_players, action_size, dropout
+        C = self.C
+        self.first_layer = _LinearNormAct(C, C, None)
+        self.trunk = nn.Sequential(_Block(C, 3 * C, False, 'avg'))
+        self.output_layers_PI = nn.Sequential(_Block(C, 3 * C, True, 'max'), nn.Flatten(1), nn.Linear(7 * C, action_size), nn.ReLU(),
+                                              nn.Linear(action_size, action_size))
+        self.output_layers_V = nn.Sequential(_Block(C, 3 * C, True, 'max'), nn.Flatten(1), nn.Linear(7 * C, num_players), nn.ReLU(),
+                                             nn.Linear(num_players, num_players))
+        self.register_buffer('lowvalue', torch.FloatTensor([-1e8]))
+
+    def forward(self, boards, valid_actions):
+        """-> (log pi [B, A], v [B, P]) like the reference module"""
+        x = boards.reshape(-1, self.C, 7).float()
+        x = self.first_layer(x)
+        x = F.dropout(self.trunk(x), p=self.dropout, training=self.training)
+        v = self.output_layers_V(x)
+        pi = torch.where(valid_actions.bool(), self.output_layers_PI(x), self.lowvalue)
+        return F.log_softmax(pi, dim=1), torch.tanh(v)
+
+
+def loss_pi(target_pi, out_log_pi):                                            # GenericNNetWrapper.py:179-181
+    return F.kl_div(out_log_pi, target_pi, reduction='batchmean')
+
+
+def loss_v(target_z, target_q, out_v, q_weight):                               # :189-191
+    t = (target_z + q_weight * target_q) / (1.0 + q_weight)
+    return torch.sum((t - out_v) ** 2) / (target_z.shape[0] * target_z.shape[-1])
+
+
+def train(module, examples, learn_rate=3e-3, batch_size=512, epochs=2, q_weight=0.5, device='cuda:0', seed=None, log=None):
+    """examples = (boards int8[n,S], pi f32[n,A], z f32[n,P], valids u8/bool[n,A], q f32[n,P]) tensors or arrays.
+    Returns the list of (pi loss, v loss) per step."""
+    boards, pi, z, valids, q = [torch.as_tensor(np.asarray(x.cpu()) if hasattr(x, 'cpu') else x).to(device) for x in examples[:5]]
+    n = boards.shape[0]
+    steps_per_epoch = n // batch_size
+    if steps_per_epoch == 0:
+        raise ValueError('fewer examples (%d) than batch_size (%d)' % (n, batch_size))
+    module.to(device).train()
+    opt = torch.optim.AdamW(module.parameters(), lr=learn_rate)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=learn_rate, steps_per_epoch=steps_per_epoch, epochs=epochs)
+    gen = torch.Generator(device='cpu')
+    if seed is not None:
+        gen.manual_seed(seed)
+    hist = []
+    for ep in range(epochs):
+        for _ in range(steps_per_epoch):
+            ids = torch.randperm(n, generator=gen)[:batch_size].to(device)   # np.random.choice(n, batch, replace=False) :57
+            opt.zero_grad(set_to_none=True)
+            out_pi, out_v = module(boards[ids], valids[ids])
+            l_pi = loss_pi(pi[ids].float(), out_pi)
+            l_v = loss_v(z[ids].float(), q[ids].float(), out_v, q_weight)
+            (l_pi + 0.25 * l_v).backward()
+            opt.step()
+            sched.step()
+            hist.append((l_pi.item(), l_v.item()))
+        if log:
+            log('epoch %d: pi loss %.4f  v loss %.4f' % (ep + 1, np.mean([h[0] for h in hist[-steps_per_epoch:]]),
+                                                         np.mean([h[1] for h in hist[-steps_per_epoch:]])))
+    module.eval()
+    return hist

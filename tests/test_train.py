@@ -1,0 +1,50 @@
+"""CPU: the trainable V80 module carries the reference's parameter names and reproduces the reference model's outputs
+(tests/golden/netfwd_splendor2_v80.npz was produced by the reference's own module); the trainer lowers its loss."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _load():
+    from azg_amd.train import SplendorV80Module
+    z = np.load(os.path.join(GOLDEN, 'weights_splendor2_v80.npz'))
+    sd = {k[3:]: torch.as_tensor(z[k]) for k in z.files if k.startswith('sd/')}
+    m = SplendorV80Module(num_players=2)
+    m.load_state_dict(sd, strict=True)          # same keys as the reference checkpoint, nothing missing / unexpected
+    return m.eval(), sd
+
+
+def test_module_matches_reference_outputs_and_names():
+    m, sd = _load()
+    d = np.load(os.path.join(GOLDEN, 'netfwd_splendor2_v80.npz'))
+    with torch.no_grad():
+        lp, v = m(torch.from_numpy(d['boards']), torch.from_numpy(d['masks'].astype(bool)))
+    assert np.allclose(torch.exp(lp).numpy(), d['pi'], atol=1e-5, rtol=0)
+    assert np.allclose(v.numpy(), d['v'], atol=1e-5, rtol=0)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+
+
+def test_losses_and_training_step():
+    from azg_amd import train as T
+    m, _ = _load()
+    d = np.load(os.path.join(GOLDEN, 'netfwd_splendor2_v80.npz'))
+    n = len(d['boards'])
+    rng = np.random.default_rng(0)
+    z = np.where(rng.random((n, 1)) < 0.5, 1.0, -1.0).astype(np.float32) * np.array([[1.0, -1.0]], dtype=np.float32)
+    q = (0.5 * z).astype(np.float32)
+    ex = (d['boards'].reshape(n, -1), d['pi'], z, d['masks'], q)
+    # loss formulas, GenericNNetWrapper.py:179-191
+    lp = torch.log(torch.tensor([[0.5, 0.5], [0.9, 0.1]]))
+    t = torch.tensor([[1.0, 0.0], [0.5, 0.5]])
+    kl = float(T.loss_pi(t, lp))
+    ref = float((t * (torch.log(t.clamp_min(1e-30)) - lp)).sum() / 2)
+    assert abs(kl - ref) < 1e-6
+    lv = float(T.loss_v(torch.tensor([[1.0, -1.0]]), torch.tensor([[0.0, 0.0]]), torch.tensor([[0.0, 0.0]]), 1.0))
+    assert abs(lv - (0.25 + 0.25) / 2) < 1e-7
+    hist = T.train(m, ex, learn_rate=3e-3, batch_size=64, epochs=6, q_weight=0.5, device='cpu', seed=1)
+    first, last = np.mean([h[1] for h in hist[:4]]), np.mean([h[1] for h in hist[-4:]])
+    assert last < first                                   # the value head fits the synthetic targets
+    assert not m.training
