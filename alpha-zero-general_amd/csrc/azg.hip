@@ -174,7 +174,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     D.U = cfg->universes > 0 ? cfg->universes : 1;
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
-                            : (size_t)D.cap * RecLayout(f->A <= 200 ? (f->A < 64 ? f->A : 64) : 128, D.U).total + 8192;
+                            : (size_t)D.cap * RecLayout(f->A <= 200 ? (f->A < 64 ? f->A : 64) : 128, D.U).total * 5 / 4 + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     D.heap_units = (uint32_t)(heap_bytes / 16);
     auto skew = [](size_t bytes) { size_t r = (bytes + 255) / 256 * 256; return ((r >> 8) & 1) ? r : r + 256; };
@@ -182,6 +182,8 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     D.s_nstate = skew((size_t)D.cap * f->SP);
     D.s_nhdr = skew((size_t)D.cap * sizeof(NodeHdr)) / sizeof(NodeHdr);
     D.s_htab = skew((size_t)D.HT * 4) / 4;
+    D.s_free = skew((size_t)D.cap * 4) / 4;
+    D.s_recfree = skew((size_t)(f->A + 1) * 4) / 4;
     D.universes = cfg->universes;
     D.numMCTSSims = cfg->numMCTSSims;
     D.ratio_fullMCTS = cfg->ratio_fullMCTS > 0 ? cfg->ratio_fullMCTS : 1;
@@ -202,6 +204,8 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     rc |= dalloc(f, &D.node_state, T * D.s_nstate);
     rc |= dalloc(f, &D.heap, T * D.s_heap);
     rc |= dalloc(f, &D.htab, T * D.s_htab);
+    rc |= dalloc(f, &D.free_ids, T * D.s_free);
+    rc |= dalloc(f, &D.rec_free, T * D.s_recfree);
     rc |= dalloc(f, &D.path, T * AZG_MAXD);
     rc |= dalloc(f, &D.root_state, T * f->SP);
     rc |= dalloc(f, &D.board, T * f->SP);
@@ -336,21 +340,23 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
     const ForestDev& D = f->dev;
     TreeHdr H;
     HIPCHK(hipMemcpy(&H, D.hdr + tree, sizeof(H), hipMemcpyDeviceToHost));
-    const int n = (int)H.n_nodes;
+    const int n = (int)H.n_nodes, top = (int)H.id_top;
     if (n > max_nodes) return n;
-    std::vector<NodeHdr> nh(n);
-    std::vector<int8_t> st((size_t)n * f->SP);
-    const size_t heap_bytes = (size_t)D.heap_units * 16;
+    std::vector<NodeHdr> nh(top);
+    std::vector<int8_t> st((size_t)top * f->SP);
     std::vector<uint8_t> hp((size_t)H.heap_top * 16);
-    if (n) {
-        HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)tree * D.s_nhdr, sizeof(NodeHdr) * n, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(st.data(), D.node_state + (size_t)tree * D.s_nstate, (size_t)n * f->SP, hipMemcpyDeviceToHost));
+    if (top) {
+        HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)tree * D.s_nhdr, sizeof(NodeHdr) * top, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(st.data(), D.node_state + (size_t)tree * D.s_nstate, (size_t)top * f->SP, hipMemcpyDeviceToHost));
     }
     if (!hp.empty()) HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)tree * D.s_heap, hp.size(), hipMemcpyDeviceToHost));
     const int A = f->A, P = f->P, S = f->S;
-    for (int i = 0; i < n; i++) {
-        memcpy(states + (size_t)i * S, st.data() + (size_t)i * f->SP, S);
-        const uint8_t* rec = hp.data() + (size_t)nh[i].rec_off * 16;
+    int i = 0;
+    for (int id = 0; id < top; id++) {                    // live nodes in id order (ids of dropped nodes are skipped)
+        if (nh[id].flags & NF_FREE) continue;
+        if (i >= n) return fail("dump_tree: more live headers than n_nodes");
+        memcpy(states + (size_t)i * S, st.data() + (size_t)id * f->SP, S);
+        const uint8_t* rec = hp.data() + (size_t)nh[id].rec_off * 16;
         const RecHdr* rh = (const RecHdr*)rec;
         Ns[i] = (int32_t)rh->Ns;
         Qs[i] = rh->Qs;
@@ -368,6 +374,7 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
                 Ps[(size_t)i * A + a] = *(const float*)(ent + AZG_E_P);
             }
         }
+        i++;
     }
     return n;
 }
@@ -386,23 +393,23 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
     for (int t = 0; t < D.T; t++) {
         TreeHdr H;
         HIPCHK(hipMemcpy(&H, D.hdr + t, sizeof(H), hipMemcpyDeviceToHost));
-        const uint32_t n = H.n_nodes;
-        if (n > (uint32_t)D.cap || H.heap_top > D.heap_units) { VBAD("[validate] t=%d n=%u heap_top=%u\n", t, n, H.heap_top); continue; }
-        if (H.root != AZG_NONE && H.root >= n) VBAD("[validate] t=%d root=%u n=%u\n", t, H.root, n);
-        HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)t * D.s_nhdr, sizeof(NodeHdr) * n, hipMemcpyDeviceToHost));
+        const uint32_t n = H.n_nodes, top = H.id_top;
+        if (top > (uint32_t)D.cap || n > top || H.heap_top > D.heap_units) { VBAD("[validate] t=%d n=%u id_top=%u heap_top=%u\n", t, n, top, H.heap_top); continue; }
+        if (H.root != AZG_NONE && H.root >= top) VBAD("[validate] t=%d root=%u id_top=%u\n", t, H.root, top);
+        HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)t * D.s_nhdr, sizeof(NodeHdr) * top, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)t * D.s_heap, (size_t)H.heap_top * 16, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(tab.data(), D.htab + (size_t)t * D.s_htab, sizeof(uint32_t) * D.HT, hipMemcpyDeviceToHost));
-        if (H.root != AZG_NONE && H.root < n && nh[H.root].rec_off != H.root_rec)
+        if (H.root != AZG_NONE && H.root < top && nh[H.root].rec_off != H.root_rec)
             VBAD("[validate] t=%d root_rec=%u but node %u has rec_off=%u\n", t, H.root_rec, H.root, nh[H.root].rec_off);
-        uint32_t expect_off = 0;
-        for (uint32_t i = 0; i < n; i++) {
+        uint32_t live = 0, n_free = 0;
+        for (uint32_t i = 0; i < top; i++) {
+            if (nh[i].flags & NF_FREE) { n_free++; continue; }
+            live++;
             RecLayout L(nh[i].nv, D.U);
-            if (nh[i].rec_off != expect_off) VBAD("[validate] t=%d node=%u rec_off=%u expect=%u nv=%u flags=%u\n", t, i, nh[i].rec_off, expect_off, nh[i].nv, nh[i].flags);
-            expect_off = nh[i].rec_off + L.total / 16u;
-            if (expect_off > H.heap_top) { VBAD("[validate] t=%d node=%u record end %u > heap_top %u (n=%u gc=%u)\n", t, i, expect_off, H.heap_top, n, H.gc_runs); break; }
+            if (nh[i].rec_off + L.total / 16u > H.heap_top) { VBAD("[validate] t=%d node=%u record beyond heap_top %u (gc=%u)\n", t, i, H.heap_top, H.gc_runs); continue; }
             const uint8_t* rec = hp.data() + (size_t)nh[i].rec_off * 16;
             const RecHdr* rh = (const RecHdr*)rec;
-            if (rh->node_id != i || rh->nv != nh[i].nv || rh->round != nh[i].round)
+            if (rh->node_id != i || rh->nv > nh[i].nv || rh->round != nh[i].round)
                 VBAD("[validate] t=%d node=%u header mismatch (rec node_id=%u nv=%u)\n", t, i, rh->node_id, rh->nv);
             if (!(rh->flags & NF_EXPANDED)) continue;
             const RecIds ids(rec, f->dev.U);
@@ -414,17 +421,20 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
                     const uint32_t cr = c & AZG_CHILD_IDX_MASK;
                     if (cr >= H.heap_top) { VBAD("[validate] t=%d node=%u child[%d][%d]=%08x beyond heap\n", t, i, j, u, c); continue; }
                     const RecHdr* ch = (const RecHdr*)(hp.data() + (size_t)cr * 16);
-                    if (ch->node_id >= n || nh[ch->node_id].rec_off != cr) VBAD("[validate] t=%d node=%u child[%d][%d] -> bad record %u\n", t, i, j, u, cr);
+                    if (ch->node_id >= top || (nh[ch->node_id].flags & NF_FREE) || nh[ch->node_id].rec_off != cr)
+                        VBAD("[validate] t=%d node=%u child[%d][%d] -> bad / dropped record %u\n", t, i, j, u, cr);
                 }
                 if (ids[j] >= f->A || (j && ids[j] <= ids[j - 1])) { VBAD("[validate] t=%d node=%u ids[%d]=%u\n", t, i, j, ids[j]); break; }
             }
         }
+        if (live != n) VBAD("[validate] t=%d live headers %u != n_nodes %u\n", t, live, n);
+        if (n_free != H.n_free_ids) VBAD("[validate] t=%d free headers %u != n_free_ids %u\n", t, n_free, H.n_free_ids);
         uint32_t cnt = 0;
         for (int k = 0; k < D.HT; k++)
             if (tab[k] != AZG_NONE) {
                 cnt++;
                 const uint32_t id = tab[k] & AZG_IDX_MASK;
-                if (id >= n) VBAD("[validate] t=%d htab[%d]=%08x n=%u\n", t, k, tab[k], n);
+                if (id >= top || (nh[id].flags & NF_FREE)) VBAD("[validate] t=%d htab[%d]=%08x -> free / out of range id\n", t, k, tab[k]);
                 else if ((uint32_t)(nh[id].hash >> 54) != (tab[k] >> AZG_IDX_BITS)) VBAD("[validate] t=%d htab tag mismatch id=%u\n", t, id);
             }
         if (cnt != n) VBAD("[validate] t=%d htab entries %u != n %u\n", t, cnt, n);

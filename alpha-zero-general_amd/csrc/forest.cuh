@@ -31,7 +31,7 @@
 namespace azg {
 
 enum : uint32_t { ST_IDLE = 0, ST_SEARCHING = 1, ST_WAIT_NN = 2, ST_DONE = 3 };
-enum : uint8_t { NF_TERMINAL = 1, NF_EXPANDED = 2 };
+enum : uint8_t { NF_TERMINAL = 1, NF_EXPANDED = 2, NF_FREE = 4 };   // NF_FREE: node id on the free stack (NodeHdr only)
 enum : uint32_t {
     ERR_NODE_OVERFLOW = 1, ERR_HEAP_OVERFLOW = 2, ERR_DEPTH_OVERFLOW = 4, ERR_BAD_STATE = 8, ERR_EXAMPLE_OVERFLOW = 16,
     ERR_REC_OVERFLOW = 32
@@ -54,7 +54,7 @@ enum : uint32_t {
 struct __attribute__((aligned(16))) NodeHdr {          // cold per-node data
     uint64_t hash;
     uint32_t rec_off;      // 16-byte units into the tree's record heap
-    uint16_t nv;
+    uint16_t nv;           // size class of the record (n_valid it was allocated for, >= the node's n_valid in RecHdr)
     uint8_t round;
     uint8_t flags;
 };
@@ -73,7 +73,8 @@ struct __attribute__((aligned(16))) RecHdr {           // first 32 bytes of ever
 };
 
 struct __attribute__((aligned(16))) TreeHdr {
-    uint32_t n_nodes, heap_top, root, status;          // root = node id of the search root (AZG_NONE: not a node yet)
+    uint32_t n_nodes, heap_top, root, status;          // n_nodes = LIVE nodes; heap_top = bump pointer of the record heap;
+                                                       // root = node id of the search root (AZG_NONE: not a node yet)
     uint32_t sim_idx, n_sims, is_full, forced;
     uint32_t pending_leaf, path_len, ply, cur_player;
     uint64_t rng_counter;
@@ -81,6 +82,8 @@ struct __attribute__((aligned(16))) TreeHdr {
     uint32_t leaf_is_root, games_done, step, n_rec;
     uint32_t mid_sim, cur_rec, cur_depth, cur_pre;     // a descent paused by the per-launch level budget
     uint32_t pending_nv, pending_node, pad0_, pad1_;   // n_valid and node id of pending_leaf (saves k_expand_backup a round trip)
+    uint32_t id_top, n_free_ids, free_units, pad2_;    // node ids ever handed out; size of the free-id stack; 16-B units on the
+                                                       // record free lists
     uint32_t max_nodes_seen, gc_runs, root_rec, noise_pending;   // root_rec = record offset of the root;
                                                                  // noise_pending: root Dirichlet noise still to apply
     uint64_t c_sims, c_levels, c_exp, c_sumvalid, c_term, c_depth, c_plies, c_examples;
@@ -101,6 +104,7 @@ struct ForestDev {
     // record, node 0, ...) walks over all HBM channels instead of hitting one (power-of-two strides were ~8 % slower)
     size_t s_heap, s_nstate;           // bytes
     size_t s_nhdr, s_htab;             // elements (NodeHdr, u32)
+    size_t s_free, s_recfree;          // elements (u32): free-id stack [cap], record free-list heads [A + 1]
     int universes, numMCTSSims, ratio_fullMCTS, forced_playouts;
     int level_budget;                  // max descent levels per tree per k_select launch (0 = unlimited)
     int work_budget;                   // max work units (level = 1, edge resolution = AZG_EDGE_UNITS) per tree per launch
@@ -112,6 +116,9 @@ struct ForestDev {
     int8_t* node_state;
     uint8_t* heap;
     uint32_t* htab;
+    uint32_t* free_ids;                // [T][cap] stack of reusable node ids
+    uint32_t* rec_free;                // [T][A + 1] head of the free list of records with n_valid == index (AZG_NONE = empty);
+                                       // a free record's first dword links to the next one
     PathEnt* path;
     int8_t* root_state;
     int8_t* board;
@@ -259,6 +266,7 @@ struct Forest {
         return F.heap + (size_t)t * F.s_heap;
     }
     __device__ static __forceinline__ uint32_t* htab(const ForestDev& F, int t) { return F.htab + (size_t)t * F.s_htab; }
+    __device__ static __forceinline__ uint32_t* rec_free(const ForestDev& F, int t) { return F.rec_free + (size_t)t * F.s_recfree; }
     __device__ static __forceinline__ uint8_t* rec_ptr(const ForestDev& F, int t, uint32_t rec_off) {
         return heap(F, t) + (size_t)rec_off * 16u;
     }
@@ -326,14 +334,50 @@ struct Forest {
     template <class HS>
     __device__ static uint32_t create_node(const ForestDev& F, int t, HS& H, const int8_t* st_lds, uint64_t h,
                                            uint32_t free_slot) {
-        if (H.n_nodes >= (uint32_t)F.cap || free_slot == AZG_NONE) { H.err |= ERR_NODE_OVERFLOW; return AZG_NONE; }
-        uint32_t id = H.n_nodes++;
+        if (free_slot == AZG_NONE) { H.err |= ERR_NODE_OVERFLOW; return AZG_NONE; }
+        uint32_t id;
+        if (H.n_free_ids > 0) {                                      // reuse the id of a node the clean-up dropped
+            H.n_free_ids--;
+            id = uni_u32((F.free_ids + (size_t)t * F.s_free)[H.n_free_ids]);
+        } else {
+            if (H.id_top >= (uint32_t)F.cap) { H.err |= ERR_NODE_OVERFLOW; return AZG_NONE; }
+            id = H.id_top++;
+        }
+        H.n_nodes++;
         store_state(nstate(F, t, id), st_lds);
         if (lane_id() == 0) {
             nhdr(F, t, id)->hash = h;
             htab(F, t)[free_slot] = (tag_of(h) << AZG_IDX_BITS) | id;
         }
         return id;
+    }
+
+    // Record for a node with nv valid actions.  Records never move; a dropped node's record sits on the free list of its
+    // size class (= the n_valid it was allocated for).  The wave reads the heads of classes nv .. nv+63 in one request and
+    // takes the first non-empty one (closest fit; *alloc_nv = its class, kept in NodeHdr.nv so that the record returns to
+    // the right list), else the bump pointer.  AZG_NONE on overflow.
+    template <class HS>
+    __device__ static __forceinline__ uint32_t alloc_record(const ForestDev& F, int t, HS& H, int nv, int* alloc_nv) {
+        uint32_t* heads = rec_free(F, t);
+        const int idx = nv + lane_id();
+        const uint32_t v = idx <= A ? heads[idx] : AZG_NONE;
+        const uint64_t m = __ballot(v != AZG_NONE);
+        if (m) {
+            const int src = first_lane(m);
+            const uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+            const uint32_t next = uni_u32(*(const uint32_t*)(heap(F, t) + (size_t)head * 16u));
+            if (lane_id() == 0) heads[nv + src] = next;
+            H.free_units -= RecLayout(nv + src, F.U).total / 16u;
+            *alloc_nv = nv + src;
+            return head;
+        }
+        const uint32_t units = RecLayout(nv, F.U).total / 16u;
+        // 256 units (4 KB) of slack: a level's speculative entry loads may reach 64 entries past a short record
+        if (H.heap_top + units + 256u > F.heap_units) { H.err |= ERR_HEAP_OVERFLOW; return AZG_NONE; }
+        const uint32_t off = H.heap_top;
+        H.heap_top += units;
+        *alloc_nv = nv;
+        return off;
     }
 
     // Lane-parallel value backup along the recorded path (MCTS.py:176-183 unwound): level d belongs to lane d.

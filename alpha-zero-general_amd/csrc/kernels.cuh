@@ -123,9 +123,11 @@ __global__ __launch_bounds__(64) void k_forest_reset(ForestDev F) {
     int t = blockIdx.x;
     uint32_t* tab = Forest<G>::htab(F, t);
     for (int i = lane_id(); i < F.HT; i += 64) tab[i] = AZG_NONE;
+    for (int i = lane_id(); i <= G::A; i += 64) Forest<G>::rec_free(F, t)[i] = AZG_NONE;
     if (lane_id() == 0) {
         TreeHdr* H = &F.hdr[t];
         H->n_nodes = 0; H->heap_top = 0; H->root = AZG_NONE; H->root_rec = AZG_NONE; H->status = ST_IDLE;
+        H->id_top = 0; H->n_free_ids = 0; H->free_units = 0;
         H->sim_idx = 0; H->n_sims = 0; H->pending_leaf = AZG_NONE; H->path_len = 0; H->mid_sim = 0;
     }
 }
@@ -238,10 +240,9 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
 #endif
     H.leaf_nv = (uint32_t)nv; H.leaf_node = id;
     const RecLayout L(nv, F.U);
-    // 256 units (4 KB) of slack: a level's speculative entry loads may reach 64 entries past a short record
-    if (H.heap_top + L.total / 16u + 256u > F.heap_units) { H.err |= ERR_HEAP_OVERFLOW; return AZG_NONE; }
-    const uint32_t rec_off = H.heap_top;
-    H.heap_top += L.total / 16u;
+    int alloc_nv = nv;
+    const uint32_t rec_off = FR::alloc_record(F, t, H, nv, &alloc_nv);
+    if (rec_off == AZG_NONE) return AZG_NONE;
     uint8_t* rec = FR::rec_ptr(F, t, rec_off);
     const uint8_t round = (uint8_t)G::get_round(sm.st);
     if (l == 0) {
@@ -252,7 +253,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
         if (!ended) { rh.sq[0] = 0.0; rh.sq[1] = sqrt(0.0 + AZG_EPS); }
         *(RecHdr*)rec = rh;
         NodeHdr* nh = FR::nhdr(F, t, id);
-        nh->rec_off = rec_off; nh->nv = (uint16_t)nv; nh->round = round; nh->flags = rh.flags;
+        nh->rec_off = rec_off; nh->nv = (uint16_t)alloc_nv; nh->round = round; nh->flags = rh.flags;
     }
     *terminal = ended;
     if (!ended) {
@@ -320,7 +321,7 @@ __device__ __forceinline__ void stat_add(uint64_t* p, uint64_t v) {
 // The fields of TreeHdr that k_select keeps live (wave-uniform => SGPRs).  Loading the whole 200-byte header into
 // registers made the kernel spill to scratch; the cold fields are read-modify-written by lane 0 at the end instead.
 struct SelState {
-    uint32_t n_nodes, heap_top, root, root_rec, sim_idx, n_sims, is_full, forced, err, leaf_is_root, mid_sim, cur_rec,
+    uint32_t n_nodes, heap_top, id_top, n_free_ids, free_units, root, root_rec, sim_idx, n_sims, is_full, forced, err, leaf_is_root, mid_sim, cur_rec,
         cur_depth, cur_pre, status, pending_leaf, path_len, leaf_nv, leaf_node, cyc_leaf, cyc_seg[4];
 };
 
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
     // every hot header field is requested in one go (status included): one memory round trip before the first level
     SelState H;
     const uint32_t status0 = Hp->status, pending0 = Hp->noise_pending;
+    H.id_top = Hp->id_top; H.n_free_ids = Hp->n_free_ids; H.free_units = Hp->free_units;
     H.n_nodes = Hp->n_nodes; H.heap_top = Hp->heap_top; H.root = Hp->root; H.root_rec = Hp->root_rec; H.sim_idx = Hp->sim_idx;
     H.n_sims = Hp->n_sims; H.is_full = Hp->is_full; H.forced = Hp->forced; H.err = Hp->err; H.leaf_is_root = Hp->leaf_is_root;
     H.mid_sim = Hp->mid_sim; H.cur_rec = Hp->cur_rec; H.cur_depth = Hp->cur_depth; H.cur_pre = Hp->cur_pre;
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
         if (l == 0) needs_eval[t] = 0;
         return;
     }
+    H.id_top = uni_u32(H.id_top); H.n_free_ids = uni_u32(H.n_free_ids); H.free_units = uni_u32(H.free_units);
     H.n_nodes = uni_u32(H.n_nodes); H.heap_top = uni_u32(H.heap_top); H.root = uni_u32(H.root);
     H.root_rec = uni_u32(H.root_rec); H.sim_idx = uni_u32(H.sim_idx); H.n_sims = uni_u32(H.n_sims);
     H.is_full = uni_u32(H.is_full); H.forced = uni_u32(H.forced); H.err = uni_u32(H.err);
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
     }
     if (l == 0) {
         Hp->n_nodes = H.n_nodes; Hp->heap_top = H.heap_top; Hp->root = H.root; Hp->root_rec = H.root_rec;
+        Hp->id_top = H.id_top; Hp->n_free_ids = H.n_free_ids; Hp->free_units = H.free_units;
         Hp->sim_idx = H.sim_idx; Hp->err = H.err; Hp->leaf_is_root = H.leaf_is_root; Hp->mid_sim = H.mid_sim;
         Hp->cur_rec = H.cur_rec; Hp->cur_depth = H.cur_depth; Hp->cur_pre = H.cur_pre; Hp->status = H.status;
         Hp->pending_leaf = H.pending_leaf; Hp->path_len = H.path_len; Hp->pending_nv = H.leaf_nv; Hp->pending_node = H.leaf_node;

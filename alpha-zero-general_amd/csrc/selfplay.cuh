@@ -17,118 +17,61 @@ __device__ __forceinline__ double temp_for_selfplay(const ForestDev& F, int n) {
 
 // Drop every node that can no longer be reached: round < root_round (the move counter is part of the state, so such
 // states cannot recur).  Equivalent to -- and stricter in memory than -- the reference's lazy clean-up MCTS.py:86-91,
-// which removes nodes with round < r-5 every >20 rounds.  In-place sliding compaction by the tree's own wave:
-//   pass 1  per node: keep?, new node id, new record offset (wave prefix sums); both maps live in the hash-table memory
-//   pass 2  rewrite the child slots of every kept record (old record offset -> child's node id -> new record offset)
-//   pass 3  slide records / states / cold headers down (dst <= src, forward copies), fix RecHdr.node_id
-//   pass 4  clear + re-insert the hash table
-// Every control value is made explicitly wave-uniform (readfirstlane) so the barriers sit in uniform control flow.
+// which removes nodes with round < r-5 every >20 rounds.
+// Records and node ids NEVER MOVE, so no child slot has to be rewritten: a live node (round >= r) can only point to nodes
+// with a round >= its own, i.e. to live ones.  One lane-parallel scan over the node headers
+//   * links every dead node's record into the free list of its size (n_valid) -- list heads are staged in LDS, so the 64
+//     lanes push concurrently with LDS atomics and write one 4-byte link per record --,
+//   * pushes its id on the free-id stack (ballot + rank), marks the header NF_FREE,
+//   * re-inserts every live node into the freshly cleared hash table (atomicCAS, linear probing).
+// ~n/64 pipelined header loads instead of the node-by-node compaction this replaces (which cost 5-20 ms per tree and
+// throttled sustained self-play to a tenth of its fresh-start rate).
 template <class G>
-__device__ __noinline__ void gc_tree(const ForestDev& F, int t, TreeHdr& H, int min_round) {
+__device__ __noinline__ void gc_tree(const ForestDev& F, int t, TreeHdr& H, int min_round, uint32_t* lds_head /*[A + 1]*/) {
     using FR = Forest<G>;
     const int l = lane_id();
-    uint32_t* map_id = FR::htab(F, t);               // [cap]   (HT >= 2*cap)
-    uint32_t* map_rec = map_id + F.cap;              // [cap]
     uint8_t* hp = FR::heap(F, t);
-    const uint32_t n = H.n_nodes;
-    const uint32_t ES = entry_stride(F.U);
-    // pass 1
-    uint32_t kept = 0, top = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t i = base + l;
-        bool keep = false;
-        uint32_t units = 0;
-        if (i < n) {
-            const NodeHdr* nh = FR::nhdr(F, t, i);
-            keep = (int)nh->round >= min_round || i == H.root;
-            units = RecLayout(nh->nv, F.U).total / 16u;
-        }
-        const uint64_t b = __ballot(keep);
-        const uint32_t rank = (uint32_t)__popcll(b & ((1ull << l) - 1ull));
-        uint32_t incl = keep ? units : 0u;           // inclusive prefix sum of kept record sizes
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (l >= d) incl += o;
-        }
-        if (i < n) {
-            map_id[i] = keep ? kept + rank : AZG_NONE;
-            map_rec[i] = keep ? top + incl - units : AZG_NONE;
-        }
-        kept += (uint32_t)__popcll(b);
-        top += uni_u32(__shfl(incl, 63, 64));
-    }
-    wave_sync();
-    // pass 2: child slots (records are still at their old places, so a child's node id can be read from its header)
-    for (uint32_t i = 0; i < n; i++) {
-        if (uni_u32(map_id[i]) == AZG_NONE) continue;
-        const NodeHdr nh = *FR::nhdr(F, t, i);
-        const uint32_t nv = uni_u32((uint32_t)nh.nv);
-        if (!(uni_u32((uint32_t)nh.flags) & NF_EXPANDED)) continue;
-        uint8_t* rec = hp + (size_t)uni_u32(nh.rec_off) * 16u;
-        const uint32_t slots = nv * (uint32_t)F.U;
-        for (uint32_t k = l; k < slots; k += 64) {
-            uint32_t* sp = (uint32_t*)(rec + AZG_REC_HDR + (size_t)(k / (uint32_t)F.U) * ES + AZG_E_C + 4u * (k % (uint32_t)F.U));
-            const uint32_t c = *sp;
-            if (c != AZG_NONE) {
-                const uint32_t cid = ((const RecHdr*)(hp + (size_t)(c & AZG_CHILD_IDX_MASK) * 16u))->node_id;
-                const uint32_t nr = cid < n ? map_rec[cid] : AZG_NONE;
-                *sp = nr == AZG_NONE ? AZG_NONE : ((c & ~AZG_CHILD_IDX_MASK) | nr);
-            }
-        }
-    }
-    wave_sync();
-    // pass 3: slide (ascending node order == ascending record order)
-    uint32_t new_root = AZG_NONE, new_root_rec = AZG_NONE;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t ni = uni_u32(map_id[i]);
-        if (ni != AZG_NONE) {
-            NodeHdr nh = *FR::nhdr(F, t, i);
-            const uint32_t old_off = uni_u32(nh.rec_off);
-            const uint32_t new_off = uni_u32(map_rec[i]);
-            const uint32_t units = RecLayout((int)uni_u32((uint32_t)nh.nv), F.U).total / 16u;
-            if (new_off != old_off) {
-                const uint4* src = (const uint4*)(hp + (size_t)old_off * 16u);
-                uint4* dst = (uint4*)(hp + (size_t)new_off * 16u);
-                for (uint32_t base = 0; base < units; base += 64) {
-                    const uint32_t k = base + (uint32_t)l;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (k < units) v = src[k];
-                    wave_sync();                       // every lane has read its chunk before anyone overwrites it
-                    if (k < units) dst[k] = v;
-                    wave_sync();
-                }
-            }
-            if (l == 0) ((RecHdr*)(hp + (size_t)new_off * 16u))->node_id = ni;
-            if (ni != i) {
-                const uint32_t* ssrc = (const uint32_t*)FR::nstate(F, t, i);
-                uint32_t* sdst = (uint32_t*)FR::nstate(F, t, ni);
-                for (int k = l; k < FR::SPW; k += 64) sdst[k] = ssrc[k];
-            }
-            nh.rec_off = new_off;
-            if (l == 0) *FR::nhdr(F, t, ni) = nh;
-            if (i == H.root) { new_root = ni; new_root_rec = new_off; }
-        }
-        wave_sync();
-    }
-    H.root = new_root;
-    H.root_rec = new_root_rec;
-    // pass 4
     uint32_t* tab = FR::htab(F, t);
-    for (int i = l; i < F.HT; i += 64) tab[i] = AZG_NONE;
-    wave_sync();
+    uint32_t* gfree = FR::rec_free(F, t);
+    uint32_t* ids = F.free_ids + (size_t)t * F.s_free;
+    const uint32_t n = H.id_top;
     const uint32_t maskHT = (uint32_t)F.HT - 1u;
-    if (l == 0) {
-        for (uint32_t i = 0; i < kept; i++) {
-            const uint64_t h = FR::nhdr(F, t, i)->hash;
-            uint32_t s = (uint32_t)h & maskHT;
-            while (tab[s] != AZG_NONE) s = (s + 1u) & maskHT;
-            tab[s] = (FR::tag_of(h) << AZG_IDX_BITS) | i;
+    for (int i = l; i <= G::A; i += 64) lds_head[i] = gfree[i];
+    for (int i = l; i < F.HT; i += 64) tab[i] = AZG_NONE;
+    __threadfence();
+    wave_sync();
+    uint32_t n_free = H.n_free_ids, live = 0, freed_units = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + (uint32_t)l;
+        NodeHdr nh;
+        nh.hash = 0; nh.rec_off = 0; nh.nv = 0; nh.round = 0; nh.flags = NF_FREE;
+        if (i < n) nh = *FR::nhdr(F, t, i);
+        const bool in_use = !(nh.flags & NF_FREE);
+        const bool dead = in_use && (int)nh.round < min_round && i != H.root;
+        const bool alive = in_use && !dead;
+        if (dead) {
+            const uint32_t old = atomicExch(&lds_head[nh.nv], nh.rec_off);           // LDS: lanes of one size chain up
+            *(uint32_t*)(hp + (size_t)nh.rec_off * 16u) = old;
+            FR::nhdr(F, t, i)->flags = NF_FREE;
+        }
+        const uint64_t bd = __ballot(dead);
+        if (dead) ids[n_free + (uint32_t)__popcll(bd & ((1ull << l) - 1ull))] = i;
+        n_free += (uint32_t)__popcll(bd);
+        freed_units += (uint32_t)wave_sum_i32(dead ? (int)(RecLayout(nh.nv, F.U).total / 16u) : 0);
+        live += (uint32_t)__popcll(__ballot(alive));
+        if (alive) {
+            const uint32_t entry = (FR::tag_of(nh.hash) << AZG_IDX_BITS) | i;
+            uint32_t s = (uint32_t)nh.hash & maskHT;
+            while (atomicCAS(&tab[s], AZG_NONE, entry) != AZG_NONE) s = (s + 1u) & maskHT;
         }
     }
     wave_sync();
-    H.n_nodes = kept;
-    H.heap_top = uni_u32(top);
+    for (int i = l; i <= G::A; i += 64) gfree[i] = lds_head[i];
+    __threadfence();
+    wave_sync();
+    H.n_free_ids = uni_u32(n_free);
+    H.n_nodes = uni_u32(live);
+    H.free_units += uni_u32(freed_units);
     H.gc_runs++;
 }
 
@@ -136,7 +79,9 @@ template <class G>
 __device__ void reset_tree(const ForestDev& F, int t, TreeHdr& H) {
     uint32_t* tab = Forest<G>::htab(F, t);
     for (int i = lane_id(); i < F.HT; i += 64) tab[i] = AZG_NONE;
+    for (int i = lane_id(); i <= G::A; i += 64) Forest<G>::rec_free(F, t)[i] = AZG_NONE;
     H.n_nodes = 0; H.heap_top = 0; H.root = AZG_NONE; H.root_rec = AZG_NONE;
+    H.id_top = 0; H.n_free_ids = 0; H.free_units = 0;
     wave_sync();
 }
 
@@ -180,16 +125,19 @@ __global__ __launch_bounds__(64) void k_selfplay_start(ForestDev F, const int8_t
 // round < r-5 every >20 rounds, MCTS.py:86-91; unreachable nodes never influence a search, so dropping them earlier does
 // not change any result).
 template <class G>
-__device__ __forceinline__ void reclaim_if_short(const ForestDev& F, int t, TreeHdr& H, typename Forest<G>::Smem& sm) {
+__device__ __forceinline__ void reclaim_if_short(const ForestDev& F, int t, TreeHdr& H, typename Forest<G>::Smem& sm,
+                                                 uint32_t* lds_head /*[A + 1]*/) {
     using FR = Forest<G>;
-    if (H.n_nodes + (uint32_t)F.numMCTSSims + 8u > (uint32_t)F.cap ||
-        H.heap_top + (uint32_t)(F.numMCTSSims + 8) * (RecLayout(G::A < 96 ? G::A : 96, F.U).total / 16u) + 256u > F.heap_units) {
-        // locate the new root first so that GC can keep it
+    const uint32_t need_nodes = (uint32_t)F.numMCTSSims + 8u;
+    const uint32_t need_units = need_nodes * (RecLayout(G::A < 96 ? G::A : 96, F.U).total / 16u) + 256u;
+    // ids in use (dead ones included until the next clean-up) / record space left on the bump pointer and the free lists
+    if ((H.id_top - H.n_free_ids) + need_nodes > (uint32_t)F.cap || (F.heap_units - H.heap_top) + H.free_units < need_units) {
+        // locate the new root first so that the clean-up keeps it
         const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
         uint32_t free_slot;
         uint32_t found_rec = AZG_NONE;
         H.root = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
-        gc_tree<G>(F, t, H, G::get_round(sm.st));
+        gc_tree<G>(F, t, H, G::get_round(sm.st), lds_head);
     }
 }
 
@@ -198,6 +146,7 @@ template <class G>
 __global__ __launch_bounds__(64) void k_begin_search(ForestDev F, const int8_t* roots, const uint8_t* full) {
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
+    __shared__ uint32_t gc_head[G::A + 1];
     const int t = blockIdx.x;
     if (full && full[t] == 2) {                    // tree sits this search out (e.g. the other player's turn): keep its contents
         if (lane_id() == 0) F.hdr[t].status = ST_IDLE;
@@ -205,7 +154,7 @@ __global__ __launch_bounds__(64) void k_begin_search(ForestDev F, const int8_t* 
     }
     TreeHdr H = load_uniform(&F.hdr[t]);
     FR::load_state_unpadded(sm.st, roots + (size_t)t * G::S);
-    if (H.n_nodes) reclaim_if_short<G>(F, t, H, sm);
+    if (H.n_nodes) reclaim_if_short<G>(F, t, H, sm, gc_head);
     begin_search_from_lds<G>(F, t, H, sm, full ? full[t] != 0 : true);
     if (H.n_nodes > H.max_nodes_seen) H.max_nodes_seen = H.n_nodes;
     if (lane_id() == 0) F.hdr[t] = H;
@@ -340,7 +289,7 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
         if (np != 0) G::swap_players(sm.st, sm.tmp, np);                                      // Coach.py:61
     }
     // ---- memory reclamation, then the next search ----
-    if (!ended) reclaim_if_short<G>(F, t, H, sm);
+    if (!ended) reclaim_if_short<G>(F, t, H, sm, (uint32_t*)w);      // w[A] f64 is free again: >= A + 1 words
     const double u_full = rng.u01();                                                           // MCTS.py:58
     begin_search_from_lds<G>(F, t, H, sm, u_full < F.prob_fullMCTS);
     H.rng_counter = rng.counter;
