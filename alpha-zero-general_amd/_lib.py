@@ -24,7 +24,7 @@ class SelfplayStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ('plies', 'games', 'sims', 'levels', 'expansions', 'sum_valid_visited',
                                           'terminal_hits', 'examples', 'gc_runs', 'max_nodes', 'errors',
                                           'sum_depth_at_expand', 'cyc_select', 'cyc_levels', 'cyc_edge', 'cyc_leaf')] + [
-                                          ('cyc_seg', C.c_uint64 * 4)]
+                                          ('cyc_seg', C.c_uint64 * 4), ('max_live_after_gc', C.c_uint64)]
 
 
 class AzgError(RuntimeError):

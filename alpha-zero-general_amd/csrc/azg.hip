@@ -172,9 +172,13 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     while (ht < 2 * D.cap) ht <<= 1;
     D.HT = ht;
     D.U = cfg->universes > 0 ? cfg->universes : 1;
+    // record size classes (forest.cuh ForestDev::cls_q): small action spaces get ONE class for all expanded nodes, so the
+    // heap is sized for cap records of the maximum size (+ cap entry-less records) and can never fragment
+    D.cls_q = f->A <= 256 ? f->A : 64;
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
-                            : (size_t)D.cap * RecLayout(f->A <= 200 ? (f->A < 64 ? f->A : 64) : 128, D.U).total * 5 / 4 + 8192;
+                            : (D.cls_q == f->A ? (size_t)D.cap * (RecLayout(f->A, D.U).total + 32)
+                                               : (size_t)D.cap * RecLayout(192, D.U).total * 5 / 4) + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     D.heap_units = (uint32_t)(heap_bytes / 16);
     auto skew = [](size_t bytes) { size_t r = (bytes + 255) / 256 * 256; return ((r >> 8) & 1) ? r : r + 256; };
@@ -183,7 +187,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     D.s_nhdr = skew((size_t)D.cap * sizeof(NodeHdr)) / sizeof(NodeHdr);
     D.s_htab = skew((size_t)D.HT * 4) / 4;
     D.s_free = skew((size_t)D.cap * 4) / 4;
-    D.s_recfree = skew((size_t)(f->A + 1) * 4) / 4;
+    D.s_recfree = skew((size_t)(f->A + 2) * 4) / 4;
     D.universes = cfg->universes;
     D.numMCTSSims = cfg->numMCTSSims;
     D.ratio_fullMCTS = cfg->ratio_fullMCTS > 0 ? cfg->ratio_fullMCTS : 1;
@@ -405,11 +409,12 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
         for (uint32_t i = 0; i < top; i++) {
             if (nh[i].flags & NF_FREE) { n_free++; continue; }
             live++;
-            RecLayout L(nh[i].nv, D.U);
+            const int cap_nv = (int)nh[i].nv * D.cls_q < f->A ? (int)nh[i].nv * D.cls_q : f->A;
+            RecLayout L(cap_nv, D.U);
             if (nh[i].rec_off + L.total / 16u > H.heap_top) { VBAD("[validate] t=%d node=%u record beyond heap_top %u (gc=%u)\n", t, i, H.heap_top, H.gc_runs); continue; }
             const uint8_t* rec = hp.data() + (size_t)nh[i].rec_off * 16;
             const RecHdr* rh = (const RecHdr*)rec;
-            if (rh->node_id != i || rh->nv > nh[i].nv || rh->round != nh[i].round)
+            if (rh->node_id != i || (int)rh->nv > cap_nv || rh->round != nh[i].round)
                 VBAD("[validate] t=%d node=%u header mismatch (rec node_id=%u nv=%u)\n", t, i, rh->node_id, rh->nv);
             if (!(rh->flags & NF_EXPANDED)) continue;
             const RecIds ids(rec, f->dev.U);
@@ -457,6 +462,9 @@ extern "C" int azg_selfplay_start(azg_forest* f, const int8_t* init_boards, void
 extern "C" int azg_selfplay_advance(azg_forest* f, void* stream) {
     if (!f) return fail("null forest");
     FDISPATCH(f, k_selfplay_advance<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev));
+    // trees whose arena ran short asked for the clean-up (16 waves per tree), then begin their search
+    FDISPATCH(f, k_gc<G><<<dim3(f->dev.T), dim3(1024), 0, (hipStream_t)stream>>>(f->dev));
+    FDISPATCH(f, k_after_gc<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -489,6 +497,7 @@ extern "C" int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out) {
         out->cyc_select += x.cyc_select; out->cyc_levels += x.cyc_levels; out->cyc_edge += x.cyc_edge; out->cyc_leaf += x.cyc_leaf;
         for (int k = 0; k < 4; k++) out->cyc_seg[k] += x.cyc_seg[k];
         if (x.max_nodes_seen > out->max_nodes) out->max_nodes = x.max_nodes_seen;
+        if (x.max_live > out->max_live_after_gc) out->max_live_after_gc = x.max_live;
     }
     return 0;
 }

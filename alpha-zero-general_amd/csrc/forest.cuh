@@ -30,7 +30,9 @@
 
 namespace azg {
 
-enum : uint32_t { ST_IDLE = 0, ST_SEARCHING = 1, ST_WAIT_NN = 2, ST_DONE = 3 };
+enum : uint32_t { ST_IDLE = 0, ST_SEARCHING = 1, ST_WAIT_NN = 2, ST_DONE = 3,
+                  ST_GC = 4,        // self-play: the next search waits for the clean-up kernel (k_gc); cur_pre = min round
+                  ST_GC_DONE = 5 }; // cleaned up: k_after_gc begins the search from root_state
 enum : uint8_t { NF_TERMINAL = 1, NF_EXPANDED = 2, NF_FREE = 4 };   // NF_FREE: node id on the free stack (NodeHdr only)
 enum : uint32_t {
     ERR_NODE_OVERFLOW = 1, ERR_HEAP_OVERFLOW = 2, ERR_DEPTH_OVERFLOW = 4, ERR_BAD_STATE = 8, ERR_EXAMPLE_OVERFLOW = 16,
@@ -54,7 +56,7 @@ enum : uint32_t {
 struct __attribute__((aligned(16))) NodeHdr {          // cold per-node data
     uint64_t hash;
     uint32_t rec_off;      // 16-byte units into the tree's record heap
-    uint16_t nv;           // size class of the record (n_valid it was allocated for, >= the node's n_valid in RecHdr)
+    uint16_t nv;           // size CLASS index of the record (see ForestDev::cls_q); the node's n_valid is in its RecHdr
     uint8_t round;
     uint8_t flags;
 };
@@ -82,8 +84,8 @@ struct __attribute__((aligned(16))) TreeHdr {
     uint32_t leaf_is_root, games_done, step, n_rec;
     uint32_t mid_sim, cur_rec, cur_depth, cur_pre;     // a descent paused by the per-launch level budget
     uint32_t pending_nv, pending_node, pad0_, pad1_;   // n_valid and node id of pending_leaf (saves k_expand_backup a round trip)
-    uint32_t id_top, n_free_ids, free_units, pad2_;    // node ids ever handed out; size of the free-id stack; 16-B units on the
-                                                       // record free lists
+    uint32_t id_top, n_free_ids, free_units, max_live; // node ids ever handed out; size of the free-id stack; 16-B units on the
+                                                       // record free lists; most nodes that survived a clean-up
     uint32_t max_nodes_seen, gc_runs, root_rec, noise_pending;   // root_rec = record offset of the root;
                                                                  // noise_pending: root Dirichlet noise still to apply
     uint64_t c_sims, c_levels, c_exp, c_sumvalid, c_term, c_depth, c_plies, c_examples;
@@ -106,6 +108,9 @@ struct ForestDev {
     size_t s_nhdr, s_htab;             // elements (NodeHdr, u32)
     size_t s_free, s_recfree;          // elements (u32): free-id stack [cap], record free-list heads [A + 1]
     int universes, numMCTSSims, ratio_fullMCTS, forced_playouts;
+    int cls_q;                         // record size classes: class 0 = no entries (terminal nodes), class c >= 1 = room for
+                                       // min(A, c * cls_q) entries; cls_q == A (small action spaces) makes every expanded
+                                       // node's record the same size, so a freed record fits any later node
     int level_budget;                  // max descent levels per tree per k_select launch (0 = unlimited)
     int work_budget;                   // max work units (level = 1, edge resolution = AZG_EDGE_UNITS) per tree per launch
     double cpuct, fpu, prob_fullMCTS, dirichletAlpha, temp_begin, temp_end, temp_root, tempThreshold;
@@ -352,31 +357,40 @@ struct Forest {
         return id;
     }
 
+    // ---- record size classes ----
+    __device__ static __forceinline__ int cls_of(const ForestDev& F, int nv) { return nv == 0 ? 0 : 1 + (nv - 1) / F.cls_q; }
+    __device__ static __forceinline__ uint32_t cls_units(const ForestDev& F, int c) {
+        const int cap_nv = c * F.cls_q < A ? c * F.cls_q : A;
+        return RecLayout(cap_nv, F.U).total / 16u;
+    }
+    __device__ static __forceinline__ int n_classes(const ForestDev& F) { return 2 + (A - 1) / F.cls_q; }
+
     // Record for a node with nv valid actions.  Records never move; a dropped node's record sits on the free list of its
-    // size class (= the n_valid it was allocated for).  The wave reads the heads of classes nv .. nv+63 in one request and
-    // takes the first non-empty one (closest fit; *alloc_nv = its class, kept in NodeHdr.nv so that the record returns to
-    // the right list), else the bump pointer.  AZG_NONE on overflow.
+    // size class.  The wave reads the heads of classes c .. c+63 in one request and takes the first non-empty one (closest
+    // fit; *cls_out = its class, kept in NodeHdr.nv so that the record returns to the right list), else the bump pointer.
+    // Entry-less records (terminal nodes) only recycle their own class.  AZG_NONE on overflow.
     template <class HS>
-    __device__ static __forceinline__ uint32_t alloc_record(const ForestDev& F, int t, HS& H, int nv, int* alloc_nv) {
+    __device__ static __forceinline__ uint32_t alloc_record(const ForestDev& F, int t, HS& H, int nv, int* cls_out) {
         uint32_t* heads = rec_free(F, t);
-        const int idx = nv + lane_id();
-        const uint32_t v = idx <= A ? heads[idx] : AZG_NONE;
+        const int c = cls_of(F, nv), nc = n_classes(F);
+        const int idx = c + lane_id();
+        const uint32_t v = (idx < nc && (c > 0 || lane_id() == 0)) ? heads[idx] : AZG_NONE;
         const uint64_t m = __ballot(v != AZG_NONE);
         if (m) {
             const int src = first_lane(m);
             const uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)v, src);
             const uint32_t next = uni_u32(*(const uint32_t*)(heap(F, t) + (size_t)head * 16u));
-            if (lane_id() == 0) heads[nv + src] = next;
-            H.free_units -= RecLayout(nv + src, F.U).total / 16u;
-            *alloc_nv = nv + src;
+            if (lane_id() == 0) heads[c + src] = next;
+            H.free_units -= cls_units(F, c + src);
+            *cls_out = c + src;
             return head;
         }
-        const uint32_t units = RecLayout(nv, F.U).total / 16u;
+        const uint32_t units = cls_units(F, c);
         // 256 units (4 KB) of slack: a level's speculative entry loads may reach 64 entries past a short record
         if (H.heap_top + units + 256u > F.heap_units) { H.err |= ERR_HEAP_OVERFLOW; return AZG_NONE; }
         const uint32_t off = H.heap_top;
         H.heap_top += units;
-        *alloc_nv = nv;
+        *cls_out = c;
         return off;
     }
 

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void k_forest_reset(ForestDev F) {
     int t = blockIdx.x;
     uint32_t* tab = Forest<G>::htab(F, t);
     for (int i = lane_id(); i < F.HT; i += 64) tab[i] = AZG_NONE;
-    for (int i = lane_id(); i <= G::A; i += 64) Forest<G>::rec_free(F, t)[i] = AZG_NONE;
+    for (int i = lane_id(); i < Forest<G>::n_classes(F); i += 64) Forest<G>::rec_free(F, t)[i] = AZG_NONE;
     if (lane_id() == 0) {
         TreeHdr* H = &F.hdr[t];
         H->n_nodes = 0; H->heap_top = 0; H->root = AZG_NONE; H->root_rec = AZG_NONE; H->status = ST_IDLE;
@@ -240,8 +240,8 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
 #endif
     H.leaf_nv = (uint32_t)nv; H.leaf_node = id;
     const RecLayout L(nv, F.U);
-    int alloc_nv = nv;
-    const uint32_t rec_off = FR::alloc_record(F, t, H, nv, &alloc_nv);
+    int alloc_cls = 0;
+    const uint32_t rec_off = FR::alloc_record(F, t, H, nv, &alloc_cls);
     if (rec_off == AZG_NONE) return AZG_NONE;
     uint8_t* rec = FR::rec_ptr(F, t, rec_off);
     const uint8_t round = (uint8_t)G::get_round(sm.st);
@@ -253,7 +253,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
         if (!ended) { rh.sq[0] = 0.0; rh.sq[1] = sqrt(0.0 + AZG_EPS); }
         *(RecHdr*)rec = rh;
         NodeHdr* nh = FR::nhdr(F, t, id);
-        nh->rec_off = rec_off; nh->nv = (uint16_t)alloc_nv; nh->round = round; nh->flags = rh.flags;
+        nh->rec_off = rec_off; nh->nv = (uint16_t)alloc_cls; nh->round = round; nh->flags = rh.flags;
     }
     *terminal = ended;
     if (!ended) {

@@ -26,22 +26,26 @@ __device__ __forceinline__ double temp_for_selfplay(const ForestDev& F, int n) {
 //   * re-inserts every live node into the freshly cleared hash table (atomicCAS, linear probing).
 // ~n/64 pipelined header loads instead of the node-by-node compaction this replaces (which cost 5-20 ms per tree and
 // throttled sustained self-play to a tenth of its fresh-start rate).
+// `n_waves` wavefronts of one workgroup share the scan (wave w takes the 64-id groups w, w + n_waves, ...); the list heads
+// and the three running counters live in LDS.  With n_waves == 1 the barriers compile away.
 template <class G>
-__device__ __noinline__ void gc_tree(const ForestDev& F, int t, TreeHdr& H, int min_round, uint32_t* lds_head /*[A + 1]*/) {
+__device__ __forceinline__ void gc_scan(const ForestDev& F, int t, TreeHdr& H, int min_round, uint32_t* lds_head /*[A + 1]*/,
+                                        uint32_t* lds_ctr /*[4]*/, int wave, int n_waves) {
     using FR = Forest<G>;
-    const int l = lane_id();
+    const int l = lane_id(), tid = wave * 64 + l, nthr = n_waves * 64;
     uint8_t* hp = FR::heap(F, t);
     uint32_t* tab = FR::htab(F, t);
     uint32_t* gfree = FR::rec_free(F, t);
     uint32_t* ids = F.free_ids + (size_t)t * F.s_free;
     const uint32_t n = H.id_top;
     const uint32_t maskHT = (uint32_t)F.HT - 1u;
-    for (int i = l; i <= G::A; i += 64) lds_head[i] = gfree[i];
-    for (int i = l; i < F.HT; i += 64) tab[i] = AZG_NONE;
+    const int nc = FR::n_classes(F);
+    for (int i = tid; i < nc; i += nthr) lds_head[i] = gfree[i];
+    for (int i = tid; i < F.HT; i += nthr) tab[i] = AZG_NONE;
+    if (tid == 0) { lds_ctr[0] = H.n_free_ids; lds_ctr[1] = 0u; lds_ctr[2] = 0u; }
     __threadfence();
-    wave_sync();
-    uint32_t n_free = H.n_free_ids, live = 0, freed_units = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
+    __syncthreads();
+    for (uint32_t base = (uint32_t)wave * 64u; base < n; base += (uint32_t)nthr) {
         const uint32_t i = base + (uint32_t)l;
         NodeHdr nh;
         nh.hash = 0; nh.rec_off = 0; nh.nv = 0; nh.round = 0; nh.flags = NF_FREE;
@@ -54,32 +58,43 @@ __device__ __noinline__ void gc_tree(const ForestDev& F, int t, TreeHdr& H, int 
             *(uint32_t*)(hp + (size_t)nh.rec_off * 16u) = old;
             FR::nhdr(F, t, i)->flags = NF_FREE;
         }
-        const uint64_t bd = __ballot(dead);
-        if (dead) ids[n_free + (uint32_t)__popcll(bd & ((1ull << l) - 1ull))] = i;
-        n_free += (uint32_t)__popcll(bd);
-        freed_units += (uint32_t)wave_sum_i32(dead ? (int)(RecLayout(nh.nv, F.U).total / 16u) : 0);
-        live += (uint32_t)__popcll(__ballot(alive));
+        const uint64_t bd = __ballot(dead), ba = __ballot(alive);
+        const int units = wave_sum_i32(dead ? (int)FR::cls_units(F, nh.nv) : 0);
+        uint32_t pos = 0;
+        if (l == 0) {
+            if (bd) { pos = atomicAdd(&lds_ctr[0], (uint32_t)__popcll(bd)); atomicAdd(&lds_ctr[2], (uint32_t)units); }
+            if (ba) atomicAdd(&lds_ctr[1], (uint32_t)__popcll(ba));
+        }
+        pos = uni_u32(pos);
+        if (dead) ids[pos + (uint32_t)__popcll(bd & ((1ull << l) - 1ull))] = i;
         if (alive) {
             const uint32_t entry = (FR::tag_of(nh.hash) << AZG_IDX_BITS) | i;
             uint32_t s = (uint32_t)nh.hash & maskHT;
             while (atomicCAS(&tab[s], AZG_NONE, entry) != AZG_NONE) s = (s + 1u) & maskHT;
         }
     }
-    wave_sync();
-    for (int i = l; i <= G::A; i += 64) gfree[i] = lds_head[i];
+    __syncthreads();
+    for (int i = tid; i < nc; i += nthr) gfree[i] = lds_head[i];
     __threadfence();
-    wave_sync();
-    H.n_free_ids = uni_u32(n_free);
-    H.n_nodes = uni_u32(live);
-    H.free_units += uni_u32(freed_units);
+    H.n_free_ids = uni_u32(lds_ctr[0]);
+    H.n_nodes = uni_u32(lds_ctr[1]);
+    if (H.n_nodes > H.max_live) H.max_live = H.n_nodes;
+    H.free_units += uni_u32(lds_ctr[2]);
     H.gc_runs++;
+    __syncthreads();
+}
+
+// single-wave form (host-driven searches)
+template <class G>
+__device__ __noinline__ void gc_tree(const ForestDev& F, int t, TreeHdr& H, int min_round, uint32_t* lds_head /*[A + 5]*/) {
+    gc_scan<G>(F, t, H, min_round, lds_head, lds_head + G::A + 1, 0, 1);
 }
 
 template <class G>
 __device__ void reset_tree(const ForestDev& F, int t, TreeHdr& H) {
     uint32_t* tab = Forest<G>::htab(F, t);
     for (int i = lane_id(); i < F.HT; i += 64) tab[i] = AZG_NONE;
-    for (int i = lane_id(); i <= G::A; i += 64) Forest<G>::rec_free(F, t)[i] = AZG_NONE;
+    for (int i = lane_id(); i < Forest<G>::n_classes(F); i += 64) Forest<G>::rec_free(F, t)[i] = AZG_NONE;
     H.n_nodes = 0; H.heap_top = 0; H.root = AZG_NONE; H.root_rec = AZG_NONE;
     H.id_top = 0; H.n_free_ids = 0; H.free_units = 0;
     wave_sync();
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(64) void k_selfplay_start(ForestDev F, const int8_t
     const int t = blockIdx.x;
     TreeHdr H = load_uniform(&F.hdr[t]);
     Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, 0ull};
-    H.err = 0; H.games_done = 0; H.gc_runs = 0; H.max_nodes_seen = 0;
+    H.err = 0; H.games_done = 0; H.gc_runs = 0; H.max_nodes_seen = 0; H.max_live = 0;
     H.c_sims = H.c_levels = H.c_exp = H.c_sumvalid = H.c_term = H.c_depth = H.c_plies = H.c_examples = 0;
     start_game<G>(F, t, H, sm, rng, init_boards ? init_boards + (size_t)t * G::S : nullptr);
     // board is canonical for player 0 (Coach.py:61 with curPlayer == 0)
@@ -125,20 +140,75 @@ __global__ __launch_bounds__(64) void k_selfplay_start(ForestDev F, const int8_t
 // round < r-5 every >20 rounds, MCTS.py:86-91; unreachable nodes never influence a search, so dropping them earlier does
 // not change any result).
 template <class G>
-__device__ __forceinline__ void reclaim_if_short(const ForestDev& F, int t, TreeHdr& H, typename Forest<G>::Smem& sm,
-                                                 uint32_t* lds_head /*[A + 1]*/) {
+__device__ __forceinline__ bool arena_is_short(const ForestDev& F, const TreeHdr& H) {
     using FR = Forest<G>;
     const uint32_t need_nodes = (uint32_t)F.numMCTSSims + 8u;
-    const uint32_t need_units = need_nodes * (RecLayout(G::A < 96 ? G::A : 96, F.U).total / 16u) + 256u;
+    const uint32_t need_units = need_nodes * FR::cls_units(F, FR::cls_of(F, G::A < 96 ? G::A : 96)) + 256u;
     // ids in use (dead ones included until the next clean-up) / record space left on the bump pointer and the free lists
-    if ((H.id_top - H.n_free_ids) + need_nodes > (uint32_t)F.cap || (F.heap_units - H.heap_top) + H.free_units < need_units) {
-        // locate the new root first so that the clean-up keeps it
-        const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
-        uint32_t free_slot;
-        uint32_t found_rec = AZG_NONE;
-        H.root = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
+    return (H.id_top - H.n_free_ids) + need_nodes > (uint32_t)F.cap || (F.heap_units - H.heap_top) + H.free_units < need_units;
+}
+
+// locate the new root (canonical state in sm.st) so that the clean-up keeps it
+template <class G>
+__device__ __forceinline__ void locate_root(const ForestDev& F, int t, TreeHdr& H, typename Forest<G>::Smem& sm) {
+    using FR = Forest<G>;
+    const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
+    uint32_t free_slot;
+    uint32_t found_rec = AZG_NONE;
+    H.root = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
+}
+
+template <class G>
+__device__ __forceinline__ void reclaim_if_short(const ForestDev& F, int t, TreeHdr& H, typename Forest<G>::Smem& sm,
+                                                 uint32_t* lds_head /*[A + 5]*/) {
+    if (arena_is_short<G>(F, H)) {
+        locate_root<G>(F, t, H, sm);
         gc_tree<G>(F, t, H, G::get_round(sm.st), lds_head);
     }
+}
+
+// the tail of a self-play ply: playout-cap draw, search set-up, root noise (MCTS.py:58-64) -- canonical root in sm.st
+template <class G>
+__device__ __forceinline__ void begin_next_search(const ForestDev& F, int t, TreeHdr& H, typename Forest<G>::Smem& sm, Rng& rng,
+                                                  float* dense /*LDS [A]*/) {
+    const double u_full = rng.u01();                                                           // MCTS.py:58
+    begin_search_from_lds<G>(F, t, H, sm, u_full < F.prob_fullMCTS);
+    H.rng_counter = rng.counter;
+    if (H.n_nodes > H.max_nodes_seen) H.max_nodes_seen = H.n_nodes;
+    // an EXISTING root gets its noise before simulation 0 (MCTS.py:64,156-160)
+    if (H.noise_pending && root_noise_tree<G>(F, t, H.root_rec, H.c_sims, nullptr, -1, dense, sm.mask)) H.noise_pending = 0u;
+}
+
+// Self-play clean-up, one workgroup of 16 wavefronts per tree that asked for it (status ST_GC): the header scan is a chain
+// of dependent memory round trips per 64 ids, so 16 waves bring a 13 k-node tree from ~0.5 ms to ~40 us.
+template <class G>
+__global__ __launch_bounds__(1024) void k_gc(ForestDev F) {
+    __shared__ uint32_t head[G::A + 1];
+    __shared__ uint32_t ctr[4];
+    const int t = blockIdx.x;
+    if (uni_u32(F.hdr[t].status) != ST_GC) return;
+    TreeHdr H = load_uniform(&F.hdr[t]);
+    const int wave = (int)(threadIdx.x >> 6);
+    gc_scan<G>(F, t, H, (int)H.cur_pre, head, ctr, wave, 16);
+    if (threadIdx.x == 0) {
+        TreeHdr* Hp = &F.hdr[t];
+        Hp->n_free_ids = H.n_free_ids; Hp->n_nodes = H.n_nodes; Hp->max_live = H.max_live; Hp->free_units = H.free_units;
+        Hp->gc_runs = H.gc_runs; Hp->status = ST_GC_DONE;
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(64) void k_after_gc(ForestDev F) {
+    using FR = Forest<G>;
+    __shared__ typename FR::Smem sm;
+    __shared__ __attribute__((aligned(16))) float dense[G::A];
+    const int t = blockIdx.x;
+    if (uni_u32(F.hdr[t].status) != ST_GC_DONE) return;
+    TreeHdr H = load_uniform(&F.hdr[t]);
+    Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, H.rng_counter};
+    FR::load_state(sm.st, F.root_state + (size_t)t * G::SP);
+    begin_next_search<G>(F, t, H, sm, rng, dense);
+    if (lane_id() == 0) F.hdr[t] = H;
 }
 
 // MCTS.getActionProb prologue for host-driven searches (azg_forest_begin_search)
@@ -146,7 +216,7 @@ template <class G>
 __global__ __launch_bounds__(64) void k_begin_search(ForestDev F, const int8_t* roots, const uint8_t* full) {
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
-    __shared__ uint32_t gc_head[G::A + 1];
+    __shared__ uint32_t gc_head[G::A + 5];
     const int t = blockIdx.x;
     if (full && full[t] == 2) {                    // tree sits this search out (e.g. the other player's turn): keep its contents
         if (lane_id() == 0) F.hdr[t].status = ST_IDLE;
@@ -289,13 +359,17 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
         if (np != 0) G::swap_players(sm.st, sm.tmp, np);                                      // Coach.py:61
     }
     // ---- memory reclamation, then the next search ----
-    if (!ended) reclaim_if_short<G>(F, t, H, sm, (uint32_t*)w);      // w[A] f64 is free again: >= A + 1 words
-    const double u_full = rng.u01();                                                           // MCTS.py:58
-    begin_search_from_lds<G>(F, t, H, sm, u_full < F.prob_fullMCTS);
-    H.rng_counter = rng.counter;
-    if (H.n_nodes > H.max_nodes_seen) H.max_nodes_seen = H.n_nodes;
-    // an EXISTING root gets its noise before simulation 0 (MCTS.py:64,156-160)
-    if (H.noise_pending && root_noise_tree<G>(F, t, H.root_rec, H.c_sims, nullptr, -1, dense, sm.mask)) H.noise_pending = 0u;
+    if (!ended && arena_is_short<G>(F, H)) {
+        // hand the tree to the clean-up kernel (k_gc, 16 waves) and let k_after_gc begin the search
+        locate_root<G>(F, t, H, sm);
+        FR::store_state(F.root_state + (size_t)t * G::SP, sm.st);
+        H.cur_pre = (uint32_t)G::get_round(sm.st);
+        H.rng_counter = rng.counter;
+        H.status = ST_GC;
+        if (l == 0) F.hdr[t] = H;
+        return;
+    }
+    begin_next_search<G>(F, t, H, sm, rng, dense);
     if (l == 0) F.hdr[t] = H;
 }
 

@@ -6,6 +6,8 @@ with no host decision in the loop, so it is captured once in a HIP graph and rep
 for a tree once per search (numMCTSSims rounds), so it is launched every `advance_every` rounds: a tree whose search is
 finished (or whose fresh root waits for its Dirichlet noise) sits out up to advance_every-1 rounds -- (advance_every-1) /
 numMCTSSims of its time -- in exchange for one launch less per round; per-tree results do not depend on the cadence.
+`work_budget` caps the work of a tree in one select launch (a launch lasts as long as its slowest tree): near the end of a
+game most simulations end on terminal nodes and would otherwise all run inside one launch (measured: 0.65 ms rounds).
 
 The descent kernel is a latency chain (few waves, each waiting on dependent loads) while the net is throughput bound, so
 the games are split into `groups` independent forests whose rounds are skewed by one stage and run on separate HIP
@@ -34,11 +36,12 @@ class _Group:
 
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
-                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=0):
+                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=48):
         self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
-        cap = node_capacity or max(1024, 8 * sims)
+        # nodes stay until the root's round passes theirs: measured up to ~11 plies' worth of simulations in Splendor
+        cap = node_capacity or max(1024, 16 * sims + 512)
         assert n_games % groups == 0
         self.T, self.G = n_games, groups
         # cadence of the advance launch: idle share (K-1)/numMCTSSims kept under ~1 %
@@ -132,7 +135,7 @@ class SelfPlayEngine:
                 tot = dict(s)
             else:
                 for k, v in s.items():
-                    tot[k] = (max(tot[k], v) if k == 'max_nodes' else tot[k] | v if k == 'errors' else
+                    tot[k] = (max(tot[k], v) if k in ('max_nodes', 'max_live_after_gc') else tot[k] | v if k == 'errors' else
                               [a + b for a, b in zip(tot[k], v)] if k == 'cyc_seg' else tot[k] + v)
         return tot
 

@@ -167,8 +167,10 @@ typedef struct azg_selfplay_stats {
         errors, sum_depth_at_expand,
         cyc_select, cyc_levels, cyc_edge, cyc_leaf,   /* (library built with -DAZG_CYC_COUNTERS only, else 0) shader-clock cycles summed over trees: whole k_select, descent levels,
                                                          frontier edge resolution (incl. leaf creation), leaf creation */
-        cyc_seg[4];                                   /* frontier edge split: parent-state load, env step, canonical form +
+        cyc_seg[4],                                   /* frontier edge split: parent-state load, env step, canonical form +
                                                          hash, table probe */
+        max_live_after_gc;                            /* most nodes of one tree that survived a clean-up: node_capacity must stay
+                                                         above this + numMCTSSims */
 } azg_selfplay_stats;
 int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out);
 /* drain finished-game examples: (board int8[S], pi f32[A], z f32[P], valids u8[A], q f32[P]) per record

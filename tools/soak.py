@@ -14,7 +14,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
 T = 4096
 g = games.SplendorGame(2)
 net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=T)
-WB = int(os.environ.get('WB', '0')); CAP = int(os.environ.get('CAP', '8512'))
+WB = int(os.environ.get('WB', '48')); CAP = int(os.environ.get('CAP', '13312'))
 e = SelfPlayEngine(g, net, a, T, node_capacity=CAP, max_examples=T * 160, work_budget=WB)
 print('work_budget', WB, 'cap', CAP)
 e.start()
@@ -26,9 +26,9 @@ while done < rounds:
     e.run(CH); done += CH
     s = e.stats(); tn = time.time()
     ds = s['sims'] - prev['sims']
-    print('rounds %6d  %.3f ms/round  yield %.2f  levels/sim %.2f  plies %d games %d examples %d gc_runs %d (+%d) max_nodes %d errors %d' % (
+    print('rounds %6d  %.3f ms/round  yield %.2f  levels/sim %.2f  plies %d games %d examples %d gc_runs %d (+%d) max_live %d errors %d' % (
         done, (tn - tp) / CH * 1e3, ds / CH / T, (s['levels'] - prev['levels']) / max(1, ds), s['plies'], s['games'], s['examples'],
-        s['gc_runs'], s['gc_runs'] - prev['gc_runs'], s['max_nodes'], s['errors']), flush=True)
+        s['gc_runs'], s['gc_runs'] - prev['gc_runs'], s['max_live_after_gc'], s['errors']), flush=True)
     prev, tp = s, tn
     if s['errors']:
         break
