@@ -111,8 +111,10 @@ def cpu_baseline(sims, seconds=15.0, n_par=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=1700)
-    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=56000,
+                    help='timed lock-step rounds; the default spans one whole game per tree (~70 plies x 800 simulations), i.e. '
+                         'opening, middle game, the terminal-heavy endgame and the restart')
+    ap.add_argument('--warmup', type=int, default=8000)
     ap.add_argument('--games', type=int, default=4096, help='concurrent games per GPU')
     ap.add_argument('--game', default='splendor2', choices=['splendor2', 'santorini1', 'santorini11', 'azul'])
     ap.add_argument('--sims', type=int, default=800)

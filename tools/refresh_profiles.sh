@@ -13,5 +13,6 @@ python tools/prof_summary.py /tmp/pw/pw_results.db 8 > gpurun_out/r01c_pmc_WRITE
 python tools/make_traffic_json.py /tmp/pf/pf_results.db /tmp/pw/pw_results.db gpurun_out/r01c_traffic.json > /dev/null
 cp gpurun_out/r01c_traffic.json profiles/r01c_traffic.json
 python bench.py > gpurun_out/r01c_bench.json 2> gpurun_out/r01c_bench.err
+python bench.py --steps 1700 --warmup 100 --no-cpu-baseline > gpurun_out/r01c_bench_fresh.json 2>/dev/null
 tail -c 1500 gpurun_out/r01c_bench.json
 cat gpurun_out/r01c_pytest.txt
