@@ -172,13 +172,14 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     while (ht < 2 * D.cap) ht <<= 1;
     D.HT = ht;
     D.U = cfg->universes > 0 ? cfg->universes : 1;
-    // record size classes (forest.cuh ForestDev::cls_q): small action spaces get ONE class for all expanded nodes, so the
-    // heap is sized for cap records of the maximum size (+ cap entry-less records) and can never fragment
-    D.cls_q = f->A <= 256 ? f->A : 64;
+    // record size classes (forest.cuh ForestDev::cls_q): a small action space (Splendor, A = 81) gets ONE class for all
+    // expanded nodes -- the heap is sized for cap records of the maximum size (+ cap entry-less records) and can never
+    // fragment; larger action spaces use classes of 32 entries and a heap sized for the typical record
+    D.cls_q = f->A <= 96 ? f->A : 32;
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
                             : (D.cls_q == f->A ? (size_t)D.cap * (RecLayout(f->A, D.U).total + 32)
-                                               : (size_t)D.cap * RecLayout(192, D.U).total * 5 / 4) + 8192;
+                                               : (size_t)D.cap * RecLayout(f->A <= 256 ? 64 : 160, D.U).total * 5 / 4) + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     D.heap_units = (uint32_t)(heap_bytes / 16);
     auto skew = [](size_t bytes) { size_t r = (bytes + 255) / 256 * 256; return ((r >> 8) & 1) ? r : r + 256; };

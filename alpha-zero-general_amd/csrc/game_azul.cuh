@@ -220,6 +220,20 @@ struct AzulDev {
         return 30 * (perm_elem(c, f) + 1) + (a - 30 * (f + 1));
     }
 
+    // monotone "age" of a state for the clean-up: Azul's round only advances every ~10-20 plies, so the tiles still on the
+    // table refine it -- every move takes at least one tile off the factories / centre, a new round puts up to 20 back:
+    // age = 21 * round + (20 - tiles on the table), saturating at 255 (saturated nodes are simply kept)
+    __device__ static __forceinline__ int gc_age(const int8_t* st) {
+        int tiles = 0;
+#pragma unroll
+        for (int r = R_CENTRE; r < R_FACT + 5; r++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) tiles += row(st, r)[c];
+        tiles = tiles > 20 ? 20 : tiles;
+        const int age = 21 * get_round(st) + (20 - tiles);
+        return age > 255 ? 255 : age;
+    }
+
     // any move can end the round, whose refill draws tiles with random_seed (setup_new_round :237-255)
     __device__ static __forceinline__ bool move_uses_seed(int) { return true; }
 

@@ -224,6 +224,9 @@ struct SantoriniDev {
         return NB * 81 * worker + 81 * power + 9 * md + bd;
     }
 
+    // monotone "age" of a state for the clean-up: the (saturating) move counter
+    __device__ static __forceinline__ int gc_age(const int8_t* st) { return get_round(st); }
+
     // no chance events in Santorini: random_seed is never read by make_move (:434-550)
     __device__ static __forceinline__ bool move_uses_seed(int) { return false; }
 

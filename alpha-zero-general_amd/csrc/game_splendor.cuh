@@ -337,6 +337,9 @@ struct SplendorDev {
         }
     }
 
+    // monotone "age" of a state for the clean-up (a state older than the root can never be reached again): the move counter
+    __device__ static __forceinline__ int gc_age(const int8_t* st) { return get_round(st); }
+
     // true when the env step of `move` may read random_seed: buying / reserving a visible or deck card draws a replacement
     // (_get_deck_card :306-336); buying a reserved card and the gem moves never do
     __device__ static __forceinline__ bool move_uses_seed(int move) { return move < 27; }

@@ -142,7 +142,7 @@ __device__ void begin_search_from_lds(const ForestDev& F, int t, TreeHdr& H, typ
     uint32_t found_rec = AZG_NONE;
     H.root = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
     H.root_rec = H.root == AZG_NONE ? AZG_NONE : found_rec;
-    H.root_round = (uint32_t)G::get_round(sm.st);
+    H.root_round = (uint32_t)G::gc_age(sm.st);
     H.is_full = full ? 1u : 0u;
     H.n_sims = (uint32_t)(full ? F.numMCTSSims : F.numMCTSSims / F.ratio_fullMCTS);
     H.forced = (full && F.forced_playouts) ? 1u : 0u;
@@ -244,7 +244,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
     const uint32_t rec_off = FR::alloc_record(F, t, H, nv, &alloc_cls);
     if (rec_off == AZG_NONE) return AZG_NONE;
     uint8_t* rec = FR::rec_ptr(F, t, rec_off);
-    const uint8_t round = (uint8_t)G::get_round(sm.st);
+    const uint8_t round = (uint8_t)G::gc_age(sm.st);          // the node's age tag for the clean-up (NodeHdr / RecHdr .round)
     if (l == 0) {
         RecHdr rh;
         rh.Ns = 0; rh.Qs = 0.f; rh.node_id = id; rh.nv = (uint16_t)nv; rh.flags = ended ? NF_TERMINAL : 0; rh.round = round;

@@ -163,7 +163,7 @@ __device__ __forceinline__ void reclaim_if_short(const ForestDev& F, int t, Tree
                                                  uint32_t* lds_head /*[A + 5]*/) {
     if (arena_is_short<G>(F, H)) {
         locate_root<G>(F, t, H, sm);
-        gc_tree<G>(F, t, H, G::get_round(sm.st), lds_head);
+        gc_tree<G>(F, t, H, G::gc_age(sm.st), lds_head);
     }
 }
 
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
         // hand the tree to the clean-up kernel (k_gc, 16 waves) and let k_after_gc begin the search
         locate_root<G>(F, t, H, sm);
         FR::store_state(F.root_state + (size_t)t * G::SP, sm.st);
-        H.cur_pre = (uint32_t)G::get_round(sm.st);
+        H.cur_pre = (uint32_t)G::gc_age(sm.st);
         H.rng_counter = rng.counter;
         H.status = ST_GC;
         if (l == 0) F.hdr[t] = H;

@@ -175,7 +175,9 @@ def main():
     else:
         net = SplendorV80.from_npz(WEIGHTS, device=dev, dtype=dtype) if pretrained else \
             SplendorV80.random_init(device=dev, dtype=dtype)
-    cap = a.node_capacity or max(2048, 16 * a.sims + 512)
+    # nodes live until the root's age passes theirs: ~12 plies' worth of simulations in Splendor, more in the narrow, deep
+    # searches of Azul / Santorini
+    cap = a.node_capacity or max(2048, (16 if a.game == 'splendor2' else 32) * a.sims + 512)
     eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
                          stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups, work_budget=a.work_budget)
     eng.start()
@@ -261,7 +263,7 @@ def main():
                            hip_graph=eng.graph is not None),
                sims_per_sec=tot_sims / dt, plies_completed=tot_plies, games_finished=tot_games,
                examples_gathered=tot_examples if world == 1 else int(ex[0].shape[0]), engine_errors=errs,
-               forest_bytes_per_gpu=eng.device_bytes, groups=a.groups, max_nodes_per_tree=s1['max_nodes'], gc_runs=s1['gc_runs'])
+               forest_bytes_per_gpu=eng.device_bytes, groups=a.groups, max_live_after_gc=int(s1.get('max_live_after_gc', 0)), max_nodes_per_tree=s1['max_nodes'], gc_runs=s1['gc_runs'])
     if roof:
         out['roofline'] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.game == 'splendor2':
