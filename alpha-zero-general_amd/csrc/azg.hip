@@ -178,7 +178,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     D.cls_q = f->A <= 96 ? f->A : 32;
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
-                            : (D.cls_q == f->A ? (size_t)D.cap * (RecLayout(f->A, D.U).total + 32)
+                            : (D.cls_q == f->A ? (size_t)D.cap * RecLayout(f->A, D.U).total + 4096
                                                : (size_t)D.cap * RecLayout(f->A <= 256 ? 64 : 160, D.U).total * 5 / 4) + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     D.heap_units = (uint32_t)(heap_bytes / 16);
@@ -349,7 +349,8 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
     if (n > max_nodes) return n;
     std::vector<NodeHdr> nh(top);
     std::vector<int8_t> st((size_t)top * f->SP);
-    std::vector<uint8_t> hp((size_t)H.heap_top * 16);
+    const size_t heap_used = D.cls_q == f->A ? (size_t)top * (RecLayout(f->A, D.U).total / 16u) : (size_t)H.heap_top;
+    std::vector<uint8_t> hp(heap_used * 16);
     if (top) {
         HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)tree * D.s_nhdr, sizeof(NodeHdr) * top, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(st.data(), D.node_state + (size_t)tree * D.s_nstate, (size_t)top * f->SP, hipMemcpyDeviceToHost));
@@ -402,7 +403,8 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
         if (top > (uint32_t)D.cap || n > top || H.heap_top > D.heap_units) { VBAD("[validate] t=%d n=%u id_top=%u heap_top=%u\n", t, n, top, H.heap_top); continue; }
         if (H.root != AZG_NONE && H.root >= top) VBAD("[validate] t=%d root=%u id_top=%u\n", t, H.root, top);
         HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)t * D.s_nhdr, sizeof(NodeHdr) * top, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)t * D.s_heap, (size_t)H.heap_top * 16, hipMemcpyDeviceToHost));
+        const uint32_t heap_used = D.cls_q == f->A ? (uint32_t)(top * (RecLayout(f->A, D.U).total / 16u)) : H.heap_top;
+        HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)t * D.s_heap, (size_t)heap_used * 16, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(tab.data(), D.htab + (size_t)t * D.s_htab, sizeof(uint32_t) * D.HT, hipMemcpyDeviceToHost));
         if (H.root != AZG_NONE && H.root < top && nh[H.root].rec_off != H.root_rec)
             VBAD("[validate] t=%d root_rec=%u but node %u has rec_off=%u\n", t, H.root_rec, H.root, nh[H.root].rec_off);
@@ -412,7 +414,7 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
             live++;
             const int cap_nv = (int)nh[i].nv * D.cls_q < f->A ? (int)nh[i].nv * D.cls_q : f->A;
             RecLayout L(cap_nv, D.U);
-            if (nh[i].rec_off + L.total / 16u > H.heap_top) { VBAD("[validate] t=%d node=%u record beyond heap_top %u (gc=%u)\n", t, i, H.heap_top, H.gc_runs); continue; }
+            if (nh[i].rec_off + L.total / 16u > heap_used) { VBAD("[validate] t=%d node=%u record beyond heap_top %u (gc=%u)\n", t, i, H.heap_top, H.gc_runs); continue; }
             const uint8_t* rec = hp.data() + (size_t)nh[i].rec_off * 16;
             const RecHdr* rh = (const RecHdr*)rec;
             if (rh->node_id != i || (int)rh->nv > cap_nv || rh->round != nh[i].round)
@@ -425,7 +427,7 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
                     const uint32_t c = *(const uint32_t*)(ent + AZG_E_C + 4 * u);
                     if (c == AZG_NONE) continue;
                     const uint32_t cr = c & AZG_CHILD_IDX_MASK;
-                    if (cr >= H.heap_top) { VBAD("[validate] t=%d node=%u child[%d][%d]=%08x beyond heap\n", t, i, j, u, c); continue; }
+                    if (cr >= heap_used) { VBAD("[validate] t=%d node=%u child[%d][%d]=%08x beyond heap\n", t, i, j, u, c); continue; }
                     const RecHdr* ch = (const RecHdr*)(hp.data() + (size_t)cr * 16);
                     if (ch->node_id >= top || (nh[ch->node_id].flags & NF_FREE) || nh[ch->node_id].rec_off != cr)
                         VBAD("[validate] t=%d node=%u child[%d][%d] -> bad / dropped record %u\n", t, i, j, u, cr);

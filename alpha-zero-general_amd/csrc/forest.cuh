@@ -370,7 +370,13 @@ struct Forest {
     // fit; *cls_out = its class, kept in NodeHdr.nv so that the record returns to the right list), else the bump pointer.
     // Entry-less records (terminal nodes) only recycle their own class.  AZG_NONE on overflow.
     template <class HS>
-    __device__ static __forceinline__ uint32_t alloc_record(const ForestDev& F, int t, HS& H, int nv, int* cls_out) {
+    __device__ static __forceinline__ uint32_t alloc_record(const ForestDev& F, int t, HS& H, int nv, uint32_t node_id,
+                                                            int* cls_out) {
+        if (F.cls_q == A) {
+            // one class for every expanded node: the record slot IS the node id (no list, no load); heap = cap slots
+            *cls_out = cls_of(F, nv);
+            return node_id * cls_units(F, 1);
+        }
         uint32_t* heads = rec_free(F, t);
         const int c = cls_of(F, nv), nc = n_classes(F);
         const int idx = c + lane_id();

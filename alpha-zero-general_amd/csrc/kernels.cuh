@@ -241,7 +241,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
     H.leaf_nv = (uint32_t)nv; H.leaf_node = id;
     const RecLayout L(nv, F.U);
     int alloc_cls = 0;
-    const uint32_t rec_off = FR::alloc_record(F, t, H, nv, &alloc_cls);
+    const uint32_t rec_off = FR::alloc_record(F, t, H, nv, id, &alloc_cls);
     if (rec_off == AZG_NONE) return AZG_NONE;
     uint8_t* rec = FR::rec_ptr(F, t, rec_off);
     const uint8_t round = (uint8_t)G::gc_age(sm.st);          // the node's age tag for the clean-up (NodeHdr / RecHdr .round)

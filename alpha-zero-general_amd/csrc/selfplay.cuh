@@ -54,12 +54,14 @@ __device__ __forceinline__ void gc_scan(const ForestDev& F, int t, TreeHdr& H, i
         const bool dead = in_use && (int)nh.round < min_round && i != H.root;
         const bool alive = in_use && !dead;
         if (dead) {
-            const uint32_t old = atomicExch(&lds_head[nh.nv], nh.rec_off);           // LDS: lanes of one size chain up
-            *(uint32_t*)(hp + (size_t)nh.rec_off * 16u) = old;
+            if (F.cls_q != G::A) {                                                       // (one-class forests: slot == node id)
+                const uint32_t old = atomicExch(&lds_head[nh.nv], nh.rec_off);           // LDS: lanes of one size chain up
+                *(uint32_t*)(hp + (size_t)nh.rec_off * 16u) = old;
+            }
             FR::nhdr(F, t, i)->flags = NF_FREE;
         }
         const uint64_t bd = __ballot(dead), ba = __ballot(alive);
-        const int units = wave_sum_i32(dead ? (int)FR::cls_units(F, nh.nv) : 0);
+        const int units = F.cls_q != G::A ? wave_sum_i32(dead ? (int)FR::cls_units(F, nh.nv) : 0) : 0;
         uint32_t pos = 0;
         if (l == 0) {
             if (bd) { pos = atomicAdd(&lds_ctr[0], (uint32_t)__popcll(bd)); atomicAdd(&lds_ctr[2], (uint32_t)units); }
@@ -145,7 +147,8 @@ __device__ __forceinline__ bool arena_is_short(const ForestDev& F, const TreeHdr
     const uint32_t need_nodes = (uint32_t)F.numMCTSSims + 8u;
     const uint32_t need_units = need_nodes * FR::cls_units(F, FR::cls_of(F, G::A < 96 ? G::A : 96)) + 256u;
     // ids in use (dead ones included until the next clean-up) / record space left on the bump pointer and the free lists
-    return (H.id_top - H.n_free_ids) + need_nodes > (uint32_t)F.cap || (F.heap_units - H.heap_top) + H.free_units < need_units;
+    if ((H.id_top - H.n_free_ids) + need_nodes > (uint32_t)F.cap) return true;
+    return F.cls_q != G::A && (F.heap_units - H.heap_top) + H.free_units < need_units;   // one-class forests: slot == node id
 }
 
 // locate the new root (canonical state in sm.st) so that the clean-up keeps it
