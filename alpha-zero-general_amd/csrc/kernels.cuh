@@ -216,18 +216,9 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
                                              bool* terminal, float* es) {
     using FR = Forest<G>;
     const int l = lane_id();
-#ifdef AZG_LEAF_SPLIT
-    long long q0 = AZG_CLK();
-#endif
     const uint32_t id = FR::create_node(F, t, H, sm.st, h, free_slot);
     if (id == AZG_NONE) return AZG_NONE;
-#ifdef AZG_LEAF_SPLIT
-    long long q1 = AZG_CLK(); H.cyc_seg[0] += (uint32_t)(q1 - q0);
-#endif
     const bool ended = G::game_ended(sm.st, 0, es, sm.mask);                                     // MCTS.py:131
-#ifdef AZG_LEAF_SPLIT
-    q0 = AZG_CLK(); H.cyc_seg[1] += (uint32_t)(q0 - q1);
-#endif
     int nv = 0;
     if (!ended) {
         G::valid_mask(sm.st, 0, sm.mask);                                                        // MCTS.py:142
@@ -235,9 +226,6 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
 #pragma unroll
         for (int k = 0; k < G::AW; k++) nv += __popcll(sm.mask[k]);
     }
-#ifdef AZG_LEAF_SPLIT
-    q1 = AZG_CLK(); H.cyc_seg[2] += (uint32_t)(q1 - q0);
-#endif
     H.leaf_nv = (uint32_t)nv; H.leaf_node = id;
     const RecLayout L(nv, F.U);
     int alloc_cls = 0;
@@ -269,9 +257,6 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
         }
         FR::store_state_unpadded(leaf_states + (size_t)t * G::S, sm.st);
     }
-#ifdef AZG_LEAF_SPLIT
-    q0 = AZG_CLK(); H.cyc_seg[3] += (uint32_t)(q0 - q1);
-#endif
     return rec_off;
 }
 
@@ -283,11 +268,7 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
                                               uint32_t parent_node, int a, long long seed, int8_t* leaf_states,
                                               uint8_t* leaf_valid, bool* is_new, bool* terminal, float* es) {
     using FR = Forest<G>;
-#ifdef AZG_LEAF_SPLIT
-#define AZG_SEG(k, d)
-#else
 #define AZG_SEG(k, d) H.cyc_seg[k] += (uint32_t)(d)
-#endif
     long long c0 = AZG_CLK();
     FR::load_state(sm.st, FR::nstate(F, t, parent_node));
     long long c1 = AZG_CLK(); AZG_SEG(0, c1 - c0);
