@@ -63,20 +63,23 @@ def test_selfplay_first_games_vs_oracle(variant, prob_full):
     f.close()
 
 
-def test_selfplay_gc_keeps_results(tmp_path):
-    """A node arena too small for a whole game forces the round-based compaction; results must not change."""
+@pytest.mark.parametrize('variant,cap', [('splendor2', 400), ('azul', 900), ('santorini1', 700)])
+def test_selfplay_gc_keeps_results(tmp_path, variant, cap):
+    """A node arena too small for a whole game forces the clean-up many times (free-id stack, record free lists / id-indexed
+    record slots, table rebuild); results must not change and the structure must stay valid."""
     import torch
     import azg_oracle as O
     from azg_amd import games
     from azg_amd.forest import Forest
     from hashnet import HashNetTorch
-    g = games.SplendorGame(2)
-    og = O.OracleGame(O.SPLENDOR, 2)
-    kw = dict(MCTS_ARGS['splendor2'])
+    name, v = {'splendor2': ('splendor', 2), 'santorini1': ('santorini', 1), 'azul': ('azul', 0)}[variant]
+    g = {'splendor': lambda: games.SplendorGame(v), 'santorini': lambda: games.SantoriniGame(v), 'azul': games.AzulGame}[name]()
+    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL}[name], v)
+    kw = dict(MCTS_ARGS[variant])
     sims, T, seed, stream0 = 60, 8, 7, 50
     args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1.0, 1.0, 1.0],
                 tempThreshold=6, **kw)
-    f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=400, max_examples=T * 200, rng_seed=seed, stream0=stream0)
+    f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=cap, max_examples=T * 300, rng_seed=seed, stream0=stream0)
     net = HashNetTorch(g.P)
     f.selfplay_start()
     for rnd in range(200000):
@@ -87,10 +90,11 @@ def test_selfplay_gc_keeps_results(tmp_path):
         if rnd % 256 == 255:
             st = f.stats()
             assert st['errors'] == 0, st
-            if st['games'] >= T:
+            if st['games'] >= 3 * T:           # every tree has finished its first game by then
                 break
     st = f.stats()
     assert st['gc_runs'] > 0
+    assert f.validate() == 0
     boards, pis, zs, valids, qs, meta = [x.cpu().numpy() for x in f.drain_examples()]
     for t in range(T):
         o = O.run_episode(og, O.make_args(numMCTSSims=sims, **kw), None, seed=seed, stream=stream0 + t,
