@@ -37,7 +37,7 @@ EXPORTS = [
     'azg_last_error', 'azg_version', 'azg_device_count', 'azg_set_device', 'azg_game_info', 'azg_env_valid_moves',
     'azg_env_next_state', 'azg_env_game_ended', 'azg_env_canonical', 'azg_env_init_boards', 'azg_env_symmetries', 'azg_forest_create',
     'azg_forest_destroy', 'azg_forest_device_bytes', 'azg_forest_reset', 'azg_forest_begin_search',
-    'azg_forest_select', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
+    'azg_forest_select', 'azg_forest_select_fused', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
     'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_forest_validate', 'azg_selfplay_start', 'azg_selfplay_advance',
     'azg_selfplay_stats_get', 'azg_selfplay_drain_examples', 'azg_forest_last_kernel_ms', 'azg_forest_enable_timing', 'azg_nn_linear', 'azg_nn_linear_ws', 'azg_nn_dw_pool', 'azg_nn_v80_block', 'azg_nn_v80_forward',
     'azg_nn_board_to_x', 'azg_nn_heads_out',
@@ -70,6 +70,7 @@ def lib():
     L.azg_forest_reset.argtypes = [vp, vp]
     L.azg_forest_begin_search.argtypes = [vp, vp, vp, vp]
     L.azg_forest_select.argtypes = [vp, vp, vp, vp, vp, i, vp]
+    L.azg_forest_select_fused.argtypes = [vp, vp, vp, vp, vp, vp, i, vp]
     L.azg_forest_expand_backup.argtypes = [vp, vp, vp, vp, i, vp]
     L.azg_forest_active.argtypes = [vp, ip]
     L.azg_forest_action_probs.argtypes = [vp, dbl, vp, vp, vp, vp]

@@ -289,7 +289,21 @@ extern "C" int azg_forest_select(azg_forest* f, int8_t* leaf_states, uint8_t* le
     f->last_leaf_valid = leaf_valid;
     ev_begin(f, 0, (hipStream_t)stream);
     FDISPATCH(f, k_select<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, leaf_states,
-                                     leaf_valid, needs_eval, wait_noise));
+                                     leaf_valid, needs_eval, wait_noise, nullptr, nullptr, 0));
+    ev_end(f, 0, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_forest_select_fused(azg_forest* f, int8_t* leaf_states, uint8_t* leaf_valid, uint8_t* needs_eval,
+                                       const float* pi, const float* v, int noise_stride, void* stream) {
+    if (!f || !leaf_states || !leaf_valid || !needs_eval || !pi || !v) return fail("null argument");
+    if (noise_stride != 0 && noise_stride != -2) return fail("azg_forest_select_fused: noise_stride must be 0 or -2");
+    const int noise = (f->cfg.dirichletAlpha != 0.0 && noise_stride == -2) ? 1 : 0;
+    f->last_leaf_valid = leaf_valid;
+    ev_begin(f, 0, (hipStream_t)stream);
+    FDISPATCH(f, k_select<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, leaf_states,
+                                     leaf_valid, needs_eval, noise, pi, v, noise));
     ev_end(f, 0, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;

@@ -299,6 +299,109 @@ __device__ __forceinline__ void stat_add(uint64_t* p, uint64_t v) {
     __hip_atomic_fetch_add((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One lock-step round, part 2: store (Ps, v) on the pending leaf and back up (MCTS.py:144-154,176-183).
+// Split in a load half (everything whose address does not depend on loaded data: header words, pi, v, the valid mask the
+// descent wrote for this leaf, the first 64 path entries -- ONE memory round trip) and an apply half, so that k_select can
+// run it in its own prologue (self-play: the expansion of round r rides on the descent launch of round r+1).
+template <class G>
+struct ExpandIn {
+    static constexpr int NA = (G::A + 63) / 64;
+    uint32_t status, pending_leaf, path_len, leaf_is_root, sim_idx, is_full, pend_nv, pend_node;
+    float pv[NA];
+    uint8_t va[NA];
+    float v[G::P];
+    PathEnt pe0;
+};
+
+template <class G>
+__device__ __forceinline__ void expand_load(const ForestDev& F, int t, const float* pi, const float* vin,
+                                            const uint8_t* leaf_valid, ExpandIn<G>& in) {
+    const TreeHdr* Hp = &F.hdr[t];
+    const int l = lane_id();
+    in.status = Hp->status; in.pending_leaf = Hp->pending_leaf; in.path_len = Hp->path_len; in.leaf_is_root = Hp->leaf_is_root;
+    in.sim_idx = Hp->sim_idx; in.is_full = Hp->is_full; in.pend_nv = Hp->pending_nv; in.pend_node = Hp->pending_node;
+#pragma unroll
+    for (int k = 0; k < ExpandIn<G>::NA; k++) {
+        const int a = l + 64 * k;
+        in.pv[k] = a < G::A ? pi[(size_t)t * G::A + a] : 0.f;
+        in.va[k] = a < G::A ? leaf_valid[(size_t)t * G::A + a] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int p = 0; p < G::P; p++) in.v[p] = vin[(size_t)t * G::P + p];
+    in.pe0 = (F.path + (size_t)t * AZG_MAXD)[l];
+}
+
+// returns true when the leaf was a fresh root that still needs its Dirichlet noise (noise_pending = 2 was set)
+template <class G>
+__device__ __forceinline__ bool expand_apply(const ForestDev& F, int t, const ExpandIn<G>& in, float* dense /*LDS [A]*/,
+                                             PathEnt* path /*LDS [AZG_MAXD]*/, int noise_enabled) {
+    using FR = Forest<G>;
+    constexpr int NA = ExpandIn<G>::NA;
+    const int l = lane_id();
+    TreeHdr* Hp = &F.hdr[t];
+    const int depth = (int)uni_u32(in.path_len);
+    const int nv = (int)uni_u32(in.pend_nv);
+    const uint32_t sim = uni_u32(in.sim_idx);
+    uint8_t* rec = FR::rec_ptr(F, t, uni_u32(in.pending_leaf));
+    RecHdr* rhp = (RecHdr*)rec;
+    const RecLayout L(nv, F.U);
+    const PathEnt* gp = F.path + (size_t)t * AZG_MAXD;
+    path[l] = in.pe0;
+    for (int d = l + 64; d < depth; d += 64) path[d] = gp[d];
+#pragma unroll
+    for (int k = 0; k < NA; k++) if (l + 64 * k < G::A) dense[l + 64 * k] = in.pv[k];
+    wave_sync();
+    // a root expanded by simulation 0 of a full search gets root noise (MCTS.py:147-149): keep the RAW net output in the
+    // entries and let the noise step do softmax -> noise -> normalise; every other leaf is normalised here (:150,250-253)
+    const bool dir_now = (noise_enabled && uni_u32(in.leaf_is_root) && sim == 0 && uni_u32(in.is_full) && F.dirichletAlpha != 0.0);
+    float s = 1.f;
+    if (!dir_now) s = np_sum_f32(dense, G::A);
+    // entry j belongs to the j-th valid action (the rank of its bit in the leaf's valid mask): no read of the record needed
+    int base_rank = 0;
+#pragma unroll
+    for (int k = 0; k < NA; k++) {                                                               // :40-41,150-152
+        const uint64_t m = __ballot(in.va[k] != 0);
+        if (in.va[k]) {
+            const int j = base_rank + __popcll(m & ((1ull << l) - 1ull));
+            uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
+            uint4 e0;
+            e0.x = __float_as_uint(dir_now ? in.pv[k] : in.pv[k] / s); e0.y = 0u;                 // P, N = 0
+            e0.z = (uint32_t)__double_as_longlong(AZG_NANQ); e0.w = (uint32_t)((uint64_t)__double_as_longlong(AZG_NANQ) >> 32);
+            *(uint4*)(ent + AZG_E_P) = e0;
+            for (int u = 0; u < F.U; u++) *(uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)u) = AZG_NONE;
+        }
+        base_rank += __popcll(m);
+    }
+    if (l == 0) {                                                                                // :152-153
+        rhp->Ns = 0; rhp->Qs = in.v[0]; rhp->flags = NF_EXPANDED;
+        FR::nhdr(F, t, uni_u32(in.pend_node))->flags = NF_EXPANDED;
+    }
+    FR::backup(F, t, path, depth, in.v);                                                         // leaf returns v :154
+    if (l == 0) {
+        Hp->sim_idx = sim + 1;
+        Hp->status = ST_SEARCHING;
+        Hp->pending_leaf = AZG_NONE;
+        stat_add(&Hp->c_exp, 1ull);
+        stat_add(&Hp->c_depth, (uint64_t)depth);
+        if (dir_now) Hp->noise_pending = 2u;
+    }
+    wave_sync();
+    return dir_now;
+}
+
+template <class G>
+__global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* pi, const float* vin, const uint8_t* leaf_valid,
+                                                      int noise_enabled) {
+    __shared__ __attribute__((aligned(16))) float dense[G::A];
+    __shared__ __attribute__((aligned(16))) PathEnt path[AZG_MAXD];
+    const int t = blockIdx.x;
+    ExpandIn<G> in;
+    expand_load<G>(F, t, pi, vin, leaf_valid, in);
+    if (uni_u32(in.status) != ST_WAIT_NN) return;
+    expand_apply<G>(F, t, in, dense, path, noise_enabled);
+}
+
+
 // The fields of TreeHdr that k_select keeps live (wave-uniform => SGPRs).  Loading the whole 200-byte header into
 // registers made the kernel spill to scratch; the cold fields are read-modify-written by lane 0 at the end instead.
 struct SelState {
@@ -309,9 +412,11 @@ struct SelState {
 // One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
 template <class G>
 __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
-                                                  uint8_t* needs_eval, int wait_noise) {
+                                                  uint8_t* needs_eval, int wait_noise, const float* pi, const float* vin,
+                                                  int noise_enabled) {
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
+    __shared__ __attribute__((aligned(16))) float dense[G::A];          // fused expansion only
     const int t = blockIdx.x;
     const int l = lane_id();
     TreeHdr* Hp = &F.hdr[t];
@@ -320,13 +425,22 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
 #endif
     // every hot header field is requested in one go (status included): one memory round trip before the first level
     SelState H;
-    const uint32_t status0 = Hp->status, pending0 = Hp->noise_pending;
+    ExpandIn<G> ein;
+    if (pi) expand_load<G>(F, t, pi, vin, leaf_valid, ein);             // pi != nullptr: the previous round's expansion first
+    uint32_t status0 = Hp->status;
+    const uint32_t pending0 = Hp->noise_pending;
     H.id_top = Hp->id_top; H.n_free_ids = Hp->n_free_ids; H.free_units = Hp->free_units;
     H.n_nodes = Hp->n_nodes; H.heap_top = Hp->heap_top; H.root = Hp->root; H.root_rec = Hp->root_rec; H.sim_idx = Hp->sim_idx;
     H.n_sims = Hp->n_sims; H.is_full = Hp->is_full; H.forced = Hp->forced; H.err = Hp->err; H.leaf_is_root = Hp->leaf_is_root;
     H.mid_sim = Hp->mid_sim; H.cur_rec = Hp->cur_rec; H.cur_depth = Hp->cur_depth; H.cur_pre = Hp->cur_pre;
+    bool fresh_noise = false;
+    if (pi && uni_u32(status0) == ST_WAIT_NN) {
+        fresh_noise = expand_apply<G>(F, t, ein, dense, sm.path, noise_enabled);
+        status0 = ST_SEARCHING;
+    }
+    const bool expanded_here = pi && uni_u32(ein.status) == ST_WAIT_NN;
     // wait_noise: the root noise is applied by the periodic k_selfplay_advance launch; until then the tree sits out
-    if (uni_u32(status0) != ST_SEARCHING || (wait_noise && uni_u32(pending0))) {
+    if (uni_u32(status0) != ST_SEARCHING || (wait_noise && (uni_u32(pending0) || fresh_noise))) {
         if (l == 0) needs_eval[t] = 0;
         return;
     }
@@ -336,6 +450,7 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
     H.is_full = uni_u32(H.is_full); H.forced = uni_u32(H.forced); H.err = uni_u32(H.err);
     H.leaf_is_root = uni_u32(H.leaf_is_root); H.mid_sim = uni_u32(H.mid_sim); H.cur_rec = uni_u32(H.cur_rec);
     H.cur_depth = uni_u32(H.cur_depth); H.cur_pre = uni_u32(H.cur_pre);
+    if (expanded_here) H.sim_idx = uni_u32(ein.sim_idx) + 1u;          // the header words were requested before the expansion
     H.status = ST_SEARCHING; H.pending_leaf = AZG_NONE; H.path_len = 0; H.cyc_leaf = 0; H.leaf_nv = 0; H.leaf_node = 0;
     H.cyc_seg[0] = H.cyc_seg[1] = H.cyc_seg[2] = H.cyc_seg[3] = 0;
     uint8_t* hp = FR::heap(F, t);
@@ -559,82 +674,6 @@ __global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_stat
         (void)t_start; (void)cyc_levels; (void)cyc_edge;
 #endif
         needs_eval[t] = need_nn ? 1 : 0;
-    }
-}
-
-// One lock-step round, part 2: store (Ps, v) on the pending leaf and back up (MCTS.py:144-154,176-183).
-template <class G>
-__global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* pi, const float* vin, const uint8_t* leaf_valid,
-                                                      int noise_enabled) {
-    using FR = Forest<G>;
-    __shared__ __attribute__((aligned(16))) float dense[G::A];
-    __shared__ __attribute__((aligned(16))) PathEnt path[AZG_MAXD];
-    const int t = blockIdx.x;
-    const int l = lane_id();
-    TreeHdr* Hp = &F.hdr[t];
-    // ---- round trip 1: everything whose address does not depend on loaded data (header words, pi, v, the valid mask the
-    //      descent wrote for this leaf, the first 64 path entries) ----
-    const uint32_t status = Hp->status, pending_leaf = Hp->pending_leaf, path_len = Hp->path_len, leaf_is_root = Hp->leaf_is_root,
-                   sim_idx = Hp->sim_idx, is_full = Hp->is_full, pend_nv = Hp->pending_nv, pend_node = Hp->pending_node;
-    constexpr int NA = (G::A + 63) / 64;
-    float pv[NA];
-    uint8_t va[NA];
-#pragma unroll
-    for (int k = 0; k < NA; k++) {
-        const int a = l + 64 * k;
-        pv[k] = a < G::A ? pi[(size_t)t * G::A + a] : 0.f;
-        va[k] = a < G::A ? leaf_valid[(size_t)t * G::A + a] : (uint8_t)0;
-    }
-    float v[G::P];
-#pragma unroll
-    for (int p = 0; p < G::P; p++) v[p] = vin[(size_t)t * G::P + p];
-    const PathEnt* gp = F.path + (size_t)t * AZG_MAXD;
-    const PathEnt pe0 = gp[l];
-    if (uni_u32(status) != ST_WAIT_NN) return;
-    const int depth = (int)uni_u32(path_len);
-    const int nv = (int)uni_u32(pend_nv);
-    const uint32_t sim = uni_u32(sim_idx);
-    uint8_t* rec = FR::rec_ptr(F, t, uni_u32(pending_leaf));
-    RecHdr* rhp = (RecHdr*)rec;
-    const RecLayout L(nv, F.U);
-    path[l] = pe0;
-    for (int d = l + 64; d < depth; d += 64) path[d] = gp[d];
-#pragma unroll
-    for (int k = 0; k < NA; k++) if (l + 64 * k < G::A) dense[l + 64 * k] = pv[k];
-    wave_sync();
-    // a root expanded by simulation 0 of a full search gets root noise (MCTS.py:147-149): keep the RAW net output in the
-    // entries and let the noise step do softmax -> noise -> normalise; every other leaf is normalised here (:150,250-253)
-    const bool dir_now = (noise_enabled && uni_u32(leaf_is_root) && sim == 0 && uni_u32(is_full) && F.dirichletAlpha != 0.0);
-    float s = 1.f;
-    if (!dir_now) s = np_sum_f32(dense, G::A);
-    // entry j belongs to the j-th valid action (the rank of its bit in the leaf's valid mask): no read of the record needed
-    int base_rank = 0;
-#pragma unroll
-    for (int k = 0; k < NA; k++) {                                                               // :40-41,150-152
-        const uint64_t m = __ballot(va[k] != 0);
-        if (va[k]) {
-            const int j = base_rank + __popcll(m & ((1ull << l) - 1ull));
-            uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
-            uint4 e0;
-            e0.x = __float_as_uint(dir_now ? pv[k] : pv[k] / s); e0.y = 0u;                       // P, N = 0
-            e0.z = (uint32_t)__double_as_longlong(AZG_NANQ); e0.w = (uint32_t)((uint64_t)__double_as_longlong(AZG_NANQ) >> 32);
-            *(uint4*)(ent + AZG_E_P) = e0;
-            for (int u = 0; u < F.U; u++) *(uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)u) = AZG_NONE;
-        }
-        base_rank += __popcll(m);
-    }
-    if (l == 0) {                                                                                // :152-153
-        rhp->Ns = 0; rhp->Qs = v[0]; rhp->flags = NF_EXPANDED;
-        FR::nhdr(F, t, uni_u32(pend_node))->flags = NF_EXPANDED;
-    }
-    FR::backup(F, t, path, depth, v);                                                            // leaf returns v :154
-    if (l == 0) {
-        Hp->sim_idx = sim + 1;
-        Hp->status = ST_SEARCHING;
-        Hp->pending_leaf = AZG_NONE;
-        stat_add(&Hp->c_exp, 1ull);
-        stat_add(&Hp->c_depth, (uint64_t)depth);
-        if (dir_now) Hp->noise_pending = 2u;
     }
 }
 

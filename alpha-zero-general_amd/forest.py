@@ -102,6 +102,13 @@ class Forest:
         check(lib().azg_forest_select(self.h, _ptr(self.leaf_states), _ptr(self.leaf_valid), _ptr(self.needs_eval),
                                       _ptr(noise), self._noise_arg(noise, normalised, device_noise), _stream()))
 
+    def select_fused(self, pi, v, device_noise=False):
+        """expand_backup(pi, v) of the previous select's leaves, then the next select, in one launch (self-play)"""
+        assert pi.dtype == torch.float32 and v.dtype == torch.float32 and pi.is_contiguous() and v.is_contiguous()
+        assert pi.shape == (self.T, self.A) and v.shape == (self.T, self.P)
+        check(lib().azg_forest_select_fused(self.h, _ptr(self.leaf_states), _ptr(self.leaf_valid), _ptr(self.needs_eval),
+                                            _ptr(pi), _ptr(v), -2 if device_noise else 0, _stream()))
+
     def expand_backup(self, pi, v, noise=None, normalised=False, device_noise=False):
         assert pi.dtype == torch.float32 and v.dtype == torch.float32 and pi.is_contiguous() and v.is_contiguous()
         assert pi.shape == (self.T, self.A) and v.shape == (self.T, self.P)

@@ -20,6 +20,10 @@ from .forest import Forest
 class _Group:
     def __init__(self, forest, net, shape, device_noise):
         self.f, self.net, self.shape, self.device_noise = forest, net, shape, device_noise
+        st = getattr(net, 'pi', None)
+        static = torch.is_tensor(st) and tuple(st.shape) == (forest.T, forest.A) and st.dtype == torch.float32
+        self.pi = st if static else torch.zeros((forest.T, forest.A), dtype=torch.float32, device=forest.device)
+        self.v = net.v if static else torch.zeros((forest.T, forest.P), dtype=torch.float32, device=forest.device)
 
     def select(self):
         self.f.select(device_noise=self.device_noise)
@@ -29,6 +33,16 @@ class _Group:
         pi, v = self.net.predict_batch(f.leaf_states.view(self.shape), f.leaf_valid)
         f.expand_backup(pi, v, device_noise=self.device_noise)
 
+    # fused form: the expansion of round r rides on the descent launch of round r + 1 (azg_forest_select_fused)
+    def select_fused(self):
+        self.f.select_fused(self.pi, self.v, device_noise=bool(self.device_noise))
+
+    def predict_into_buffers(self):
+        f = self.f
+        pi, v = self.net.predict_batch(f.leaf_states.view(self.shape), f.leaf_valid)
+        if pi.data_ptr() != self.pi.data_ptr():          # nets without static output buffers: keep the addresses stable
+            self.pi.copy_(pi); self.v.copy_(v)
+
     def predict_expand_advance(self):
         self.predict_expand()
         self.f.selfplay_advance()
@@ -36,7 +50,7 @@ class _Group:
 
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
-                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=48):
+                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=48, fused=True):
         self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
@@ -44,6 +58,7 @@ class SelfPlayEngine:
         cap = node_capacity or max(1024, 16 * sims + 512)
         assert n_games % groups == 0
         self.T, self.G = n_games, groups
+        self.fused = bool(fused) and groups == 1
         # cadence of the advance launch: idle share (K-1)/numMCTSSims kept under ~1 %
         self.K = max(1, min(8, sims // 100)) if advance_every is None else int(advance_every)
         assert self.K == 1 or groups == 1
@@ -80,6 +95,12 @@ class SelfPlayEngine:
         """one round of every group; group g's stage order is rotated by g (software-pipeline skew)"""
         if self.G == 1:
             grp = self.groups[0]
+            if self.fused:
+                grp.select_fused()                   # expansion of the previous round's leaves + this round's descent
+                if advance:
+                    grp.f.selfplay_advance()
+                grp.predict_into_buffers()
+                return
             grp.select()
             grp.predict_expand()
             if advance:

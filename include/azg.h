@@ -130,6 +130,12 @@ int azg_forest_select(azg_forest* f, int8_t* leaf_states_dev, uint8_t* leaf_vali
    root_noise_dev == NULL with noise_stride == -2 (self-play): same device sampler, but run by the next
    azg_selfplay_advance launch instead of a launch of its own; a tree whose root noise is pending sits out the selects
    in between (same per-tree event sequence, so results do not depend on how often advance is launched). */
+/* part 2 + part 1 in one launch (self-play): first the expansion + backup of the leaves the PREVIOUS select handed out
+   (pi / v as for azg_forest_expand_backup; leaf_valid must still hold that select's masks), then the next descent.  Saves
+   a launch and its cold header reads per round; results are identical to expand_backup followed by select.
+   noise_stride: 0 = no root noise, -2 = device sampler run by azg_selfplay_advance (see azg_forest_select). */
+int azg_forest_select_fused(azg_forest* f, int8_t* leaf_states_dev, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev,
+                            const float* pi_dev, const float* v_dev, int noise_stride, void* stream);
 /* part 2: store (Ps, v) on the pending leaves and back the values up (MCTS.py:147-154,176-183).
    pi f32[T][A] are PROBABILITIES (exp of the net's log-softmax, GenericNNetWrapper.py:107,119), v f32[T][P].
    The leaf_valid buffer handed to the preceding azg_forest_select must still hold what that call wrote (the kernel maps

@@ -110,7 +110,8 @@ def test_selfplay_gc_keeps_results(tmp_path, variant, cap):
 
 def test_advance_cadence_does_not_change_results():
     """SelfPlayEngine launches selfplay_advance (move sampling, re-rooting, root Dirichlet noise) every `advance_every`
-    rounds; trees wait for it, so the examples of every game must be identical for any cadence (device noise sampler on)."""
+    rounds; trees wait for it, so the examples of every game must be identical for any cadence (device noise sampler on) --
+    and for the fused form, where the expansion of round r rides on the descent launch of round r + 1."""
     import torch
     from azg_amd import games
     from azg_amd.selfplay import SelfPlayEngine
@@ -120,9 +121,9 @@ def test_advance_cadence_does_not_change_results():
                 tempThreshold=6, **MCTS_ARGS['splendor2'])
     T = 32
     res = []
-    for K, graph in ((1, False), (5, True)):
+    for K, graph, fused in ((1, False, False), (5, True, True), (3, True, False), (1, False, True)):
         e = SelfPlayEngine(g, HashNetTorch(2), args, T, node_capacity=2048, max_examples=T * 400, rng_seed=99, stream0=7,
-                           use_graph=graph, advance_every=K)
+                           use_graph=graph, advance_every=K, fused=fused)
         e.start()
         for _ in range(400):
             e.run(40)
@@ -137,9 +138,11 @@ def test_advance_cadence_does_not_change_results():
         res.append([x[order] for x in ex])
         for grp in e.groups:
             grp.f.close()
-    assert len(res[0][0]) == len(res[1][0]) > 0
-    for a, b in zip(res[0], res[1]):
-        assert np.array_equal(a, b)
+    assert len(res[0][0]) > 0
+    for other in res[1:]:
+        assert len(res[0][0]) == len(other[0])
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
 
 
 def test_drain_examples_with_symmetries():
