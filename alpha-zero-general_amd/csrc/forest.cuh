@@ -401,7 +401,7 @@ struct Forest {
     }
 
     // Lane-parallel value backup along the recorded path (MCTS.py:176-183 unwound): level d belongs to lane d.
-    __device__ static void backup(const ForestDev& F, int t, const PathEnt* path, int depth, const float* v) {
+    __device__ static __forceinline__ void backup(const ForestDev& F, int t, const PathEnt* path, int depth, const float* v) {
         if (depth == 0) return;
         int tot = 0;
         {
@@ -415,7 +415,17 @@ struct Forest {
             if (d < depth) {
                 PathEnt e = path[d];
                 int roll = ((tot - e.pre) % P + P) % P;            // sum of next_player over levels >= d
-                float v0 = v[((0 - roll) % P + P) % P];             // np.roll(v, n)[0] = v[(-n) mod P]
+                const int vi = ((0 - roll) % P + P) % P;            // np.roll(v, n)[0] = v[(-n) mod P]
+                // select chain over opaque register copies: a dynamically indexed v[] (or the load-of-select the optimiser
+                // makes of a plain select chain) would force the caller's whole value block into scratch memory
+                float v0 = v[0];
+                asm volatile("" : "+v"(v0));
+#pragma unroll
+                for (int p = 1; p < P; p++) {
+                    float vp = v[p];
+                    asm volatile("" : "+v"(vp));
+                    v0 = vi == p ? vp : v0;
+                }
                 uint8_t* rec = hp + (size_t)e.rec * 16u;
                 RecHdr* rh = (RecHdr*)rec;
                 uint8_t* ent = rec + AZG_REC_HDR + (size_t)e.j * ES;

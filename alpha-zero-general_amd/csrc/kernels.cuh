@@ -411,7 +411,7 @@ struct SelState {
 
 // One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
 template <class G>
-__global__ __launch_bounds__(64, 4) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
+__global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
                                                   uint8_t* needs_eval, int wait_noise, const float* pi, const float* vin,
                                                   int noise_enabled) {
     using FR = Forest<G>;
