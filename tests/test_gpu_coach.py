@@ -13,7 +13,7 @@ class Args(dict):
     __getattr__ = dict.get
 
 
-def test_coach_learn_one_iteration(tmp_path):
+def test_coach_learn_two_iterations(tmp_path):
     from azg_amd import formats, games
     from azg_amd.coach import Coach
     from azg_amd.train import SplendorV80Module
@@ -22,15 +22,16 @@ def test_coach_learn_one_iteration(tmp_path):
     m = SplendorV80Module(2)
     m.load_state_dict({k[3:]: torch.as_tensor(z[k]) for k in z.files if k.startswith('sd/')})
     args = Args(numMCTSSims=8, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, dirichletAlpha=0.3, prob_fullMCTS=1.0,
-                ratio_fullMCTS=5, temperature=[1.25, 0.8, 1.0], tempThreshold=6, numIters=1, numEps=16, numItersHistory=2,
+                ratio_fullMCTS=5, temperature=[1.25, 0.8, 1.0], tempThreshold=6, numIters=2, numEps=16, numItersHistory=2,
                 maxlenOfQueue=100000, learn_rate=1e-3, batch_size=64, epochs=1, q_weight=0.5, arenaCompare=8,
                 updateThreshold=0.6, checkpoint=str(tmp_path))
     c = Coach(g, m, args, n_games=32, node_capacity=1024, log=lambda s: None)
     res = c.learn()
-    assert len(res) == 1 and res[0]['nwins'] + res[0]['pwins'] + res[0]['draws'] == 8 and res[0]['examples'] > 64
+    assert len(res) == 2 and all(r["nwins"] + r["pwins"] + r["draws"] == 8 for r in res) and res[0]["examples"] > 64
+    assert res[1]["examples"] > res[0]["examples"]            # the history window holds both iterations
     hist = formats.load_train_examples(os.path.join(tmp_path, 'checkpoint.examples'))
-    assert len(hist) == 1 and hist[0][0][0].shape == (56, 7) and len(hist[0][0][1]) == 81
+    assert len(hist) == 2 and hist[0][0][0].shape == (56, 7) and len(hist[0][0][1]) == 81
     ck = torch.load(os.path.join(tmp_path, 'temp.pt'), map_location='cpu', weights_only=False)
     assert 'state_dict' in ck and ck['numMCTSSims'] == 8 and ck['full_model'].version == 80
-    if res[0]['accepted']:
+    if res[-1]["accepted"]:
         assert os.path.exists(os.path.join(tmp_path, 'best.pt'))
