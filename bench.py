@@ -122,7 +122,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--groups', type=int, default=1, help='independent forests with skewed rounds on separate streams')
     ap.add_argument('--level-budget', type=int, default=0, help='max descent levels per tree per select launch (0 = unlimited)')
-    ap.add_argument('--work-budget', type=int, default=48, help='per-launch work cap per tree (level units), 0 = off')
+    ap.add_argument('--advance-every', type=int, default=0, help='rounds per selfplay_advance launch / HIP graph (0 = engine default)')
+    ap.add_argument('--work-budget', type=int, default=20, help='per-launch work cap per tree (level units), 0 = off')
     ap.add_argument('--net-dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--net', default='hip', choices=['hip', 'torch'], help='hip: engine MFMA kernels; torch: PyTorch-ROCm ops')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -179,7 +180,8 @@ def main():
     # searches of Azul / Santorini
     cap = a.node_capacity or max(2048, (16 if a.game == 'splendor2' else 32) * a.sims + 512)
     eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
-                         stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups, work_budget=a.work_budget)
+                         stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups, work_budget=a.work_budget,
+                         advance_every=a.advance_every or None)
     eng.start()
     eng.run(a.warmup)
     torch.cuda.synchronize()

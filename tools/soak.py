@@ -14,7 +14,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
 T = 4096
 g = games.SplendorGame(2)
 net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=T)
-WB = int(os.environ.get('WB', '48')); CAP = int(os.environ.get('CAP', '13312'))
+WB = int(os.environ.get('WB', '20')); CAP = int(os.environ.get('CAP', '13312'))
 e = SelfPlayEngine(g, net, a, T, node_capacity=CAP, max_examples=T * 160, work_budget=WB)
 print('work_budget', WB, 'cap', CAP)
 e.start()
