@@ -178,3 +178,35 @@ def test_drain_examples_with_symmetries():
     assert i == len(boards) and n_records == e.stats()['examples'] or n_records > 0
     for grp in e.groups:
         grp.f.close()
+
+
+def test_full_size_properties():
+    """BASELINE.json's headline configuration at full size (4096 concurrent Splendor-2p games, 800 simulations per move,
+    the pretrained V80 net on the engine's kernels): size-independent invariants after a few plies -- no error flag, the
+    structural validator passes on all 4096 trees, every root's visit counts add up, every tree keeps moving."""
+    import os
+    import torch
+    from azg_amd import games
+    from azg_amd.nnet import SplendorV80Hip
+    from azg_amd.selfplay import SelfPlayEngine
+    T, sims = 4096, 800
+    g = games.SplendorGame(2)
+    net = SplendorV80Hip.from_npz(os.path.join(os.path.dirname(__file__), 'golden', 'weights_splendor2_v80.npz'), max_batch=T)
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0],
+                tempThreshold=6, **MCTS_ARGS['splendor2'])
+    e = SelfPlayEngine(g, net, args, T, max_examples=T * 8)
+    e.start()
+    e.run(3 * sims + 64)
+    st = e.stats()
+    assert st['errors'] == 0
+    assert st['plies'] >= 2 * T and st['plies'] <= 4 * T                 # every tree is in its 3rd or 4th search
+    assert st['sims'] >= st['expansions'] > 0
+    assert e.forest.validate() == 0
+    rs = e.forest.root_stats()
+    Ns, Nsa = rs['Ns'].cpu().numpy().astype(np.int64), rs['Nsa'].cpu().numpy().astype(np.int64)
+    has_root = Ns > 0
+    assert has_root.mean() > 0.9
+    # MCTS.py:180-181: every visit of the root increments Ns and exactly one Nsa (tree reuse keeps both from earlier searches)
+    assert np.array_equal(Nsa.sum(axis=1)[has_root], Ns[has_root])
+    for grp in e.groups:
+        grp.f.close()
