@@ -23,6 +23,23 @@
 namespace azg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));     // v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 operands
+
+// wave-wide f32 max / sum through DPP butterflies (rows of 16) + four readlanes; every lane gets the result
+__device__ __forceinline__ float nn_wave_max(float x) {
+    x = fmaxf(x, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(x)))); x = fmaxf(x, __uint_as_float(dpp_u32<0x4E>(__float_as_uint(x))));
+    x = fmaxf(x, __uint_as_float(dpp_u32<0x141>(__float_as_uint(x)))); x = fmaxf(x, __uint_as_float(dpp_u32<0x140>(__float_as_uint(x))));
+    const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 0)), b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 16));
+    const float c = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 32)), d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float nn_wave_sum(float x) {
+    x += __uint_as_float(dpp_u32<0xB1>(__float_as_uint(x))); x += __uint_as_float(dpp_u32<0x4E>(__float_as_uint(x)));
+    x += __uint_as_float(dpp_u32<0x141>(__float_as_uint(x))); x += __uint_as_float(dpp_u32<0x140>(__float_as_uint(x)));
+    const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 0)), b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 16));
+    const float c = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 32)), d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 48));
+    return (a + b) + (c + d);
+}
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_HSIGMOID = 3 };
 
@@ -30,6 +47,17 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     if (act == ACT_RELU) return x > 0.f ? x : 0.f;
     if (act == ACT_HSWISH) { float t = fminf(fmaxf(x + 3.f, 0.f), 6.f); return x * t * (1.f / 6.f); }
     if (act == ACT_HSIGMOID) return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    return x;
+}
+// activation of two packed values: the clamp is one v_med3_f32 per component, the rest packed (v_pk_add / v_pk_mul)
+__device__ __forceinline__ f32x2 act_apply2(f32x2 x, int act) {
+    if (act == ACT_RELU) return f32x2{fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
+    if (act == ACT_HSWISH || act == ACT_HSIGMOID) {
+        f32x2 t = x + 3.f;
+        t.x = __builtin_amdgcn_fmed3f(t.x, 0.f, 6.f);
+        t.y = __builtin_amdgcn_fmed3f(t.y, 0.f, 6.f);
+        return act == ACT_HSWISH ? x * t * (1.f / 6.f) : t * (1.f / 6.f);
+    }
     return x;
 }
 __device__ __forceinline__ float hardsigmoid(float x) { return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
@@ -434,10 +462,9 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
             }
             const int col0 = nt_e * 16 + 4 * g;
             if (col0 < E) {
-                float4 v;
-                v.x = act_apply(acc[0] + be4.x, ACT); v.y = act_apply(acc[1] + be4.y, ACT);
-                v.z = act_apply(acc[2] + be4.z, ACT); v.w = act_apply(acc[3] + be4.w, ACT);
-                *(float4*)(H + (rt * 16 + r16) * HS + col0) = v;
+                const f32x2 lo = act_apply2(f32x2{acc[0] + be4.x, acc[1] + be4.y}, ACT);
+                const f32x2 hi = act_apply2(f32x2{acc[2] + be4.z, acc[3] + be4.w}, ACT);
+                *(float4*)(H + (rt * 16 + r16) * HS + col0) = make_float4(lo.x, lo.y, hi.x, hi.y);
             }
         }
     }
@@ -452,24 +479,26 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
     float wd[49];                      // wave-uniform 7x7 weights -> SGPRs (one LDS broadcast read each, once per wave)
 #pragma unroll
     for (int k = 0; k < 49; k++) wd[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, WD[k])));
-    for (int i = tid; i < NS * E; i += 768) {
-        const int s = i / E, c = i - s * E;
+    // two adjacent channels per thread as one f32x2: the 49 multiply-adds of the token mix run as v_pk_fma_f32
+    for (int i = tid; i < NS * (E / 2); i += 768) {
+        const int s = i / (E / 2), c = 2 * (i - s * (E / 2));
         float* base = H + (s * 7) * HS + c;
-        float in[7];
+        f32x2 in[7];
 #pragma unroll
-        for (int l = 0; l < 7; l++) in[l] = base[l * HS];
-        const float scl = W.sd[c], bb = W.bd[c];
-        float pool = POOLMAX ? -INFINITY : 0.f;
+        for (int l = 0; l < 7; l++) in[l] = *(const f32x2*)(base + l * HS);
+        const f32x2 scl = *(const f32x2*)(W.sd + c), bb = *(const f32x2*)(W.bd + c);
+        f32x2 pool = POOLMAX ? f32x2{-INFINITY, -INFINITY} : f32x2{0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 7; m++) {
-            float a = 0.f;
+            f32x2 a = f32x2{0.f, 0.f};
 #pragma unroll
             for (int l = 0; l < 7; l++) a += wd[m * 7 + l] * in[l];
-            a = act_apply(a * scl + bb, ACT);
-            base[m * HS] = a;
-            pool = POOLMAX ? fmaxf(pool, a) : pool + a;
+            a = act_apply2(a * scl + bb, ACT);
+            *(f32x2*)(base + m * HS) = a;
+            if (POOLMAX) { pool.x = fmaxf(pool.x, a.x); pool.y = fmaxf(pool.y, a.y); } else pool += a;
         }
-        PL[s * HS + c] = POOLMAX ? pool : pool / 7.f;
+        if (!POOLMAX) pool = pool * (1.f / 7.f);
+        *(f32x2*)(PL + s * HS + c) = pool;
     }
     __syncthreads();
     AZG_PH(4);
@@ -626,14 +655,10 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
             const int a1 = lane + 64;
             float x0 = valid[(size_t)b * A + lane] ? LG[s * LS + lane] : -1e8f;
             float x1 = a1 < A ? (valid[(size_t)b * A + a1] ? LG[s * LS + a1] : -1e8f) : -INFINITY;
-            float mx = fmaxf(x0, x1);
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+            const float mx = nn_wave_max(fmaxf(x0, x1));
             x0 = expf(x0 - mx);
             x1 = a1 < A ? expf(x1 - mx) : 0.f;
-            float sum = x0 + x1;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+            const float sum = nn_wave_sum(x0 + x1);
             pi_out[(size_t)b * A + lane] = x0 / sum;
             if (a1 < A) pi_out[(size_t)b * A + a1] = x1 / sum;
         }
