@@ -36,6 +36,9 @@ OTHER_GAMES = {
     'santorini1': dict(args=dict(numMCTSSims=800, cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True, dirichletAlpha=0.2,
                                  temperature=[1.25, 0.8, 1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0),
                        weights='weights_santorini1_v89.npz', net='SantoriniV89', label='Santorini no-gods (NB_GODS=1), V89 net'),
+    'splendor4': dict(args=dict(numMCTSSims=800, cpuct=0.8, fpu=0.1, universes=3, forced_playouts=True, dirichletAlpha=0.3,
+                                temperature=[1.25, 0.8, 1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0),
+                      weights='weights_splendor4_v80.npz', net='SplendorV80', label='Splendor 4p (chance nodes = 3 universes), V80 net'),
     'santorini11': dict(args=dict(numMCTSSims=800, cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True, dirichletAlpha=0.2,
                                   temperature=[1.25, 0.8, 1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0),
                         weights='weights_santorini11_v78.npz', net='SantoriniV78',
@@ -116,7 +119,7 @@ def main():
                          'opening, middle game, the terminal-heavy endgame and the restart')
     ap.add_argument('--warmup', type=int, default=8000)
     ap.add_argument('--games', type=int, default=4096, help='concurrent games per GPU')
-    ap.add_argument('--game', default='splendor2', choices=['splendor2', 'santorini1', 'santorini11', 'azul'])
+    ap.add_argument('--game', default='splendor2', choices=['splendor2', 'splendor4', 'santorini1', 'santorini11', 'azul'])
     ap.add_argument('--sims', type=int, default=800)
     ap.add_argument('--node-capacity', type=int, default=0)
     ap.add_argument('--no-graph', action='store_true')
@@ -159,9 +162,10 @@ def main():
         og = OTHER_GAMES[a.game]
         margs = Args(og['args'])
         margs['numMCTSSims'] = a.sims
-        game = {'santorini1': lambda: games.SantoriniGame(1, device=dev), 'santorini11': lambda: games.SantoriniGame(11, device=dev),
+        game = {'splendor4': lambda: games.SplendorGame(4, device=dev), 'santorini1': lambda: games.SantoriniGame(1, device=dev), 'santorini11': lambda: games.SantoriniGame(11, device=dev),
                 'azul': lambda: games.AzulGame(device=dev)}[a.game]()
-        net = getattr(_nn, og['net']).from_npz(os.path.join(ROOT, 'tests', 'golden', og['weights']), device=dev, dtype=dtype)
+        nkw = dict(num_players=4) if a.game == 'splendor4' else {}
+        net = getattr(_nn, og['net']).from_npz(os.path.join(ROOT, 'tests', 'golden', og['weights']), device=dev, dtype=dtype, **nkw)
         a.net = 'torch'
         label = og['label']
         pretrained = True

@@ -152,3 +152,24 @@ def test_v78_forward_cpu():
 @pytest.mark.gpu
 def test_v78_forward_gpu():
     _check_v78('cuda:0')
+
+
+def _check_v80_4p(device):
+    """Splendor-4p checkpoint (pretrained_4players.pt, 88 tokens-channels): SplendorV80(num_players=4) vs the reference model"""
+    from azg_amd.nnet import SplendorV80
+    root = os.path.join(os.path.dirname(__file__), 'golden')
+    net = SplendorV80.from_npz(os.path.join(root, 'weights_splendor4_v80.npz'), num_players=4, device=device)
+    d = np.load(os.path.join(root, 'netfwd_splendor4_v80.npz'))
+    pi, v = net.predict_batch(torch.from_numpy(d['boards']).to(device), torch.from_numpy(d['masks']).to(device))
+    assert v.shape[1] == 4
+    assert np.allclose(pi.cpu().numpy(), d['pi'], atol=1e-5, rtol=0)
+    assert np.allclose(v.cpu().numpy(), d['v'], atol=1e-5, rtol=0)
+
+
+def test_v80_4p_forward_cpu():
+    _check_v80_4p('cpu')
+
+
+@pytest.mark.gpu
+def test_v80_4p_forward_gpu():
+    _check_v80_4p('cuda:0')

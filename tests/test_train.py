@@ -48,3 +48,14 @@ def test_losses_and_training_step():
     first, last = np.mean([h[1] for h in hist[:4]]), np.mean([h[1] for h in hist[-4:]])
     assert last < first                                   # the value head fits the synthetic targets
     assert not m.training
+
+
+def test_module_4p_matches_reference_outputs():
+    from azg_amd.train import SplendorV80Module
+    z = np.load(os.path.join(GOLDEN, 'weights_splendor4_v80.npz'))
+    m = SplendorV80Module(num_players=4)
+    m.load_state_dict({k[3:]: torch.as_tensor(z[k]) for k in z.files if k.startswith('sd/')}, strict=True)
+    d = np.load(os.path.join(GOLDEN, 'netfwd_splendor4_v80.npz'))
+    with torch.no_grad():
+        lp, v = m.eval()(torch.from_numpy(d['boards']), torch.from_numpy(d['masks'].astype(bool)))
+    assert np.allclose(torch.exp(lp).numpy(), d['pi'], atol=1e-5, rtol=0) and np.allclose(v.numpy(), d['v'], atol=1e-5, rtol=0)

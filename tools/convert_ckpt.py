@@ -53,6 +53,7 @@ def convert(name, ckpt_rel, load_kw, game_mod, game_cls, n_vec=256, forward=True
 
 def main():
     convert('splendor2_v80', 'splendor/pretrained_2players.pt', dict(splendor_players=2), 'SplendorGame', 'SplendorGame')
+    convert('splendor4_v80', 'splendor/pretrained_4players.pt', dict(splendor_players=4), 'SplendorGame', 'SplendorGame', n_vec=128)
     convert('santorini1_v89', 'santorini/pretrained.pt', dict(santorini_gods=1), 'SantoriniGame', 'SantoriniGame', n_vec=128)
     convert('azul_v84', 'azul/pretrained.pt', dict(), 'AzulGame', 'AzulGame', n_vec=128)
     # V78 is built from torchvision.models.mobilenetv3.InvertedResidual, which is only a placeholder class in tools/refshim:
