@@ -142,7 +142,10 @@ static int dalloc(azg_forest* f, T** p, size_t count) {
     if (b == 0) b = 16;
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, b);
-    if (e != hipSuccess) return fail(std::string("hipMalloc(") + std::to_string(b) + "): " + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();        // clear the sticky error: the caller may retry with a smaller forest
+        return fail(std::string("hipMalloc(") + std::to_string(b) + "): " + hipGetErrorString(e));
+    }
     f->allocs.push_back(q);
     f->bytes += b;
     *p = (T*)q;

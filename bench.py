@@ -183,9 +183,19 @@ def main():
     # nodes live until the root's age passes theirs: ~12 plies' worth of simulations in Splendor, more in the narrow, deep
     # searches of Azul / Santorini
     cap = a.node_capacity or max(2048, (16 if a.game == 'splendor2' else 32) * a.sims + 512)
-    eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
-                         stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups, work_budget=a.work_budget,
-                         advance_every=a.advance_every or None)
+    eng = None
+    for attempt in range(3):           # the forest wants ~170 GB of the 288 GB HBM: shrink the arena if the device has less to give
+        try:
+            eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
+                                 stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups,
+                                 work_budget=a.work_budget, advance_every=a.advance_every or None)
+            break
+        except Exception as ex:        # azg_amd.AzgError: hipMalloc failed
+            if a.node_capacity or attempt == 2:
+                raise
+            sys.stderr.write('forest with node_capacity %d did not fit (%s); retrying smaller\n' % (cap, ex))
+            torch.cuda.empty_cache()
+            cap = cap * 3 // 4
     eng.start()
     eng.run(a.warmup)
     torch.cuda.synchronize()
