@@ -429,7 +429,7 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
     }
     if (MODE != 1) load_we();
     const float4 be4 = *(const float4*)(W.be + nt_e * 16 + 4 * g);
-    if (tid < 49) WD[tid] = W.Wd[tid];
+    const float wd_stage = tid < 49 ? W.Wd[tid] : 0.f;       // requested now, parked in LDS after the expand phase (used by P2)
     if (MODE != 1 && !INLDS) {
         // ---- P0: x tile -> LDS (contiguous rows, float4); pad columns 56..59 zeroed ----
 #pragma unroll
@@ -468,6 +468,7 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
             }
         }
     }
+    if (tid < 49) WD[tid] = wd_stage;
     __syncthreads();
     AZG_PH(3);
     if (wave < 3) {                    // SE fc1 weights: requested now (the expand fragments are dead), they land during P2
