@@ -323,7 +323,9 @@ struct V80NetW {
 };
 
 // weight operands are stored in MFMA fragment order: frag[tile nt][K chunk c][lane][j] = W[16c + 4*(lane>>4) + j][16nt + (lane&15)],
-// so a wave fetches one chunk of one column tile as a single 1 KiB global_load_dwordx4
+// so a wave fetches one chunk of one column tile as a single 1 KiB global_load_dwordx4.  Where K = 8 mod 16 (56, 168) the
+// last chunk is stored "half": frag[nt][c_last][lane][j] = W[16c + 2*(lane>>4) + j] for j < 2 (j >= 2 unused), so that
+// chunk costs two MFMAs instead of four
 #define FRAG(ptr, NCH, nt, c) (*(const float4*)((ptr) + ((((size_t)(nt) * (NCH) + (c)) * 64 + lane) << 2)))
 
 #ifdef AZG_NN_PHASE_TIMES
@@ -399,13 +401,17 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
             const float* xr = X0 + (rt * 16 + r16) * XS + 4 * g;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (16 * c + 4 * g < C) a = *(const float4*)(xr + 16 * c);
+            for (int c = 0; c < 3; c++) {
+                const float4 a = *(const float4*)(xr + 16 * c);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c].x, a.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c].y, a.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c].z, a.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[c].w, a.w, acc, 0, 0, 0);
+            }
+            {   // half chunk k = 48..55 (FRAG_HALF order: lane group g holds k = 48 + 2g + {0,1})
+                const f32x2 a = *(const f32x2*)(xr + 48 - 2 * g);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[3].x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[3].y, a.y, acc, 0, 0, 0);
             }
             const int col0 = nt_p * 16 + 4 * g;
             if (col0 < XS)            // columns 56..59 get 0 (zero-padded W0 / b0)
@@ -452,13 +458,17 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
             const float* xr = X + (rt * 16 + r16) * XS + 4 * g;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (16 * c + 4 * g < C) a = *(const float4*)(xr + 16 * c);
+            for (int c = 0; c < 3; c++) {
+                const float4 a = *(const float4*)(xr + 16 * c);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c].x, a.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c].y, a.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c].z, a.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[c].w, a.w, acc, 0, 0, 0);
+            }
+            {   // half chunk k = 48..55
+                const f32x2 a = *(const f32x2*)(xr + 48 - 2 * g);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[3].x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[3].y, a.y, acc, 0, 0, 0);
             }
             const int col0 = nt_e * 16 + 4 * g;
             if (col0 < E) {
@@ -509,13 +519,17 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
         const float* pr = PL + r16 * HS + 4 * g;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 11; c++) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (16 * c + 4 * g < E) a = *(const float4*)(pr + 16 * c);
+        for (int c = 0; c < 10; c++) {
+            const float4 a = *(const float4*)(pr + 16 * c);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c].x, a.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c].y, a.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c].z, a.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[c].w, a.w, acc, 0, 0, 0);
+        }
+        {   // half chunk k = 160..167
+            const f32x2 a = *(const f32x2*)(pr + 160 - 2 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[10].x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1r[10].y, a.y, acc, 0, 0, 0);
         }
         float4 v;
         v.x = fmaxf(acc[0] + b14.x, 0.f); v.y = fmaxf(acc[1] + b14.y, 0.f);
@@ -569,17 +583,19 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
         const float* sr = SC + (row / 7) * HS + 4 * g;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 11; c++) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (16 * c + 4 * g < E) {
-                a = *(const float4*)(hr + 16 * c);
-                const float4 s4 = *(const float4*)(sr + 16 * c);
-                a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
-            }
+        for (int c = 0; c < 10; c++) {
+            float4 a = *(const float4*)(hr + 16 * c);
+            const float4 s4 = *(const float4*)(sr + 16 * c);
+            a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c].x, a.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c].y, a.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c].z, a.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[c].w, a.w, acc, 0, 0, 0);
+        }
+        {   // half chunk k = 160..167
+            const f32x2 a = *(const f32x2*)(hr + 160 - 2 * g) * *(const f32x2*)(sr + 160 - 2 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[10].x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[10].y, a.y, acc, 0, 0, 0);
         }
         const int col0 = nt_p * 16 + 4 * g;
         if (MODE >= 2 || OUTLDS) {

@@ -241,7 +241,7 @@ class SplendorV80Hip(SplendorV80):
         head = [self._frag(flat60(self.Wpi1, 96)), pad(self.bpi1, (96,)), self._frag(pad(self.Wpi2, (96, 96))),
                 pad(self.bpi2, (96,)), self._frag(flat60(self.Wv1, 16)), pad(self.bv1, (16,)), self.Wv2.contiguous(),
                 self.bv2.contiguous()]
-        first = [self._frag(pad(self.W0, (64, 64))), pad(self.b0, (64,))]
+        first = [self._frag(pad(self.W0, (64, 64)), True), pad(self.b0, (64,))]
         self._net_keep = first + self.trunk._keep + self.head_pi._keep + self.head_v._keep + head
         assert len(self._net_keep) == 43
         self.net_ptrs = (C.c_void_p * 43)(*[t.data_ptr() for t in self._net_keep])
@@ -266,11 +266,19 @@ class SplendorV80Hip(SplendorV80):
                                                       self._stream()))
 
     @staticmethod
-    def _frag(Wp):
+    def _frag(Wp, half_last=False):
         """zero-padded [Kp][NP] -> MFMA fragment order [NP/16][Kp/16][64 lanes][4]:
-        frag[nt][c][lane][j] = Wp[16c + 4*(lane>>4) + j][16nt + (lane&15)]  (FRAG in csrc/nn_kernels.cuh)"""
+        frag[nt][c][lane][j] = Wp[16c + 4*(lane>>4) + j][16nt + (lane&15)]  (FRAG in csrc/nn_kernels.cuh).
+        half_last: the last chunk holds only 8 rows of K; lane group g gets rows 16c + 2g + {0, 1} in j = 0, 1"""
         Kp, NP = Wp.shape
         assert Kp % 16 == 0 and NP % 16 == 0
+        if half_last:
+            last = Wp[Kp - 16:].clone()
+            assert float(last[8:].abs().max()) == 0.0
+            Wp = Wp.clone()
+            Wp[Kp - 16:] = 0
+            for g in range(4):
+                Wp[Kp - 16 + 4 * g: Kp - 16 + 4 * g + 2] = last[2 * g: 2 * g + 2]
         return Wp.view(Kp // 16, 4, 4, NP // 16, 16).permute(3, 0, 1, 4, 2).contiguous().view(-1)
 
     def _block_ptrs(self, blk):
@@ -280,8 +288,8 @@ class SplendorV80Hip(SplendorV80):
             out = torch.zeros(n, dtype=torch.float32, device=v.device)
             out[:v.numel()] = v
             return out
-        blk._keep = [self._frag(blk.pWe), pad1(blk.be, 176), blk.Wd.contiguous(), blk.sd.contiguous(), blk.bd.contiguous(),
-                     self._frag(blk.pW1), pad1(blk.b1, 48), self._frag(blk.pW2), pad1(blk.b2, 176), self._frag(blk.pWp),
+        blk._keep = [self._frag(blk.pWe, True), pad1(blk.be, 176), blk.Wd.contiguous(), blk.sd.contiguous(), blk.bd.contiguous(),
+                     self._frag(blk.pW1, True), pad1(blk.b1, 48), self._frag(blk.pW2), pad1(blk.b2, 176), self._frag(blk.pWp, True),
                      pad1(blk.bp, 64)]
         assert tuple(blk.pWe.shape) == (64, 176) and tuple(blk.pW1.shape) == (176, 48)
         assert tuple(blk.pW2.shape) == (48, 176) and tuple(blk.pWp.shape) == (176, 64)

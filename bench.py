@@ -129,6 +129,9 @@ def main():
     ap.add_argument('--work-budget', type=int, default=20, help='per-launch work cap per tree (level units), 0 = off')
     ap.add_argument('--net-dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--net', default='hip', choices=['hip', 'torch'], help='hip: engine MFMA kernels; torch: PyTorch-ROCm ops')
+    ap.add_argument('--prob-full', type=float, default=1.0,
+                    help='prob_fullMCTS: 1.0 = every ply a full search (the headline metric); 0.25 = the reference default mix of '
+                         'full and numMCTSSims//5 searches (main.py), a secondary figure')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--roofline-rounds', type=int, default=300)
@@ -154,6 +157,7 @@ def main():
     T = a.games
     margs = Args(SPLENDOR2_ARGS)
     margs['numMCTSSims'] = a.sims
+    margs['prob_fullMCTS'] = a.prob_full
     dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[a.net_dtype]
     pretrained = os.path.exists(WEIGHTS)
     label = 'Splendor 2p'
@@ -162,6 +166,7 @@ def main():
         og = OTHER_GAMES[a.game]
         margs = Args(og['args'])
         margs['numMCTSSims'] = a.sims
+        margs['prob_fullMCTS'] = a.prob_full
         game = {'splendor4': lambda: games.SplendorGame(4, device=dev), 'santorini1': lambda: games.SantoriniGame(1, device=dev), 'santorini11': lambda: games.SantoriniGame(11, device=dev),
                 'azul': lambda: games.AzulGame(device=dev)}[a.game]()
         nkw = dict(num_players=4) if a.game == 'splendor4' else {}
@@ -225,7 +230,8 @@ def main():
     if world > 1:
         dist.all_reduce(loc, op=dist.ReduceOp.SUM)
     tot_sims, tot_plies, errs, tot_games, tot_examples = [int(x) for x in loc.tolist()]
-    value = tot_sims / a.sims / dt
+    # full searches only: simulations / numMCTSSims (counts partial plies at the window edges); mixed searches: plies
+    value = tot_sims / a.sims / dt if a.prob_full >= 1.0 else tot_plies / dt
 
     # ---- roofline segment: eager rounds with HIP events around the select / expand_backup launches ----
     roof = None
@@ -267,6 +273,8 @@ def main():
                     select_ms=ms_sel, expand_backup_ms=ms_exp, launches=int(n_sel),
                     d_levels_per_sim=d, v_valid_per_level=vbar, e_expansions_per_sim=e)
 
+    search_mix = ('every ply a full search' if a.prob_full >= 1.0 else
+                  'prob_fullMCTS=%g: full searches mixed with numMCTSSims//5 fast ones (reference default mix, secondary figure)' % a.prob_full)
     out = dict(metric='self-play env-steps/sec @ numMCTSSims=%d, %s' % (a.sims, 'Splendor-2p' if a.game == 'splendor2' else label), value=value,
                unit='env-steps/sec', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
                higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
@@ -275,8 +283,8 @@ def main():
                        if pretrained else 'random-init V80'),
                config=dict(workload=('Splendor 2p, numMCTSSims=%d, %d concurrent self-play games per GPU, V80 net %s (%s), '
                                      'args of pretrained_2players.pt (cpuct 0.8 fpu 0.0593 universes 3 forced playouts '
-                                     'dirichlet 0.3), every ply a full search' % (a.sims, T, a.net_dtype, 'engine MFMA-f32 kernels' if a.net == 'hip' else 'PyTorch-ROCm ops'))
-                           if a.game == 'splendor2' else '%s, numMCTSSims=%d, %d concurrent self-play games per GPU, MCTS args of the pretrained checkpoint, every ply a full search' % (label, a.sims, T),
+                                     'dirichlet 0.3), %s' % (a.sims, T, a.net_dtype, 'engine MFMA-f32 kernels' if a.net == 'hip' else 'PyTorch-ROCm ops', search_mix))
+                           if a.game == 'splendor2' else '%s, numMCTSSims=%d, %d concurrent self-play games per GPU, MCTS args of the pretrained checkpoint, %s' % (label, a.sims, T, search_mix),
                            games_per_gpu=T, parallelism='games sharded x%d, 1 RCCL example all_gather at episode end'
                                                         % world if world > 1 else 'single GPU',
                            hip_graph=eng.graph is not None),
