@@ -143,8 +143,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get('AZG_FORCE_DIST'))      # AZG_FORCE_DIST: exercise the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     assert world == a.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
     torch.cuda.set_device(local_rank)
@@ -204,7 +206,7 @@ def main():
     eng.start()
     eng.run(a.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     s0 = eng.stats()
     torch.cuda.synchronize()
@@ -212,14 +214,14 @@ def main():
     eng.run(a.steps)
     ex = eng.drain_examples()
     n_local_examples = int(ex[0].shape[0])
-    if world > 1:
+    if use_dist:
         ex = gather_examples(list(ex))           # the one RCCL collective of the path (episode-end example gather)
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     s1 = eng.stats()
     dt = t1 - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -227,7 +229,7 @@ def main():
     d_plies = s1['plies'] - s0['plies']
     loc = torch.tensor([d_sims, d_plies, s1['errors'], s1['games'] - s0['games'], n_local_examples], dtype=torch.int64,
                        device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(loc, op=dist.ReduceOp.SUM)
     tot_sims, tot_plies, errs, tot_games, tot_examples = [int(x) for x in loc.tolist()]
     # full searches only: simulations / numMCTSSims (counts partial plies at the window edges); mixed searches: plies
@@ -297,7 +299,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline(a.sims, a.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -11,7 +11,7 @@ a = Args(numMCTSSims=800, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=Tr
 g = games.SplendorGame(2)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=T)
-e = SelfPlayEngine(g, net, a, T, node_capacity=8512, max_examples=T*160, use_graph=False)
+e = SelfPlayEngine(g, net, a, T, node_capacity=13312, max_examples=T*160, use_graph=False)
 e.start(); e.run(1200)
 s0 = e.stats(); e.run(300); s1 = e.stats()
 seg = [s1['cyc_seg'][k]-s0['cyc_seg'][k] for k in range(4)]

@@ -11,7 +11,7 @@ a = Args(numMCTSSims=800, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=Tr
 g = games.SplendorGame(2); T = 4096
 net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=T)
 WB = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-e = SelfPlayEngine(g, net, a, T, node_capacity=8512, max_examples=T*160, use_graph=False, work_budget=WB)
+e = SelfPlayEngine(g, net, a, T, node_capacity=13312, max_examples=T*160, use_graph=False, work_budget=WB)
 print('work_budget', WB)
 e.start(); e.run(1500)
 L = _lib.lib(); L.azg_debug_tree_cycles.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

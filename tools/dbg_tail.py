@@ -10,7 +10,7 @@ class Args(dict): __getattr__ = dict.get
 a = Args(numMCTSSims=800, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, dirichletAlpha=0.3, temperature=[1.25,0.8,1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0)
 g = games.SplendorGame(2); T = 4096
 net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=T)
-e = SelfPlayEngine(g, net, a, T, node_capacity=8512, max_examples=T*160, use_graph=False)
+e = SelfPlayEngine(g, net, a, T, node_capacity=13312, max_examples=T*160, use_graph=False)
 e.start(); e.run(int(sys.argv[1]) if len(sys.argv) > 1 else 1500)
 L = _lib.lib(); L.azg_debug_tree_cycles.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 f = e.forest
