@@ -636,7 +636,8 @@ extern "C" int azg_nn_linear(const float* A, int lda, const float* Wp, int Kp, i
         case 4: LIN(4);
         case 6: LIN(6);
         case 11: LIN(11);
-        default: return fail("azg_nn_linear: NP/16 must be 1, 4, 6 or 11");
+        case 12: LIN(12);
+        default: return fail("azg_nn_linear: NP/16 must be 1, 4, 6, 11 or 12");
     }
 #undef LIN
 #undef LIN_N
@@ -671,24 +672,34 @@ extern "C" int azg_nn_linear_ws(const float* A, int lda, const float* Wp, int Kp
 #define WS(NCHV) return launch_linear_ws<NCHV>(A, lda, Wp, NP, bias_padded, R, ldr, rowscale, rows_per_group, out, ldc, M, K, N, act, s)
     switch (Kp / 16) {
         case 1: WS(1);
+        case 2: WS(2);
         case 3: WS(3);
         case 4: WS(4);
         case 6: WS(6);
+        case 8: WS(8);
         case 11: WS(11);
+        case 17: WS(17);
         case 25: WS(25);
-        default: return fail("azg_nn_linear_ws: Kp/16 must be 1, 3, 4, 6, 11 or 25");
+        default: return fail("azg_nn_linear_ws: Kp/16 must be 1, 2, 3, 4, 6, 8, 11, 17 or 25");
     }
 #undef WS
 }
 
-extern "C" int azg_nn_dw_pool(float* H, int ldh, const float* Wd, const float* sd, const float* bd, float* pooled, int B,
-                              int E, int act, int pool_max, void* stream) {
+extern "C" int azg_nn_dw_pool_l(float* H, int ldh, const float* Wd, const float* sd, const float* bd, float* pooled, int B,
+                                int E, int L, int act, int pool_max, void* stream) {
     if (!H || !Wd || !pooled || B <= 0) return fail("azg_nn_dw_pool: null/empty argument");
     const long long total = (long long)B * E;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    k_dw_pool<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(H, ldh, Wd, sd, bd, pooled, B, E, act, pool_max);
+    if (L == 7) k_dw_pool<7><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(H, ldh, Wd, sd, bd, pooled, B, E, act, pool_max);
+    else if (L == 6) k_dw_pool<6><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(H, ldh, Wd, sd, bd, pooled, B, E, act, pool_max);
+    else return fail("azg_nn_dw_pool: token count must be 6 or 7");
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+extern "C" int azg_nn_dw_pool(float* H, int ldh, const float* Wd, const float* sd, const float* bd, float* pooled, int B,
+                              int E, int act, int pool_max, void* stream) {
+    return azg_nn_dw_pool_l(H, ldh, Wd, sd, bd, pooled, B, E, 7, act, pool_max, stream);
 }
 
 static constexpr size_t V80_LDS = (size_t)(112 * 60 + 112 * 172 + 2 * 16 * 172 + 16 * 52 + 64) * sizeof(float);
@@ -757,13 +768,17 @@ extern "C" int azg_nn_debug_phase_times(long long* out /* [4][16] */) {
 }
 #endif
 
-extern "C" int azg_nn_board_to_x(const int8_t* boards, float* x, int B, int C, void* stream) {
-    if (!boards || !x || B <= 0) return fail("azg_nn_board_to_x: null/empty argument");
-    const long long total = (long long)B * 7 * C;
+extern "C" int azg_nn_board_to_x_ld(const int8_t* boards, float* x, int B, int C, int L, int ldx, void* stream) {
+    if (!boards || !x || B <= 0 || L <= 0 || ldx < C) return fail("azg_nn_board_to_x: null/empty argument");
+    const long long total = (long long)B * L * ldx;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    k_board_to_x<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(boards, x, B, C);
+    k_board_to_x<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(boards, x, B, C, L, ldx);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+extern "C" int azg_nn_board_to_x(const int8_t* boards, float* x, int B, int C, void* stream) {
+    return azg_nn_board_to_x_ld(boards, x, B, C, 7, C, stream);
 }
 
 extern "C" int azg_nn_heads_out(const float* logits, int ldl, const uint8_t* valid, const float* vhid, int ldv,

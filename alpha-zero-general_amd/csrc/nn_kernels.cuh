@@ -261,34 +261,36 @@ __global__ __launch_bounds__(256) void k_linear_ws(const float* __restrict__ A, 
     }
 }
 
-// H[b*7 + m][c] <- act( sd[c] * sum_l Wd[m][l] * H[b*7 + l][c] + bd[c] );  pooled[b][c] = mean_m / max_m of the result
+// H[b*L + m][c] <- act( sd[c] * sum_l Wd[m][l] * H[b*L + l][c] + bd[c] );  pooled[b][c] = mean_m / max_m of the result
+// (L = 7 tokens for Splendor, 6 for Azul)
 // (LinearNormActivation depthwise + SqueezeExcitation1d pooling, SplendorNNet.py:148-187).  One (sample, channel) per
 // thread, channel-fastest => coalesced; wide grid for memory-level parallelism (2 x 19 MB of traffic at T = 4096).
+template <int L>
 __global__ __launch_bounds__(256) void k_dw_pool(float* __restrict__ H, int ldh, const float* __restrict__ Wd,
                                                  const float* __restrict__ sd, const float* __restrict__ bd,
                                                  float* __restrict__ pooled, int B, int E, int act, int pool_max) {
-    __shared__ float w[49];
-    if (threadIdx.x < 49) w[threadIdx.x] = Wd[threadIdx.x];
+    __shared__ float w[L * L];
+    if (threadIdx.x < L * L) w[threadIdx.x] = Wd[threadIdx.x];
     __syncthreads();
     const long long total = (long long)B * E;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int b = (int)(i / E), c = (int)(i - (long long)b * E);
-        float* base = H + (size_t)b * 7 * ldh + c;
-        float in[7];
+        float* base = H + (size_t)b * L * ldh + c;
+        float in[L];
 #pragma unroll
-        for (int l = 0; l < 7; l++) in[l] = base[(size_t)l * ldh];
+        for (int l = 0; l < L; l++) in[l] = base[(size_t)l * ldh];
         const float s = sd[c], bb = bd[c];
         float pool = pool_max ? -INFINITY : 0.f;
 #pragma unroll
-        for (int m = 0; m < 7; m++) {
+        for (int m = 0; m < L; m++) {
             float a = 0.f;
 #pragma unroll
-            for (int l = 0; l < 7; l++) a += w[m * 7 + l] * in[l];
+            for (int l = 0; l < L; l++) a += w[m * L + l] * in[l];
             a = act_apply(a * s + bb, act);
             base[(size_t)m * ldh] = a;
             pool = pool_max ? fmaxf(pool, a) : pool + a;
         }
-        pooled[(size_t)b * E + c] = pool_max ? pool : pool / 7.f;
+        pooled[(size_t)b * E + c] = pool_max ? pool : pool / (float)L;
     }
 }
 
@@ -748,12 +750,13 @@ __global__ __launch_bounds__(768) void k_v80_net(V80BlockW Wt, V80BlockW Wp, V80
     v80_block_body<2, 1, 3, true, false, false>(XT, H, nullptr, nullptr, nullptr, Wv, B, nullptr, Nv, nullptr, nullptr, v_out, P);
 }
 
-// boards int8 [B][C][7] (reference layout) -> x f32 [B][7][C] (channels-last)
-__global__ __launch_bounds__(256) void k_board_to_x(const int8_t* __restrict__ boards, float* __restrict__ x, int B, int C) {
-    const long long total = (long long)B * 7 * C;
+// boards int8 [B][C][L] (reference layout) -> x f32 [B][L][ldx] (channels-last; columns C..ldx-1 zeroed)
+__global__ __launch_bounds__(256) void k_board_to_x(const int8_t* __restrict__ boards, float* __restrict__ x, int B, int C,
+                                                    int L, int ldx) {
+    const long long total = (long long)B * L * ldx;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / (7 * C)), rem = (int)(i - (long long)b * 7 * C), l = rem / C, c = rem - l * C;
-        x[i] = (float)boards[(size_t)b * 7 * C + c * 7 + l];
+        const int b = (int)(i / (L * ldx)), rem = (int)(i - (long long)b * L * ldx), l = rem / ldx, c = rem - l * ldx;
+        x[i] = c < C ? (float)boards[(size_t)b * L * C + c * L + l] : 0.f;
     }
 }
 

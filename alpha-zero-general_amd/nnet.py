@@ -380,6 +380,149 @@ class AzulV84(SplendorV80):
         return torch.softmax(logits, dim=1).contiguous(), v.contiguous()
 
 
+class MobileNet1dHip:
+    """The MobileNetV3-1d policy/value nets of any geometry (Splendor V80 for 2-4 players: C = 32 + 10n + n^2 channels x 7
+    tokens; Azul V84: 23 channels x 6 tokens, AzulNNet.py:91-113) evaluated by the engine's gfx950 kernels instead of ~65
+    torch ops per leaf batch: azg_nn_board_to_x_ld, then per InvertedResidual1d block (SplendorNNet.py:189-202) expand GEMM
+    (bias + activation fused), depthwise+BN+act+squeeze, the two SE GEMMs and the project GEMM (SE scale on the operand,
+    bias, residual fused); flatten->Linear heads through the K-split GEMM; masked softmax / tanh tail.  17 launches.
+    Wraps a SplendorV80 / AzulV84 instance (folded-BN fp32 weights); channel counts are zero-padded to multiples of 4
+    (row strides) and of 16 (weight tiles), which leaves the results unchanged."""
+
+    _WS_CHUNKS = (1, 2, 3, 4, 6, 8, 11, 17, 25)
+
+    def __init__(self, base, max_batch=4096):
+        from . import _lib
+        self._lib = _lib
+        self.base = base
+        self.device = base.device
+        self.P, self.A, self.C = base.P, base.A, base.nb_vect
+        self.L = getattr(base, 'L', 7)
+        self.nb_vect = base.nb_vect
+        assert base.dtype == torch.float32 and self.device.type == 'cuda'
+        r4, r16 = (lambda n: (n + 3) // 4 * 4), (lambda n: (n + 15) // 16 * 16)
+        self.Cp = r4(self.C)
+        d = self.device
+
+        def padw(W, Kp, NP):
+            out = torch.zeros((Kp, NP), dtype=torch.float32, device=d)
+            out[:W.shape[0], :W.shape[1]] = W
+            return out
+
+        def padv(v, n):
+            out = torch.zeros(n, dtype=torch.float32, device=d)
+            out[:v.numel()] = v
+            return out
+        self.pW0, self.pb0 = padw(base.W0, r16(self.Cp), r16(self.C)), padv(base.b0, r16(self.C))
+        self.blocks = []
+        for blk in (base.trunk, base.head_pi, base.head_v):
+            cin, E = blk.We.shape
+            Q, cout = blk.W1.shape[1], blk.Wp.shape[1]
+            g = dict(cin=cin, cinp=r4(cin), E=E, Ep=r4(E), Q=Q, Qp=r16(Q), cout=cout, coutp=r4(cout), act=2 if blk.use_hs else 1,
+                     pool_max=0 if blk.setype == 'avg' else 1, res=cin == cout)
+            g['We'], g['be'] = padw(blk.We, r16(g['cinp']), r16(g['Ep'])), padv(blk.be, r16(g['Ep']))
+            g['Wd'], g['sd'], g['bd'] = blk.Wd.contiguous(), padv(blk.sd, g['Ep']), padv(blk.bd, g['Ep'])
+            g['W1'], g['b1'] = padw(blk.W1, r16(g['Ep']), g['Qp']), padv(blk.b1, g['Qp'])
+            g['W2'], g['b2'] = padw(blk.W2, g['Qp'], r16(g['Ep'])), padv(blk.b2, r16(g['Ep']))
+            g['Wp'], g['bp'] = padw(blk.Wp, r16(g['Ep']), r16(cout)), padv(blk.bp, r16(cout))
+            self.blocks.append(g)
+        L = self.L
+
+        def flat(W, cout, coutp):          # rows l*cout + c  ->  l*coutp + c (pad rows zero), then tile padding
+            N = W.shape[1]
+            w = torch.zeros((L, coutp, N), dtype=torch.float32, device=d)
+            w[:, :cout] = W.view(L, cout, N)
+            return padw(w.view(L * coutp, N), r16(L * coutp), r16(N))
+        gp, gv = self.blocks[1], self.blocks[2]
+        self.Ap = r16(self.A)
+        self.pWpi1, self.pWpi2 = flat(base.Wpi1, gp['cout'], gp['coutp']), padw(base.Wpi2, self.Ap, self.Ap)
+        self.pWv1 = flat(base.Wv1, gv['cout'], gv['coutp'])
+        self.bpi1, self.bpi2, self.bv1 = base.bpi1.contiguous(), base.bpi2.contiguous(), base.bv1.contiguous()
+        self.Wv2, self.bv2 = base.Wv2.contiguous(), base.bv2.contiguous()
+        self._alloc(max_batch)
+
+    def _alloc(self, B):
+        d, f = self.device, torch.float32
+        self.maxB = B
+        M = B * self.L
+        z = lambda *shape: torch.zeros(shape, dtype=f, device=d)  # noqa: E731   (pad columns must stay zero)
+        self.x0, self.x1, self.x2 = z(M, self.Cp), z(M, self.Cp), z(M, self.blocks[0]['coutp'])
+        Epm, Qpm = max(g['Ep'] for g in self.blocks), max(g['Qp'] for g in self.blocks)
+        self.h, self.pooled, self.sc, self.se_h = z(M * Epm), z(B * Epm), z(B * Epm), z(B * Qpm)
+        self.xh_pi, self.xh_v = z(M * self.blocks[1]['coutp']), z(M * self.blocks[2]['coutp'])
+        self.hid_pi, self.logits, self.hid_v = z(B, self.Ap), z(B, self.Ap), z(B, 16)
+        self.pi = torch.empty((B, self.A), dtype=f, device=d)
+        self.v = torch.empty((B, self.P), dtype=f, device=d)
+
+    def clone_buffers(self):
+        import copy
+        other = copy.copy(self)
+        other._alloc(self.maxB)
+        return other
+
+    def _lin(self, A, lda, Wp, bias_p, out, ldc, M, K, N, act=0, R=None, ldr=0, rowscale=None, rpg=0, ksplit=False):
+        import ctypes as C
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        L = self._lib.lib()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        Kp, NP = Wp.shape
+        if not ksplit and Kp // 16 in self._WS_CHUNKS:
+            self._lib.check(L.azg_nn_linear_ws(p(A), lda, p(Wp), Kp, NP, p(bias_p), p(R), ldr, p(rowscale), rpg, p(out), ldc,
+                                               M, K, N, act, st))
+        else:
+            self._lib.check(L.azg_nn_linear(p(A), lda, p(Wp), Kp, NP, p(bias_p), p(R), ldr, p(rowscale), rpg, p(out), ldc,
+                                            M, K, N, act, 1 if ksplit else 0, st))
+
+    def _block(self, g, xin, xout, B):
+        import ctypes as C
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        M, Ep = B * self.L, g['Ep']
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._lin(xin, g['cinp'], g['We'], g['be'], self.h, Ep, M, g['cinp'], Ep, act=g['act'])
+        self._lib.check(self._lib.lib().azg_nn_dw_pool_l(p(self.h), Ep, p(g['Wd']), p(g['sd']), p(g['bd']), p(self.pooled), B,
+                                                         Ep, self.L, g['act'], g['pool_max'], st))
+        self._lin(self.pooled, Ep, g['W1'], g['b1'], self.se_h, g['Qp'], B, Ep, g['Q'], act=1)
+        self._lin(self.se_h, g['Qp'], g['W2'], g['b2'], self.sc, Ep, B, g['Qp'], Ep, act=3)
+        self._lin(self.h, Ep, g['Wp'], g['bp'], xout, g['coutp'], M, Ep, g['cout'], R=xin if g['res'] else None,
+                  ldr=g['cinp'], rowscale=self.sc, rpg=self.L)
+
+    @torch.no_grad()
+    def forward(self, boards, valids):
+        import ctypes as C
+        B = boards.shape[0]
+        if B > self.maxB:
+            self._alloc(B)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        Lb = self._lib.lib()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        boards = boards.reshape(B, -1)
+        assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda
+        valids = valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)
+        self._lib.check(Lb.azg_nn_board_to_x_ld(p(boards), p(self.x0), B, self.C, self.L, self.Cp, st))
+        self._lin(self.x0, self.Cp, self.pW0, self.pb0, self.x1, self.Cp, B * self.L, self.Cp, self.C)       # first_layer
+        gt, gp, gv = self.blocks
+        self._block(gt, self.x1, self.x2, B)
+        self._block(gp, self.x2, self.xh_pi, B)
+        Kp1 = self.L * gp['coutp']
+        self._lin(self.xh_pi, Kp1, self.pWpi1, self.bpi1, self.hid_pi, self.Ap, B, Kp1, self.A, act=1, ksplit=True)
+        self._lin(self.hid_pi, self.Ap, self.pWpi2, self.bpi2, self.logits, self.Ap, B, self.Ap, self.A, ksplit=True)
+        self._block(gv, self.x2, self.xh_v, B)
+        Kv1 = self.L * gv['coutp']
+        self._lin(self.xh_v, Kv1, self.pWv1, self.bv1, self.hid_v, 16, B, Kv1, self.P, ksplit=True)
+        self._lib.check(Lb.azg_nn_heads_out(p(self.logits), self.Ap, p(valids), p(self.hid_v), 16, p(self.Wv2), p(self.bv2),
+                                            p(self.pi), p(self.v), B, self.A, self.P, st))
+        return self.pi[:B], self.v[:B]
+
+    def predict_batch(self, boards, valids):
+        return self.forward(boards, valids)
+
+    def predict(self, board, valid_actions):
+        b = torch.as_tensor(np.asarray(board, dtype=np.int8)).reshape(1, -1).to(self.device)
+        va = torch.as_tensor(np.asarray(valid_actions).astype(np.uint8)).reshape(1, -1).to(self.device)
+        pi, v = self.forward(b, va)
+        return pi[0].cpu().numpy(), v[0].cpu().numpy()
+
+
 class SantoriniV89:
     """santorini/SantoriniNNet.py nn_version 88/89 (:194-219,273-281; SimpleResBlock :71-84, SimpleHead :17-40): the 2
     spatial planes (workers, levels) of the (5,5,3) board -> conv3x3(2->64)+BN+ReLU -> 5 residual blocks -> 1x1-conv heads.

@@ -111,6 +111,29 @@ def cpu_baseline(sims, seconds=15.0, n_par=8):
                 sims_per_sec=sims_done / dt, host_cores_available=os.cpu_count())
 
 
+def cpu_baseline_multi(sims, seconds, procs):
+    """the CPU path on several host cores = `procs` independent single-thread copies of cpu_baseline (one
+    process per core, 8 games each, like the reference's one-process-per-core self-play), summed."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', '--sims', str(sims), '--cpu-seconds', str(seconds)]
+    ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                           env=dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1')) for _ in range(procs)]
+    rs = []
+    for p in ps:
+        out, _ = p.communicate(timeout=seconds * 4 + 600)
+        try:
+            rs.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:
+            pass
+    if not rs:
+        return cpu_baseline(sims, seconds)
+    one = rs[0]
+    return dict(value=sum(r['value'] for r in rs), unit='env-steps/sec', cores=len(rs), kind='port',
+                sample='%d processes x (%s)' % (len(rs), one['sample']),
+                sims_per_sec=sum(r['sims_per_sec'] for r in rs), per_core=sum(r['value'] for r in rs) / len(rs),
+                host_cores_available=os.cpu_count())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -134,9 +157,15 @@ def main():
                          'full and numMCTSSims//5 searches (main.py), a secondary figure')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--cpu-procs', type=int, default=1,
+                    help='cpu_baseline on this many host cores (independent single-thread processes, summed); 1 = scalar port')
+    ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--roofline-rounds', type=int, default=300)
     ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'r01c_traffic.json'))
     a = ap.parse_args()
+    if a.cpu_worker:
+        print(json.dumps(cpu_baseline(a.sims, a.cpu_seconds)))
+        return
 
     import torch
     import torch.distributed as dist
@@ -173,7 +202,11 @@ def main():
                 'azul': lambda: games.AzulGame(device=dev)}[a.game]()
         nkw = dict(num_players=4) if a.game == 'splendor4' else {}
         net = getattr(_nn, og['net']).from_npz(os.path.join(ROOT, 'tests', 'golden', og['weights']), device=dev, dtype=dtype, **nkw)
-        a.net = 'torch'
+        if a.net == 'hip' and og['net'] in ('SplendorV80', 'AzulV84') and a.net_dtype == 'fp32':
+            net = _nn.MobileNet1dHip(net, max_batch=T // a.groups)        # engine GEMM / depthwise / head kernels
+            og = dict(og, label=og['label'] + ' (engine kernels)')
+        else:
+            a.net = 'torch'
         label = og['label']
         pretrained = True
     else:
@@ -296,7 +329,8 @@ def main():
     if roof:
         out['roofline'] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.game == 'splendor2':
-        out['cpu_baseline'] = cpu_baseline(a.sims, a.cpu_seconds)
+        out['cpu_baseline'] = (cpu_baseline_multi(a.sims, a.cpu_seconds, a.cpu_procs) if a.cpu_procs > 1
+                               else cpu_baseline(a.sims, a.cpu_seconds))
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

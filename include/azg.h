@@ -205,6 +205,9 @@ int azg_nn_linear_ws(const float* A_dev, int lda, const float* Wp_dev, int Kp, i
    hardsigmoid(relu(pooled @ W1 + b1) @ W2 + b2) is two azg_nn_linear calls (act 1, then act 3 = Hardsigmoid). */
 int azg_nn_dw_pool(float* H_dev, int ldh, const float* Wd_dev /*[7][7] out,in*/, const float* bn_scale_dev,
                    const float* bn_bias_dev, float* pooled_dev, int B, int E, int act, int pool_max, void* stream);
+/* the same for L tokens per sample (7: Splendor boards [C][7]; 6: Azul boards [23][6], AzulNNet.py:91-113) */
+int azg_nn_dw_pool_l(float* H_dev, int ldh, const float* Wd_dev /*[L][L] out,in*/, const float* bn_scale_dev,
+                     const float* bn_bias_dev, float* pooled_dev, int B, int E, int L, int act, int pool_max, void* stream);
 /* One fused InvertedResidual1d block of the V80 net (SplendorNNet.py:189-202: expand + depthwise + SE + project +
    residual) for x[B*7][56] -> out[B*7][56]; the 168-wide expanded activations stay in LDS.  w = 11 HOST-array device
    pointers {We[64][176], be[176], Wd[7][7], bn_scale[168], bn_bias[168], W1[176][48], b1[48], W2[48][176], b2[176],
@@ -225,6 +228,8 @@ int azg_nn_v80_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const
                        float* x_trunk_dev, float* pi_dev, float* v_dev, void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
 int azg_nn_board_to_x(const int8_t* boards_dev, float* x_dev, int B, int C, void* stream);
+/* boards int8 [B][C][L] -> x f32 [B][L][ldx], columns C..ldx-1 zeroed (row stride padded to a multiple of 4 floats) */
+int azg_nn_board_to_x_ld(const int8_t* boards_dev, float* x_dev, int B, int C, int L, int ldx, void* stream);
 /* pi = softmax(where(valid, logits, -1e8)) (== exp(log_softmax), GenericNNetWrapper.py:107); v = tanh(relu(vhid) @ Wv2 + bv2) */
 int azg_nn_heads_out(const float* logits_dev, int ldl, const uint8_t* valid_dev, const float* vhid_dev, int ldv,
                      const float* Wv2_dev, const float* bv2_dev, float* pi_dev, float* v_dev, int B, int A, int P,

@@ -173,3 +173,34 @@ def test_v80_4p_forward_cpu():
 @pytest.mark.gpu
 def test_v80_4p_forward_gpu():
     _check_v80_4p('cuda:0')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['splendor2_v80', 'splendor4_v80', 'azul_v84'])
+def test_mobilenet1d_engine_kernels_gpu(tag):
+    """MobileNet1dHip (engine GEMM / depthwise / head kernels, any geometry) vs the reference models' golden outputs, and at
+    a batch that is not a multiple of the 16-row tiles vs the torch-ops evaluation of the same weights."""
+    from azg_amd import nnet
+    root = os.path.join(os.path.dirname(__file__), 'golden')
+    if tag == 'azul_v84':
+        base = nnet.AzulV84.from_npz(os.path.join(root, 'weights_%s.npz' % tag), device='cuda:0')
+    else:
+        npl = 4 if tag.startswith('splendor4') else 2
+        base = nnet.SplendorV80.from_npz(os.path.join(root, 'weights_%s.npz' % tag), num_players=npl, device='cuda:0')
+    net = nnet.MobileNet1dHip(base, max_batch=64)
+    d = np.load(os.path.join(root, 'netfwd_%s.npz' % tag))
+    boards = torch.from_numpy(d['boards']).to('cuda:0')
+    masks = torch.from_numpy(d['masks']).to('cuda:0')
+    pi, v = net.predict_batch(boards.to(torch.int8), masks)
+    assert np.allclose(pi.cpu().numpy(), d['pi'], atol=1e-5, rtol=0)
+    assert np.allclose(v.cpu().numpy(), d['v'], atol=3e-5 if tag == 'azul_v84' else 1e-5, rtol=0)
+    # ragged batch (B * L not a multiple of 16), larger than max_batch (buffers regrow), random boards
+    g = torch.Generator().manual_seed(5)
+    B = 203
+    rb = torch.randint(0, 6, (B,) + tuple(boards.shape[1:]), generator=g, dtype=torch.int8).to('cuda:0')
+    rm = (torch.rand((B, masks.shape[1]), generator=g) < 0.4).to('cuda:0')
+    rm[:, -1] = True
+    pi2, v2 = net.predict_batch(rb, rm)
+    pr, vr = base.predict_batch(rb, rm)
+    assert float((pi2 - pr).abs().max()) < 1e-5 and float((v2 - vr).abs().max()) < 3e-5
+    assert float(pi2[~rm].abs().max()) == 0.0
