@@ -12,6 +12,7 @@
 #include "game_azul.cuh"
 #include "selfplay.cuh"
 #include "nn_kernels.cuh"
+#include "nn_mb1d.cuh"
 
 using namespace azg;
 
@@ -767,6 +768,48 @@ extern "C" int azg_nn_debug_phase_times(long long* out /* [4][16] */) {
     return 0;
 }
 #endif
+
+// ---- whole MobileNet-1d forward, any supported geometry, one launch (nn_mb1d.cuh) ----
+//                        L   C  NS    A  P   E0   E1   E2  Q0  Q1  Q2 CO1 A0 A12 PMAX
+typedef Mb1dCfg<7, 56, 8, 81, 2, 168, 168, 168, 40, 40, 40, 56, 1, 2, 1> CfgSplendor2;
+typedef Mb1dCfg<7, 71, 8, 81, 3, 213, 213, 213, 56, 56, 56, 71, 1, 2, 1> CfgSplendor3;
+typedef Mb1dCfg<7, 88, 8, 81, 4, 264, 264, 264, 64, 64, 64, 88, 1, 2, 1> CfgSplendor4;
+typedef Mb1dCfg<6, 23, 16, 180, 2, 115, 115, 46, 32, 32, 16, 46, 1, 2, 0> CfgAzul;
+
+template <class CF>
+static int launch_mb1d(const Mb1dNetW& N, const int8_t* boards, const uint8_t* valid, int B, float* pi, float* v, hipStream_t s) {
+    constexpr size_t lds = (size_t)CF::LDS_FLOATS * sizeof(float);
+    static_assert(lds <= 160 * 1024, "geometry does not fit the LDS of a CU");
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_mb1d_net<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    k_mb1d_net<CF><<<dim3((B + CF::NS - 1) / CF::NS), dim3(768), lds, s>>>(N, boards, valid, B, pi, v);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_nn_mb1d_forward(int geometry, const int8_t* boards, const uint8_t* valid, const float* const* w, int B,
+                                   float* pi, float* v, void* stream) {
+    if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_mb1d_forward: null/empty argument");
+    Mb1dNetW N;
+    N.W0 = w[0]; N.b0 = w[1];
+    for (int b = 0; b < 3; b++) {
+        const float* const* q = w + 2 + 11 * b;
+        N.blk[b] = Mb1dBlockW{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10]};
+    }
+    const float* const* h = w + 35;
+    N.Wpi1 = h[0]; N.bpi1 = h[1]; N.Wpi2 = h[2]; N.bpi2 = h[3]; N.Wv1 = h[4]; N.bv1 = h[5]; N.Wv2 = h[6]; N.bv2 = h[7];
+    hipStream_t s = (hipStream_t)stream;
+    switch (geometry) {
+        case AZG_NET_SPLENDOR2: return launch_mb1d<CfgSplendor2>(N, boards, valid, B, pi, v, s);
+        case AZG_NET_SPLENDOR3: return launch_mb1d<CfgSplendor3>(N, boards, valid, B, pi, v, s);
+        case AZG_NET_SPLENDOR4: return launch_mb1d<CfgSplendor4>(N, boards, valid, B, pi, v, s);
+        case AZG_NET_AZUL: return launch_mb1d<CfgAzul>(N, boards, valid, B, pi, v, s);
+        default: return fail("azg_nn_mb1d_forward: unknown geometry");
+    }
+}
 
 extern "C" int azg_nn_board_to_x_ld(const int8_t* boards, float* x, int B, int C, int L, int ldx, void* stream) {
     if (!boards || !x || B <= 0 || L <= 0 || ldx < C) return fail("azg_nn_board_to_x: null/empty argument");

@@ -1,0 +1,305 @@
+// nn_mb1d.cuh -- the MobileNetV3-1d policy/value net (splendor/SplendorNNet.py:259-283,397-440 for 2-4 players,
+// azul/AzulNNet.py:91-113,130-142) as ONE launch for any geometry: the generic sibling of k_v80_net (nn_kernels.cuh), which
+// is hand-laid-out for the 2-player Splendor shape.  Same data flow -- a workgroup owns NS samples, every activation lives
+// in LDS, all GEMMs are v_mfma_f32_16x16x4_f32 with the weight tile as the A operand (fragment order, see FRAG) and the
+// activations as the B operand read as float4 from LDS -- but tile loops instead of a fixed wave->tile map:
+//   first layer -> trunk block (X -> X2) -> policy block (X2 -> O) + Linear/ReLU/Linear/masked softmax
+//                                        -> value  block (X2 -> O) + Linear/ReLU/Linear/tanh
+// Channel counts are zero-padded to multiples of 16 (weights, biases) so no bounds logic is needed inside the GEMMs; LDS
+// rows carry 4 floats of padding (row stride = 4 mod 8 floats: conflict-free float4 fragment reads).  The LDS is cleared
+// once at kernel start: every padding element that a K loop can reach is then a finite number times a zero weight.
+#pragma once
+#include "nn_kernels.cuh"
+
+namespace azg {
+
+#pragma clang fp contract(fast)
+
+struct Mb1dBlockW { const float *We, *be, *Wd, *sd, *bd, *W1, *b1, *W2, *b2, *Wp, *bp; };
+struct Mb1dNetW {
+    const float *W0, *b0;
+    Mb1dBlockW blk[3];                                  // trunk, policy head, value head
+    const float *Wpi1, *bpi1, *Wpi2, *bpi2;             // [L*OS -> A] (rows l*OS + c), [A -> A]      fragment order
+    const float *Wv1, *bv1, *Wv2, *bv2;                 // [L*OS -> P] fragment order; Wv2 [P][P] plain (in, out)
+};
+
+constexpr int mb_r16(int n) { return (n + 15) / 16 * 16; }
+
+// Geometry of one net.  E / Q / CO / ACT / PMAX per block (trunk, policy head, value head).
+template <int L_, int C_, int NS_, int A_, int P_, int E0, int E1, int E2, int Q0, int Q1, int Q2, int CO1, int ACT0, int ACT12,
+          int PMAX12>
+struct Mb1dCfg {
+    static constexpr int L = L_, C = C_, NS = NS_, A = A_, P = P_, NW = 12;
+    static constexpr int E[3] = {E0, E1, E2}, Q[3] = {Q0, Q1, Q2}, CO[3] = {C_, CO1, C_};
+    static constexpr int ACT[3] = {ACT0, ACT12, ACT12}, PMAX[3] = {0, PMAX12, PMAX12};
+    static constexpr int ROWS = NS * L, ROWSP = mb_r16(ROWS), RT = ROWSP / 16;
+    static constexpr int CP = mb_r16(C), XS = CP + 4;
+    static constexpr int COPmax = mb_r16(CO1 > C_ ? CO1 : C_), OS = COPmax + 4;     // head block output row stride
+    static constexpr int EPmax = mb_r16(E0 > E1 ? (E0 > E2 ? E0 : E2) : (E1 > E2 ? E1 : E2)), HS = EPmax + 4;
+    static constexpr int QPmax = mb_r16(Q0 > Q1 ? (Q0 > Q2 ? Q0 : Q2) : (Q1 > Q2 ? Q1 : Q2)), QS = QPmax + 4;
+    static constexpr int AP = mb_r16(A), AS = AP + 4;
+    // LDS map (floats)
+    static constexpr int XA_SZ = ROWSP * (XS > OS ? XS : OS), X2_SZ = ROWSP * XS, H_SZ = ROWSP * HS;
+    static constexpr int PL_SZ = NS * HS, SC_SZ = (ROWSP / L + 1) * HS, SH_SZ = 16 * QS;
+    static constexpr int KS_PI = AP / 16 >= NW ? 1 : NW / (AP / 16);    // K slices of the policy head GEMMs
+    static constexpr int HEAD_PI = (KS_PI + 1) * 16 * AS, HEAD_V = NW * 16 * 20;     // RED[KS][16][AS] + HID; value RED[NW][16][20]
+    static constexpr int HEAD_SZ = HEAD_PI > HEAD_V ? HEAD_PI : HEAD_V;              // aliases H
+    static constexpr int H_ALLOC = H_SZ > HEAD_SZ ? H_SZ : HEAD_SZ;
+    static constexpr int LDS_FLOATS = XA_SZ + X2_SZ + H_ALLOC + PL_SZ + SC_SZ + SH_SZ + 64;
+};
+
+// One GEMM phase over the workgroup:  out(row, 16*ct + 4g .. +3) = epi( sum_k in[row][k] * W[k][col] )
+//   KCH K-chunks of 16, NT column tiles, RTN row tiles; loadB(rt, c) returns this lane's float4 of the B operand
+//   (activation row rt*16 + r16, K offset 16c + 4g); epi(ct, rt, acc) consumes the C tile (lane: row r16, 4 columns).
+// NT >= NW: wave w owns column tiles w, w + NW, ... and all row tiles (weights stationary in registers).
+// NT <  NW: NW / NT waves share a column tile and split its row tiles.
+template <int KCH, int NT, int RTN, int NW, class LoadB, class Epi>
+__device__ __forceinline__ void mb_gemm(const float* __restrict__ Wfrag, LoadB loadB, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int G = NT >= NW ? 1 : NW / NT;            // waves per column tile
+    const int sub = NT >= NW ? 0 : wave / NT;
+    if (NT < NW && sub >= G) return;
+    for (int ct = NT >= NW ? wave : wave % NT; ct < NT; ct += NW) {
+        float4 w[KCH];
+#pragma unroll
+        for (int c = 0; c < KCH; c++) w[c] = FRAG(Wfrag, KCH, ct, c);
+#pragma unroll 1
+        for (int rt = sub; rt < RTN; rt += G) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < KCH; c++) {
+                const float4 a = loadB(rt, c);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].w, a.w, acc, 0, 0, 0);
+            }
+            epi(ct, rt, acc);
+        }
+        if (NT < NW) break;
+    }
+}
+
+// Flatten -> Linear on one 16-row tile (rows = samples): K is long and every weight is used once, so the fragments are
+// streamed; the NW waves split (column tile, K slice) and leave partial sums in RED[slice][16][AS].  Returns the slice count.
+template <int KCH, int NT, int NW, int AS, int NROWS>
+__device__ __forceinline__ int mb_head_gemm(const float* __restrict__ Wfrag, const float* __restrict__ in, int ldi,
+                                            float* __restrict__ RED) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int rr = r16 < NROWS ? r16 : 0;                // rows >= NROWS do not exist: recompute row 0, never used
+    constexpr int KS = NT >= NW ? 1 : NW / NT;           // K slices
+    constexpr int PER = (KCH + KS - 1) / KS;
+    for (int u = wave; u < NT * KS; u += NW) {
+        const int ct = u % NT, ks = u / NT;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c_end = (ks + 1) * PER < KCH ? (ks + 1) * PER : KCH;
+#pragma unroll 4
+        for (int c = ks * PER; c < c_end; c++) {
+            const float4 w = FRAG(Wfrag, KCH, ct, c);
+            const float4 a = *(const float4*)(in + rr * ldi + 16 * c + 4 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a.w, acc, 0, 0, 0);
+        }
+        *(float4*)(RED + (ks * 16 + r16) * AS + ct * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    return KS;
+}
+
+// InvertedResidual1d block bi (SplendorNNet.py:189-202): IN [ROWSP][XS] -> OUT [..][OSTRIDE]
+template <class CF, int BI, int CIN_P, int OSTRIDE>
+__device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, float* OUT, float* H, float* PL, float* SC,
+                                         float* SH, float* WD, bool residual) {
+    constexpr int L = CF::L, NS = CF::NS, NW = CF::NW, RT = CF::RT, XS = CF::XS, HS = CF::HS, QS = CF::QS;
+    constexpr int EP = mb_r16(CF::E[BI]), QP = mb_r16(CF::Q[BI]), COP = mb_r16(CF::CO[BI]);
+    constexpr int ACT = CF::ACT[BI], PMAX = CF::PMAX[BI];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
+    if (tid < L * L) WD[tid] = W.Wd[tid];
+    // ---- expand + BN + act -> H ----
+    mb_gemm<CIN_P / 16, EP / 16, RT, NW>(
+        W.We, [&](int rt, int c) { return *(const float4*)(IN + (rt * 16 + r16) * XS + 16 * c + 4 * g); },
+        [&](int ct, int rt, f32x4 acc) {
+            const float4 b = *(const float4*)(W.be + ct * 16 + 4 * g);
+            const f32x2 lo = act_apply2(f32x2{acc[0] + b.x, acc[1] + b.y}, ACT), hi = act_apply2(f32x2{acc[2] + b.z, acc[3] + b.w}, ACT);
+            *(float4*)(H + (rt * 16 + r16) * HS + ct * 16 + 4 * g) = make_float4(lo.x, lo.y, hi.x, hi.y);
+        });
+    __syncthreads();
+    // ---- depthwise Linear(L->L) over the tokens + BN + act (in place) + SE squeeze ----
+    {
+        float wd[L * L];
+#pragma unroll
+        for (int k = 0; k < L * L; k++) wd[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, WD[k])));
+        for (int i = tid; i < NS * (EP / 2); i += NW * 64) {
+            const int s = i / (EP / 2), c = 2 * (i - s * (EP / 2));
+            float* base = H + (s * L) * HS + c;
+            f32x2 in[L];
+#pragma unroll
+            for (int l = 0; l < L; l++) in[l] = *(const f32x2*)(base + l * HS);
+            const f32x2 scl = *(const f32x2*)(W.sd + c), bb = *(const f32x2*)(W.bd + c);
+            f32x2 pool = PMAX ? f32x2{-INFINITY, -INFINITY} : f32x2{0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < L; m++) {
+                f32x2 a = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int l = 0; l < L; l++) a += wd[m * L + l] * in[l];
+                a = act_apply2(a * scl + bb, ACT);
+                *(f32x2*)(base + m * HS) = a;
+                if (PMAX) { pool.x = fmaxf(pool.x, a.x); pool.y = fmaxf(pool.y, a.y); } else pool += a;
+            }
+            if (!PMAX) pool = pool * (1.f / (float)L);
+            *(f32x2*)(PL + s * HS + c) = pool;
+        }
+    }
+    __syncthreads();
+    // ---- SE fc1 + ReLU -> SH[16][QS];  SE fc2 + Hardsigmoid -> SC[.][HS]  (rows = samples; rows >= NS are scratch) ----
+    mb_gemm<EP / 16, QP / 16, 1, NW>(
+        W.W1, [&](int, int c) { return *(const float4*)(PL + r16 * HS + 16 * c + 4 * g); },
+        [&](int ct, int, f32x4 acc) {
+            const float4 b = *(const float4*)(W.b1 + ct * 16 + 4 * g);
+            *(float4*)(SH + r16 * QS + ct * 16 + 4 * g) =
+                make_float4(fmaxf(acc[0] + b.x, 0.f), fmaxf(acc[1] + b.y, 0.f), fmaxf(acc[2] + b.z, 0.f), fmaxf(acc[3] + b.w, 0.f));
+        });
+    __syncthreads();
+    mb_gemm<QP / 16, EP / 16, 1, NW>(
+        W.W2, [&](int, int c) { return *(const float4*)(SH + r16 * QS + 16 * c + 4 * g); },
+        [&](int ct, int, f32x4 acc) {
+            if (r16 < NS) {
+                const float4 b = *(const float4*)(W.b2 + ct * 16 + 4 * g);
+                *(float4*)(SC + r16 * HS + ct * 16 + 4 * g) =
+                    make_float4(hardsigmoid(acc[0] + b.x), hardsigmoid(acc[1] + b.y), hardsigmoid(acc[2] + b.z), hardsigmoid(acc[3] + b.w));
+            }
+        });
+    __syncthreads();
+    // ---- project (SE-scaled operand) + BN (+ residual) -> OUT ----
+    mb_gemm<EP / 16, COP / 16, RT, NW>(
+        W.Wp,
+        [&](int rt, int c) {
+            const int row = rt * 16 + r16;
+            float4 a = *(const float4*)(H + row * HS + 16 * c + 4 * g);
+            const float4 s4 = *(const float4*)(SC + (row / L) * HS + 16 * c + 4 * g);
+            a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
+            return a;
+        },
+        [&](int ct, int rt, f32x4 acc) {
+            const int row = rt * 16 + r16, col0 = ct * 16 + 4 * g;
+            const float4 b = *(const float4*)(W.bp + col0);
+            float4 o = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
+            if (residual) {
+                const float4 x = *(const float4*)(IN + row * XS + col0);
+                o.x += x.x; o.y += x.y; o.z += x.z; o.w += x.w;
+            }
+            *(float4*)(OUT + row * OSTRIDE + col0) = o;
+        });
+    __syncthreads();
+}
+
+template <class CF>
+__global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __restrict__ boards,
+                                                  const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
+                                                  float* __restrict__ v_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int L = CF::L, C = CF::C, NS = CF::NS, NW = CF::NW, RT = CF::RT, XS = CF::XS, OS = CF::OS, HS = CF::HS, A = CF::A,
+                  P = CF::P, AS = CF::AS, CP = CF::CP;
+    float* XA = smem;                       // first-layer output, later the head blocks' output O (row stride OS)
+    float* X2 = XA + CF::XA_SZ;             // trunk output
+    float* H = X2 + CF::X2_SZ;              // expanded activations; board tile before, head temporaries after
+    float* PL = H + CF::H_ALLOC;
+    float* SC = PL + CF::PL_SZ;
+    float* SH = SC + CF::SC_SZ;
+    float* WD = SH + CF::SH_SZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
+
+    for (int i = tid; i < CF::LDS_FLOATS / 4; i += NW * 64) ((float4*)smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // ---- board tile int8 [s][c][l] -> X0[s*L + l][c] f32 (in H), first layer (+BN) -> XA ----
+    float* X0 = H;
+    {
+        const int8_t* src = boards + (size_t)b0 * (C * L);
+        for (int i = tid; i < nb * C * L; i += NW * 64) {
+            const int s = i / (C * L), rem = i - s * (C * L), c = rem / L, l = rem - c * L;
+            X0[(s * L + l) * XS + c] = (float)src[i];
+        }
+    }
+    __syncthreads();
+    mb_gemm<CP / 16, CP / 16, RT, NW>(
+        N.W0, [&](int rt, int c) { return *(const float4*)(X0 + (rt * 16 + r16) * XS + 16 * c + 4 * g); },
+        [&](int ct, int rt, f32x4 acc) {
+            const float4 b = *(const float4*)(N.b0 + ct * 16 + 4 * g);
+            *(float4*)(XA + (rt * 16 + r16) * XS + ct * 16 + 4 * g) = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
+        });
+    __syncthreads();
+    mb_block<CF, 0, CP, XS>(N.blk[0], XA, X2, H, PL, SC, SH, WD, true);
+
+    // ================= policy head =================
+    mb_block<CF, 1, CP, OS>(N.blk[1], X2, XA, H, PL, SC, SH, WD, CF::CO[1] == C);
+    {
+        constexpr int KCH1 = (L * OS + 15) / 16, NT1 = CF::AP / 16;
+        float* RED = H;
+        float* HID = RED + CF::KS_PI * 16 * AS;
+        const int ks1 = mb_head_gemm<KCH1, NT1, NW, AS, NS>(N.Wpi1, XA, L * OS, RED);
+        __syncthreads();
+        for (int i = tid; i < 16 * (CF::AP / 4); i += NW * 64) {
+            const int s = i / (CF::AP / 4), col = 4 * (i - s * (CF::AP / 4));
+            float4 v = *(const float4*)(N.bpi1 + col);
+            for (int k = 0; k < ks1; k++) {
+                const float4 p = *(const float4*)(RED + (k * 16 + s) * AS + col);
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            *(float4*)(HID + s * AS + col) = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        }
+        __syncthreads();
+        const int ks2 = mb_head_gemm<NT1, NT1, NW, AS, 16>(N.Wpi2, HID, AS, RED);
+        __syncthreads();
+        // masked softmax == exp(log_softmax(where(valid, logits, -1e8))) (GenericNNetWrapper.py:105-107), one wave per sample
+        for (int s = wave; s < nb; s += NW) {
+            const int b = b0 + s;
+            float x[(A + 63) / 64];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < (A + 63) / 64; k++) {
+                const int a = lane + 64 * k;
+                x[k] = -INFINITY;
+                if (a < A) {
+                    float lg = N.bpi2[a];
+                    for (int q = 0; q < ks2; q++) lg += RED[(q * 16 + s) * AS + a];
+                    x[k] = valid[(size_t)b * A + a] ? lg : -1e8f;
+                }
+                mx = fmaxf(mx, x[k]);
+            }
+            mx = nn_wave_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < (A + 63) / 64; k++) { x[k] = (lane + 64 * k < A) ? expf(x[k] - mx) : 0.f; sum += x[k]; }
+            sum = nn_wave_sum(sum);
+#pragma unroll
+            for (int k = 0; k < (A + 63) / 64; k++)
+                if (lane + 64 * k < A) pi_out[(size_t)b * A + lane + 64 * k] = x[k] / sum;
+        }
+        __syncthreads();
+    }
+
+    // ================= value head =================
+    mb_block<CF, 2, CP, OS>(N.blk[2], X2, XA, H, PL, SC, SH, WD, true);
+    {
+        constexpr int KCH1 = (L * OS + 15) / 16;
+        float* RED = H;                      // [NW][16][20]
+        const int ks = mb_head_gemm<KCH1, 1, NW, 20, NS>(N.Wv1, XA, L * OS, RED);
+        __syncthreads();
+        if (tid < nb * P) {
+            const int s = tid / P, p = tid - s * P;
+            float a = N.bv2[p];
+            for (int j = 0; j < P; j++) {
+                float h = N.bv1[j];
+                for (int w = 0; w < ks; w++) h += RED[(w * 16 + s) * 20 + j];
+                a += fmaxf(h, 0.f) * N.Wv2[j * P + p];
+            }
+            v_out[(size_t)(b0 + s) * P + p] = tanhf(a);
+        }
+    }
+}
+
+#pragma clang fp contract(off)
+
+}  // namespace azg

@@ -391,7 +391,7 @@ class MobileNet1dHip:
 
     _WS_CHUNKS = (1, 2, 3, 4, 6, 8, 11, 17, 25)
 
-    def __init__(self, base, max_batch=4096):
+    def __init__(self, base, max_batch=4096, fused=True):
         from . import _lib
         self._lib = _lib
         self.base = base
@@ -439,7 +439,35 @@ class MobileNet1dHip:
         self.pWv1 = flat(base.Wv1, gv['cout'], gv['coutp'])
         self.bpi1, self.bpi2, self.bv1 = base.bpi1.contiguous(), base.bpi2.contiguous(), base.bv1.contiguous()
         self.Wv2, self.bv2 = base.Wv2.contiguous(), base.bv2.contiguous()
+        self.geometry = {(7, 56): 0, (7, 71): 1, (7, 88): 2, (6, 23): 3}.get((self.L, self.C))    # AZG_NET_* of azg.h
+        self.fused = fused and self.geometry is not None
+        if self.fused:
+            self._pack_fused(padw, padv, r16)
         self._alloc(max_batch)
+
+    def _pack_fused(self, padw, padv, r16):
+        """the 43 weight pointers of azg_nn_mb1d_forward: matrices zero-padded to multiples of 16 and stored in MFMA
+        fragment order, vectors zero-padded to multiples of 16"""
+        import ctypes as C
+        base, L, frag = self.base, self.L, SplendorV80Hip._frag
+        fw = lambda W: frag(padw(W, r16(W.shape[0]), r16(W.shape[1])))  # noqa: E731
+        keep = [fw(base.W0), padv(base.b0, r16(self.C))]
+        for blk in (base.trunk, base.head_pi, base.head_v):
+            E, Q, co = blk.We.shape[1], blk.W1.shape[1], blk.Wp.shape[1]
+            keep += [fw(blk.We), padv(blk.be, r16(E)), blk.Wd.contiguous(), padv(blk.sd, r16(E)), padv(blk.bd, r16(E)),
+                     fw(blk.W1), padv(blk.b1, r16(Q)), fw(blk.W2), padv(blk.b2, r16(E)), fw(blk.Wp), padv(blk.bp, r16(co))]
+        co_pi, co_v = base.head_pi.Wp.shape[1], base.head_v.Wp.shape[1]
+        OS = r16(max(self.C, co_pi)) + 4
+
+        def flat(W, cout):                 # rows l*cout + c -> l*OS + c
+            w = torch.zeros((L, OS, W.shape[1]), dtype=torch.float32, device=W.device)
+            w[:, :cout] = W.view(L, cout, W.shape[1])
+            return fw(w.view(L * OS, W.shape[1]))
+        keep += [flat(base.Wpi1, co_pi), padv(base.bpi1, r16(self.A)), fw(base.Wpi2), padv(base.bpi2, r16(self.A)),
+                 flat(base.Wv1, co_v), padv(base.bv1, 16), base.Wv2.contiguous(), base.bv2.contiguous()]
+        assert len(keep) == 43
+        self._fused_keep = keep
+        self.fused_ptrs = (C.c_void_p * 43)(*[t.data_ptr() for t in keep])
 
     def _alloc(self, B):
         d, f = self.device, torch.float32
@@ -498,6 +526,10 @@ class MobileNet1dHip:
         boards = boards.reshape(B, -1)
         assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda
         valids = valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)
+        if self.fused:                                  # the whole forward in one launch (nn_mb1d.cuh)
+            self._lib.check(Lb.azg_nn_mb1d_forward(self.geometry, p(boards), p(valids.contiguous()), self.fused_ptrs, B,
+                                                   p(self.pi), p(self.v), st))
+            return self.pi[:B], self.v[:B]
         self._lib.check(Lb.azg_nn_board_to_x_ld(p(boards), p(self.x0), B, self.C, self.L, self.Cp, st))
         self._lin(self.x0, self.Cp, self.pW0, self.pb0, self.x1, self.Cp, B * self.L, self.Cp, self.C)       # first_layer
         gt, gp, gv = self.blocks

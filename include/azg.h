@@ -226,6 +226,18 @@ int azg_nn_v80_block(const float* xin_dev, float* xout_dev, const float* const* 
    padded; every matrix except Wv2 is in the fragment order described at azg_nn_v80_block.  Fixed to the V80 activations (trunk ReLU + mean squeeze, heads Hardswish + max squeeze). */
 int azg_nn_v80_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int B, int P,
                        float* x_trunk_dev, float* pi_dev, float* v_dev, void* stream);
+/* The whole MobileNetV3-1d forward (first layer, trunk block, policy block + head, value block + head) in one launch for
+   the geometries of the reference's Splendor (SplendorNNet.py:259-283, n players: C = 32 + 10n + n^2 channels x 7 tokens)
+   and Azul (AzulNNet.py:91-113: 23 channels x 6 tokens) nets -- the generic sibling of azg_nn_v80_forward.
+   boards int8 [B][C][L], valid u8 [B][A] -> pi f32 [B][A] (probabilities), v f32 [B][P].  w = 43 device pointers:
+   {W0, b0}, 3 x {We, be, Wd[L][L], bn_scale_d, bn_bias_d, W1, b1, W2, b2, Wp, bp} (trunk, policy head, value head),
+   {Wpi1, bpi1, Wpi2, bpi2, Wv1, bv1, Wv2[P][P], bv2}; every matrix but Wd / Wv2 is zero-padded to multiples of 16 in both
+   dimensions and stored in MFMA fragment order frag[N/16][K/16][64][4] = W[16c + 4*(lane>>4) + j][16nt + (lane&15)],
+   every vector zero-padded to a multiple of 16; the rows of Wpi1 / Wv1 are indexed l*OS + c with OS = 16*ceil(max(C,
+   policy-block channels)/16) + 4. */
+enum { AZG_NET_SPLENDOR2 = 0, AZG_NET_SPLENDOR3 = 1, AZG_NET_SPLENDOR4 = 2, AZG_NET_AZUL = 3 };
+int azg_nn_mb1d_forward(int geometry, const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int B,
+                        float* pi_dev, float* v_dev, void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
 int azg_nn_board_to_x(const int8_t* boards_dev, float* x_dev, int B, int C, void* stream);
 /* boards int8 [B][C][L] -> x f32 [B][L][ldx], columns C..ldx-1 zeroed (row stride padded to a multiple of 4 floats) */

@@ -176,8 +176,9 @@ def test_v80_4p_forward_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('fused', [False, True], ids=['launches17', 'fused'])
 @pytest.mark.parametrize('tag', ['splendor2_v80', 'splendor4_v80', 'azul_v84'])
-def test_mobilenet1d_engine_kernels_gpu(tag):
+def test_mobilenet1d_engine_kernels_gpu(tag, fused):
     """MobileNet1dHip (engine GEMM / depthwise / head kernels, any geometry) vs the reference models' golden outputs, and at
     a batch that is not a multiple of the 16-row tiles vs the torch-ops evaluation of the same weights."""
     from azg_amd import nnet
@@ -187,7 +188,8 @@ def test_mobilenet1d_engine_kernels_gpu(tag):
     else:
         npl = 4 if tag.startswith('splendor4') else 2
         base = nnet.SplendorV80.from_npz(os.path.join(root, 'weights_%s.npz' % tag), num_players=npl, device='cuda:0')
-    net = nnet.MobileNet1dHip(base, max_batch=64)
+    net = nnet.MobileNet1dHip(base, max_batch=64, fused=fused)
+    assert net.fused == fused
     d = np.load(os.path.join(root, 'netfwd_%s.npz' % tag))
     boards = torch.from_numpy(d['boards']).to('cuda:0')
     masks = torch.from_numpy(d['masks']).to('cuda:0')
