@@ -51,32 +51,34 @@ struct Mb1dCfg {
 // One GEMM phase over the workgroup:  out(row, 16*ct + 4g .. +3) = epi( sum_k in[row][k] * W[k][col] )
 //   KCH K-chunks of 16, NT column tiles, RTN row tiles; loadB(rt, c) returns this lane's float4 of the B operand
 //   (activation row rt*16 + r16, K offset 16c + 4g); epi(ct, rt, acc) consumes the C tile (lane: row r16, 4 columns).
-// NT >= NW: wave w owns column tiles w, w + NW, ... and all row tiles (weights stationary in registers).
-// NT <  NW: NW / NT waves share a column tile and split its row tiles.
+// The weight fragments of a column tile stay in registers across the row tiles a wave computes for it.
 template <int KCH, int NT, int RTN, int NW, class LoadB, class Epi>
 __device__ __forceinline__ void mb_gemm(const float* __restrict__ Wfrag, LoadB loadB, Epi epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int G = NT >= NW ? 1 : NW / NT;            // waves per column tile
-    const int sub = NT >= NW ? 0 : wave / NT;
-    if (NT < NW && sub >= G) return;
-    for (int ct = NT >= NW ? wave : wave % NT; ct < NT; ct += NW) {
-        float4 w[KCH];
-#pragma unroll
-        for (int c = 0; c < KCH; c++) w[c] = FRAG(Wfrag, KCH, ct, c);
+    // the NT x RTN output tiles in column-major order, an equal contiguous share per wave: a wave changes its column tile
+    // (= reloads the weight fragments into registers) at most (NT + NW - 1) / NW + 1 times
+    constexpr int U = NT * RTN;
+    const int u0 = wave * U / NW, u1 = (wave + 1) * U / NW;
+    float4 w[KCH];
+    int cur = -1;
 #pragma unroll 1
-        for (int rt = sub; rt < RTN; rt += G) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = u0; u < u1; u++) {
+        const int ct = u / RTN, rt = u - ct * RTN;
+        if (ct != cur) {
 #pragma unroll
-            for (int c = 0; c < KCH; c++) {
-                const float4 a = loadB(rt, c);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].x, a.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].y, a.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].z, a.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].w, a.w, acc, 0, 0, 0);
-            }
-            epi(ct, rt, acc);
+            for (int c = 0; c < KCH; c++) w[c] = FRAG(Wfrag, KCH, ct, c);
+            cur = ct;
         }
-        if (NT < NW) break;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KCH; c++) {
+            const float4 a = loadB(rt, c);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].w, a.w, acc, 0, 0, 0);
+        }
+        epi(ct, rt, acc);
     }
 }
 
