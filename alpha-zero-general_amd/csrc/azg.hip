@@ -761,6 +761,15 @@ extern "C" int azg_nn_v80_forward(const int8_t* boards, const uint8_t* valid, co
     return 0;
 }
 
+#ifdef AZG_CYC_COUNTERS
+extern "C" int azg_debug_prolog(unsigned long long* out /* [16] */, int reset) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prolog), 16 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_prolog), z, sizeof(z))); }
+    return 0;
+}
+#endif
+
 #ifdef AZG_NN_PHASE_TIMES
 extern "C" int azg_nn_debug_phase_times(long long* out /* [4][16] */) {
     HIPCHK(hipDeviceSynchronize());

@@ -307,6 +307,14 @@ __device__ __forceinline__ void stat_add(uint64_t* p, uint64_t v) {
     __hip_atomic_fetch_add((unsigned long long*)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef AZG_CYC_COUNTERS
+// debug: ordered clock stamps through the prologue (asm volatile + memory clobber: memory operations cannot move across)
+__device__ unsigned long long g_prolog[16];
+#define AZG_STAMP(k) do { long long c_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_)::"memory"); azg_stamp[k] = c_; } while (0)
+#else
+#define AZG_STAMP(k)
+#endif
+
 // One lock-step round, part 2: store (Ps, v) on the pending leaf and back up (MCTS.py:144-154,176-183).
 // Split in a load half (everything whose address does not depend on loaded data: header words, pi, v, the valid mask the
 // descent wrote for this leaf, the first 64 path entries -- ONE memory round trip) and an apply half, so that k_select can
@@ -321,13 +329,41 @@ struct ExpandIn {
     PathEnt pe0;
 };
 
+// The hot words of a tree header (everything up to the statistics counters), fetched as ONE batch of wide scalar loads and
+// pinned in SGPRs: left to itself the compiler turns the individual field reads into scalar loads that it issues -- and
+// waits for -- group by group along the prologue (4 serialised round trips measured).
+constexpr int AZG_HOT_WORDS = offsetof(TreeHdr, c_sims) / 4;
+#define AZG_HW(w, field) ((w)[offsetof(TreeHdr, field) / 4])
+__device__ __forceinline__ void load_hot_header(const TreeHdr* Hp, uint32_t (&w)[AZG_HOT_WORDS]) {
+    const uint32_t* p = (const uint32_t*)Hp;
+#pragma unroll
+    for (int i = 0; i < AZG_HOT_WORDS; i++) w[i] = p[i];
+}
+// second half, after every other load of the batch has been issued: one wait, the words move to SGPRs
+__device__ __forceinline__ void pin_hot_header(uint32_t (&w)[AZG_HOT_WORDS]) {
+#pragma unroll
+    for (int i = 0; i < AZG_HOT_WORDS; i++) { w[i] = uni_u32(w[i]); asm volatile("" : "+s"(w[i])); }
+}
+
+// Touch every 64-byte line of the kernel-argument segment in ONE scalar batch at kernel entry: with ~100 SGPRs worth of
+// ForestDev fields the compiler re-loads them from the segment wherever they are needed, and each first touch of a line
+// would otherwise be a serialised scalar-cache miss in the middle of the prologue.
+__device__ __forceinline__ void warm_kernarg_512() {
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t a, b, c, d, e, f, g, h;
+    asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
+                 "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
+                 "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d), "=&s"(e), "=&s"(f), "=&s"(g), "=&s"(h)
+                 : "s"(ka)
+                 : "memory");
+}
+
 template <class G>
 __device__ __forceinline__ void expand_load(const ForestDev& F, int t, const float* pi, const float* vin,
-                                            const uint8_t* leaf_valid, ExpandIn<G>& in) {
-    const TreeHdr* Hp = &F.hdr[t];
+                                            const uint8_t* leaf_valid, ExpandIn<G>& in, const uint32_t (&hw)[AZG_HOT_WORDS]) {
     const int l = lane_id();
-    in.status = Hp->status; in.pending_leaf = Hp->pending_leaf; in.path_len = Hp->path_len; in.leaf_is_root = Hp->leaf_is_root;
-    in.sim_idx = Hp->sim_idx; in.is_full = Hp->is_full; in.pend_nv = Hp->pending_nv; in.pend_node = Hp->pending_node;
+    (void)hw;
 #pragma unroll
     for (int k = 0; k < ExpandIn<G>::NA; k++) {
         const int a = l + 64 * k;
@@ -339,10 +375,17 @@ __device__ __forceinline__ void expand_load(const ForestDev& F, int t, const flo
     in.pe0 = (F.path + (size_t)t * AZG_MAXD)[l];
 }
 
+template <class G>
+__device__ __forceinline__ void expand_header(ExpandIn<G>& in, const uint32_t (&hw)[AZG_HOT_WORDS]) {
+    in.status = AZG_HW(hw, status); in.pending_leaf = AZG_HW(hw, pending_leaf); in.path_len = AZG_HW(hw, path_len);
+    in.leaf_is_root = AZG_HW(hw, leaf_is_root); in.sim_idx = AZG_HW(hw, sim_idx); in.is_full = AZG_HW(hw, is_full);
+    in.pend_nv = AZG_HW(hw, pending_nv); in.pend_node = AZG_HW(hw, pending_node);
+}
+
 // returns true when the leaf was a fresh root that still needs its Dirichlet noise (noise_pending = 2 was set)
 template <class G>
 __device__ __forceinline__ bool expand_apply(const ForestDev& F, int t, const ExpandIn<G>& in, float* dense /*LDS [A]*/,
-                                             PathEnt* path /*LDS [AZG_MAXD]*/, int noise_enabled) {
+                                             PathEnt* path /*LDS [AZG_MAXD]*/, int noise_enabled, long long* azg_stamp) {
     using FR = Forest<G>;
     constexpr int NA = ExpandIn<G>::NA;
     const int l = lane_id();
@@ -364,6 +407,7 @@ __device__ __forceinline__ bool expand_apply(const ForestDev& F, int t, const Ex
     const bool dir_now = (noise_enabled && uni_u32(in.leaf_is_root) && sim == 0 && uni_u32(in.is_full) && F.dirichletAlpha != 0.0);
     float s = 1.f;
     if (!dir_now) s = np_sum_f32(dense, G::A);
+    AZG_STAMP(2);
     // entry j belongs to the j-th valid action (the rank of its bit in the leaf's valid mask): no read of the record needed
     int base_rank = 0;
 #pragma unroll
@@ -384,7 +428,9 @@ __device__ __forceinline__ bool expand_apply(const ForestDev& F, int t, const Ex
         rhp->Ns = 0; rhp->Qs = in.v[0]; rhp->flags = NF_EXPANDED;
         FR::nhdr(F, t, uni_u32(in.pend_node))->flags = NF_EXPANDED;
     }
+    AZG_STAMP(3);
     FR::backup(F, t, path, depth, in.v);                                                         // leaf returns v :154
+    AZG_STAMP(4);
     if (l == 0) {
         Hp->sim_idx = sim + 1;
         Hp->status = ST_SEARCHING;
@@ -404,9 +450,15 @@ __global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* 
     __shared__ __attribute__((aligned(16))) PathEnt path[AZG_MAXD];
     const int t = blockIdx.x;
     ExpandIn<G> in;
-    expand_load<G>(F, t, pi, vin, leaf_valid, in);
+    uint32_t hw[AZG_HOT_WORDS];
+    load_hot_header(&F.hdr[t], hw);
+    expand_load<G>(F, t, pi, vin, leaf_valid, in, hw);
+    pin_hot_header(hw);
+    expand_header<G>(in, hw);
     if (uni_u32(in.status) != ST_WAIT_NN) return;
-    expand_apply<G>(F, t, in, dense, path, noise_enabled);
+    long long azg_stamp[8];
+    expand_apply<G>(F, t, in, dense, path, noise_enabled, azg_stamp);
+    (void)azg_stamp;
 }
 
 
@@ -425,6 +477,11 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
     __shared__ __attribute__((aligned(16))) float dense[G::A];          // fused expansion only
+    static_assert(sizeof(ForestDev) + 56 <= 512, "warm_kernarg_512 covers the kernel arguments");
+    warm_kernarg_512();
+    long long azg_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    AZG_STAMP(0);
+    const long long t_first = AZG_CLK();
     const int t = blockIdx.x;
     const int l = lane_id();
     TreeHdr* Hp = &F.hdr[t];
@@ -434,16 +491,23 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     // every hot header field is requested in one go (status included): one memory round trip before the first level
     SelState H;
     ExpandIn<G> ein;
-    if (pi) expand_load<G>(F, t, pi, vin, leaf_valid, ein);             // pi != nullptr: the previous round's expansion first
-    uint32_t status0 = Hp->status;
-    const uint32_t pending0 = Hp->noise_pending;
-    H.id_top = Hp->id_top; H.n_free_ids = Hp->n_free_ids; H.free_units = Hp->free_units;
-    H.n_nodes = Hp->n_nodes; H.heap_top = Hp->heap_top; H.root = Hp->root; H.root_rec = Hp->root_rec; H.sim_idx = Hp->sim_idx;
-    H.n_sims = Hp->n_sims; H.is_full = Hp->is_full; H.forced = Hp->forced; H.err = Hp->err; H.leaf_is_root = Hp->leaf_is_root;
-    H.mid_sim = Hp->mid_sim; H.cur_rec = Hp->cur_rec; H.cur_depth = Hp->cur_depth; H.cur_pre = Hp->cur_pre;
+    uint32_t hw[AZG_HOT_WORDS];
+    load_hot_header(Hp, hw);
+    if (pi) expand_load<G>(F, t, pi, vin, leaf_valid, ein, hw);         // pi != nullptr: the previous round's expansion first
+    pin_hot_header(hw);
+    AZG_STAMP(1);
+    expand_header<G>(ein, hw);
+    uint32_t status0 = AZG_HW(hw, status);
+    const uint32_t pending0 = AZG_HW(hw, noise_pending);
+    H.id_top = AZG_HW(hw, id_top); H.n_free_ids = AZG_HW(hw, n_free_ids); H.free_units = AZG_HW(hw, free_units);
+    H.n_nodes = AZG_HW(hw, n_nodes); H.heap_top = AZG_HW(hw, heap_top); H.root = AZG_HW(hw, root); H.root_rec = AZG_HW(hw, root_rec);
+    H.sim_idx = AZG_HW(hw, sim_idx); H.n_sims = AZG_HW(hw, n_sims); H.is_full = AZG_HW(hw, is_full); H.forced = AZG_HW(hw, forced);
+    H.err = AZG_HW(hw, err); H.leaf_is_root = AZG_HW(hw, leaf_is_root); H.mid_sim = AZG_HW(hw, mid_sim); H.cur_rec = AZG_HW(hw, cur_rec);
+    H.cur_depth = AZG_HW(hw, cur_depth); H.cur_pre = AZG_HW(hw, cur_pre);
     bool fresh_noise = false;
     if (pi && uni_u32(status0) == ST_WAIT_NN) {
-        fresh_noise = expand_apply<G>(F, t, ein, dense, sm.path, noise_enabled);
+        fresh_noise = expand_apply<G>(F, t, ein, dense, sm.path, noise_enabled, azg_stamp);
+        AZG_STAMP(5);
         status0 = ST_SEARCHING;
     }
     const bool expanded_here = pi && uni_u32(ein.status) == ST_WAIT_NN;
@@ -467,6 +531,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     const float inv_units1 = 1.0f / (float)FR::cls_units(F, 1);
     bool need_nn = false;
     uint32_t c_sims = 0, c_levels = 0, c_sumvalid = 0, c_term = 0, levels_this_launch = 0, edges_this_launch = 0, work_units = 0;
+    AZG_STAMP(6);
     const long long t_start = AZG_CLK();
 #ifdef AZG_WALL_CAL
     const long long w_start = wall_clock64();
@@ -690,9 +755,12 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #endif
         stat_add(&Hp->cyc_select, (uint64_t)(AZG_CLK() - t_start)); stat_add(&Hp->cyc_levels, (uint64_t)cyc_levels);
         stat_add(&Hp->cyc_edge, (uint64_t)cyc_edge); stat_add(&Hp->cyc_leaf, (uint64_t)H.cyc_leaf);
+        H.cyc_seg[0] += (uint32_t)(t_start - t_first);          // prologue: header round trip + fused expansion + backup
+        if (azg_stamp[5]) for (int k = 1; k < 7; k++) atomicAdd(&g_prolog[k], (unsigned long long)(azg_stamp[k] - azg_stamp[k - 1]));
+        if (azg_stamp[5]) atomicAdd(&g_prolog[0], 1ull);
         for (int k = 0; k < 4; k++) stat_add(&Hp->cyc_seg[k], (uint64_t)H.cyc_seg[k]);
 #else
-        (void)t_start; (void)cyc_levels; (void)cyc_edge;
+        (void)t_start; (void)t_first; (void)cyc_levels; (void)cyc_edge; (void)azg_stamp;
 #endif
         needs_eval[t] = need_nn ? 1 : 0;
     }

@@ -11,7 +11,7 @@ a = Args(numMCTSSims=800, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=Tr
 g = games.SplendorGame(2)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=T)
-e = SelfPlayEngine(g, net, a, T, node_capacity=13312, max_examples=T*160, use_graph=False)
+e = SelfPlayEngine(g, net, a, T, node_capacity=13312, max_examples=T*160, use_graph=False, fused=os.environ.get('FUSED', '1') == '1')
 e.start(); e.run(1200)
 s0 = e.stats(); e.run(300); s1 = e.stats()
 seg = [s1['cyc_seg'][k]-s0['cyc_seg'][k] for k in range(4)]
@@ -19,5 +19,18 @@ d = {k: s1[k]-s0[k] for k in s0 if k != 'cyc_seg'}
 n = 300 * T
 print('per tree-launch cycles: select', d['cyc_select']/n, 'levels', d['cyc_levels']/n, 'edge', d['cyc_edge']/n, 'leaf', d['cyc_leaf']/n)
 print('levels/launch', d['levels']/n, 'sims/launch', d['sims']/n, 'cycles per level', d['cyc_levels']/max(1,d['levels']))
-print('edge split per tree-launch: load_state %.0f make_move %.0f canon+hash %.0f probe %.0f' % tuple(x/n for x in seg))
+print('edge split per tree-launch: prologue+load_state %.0f make_move %.0f canon+hash %.0f probe %.0f' % tuple(x/n for x in seg))
 print('expansions/launch', d['expansions']/n, 'terminal', d['terminal_hits']/n)
+
+try:
+    import ctypes as C
+    from azg_amd import _lib
+    out = (C.c_ulonglong * 16)()
+    _lib.lib().azg_debug_prolog(out, 1)
+    e.run(200)
+    _lib.lib().azg_debug_prolog(out, 0)
+    n = max(1, out[0])
+    print('prologue stamps per expansion (cycles): hdr+pi arrive %.0f | to np_sum done %.0f | entries written %.0f | backup %.0f | tail of expand_apply %.0f | to loop start %.0f'
+          % tuple(out[k] / n for k in range(1, 7)))
+except Exception as ex:
+    print('no prologue stamps:', ex)
