@@ -12,7 +12,7 @@ a = Args(numMCTSSims=800, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=Tr
 T = 4096
 g = games.SplendorGame(2)
 net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=T)
-e = SelfPlayEngine(g, net, a, T, node_capacity=int(os.environ.get('CAP', '8512')), max_examples=T * 160, work_budget=int(os.environ.get('WB', '0')))
+e = SelfPlayEngine(g, net, a, T, node_capacity=int(os.environ.get('CAP', '13312')), max_examples=T * 160, work_budget=int(os.environ.get('WB', '0')))
 e.start(); e.run(int(sys.argv[1]) if len(sys.argv) > 1 else 56000)
 torch.cuda.synchronize()
 grp = e.groups[0]; f = grp.f
