@@ -204,6 +204,11 @@ __device__ __forceinline__ float np_sum_block_f32(const float* a, int n) {
 // full pairwise recursion (n > 128 splits in halves rounded down to a multiple of 8)
 __device__ inline float np_sum_f32(const float* a, int n) {
     if (n <= 128) return np_sum_block_f32(a, n);
+    if (n <= 256) {                             // one split: both halves are leaf blocks (Azul's 180 actions: 88 + 92)
+        int n2 = n / 2; n2 -= n2 % 8;
+        const float lo = np_sum_block_f32(a, n2);
+        return lo + np_sum_block_f32(a + n2, n - n2);
+    }
     // iterative traversal of the recursion tree with an explicit stack (depth <= 8 for n <= 32768)
     int st_off[12], st_n[12], st_state[12];
     float st_acc[12];

@@ -7,11 +7,27 @@ from azg_amd import games
 from azg_amd.nnet import SplendorV80Hip
 from azg_amd.selfplay import SelfPlayEngine
 class Args(dict): __getattr__ = dict.get
-a = Args(numMCTSSims=800, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, dirichletAlpha=0.3, temperature=[1.25,0.8,1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0)
-g = games.SplendorGame(2)
+GAME = os.environ.get('GAME', 'splendor2')
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=T)
-e = SelfPlayEngine(g, net, a, T, node_capacity=13312, max_examples=T*160, use_graph=False, fused=os.environ.get('FUSED', '1') == '1')
+G = os.path.join(ROOT, 'tests/golden')
+if GAME == 'azul':
+    from azg_amd import nnet
+    a = Args(numMCTSSims=800, cpuct=0.5, fpu=0.05, universes=1, forced_playouts=True, dirichletAlpha=-1, temperature=[1.25,0.8,1.0], tempThreshold=10, ratio_fullMCTS=5, prob_fullMCTS=1.0)
+    g = games.AzulGame()
+    net = nnet.MobileNet1dHip(nnet.AzulV84.from_npz(G + '/weights_azul_v84.npz', device='cuda:0'), max_batch=T)
+    cap = 32 * 800 + 512
+elif GAME == 'splendor4':
+    from azg_amd import nnet
+    a = Args(numMCTSSims=800, cpuct=0.8, fpu=0.1, universes=3, forced_playouts=True, dirichletAlpha=0.3, temperature=[1.25,0.8,1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0)
+    g = games.SplendorGame(4)
+    net = nnet.MobileNet1dHip(nnet.SplendorV80.from_npz(G + '/weights_splendor4_v80.npz', num_players=4, device='cuda:0'), max_batch=T)
+    cap = 32 * 800 + 512
+else:
+    a = Args(numMCTSSims=800, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, dirichletAlpha=0.3, temperature=[1.25,0.8,1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0)
+    g = games.SplendorGame(2)
+    net = SplendorV80Hip.from_npz(G + '/weights_splendor2_v80.npz', max_batch=T)
+    cap = 13312
+e = SelfPlayEngine(g, net, a, T, node_capacity=cap, max_examples=T*160, use_graph=False, fused=os.environ.get('FUSED', '1') == '1')
 e.start(); e.run(1200)
 s0 = e.stats(); e.run(300); s1 = e.stats()
 seg = [s1['cyc_seg'][k]-s0['cyc_seg'][k] for k in range(4)]
