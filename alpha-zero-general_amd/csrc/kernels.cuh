@@ -245,16 +245,8 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
     }
     *terminal = ended;
     if (!ended) {
-        for (int a = l; a < G::A; a += 64) {
-            const uint64_t w = sm.mask[a >> 6];
-            const bool v = (w >> (a & 63)) & 1;
-            if (v) {
-                int rank = __popcll(w & ((1ull << (a & 63)) - 1ull));
-                for (int k = 0; k < (a >> 6); k++) rank += __popcll(sm.mask[k]);
-                *(uint16_t*)(rec + AZG_REC_HDR + (size_t)rank * L.ES + AZG_E_ID(F.U)) = (uint16_t)a;
-            }
-            leaf_valid[(size_t)t * G::A + a] = (uint8_t)v;
-        }
+        // the entries themselves (action id included) are written by the expansion, in one pass, when the policy arrives
+        for (int a = l; a < G::A; a += 64) leaf_valid[(size_t)t * G::A + a] = (uint8_t)((sm.mask[a >> 6] >> (a & 63)) & 1);
         FR::store_state_unpadded(leaf_states + (size_t)t * G::S, sm.st);
     }
     return rec_off;
@@ -420,7 +412,12 @@ __device__ __forceinline__ bool expand_apply(const ForestDev& F, int t, const Ex
             e0.x = __float_as_uint(dir_now ? in.pv[k] : in.pv[k] / s); e0.y = 0u;                 // P, N = 0
             e0.z = (uint32_t)__double_as_longlong(AZG_NANQ); e0.w = (uint32_t)((uint64_t)__double_as_longlong(AZG_NANQ) >> 32);
             *(uint4*)(ent + AZG_E_P) = e0;
-            for (int u = 0; u < F.U; u++) *(uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)u) = AZG_NONE;
+            const uint32_t aid = (uint32_t)(l + 64 * k);                                          // the entry's action id
+            if (F.U == 3) *(uint4*)(ent + AZG_E_C) = make_uint4(AZG_NONE, AZG_NONE, AZG_NONE, aid);   // child[3], id + pad
+            else {
+                for (int u = 0; u < F.U; u++) *(uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)u) = AZG_NONE;
+                *(uint16_t*)(ent + AZG_E_ID(F.U)) = (uint16_t)aid;
+            }
         }
         base_rank += __popcll(m);
     }
