@@ -337,16 +337,16 @@ __device__ __forceinline__ void pin_hot_header(uint32_t (&w)[AZG_HOT_WORDS]) {
     for (int i = 0; i < AZG_HOT_WORDS; i++) { w[i] = uni_u32(w[i]); asm volatile("" : "+s"(w[i])); }
 }
 
-// Touch every 64-byte line of the kernel-argument segment in ONE scalar batch at kernel entry: with ~100 SGPRs worth of
+// Touch every 64-byte line of the kernel's explicit arguments in ONE scalar batch at kernel entry: with ~100 SGPRs worth of
 // ForestDev fields the compiler re-loads them from the segment wherever they are needed, and each first touch of a line
 // would otherwise be a serialised scalar-cache miss in the middle of the prologue.
-__device__ __forceinline__ void warm_kernarg_512() {
+__device__ __forceinline__ void warm_kernarg_448() {
     const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t a, b, c, d, e, f, g, h;
-    asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
-                 "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
-                 "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d), "=&s"(e), "=&s"(f), "=&s"(g), "=&s"(h)
+    uint32_t a, b, c, d, e, f, g;
+    asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\t"
+                 "s_load_dword %3, %7, 0xc0\n\ts_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\t"
+                 "s_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d), "=&s"(e), "=&s"(f), "=&s"(g)
                  : "s"(ka)
                  : "memory");
 }
@@ -474,8 +474,9 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
     __shared__ __attribute__((aligned(16))) float dense[G::A];          // fused expansion only
-    static_assert(sizeof(ForestDev) + 56 <= 512, "warm_kernarg_512 covers the kernel arguments");
-    warm_kernarg_512();
+    static_assert(sizeof(ForestDev) + 52 <= 448 && sizeof(ForestDev) + 52 > 0x180 + 4,
+                  "warm_kernarg_448 touches exactly the seven 64-byte lines of this kernel's explicit arguments");
+    warm_kernarg_448();
     long long azg_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     AZG_STAMP(0);
     const long long t_first = AZG_CLK();

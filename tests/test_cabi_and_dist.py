@@ -64,7 +64,8 @@ assert torch.equal(out[1][3:], torch.arange(5 * 81, dtype=torch.float32).reshape
 empty = gather_examples([torch.zeros((0 if rank == 0 else 2, 4), dtype=torch.float32)])
 assert empty[0].shape == (2, 4)
 dist.destroy_process_group()
-print('rank', rank, 'ok')
+import sys
+sys.stdout.write('rank ' + str(rank) + ' ok' + chr(10)); sys.stdout.flush()      # one write: the two ranks share the pipe
 '''
 
 
