@@ -210,3 +210,43 @@ def test_full_size_properties():
     assert np.array_equal(Nsa.sum(axis=1)[has_root], Ns[has_root])
     for grp in e.groups:
         grp.f.close()
+
+
+@pytest.mark.parametrize('variant', ['azul', 'splendor4'])
+def test_engine_with_one_launch_net_other_games(variant):
+    """SelfPlayEngine (HIP graph, fused expansion) with the generic one-launch net (MobileNet1dHip) on the pretrained Azul /
+    Splendor-4p weights: a few hundred rounds, no engine error, and every recorded example is well-formed -- pi is a
+    distribution over the valid actions, z and q are in range, the board is a state of the game the net was built for."""
+    import os
+    import torch
+    from azg_amd import games, nnet
+    from azg_amd.selfplay import SelfPlayEngine
+    root = os.path.join(os.path.dirname(__file__), 'golden')
+    if variant == 'azul':
+        g = games.AzulGame()
+        base = nnet.AzulV84.from_npz(os.path.join(root, 'weights_azul_v84.npz'), device='cuda:0')
+    else:
+        g = games.SplendorGame(4)
+        base = nnet.SplendorV80.from_npz(os.path.join(root, 'weights_splendor4_v80.npz'), num_players=4, device='cuda:0')
+    T, sims = 64, 25
+    net = nnet.MobileNet1dHip(base, max_batch=T)
+    assert net.fused
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0],
+                tempThreshold=6, **dict(MCTS_ARGS[variant]))
+    eng = SelfPlayEngine(g, net, args, T, node_capacity=4096, max_examples=T * 400, rng_seed=7)
+    eng.start()
+    eng.run(sims * 40 + 64)
+    torch.cuda.synchronize()
+    st = eng.stats()
+    assert st['errors'] == 0 and st['plies'] >= T * 30
+    boards, pi, z, valids, q, meta = eng.drain_examples()
+    n = boards.shape[0]
+    if n:                                              # only finished games deliver examples
+        assert torch.allclose(pi.sum(dim=1), torch.ones(n, device=pi.device), atol=1e-4)
+        assert float(pi[valids == 0].abs().max()) == 0.0
+        assert float(z.abs().max()) <= 1.0 and float(q.abs().max()) <= 1.0 + 1e-6
+    # the net the engine used agrees with the plain torch evaluation on the engine's own leaf batch
+    f = eng.forest
+    lp, lv = net.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid)
+    rp, rv = base.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid.bool())
+    assert float((lp - rp).abs().max()) < 1e-5 and float((lv - rv).abs().max()) < 3e-5
