@@ -13,6 +13,7 @@
 #include "selfplay.cuh"
 #include "nn_kernels.cuh"
 #include "nn_mb1d.cuh"
+#include "nn_conv5x5.cuh"
 
 using namespace azg;
 
@@ -818,6 +819,23 @@ extern "C" int azg_nn_mb1d_forward(int geometry, const int8_t* boards, const uin
         case AZG_NET_AZUL: return launch_mb1d<CfgAzul>(N, boards, valid, B, pi, v, s);
         default: return fail("azg_nn_mb1d_forward: unknown geometry");
     }
+}
+
+// ---- Santorini ResNet V88/V89 (no-gods geometry: A = 162, P = 2, 5 residual blocks), one launch (nn_conv5x5.cuh) ----
+extern "C" int azg_nn_conv5_forward(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A,
+                                    int P, int B, float* pi, float* v, void* stream) {
+    if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_conv5_forward: null/empty argument");
+    if (n_blocks != 5 || A != 162 || P != 2) return fail("azg_nn_conv5_forward: built for 5 residual blocks, A = 162, P = 2");
+    Conv5NetW N{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13]};
+    constexpr size_t lds = (size_t)2 * 200 * 68 * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    k_conv5_net<5, 162, 2><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 extern "C" int azg_nn_board_to_x_ld(const int8_t* boards, float* x, int B, int C, int L, int ldx, void* stream) {

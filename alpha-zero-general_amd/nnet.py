@@ -619,6 +619,69 @@ class SantoriniV89:
         return pi[0].cpu().numpy(), v[0].cpu().numpy()
 
 
+class SantoriniV89Hip:
+    """SantoriniV89 (no-gods geometry: 5 residual blocks, A = 162) evaluated by the engine's one-launch implicit-GEMM kernel
+    (azg_nn_conv5_forward, csrc/nn_conv5x5.cuh) instead of 11 MIOpen convolutions + glue ops.  Wraps a SantoriniV89."""
+
+    def __init__(self, base, max_batch=4096):
+        import ctypes as C
+        from . import _lib
+        self._lib, self.base, self.device = _lib, base, base.device
+        self.P, self.A = base.P, base.A
+        assert base.dtype == torch.float32 and self.device.type == 'cuda' and len(base.blocks) == 5 and self.A == 162 and self.P == 2
+        frag = SplendorV80Hip._frag
+        d = self.device
+
+        def conv_mat(w, cin_pad):          # [co][ci][3][3] -> [tap*cin_pad + ci][co], fragment order
+            co, ci = w.shape[0], w.shape[1]
+            m = torch.zeros((9, cin_pad, co), dtype=torch.float32, device=d)
+            m[:, :ci] = w.permute(2, 3, 1, 0).reshape(9, ci, co)
+            return frag(m.reshape(9 * cin_pad, co).contiguous())
+        convs = [c for blk in base.blocks for c in blk]
+        keep = [conv_mat(base.c0[0], 16), base.c0[1].contiguous(),
+                torch.cat([conv_mat(w, 64) for w, _ in convs]).contiguous(), torch.cat([b for _, b in convs]).contiguous(),
+                base.hp[0].reshape(2, 64).t().contiguous(), base.hp[1].contiguous(), base.fc_pi[0].contiguous(), base.fc_pi[1].contiguous(),
+                base.hv[0].reshape(64).contiguous(), base.hv[1].contiguous(), base.fc_v1[0].contiguous(), base.fc_v1[1].contiguous(),
+                base.fc_v2[0].contiguous(), base.fc_v2[1].contiguous()]
+        self._keep = keep
+        self.ptrs = (C.c_void_p * 14)(*[t.data_ptr() for t in keep])
+        self._alloc(max_batch)
+
+    def _alloc(self, B):
+        self.maxB = B
+        self.pi = torch.empty((B, self.A), dtype=torch.float32, device=self.device)
+        self.v = torch.empty((B, self.P), dtype=torch.float32, device=self.device)
+
+    def clone_buffers(self):
+        import copy
+        other = copy.copy(self)
+        other._alloc(self.maxB)
+        return other
+
+    @torch.no_grad()
+    def forward(self, boards, valids):
+        import ctypes as C
+        B = boards.shape[0]
+        if B > self.maxB:
+            self._alloc(B)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        boards = boards.reshape(B, -1)
+        assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda and boards.shape[1] == 75
+        valids = (valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)).contiguous()
+        self._lib.check(self._lib.lib().azg_nn_conv5_forward(p(boards), p(valids), self.ptrs, 5, self.A, self.P, B, p(self.pi),
+                                                             p(self.v), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return self.pi[:B], self.v[:B]
+
+    def predict_batch(self, boards, valids):
+        return self.forward(boards, valids)
+
+    def predict(self, board, valid_actions):
+        b = torch.as_tensor(np.asarray(board, dtype=np.int8)).reshape(1, -1).to(self.device)
+        va = torch.as_tensor(np.asarray(valid_actions).astype(np.uint8)).reshape(1, -1).to(self.device)
+        pi, v = self.forward(b, va)
+        return pi[0].cpu().numpy(), v[0].cpu().numpy()
+
+
 class SantoriniV78(SantoriniV89):
     """santorini/SantoriniNNet.py nn_version 78 (:167-192,264-271; HeadWithMeta :42-69) -- the with-gods net of
     pretrained_withgods.pt: conv3x3(2->64, no BN) -> 10 torchvision MobileNetV3 InvertedResidual blocks (1x1 expand

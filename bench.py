@@ -203,7 +203,10 @@ def main():
         nkw = dict(num_players=4) if a.game == 'splendor4' else {}
         net = getattr(_nn, og['net']).from_npz(os.path.join(ROOT, 'tests', 'golden', og['weights']), device=dev, dtype=dtype, **nkw)
         if a.net == 'hip' and og['net'] in ('SplendorV80', 'AzulV84') and a.net_dtype == 'fp32':
-            net = _nn.MobileNet1dHip(net, max_batch=T // a.groups)        # engine GEMM / depthwise / head kernels
+            net = _nn.MobileNet1dHip(net, max_batch=T // a.groups)        # the whole forward in one launch (nn_mb1d.cuh)
+            og = dict(og, label=og['label'] + ' (engine kernels)')
+        elif a.net == 'hip' and a.game == 'santorini1' and a.net_dtype == 'fp32':
+            net = _nn.SantoriniV89Hip(net, max_batch=T // a.groups)       # implicit-GEMM ResNet in one launch (nn_conv5x5.cuh)
             og = dict(og, label=og['label'] + ' (engine kernels)')
         else:
             a.net = 'torch'

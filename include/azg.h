@@ -238,6 +238,15 @@ int azg_nn_v80_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const
 enum { AZG_NET_SPLENDOR2 = 0, AZG_NET_SPLENDOR3 = 1, AZG_NET_SPLENDOR4 = 2, AZG_NET_AZUL = 3 };
 int azg_nn_mb1d_forward(int geometry, const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int B,
                         float* pi_dev, float* v_dev, void* stream);
+/* The Santorini ResNet (santorini/SantoriniNNet.py nn_version 88/89 :194-219,273-281: conv3x3(2->64)+BN+ReLU, n_blocks
+   SimpleResBlocks :71-84, SimpleHead heads :17-40) in one launch.  boards int8 [B][5][5][3] (planes 0, 1 are the net's
+   input), valid u8 [B][A] -> pi f32 [B][A], v f32 [B][P].  w = 14 device pointers {W0, b0, Wc, bc, Wp, bp, Wfp, bfp, Wv, bv,
+   Wf1, bf1, Wf2, bf2}: BatchNorm folded; W0 [9*16][64] and the 2*n_blocks trunk matrices Wc [9*64][64] (row = tap*Cin + ci,
+   tap = ky*3 + kx, column = co) in the MFMA fragment order of azg_nn_mb1d_forward, back to back; bc [2*n_blocks][64];
+   Wp [64][2], Wfp [50][A] (row = c*25 + cell), Wv [64], Wf1 [25][64], Wf2 [64][P] plain row-major.
+   Built for the no-gods geometry (n_blocks = 5, A = 162, P = 2). */
+int azg_nn_conv5_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int n_blocks, int A, int P,
+                         int B, float* pi_dev, float* v_dev, void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
 int azg_nn_board_to_x(const int8_t* boards_dev, float* x_dev, int B, int C, void* stream);
 /* boards int8 [B][C][L] -> x f32 [B][L][ldx], columns C..ldx-1 zeroed (row stride padded to a multiple of 4 floats) */

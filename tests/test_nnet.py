@@ -206,3 +206,28 @@ def test_mobilenet1d_engine_kernels_gpu(tag, fused):
     pr, vr = base.predict_batch(rb, rm)
     assert float((pi2 - pr).abs().max()) < 1e-5 and float((v2 - vr).abs().max()) < 3e-5
     assert float(pi2[~rm].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_santorini_v89_one_launch_gpu():
+    """SantoriniV89Hip (implicit-GEMM 3x3 convolutions + heads in one launch) vs the reference model's golden outputs and,
+    on a ragged random batch, vs the MIOpen evaluation of the same weights."""
+    from azg_amd import nnet
+    root = os.path.join(os.path.dirname(__file__), 'golden')
+    base = nnet.SantoriniV89.from_npz(os.path.join(root, 'weights_santorini1_v89.npz'), device='cuda:0')
+    net = nnet.SantoriniV89Hip(base, max_batch=64)
+    d = np.load(os.path.join(root, 'netfwd_santorini1_v89.npz'))
+    boards = torch.from_numpy(d['boards']).to('cuda:0').to(torch.int8)
+    masks = torch.from_numpy(d['masks']).to('cuda:0')
+    pi, v = net.predict_batch(boards, masks)
+    assert np.allclose(pi.cpu().numpy(), d['pi'], atol=1e-5, rtol=0)
+    assert np.allclose(v.cpu().numpy(), d['v'], atol=1e-5, rtol=0)
+    g = torch.Generator().manual_seed(9)
+    B = 203
+    rb = torch.randint(-2, 5, (B, 5, 5, 3), generator=g, dtype=torch.int8).to('cuda:0')
+    rm = (torch.rand((B, 162), generator=g) < 0.3).to('cuda:0')
+    rm[:, 0] = True
+    pi2, v2 = net.predict_batch(rb, rm)
+    pr, vr = base.predict_batch(rb, rm)
+    assert float((pi2 - pr).abs().max()) < 1e-5 and float((v2 - vr).abs().max()) < 2e-5
+    assert float(pi2[~rm].abs().max()) == 0.0

@@ -32,3 +32,10 @@ for tag, mk, shape, A in [('splendor2', lambda: nnet.SplendorV80.from_npz(G + '/
     if tag == 'splendor2':
         row['k_v80_net'] = timed(nnet.SplendorV80Hip.from_npz(G + '/weights_splendor2_v80.npz', max_batch=T), boards, valids)
     print(tag, 'T=%d' % T, '  '.join('%s %.1f us' % kv for kv in row.items()), flush=True)
+
+base = nnet.SantoriniV89.from_npz(G + '/weights_santorini1_v89.npz', device='cuda:0')
+boards = torch.randint(-2, 5, (T, 5, 5, 3), dtype=torch.int8, device='cuda:0')
+valids = (torch.rand((T, 162), device='cuda:0') < 0.5).to(torch.uint8)
+valids[:, 0] = 1
+print('santorini1 V89 T=%d' % T, 'torch ops (MIOpen) %.1f us' % timed(base, boards, valids.bool(), 10),
+      ' k_conv5_net %.1f us' % timed(nnet.SantoriniV89Hip(base, max_batch=T), boards, valids), flush=True)
