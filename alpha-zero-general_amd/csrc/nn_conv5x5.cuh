@@ -9,6 +9,7 @@
 // sample and run on the vector ALUs.  (MIOpen's Winograd path needs 11 launches of ~100 us for the same batch.)
 #pragma once
 #include "nn_kernels.cuh"
+#include "nn_mb1d.cuh"
 
 namespace azg {
 
@@ -26,7 +27,7 @@ struct Conv5NetW {
 
 // one 3x3 convolution over the workgroup's tile.  KC = input-channel chunks of 16 per tap.
 //   IN [ROWS][CS] -> OUT [ROWS][CS] = relu(conv(IN) + bias (+ RES)); OUT may alias RES (same lane reads and writes an element)
-template <int KC, int NS>
+template <int KC, int NS, bool RELU = true>
 __device__ __forceinline__ void conv3x3_tile(const float* __restrict__ Wfrag, const float* __restrict__ bias,
                                              const float* IN, float* OUT, const float* RES) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, KCH = 9 * KC, RG = 3, MAXT = (RT + RG - 1) / RG;
@@ -89,7 +90,7 @@ __device__ __forceinline__ void conv3x3_tile(const float* __restrict__ Wfrag, co
             const float4 r = *(const float4*)(RES + row[i] * CS + ct * 16 + 4 * g);
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
-        *(float4*)dst = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        *(float4*)dst = RELU ? make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)) : o;
     }
 }
 
@@ -168,6 +169,181 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         sum = nn_wave_sum(sum);
 #pragma unroll
         for (int k = 0; k < (A + 63) / 64; k++)
+            if (lane + 64 * k < A) pi_out[(size_t)b * A + lane + 64 * k] = x[k] / sum;
+    }
+    if (tid < nb * P) {
+        const int s = tid / P, p = tid - s * P;
+        float acc = N.bf2[p];
+        for (int j = 0; j < 64; j++) acc += H1[s * 64 + j] * N.Wf2[j * P + p];
+        v_out[(size_t)(b0 + s) * P + p] = tanhf(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The Santorini-with-gods net (nn_version 78, SantoriniNNet.py:167-192,264-271; HeadWithMeta :42-69): conv3x3(2->64, no BN,
+// no activation) -> NB torchvision InvertedResidual blocks (1x1 expand 64->192 + BN + ReLU, depthwise 3x3 + BN + ReLU,
+// 1x1 project 192->64 + BN, residual) -> 1x1-conv heads whose flattened features are concatenated with a 32-wide embedding
+// of the gods / metadata plane (Linear(25,32) + ReLU) -> FC.  One launch; a workgroup owns 4 samples = 100 board cells:
+// X [112][68] and the expanded tile H [112][196] live in LDS, the two 1x1 convolutions are MFMA GEMMs (mb_gemm), the
+// depthwise convolution runs in place -- one thread owns the 5x5 plane of one (sample, channel) -- and the heads
+// (132 x 1782 policy FC included) run on the vector ALUs.  (As PyTorch ops MIOpen falls back to its naive kernel for the
+// depthwise convolutions: 3 ms per batch of 1024.)
+struct S78NetW {
+    const float *W0;                  // first conv [9*16][64] fragment order, no bias
+    const float *We, *be;             // NB x [64][192] fragment order, bias [NB][192]
+    const float *Wd, *bd;             // NB x [192][9] plain (channel, tap = ky*3 + kx), bias [NB][192]
+    const float *Wp, *bp;             // NB x [192][64] fragment order, bias [NB][64]
+    const float *Wm, *bm;             // meta Linear [25][32], bias [32]
+    const float *Whp, *bhp;           // policy 1x1 conv [64][4], bias [4]
+    const float *Wfp, *bfp;           // policy FC [132][A] (rows: c*25 + cell, then the 32 meta features), bias [A]
+    const float *Whv, *bhv;           // value 1x1 conv [64][2], bias [2]
+    const float *Wf1, *bf1;           // value fc1 [82][64], bias [64]
+    const float *Wf2, *bf2;           // value fc2 [64][P], bias [P]
+};
+
+template <int NB, int A, int P>
+__global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid,
+                                                 int B, float* __restrict__ pi_out, float* __restrict__ v_out) {
+    constexpr int NS = 4, ROWS = NS * 25, RT = (ROWS + 15) / 16, ROWSP = RT * 16, CS = 68, HS = 196, E = 192, NW = 12;
+    constexpr int CPI = 4, CV = 2, FP = CPI * 25 + 32, FV = CV * 25 + 32, AS = (A + 3) / 4 * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                        // [ROWSP][CS]
+    float* H = X + ROWSP * CS;              // [ROWSP][HS]
+    float* META = H + ROWSP * HS;           // [NS][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
+    for (int i = tid; i < (ROWSP * CS + ROWSP * HS + NS * 32) / 4; i += 768) ((float4*)smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // ---- planes 0, 1 -> H[cell][0..1] (row stride CS inside the H region, channels 2..15 stay zero); plane 2 -> meta ----
+    float* IN0 = H;
+    for (int i = tid; i < nb * 25 * 2; i += 768) {
+        const int r = i >> 1, pl = i & 1;
+        IN0[r * CS + pl] = (float)boards[(size_t)b0 * 75 + r * 3 + pl];
+    }
+    for (int i = tid; i < nb * 32; i += 768) {
+        const int s = i >> 5, j = i & 31;
+        float acc = N.bm[j];
+        for (int k = 0; k < 25; k++) acc += (float)boards[(size_t)(b0 + s) * 75 + k * 3 + 2] * N.Wm[k * 32 + j];
+        META[s * 32 + j] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    {
+        __shared__ float zero_bias[64];
+        if (tid < 64) zero_bias[tid] = 0.f;
+        __syncthreads();
+        conv3x3_tile<1, NS, false>(N.W0, zero_bias, IN0, X, nullptr);
+    }
+    __syncthreads();
+    for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(IN0 + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+#pragma unroll 1
+    for (int blk = 0; blk < NB; blk++) {
+        const float* be = N.be + blk * E;
+        // ---- 1x1 expand + BN + ReLU -> H ----
+        mb_gemm<4, E / 16, RT, NW>(
+            N.We + (size_t)blk * (64 * E), [&](int rt, int c) { return *(const float4*)(X + (rt * 16 + r16) * CS + 16 * c + 4 * g); },
+            [&](int ct, int rt, f32x4 acc) {
+                const float4 b = *(const float4*)(be + ct * 16 + 4 * g);
+                *(float4*)(H + (rt * 16 + r16) * HS + ct * 16 + 4 * g) =
+                    make_float4(fmaxf(acc[0] + b.x, 0.f), fmaxf(acc[1] + b.y, 0.f), fmaxf(acc[2] + b.z, 0.f), fmaxf(acc[3] + b.w, 0.f));
+            });
+        __syncthreads();
+        // ---- depthwise 3x3 + BN + ReLU, in place: one thread = the 5x5 plane of one (sample, channel) ----
+        for (int i = tid; i < NS * E; i += 768) {
+            const int s = i / E, c = i - s * E;
+            float* base = H + (s * 25) * HS + c;
+            float in[25], w[9];
+#pragma unroll
+            for (int k = 0; k < 25; k++) in[k] = base[k * HS];
+#pragma unroll
+            for (int k = 0; k < 9; k++) w[k] = N.Wd[((size_t)blk * E + c) * 9 + k];
+            const float bias = N.bd[blk * E + c];
+#pragma unroll
+            for (int y = 0; y < 5; y++)
+#pragma unroll
+                for (int x = 0; x < 5; x++) {
+                    float a = bias;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            const int yy = y + ky - 1, xx = x + kx - 1;
+                            if (yy >= 0 && yy < 5 && xx >= 0 && xx < 5) a += w[ky * 3 + kx] * in[yy * 5 + xx];
+                        }
+                    base[(y * 5 + x) * HS] = fmaxf(a, 0.f);
+                }
+        }
+        __syncthreads();
+        // ---- 1x1 project + BN + residual -> X (in place: a lane reads and writes its own elements) ----
+        const float* bp = N.bp + blk * 64;
+        mb_gemm<E / 16, 4, RT, NW>(
+            N.Wp + (size_t)blk * (E * 64), [&](int rt, int c) { return *(const float4*)(H + (rt * 16 + r16) * HS + 16 * c + 4 * g); },
+            [&](int ct, int rt, f32x4 acc) {
+                float* xp = X + (rt * 16 + r16) * CS + ct * 16 + 4 * g;
+                const float4 b = *(const float4*)(bp + ct * 16 + 4 * g), x = *(const float4*)xp;
+                *(float4*)xp = make_float4(acc[0] + b.x + x.x, acc[1] + b.y + x.y, acc[2] + b.z + x.z, acc[3] + b.w + x.w);
+            });
+        __syncthreads();
+    }
+    // ---- heads ----
+    float* FEAT_P = H;                      // [NS][FP]   policy features: 4 x 25 conv outputs (channel-major) + meta
+    float* FEAT_V = FEAT_P + NS * FP;       // [NS][FV]
+    float* LG = FEAT_V + NS * FV;           // [NS][AS]
+    float* H1 = LG + NS * AS;               // [NS][64]
+    for (int i = tid; i < NS * 25 * (CPI + CV); i += 768) {
+        const int r = i / (CPI + CV), c = i - r * (CPI + CV);
+        const float* xr = X + r * CS;
+        float a = c < CPI ? N.bhp[c] : N.bhv[c - CPI];
+#pragma unroll 8
+        for (int k = 0; k < 64; k++) a += xr[k] * (c < CPI ? N.Whp[k * CPI + c] : N.Whv[k * CV + (c - CPI)]);
+        a = fmaxf(a, 0.f);
+        const int s = r / 25, cell = r - 25 * s;
+        if (c < CPI) FEAT_P[s * FP + c * 25 + cell] = a; else FEAT_V[s * FV + (c - CPI) * 25 + cell] = a;
+    }
+    for (int i = tid; i < NS * 32; i += 768) {
+        const int s = i >> 5, j = i & 31;
+        FEAT_P[s * FP + CPI * 25 + j] = META[i];
+        FEAT_V[s * FV + CV * 25 + j] = META[i];
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += 768) {                      // policy FC: every thread one action for all NS samples
+        float acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc[s] = N.bfp[a];
+        for (int k = 0; k < FP; k++) {
+            const float w = N.Wfp[(size_t)k * A + a];
+#pragma unroll
+            for (int s = 0; s < NS; s++) acc[s] += FEAT_P[s * FP + k] * w;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++) LG[s * AS + a] = acc[s];
+    }
+    for (int i = tid; i < NS * 64; i += 768) {
+        const int s = i >> 6, j = i & 63;
+        float acc = N.bf1[j];
+        for (int k = 0; k < FV; k++) acc += FEAT_V[s * FV + k] * N.Wf1[k * 64 + j];
+        H1[s * 64 + j] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int s = wave; s < nb; s += NW) {                      // masked softmax, one wave per sample
+        const int b = b0 + s;
+        constexpr int NK = (A + 63) / 64;
+        float x[NK];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int a = lane + 64 * k;
+            x[k] = -INFINITY;
+            if (a < A) x[k] = valid[(size_t)b * A + a] ? LG[s * AS + a] : -1e8f;
+            mx = fmaxf(mx, x[k]);
+        }
+        mx = nn_wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; k++) { x[k] = (lane + 64 * k < A) ? expf(x[k] - mx) : 0.f; sum += x[k]; }
+        sum = nn_wave_sum(sum);
+#pragma unroll
+        for (int k = 0; k < NK; k++)
             if (lane + 64 * k < A) pi_out[(size_t)b * A + lane + 64 * k] = x[k] / sum;
     }
     if (tid < nb * P) {

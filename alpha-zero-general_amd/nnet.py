@@ -735,3 +735,48 @@ class SantoriniV78(SantoriniV89):
         logits = torch.where(valids.bool(), logits, torch.full_like(logits, -1e8))
         return torch.softmax(logits, dim=1).contiguous(), v.contiguous()
 
+
+
+class SantoriniV78Hip(SantoriniV89Hip):
+    """SantoriniV78 (with gods: 10 InvertedResidual blocks, A = 1782) evaluated by the engine's one-launch kernel
+    (azg_nn_s78_forward, csrc/nn_conv5x5.cuh): MFMA GEMMs for the 1x1 convolutions, in-place depthwise 3x3 on the LDS tile,
+    heads on the vector ALUs.  Wraps a SantoriniV78."""
+
+    def __init__(self, base, max_batch=4096):
+        import ctypes as C
+        from . import _lib
+        self._lib, self.base, self.device = _lib, base, base.device
+        self.P, self.A = base.P, base.A
+        assert base.dtype == torch.float32 and self.device.type == 'cuda' and len(base.blocks) == 10 and self.A == 1782 and self.P == 2
+        frag = SplendorV80Hip._frag
+        d = self.device
+        m0 = torch.zeros((9, 16, 64), dtype=torch.float32, device=d)
+        m0[:, :2] = base.c0[0].permute(2, 3, 1, 0).reshape(9, 2, 64)
+        assert float(base.c0[1].abs().max()) == 0.0          # the first conv of V78 has no bias and no BatchNorm
+        cat = lambda ts: torch.cat([t.reshape(-1) for t in ts]).contiguous()  # noqa: E731
+        keep = [frag(m0.reshape(144, 64).contiguous()),
+                cat([frag(we.reshape(192, 64).t().contiguous()) for (we, _), _, _ in base.blocks]), cat([be for (_, be), _, _ in base.blocks]),
+                cat([wd.reshape(192, 9) for _, (wd, _), _ in base.blocks]), cat([bd for _, (_, bd), _ in base.blocks]),
+                cat([frag(wp.reshape(64, 192).t().contiguous()) for _, _, (wp, _) in base.blocks]), cat([bp for _, _, (_, bp) in base.blocks]),
+                base.meta[0].contiguous(), base.meta[1].contiguous(),
+                base.hp[0].reshape(4, 64).t().contiguous(), base.hp[1].contiguous(), base.fc_pi[0].contiguous(), base.fc_pi[1].contiguous(),
+                base.hv[0].reshape(2, 64).t().contiguous(), base.hv[1].contiguous(), base.fc_v1[0].contiguous(), base.fc_v1[1].contiguous(),
+                base.fc_v2[0].contiguous(), base.fc_v2[1].contiguous()]
+        assert len(keep) == 19 and tuple(base.fc_pi[0].shape) == (132, 1782) and tuple(base.fc_v1[0].shape) == (82, 64)
+        self._keep = keep
+        self.ptrs = (C.c_void_p * 19)(*[t.data_ptr() for t in keep])
+        self._alloc(max_batch)
+
+    @torch.no_grad()
+    def forward(self, boards, valids):
+        import ctypes as C
+        B = boards.shape[0]
+        if B > self.maxB:
+            self._alloc(B)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        boards = boards.reshape(B, -1)
+        assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda and boards.shape[1] == 75
+        valids = (valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)).contiguous()
+        self._lib.check(self._lib.lib().azg_nn_s78_forward(p(boards), p(valids), self.ptrs, 10, self.A, self.P, B, p(self.pi),
+                                                           p(self.v), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return self.pi[:B], self.v[:B]

@@ -205,8 +205,9 @@ def main():
         if a.net == 'hip' and og['net'] in ('SplendorV80', 'AzulV84') and a.net_dtype == 'fp32':
             net = _nn.MobileNet1dHip(net, max_batch=T // a.groups)        # the whole forward in one launch (nn_mb1d.cuh)
             og = dict(og, label=og['label'] + ' (engine kernels)')
-        elif a.net == 'hip' and a.game == 'santorini1' and a.net_dtype == 'fp32':
-            net = _nn.SantoriniV89Hip(net, max_batch=T // a.groups)       # implicit-GEMM ResNet in one launch (nn_conv5x5.cuh)
+        elif a.net == 'hip' and a.game in ('santorini1', 'santorini11') and a.net_dtype == 'fp32':
+            # the ResNet / the with-gods MobileNet in one launch (nn_conv5x5.cuh)
+            net = (_nn.SantoriniV89Hip if a.game == 'santorini1' else _nn.SantoriniV78Hip)(net, max_batch=T // a.groups)
             og = dict(og, label=og['label'] + ' (engine kernels)')
         else:
             a.net = 'torch'
@@ -225,7 +226,8 @@ def main():
             SplendorV80.random_init(device=dev, dtype=dtype)
     # nodes live until the root's age passes theirs: ~12 plies' worth of simulations in Splendor, more in the narrow, deep
     # searches of Azul / Santorini
-    cap = a.node_capacity or max(2048, (16 if a.game == 'splendor2' else 32) * a.sims + 512)
+    # (Santorini with gods: A = 1782 makes a node ~5 KB; 14 x sims keeps 4096 trees within the 288 GB, clean-up leaves <= 9.4 k alive)
+    cap = a.node_capacity or max(2048, {'splendor2': 16, 'santorini11': 14}.get(a.game, 32) * a.sims + 512)
     eng = None
     for attempt in range(3):           # the forest wants ~170 GB of the 288 GB HBM: shrink the arena if the device has less to give
         try:

@@ -231,3 +231,25 @@ def test_santorini_v89_one_launch_gpu():
     pr, vr = base.predict_batch(rb, rm)
     assert float((pi2 - pr).abs().max()) < 1e-5 and float((v2 - vr).abs().max()) < 2e-5
     assert float(pi2[~rm].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_santorini_v78_one_launch_gpu():
+    """SantoriniV78Hip (one launch: MFMA 1x1 convolutions, in-place depthwise 3x3, VALU heads) vs the torch-ops SantoriniV78
+    of the same pretrained_withgods weights (itself checked against an nn.Module restatement: V78 parity is unpinned) on
+    boards from the golden env trajectories and on a ragged random batch."""
+    from azg_amd import nnet
+    root = os.path.join(os.path.dirname(__file__), 'golden')
+    base = nnet.SantoriniV78.from_npz(os.path.join(root, 'weights_santorini11_v78.npz'), device='cuda:0')
+    net = nnet.SantoriniV78Hip(base, max_batch=64)
+    env = np.load(os.path.join(root, 'env_santorini11.npz'))
+    states = torch.from_numpy(env['state'][:150].astype(np.int8)).reshape(-1, 75).to('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    for boards in (states, torch.randint(-2, 5, (203, 75), generator=g, dtype=torch.int8).to('cuda:0')):
+        B = boards.shape[0]
+        rm = (torch.rand((B, 1782), generator=g) < 0.05).to('cuda:0')
+        rm[:, 7] = True
+        pi, v = net.predict_batch(boards, rm)
+        pr, vr = base.predict_batch(boards.reshape(B, 5, 5, 3), rm)
+        assert float((pi - pr).abs().max()) < 1e-5 and float((v - vr).abs().max()) < 2e-5
+        assert float(pi[~rm].abs().max()) == 0.0 and abs(float(pi.sum(dim=1).mean()) - 1.0) < 1e-5

@@ -39,3 +39,11 @@ valids = (torch.rand((T, 162), device='cuda:0') < 0.5).to(torch.uint8)
 valids[:, 0] = 1
 print('santorini1 V89 T=%d' % T, 'torch ops (MIOpen) %.1f us' % timed(base, boards, valids.bool(), 10),
       ' k_conv5_net %.1f us' % timed(nnet.SantoriniV89Hip(base, max_batch=T), boards, valids), flush=True)
+
+base = nnet.SantoriniV78.from_npz(G + '/weights_santorini11_v78.npz', device='cuda:0')
+Tg = min(T, 1024)
+boards = torch.randint(-2, 5, (Tg, 5, 5, 3), dtype=torch.int8, device='cuda:0')
+valids = (torch.rand((Tg, 1782), device='cuda:0') < 0.1).to(torch.uint8)
+valids[:, 0] = 1
+print('santorini11 V78 T=%d' % Tg, 'torch ops (MIOpen) %.1f us' % timed(base, boards, valids.bool(), 5),
+      ' k_s78_net %.1f us' % timed(nnet.SantoriniV78Hip(base, max_batch=Tg), boards, valids), flush=True)
