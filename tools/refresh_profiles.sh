@@ -16,8 +16,8 @@ python bench.py > gpurun_out/r01c_bench.json 2> gpurun_out/r01c_bench.err
 python bench.py --steps 1700 --warmup 100 --no-cpu-baseline > gpurun_out/r01c_bench_fresh.json 2>/dev/null
 python bench.py --prob-full 0.25 --no-cpu-baseline --roofline-rounds 0 2>/dev/null | tail -1 > gpurun_out/r01c_bench_mix.json
 python bench.py --steps 3000 --warmup 500 --roofline-rounds 0 --cpu-procs 64 2>/dev/null | tail -1 > gpurun_out/r01c_bench_cpu64.json
-for g in azul splendor4 santorini1; do
-  python bench.py --game $g --steps 40000 --warmup 4000 --no-cpu-baseline --roofline-rounds 0 2>/dev/null | tail -1 > gpurun_out/r01c_bench_$g.json
+for g in azul splendor4 santorini1 santorini11; do
+  python bench.py --game $g --steps $([ $g = santorini11 ] && echo 20000 || echo 40000) --warmup 4000 --no-cpu-baseline --roofline-rounds 0 2>/dev/null | tail -1 > gpurun_out/r01c_bench_$g.json
 done
 tail -c 1500 gpurun_out/r01c_bench.json
 cat gpurun_out/r01c_pytest.txt
