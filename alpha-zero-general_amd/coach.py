@@ -27,8 +27,16 @@ class Coach:
         self.results = []
 
     def _infer_net(self, module, max_batch):
+        """the engine-kernel evaluator of the module's current weights (BatchNorm folded): the 2-player V80 layout kernel, or
+        the generic one-launch kernel for the other geometries of the family (Splendor 3-4p, Azul V84)"""
+        from . import nnet
         sd = {k: v.detach().cpu() for k, v in module.state_dict().items()}
-        return SplendorV80Hip(sd, num_players=self.game.P, device=str(self.game.device), max_batch=max_batch)
+        dev = str(self.game.device)
+        if getattr(module, 'version', 80) == 84:
+            return nnet.MobileNet1dHip(nnet.AzulV84(sd, num_players=self.game.P, device=dev), max_batch=max_batch)
+        if self.game.P == 2:
+            return SplendorV80Hip(sd, num_players=2, device=dev, max_batch=max_batch)
+        return nnet.MobileNet1dHip(nnet.SplendorV80(sd, num_players=self.game.P, device=dev), max_batch=max_batch)
 
     def execute_episodes(self):
         """Coach.executeEpisodes (:86-148): numEps finished games of self-play with the current net -> one iteration's examples"""

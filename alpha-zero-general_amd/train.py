@@ -38,17 +38,29 @@ class _SE(nn.Module):
         return x * s[:, :, None]
 
 
+def _make_divisible(v, divisor=8, min_value=None):
+    """torchvision.models._utils._make_divisible (the SE squeeze width of the reference blocks)"""
+    min_value = divisor if min_value is None else min_value
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    return new_v + divisor if new_v < 0.9 * v else new_v
+
+
 class _Block(nn.Module):
-    def __init__(self, c, e, use_hs, setype, tokens=7):
+    """InvertedResidual1d (SplendorNNet.py:189-202, AzulNNet.py:47-80): residual only when in == out channels"""
+
+    def __init__(self, c, e, use_hs, setype, tokens=7, c_out=None):
         super().__init__()
+        c_out = c if c_out is None else c_out
         act = nn.Hardswish if use_hs else nn.ReLU
         self.expand = _LinearNormAct(c, e, act)
         self.depthwise = _LinearNormAct(tokens, tokens, act, depthwise=True, channels=e)
-        self.se = _SE(e, max(8, (e // 4 + 4) // 8 * 8), setype)          # _make_divisible(e // 4, 8)
-        self.project = _LinearNormAct(e, c, None)
+        self.se = _SE(e, _make_divisible(e // 4, 8), setype)
+        self.project = _LinearNormAct(e, c_out, None)
+        self.use_res_connect = c == c_out
 
     def forward(self, x):
-        return self.project(self.se(self.depthwise(self.expand(x)))) + x
+        y = self.project(self.se(self.depthwise(self.expand(x))))
+        return y + x if self.use_res_connect else y
 
 
 class SplendorV80Module(nn.Module):
@@ -70,6 +82,32 @@ class SplendorV80Module(nn.Module):
     def forward(self, boards, valid_actions):
         """-> (log pi [B, A], v [B, P]) like the reference module"""
         x = boards.reshape(-1, self.C, 7).float()
+        x = self.first_layer(x)
+        x = F.dropout(self.trunk(x), p=self.dropout, training=self.training)
+        v = self.output_layers_V(x)
+        pi = torch.where(valid_actions.bool(), self.output_layers_PI(x), self.lowvalue)
+        return F.log_softmax(pi, dim=1), torch.tanh(v)
+
+
+class AzulV84Module(nn.Module):
+    """azul/AzulNNet.py nn_version 84 (:91-113,130-142) with the reference's parameter names: [B, 23, 6] boards, trunk block
+    23->115->23, policy head block 23->115->46 (no residual) + Linear(276,180)+ReLU+Linear, value head block 23->46->23."""
+    version = 84
+
+    def __init__(self, num_players=2, action_size=180, dropout=0.0):
+        super().__init__()
+        self.C, self.L, self.P, self.A, self.dropout = 23, 6, num_players, action_size, dropout
+        C, L = self.C, self.L
+        self.first_layer = _LinearNormAct(C, C, None)
+        self.trunk = nn.Sequential(_Block(C, 5 * C, False, 'avg', tokens=L))
+        self.output_layers_PI = nn.Sequential(_Block(C, 5 * C, True, 'avg', tokens=L, c_out=2 * C), nn.Flatten(1),
+                                              nn.Linear(2 * C * L, action_size), nn.ReLU(), nn.Linear(action_size, action_size))
+        self.output_layers_V = nn.Sequential(_Block(C, 2 * C, True, 'avg', tokens=L), nn.Flatten(1), nn.Linear(C * L, num_players),
+                                             nn.ReLU(), nn.Linear(num_players, num_players))
+        self.register_buffer('lowvalue', torch.FloatTensor([-1e8]))
+
+    def forward(self, boards, valid_actions):
+        x = boards.reshape(-1, self.C, self.L).float()
         x = self.first_layer(x)
         x = F.dropout(self.trunk(x), p=self.dropout, training=self.training)
         v = self.output_layers_V(x)

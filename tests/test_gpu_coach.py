@@ -35,3 +35,26 @@ def test_coach_learn_two_iterations(tmp_path):
     assert 'state_dict' in ck and ck['numMCTSSims'] == 8 and ck['full_model'].version == 80
     if res[-1]["accepted"]:
         assert os.path.exists(os.path.join(tmp_path, 'best.pt'))
+
+
+def test_coach_learn_azul_one_iteration(tmp_path):
+    """BASELINE config 5 in miniature: Coach.learn on Azul (V84 module, engine self-play with the one-launch net, training,
+    arena gate) -- one iteration end to end."""
+    from azg_amd import formats, games
+    from azg_amd.coach import Coach
+    from azg_amd.train import AzulV84Module
+    g = games.AzulGame()
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'weights_azul_v84.npz'))
+    m = AzulV84Module()
+    m.load_state_dict({k[3:]: torch.as_tensor(z[k]) for k in z.files if k.startswith('sd/')})
+    args = Args(numMCTSSims=8, cpuct=0.5, fpu=0.05, universes=1, forced_playouts=True, dirichletAlpha=-1, prob_fullMCTS=1.0,
+                ratio_fullMCTS=5, temperature=[1.25, 0.8, 1.0], tempThreshold=10, numIters=1, numEps=8, numItersHistory=2,
+                maxlenOfQueue=100000, learn_rate=1e-3, batch_size=64, epochs=1, q_weight=1.0, arenaCompare=4,
+                updateThreshold=0.6, checkpoint=str(tmp_path))
+    c = Coach(g, m, args, n_games=16, node_capacity=2048, log=lambda s: None)
+    res = c.learn()
+    assert len(res) == 1 and res[0]["nwins"] + res[0]["pwins"] + res[0]["draws"] == 4 and res[0]["examples"] > 64
+    hist = formats.load_train_examples(os.path.join(tmp_path, 'checkpoint.examples'))
+    assert hist[0][0][0].shape == (23, 6) and len(hist[0][0][1]) == 180
+    ck = torch.load(os.path.join(tmp_path, 'temp.pt'), map_location='cpu', weights_only=False)
+    assert ck['full_model'].version == 84 and set(ck['state_dict'].keys()) == set(m.state_dict().keys())

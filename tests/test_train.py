@@ -59,3 +59,18 @@ def test_module_4p_matches_reference_outputs():
     with torch.no_grad():
         lp, v = m.eval()(torch.from_numpy(d['boards']), torch.from_numpy(d['masks'].astype(bool)))
     assert np.allclose(torch.exp(lp).numpy(), d['pi'], atol=1e-5, rtol=0) and np.allclose(v.numpy(), d['v'], atol=1e-5, rtol=0)
+
+
+def test_azul_module_matches_reference_outputs_and_names():
+    """AzulV84Module: the reference checkpoint loads with strict=True (same parameter names) and reproduces the reference
+    model's golden outputs (BASELINE config 5 trains this net)."""
+    from azg_amd.train import AzulV84Module
+    z = np.load(os.path.join(GOLDEN, 'weights_azul_v84.npz'))
+    sd = {k[3:]: torch.as_tensor(z[k]) for k in z.files if k.startswith('sd/')}
+    m = AzulV84Module()
+    m.load_state_dict(sd, strict=True)
+    d = np.load(os.path.join(GOLDEN, 'netfwd_azul_v84.npz'))
+    with torch.no_grad():
+        lp, v = m.eval()(torch.from_numpy(d['boards']), torch.from_numpy(d['masks'].astype(bool)))
+    assert np.allclose(torch.exp(lp).numpy(), d['pi'], atol=1e-5, rtol=0)
+    assert np.allclose(v.numpy(), d['v'], atol=3e-5, rtol=0)
