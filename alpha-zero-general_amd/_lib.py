@@ -24,7 +24,7 @@ class SelfplayStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ('plies', 'games', 'sims', 'levels', 'expansions', 'sum_valid_visited',
                                           'terminal_hits', 'examples', 'gc_runs', 'max_nodes', 'errors',
                                           'sum_depth_at_expand', 'cyc_select', 'cyc_levels', 'cyc_edge', 'cyc_leaf')] + [
-                                          ('cyc_seg', C.c_uint64 * 4), ('max_live_after_gc', C.c_uint64)]
+                                          ('cyc_seg', C.c_uint64 * 4), ('max_live_after_gc', C.c_uint64), ('examples_dropped', C.c_uint64)]
 
 
 class AzgError(RuntimeError):
@@ -38,7 +38,7 @@ EXPORTS = [
     'azg_env_next_state', 'azg_env_game_ended', 'azg_env_canonical', 'azg_env_init_boards', 'azg_env_symmetries', 'azg_forest_create',
     'azg_forest_destroy', 'azg_forest_device_bytes', 'azg_forest_reset', 'azg_forest_begin_search',
     'azg_forest_select', 'azg_forest_select_fused', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
-    'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_forest_validate', 'azg_selfplay_start', 'azg_selfplay_advance',
+    'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_forest_validate', 'azg_selfplay_start', 'azg_selfplay_start_ex', 'azg_selfplay_advance', 'azg_selfplay_active',
     'azg_selfplay_stats_get', 'azg_selfplay_drain_examples', 'azg_forest_last_kernel_ms', 'azg_forest_enable_timing', 'azg_nn_linear', 'azg_nn_linear_ws', 'azg_nn_dw_pool', 'azg_nn_v80_block', 'azg_nn_v80_forward',
     'azg_nn_board_to_x', 'azg_nn_heads_out', 'azg_nn_dw_pool_l', 'azg_nn_board_to_x_ld', 'azg_nn_mb1d_forward', 'azg_nn_conv5_forward', 'azg_nn_s78_forward',
 ]
@@ -78,7 +78,9 @@ def lib():
     L.azg_forest_dump_tree.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp]
     L.azg_forest_validate.argtypes = [vp, i]
     L.azg_selfplay_start.argtypes = [vp, vp, vp]
+    L.azg_selfplay_start_ex.argtypes = [vp, vp, u64, C.c_int64, vp]
     L.azg_selfplay_advance.argtypes = [vp, vp]
+    L.azg_selfplay_active.argtypes = [vp, ip]
     L.azg_selfplay_stats_get.argtypes = [vp, C.POINTER(SelfplayStats)]
     L.azg_selfplay_drain_examples.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, ip, vp]
     L.azg_forest_last_kernel_ms.argtypes = [vp, i, C.POINTER(dbl), C.POINTER(u64)]

@@ -49,14 +49,20 @@ class Coach:
             for grp in self.engine.groups:
                 grp.net = net
             self.engine.nnet, self.engine.graph = net, None          # new weights: the captured rounds are stale
-        self.engine.start()
-        games0 = self.engine.stats()['games']
+        # exactly numEps episodes, each played to its end (Coach.py:86-148); a new RNG epoch per call, so an iteration never
+        # replays the games of the previous one (the reference draws fresh randomness every iteration)
+        self.n_selfplay_waves = getattr(self, 'n_selfplay_waves', 0) + 1
+        self.engine.start(epoch=self.n_selfplay_waves, episode_quota=num_eps)
         sims = int(_get(self.args, 'numMCTSSims', 800))
-        while self.engine.stats()['games'] - games0 < num_eps:
+        while True:
             self.engine.run(8 * max(8, sims))
             st = self.engine.stats()
             if st['errors']:
-                raise RuntimeError('engine error flags %d' % st['errors'])
+                raise RuntimeError('engine error flags %d (16 = example ring overflow: %d records dropped)'
+                                   % (st['errors'], st['examples_dropped']))
+            if st['active'] == 0:
+                break
+        assert st['games'] == num_eps, (st['games'], num_eps)
         return self.engine.drain_examples(symmetries=True)
 
     def learn(self):
@@ -80,8 +86,9 @@ class Coach:
                   epochs=int(_get(a, 'epochs', 2)), q_weight=float(_get(a, 'q_weight', 0.5)), device=str(self.game.device),
                   log=self.log)
             n_arena = int(_get(a, 'arenaCompare', 30))
+            # a fresh block of RNG streams per iteration (boards and chance outcomes of the arena games)
             arena = BatchedArena(self.game, self._infer_net(self.module, n_arena), self._infer_net(previous, n_arena), a,
-                                 n_parallel=n_arena, node_capacity=self.cap)
+                                 n_parallel=n_arena, node_capacity=self.cap, stream0=(1 << 32) * it)
             nwins, pwins, draws = arena.playGames(n_arena)
             for m in arena.mcts:
                 m.forest.close()

@@ -22,7 +22,7 @@ static int fail(const std::string& m) { g_err = m; return -1; }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
 
 extern "C" const char* azg_last_error(void) { return g_err.c_str(); }
-extern "C" const char* azg_version(void) { return "azg-hip r1 (gfx950)"; }
+extern "C" const char* azg_version(void) { return "azg-hip r2 (gfx950)"; }
 extern "C" int azg_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
 
@@ -234,10 +234,13 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
         rc |= dalloc(f, &D.ex_q, E * f->P);
         rc |= dalloc(f, &D.ex_meta, E * 4);
     }
-    rc |= dalloc(f, &D.ex_count, 2);
+    rc |= dalloc(f, &D.ex_count, 4);
     if (rc) { azg_forest_destroy(f); return -1; }
     hipError_t e = hipMemset(D.hdr, 0, T * sizeof(TreeHdr));
-    if (e == hipSuccess) e = hipMemset(D.ex_count, 0, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        const unsigned long long init[4] = {0ull, 0ull, 0ull, (unsigned long long)cfg->rng_seed};   // [3] = effective RNG seed
+        e = hipMemcpy(D.ex_count, init, sizeof(init), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemset(D.root_state, 0, T * f->SP);
     if (e == hipSuccess) e = hipMemset(D.board, 0, T * f->SP);
     if (e != hipSuccess) { azg_forest_destroy(f); return fail(hipGetErrorString(e)); }
@@ -471,13 +474,35 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
 }
 
 // ---- self-play ------------------------------------------------------------------------------------------------------
-extern "C" int azg_selfplay_start(azg_forest* f, const int8_t* init_boards, void* stream) {
+extern "C" int azg_selfplay_start_ex(azg_forest* f, const int8_t* init_boards, uint64_t epoch, int64_t episode_quota,
+                                     void* stream) {
     if (!f) return fail("null forest");
     if (f->dev.max_examples <= 0) return fail("forest created with max_examples == 0");
-    HIPCHK(hipMemsetAsync(f->dev.ex_count, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream));
+    if (episode_quota < 0) return fail("azg_selfplay_start_ex: episode_quota < 0");
+    // epoch 0 keeps the streams of the RNG contract; any other epoch re-keys every stream of this forest (boards, playout-cap
+    // draws, root noise, move picks), so that successive self-play / arena waves of one run do not replay the same games
+    // (the effective seed lives in device memory, ex_count[3]: kernels captured in a HIP graph see the new epoch)
+    const unsigned long long seed = epoch ? f->cfg.rng_seed ^ (0x9E3779B97F4A7C15ULL * (epoch + 0x632BE59BD9B4E019ULL)) : f->cfg.rng_seed;
+    const unsigned long long init[4] = {0ull, 0ull, (unsigned long long)episode_quota, seed};
+    HIPCHK(hipMemcpyAsync(f->dev.ex_count, init, sizeof(init), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));           // `init` is a stack buffer
     FDISPATCH(f, k_selfplay_start<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev,
                                      init_boards));
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azg_selfplay_start(azg_forest* f, const int8_t* init_boards, void* stream) {
+    return azg_selfplay_start_ex(f, init_boards, 0, 0, stream);
+}
+
+extern "C" int azg_selfplay_active(azg_forest* f, int* n_active) {
+    if (!f || !n_active) return fail("null argument");
+    std::vector<TreeHdr> h(f->dev.T);
+    HIPCHK(hipMemcpy(h.data(), f->dev.hdr, sizeof(TreeHdr) * h.size(), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (auto& x : h) n += (x.status != ST_IDLE && !x.err);
+    *n_active = n;
     return 0;
 }
 
@@ -521,6 +546,10 @@ extern "C" int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out) {
         if (x.max_nodes_seen > out->max_nodes) out->max_nodes = x.max_nodes_seen;
         if (x.max_live > out->max_live_after_gc) out->max_live_after_gc = x.max_live;
     }
+    unsigned long long cnt[4];
+    HIPCHK(hipMemcpy(cnt, f->dev.ex_count, sizeof(cnt), hipMemcpyDeviceToHost));
+    out->examples_dropped = cnt[1];
+    if (cnt[1]) out->errors |= ERR_EXAMPLE_OVERFLOW;              // finished games that did not fit the example ring
     return 0;
 }
 

@@ -132,8 +132,13 @@ struct ForestDev {
     // example ring
     int8_t* ex_board; float* ex_pi; float* ex_z; uint8_t* ex_valid; float* ex_q;
     int32_t* ex_meta;                  // [max_examples][4] = (global game stream, game index on that stream, ply, player)
-    unsigned long long* ex_count;      // [0] = records written (may exceed capacity => dropped), [1] = dropped
+    unsigned long long* ex_count;      // [0] = records written, [1] = dropped (games that did not fit), [2] = episode quota
+                                       // (0 = restart forever), [3] = effective RNG seed (cfg.rng_seed re-keyed by the epoch
+                                       // of azg_selfplay_start_ex; in device memory so that captured graphs see a new epoch)
 };
+__device__ __forceinline__ uint64_t forest_seed(const ForestDev& F) {
+    return ((uint64_t)uni_u32((uint32_t)(F.ex_count[3] >> 32)) << 32) | uni_u32((uint32_t)F.ex_count[3]);
+}
 
 // Load a header through the vector path but keep every word wave-uniform (SGPR): the tree / node headers drive the
 // control flow of the whole wave, so they should not occupy 64 lanes' worth of VGPRs.

@@ -182,7 +182,7 @@ __device__ __forceinline__ bool root_noise_tree(const ForestDev& F, int t, uint3
     wave_sync();
     const double* nz = root_noise ? root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride) : nullptr;
     FR::root_noise_dense(dense, mask, F.temp_root, nz, root_noise != nullptr && noise_stride < 0, F.dirichletAlpha,
-                         mix64(mix64(F.rng_seed ^ 0xA5A5A5A55A5A5A5AULL) + F.stream0 + (uint64_t)t), c_sims << 20);
+                         mix64(mix64(forest_seed(F) ^ 0xA5A5A5A55A5A5A5AULL) + F.stream0 + (uint64_t)t), c_sims << 20);
     for (int j = l; j < nv; j += 64) *(float*)(rec + AZG_REC_HDR + (size_t)j * L.ES + AZG_E_P) = dense[ids[j]];
     return true;
 }

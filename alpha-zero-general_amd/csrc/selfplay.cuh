@@ -120,15 +120,29 @@ __device__ void start_game(const ForestDev& F, int t, TreeHdr& H, typename Fores
     H.cur_player = 0; H.ply = 0; H.step = 0; H.n_rec = 0;
 }
 
+// Episode quota (Coach.executeEpisodes plays exactly numEps episodes, every one to its end, Coach.py:86-148): with
+// ex_count[2] = numEps != 0, tree t plays numEps / T (+1 for t < numEps % T) games and then goes idle instead of
+// restarting, so every started game finishes and is kept -- no bias towards short games.  0 = restart forever.
+__device__ __forceinline__ uint32_t tree_quota(const ForestDev& F, int t) {
+    const unsigned long long q = F.ex_count[2];
+    return (uint32_t)(q / (unsigned long long)F.T) + ((unsigned long long)t < q % (unsigned long long)F.T ? 1u : 0u);
+}
+
 template <class G>
 __global__ __launch_bounds__(64) void k_selfplay_start(ForestDev F, const int8_t* init_boards) {
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
     const int t = blockIdx.x;
     TreeHdr H = load_uniform(&F.hdr[t]);
-    Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, 0ull};
+    Rng rng{forest_seed(F), F.stream0 + (uint64_t)t, 0ull};
     H.err = 0; H.games_done = 0; H.gc_runs = 0; H.max_nodes_seen = 0; H.max_live = 0;
     H.c_sims = H.c_levels = H.c_exp = H.c_sumvalid = H.c_term = H.c_depth = H.c_plies = H.c_examples = 0;
+    if (F.ex_count[2] != 0ull && tree_quota(F, t) == 0u) {       // fewer episodes than trees: this tree plays none
+        reset_tree<G>(F, t, H);
+        H.status = ST_IDLE; H.noise_pending = 0; H.pending_leaf = AZG_NONE; H.mid_sim = 0; H.n_rec = 0; H.rng_counter = 0;
+        if (lane_id() == 0) F.hdr[t] = H;
+        return;
+    }
     start_game<G>(F, t, H, sm, rng, init_boards ? init_boards + (size_t)t * G::S : nullptr);
     // board is canonical for player 0 (Coach.py:61 with curPlayer == 0)
     const double u_full = rng.u01();
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(64) void k_after_gc(ForestDev F) {
     const int t = blockIdx.x;
     if (uni_u32(F.hdr[t].status) != ST_GC_DONE) return;
     TreeHdr H = load_uniform(&F.hdr[t]);
-    Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, H.rng_counter};
+    Rng rng{forest_seed(F), F.stream0 + (uint64_t)t, H.rng_counter};
     FR::load_state(sm.st, F.root_state + (size_t)t * G::SP);
     begin_next_search<G>(F, t, H, sm, rng, dense);
     if (lane_id() == 0) F.hdr[t] = H;
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     }
     TreeHdr H = load_uniform(&F.hdr[t]);
     if (H.err) return;                         // tree is parked; the host reads the error flag
-    Rng rng{F.rng_seed, F.stream0 + (uint64_t)t, H.rng_counter};
+    Rng rng{forest_seed(F), F.stream0 + (uint64_t)t, H.rng_counter};
     float q[G::P];
 #pragma unroll
     for (int p = 0; p < G::P; p++) q[p] = 0.f;
@@ -327,13 +341,23 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     const bool ended = G::game_ended(sm.st, np, es, sm.mask);                                  // Coach.py:73
     if (ended) {
         // z = np.roll(r, -player) (Coach.py:76-82): z[i] = r[(i + player) mod P]
+        // reserve the ring slots of the whole game or of none of it (a finished game is never truncated); a game that
+        // does not fit is dropped and counted in ex_count[1] (azg_selfplay_stats.examples_dropped, error bit 16)
         unsigned long long base = 0;
-        if (l == 0) base = atomicAdd(F.ex_count, (unsigned long long)H.n_rec);
+        if (l == 0) {
+            const unsigned long long n = (unsigned long long)H.n_rec, cap = (unsigned long long)F.max_examples;
+            unsigned long long seen = *(volatile unsigned long long*)F.ex_count;
+            while (true) {
+                if (seen + n > cap) { base = ~0ull; atomicAdd(F.ex_count + 1, n); break; }
+                const unsigned long long prev = atomicCAS(F.ex_count, seen, seen + n);
+                if (prev == seen) { base = seen; break; }
+                seen = prev;
+            }
+        }
         base = bcast_u64(base, 0);
-        for (uint32_t k = 0; k < H.n_rec; k++) {
+        for (uint32_t k = 0; k < H.n_rec && base != ~0ull; k++) {
             const size_t r = (size_t)t * F.max_rec + k;
             const unsigned long long dst = base + k;
-            if (dst >= (unsigned long long)F.max_examples) { if (l == 0) atomicAdd(F.ex_count + 1, 1ull); continue; }
             for (int i = l; i < G::S; i += 64) F.ex_board[dst * G::S + i] = F.rec_board[r * G::S + i];
             for (int a = l; a < G::A; a += 64) {
                 F.ex_pi[dst * G::A + a] = F.rec_pi[r * G::A + a];
@@ -351,8 +375,13 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
                 F.ex_meta[dst * 4 + 3] = pl;
             }
         }
-        H.c_examples += H.n_rec;
+        if (base != ~0ull) H.c_examples += H.n_rec;
         H.games_done++;
+        if (F.ex_count[2] != 0ull && H.games_done >= tree_quota(F, t)) {      // episode quota reached: no restart
+            H.status = ST_IDLE; H.n_rec = 0; H.rng_counter = rng.counter;
+            if (l == 0) F.hdr[t] = H;
+            return;
+        }
         start_game<G>(F, t, H, sm, rng, nullptr);
     } else {
         FR::store_state(F.board + (size_t)t * G::SP, sm.st);

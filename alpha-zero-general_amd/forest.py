@@ -160,10 +160,12 @@ class Forest:
         return check(lib().azg_forest_validate(self.h, int(verbose)))
 
     # ---- self-play ----
-    def selfplay_start(self, init_boards=None):
+    def selfplay_start(self, init_boards=None, epoch=0, episode_quota=0):
+        """epoch: re-keys the forest's random streams (0 = the RNG contract's streams); episode_quota: Coach.executeEpisodes'
+        numEps for this forest (every started game is played to its end, then the tree idles), 0 = restart forever"""
         ib = None if init_boards is None else init_boards.reshape(self.T, self.S).contiguous()
         self._keep_ib = ib
-        check(lib().azg_selfplay_start(self.h, _ptr(ib), _stream()))
+        check(lib().azg_selfplay_start_ex(self.h, _ptr(ib), int(epoch), int(episode_quota), _stream()))
 
     def selfplay_advance(self):
         check(lib().azg_selfplay_advance(self.h, _stream()))
@@ -171,7 +173,15 @@ class Forest:
     def stats(self):
         s = SelfplayStats()
         check(lib().azg_selfplay_stats_get(self.h, C.byref(s)))
-        return {n: (list(getattr(s, n)) if n == 'cyc_seg' else int(getattr(s, n))) for n, _ in SelfplayStats._fields_}
+        d = {n: (list(getattr(s, n)) if n == 'cyc_seg' else int(getattr(s, n))) for n, _ in SelfplayStats._fields_}
+        d['active'] = self.active_count()
+        return d
+
+    def active_count(self):
+        """trees that are still playing (searching, waiting for the net, the clean-up or their next search)"""
+        n = C.c_int()
+        check(lib().azg_selfplay_active(self.h, C.byref(n)))
+        return n.value
 
     def drain_examples(self, max_records=None):
         max_records = max_records or self.cfg.max_examples

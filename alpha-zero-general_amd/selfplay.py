@@ -82,10 +82,19 @@ class SelfPlayEngine:
         self.rounds = 0
         self._streams = [torch.cuda.Stream() for _ in range(groups)] if groups > 1 else None
 
-    def start(self, init_boards=None):
+    def start(self, init_boards=None, epoch=0, episode_quota=0):
+        """epoch: re-keys every random stream (Coach passes the iteration number, so that successive iterations do not
+        replay the same games); episode_quota = numEps of Coach.executeEpisodes: exactly that many games are played, each to
+        its end (0 = trees restart forever; the caller decides when to stop)"""
         Tg = self.T // self.G
         for g, grp in enumerate(self.groups):
-            grp.f.selfplay_start(None if init_boards is None else init_boards[g * Tg:(g + 1) * Tg])
+            q = episode_quota // self.G + (1 if g < episode_quota % self.G else 0)
+            if episode_quota and q == 0:
+                q = -1                       # this group plays nothing (handled below)
+            grp.f.selfplay_start(None if init_boards is None else init_boards[g * Tg:(g + 1) * Tg], epoch=epoch,
+                                 episode_quota=max(q, 0) if q >= 0 else 0)
+            assert q >= 0, 'episode_quota smaller than the number of groups'
+        # a captured graph stays valid: the epoch-keyed seed and the quota live in device memory (ex_count[2..3])
         torch.cuda.synchronize()
         # pipeline prologue: odd groups enter the steady state one stage ahead (their leaves are already selected)
         for g, grp in enumerate(self.groups):

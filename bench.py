@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- self-play env-steps/sec @ numMCTSSims=800, Splendor-2p, T concurrent games per MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by torch.distributed.run, one rank per GPU).
-A "step" is one lock-step round of the hot path over the batch of T games:
-    select (HIP) -> NeuralNet.predict_batch (PyTorch-ROCm) -> expand_backup (HIP) -> selfplay_advance (HIP)
-i.e. one MCTS simulation for every concurrent game, incl. the env steps, root noise, move sampling and example
-recording that fall into that round.  Every ply is a full numMCTSSims search (prob_fullMCTS=1).
-value = env-steps/sec = (simulations completed in the timed region / numMCTSSims) / seconds, summed over ranks; the
-integer number of plies that completed inside the region is reported next to it.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 either launch it under torch.distributed.run (one
+rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE in the environment) or call it plainly: without WORLD_SIZE it re-executes
+itself under torch.distributed.run with N ranks on 127.0.0.1 and rank 0 prints the one JSON line.
 
-Extra objects on the JSON line: "roofline" (select+backup kernels, HIP events on the launch stream, algorithmic bytes
-from live engine counters, SURVEY.md §8d formula) and "cpu_baseline" (the C oracle + PyTorch-CPU net on one host core,
-bounded sample, rank 0 at N=1 only).
+A "step" is one PLY WAVE of the hot path over the batch of T games per GPU: numMCTSSims lock-step rounds of
+    select + expand/backup (HIP, one launch) -> NeuralNet.predict_batch (engine MFMA kernel) [-> selfplay_advance (HIP)]
+i.e. one full search for every concurrent game plus the per-ply work of Coach.executeEpisode (Coach.py:61-84: policy
+target, move sampling, example record, the env step Coach.py:71, end detection, restart, re-root, clean-up, root noise).
+Every ply is a full numMCTSSims search (prob_fullMCTS=1).  value = env-steps/sec = plies executed in the
+timed region / seconds, summed over ranks (Coach.py:71: one getNextState = one env step); the simulation-based figure
+(simulations / numMCTSSims / seconds, which also counts the partial plies at the window edges) is printed next to it.
+
+Extra objects on the JSON line: "roofline" (the select+expand+backup kernel, HIP events on the launch stream, algorithmic
+bytes from live engine counters, SURVEY.md §8d formula), "cpu_baseline" (the C oracle + PyTorch-CPU net on the host
+cores, bounded sample, rank 0 at N=1 only) and "secondary" (the north star's second target, Santorini no-gods, same
+engine, shorter window, with its own roofline).
 """
 import argparse
 import json
@@ -56,7 +61,7 @@ def algorithmic_bytes_per_sim(S, A, P, d, vbar, e):
     return d * (mask + 12.0 * vbar + 8 + S + 16) + e * (S + mask + 12.0 * vbar + 8 + 4 * A + 4 * P)
 
 
-def cpu_baseline(sims, seconds=15.0, n_par=8):
+def cpu_baseline(sims, seconds=12.0, n_par=8):
     """The oracle (C restatement of MCTS.py + SplendorLogicNumba, pinned against the reference) with the PyTorch-CPU net,
     one host thread, leaves batched over n_par games like --parallel-inferences 8 (Coach.py:117-144)."""
     import numpy as np
@@ -134,13 +139,185 @@ def cpu_baseline_multi(sims, seconds, procs):
                 host_cores_available=os.cpu_count())
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def respawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run on this node"""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
+
+
+def build_engine(a, game_key, T, rank, dev):
+    """game + engine-kernel net + SelfPlayEngine for one of the hot-path configs"""
+    import torch
+    from azg_amd import games
+    from azg_amd import nnet as _nn
+    from azg_amd.selfplay import SelfPlayEngine
+    dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[a.net_dtype]
+    net_kind = a.net
+    if game_key == 'splendor2':
+        margs = Args(SPLENDOR2_ARGS)
+        game = games.SplendorGame(2, device=dev)
+        label = 'Splendor 2p'
+        weights = os.path.basename(WEIGHTS)
+        if net_kind == 'hip':
+            assert a.net_dtype == 'fp32'
+            net = _nn.SplendorV80Hip.from_npz(WEIGHTS, device=dev, max_batch=T // a.groups)
+        else:
+            net = _nn.SplendorV80.from_npz(WEIGHTS, device=dev, dtype=dtype)
+    else:
+        og = OTHER_GAMES[game_key]
+        margs = Args(og['args'])
+        game = {'splendor4': lambda: games.SplendorGame(4, device=dev), 'santorini1': lambda: games.SantoriniGame(1, device=dev),
+                'santorini11': lambda: games.SantoriniGame(11, device=dev), 'azul': lambda: games.AzulGame(device=dev)}[game_key]()
+        nkw = dict(num_players=4) if game_key == 'splendor4' else {}
+        net = getattr(_nn, og['net']).from_npz(os.path.join(ROOT, 'tests', 'golden', og['weights']), device=dev, dtype=dtype, **nkw)
+        label, weights = og['label'], og['weights']
+        if net_kind == 'hip' and og['net'] in ('SplendorV80', 'AzulV84') and a.net_dtype == 'fp32':
+            net = _nn.MobileNet1dHip(net, max_batch=T // a.groups)        # the whole forward in one launch (nn_mb1d.cuh)
+        elif net_kind == 'hip' and game_key in ('santorini1', 'santorini11') and a.net_dtype == 'fp32':
+            # the ResNet / the with-gods MobileNet in one launch (nn_conv5x5.cuh)
+            net = (_nn.SantoriniV89Hip if game_key == 'santorini1' else _nn.SantoriniV78Hip)(net, max_batch=T // a.groups)
+        else:
+            net_kind = 'torch'
+    margs['numMCTSSims'] = a.sims
+    margs['prob_fullMCTS'] = a.prob_full
+    # nodes live until the root's age passes theirs: ~12 plies' worth of simulations in Splendor, more in the narrow, deep
+    # searches of Azul / Santorini (with gods: A = 1782 makes a node ~5 KB; 14 x sims keeps 4096 trees within the 288 GB)
+    cap = a.node_capacity or max(2048, {'splendor2': 16, 'santorini11': 14}.get(game_key, 32) * a.sims + 512)
+    eng = None
+    for attempt in range(3):           # the forest wants a large share of the 288 GB HBM: shrink the arena if the device has less to give
+        try:
+            eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
+                                 stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups,
+                                 work_budget=a.work_budget, advance_every=a.advance_every or None)
+            break
+        except Exception as ex:        # azg_amd.AzgError: hipMalloc failed
+            if a.node_capacity or attempt == 2:
+                raise
+            sys.stderr.write('forest with node_capacity %d did not fit (%s); retrying smaller\n' % (cap, ex))
+            torch.cuda.empty_cache()
+            cap = cap * 3 // 4
+    return eng, margs, label, weights, net_kind
+
+
+def measure_roofline(a, eng, T):
+    """eager rounds with HIP events around the select (+ fused expand/backup) launches, on the stream they are launched on"""
+    import torch
+    f = eng.forest
+    r0 = eng.stats()
+    f.enable_timing(True)
+    for _ in range(a.roofline_rounds):
+        eng._round()
+    torch.cuda.synchronize()
+    ms_sel, n_sel = f.kernel_ms(0)
+    ms_exp, n_exp = f.kernel_ms(1)
+    if not n_exp:                 # fused engine: the expansion + backup runs in the prologue of k_select, no launch of its own
+        ms_exp = 0.0
+    f.enable_timing(False)
+    r1 = eng.stats()
+    rs = r1['sims'] - r0['sims']
+    if rs <= 0 or n_sel <= 0:
+        return None
+    d = (r1['levels'] - r0['levels']) / rs
+    e = (r1['expansions'] - r0['expansions']) / rs
+    vbar = (r1['sum_valid_visited'] - r0['sum_valid_visited']) / max(1, r1['levels'] - r0['levels'])
+    b_sim = algorithmic_bytes_per_sim(f.S, f.A, f.P, d, vbar, e)
+    rs = rs / a.groups          # the timed launches are group 0's (T/groups trees each)
+    sims_per_launch = rs / n_sel
+    bytes_per_launch = b_sim * sims_per_launch
+    pair_ms = ms_sel + ms_exp
+    achieved = bytes_per_launch / (pair_ms * 1e-3) / 1e9
+    prof = None
+    if os.path.exists(a.traffic_json):
+        try:
+            tj = json.load(open(a.traffic_json))
+            if tj.get('games') == T and tj.get('sims') == a.sims and tj.get('game', 'splendor2') == eng.game_key:
+                prof = dict(hbm_bytes_per_launch=tj.get('hbm_bytes_per_launch'), file=os.path.relpath(a.traffic_json, ROOT),
+                            note='PMC FETCH_SIZE/WRITE_SIZE of an earlier rocprofv3 run of this command (separate --pmc passes, '
+                                 'gfx950 corrections); NOT measured in this run')
+        except Exception:
+            prof = None
+    return dict(bound='hbm', kernels=['k_select', 'k_expand_backup'] if n_exp else ['k_select (expand+backup fused into its prologue)'],
+                achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
+                traffic=None, traffic_from_profile=prof,
+                bytes_per_sim=b_sim, sims_per_launch=sims_per_launch, bytes_per_launch=bytes_per_launch,
+                select_ms=ms_sel, expand_backup_ms=ms_exp, launches=int(n_sel),
+                d_levels_per_sim=d, v_valid_per_level=vbar, e_expansions_per_sim=e)
+
+
+def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roofline=True):
+    """warm-up ply waves, then exactly `steps` timed ply waves bracketed by barrier + synchronize; -> result dict (rank-reduced)"""
+    import torch
+    import torch.distributed as dist
+    from azg_amd.selfplay import gather_examples
+    eng, margs, label, weights, net_kind = build_engine(a, game_key, T, rank, dev)
+    eng.game_key = game_key
+    sims = a.sims
+    eng.start()
+    eng.run(warmup * sims)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    s0 = eng.stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(steps * sims)
+    ex = eng.drain_examples()
+    n_local_examples = int(ex[0].shape[0])
+    if use_dist:
+        ex = gather_examples(list(ex))           # the one RCCL collective of the path (episode-end example gather)
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    s1 = eng.stats()
+    dt = t1 - t0
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loc = torch.tensor([s1['sims'] - s0['sims'], s1['plies'] - s0['plies'], s1['errors'], s1['games'] - s0['games'],
+                        n_local_examples, s1['examples_dropped']], dtype=torch.int64, device=dev)
+    if use_dist:
+        # error flags are a bit mask: OR them (a SUM over ranks would garble the bits)
+        errs_t = loc[2:3].clone()
+        dist.all_reduce(loc, op=dist.ReduceOp.SUM)
+        dist.all_reduce(errs_t, op=dist.ReduceOp.BOR)
+        loc[2] = errs_t[0]
+    tot_sims, tot_plies, errs, tot_games, tot_examples, dropped = [int(x) for x in loc.tolist()]
+    assert tot_plies > 0, 'no ply completed inside the timed region: raise --steps'
+    res = dict(label=label, weights=weights, net_kind=net_kind, value=tot_plies / dt, value_from_sims=tot_sims / sims / dt,
+               dt=dt, sims_per_sec=tot_sims / dt, plies_completed=tot_plies, games_finished=tot_games,
+               examples_gathered=tot_examples if world == 1 else int(ex[0].shape[0]), examples_dropped=dropped,
+               engine_errors=errs, forest_bytes_per_gpu=eng.device_bytes,
+               max_live_after_gc=int(s1.get('max_live_after_gc', 0)), max_nodes_per_tree=s1['max_nodes'],
+               gc_runs=s1['gc_runs'], hip_graph=eng.graph is not None, rounds_timed=steps * sims,
+               ms_per_round=dt / (steps * sims) * 1e3)
+    res['roofline'] = measure_roofline(a, eng, T) if roofline and a.roofline_rounds > 0 else None
+    del ex
+    for grp in eng.groups:
+        grp.f.close()
+    del eng
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=56000,
-                    help='timed lock-step rounds; the default spans one whole game per tree (~70 plies x 800 simulations), i.e. '
-                         'opening, middle game, the terminal-heavy endgame and the restart')
-    ap.add_argument('--warmup', type=int, default=8000)
+    ap.add_argument('--steps', type=int, default=70,
+                    help='timed ply waves (one step = numMCTSSims lock-step rounds = one full search + one executed ply for every '
+                         'concurrent game); the default spans one whole game per tree (~70 plies): opening, middle game, the '
+                         'terminal-heavy endgame and the restart')
+    ap.add_argument('--warmup', type=int, default=10, help='untimed ply waves before the timed region')
     ap.add_argument('--games', type=int, default=4096, help='concurrent games per GPU')
     ap.add_argument('--game', default='splendor2', choices=['splendor2', 'splendor4', 'santorini1', 'santorini11', 'azul'])
     ap.add_argument('--sims', type=int, default=800)
@@ -156,16 +333,21 @@ def main():
                     help='prob_fullMCTS: 1.0 = every ply a full search (the headline metric); 0.25 = the reference default mix of '
                          'full and numMCTSSims//5 searches (main.py), a secondary figure')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
-    ap.add_argument('--cpu-procs', type=int, default=1,
-                    help='cpu_baseline on this many host cores (independent single-thread processes, summed); 1 = scalar port')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--cpu-procs', type=int, default=0,
+                    help='cpu_baseline on this many host cores (independent single-thread processes, summed); 0 = min(64, host '
+                         'cores) -- SURVEY.md §8d asks for the host cores, not one')
     ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--roofline-rounds', type=int, default=300)
-    ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'r01c_traffic.json'))
+    ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'r02_traffic.json'))
+    ap.add_argument('--no-secondary', action='store_true', help='skip the Santorini no-gods leg (north star\'s second target)')
+    ap.add_argument('--secondary-steps', type=int, default=0, help='timed ply waves of the secondary leg (0 = max(3, steps // 5))')
     a = ap.parse_args()
     if a.cpu_worker:
         print(json.dumps(cpu_baseline(a.sims, a.cpu_seconds)))
         return
+    if (a.gpus > 1 or os.environ.get('AZG_BENCH_SPAWN')) and 'WORLD_SIZE' not in os.environ:   # AZG_BENCH_SPAWN: test the self-launch on one GPU
+        sys.exit(respawn_ranks(a.gpus))
 
     import torch
     import torch.distributed as dist
@@ -173,171 +355,60 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     use_dist = world > 1 or bool(os.environ.get('AZG_FORCE_DIST'))      # AZG_FORCE_DIST: exercise the RCCL path on one GPU
+    assert world == a.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, a.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    assert world == a.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
-    torch.cuda.set_device(local_rank)
-    dev = 'cuda:%d' % local_rank
-
-    from azg_amd import games
-    from azg_amd.nnet import SplendorV80, SplendorV80Hip
-    from azg_amd.selfplay import SelfPlayEngine, gather_examples
 
     T = a.games
-    margs = Args(SPLENDOR2_ARGS)
-    margs['numMCTSSims'] = a.sims
-    margs['prob_fullMCTS'] = a.prob_full
-    dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[a.net_dtype]
-    pretrained = os.path.exists(WEIGHTS)
-    label = 'Splendor 2p'
-    if a.game != 'splendor2':
-        from azg_amd import nnet as _nn
-        og = OTHER_GAMES[a.game]
-        margs = Args(og['args'])
-        margs['numMCTSSims'] = a.sims
-        margs['prob_fullMCTS'] = a.prob_full
-        game = {'splendor4': lambda: games.SplendorGame(4, device=dev), 'santorini1': lambda: games.SantoriniGame(1, device=dev), 'santorini11': lambda: games.SantoriniGame(11, device=dev),
-                'azul': lambda: games.AzulGame(device=dev)}[a.game]()
-        nkw = dict(num_players=4) if a.game == 'splendor4' else {}
-        net = getattr(_nn, og['net']).from_npz(os.path.join(ROOT, 'tests', 'golden', og['weights']), device=dev, dtype=dtype, **nkw)
-        if a.net == 'hip' and og['net'] in ('SplendorV80', 'AzulV84') and a.net_dtype == 'fp32':
-            net = _nn.MobileNet1dHip(net, max_batch=T // a.groups)        # the whole forward in one launch (nn_mb1d.cuh)
-            og = dict(og, label=og['label'] + ' (engine kernels)')
-        elif a.net == 'hip' and a.game in ('santorini1', 'santorini11') and a.net_dtype == 'fp32':
-            # the ResNet / the with-gods MobileNet in one launch (nn_conv5x5.cuh)
-            net = (_nn.SantoriniV89Hip if a.game == 'santorini1' else _nn.SantoriniV78Hip)(net, max_batch=T // a.groups)
-            og = dict(og, label=og['label'] + ' (engine kernels)')
-        else:
-            a.net = 'torch'
-        label = og['label']
-        pretrained = True
-    else:
-        game = games.SplendorGame(2, device=dev)
-    if a.game != 'splendor2':
-        pass
-    elif a.net == 'hip':
-        assert a.net_dtype == 'fp32'
-        net = SplendorV80Hip.from_npz(WEIGHTS, device=dev, max_batch=T // a.groups) if pretrained else \
-            SplendorV80Hip.random_init(device=dev, max_batch=T // a.groups)
-    else:
-        net = SplendorV80.from_npz(WEIGHTS, device=dev, dtype=dtype) if pretrained else \
-            SplendorV80.random_init(device=dev, dtype=dtype)
-    # nodes live until the root's age passes theirs: ~12 plies' worth of simulations in Splendor, more in the narrow, deep
-    # searches of Azul / Santorini
-    # (Santorini with gods: A = 1782 makes a node ~5 KB; 14 x sims keeps 4096 trees within the 288 GB, clean-up leaves <= 9.4 k alive)
-    cap = a.node_capacity or max(2048, {'splendor2': 16, 'santorini11': 14}.get(a.game, 32) * a.sims + 512)
-    eng = None
-    for attempt in range(3):           # the forest wants ~170 GB of the 288 GB HBM: shrink the arena if the device has less to give
-        try:
-            eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
-                                 stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups,
-                                 work_budget=a.work_budget, advance_every=a.advance_every or None)
-            break
-        except Exception as ex:        # azg_amd.AzgError: hipMalloc failed
-            if a.node_capacity or attempt == 2:
-                raise
-            sys.stderr.write('forest with node_capacity %d did not fit (%s); retrying smaller\n' % (cap, ex))
-            torch.cuda.empty_cache()
-            cap = cap * 3 // 4
-    eng.start()
-    eng.run(a.warmup)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    s0 = eng.stats()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.run(a.steps)
-    ex = eng.drain_examples()
-    n_local_examples = int(ex[0].shape[0])
-    if use_dist:
-        ex = gather_examples(list(ex))           # the one RCCL collective of the path (episode-end example gather)
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    s1 = eng.stats()
-    dt = t1 - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    d_sims = s1['sims'] - s0['sims']
-    d_plies = s1['plies'] - s0['plies']
-    loc = torch.tensor([d_sims, d_plies, s1['errors'], s1['games'] - s0['games'], n_local_examples], dtype=torch.int64,
-                       device=dev)
-    if use_dist:
-        dist.all_reduce(loc, op=dist.ReduceOp.SUM)
-    tot_sims, tot_plies, errs, tot_games, tot_examples = [int(x) for x in loc.tolist()]
-    # full searches only: simulations / numMCTSSims (counts partial plies at the window edges); mixed searches: plies
-    value = tot_sims / a.sims / dt if a.prob_full >= 1.0 else tot_plies / dt
-
-    # ---- roofline segment: eager rounds with HIP events around the select / expand_backup launches ----
-    roof = None
-    f = eng.forest
-    r0 = eng.stats()
-    f.enable_timing(True)
-    for _ in range(a.roofline_rounds):
-        eng._round()
-    torch.cuda.synchronize()
-    ms_sel, n_sel = f.kernel_ms(0)
-    ms_exp, n_exp = f.kernel_ms(1)
-    if not n_exp:                 # fused engine: the expansion + backup runs in the prologue of k_select, no launch of its own
-        ms_exp = 0.0
-    f.enable_timing(False)
-    r1 = eng.stats()
-    rs = r1['sims'] - r0['sims']
-    if rs > 0 and n_sel > 0:
-        d = (r1['levels'] - r0['levels']) / rs
-        e = (r1['expansions'] - r0['expansions']) / rs
-        vbar = (r1['sum_valid_visited'] - r0['sum_valid_visited']) / max(1, r1['levels'] - r0['levels'])
-        b_sim = algorithmic_bytes_per_sim(f.S, f.A, f.P, d, vbar, e)
-        rs = rs / a.groups          # the timed launches are group 0's (T/groups trees each)
-        sims_per_launch = rs / n_sel
-        bytes_per_launch = b_sim * sims_per_launch
-        pair_ms = ms_sel + ms_exp
-        achieved = bytes_per_launch / (pair_ms * 1e-3) / 1e9
-        traffic = None
-        if os.path.exists(a.traffic_json):
-            try:
-                tj = json.load(open(a.traffic_json))
-                if tj.get('games') == T and tj.get('sims') == a.sims:
-                    traffic = tj.get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
-        roof = dict(bound='hbm', kernels=['k_select', 'k_expand_backup'] if n_exp else ['k_select (expand+backup fused into its prologue)'],
-                    achieved=achieved, peak=HBM_PEAK_GBS,
-                    unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                    bytes_per_sim=b_sim, sims_per_launch=sims_per_launch, bytes_per_launch=bytes_per_launch,
-                    select_ms=ms_sel, expand_backup_ms=ms_exp, launches=int(n_sel),
-                    d_levels_per_sim=d, v_valid_per_level=vbar, e_expansions_per_sim=e)
-
+    r = run_workload(a, a.game, T, a.steps, a.warmup, rank, world, dev, use_dist)
     search_mix = ('every ply a full search' if a.prob_full >= 1.0 else
                   'prob_fullMCTS=%g: full searches mixed with numMCTSSims//5 fast ones (reference default mix, secondary figure)' % a.prob_full)
-    out = dict(metric='self-play env-steps/sec @ numMCTSSims=%d, %s' % (a.sims, 'Splendor-2p' if a.game == 'splendor2' else label), value=value,
-               unit='env-steps/sec', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
-               higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
-               data='synthetic (Board.init_game boards from the counter RNG; net weights: %s)'
-                    % (('reference checkpoint converted (%s)' % (os.path.basename(WEIGHTS) if a.game == 'splendor2' else OTHER_GAMES[a.game]['weights']))
-                       if pretrained else 'random-init V80'),
-               config=dict(workload=('Splendor 2p, numMCTSSims=%d, %d concurrent self-play games per GPU, V80 net %s (%s), '
-                                     'args of pretrained_2players.pt (cpuct 0.8 fpu 0.0593 universes 3 forced playouts '
-                                     'dirichlet 0.3), %s' % (a.sims, T, a.net_dtype, 'engine MFMA-f32 kernels' if a.net == 'hip' else 'PyTorch-ROCm ops', search_mix))
-                           if a.game == 'splendor2' else '%s, numMCTSSims=%d, %d concurrent self-play games per GPU, MCTS args of the pretrained checkpoint, %s' % (label, a.sims, T, search_mix),
-                           games_per_gpu=T, parallelism='games sharded x%d, 1 RCCL example all_gather at episode end'
-                                                        % world if world > 1 else 'single GPU',
-                           hip_graph=eng.graph is not None),
-               sims_per_sec=tot_sims / dt, plies_completed=tot_plies, games_finished=tot_games,
-               examples_gathered=tot_examples if world == 1 else int(ex[0].shape[0]), engine_errors=errs,
-               forest_bytes_per_gpu=eng.device_bytes, groups=a.groups, max_live_after_gc=int(s1.get('max_live_after_gc', 0)), max_nodes_per_tree=s1['max_nodes'], gc_runs=s1['gc_runs'])
-    if roof:
-        out['roofline'] = roof
+    net_txt = 'engine MFMA-f32 kernels' if r['net_kind'] == 'hip' else 'PyTorch-ROCm ops'
+    workload = ('Splendor 2p, numMCTSSims=%d, %d concurrent self-play games per GPU, V80 net %s (%s), args of pretrained_2players.pt '
+                '(cpuct 0.8 fpu 0.0593 universes 3 forced playouts dirichlet 0.3), %s' % (a.sims, T, a.net_dtype, net_txt, search_mix)
+                if a.game == 'splendor2' else
+                '%s (%s), numMCTSSims=%d, %d concurrent self-play games per GPU, MCTS args of the pretrained checkpoint, %s'
+                % (r['label'], net_txt, a.sims, T, search_mix))
+    out = dict(metric='self-play env-steps/sec @ numMCTSSims=%d, %s' % (a.sims, 'Splendor-2p' if a.game == 'splendor2' else r['label']),
+               value=r['value'], unit='env-steps/sec', n_gpus=world, steps=a.steps, warmup=a.warmup,
+               ms_per_step=r['dt'] / a.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
+               data='synthetic (Board.init_game boards from the counter RNG; net weights: reference checkpoint converted (%s))' % r['weights'],
+               config=dict(workload=workload, games_per_gpu=T, step='one ply wave = %d lock-step rounds' % a.sims,
+                           parallelism='games sharded x%d, 1 RCCL example all_gather at episode end' % world if world > 1 else 'single GPU',
+                           hip_graph=r['hip_graph']),
+               groups=a.groups)
+    for k in ('value_from_sims', 'sims_per_sec', 'plies_completed', 'games_finished', 'examples_gathered', 'examples_dropped',
+              'engine_errors', 'forest_bytes_per_gpu', 'max_live_after_gc', 'max_nodes_per_tree', 'gc_runs', 'rounds_timed', 'ms_per_round'):
+        out[k] = r[k]
+    if r['roofline']:
+        out['roofline'] = r['roofline']
+    if use_dist:
+        dist.barrier()
+    # ---- secondary: the north star's second target (Santorini no-gods), same engine, shorter window, own roofline ----
+    if a.game == 'splendor2' and not a.no_secondary:
+        try:
+            st = a.secondary_steps or max(3, a.steps // 5)
+            r2 = run_workload(a, 'santorini1', T, st, max(1, min(a.warmup, 2)), rank, world, dev, use_dist)
+            out['secondary'] = dict(metric='self-play env-steps/sec @ numMCTSSims=%d, Santorini no-gods' % a.sims, value=r2['value'],
+                                    unit='env-steps/sec', steps=st, ms_per_step=r2['dt'] / st * 1e3,
+                                    config=dict(workload='%s (%s), numMCTSSims=%d, %d concurrent self-play games per GPU, args of '
+                                                         'santorini/pretrained.pt (cpuct 1.1 fpu 0.03 universes 0 dirichlet 0.2)'
+                                                         % (r2['label'], 'engine MFMA-f32 kernel' if r2['net_kind'] == 'hip' else 'PyTorch-ROCm ops', a.sims, T)),
+                                    value_from_sims=r2['value_from_sims'], plies_completed=r2['plies_completed'],
+                                    games_finished=r2['games_finished'], engine_errors=r2['engine_errors'],
+                                    ms_per_round=r2['ms_per_round'], roofline=r2['roofline'])
+        except Exception as ex:                       # the headline line must still be printed
+            out['secondary'] = dict(error=repr(ex))
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.game == 'splendor2':
-        out['cpu_baseline'] = (cpu_baseline_multi(a.sims, a.cpu_seconds, a.cpu_procs) if a.cpu_procs > 1
-                               else cpu_baseline(a.sims, a.cpu_seconds))
+        procs = a.cpu_procs or min(64, os.cpu_count() or 1)
+        out['cpu_baseline'] = cpu_baseline_multi(a.sims, a.cpu_seconds, procs) if procs > 1 else cpu_baseline(a.sims, a.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if use_dist:
         dist.destroy_process_group()
 

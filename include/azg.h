@@ -163,10 +163,19 @@ int azg_forest_validate(azg_forest* f, int verbose);
 /* --- self-play mode: Coach.executeEpisode on device (Coach.py:37-84) --- */
 /* start one game per tree (Board.init_game or the given init boards int8[T][S]) */
 int azg_selfplay_start(azg_forest* f, const int8_t* init_boards_dev /* or NULL */, void* stream);
+/* the same with (a) an RNG epoch: epoch 0 == azg_selfplay_start; another epoch re-keys every random stream of the forest, so
+   the next wave of episodes of one Coach.learn run (Coach.py:150-215 draws fresh randomness every iteration) does not replay
+   the previous one; (b) an episode quota = Coach.executeEpisodes' numEps (Coach.py:86-148): tree t plays quota / T (+1 for
+   t < quota % T) games to their end and then idles -- every started game is finished and kept; 0 = restart forever.
+   Synchronises `stream` once (the quota word is copied from the host). */
+int azg_selfplay_start_ex(azg_forest* f, const int8_t* init_boards_dev /* or NULL */, uint64_t epoch, int64_t episode_quota,
+                          void* stream);
 /* to be called after expand_backup, every round or every few rounds: trees whose search finished sample the move
    (Coach.py:63,278-292), record the example (Coach.py:65-69), play it (Coach.py:71), detect the end (Coach.py:73-82),
    restart finished games, re-root and begin the next search -- all on device. */
 int azg_selfplay_advance(azg_forest* f, void* stream);
+/* trees that are still playing (synchronises): 0 once every tree has used up its episode quota (or stopped on an error) */
+int azg_selfplay_active(azg_forest* f, int* n_active);
 /* counters (synchronises): plies executed, games finished, simulations run, examples stored, error flags */
 typedef struct azg_selfplay_stats {
     uint64_t plies, games, sims, levels, expansions, sum_valid_visited, terminal_hits, examples, gc_runs, max_nodes,
@@ -175,8 +184,10 @@ typedef struct azg_selfplay_stats {
                                                          frontier edge resolution (incl. leaf creation), leaf creation */
         cyc_seg[4],                                   /* frontier edge split: parent-state load, env step, canonical form +
                                                          hash, table probe */
-        max_live_after_gc;                            /* most nodes of one tree that survived a clean-up: node_capacity must stay
+        max_live_after_gc,                            /* most nodes of one tree that survived a clean-up: node_capacity must stay
                                                          above this + numMCTSSims */
+        examples_dropped;                             /* records of finished games that did not fit the example ring (a game is
+                                                         stored whole or not at all); != 0 also sets error bit 16 */
 } azg_selfplay_stats;
 int azg_selfplay_stats_get(azg_forest* f, azg_selfplay_stats* out);
 /* drain finished-game examples: (board int8[S], pi f32[A], z f32[P], valids u8[A], q f32[P]) per record

@@ -250,3 +250,84 @@ def test_engine_with_one_launch_net_other_games(variant):
     lp, lv = net.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid)
     rp, rv = base.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid.bool())
     assert float((lp - rp).abs().max()) < 1e-5 and float((lv - rv).abs().max()) < 3e-5
+
+
+def _mini_engine(T=16, sims=12, max_examples=None, rng_seed=11):
+    from azg_amd import games
+    from azg_amd.selfplay import SelfPlayEngine
+    from hashnet import HashNetTorch
+    g = games.SplendorGame(2)
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0],
+                tempThreshold=6, **MCTS_ARGS['splendor2'])
+    return SelfPlayEngine(g, HashNetTorch(2), args, T, node_capacity=1024, max_examples=max_examples or T * 400,
+                          rng_seed=rng_seed, use_graph=False)
+
+
+def _play_quota(e, quota, epoch):
+    e.start(epoch=epoch, episode_quota=quota)
+    for _ in range(400):
+        e.run(128)
+        st = e.stats()
+        assert st['errors'] == 0
+        if st['active'] == 0:
+            break
+    return st, [x.cpu().numpy() for x in e.drain_examples()]
+
+
+def test_episode_quota_and_rng_epoch():
+    """Coach.executeEpisodes semantics (Coach.py:86-148): exactly numEps games, every one played to its end and kept (no bias
+    towards short games), then the trees idle; a new RNG epoch plays different games, the same epoch the same ones."""
+    T = 16
+    e = _mini_engine(T)
+    for quota in (5, 16, 37):                                   # fewer episodes than trees, one each, several waves
+        st, ex = _play_quota(e, quota, epoch=1)
+        assert st['games'] == quota and st['active'] == 0
+        meta = ex[5]
+        games = {(int(m[0]), int(m[1])) for m in meta}
+        assert len(games) == quota                              # every finished game delivered its examples
+        per_tree = np.bincount([s for s, _ in games], minlength=T)[:T]
+        assert per_tree.max() - per_tree.min() <= 1 and per_tree.sum() == quota
+        e.run(64)                                               # idle trees stay idle
+        assert e.stats()['games'] == quota
+    _, a1 = _play_quota(e, T, epoch=1)
+    _, a2 = _play_quota(e, T, epoch=1)
+    _, b = _play_quota(e, T, epoch=2)
+    key = lambda ex: np.lexsort((ex[5][:, 2], ex[5][:, 0]))     # noqa: E731  (stream, ply)
+    assert all(np.array_equal(x[key(a1)], y[key(a2)]) for x, y in zip(a1, a2))          # same epoch: identical games
+    assert b[0].shape != a1[0].shape or not np.array_equal(b[0][key(b)], a1[0][key(a1)])   # new epoch: fresh randomness
+    # epoch 0 == the plain RNG-contract streams of azg_selfplay_start
+    e0 = _mini_engine(T)
+    e0.start()
+    _, c0 = _play_quota(e, T, epoch=0)
+    for _ in range(400):
+        e0.run(128)
+        if e0.stats()['games'] >= 3 * T:
+            break
+    d0 = [x.cpu().numpy() for x in e0.drain_examples()]
+    first = d0[5][:, 1] == 0
+    d0 = [x[first] for x in d0]
+    assert all(np.array_equal(x[key(c0)], y[key(d0)]) for x, y in zip(c0, d0))
+    for eng in (e, e0):
+        for grp in eng.groups:
+            grp.f.close()
+
+
+def test_example_ring_overflow_is_loud_and_never_truncates_a_game():
+    e = _mini_engine(T=16, max_examples=200)
+    e.start()
+    for _ in range(400):
+        e.run(128)
+        st = e.stats()
+        if st['examples_dropped']:
+            break
+    assert st['examples_dropped'] > 0 and (st['errors'] & 16)
+    ex = [x.cpu().numpy() for x in e.drain_examples()]
+    meta = ex[5]
+    assert len(meta) <= 200
+    # every delivered game is complete: its plies are 0..n-1 without a gap (Splendor records every ply at prob_full = 1)
+    for s in np.unique(meta[:, 0]):
+        for gidx in np.unique(meta[meta[:, 0] == s, 1]):
+            plies = np.sort(meta[(meta[:, 0] == s) & (meta[:, 1] == gidx), 2])
+            assert np.array_equal(plies, np.arange(len(plies)))
+    for grp in e.groups:
+        grp.f.close()
