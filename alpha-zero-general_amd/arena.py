@@ -5,8 +5,10 @@ The reference's own Arena only needs the duck-typed surface, so `Arena.Arena(pla
 with `azg_amd.mcts.MCTS`-based players already works unchanged (one game at a time); this class is the batched form:
   * seats alternate 1-2-2-1 over the games (Arena.py:121-125): game i is "one vs two" when i % 4 in (0, 3); with more than
     two players the first seat belongs to one contestant and all other seats to the other (Arena.py:52-55);
-  * a contestant = (nnet, args): its move is argmax_a of getActionProb(canonical, temp > 0, force_full_search=True)
-    (pit.py:60-64: the temperature only sharpens the visit counts, the argmax is the most visited action, first index on ties);
+  * a contestant = (nnet, args): its move is argmax_a of getActionProb(canonical, temp=temp_for_game(turn),
+    force_full_search=True) (Coach.py:193-194, pit.py:60-64): above 0.02 the temperature only sharpens the visit counts and the
+    argmax is the most visited action (first index on ties, np.argmax); once temp_for_game(turn) <= 0.02 (late in long games)
+    getActionProb itself returns a one-hot on a maximum drawn at random among ties (MCTS.py:93-98; the tree's counter RNG);
   * the real move uses random_seed = 0 (Arena.py:84) -- the engine's counter-based RNG stream of that game;
   * the result of a game is getGameEnded(board, curPlayer)[0] (Arena.py:101), tallied like playGames (:126-131)."""
 import torch
@@ -15,8 +17,11 @@ from .mcts import BatchedMCTS
 
 
 class BatchedArena:
-    def __init__(self, game, nnet1, nnet2, args1, args2=None, n_parallel=64, node_capacity=None, stream0=0):
+    def __init__(self, game, nnet1, nnet2, args1, args2=None, n_parallel=64, node_capacity=None, stream0=0, temp_for_game=None):
+        """temp_for_game(turn) -> temperature of getActionProb at that turn (Coach.temp_for_game, Coach.py:273-276, or pit.py's
+        variant); None = 1 at every turn (plain argmax of the visit counts)"""
         self.game, self.T, self.stream0 = game, n_parallel, stream0
+        self.temp_for_game = temp_for_game
         self.mcts = [BatchedMCTS(game, nnet1, args1, n_parallel, node_capacity=node_capacity),
                      BatchedMCTS(game, nnet2, args2 if args2 is not None else args1, n_parallel, node_capacity=node_capacity)]
         self.max_plies = 4096
@@ -48,7 +53,8 @@ class BatchedArena:
                 if not bool(active.any().item()):
                     continue
                 full = torch.where(active, torch.ones(T, dtype=torch.uint8, device=dev), torch.full((T,), 2, dtype=torch.uint8, device=dev))
-                probs, _, _ = m.getActionProb(canonical, temp=1, full=full)
+                temp = 1 if self.temp_for_game is None else self.temp_for_game(ply + 1)       # `it` of Arena.py:67-68
+                probs, _, _ = m.getActionProb(canonical, temp=temp, full=full)
                 ar = torch.arange(probs.shape[1], device=dev)[None, :]              # np.argmax: FIRST index of the maximum
                 first_max = torch.where(probs == probs.max(dim=1, keepdim=True).values, ar, probs.shape[1]).min(dim=1).values
                 first_max = torch.where(first_max >= probs.shape[1], torch.zeros_like(first_max), first_max)   # all-NaN row -> 0, like np.argmax

@@ -821,8 +821,21 @@ __global__ __launch_bounds__(64) void k_action_probs(ForestDev F, double temp, d
     if (!probs) return;
     double* pr = probs + (size_t)t * G::A;
     if (temp <= 0.02) {                                                                          // :93-98
-        int best = -1, ba = 0;
-        for (int a = 0; a < G::A; a++) if (cnt[a] > best) { best = cnt[a]; ba = a; }
+        // one-hot on a maximum of the (pruned) counts; among several maxima the reference draws np.random.choice(bestAs):
+        // here the k-th of nb tied actions, k = floor(u * nb), with u the next uniform of this tree's counter RNG stream
+        // (include/azg.h "RNG contract"); a unique maximum consumes no uniform
+        int best = -1, nb = 0;
+        for (int a = 0; a < G::A; a++) if (cnt[a] > best) best = cnt[a];
+        for (int a = 0; a < G::A; a++) nb += cnt[a] == best;
+        int k = 0;
+        if (nb > 1) {
+            Rng rng{forest_seed(F), F.stream0 + (uint64_t)t, H.rng_counter};
+            k = (int)(rng.u01() * (double)nb);
+            k = k >= nb ? nb - 1 : k;
+            if (l == 0) F.hdr[t].rng_counter = rng.counter;
+        }
+        int ba = 0;
+        for (int a = 0; a < G::A; a++) if (cnt[a] == best) { if (k-- == 0) { ba = a; break; } }
         for (int a = l; a < G::A; a += 64) pr[a] = a == ba ? 1.0 : 0.0;
         return;
     }

@@ -13,10 +13,40 @@ import torch
 from .forest import Forest
 
 
+class _ArgsView:
+    """the caller's args with a few values overridden (the original object is not touched)"""
+
+    def __init__(self, base, **over):
+        self._b, self._o = base, over
+
+    def __getattr__(self, k):
+        if k.startswith('_'):
+            raise AttributeError(k)
+        if k in self._o:
+            return self._o[k]
+        b = self._b
+        if isinstance(b, dict):
+            if k in b:
+                return b[k]
+            raise AttributeError(k)
+        return getattr(b, k)
+
+    def get(self, k, d=None):
+        if k in self._o:
+            return self._o[k]
+        b = self._b
+        v = b.get(k, d) if isinstance(b, dict) else getattr(b, k, d)
+        return d if v is None else v
+
+
 class BatchedMCTS:
     def __init__(self, game, nnet, args, n_trees, dirichlet_noise=False, node_capacity=None, **forest_kw):
         self.game, self.nnet, self.args = game, nnet, args
-        self.dirichlet_noise = dirichlet_noise
+        self.dirichlet_noise = bool(dirichlet_noise)
+        if not self.dirichlet_noise:
+            # no root noise for this MCTS object whatever args.dirichletAlpha says (MCTS.py:64): the forest applies noise
+            # only when its own alpha is non-zero
+            args = _ArgsView(args, dirichletAlpha=0.0)
         sims = int(getattr(args, 'numMCTSSims', 800) if not isinstance(args, dict) else args.get('numMCTSSims', 800))
         # nodes live until the root's round passes theirs (the clean-up before each search, cf. MCTS.py:86-91): a few
         # plies' worth of simulations
@@ -38,30 +68,26 @@ class BatchedMCTS:
         return (torch.tensor(np.asarray(pis), dtype=torch.float32, device=dev),
                 torch.tensor(np.asarray(vs), dtype=torch.float32, device=dev))
 
-    def _noise(self):
-        if not self.dirichlet_noise:
-            return None
-        alpha = float(self.forest.cfg.dirichletAlpha)
-        if alpha == 0:
-            return None
-        # applyDirNoise MCTS.py:187-197: Dirichlet over the root's valid actions, alpha (or 10/n_valid if alpha < 0).
-        # Gamma variates for all A slots; the kernel reads the first n_valid entries and the row is normalised here.
-        raise NotImplementedError('root noise for host-driven searches is supplied via search(noise=...)')
-
     def search(self, roots, full=None, noise=None):
         """Run numMCTSSims simulations from `roots` (int8 cuda tensor [T, S...])."""
         f = self.forest
         f.begin_search(roots.reshape(self.T, -1), full)
+        # root Dirichlet noise (MCTS.py:64,147-149,156-160,187-197): on simulation 0 of a FULL search of an MCTS built with
+        # dirichlet_noise=True (Coach.py:31,96 passes dirichletAlpha != 0; Arena / pit players pass nothing).  `noise`
+        # injects the sample (parity tests); otherwise the engine draws rng.dirichlet([alpha] * n_valid) on device.
+        dev_noise = bool(self.dirichlet_noise) and noise is None and float(f.cfg.dirichletAlpha) != 0.0
+        if noise is not None:
+            assert self.dirichlet_noise, 'a noise sample was passed to an MCTS built with dirichlet_noise=False'
         rounds = 0
         while True:
-            f.select(noise)
+            f.select(noise, device_noise=dev_noise)
             ne = f.needs_eval
             if not bool(ne.any().item()):
                 if f.active() == 0:
                     break
                 continue
             pi, v = self._predict(f.leaf_states, f.leaf_valid)
-            f.expand_backup(pi, v, noise)
+            f.expand_backup(pi, v, noise, device_noise=dev_noise)
             rounds += 1
         return rounds
 

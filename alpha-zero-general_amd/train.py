@@ -115,6 +115,97 @@ class AzulV84Module(nn.Module):
         return F.log_softmax(pi, dim=1), torch.tanh(v)
 
 
+class _ResBlock(nn.Module):
+    """SimpleResBlock (santorini/SantoriniNNet.py:71-84): conv3x3+BN+ReLU, conv3x3+BN, + input, ReLU"""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv1, self.bn1 = nn.Conv2d(c, c, 3, padding=1, bias=False), nn.BatchNorm2d(c)
+        self.conv2, self.bn2 = nn.Conv2d(c, c, 3, padding=1, bias=False), nn.BatchNorm2d(c)
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        return F.relu(self.bn2(self.conv2(y)) + x)
+
+
+class _Head2d(nn.Module):
+    """SimpleHead / HeadWithMeta (SantoriniNNet.py:17-69): 1x1 bottleneck conv + BN + ReLU, flatten (+ the 32 metadata
+    features), Linear (policy) or Linear + ReLU + Linear (value)"""
+
+    def __init__(self, c, bottleneck, out, value, meta=0):
+        super().__init__()
+        self.conv1x1, self.bn, self.value = nn.Conv2d(c, bottleneck, 1, bias=False), nn.BatchNorm2d(bottleneck), value
+        flat = bottleneck * 25 + meta
+        if value:
+            self.fc1, self.fc2 = nn.Linear(flat, 64), nn.Linear(64, out)
+        else:
+            self.fc = nn.Linear(flat, out)
+
+    def forward(self, x, meta=None):
+        x = torch.flatten(F.relu(self.bn(self.conv1x1(x))), 1)
+        if meta is not None:
+            x = torch.cat([x, meta], dim=1)
+        return self.fc2(F.relu(self.fc1(x))) if self.value else self.fc(x)
+
+
+class SantoriniV89Module(nn.Module):
+    """santorini/SantoriniNNet.py nn_version 89 (:194-219,273-281; no gods, A = 162) with the reference's parameter names:
+    conv3x3(2->64)+BN+ReLU, five SimpleResBlocks, SimpleHead heads (bottlenecks 2 / 1)."""
+    version = 89
+
+    def __init__(self, num_players=2, action_size=162, dropout=0.0):
+        super().__init__()
+        self.P, self.A, self.dropout = num_players, action_size, dropout
+        self.first_layer = nn.Sequential(nn.Conv2d(2, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU())
+        self.trunk = nn.Sequential(*[_ResBlock(64) for _ in range(5)])
+        self.head_PI, self.head_V = _Head2d(64, 2, action_size, False), _Head2d(64, 1, num_players, True)
+        self.register_buffer('lowvalue', torch.FloatTensor([-1e8]))
+
+    def forward(self, boards, valid_actions):
+        x = boards.reshape(-1, 5, 5, 3).float().permute(0, 3, 1, 2)
+        f = self.trunk(self.first_layer(x[:, :2]))
+        v = self.head_V(f)
+        pi = torch.where(valid_actions.bool(), self.head_PI(f), self.lowvalue)
+        return F.log_softmax(pi, dim=1), torch.tanh(v)
+
+
+class _MBBlock2d(nn.Module):
+    """torchvision's MobileNetV3 InvertedResidual as the reference configures it (SantoriniNNet.py:172-178: 64 -> 192 -> 64,
+    3x3 depthwise, no SE, ReLU, residual); parameter names block.{0,1,2}.{0 conv, 1 BatchNorm}"""
+
+    def __init__(self, c, e):
+        super().__init__()
+        cna = lambda i, o, k, g, act: nn.Sequential(nn.Conv2d(i, o, k, padding=(k - 1) // 2, groups=g, bias=False),  # noqa: E731
+                                                    nn.BatchNorm2d(o), *([nn.ReLU()] if act else []))
+        self.block = nn.Sequential(cna(c, e, 1, 1, True), cna(e, e, 3, e, True), cna(e, c, 1, 1, False))
+
+    def forward(self, x):
+        return self.block(x) + x
+
+
+class SantoriniV78Module(nn.Module):
+    """santorini/SantoriniNNet.py nn_version 78 (:167-192,264-271; with gods, A = 1782) with the reference's parameter names:
+    conv3x3(2->64), ten InvertedResidual blocks, meta_fc (gods plane -> 32 features), HeadWithMeta heads (bottlenecks 4 / 2)."""
+    version = 78
+
+    def __init__(self, num_players=2, action_size=1782, dropout=0.0):
+        super().__init__()
+        self.P, self.A, self.dropout = num_players, action_size, dropout
+        self.first_layer = nn.Conv2d(2, 64, 3, padding=1, bias=False)
+        self.trunk = nn.Sequential(*[_MBBlock2d(64, 192) for _ in range(10)])
+        self.meta_fc = nn.Sequential(nn.Flatten(1), nn.Linear(25, 32), nn.ReLU())
+        self.head_PI, self.head_V = _Head2d(64, 4, action_size, False, meta=32), _Head2d(64, 2, num_players, True, meta=32)
+        self.register_buffer('lowvalue', torch.FloatTensor([-1e8]))
+
+    def forward(self, boards, valid_actions):
+        x = boards.reshape(-1, 5, 5, 3).float().permute(0, 3, 1, 2)
+        f = self.trunk(self.first_layer(x[:, :2]))
+        meta = self.meta_fc(x[:, 2:3])
+        v = self.head_V(f, meta)
+        pi = torch.where(valid_actions.bool(), self.head_PI(f, meta), self.lowvalue)
+        return F.log_softmax(pi, dim=1), torch.tanh(v)
+
+
 def loss_pi(target_pi, out_log_pi):                                            # GenericNNetWrapper.py:179-181
     return F.kl_div(out_log_pi, target_pi, reduction='batchmean')
 

@@ -287,11 +287,11 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
     loc = torch.tensor([s1['sims'] - s0['sims'], s1['plies'] - s0['plies'], s1['errors'], s1['games'] - s0['games'],
                         n_local_examples, s1['examples_dropped']], dtype=torch.int64, device=dev)
     if use_dist:
-        # error flags are a bit mask: OR them (a SUM over ranks would garble the bits)
-        errs_t = loc[2:3].clone()
+        # error flags are a bit mask: OR them over the ranks as a MAX per bit (RCCL has no BOR; a SUM would garble the bits)
+        bits = torch.tensor([(int(loc[2]) >> b) & 1 for b in range(8)], dtype=torch.int64, device=dev)
         dist.all_reduce(loc, op=dist.ReduceOp.SUM)
-        dist.all_reduce(errs_t, op=dist.ReduceOp.BOR)
-        loc[2] = errs_t[0]
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX)
+        loc[2] = sum(int(x) << b for b, x in enumerate(bits.tolist()))
     tot_sims, tot_plies, errs, tot_games, tot_examples, dropped = [int(x) for x in loc.tolist()]
     assert tot_plies > 0, 'no ply completed inside the timed region: raise --steps'
     res = dict(label=label, weights=weights, net_kind=net_kind, value=tot_plies / dt, value_from_sims=tot_sims / sims / dt,

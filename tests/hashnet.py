@@ -22,3 +22,23 @@ class HashNetTorch:
                                                                           1 << 32), 13))
         pi = (w.to(torch.float64) / w.sum(dim=1, keepdim=True).to(torch.float64)).to(torch.float32)
         return pi.contiguous(), v.contiguous()
+
+
+class HashNetNumpy:
+    """the same integer hash-net behind the reference's per-sample NeuralNet.predict(board, valid_actions) signature
+    (NeuralNet.py:32-43): numpy in, (pi f32[A], v f32[P]) out -- exercises the engine's single-sample slow path"""
+
+    def __init__(self, P):
+        self.P, self.calls = P, 0
+
+    def predict(self, board, valids):
+        import numpy as np
+        self.calls += 1
+        flat = np.asarray(board).reshape(-1).astype(np.int64)
+        s = int((flat * np.arange(1, flat.size + 1, dtype=np.int64)).sum())
+        h = (s * 2654435761) % (1 << 32)
+        v0 = np.float32(h / 2147483648.0 - 1.0)
+        v = np.array([v0] + [np.float32(-float(v0) / (self.P - 1))] * (self.P - 1), dtype=np.float32)
+        a = np.arange(len(valids), dtype=np.int64)
+        w = np.asarray(valids).astype(np.int64) * (1 + (((h >> 8) + 2654435761 * a) % (1 << 32)) % 13)
+        return (w / w.sum()).astype(np.float32), v

@@ -40,3 +40,20 @@ def test_arena_initial_state_string():
     assert int(data[-3]) == 1 and int.from_bytes(data[-2:], 'big') == 300
     b, p, it = formats.decode_initial_state(s, (56, 7))
     assert np.array_equal(b, board) and (p, it) == (1, 300)
+
+
+def test_reads_a_file_written_by_the_reference():
+    """tests/golden/ref_checkpoint.examples was written by the reference's own Coach.saveTrainExamples (Coach.py:220-226,
+    tools/gen_train_golden.py): two iterations of zlib-compressed 5-tuples = the first six examples of the trainer fixture.
+    (The opposite direction -- the reference's Coach.loadTrainExamples + trainer reading a file written by
+    formats.save_train_examples -- is executed live by tools/gen_train_golden.py in the build container and by
+    tests/test_live_reference.py when /root/reference is present.)"""
+    from azg_amd import formats
+    here = os.path.dirname(__file__)
+    hist = formats.load_train_examples(os.path.join(here, 'golden', 'ref_checkpoint.examples'))
+    d = np.load(os.path.join(here, 'golden', 'train_splendor2_v80.npz'))
+    assert [len(it) for it in hist] == [4, 2]
+    flat = [e for it in hist for e in it]
+    for i, (b, p, z, v, q) in enumerate(flat):
+        assert b.dtype == np.int8 and np.array_equal(b, d['boards'][i]) and np.array_equal(p, d['pi'][i])
+        assert np.array_equal(z, d['z'][i]) and np.array_equal(v, d['valids'][i].astype(bool)) and np.array_equal(q, d['q'][i])

@@ -26,12 +26,14 @@ def make(variant):
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
 
 
-@pytest.mark.parametrize('variant', list(VARIANTS))
-def test_mcts_traces_vs_golden(golden_dir, variant):
+@pytest.mark.parametrize('variant,prefix', [(v, 'mcts') for v in VARIANTS] + [(v, 'mcts800') for v in VARIANTS])
+def test_mcts_traces_vs_golden(golden_dir, variant, prefix):
+    """`mcts`: 25 / 200 simulations over several argument sets; `mcts800`: the headline search size (800 simulations, the
+    checkpoint's args) -- both are outputs of the reference's own MCTS.getActionProb (tools/gen_golden*.py)."""
     import torch
     from azg_amd.mcts import BatchedMCTS
     from hashnet import HashNetTorch
-    d = np.load(os.path.join(golden_dir, 'mcts_%s_numba.npz' % variant))
+    d = np.load(os.path.join(golden_dir, '%s_%s_numba.npz' % (prefix, variant)))
     g = make(variant)
     n_cases = len(d['case_sims'])
     # group the cases by identical args so that each group runs as one batched forest
@@ -249,4 +251,52 @@ def test_level_budget_is_pure_scheduling(golden_dir, budget):
         assert np.array_equal(probs[k].cpu().numpy(), d['case_probs'][i])
         assert int(rs['n_nodes'][k]) == int(d['case_nodes'][i])
     assert m.forest.validate() == 0
+    m.forest.close()
+
+
+# RNG-free known answers of the reference's MCTS with the integer hash-net from the deterministic
+# start states of Appendix C.1 (no fixture file involved) -- the HIP forest's twin of tests/test_oracle_known_answers.py
+C3 = [
+    ('splendor2', (0, 0), dict(cpuct=0.8, fpu=0.0593, universes=3), 25, 25, 24, 0.2179533839225769, '831b8a698a50baae', 1,
+     [(13, 22, 0.3160876), (30, 1, -0.7252549), (16, 1, -0.0159627)]),
+    ('splendor2', (0, 0), dict(cpuct=0.8, fpu=0.0593, universes=3), 800, 800, 799, -0.0020540114492177963, '617f8d15987a642e', 18,
+     [(13, 217, 0.0368961), (25, 179, 0.0762485), (46, 88, 0.0316085), (53, 85, 0.030627), (16, 65, 0.0238493)]),
+    ('santorini1', (0, 0), dict(cpuct=1.1, fpu=0.03, universes=0), 25, 25, 24, -0.17132920026779175, '1b51c44b02553a62', 1,
+     [(156, 19, -0.0699613)]),
+    ('santorini1', (0, 0), dict(cpuct=1.1, fpu=0.03, universes=0), 800, 800, 799, -0.018680008128285408, 'f6a86e2b69d5f887', 31,
+     [(69, 198, 0.0326832), (127, 61, 0.021105), (152, 60, 0.0304925), (100, 42, 0.0265984)]),
+    ('santorini11', (1, 5), dict(cpuct=1.1, fpu=0.03, universes=0), 800, 800, 799, 0.0020819352939724922, '5bb85ebbe5d154c8', 37,
+     [(101, 104, 0.0759137), (1, 102, 0.071334), (10, 45, 0.1134226), (28, 41, 0.0644857)]),
+    ('azul', (0, 0), dict(cpuct=0.5, fpu=0.05, universes=1), 800, 800, 799, -0.01931973174214363, 'f0e32ed35ac9f702', 32,
+     [(122, 169, 0.0459814), (34, 64, -0.0727988), (169, 53, 0.0370114), (41, 52, 0.0458253)]),
+]
+
+
+@pytest.mark.parametrize('case', C3, ids=lambda c: '%s-%d' % (c[0], c[3]))
+def test_c3_known_answers_on_the_forest(case):
+    import hashlib
+    import torch
+    import azg_oracle as O
+    from azg_amd.mcts import BatchedMCTS
+    from hashnet import HashNetTorch
+    variant, gods, kw, sims, nodes, Ns, Qs, nsa_sha, nonzero, top = case
+    name, v = VARIANTS[variant]
+    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL}[name], v)
+    root = og.known_start(*gods).reshape(1, -1)           # Appendix C.1 start state (the oracle only builds the INPUT here)
+    g = make(variant)
+    args = Args(numMCTSSims=sims, forced_playouts=True, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0,
+                temperature=[1, 1, 1], **kw)
+    m = BatchedMCTS(g, HashNetTorch(g.P), args, 1, node_capacity=sims + 64)
+    probs, q, _ = m.getActionProb(torch.from_numpy(root).to(g.device), temp=1, force_full_search=True)
+    rs = m.forest.root_stats()
+    nsa = rs['Nsa'][0].cpu().numpy().astype(np.int64)
+    qsa = rs['Qsa'][0].cpu().numpy()
+    assert int(rs['n_nodes'][0]) == nodes and int(rs['Ns'][0]) == Ns
+    assert float(rs['Qs'][0]) == float(np.float32(Qs))
+    assert hashlib.sha256(nsa.tobytes()).hexdigest()[:16] == nsa_sha
+    for a, n, qv in top:
+        assert nsa[a] == n and abs(qsa[a] - qv) < 1e-6, (a, nsa[a], qsa[a])
+    assert int((probs[0] > 0).sum()) == nonzero
+    qq = q[0].cpu().numpy()
+    assert qq[0] == np.float32(Qs) and qq[1] == -np.float32(Qs)
     m.forest.close()

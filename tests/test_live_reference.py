@@ -1,0 +1,113 @@
+"""CPU, build container only: drop-in checks against the LIVE reference (imported from /root/reference in pure-Python mode
+through tools/refshim).  Skipped wherever the reference is absent (the GPU box): the same facts are pinned there through the
+committed fixtures these scripts generated."""
+import os
+import pickle
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = os.environ.get('AZG_REFERENCE', '/root/reference')
+pytestmark = pytest.mark.skipif(not os.path.isdir(REFERENCE), reason='the reference tree is not on this machine')
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(scope='module')
+def ref():
+    sys.path.insert(0, os.path.join(ROOT, 'tools', 'refshim'))
+    import harness as H
+    import importlib
+    m = H.load_reference(splendor_players=2)
+    m['NNet'] = importlib.import_module('splendor.NNet')
+    m['Coach'] = importlib.import_module('Coach')
+    m['H'] = H
+    yield m
+    H.cleanup()
+
+
+class _CpuGame:
+    """what NNetWrapper needs from a game before any inference is requested (no GPU in this container)"""
+    GAME_ID, variant, P, A, num_players, device = 0, 2, 2, 81, 2, 'cpu'
+
+    def getBoardSize(self):
+        return (56, 7)
+
+    def getActionSize(self):
+        return 81
+
+
+class A(dict):
+    __getattr__ = dict.get
+
+
+def _examples():
+    d = np.load(os.path.join(GOLDEN, 'train_splendor2_v80.npz'))
+    return d, [(d['boards'][i], d['pi'][i], d['z'][i], d['valids'][i].astype(bool), d['q'][i]) for i in range(len(d['pi']))]
+
+
+def test_reference_reader_and_trainer_take_our_examples_file(ref, tmp_path):
+    """formats.save_train_examples -> the reference's Coach.loadTrainExamples (Coach.py:228-262) -> the reference's
+    GenericNNetWrapper.train: the file round-trips and the training reproduces the trainer fixture."""
+    from azg_amd import formats
+    d, ex = _examples()
+    cols = [np.stack([np.asarray(e[k]).reshape(-1) for e in ex]) for k in range(5)]
+    formats.save_train_examples(os.path.join(tmp_path, 'checkpoint.examples'),
+                                [formats.examples_to_iteration(cols, (56, 7), compress=True, maxlen=10 ** 6)])
+    c = ref['Coach'].Coach.__new__(ref['Coach'].Coach)
+    c.args = A(load_folder_file=os.path.join(tmp_path, 'best.pt'), no_compression=True, numItersHistory=5, maxlenOfQueue=10 ** 6,
+               useray=True)
+    c.loadTrainExamples()
+    got = c.trainExamplesHistory
+    assert len(got) == 1 and len(got[0]) == len(ex)
+    for a, b in zip(got[0], ex):
+        assert all(np.array_equal(x, y) and np.asarray(x).dtype == np.asarray(y).dtype for x, y in zip(a, b))
+    game = ref['SplendorGame'].SplendorGame()
+    w = ref['NNet'].NNetWrapper(game, dict(lr=1e-3, learn_rate=float(d['hp/learn_rate']), dropout=0., epochs=int(d['hp/epochs']),
+                                           batch_size=int(d['hp/batch_size']), nn_version=80, q_weight=float(d['hp/q_weight']),
+                                           no_compression=True))
+    w.load_checkpoint(os.path.join(REFERENCE, 'splendor'), 'pretrained_2players.pt')
+    np.random.seed(0)
+    w.train(list(got[0]))
+    sd = w.nnet.state_dict()
+    for k in [f[6:] for f in d.files if f.startswith('after/')]:
+        assert np.abs(sd[k].numpy() - d['after/' + k]).max() <= 1e-6, k
+
+
+def test_checkpoints_cross_load(ref, tmp_path):
+    """GenericNNetWrapper.save_checkpoint (:192-205) <-> azg_amd.nnet_wrapper.NNetWrapper: a checkpoint written by either side
+    loads on the other (state_dict names are the reference's; `full_model` carries `.version`), and pit.py's call sequence
+    (create_player, pit.py:40-57: NNet(game, nn_args with nn_version=-1).load_checkpoint -> additional keys) works."""
+    from azg_amd.nnet_wrapper import NNetWrapper
+    game = ref['SplendorGame'].SplendorGame()
+    rw = ref['NNet'].NNetWrapper(game, dict(lr=None, dropout=0., epochs=None, batch_size=None, nn_version=80))
+    rw.load_checkpoint(os.path.join(REFERENCE, 'splendor'), 'pretrained_2players.pt')
+    rw.save_checkpoint(str(tmp_path), 'from_ref.pt', additional_keys=dict(cpuct=0.8, numMCTSSims=800, temperature=[1.25, 0.8]))
+    ours = NNetWrapper(_CpuGame(), dict(lr=None, dropout=0., epochs=None, batch_size=None, nn_version=-1))   # pit.py:44
+    keys = ours.load_checkpoint(str(tmp_path), 'from_ref.pt')
+    assert keys.get('cpuct') == 0.8 and keys.get('numMCTSSims') == 800 and keys['temperature'][:2] == [1.25, 0.8]
+    assert ours.nnet.version == 80 and not ours.requestKnowledgeTransfer
+    ref_sd = rw.nnet.state_dict()
+    assert all(torch.equal(v, ref_sd[k]) for k, v in ours.nnet.state_dict().items())
+    # the reference's own pretrained file straight from its tree
+    ours2 = NNetWrapper(_CpuGame(), dict(nn_version=80))
+    k2 = ours2.load_checkpoint(os.path.join(REFERENCE, 'splendor'), 'pretrained_2players.pt')
+    assert k2['nn_version'] == 80 and all(torch.equal(v, ref_sd[k]) for k, v in ours2.nnet.state_dict().items())
+    # a version mismatch asks for knowledge transfer like GenericNNetWrapper.load_network (:250-253)
+    ours3 = NNetWrapper(_CpuGame(), dict(nn_version=80))
+    ours3.nnet.version = 80
+    rw.nnet.version = 77
+    rw.save_checkpoint(str(tmp_path), 'v77.pt')
+    rw.nnet.version = 80
+    ours3.load_checkpoint(str(tmp_path), 'v77.pt')
+    assert ours3.requestKnowledgeTransfer
+    # our writer -> the reference's reader
+    sys.path.insert(0, ROOT)
+    ours.save_checkpoint(str(tmp_path), 'from_engine.pt', additional_keys=dict(cpuct=0.8))
+    rw2 = ref['NNet'].NNetWrapper(game, dict(lr=None, dropout=0., epochs=None, batch_size=None, nn_version=80))
+    got = rw2.load_checkpoint(str(tmp_path), 'from_engine.pt')
+    assert got is not None and got['cpuct'] == 0.8 and not rw2.requestKnowledgeTransfer
+    assert all(torch.equal(v, ref_sd[k]) for k, v in rw2.nnet.state_dict().items())

@@ -77,11 +77,12 @@ def oracle_tree_digest(mc, game):
 MCTS_VARIANTS = ['splendor2', 'splendor4', 'santorini1', 'santorini11', 'azul']
 
 
-@pytest.mark.parametrize('typing', ['numpy2', 'numba'])
-@pytest.mark.parametrize('variant', MCTS_VARIANTS)
-def test_mcts_traces(golden_dir, variant, typing):
-    """G3: whole-tree parity (every node's Ns, Nsa, Qsa, Ps, Qs bit-exact through a SHA-256 digest)."""
-    d = load(golden_dir, 'mcts_%s_%s.npz' % (variant, typing))
+@pytest.mark.parametrize('variant,typing,prefix', [(v, t, 'mcts') for v in MCTS_VARIANTS for t in ('numpy2', 'numba')] +
+                         [(v, 'numba', 'mcts800') for v in MCTS_VARIANTS])
+def test_mcts_traces(golden_dir, variant, typing, prefix):
+    """G3: whole-tree parity (every node's Ns, Nsa, Qsa, Ps, Qs bit-exact through a SHA-256 digest); `mcts800` = the
+    headline search size (800 simulations, tools/gen_golden_800.py)."""
+    d = load(golden_dir, '%s_%s_%s.npz' % (prefix, variant, typing))
     g = O.OracleGame(*VARIANTS[variant])
     for i in range(len(d['case_sims'])):
         args = O.make_args(numMCTSSims=int(d['case_sims'][i]), cpuct=float(d['case_cpuct'][i]),

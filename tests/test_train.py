@@ -72,5 +72,56 @@ def test_azul_module_matches_reference_outputs_and_names():
     d = np.load(os.path.join(GOLDEN, 'netfwd_azul_v84.npz'))
     with torch.no_grad():
         lp, v = m.eval()(torch.from_numpy(d['boards']), torch.from_numpy(d['masks'].astype(bool)))
-    assert np.allclose(torch.exp(lp).numpy(), d['pi'], atol=1e-5, rtol=0)
-    assert np.allclose(v.numpy(), d['v'], atol=3e-5, rtol=0)
+    from test_nnet import assert_net_close
+    assert_net_close(torch.exp(lp), v, 'azul_v84', d)
+
+
+def _train_vs_reference(device):
+    """train.train == the reference's GenericNNetWrapper.train (:44-92): same (pi loss, v loss) at both AdamW + OneCycleLR steps
+    and the same weights afterwards (fixture: tools/gen_train_golden.py ran the reference's own trainer from
+    pretrained_2players.pt on these 64 examples; one batch = all examples, so the sampling order does not matter)."""
+    from azg_amd.train import train
+    m, _ = _load()
+    d = np.load(os.path.join(GOLDEN, 'train_splendor2_v80.npz'))
+    ex = (d['boards'].reshape(len(d['boards']), -1), d['pi'], d['z'], d['valids'], d['q'])
+    hist = train(m, ex, learn_rate=float(d['hp/learn_rate']), batch_size=int(d['hp/batch_size']), epochs=int(d['hp/epochs']),
+                 q_weight=float(d['hp/q_weight']), device=device, seed=0)
+    assert len(hist) == 2
+    got_pi, got_v = np.array([h[0] for h in hist]), np.array([h[1] for h in hist])
+    assert np.abs(got_pi - d['loss_pi']).max() <= 1e-5, (got_pi, d['loss_pi'])
+    assert np.abs(got_v - d['loss_v']).max() <= 1e-5, (got_v, d['loss_v'])
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    for k in [f[6:] for f in d.files if f.startswith('after/')]:
+        assert np.abs(sd[k] - d['after/' + k]).max() <= 1e-5, k
+
+
+def test_trainer_matches_reference_trainer_cpu():
+    _train_vs_reference('cpu')
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_trainer_matches_reference_trainer_gpu():
+    _train_vs_reference('cuda:0')
+
+
+def test_nnet_wrapper_examples_list_and_losses():
+    """NNetWrapper.train takes Coach's example list (compressed pickles or tuples, Coach.py:84) and its loss_pi / loss_v are the
+    reference's (:179-190): the first-step losses of the trainer fixture, evaluated directly."""
+    import pickle
+    import zlib
+    from azg_amd.nnet_wrapper import decode_examples
+    from azg_amd.train import loss_pi, loss_v
+    d = np.load(os.path.join(GOLDEN, 'train_splendor2_v80.npz'))
+    tuples = [(d['boards'][i], d['pi'][i], d['z'][i], d['valids'][i].astype(bool), d['q'][i]) for i in range(len(d['pi']))]
+    packed = [zlib.compress(pickle.dumps(t), level=1) for t in tuples]
+    for lst in (tuples, packed):
+        cols = decode_examples(lst)
+        assert np.array_equal(cols[0], d['boards'].reshape(len(tuples), -1)) and np.array_equal(cols[1], d['pi'])
+    m, _ = _load()
+    m.train()                                           # the reference evaluates the losses in training mode (BatchNorm batch stats)
+    lp, v = m(torch.from_numpy(d['boards']), torch.from_numpy(d['valids'].astype(bool)))
+    assert abs(float(loss_pi(torch.from_numpy(d['pi']), lp)) - d['loss_pi'][0]) <= 1e-5
+    assert abs(float(loss_v(torch.from_numpy(d['z']), torch.from_numpy(d['q']), v, float(d['hp/q_weight']))) - d['loss_v'][0]) <= 1e-5
