@@ -238,7 +238,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     if (rc) { azg_forest_destroy(f); return -1; }
     hipError_t e = hipMemset(D.hdr, 0, T * sizeof(TreeHdr));
     if (e == hipSuccess) {
-        const unsigned long long init[4] = {0ull, 0ull, 0ull, (unsigned long long)cfg->rng_seed};   // [3] = effective RNG seed
+        const unsigned long long init[4] = {0ull, 0ull, 0ull, 0ull};
         e = hipMemcpy(D.ex_count, init, sizeof(init), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMemset(D.root_state, 0, T * f->SP);
@@ -481,11 +481,11 @@ extern "C" int azg_selfplay_start_ex(azg_forest* f, const int8_t* init_boards, u
     if (episode_quota < 0) return fail("azg_selfplay_start_ex: episode_quota < 0");
     // epoch 0 keeps the streams of the RNG contract; any other epoch re-keys every stream of this forest (boards, playout-cap
     // draws, root noise, move picks), so that successive self-play / arena waves of one run do not replay the same games
-    // (the effective seed lives in device memory, ex_count[3]: kernels captured in a HIP graph see the new epoch)
-    const unsigned long long seed = epoch ? f->cfg.rng_seed ^ (0x9E3779B97F4A7C15ULL * (epoch + 0x632BE59BD9B4E019ULL)) : f->cfg.rng_seed;
-    const unsigned long long init[4] = {0ull, 0ull, (unsigned long long)episode_quota, seed};
-    HIPCHK(hipMemcpyAsync(f->dev.ex_count, init, sizeof(init), hipMemcpyHostToDevice, (hipStream_t)stream));
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));           // `init` is a stack buffer
+    // (seed and quota are kernel arguments: HIP graphs captured under other values must be captured again)
+    f->dev.rng_seed = epoch ? f->cfg.rng_seed ^ (0x9E3779B97F4A7C15ULL * (epoch + 0x632BE59BD9B4E019ULL)) : f->cfg.rng_seed;
+    if (episode_quota > 0xFFFFFFFFll) return fail("azg_selfplay_start_ex: episode_quota too large");
+    f->dev.episode_quota = (uint32_t)episode_quota;
+    HIPCHK(hipMemsetAsync(f->dev.ex_count, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));
     FDISPATCH(f, k_selfplay_start<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev,
                                      init_boards));
     HIPCHK(hipGetLastError());

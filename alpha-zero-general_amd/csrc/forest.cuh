@@ -113,6 +113,7 @@ struct ForestDev {
                                        // node's record the same size, so a freed record fits any later node
     int level_budget;                  // max descent levels per tree per k_select launch (0 = unlimited)
     int work_budget;                   // max work units (level = 1, edge resolution = AZG_EDGE_UNITS) per tree per launch
+    uint32_t episode_quota;            // self-play: total games this forest plays (azg_selfplay_start_ex), 0 = restart forever
     double cpuct, fpu, prob_fullMCTS, dirichletAlpha, temp_begin, temp_end, temp_root, tempThreshold;
     uint64_t rng_seed, stream0;
     int max_examples, max_rec;
@@ -132,13 +133,11 @@ struct ForestDev {
     // example ring
     int8_t* ex_board; float* ex_pi; float* ex_z; uint8_t* ex_valid; float* ex_q;
     int32_t* ex_meta;                  // [max_examples][4] = (global game stream, game index on that stream, ply, player)
-    unsigned long long* ex_count;      // [0] = records written, [1] = dropped (games that did not fit), [2] = episode quota
-                                       // (0 = restart forever), [3] = effective RNG seed (cfg.rng_seed re-keyed by the epoch
-                                       // of azg_selfplay_start_ex; in device memory so that captured graphs see a new epoch)
+    unsigned long long* ex_count;      // [0] = records written, [1] = dropped (games that did not fit)
 };
-__device__ __forceinline__ uint64_t forest_seed(const ForestDev& F) {
-    return ((uint64_t)uni_u32((uint32_t)(F.ex_count[3] >> 32)) << 32) | uni_u32((uint32_t)F.ex_count[3]);
-}
+// the forest's effective RNG seed: cfg.rng_seed, re-keyed by the epoch of azg_selfplay_start_ex (a kernel argument: HIP graphs
+// captured before a change of epoch or episode quota must be captured again -- SelfPlayEngine.start does)
+__device__ __forceinline__ uint64_t forest_seed(const ForestDev& F) { return F.rng_seed; }
 
 // Load a header through the vector path but keep every word wave-uniform (SGPR): the tree / node headers drive the
 // control flow of the whole wave, so they should not occupy 64 lanes' worth of VGPRs.

@@ -121,11 +121,11 @@ __device__ void start_game(const ForestDev& F, int t, TreeHdr& H, typename Fores
 }
 
 // Episode quota (Coach.executeEpisodes plays exactly numEps episodes, every one to its end, Coach.py:86-148): with
-// ex_count[2] = numEps != 0, tree t plays numEps / T (+1 for t < numEps % T) games and then goes idle instead of
+// ForestDev.episode_quota = numEps != 0, tree t plays numEps / T (+1 for t < numEps % T) games and then goes idle instead of
 // restarting, so every started game finishes and is kept -- no bias towards short games.  0 = restart forever.
 __device__ __forceinline__ uint32_t tree_quota(const ForestDev& F, int t) {
-    const unsigned long long q = F.ex_count[2];
-    return (uint32_t)(q / (unsigned long long)F.T) + ((unsigned long long)t < q % (unsigned long long)F.T ? 1u : 0u);
+    const uint32_t q = F.episode_quota;
+    return q / (uint32_t)F.T + ((uint32_t)t < q % (uint32_t)F.T ? 1u : 0u);
 }
 
 template <class G>
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k_selfplay_start(ForestDev F, const int8_t
     Rng rng{forest_seed(F), F.stream0 + (uint64_t)t, 0ull};
     H.err = 0; H.games_done = 0; H.gc_runs = 0; H.max_nodes_seen = 0; H.max_live = 0;
     H.c_sims = H.c_levels = H.c_exp = H.c_sumvalid = H.c_term = H.c_depth = H.c_plies = H.c_examples = 0;
-    if (F.ex_count[2] != 0ull && tree_quota(F, t) == 0u) {       // fewer episodes than trees: this tree plays none
+    if (F.episode_quota != 0u && tree_quota(F, t) == 0u) {       // fewer episodes than trees: this tree plays none
         reset_tree<G>(F, t, H);
         H.status = ST_IDLE; H.noise_pending = 0; H.pending_leaf = AZG_NONE; H.mid_sim = 0; H.n_rec = 0; H.rng_counter = 0;
         if (lane_id() == 0) F.hdr[t] = H;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
         }
         if (base != ~0ull) H.c_examples += H.n_rec;
         H.games_done++;
-        if (F.ex_count[2] != 0ull && H.games_done >= tree_quota(F, t)) {      // episode quota reached: no restart
+        if (F.episode_quota != 0u && H.games_done >= tree_quota(F, t)) {      // episode quota reached: no restart
             H.status = ST_IDLE; H.n_rec = 0; H.rng_counter = rng.counter;
             if (l == 0) F.hdr[t] = H;
             return;

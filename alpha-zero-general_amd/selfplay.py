@@ -94,7 +94,9 @@ class SelfPlayEngine:
             grp.f.selfplay_start(None if init_boards is None else init_boards[g * Tg:(g + 1) * Tg], epoch=epoch,
                                  episode_quota=max(q, 0) if q >= 0 else 0)
             assert q >= 0, 'episode_quota smaller than the number of groups'
-        # a captured graph stays valid: the epoch-keyed seed and the quota live in device memory (ex_count[2..3])
+        if (epoch, episode_quota) != getattr(self, '_epoch_quota', (0, 0)):
+            self.graph = None                # seed and quota are kernel arguments: the captured rounds are stale
+        self._epoch_quota = (epoch, episode_quota)
         torch.cuda.synchronize()
         # pipeline prologue: odd groups enter the steady state one stage ahead (their leaves are already selected)
         for g, grp in enumerate(self.groups):

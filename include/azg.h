@@ -167,7 +167,8 @@ int azg_selfplay_start(azg_forest* f, const int8_t* init_boards_dev /* or NULL *
    the next wave of episodes of one Coach.learn run (Coach.py:150-215 draws fresh randomness every iteration) does not replay
    the previous one; (b) an episode quota = Coach.executeEpisodes' numEps (Coach.py:86-148): tree t plays quota / T (+1 for
    t < quota % T) games to their end and then idles -- every started game is finished and kept; 0 = restart forever.
-   Synchronises `stream` once (the quota word is copied from the host). */
+   Seed and quota are kernel arguments: HIP graphs that captured this forest's launches under another epoch / quota must be
+   captured again. */
 int azg_selfplay_start_ex(azg_forest* f, const int8_t* init_boards_dev /* or NULL */, uint64_t epoch, int64_t episode_quota,
                           void* stream);
 /* to be called after expand_backup, every round or every few rounds: trees whose search finished sample the move
