@@ -4,10 +4,14 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-LIB = os.path.join(HERE, 'libazg_hip.so')
+LIB = os.environ.get('AZG_OUT') or os.path.join(HERE, 'libazg_hip.so')          # AZG_OUT: build a variant for A/B runs
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
-         '-I' + os.path.join(HERE, '..', 'include')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-I' + os.path.join(HERE, '..', 'include')]
+# Translation units of the library (compiled concurrently): the forest / env / self-play kernels with their C-ABI, and the net
+# kernels with theirs.  (Wave-uniform reads of mutable forest memory are relaxed agent-scope atomic loads -- forest.cuh
+# ld_agent_u32 / load_uniform -- so that the compiler cannot turn them into scalar-cache loads; the blanket alternative,
+# -mllvm -amdgpu-scalarize-global-loads=false, was tried in round 2 and miscompiled k_selfplay_advance<AzulDev>.)
+UNITS = [('azg.hip', []), ('azg_nn.hip', [])]
 # debugging builds: AZG_DEFINES="AZG_CYC_COUNTERS AZG_NN_PHASE_TIMES" python alpha-zero-general_amd/build.py
 FLAGS += ['-D' + d for d in os.environ.get('AZG_DEFINES', '').split()]
 
@@ -27,10 +31,25 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, 'azg.hip'), '-o', LIB]
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='azg_build_')
+    objs, procs = [], []
+    for src, extra in UNITS:                       # the units compile concurrently
+        obj = os.path.join(tmp, src.replace('.hip', '.o'))
+        cmd = [HIPCC] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
+    shutil.rmtree(tmp, ignore_errors=True)
     return LIB
 
 

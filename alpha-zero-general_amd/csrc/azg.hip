@@ -1,7 +1,9 @@
 // azg.hip -- C-ABI (include/azg.h) of the MI355X self-play engine: host-side launch code for the gfx950 kernels.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared azg.hip -o libazg_hip.so
+// Forest, env and self-play kernels + their C-ABI; the net kernels live in azg_nn.hip (second translation unit of the same
+// library, see build.py for the flags of each).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -11,15 +13,12 @@
 #include "game_santorini.cuh"
 #include "game_azul.cuh"
 #include "selfplay.cuh"
-#include "nn_kernels.cuh"
-#include "nn_mb1d.cuh"
-#include "nn_conv5x5.cuh"
+#include "azg_host.h"
 
 using namespace azg;
 
 static thread_local std::string g_err;
-static int fail(const std::string& m) { g_err = m; return -1; }
-#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
+int azg_fail(const std::string& m) { g_err = m; return -1; }
 
 extern "C" const char* azg_last_error(void) { return g_err.c_str(); }
 extern "C" const char* azg_version(void) { return "azg-hip r2 (gfx950)"; }
@@ -508,10 +507,15 @@ extern "C" int azg_selfplay_active(azg_forest* f, int* n_active) {
 
 extern "C" int azg_selfplay_advance(azg_forest* f, void* stream) {
     if (!f) return fail("null forest");
+    static const bool dbg = getenv("AZG_DEBUG_SYNC") != nullptr;       // debugging aid: attribute a device fault to one kernel
+    if (dbg) { fprintf(stderr, "[azg] k_selfplay_advance\n"); fflush(stderr); }
     FDISPATCH(f, k_selfplay_advance<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev));
+    if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "[azg] k_gc\n"); fflush(stderr); }
     // trees whose arena ran short asked for the clean-up (16 waves per tree), then begin their search
     FDISPATCH(f, k_gc<G><<<dim3(f->dev.T), dim3(1024), 0, (hipStream_t)stream>>>(f->dev));
+    if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "[azg] k_after_gc\n"); fflush(stderr); }
     FDISPATCH(f, k_after_gc<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev));
+    if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "[azg] advance done\n"); fflush(stderr); }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -612,185 +616,6 @@ extern "C" int azg_forest_last_kernel_ms(azg_forest* f, int which, double* avg_m
     return 0;
 }
 
-// ---- policy/value net building blocks (NeuralNet.predict, GenericNNetWrapper.py:94-120; V80: SplendorNNet.py:262-283) ----
-template <int NT, int KSPLIT, int NCH>
-static int launch_linear(const float* A, int lda, const float* Wp, const float* bias, const float* R, int ldr,
-                         const float* rowscale, int rpg, float* out, int ldc, int M, int K, int Kp, int N, int act,
-                         hipStream_t s) {
-    constexpr int NP = NT * 16;
-    const int tiles = (M + 15) / 16;
-    size_t lds;
-    int grid;
-    if (KSPLIT) {
-        lds = (size_t)4 * NT * 4 * 64 * sizeof(float);
-        grid = tiles;
-    } else {
-        lds = (size_t)Kp * NP * sizeof(float);
-        grid = (tiles + 3) / 4;
-        if (grid > 512) grid = 512;
-    }
-    if (lds > 160 * 1024) return fail("azg_nn_linear: weight tile exceeds LDS");
-    static bool attr_done = false;
-    if (lds > 64 * 1024 && !attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_linear<NT, KSPLIT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
-    k_linear<NT, KSPLIT, NCH><<<dim3(grid), dim3(256), lds, s>>>(A, lda, Wp, bias, R, ldr, rowscale, rpg, out, ldc, M, K, Kp,
-                                                                  N, act);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int azg_nn_linear(const float* A, int lda, const float* Wp, int Kp, int NP, const float* bias, const float* R,
-                             int ldr, const float* rowscale, int rows_per_group, float* out, int ldc, int M, int K, int N,
-                             int act, int ksplit, void* stream) {
-    if (!A || !Wp || !out || M <= 0) return fail("azg_nn_linear: null/empty argument");
-    if (K % 4 || lda % 4 || Kp % 16 || Kp < K || NP % 16 || NP < N || (rowscale && rows_per_group <= 0))
-        return fail("azg_nn_linear: K, lda multiples of 4; Wp padded to [Kp % 16 == 0][NP % 16 == 0]");
-    hipStream_t s = (hipStream_t)stream;
-    const int nt = NP / 16;
-    const int chunks = Kp / 16;
-    const int per_wave = ksplit ? (chunks + 3) / 4 : chunks;
-    const int nch = per_wave <= 2 ? 2 : (per_wave <= 4 ? 4 : (per_wave <= 7 ? 7 : (per_wave <= 11 ? 11 : 0)));
-    if (!nch) return fail("azg_nn_linear: K too long for this variant (K <= 176, or <= 704 with ksplit)");
-#define ARGS A, lda, Wp, bias, R, ldr, rowscale, rows_per_group, out, ldc, M, K, Kp, N, act, s
-#define LIN_N(NTV, KS)                                                                     \
-    switch (nch) {                                                                         \
-        case 2: return launch_linear<NTV, KS, 2>(ARGS);                                    \
-        case 4: return launch_linear<NTV, KS, 4>(ARGS);                                    \
-        case 7: return launch_linear<NTV, KS, 7>(ARGS);                                    \
-        default: return launch_linear<NTV, KS, 11>(ARGS);                                  \
-    }
-#define LIN(NTV) do { if (ksplit) { LIN_N(NTV, 1) } else { LIN_N(NTV, 0) } } while (0)
-    switch (nt) {
-        case 1: LIN(1);
-        case 4: LIN(4);
-        case 6: LIN(6);
-        case 11: LIN(11);
-        case 12: LIN(12);
-        default: return fail("azg_nn_linear: NP/16 must be 1, 4, 6, 11 or 12");
-    }
-#undef LIN
-#undef LIN_N
-#undef ARGS
-}
-
-template <int NCH>
-static int launch_linear_ws(const float* A, int lda, const float* Wp, int NP, const float* biasp, const float* R, int ldr,
-                            const float* rowscale, int rpg, float* out, int ldc, int M, int K, int N, int act,
-                            hipStream_t s) {
-    const int tiles = (M + 15) / 16;
-    const int col_groups = ((N + 15) / 16 + 3) / 4;
-    // enough workgroups to fill the chip (~2048 waves), but several row tiles per wave so the weight fragment and the
-    // software prefetch are amortised
-    int tiles_per_wg = (tiles * col_groups + 2047) / 2048;
-    if (tiles_per_wg < 1) tiles_per_wg = 1;
-    const int gx = (tiles + tiles_per_wg - 1) / tiles_per_wg;
-    k_linear_ws<NCH><<<dim3(gx, col_groups), dim3(256), 0, s>>>(A, lda, Wp, NP, biasp, R, ldr, rowscale, rpg, out, ldc, M, K, N,
-                                                                act, tiles_per_wg);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int azg_nn_linear_ws(const float* A, int lda, const float* Wp, int Kp, int NP, const float* bias_padded,
-                                const float* R, int ldr, const float* rowscale, int rows_per_group, float* out, int ldc,
-                                int M, int K, int N, int act, void* stream) {
-    if (!A || !Wp || !out || M <= 0) return fail("azg_nn_linear_ws: null/empty argument");
-    if (K % 4 || lda % 4 || ldc % 4 || (R && ldr % 4) || Kp % 16 || Kp < K || NP % 16 || NP < N ||
-        (rowscale && rows_per_group <= 0))
-        return fail("azg_nn_linear_ws: K, lda, ldc, ldr multiples of 4; Wp padded to [Kp % 16 == 0][NP % 16 == 0]");
-    hipStream_t s = (hipStream_t)stream;
-#define WS(NCHV) return launch_linear_ws<NCHV>(A, lda, Wp, NP, bias_padded, R, ldr, rowscale, rows_per_group, out, ldc, M, K, N, act, s)
-    switch (Kp / 16) {
-        case 1: WS(1);
-        case 2: WS(2);
-        case 3: WS(3);
-        case 4: WS(4);
-        case 6: WS(6);
-        case 8: WS(8);
-        case 11: WS(11);
-        case 17: WS(17);
-        case 25: WS(25);
-        default: return fail("azg_nn_linear_ws: Kp/16 must be 1, 2, 3, 4, 6, 8, 11, 17 or 25");
-    }
-#undef WS
-}
-
-extern "C" int azg_nn_dw_pool_l(float* H, int ldh, const float* Wd, const float* sd, const float* bd, float* pooled, int B,
-                                int E, int L, int act, int pool_max, void* stream) {
-    if (!H || !Wd || !pooled || B <= 0) return fail("azg_nn_dw_pool: null/empty argument");
-    const long long total = (long long)B * E;
-    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (L == 7) k_dw_pool<7><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(H, ldh, Wd, sd, bd, pooled, B, E, act, pool_max);
-    else if (L == 6) k_dw_pool<6><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(H, ldh, Wd, sd, bd, pooled, B, E, act, pool_max);
-    else return fail("azg_nn_dw_pool: token count must be 6 or 7");
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int azg_nn_dw_pool(float* H, int ldh, const float* Wd, const float* sd, const float* bd, float* pooled, int B,
-                              int E, int act, int pool_max, void* stream) {
-    return azg_nn_dw_pool_l(H, ldh, Wd, sd, bd, pooled, B, E, 7, act, pool_max, stream);
-}
-
-static constexpr size_t V80_LDS = (size_t)(112 * 60 + 112 * 172 + 2 * 16 * 172 + 16 * 52 + 64) * sizeof(float);
-
-template <int A_, int P_, int M_>
-static int launch_v80(const float* xin, float* xout, const V80BlockW& W, int B, const int8_t* boards, const V80NetW& N,
-                      const uint8_t* valid, float* pi, float* v, int P, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_v80_block<A_, P_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-        attr = true;
-    }
-    k_v80_block<A_, P_, M_><<<dim3((B + 15) / 16), dim3(768), V80_LDS, s>>>(xin, xout, W, B, boards, N, valid, pi, v, P);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int azg_nn_v80_block(const float* xin, float* xout, const float* const* w /* 11 device pointers */, int B,
-                                int act, int pool_max, void* stream) {
-    if (!xin || !xout || !w || B <= 0) return fail("azg_nn_v80_block: null/empty argument");
-    V80BlockW W{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10]};
-    V80NetW N{};
-    hipStream_t s = (hipStream_t)stream;
-    if (act == 1 && !pool_max) return launch_v80<1, 0, 0>(xin, xout, W, B, nullptr, N, nullptr, nullptr, nullptr, 0, s);
-    if (act == 1 && pool_max) return launch_v80<1, 1, 0>(xin, xout, W, B, nullptr, N, nullptr, nullptr, nullptr, 0, s);
-    if (act == 2 && !pool_max) return launch_v80<2, 0, 0>(xin, xout, W, B, nullptr, N, nullptr, nullptr, nullptr, 0, s);
-    if (act == 2 && pool_max) return launch_v80<2, 1, 0>(xin, xout, W, B, nullptr, N, nullptr, nullptr, nullptr, 0, s);
-    return fail("azg_nn_v80_block: act must be 1 (ReLU) or 2 (Hardswish)");
-}
-
-extern "C" int azg_nn_v80_forward(const int8_t* boards, const uint8_t* valid, const float* const* w /* 43 */, int B,
-                                  int P, float* x_trunk, float* pi, float* v, void* stream) {
-    if (!boards || !valid || !w || !x_trunk || !pi || !v || B <= 0) return fail("azg_nn_v80_forward: null/empty argument");
-    if (P < 2 || P > 4) return fail("azg_nn_v80_forward: 2 <= P <= 4");
-    V80BlockW Wt{w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12]};
-    V80BlockW Wp{w[13], w[14], w[15], w[16], w[17], w[18], w[19], w[20], w[21], w[22], w[23]};
-    V80BlockW Wv{w[24], w[25], w[26], w[27], w[28], w[29], w[30], w[31], w[32], w[33], w[34]};
-    V80NetW N0{w[0], w[1], nullptr, nullptr, nullptr, nullptr};
-    V80NetW Np{nullptr, nullptr, w[35], w[36], w[37], w[38]};
-    V80NetW Nv{nullptr, nullptr, w[39], w[40], w[41], w[42]};
-    hipStream_t s = (hipStream_t)stream;
-    // V80 geometry (SplendorNNet.py:262-283): trunk ReLU + mean-SE, both heads Hardswish + max-SE
-    if (getenv("AZG_NN_THREE_LAUNCHES")) {       // the per-block path (kept for A/B measurements)
-        if (launch_v80<1, 0, 1>(nullptr, x_trunk, Wt, B, boards, N0, nullptr, nullptr, nullptr, P, s)) return -1;
-        if (launch_v80<2, 1, 2>(x_trunk, nullptr, Wp, B, nullptr, Np, valid, pi, nullptr, P, s)) return -1;
-        if (launch_v80<2, 1, 3>(x_trunk, nullptr, Wv, B, nullptr, Nv, nullptr, nullptr, v, P, s)) return -1;
-        return 0;
-    }
-    static bool attr = false;
-    constexpr size_t lds = V80_LDS + (size_t)112 * 60 * sizeof(float);
-    if (!attr) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_v80_net, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    k_v80_net<<<dim3((B + 15) / 16), dim3(768), lds, s>>>(Wt, Wp, Wv, N0, Np, Nv, boards, valid, B, P, pi, v);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
 #ifdef AZG_CYC_COUNTERS
 extern "C" int azg_debug_prolog(unsigned long long* out /* [16] */, int reset) {
     HIPCHK(hipDeviceSynchronize());
@@ -799,110 +624,3 @@ extern "C" int azg_debug_prolog(unsigned long long* out /* [16] */, int reset) {
     return 0;
 }
 #endif
-
-#ifdef AZG_NN_PHASE_TIMES
-extern "C" int azg_nn_debug_phase_times(long long* out /* [4][16] */) {
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v80_phase), sizeof(long long) * 64));
-    return 0;
-}
-#endif
-
-// ---- whole MobileNet-1d forward, any supported geometry, one launch (nn_mb1d.cuh) ----
-//                        L   C  NS    A  P   E0   E1   E2  Q0  Q1  Q2 CO1 A0 A12 PMAX
-typedef Mb1dCfg<7, 56, 8, 81, 2, 168, 168, 168, 40, 40, 40, 56, 1, 2, 1> CfgSplendor2;
-typedef Mb1dCfg<7, 71, 8, 81, 3, 213, 213, 213, 56, 56, 56, 71, 1, 2, 1> CfgSplendor3;
-typedef Mb1dCfg<7, 88, 8, 81, 4, 264, 264, 264, 64, 64, 64, 88, 1, 2, 1> CfgSplendor4;
-typedef Mb1dCfg<6, 23, 16, 180, 2, 115, 115, 46, 32, 32, 16, 46, 1, 2, 0> CfgAzul;
-
-template <class CF>
-static int launch_mb1d(const Mb1dNetW& N, const int8_t* boards, const uint8_t* valid, int B, float* pi, float* v, hipStream_t s) {
-    constexpr size_t lds = (size_t)CF::LDS_FLOATS * sizeof(float);
-    static_assert(lds <= 160 * 1024, "geometry does not fit the LDS of a CU");
-    static bool attr = false;
-    if (!attr) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_mb1d_net<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    k_mb1d_net<CF><<<dim3((B + CF::NS - 1) / CF::NS), dim3(768), lds, s>>>(N, boards, valid, B, pi, v);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int azg_nn_mb1d_forward(int geometry, const int8_t* boards, const uint8_t* valid, const float* const* w, int B,
-                                   float* pi, float* v, void* stream) {
-    if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_mb1d_forward: null/empty argument");
-    Mb1dNetW N;
-    N.W0 = w[0]; N.b0 = w[1];
-    for (int b = 0; b < 3; b++) {
-        const float* const* q = w + 2 + 11 * b;
-        N.blk[b] = Mb1dBlockW{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10]};
-    }
-    const float* const* h = w + 35;
-    N.Wpi1 = h[0]; N.bpi1 = h[1]; N.Wpi2 = h[2]; N.bpi2 = h[3]; N.Wv1 = h[4]; N.bv1 = h[5]; N.Wv2 = h[6]; N.bv2 = h[7];
-    hipStream_t s = (hipStream_t)stream;
-    switch (geometry) {
-        case AZG_NET_SPLENDOR2: return launch_mb1d<CfgSplendor2>(N, boards, valid, B, pi, v, s);
-        case AZG_NET_SPLENDOR3: return launch_mb1d<CfgSplendor3>(N, boards, valid, B, pi, v, s);
-        case AZG_NET_SPLENDOR4: return launch_mb1d<CfgSplendor4>(N, boards, valid, B, pi, v, s);
-        case AZG_NET_AZUL: return launch_mb1d<CfgAzul>(N, boards, valid, B, pi, v, s);
-        default: return fail("azg_nn_mb1d_forward: unknown geometry");
-    }
-}
-
-// ---- Santorini ResNet V88/V89 (no-gods geometry: A = 162, P = 2, 5 residual blocks), one launch (nn_conv5x5.cuh) ----
-extern "C" int azg_nn_conv5_forward(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A,
-                                    int P, int B, float* pi, float* v, void* stream) {
-    if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_conv5_forward: null/empty argument");
-    if (n_blocks != 5 || A != 162 || P != 2) return fail("azg_nn_conv5_forward: built for 5 residual blocks, A = 162, P = 2");
-    Conv5NetW N{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13]};
-    constexpr size_t lds = (size_t)2 * 200 * 68 * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    k_conv5_net<5, 162, 2><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-// ---- Santorini-with-gods net V78 (10 InvertedResidual blocks, A = 1782, P = 2), one launch (nn_conv5x5.cuh) ----
-extern "C" int azg_nn_s78_forward(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A, int P,
-                                  int B, float* pi, float* v, void* stream) {
-    if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_s78_forward: null/empty argument");
-    if (n_blocks != 10 || A != 1782 || P != 2) return fail("azg_nn_s78_forward: built for 10 blocks, A = 1782, P = 2");
-    S78NetW N{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15], w[16], w[17], w[18]};
-    constexpr size_t lds = (size_t)(112 * 68 + 112 * 196 + 4 * 32) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_s78_net<10, 1782, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    k_s78_net<10, 1782, 2><<<dim3((B + 3) / 4), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int azg_nn_board_to_x_ld(const int8_t* boards, float* x, int B, int C, int L, int ldx, void* stream) {
-    if (!boards || !x || B <= 0 || L <= 0 || ldx < C) return fail("azg_nn_board_to_x: null/empty argument");
-    const long long total = (long long)B * L * ldx;
-    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    k_board_to_x<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(boards, x, B, C, L, ldx);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int azg_nn_board_to_x(const int8_t* boards, float* x, int B, int C, void* stream) {
-    return azg_nn_board_to_x_ld(boards, x, B, C, 7, C, stream);
-}
-
-extern "C" int azg_nn_heads_out(const float* logits, int ldl, const uint8_t* valid, const float* vhid, int ldv,
-                                const float* Wv2, const float* bv2, float* pi, float* v, int B, int A, int P,
-                                void* stream) {
-    if (!logits || !valid || !pi || !v || B <= 0) return fail("azg_nn_heads_out: null/empty argument");
-    if (A > 256 || P > 4) return fail("azg_nn_heads_out: A <= 256, P <= 4");
-    k_heads_out<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(logits, ldl, valid, vhid, ldv, Wv2, bv2, pi, v, B, A, P);
-    HIPCHK(hipGetLastError());
-    return 0;
-}

@@ -1,0 +1,8 @@
+// host-side helpers shared by the two translation units of libazg_hip.so (azg.hip, azg_nn.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+
+int azg_fail(const std::string& m);               // records the message for azg_last_error(), returns -1
+static inline int fail(const std::string& m) { return azg_fail(m); }
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)

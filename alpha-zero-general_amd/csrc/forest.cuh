@@ -139,18 +139,34 @@ struct ForestDev {
 // captured before a change of epoch or episode quota must be captured again -- SelfPlayEngine.start does)
 __device__ __forceinline__ uint64_t forest_seed(const ForestDev& F) { return F.rng_seed; }
 
-// Load a header through the vector path but keep every word wave-uniform (SGPR): the tree / node headers drive the
-// control flow of the whole wave, so they should not occupy 64 lanes' worth of VGPRs.
-template <class T>
+// Wave-uniform reads of MUTABLE global memory (tree / node / record headers, counters, free lists).
+// They must never become scalar loads: the compiler turns a uniform-address load of global memory into an s_load whenever it
+// sees no earlier store in the kernel, the scalar data cache is not coherent with the vector stores / L2 atomics of earlier
+// launches, and HIP-graph replays do not reliably invalidate it between kernel nodes (measured in round 2: a scalarised read of
+// TreeHdr.c_sims made self-play results depend on the launch cadence).  A relaxed agent-scope atomic load is never scalarised
+// and is served by the L2 (`global_load ... sc1`); `load_uniform_hot` keeps plain vector loads for the descent loop of k_select,
+// where the surrounding stores already rule the scalar path out and the loads may merge into dwordx4.
+__device__ __forceinline__ uint32_t ld_agent_u32(const uint32_t* p) {
+    return uni_u32(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ uint64_t ld_agent_u64(const uint64_t* p) {
+    const uint64_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ((uint64_t)uni_u32((uint32_t)(v >> 32)) << 32) | uni_u32((uint32_t)v);
+}
+__device__ __forceinline__ int ld_agent_i32(const int32_t* p) { return (int)ld_agent_u32((const uint32_t*)p); }
+template <class T, bool HOT = false>
 __device__ __forceinline__ T load_uniform(const T* p) {
     static_assert(sizeof(T) % 4 == 0, "word-sized struct");
-    T out;
     const uint32_t* s = (const uint32_t*)p;
-    uint32_t* d = (uint32_t*)&out;
+    uint32_t w[sizeof(T) / 4];
 #pragma unroll
-    for (int k = 0; k < (int)(sizeof(T) / 4); k++) d[k] = uni_u32(s[k]);
+    for (int k = 0; k < (int)(sizeof(T) / 4); k++) w[k] = HOT ? uni_u32(s[k]) : ld_agent_u32(s + k);
+    T out;
+    __builtin_memcpy(&out, w, sizeof(T));          // (not a cast of &out: writes through uint32_t* may not alias T's fields)
     return out;
 }
+template <class T>
+__device__ __forceinline__ T load_uniform_hot(const T* p) { return load_uniform<T, true>(p); }
 
 __device__ __constant__ long long AZG_MAGIC_SEEDS[8] = {31416, 1, 14142, 42, 27183, 2, 16180, 7};   // MCTS.py:14
 
@@ -352,7 +368,7 @@ struct Forest {
         uint32_t id;
         if (H.n_free_ids > 0) {                                      // reuse the id of a node the clean-up dropped
             H.n_free_ids--;
-            id = uni_u32((F.free_ids + (size_t)t * F.s_free)[H.n_free_ids]);
+            id = uni_u32((F.free_ids + (size_t)t * F.s_free)[H.n_free_ids]);     // (k_select only: plain vector load)
         } else {
             if (H.id_top >= (uint32_t)F.cap) { H.err |= ERR_NODE_OVERFLOW; return AZG_NONE; }
             id = H.id_top++;

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(64) void k_env_valid_moves(const int8_t* states, co
     int t = blockIdx.x;
     if (t >= n) return;
     Forest<G>::load_state_unpadded(st, states + (size_t)t * G::S);
-    G::valid_mask(st, players ? players[t] : 0, mask);
+    G::valid_mask(st, players ? ld_agent_i32(players + t) : 0, mask);
     wave_sync();
     for (int a = lane_id(); a < G::A; a += 64) out[(size_t)t * G::A + a] = (uint8_t)((mask[a >> 6] >> (a & 63)) & 1);
 }
@@ -30,8 +30,9 @@ __global__ __launch_bounds__(64) void k_env_next_state(const int8_t* states, con
     int t = blockIdx.x;
     if (t >= n) return;
     Forest<G>::load_state_unpadded(st, states + (size_t)t * G::S);
-    Rng rng{rng_seed, stream0 + (uint64_t)t, counters ? counters[t] : 0ull};
-    const int np = G::wave_make_move(st, actions[t], players ? players[t] : 0, seeds ? (long long)seeds[t] : 0ll, rng);
+    Rng rng{rng_seed, stream0 + (uint64_t)t, counters ? ld_agent_u64(counters + t) : 0ull};
+    const int np = G::wave_make_move(st, ld_agent_i32(actions + t), players ? ld_agent_i32(players + t) : 0,
+                                     seeds ? (long long)ld_agent_u64((const uint64_t*)seeds + t) : 0ll, rng);
     if (lane_id() == 0) {
         if (counters) counters[t] = rng.counter;
         out_next[t] = np;
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(64) void k_env_game_ended(const int8_t* states, con
     if (t >= n) return;
     Forest<G>::load_state_unpadded(st, states + (size_t)t * G::S);
     float es[G::P];
-    G::game_ended(st, next_players ? next_players[t] : 0, es, mask);
+    G::game_ended(st, next_players ? ld_agent_i32(next_players + t) : 0, es, mask);
     if (lane_id() == 0) {
         for (int p = 0; p < G::P; p++) {
             if (out_ended) out_ended[(size_t)t * G::P + p] = es[p];
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(64) void k_env_canonical(const int8_t* states, cons
     int t = blockIdx.x;
     if (t >= n) return;
     Forest<G>::load_state_unpadded(st, states + (size_t)t * G::S);
-    int p = players[t];
+    int p = ld_agent_i32(players + t);
     if (p != 0) G::swap_players(st, tmp, p);
     Forest<G>::store_state_unpadded(out_states + (size_t)t * G::S, st);
 }
@@ -171,6 +172,7 @@ __device__ __forceinline__ bool root_noise_tree(const ForestDev& F, int t, uint3
     const RecHdr rh = load_uniform((const RecHdr*)rec);
     if (!(rh.flags & NF_EXPANDED)) return false;
     const int nv = rh.nv;
+
     const RecLayout L(nv, F.U);
     const RecIds ids(rec, F.U);
     for (int i = l; i < G::A; i += 64) dense[i] = 0.f;
@@ -192,9 +194,9 @@ __global__ __launch_bounds__(64) void k_root_noise(ForestDev F, const double* ro
     __shared__ __attribute__((aligned(16))) float dense[G::A];
     __shared__ __attribute__((aligned(16))) uint64_t mask[G::AW];
     const int t = blockIdx.x;
-    if (!uni_u32(F.hdr[t].noise_pending)) return;
-    const uint32_t root_rec = uni_u32(F.hdr[t].root_rec);
-    const uint64_t c_sims = F.hdr[t].c_sims;
+    if (!ld_agent_u32(&F.hdr[t].noise_pending)) return;
+    const uint32_t root_rec = ld_agent_u32(&F.hdr[t].root_rec);
+    const uint64_t c_sims = ld_agent_u64(&F.hdr[t].c_sims);
     if (root_noise_tree<G>(F, t, root_rec, c_sims, root_noise, noise_stride, dense, mask) && lane_id() == 0)
         F.hdr[t].noise_pending = 0u;
 }
@@ -326,10 +328,13 @@ struct ExpandIn {
 // waits for -- group by group along the prologue (4 serialised round trips measured).
 constexpr int AZG_HOT_WORDS = offsetof(TreeHdr, c_sims) / 4;
 #define AZG_HW(w, field) ((w)[offsetof(TreeHdr, field) / 4])
+// HOT (k_select): plain vector loads that merge into dwordx4 -- the kernel's own header stores keep the compiler from using
+// the scalar path (checked in the ISA: no s_load of the header); elsewhere agent-scope atomic loads (forest.cuh ld_agent_u32).
+template <bool HOT>
 __device__ __forceinline__ void load_hot_header(const TreeHdr* Hp, uint32_t (&w)[AZG_HOT_WORDS]) {
     const uint32_t* p = (const uint32_t*)Hp;
 #pragma unroll
-    for (int i = 0; i < AZG_HOT_WORDS; i++) w[i] = p[i];
+    for (int i = 0; i < AZG_HOT_WORDS; i++) w[i] = HOT ? p[i] : __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // second half, after every other load of the batch has been issued: one wait, the words move to SGPRs
 __device__ __forceinline__ void pin_hot_header(uint32_t (&w)[AZG_HOT_WORDS]) {
@@ -363,7 +368,8 @@ __device__ __forceinline__ void expand_load(const ForestDev& F, int t, const flo
         in.va[k] = a < G::A ? leaf_valid[(size_t)t * G::A + a] : (uint8_t)0;
     }
 #pragma unroll
-    for (int p = 0; p < G::P; p++) in.v[p] = vin[(size_t)t * G::P + p];
+    for (int p = 0; p < G::P; p++)     // (the net's output of the previous launch: never through the scalar cache)
+        in.v[p] = __uint_as_float(__hip_atomic_load((const uint32_t*)vin + (size_t)t * G::P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     in.pe0 = (F.path + (size_t)t * AZG_MAXD)[l];
 }
 
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* 
     const int t = blockIdx.x;
     ExpandIn<G> in;
     uint32_t hw[AZG_HOT_WORDS];
-    load_hot_header(&F.hdr[t], hw);
+    load_hot_header<false>(&F.hdr[t], hw);
     expand_load<G>(F, t, pi, vin, leaf_valid, in, hw);
     pin_hot_header(hw);
     expand_header<G>(in, hw);
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     SelState H;
     ExpandIn<G> ein;
     uint32_t hw[AZG_HOT_WORDS];
-    load_hot_header(Hp, hw);
+    load_hot_header<true>(Hp, hw);
     if (pi) expand_load<G>(F, t, pi, vin, leaf_valid, ein, hw);         // pi != nullptr: the previous round's expansion first
     pin_hot_header(hw);
     AZG_STAMP(1);
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 if (l + 64 < FR::SPW) ps1 = nsp[l + 64];
                 if (FR::SPW > 128 && l + 128 < FR::SPW) ps2 = nsp[l + 128];
             }
-            const RecHdr rh = load_uniform((const RecHdr*)rp);
+            const RecHdr rh = load_uniform_hot((const RecHdr*)rp);
             if (rh.flags & NF_TERMINAL) {                                                       // MCTS.py:136-138
                 c_term++;
                 float v[G::P];

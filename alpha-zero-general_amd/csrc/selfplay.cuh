@@ -203,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_gc(ForestDev F) {
     __shared__ uint32_t head[G::A + 1];
     __shared__ uint32_t ctr[4];
     const int t = blockIdx.x;
-    if (uni_u32(F.hdr[t].status) != ST_GC) return;
+    if (ld_agent_u32(&F.hdr[t].status) != ST_GC) return;
     TreeHdr H = load_uniform(&F.hdr[t]);
     const int wave = (int)(threadIdx.x >> 6);
     gc_scan<G>(F, t, H, (int)H.cur_pre, head, ctr, wave, 16);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) void k_after_gc(ForestDev F) {
     __shared__ typename FR::Smem sm;
     __shared__ __attribute__((aligned(16))) float dense[G::A];
     const int t = blockIdx.x;
-    if (uni_u32(F.hdr[t].status) != ST_GC_DONE) return;
+    if (ld_agent_u32(&F.hdr[t].status) != ST_GC_DONE) return;
     TreeHdr H = load_uniform(&F.hdr[t]);
     Rng rng{forest_seed(F), F.stream0 + (uint64_t)t, H.rng_counter};
     FR::load_state(sm.st, F.root_state + (size_t)t * G::SP);
@@ -256,12 +256,12 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     __shared__ __attribute__((aligned(16))) float dense[G::A];
     const int t = blockIdx.x;
     const int l = lane_id();
-    const uint32_t status0 = uni_u32(F.hdr[t].status);
+    const uint32_t status0 = ld_agent_u32(&F.hdr[t].status);
     if (status0 != ST_DONE) {
         // nothing to advance; a root expanded by simulation 0 may still be waiting for its Dirichlet noise (MCTS.py:147-149)
-        if (!uni_u32(F.hdr[t].noise_pending) || status0 != ST_SEARCHING) return;
-        const uint32_t root_rec = uni_u32(F.hdr[t].root_rec);
-        const uint64_t c_sims = F.hdr[t].c_sims;
+        if (!ld_agent_u32(&F.hdr[t].noise_pending) || status0 != ST_SEARCHING) return;
+        const uint32_t root_rec = ld_agent_u32(&F.hdr[t].root_rec);
+        const uint64_t c_sims = ld_agent_u64(&F.hdr[t].c_sims);
         if (root_noise_tree<G>(F, t, root_rec, c_sims, nullptr, -1, dense, sm.mask) && l == 0) F.hdr[t].noise_pending = 0u;
         return;
     }

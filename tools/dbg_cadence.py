@@ -19,7 +19,7 @@ def run(K, graph, fused):
     meta = ex[5]; keep = np.flatnonzero(meta[:, 1] == 0); order = keep[np.lexsort((meta[keep, 2], meta[keep, 0]))]
     for grp in e.groups: grp.f.close()
     return [x[order] for x in ex]
-cfgs = [(1, False, False), (1, False, False), (5, True, True), (3, True, False), (1, False, True), (1, False, True)]
+cfgs = [(1, False, False), (5, False, True), (3, False, False), (5, True, True), (3, True, False), (1, True, True), (1, True, False)]
 res = [run(*c) for c in cfgs]
 for c, r in zip(cfgs[1:], res[1:]):
     same = all(np.array_equal(a, b) for a, b in zip(res[0], r)) if len(r[0]) == len(res[0][0]) else False
