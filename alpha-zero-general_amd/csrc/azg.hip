@@ -12,6 +12,7 @@
 #include "game_splendor.cuh"
 #include "game_santorini.cuh"
 #include "game_azul.cuh"
+#include "game_minivilles.cuh"
 #include "selfplay.cuh"
 #include "azg_host.h"
 
@@ -34,6 +35,9 @@ extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
         else if ((game) == AZG_SANTORINI && (variant) == 1) { using G = SantoriniDev<1>; __VA_ARGS__; }   \
         else if ((game) == AZG_SANTORINI && (variant) == 11) { using G = SantoriniDev<11>; __VA_ARGS__; } \
         else if ((game) == AZG_AZUL) { using G = AzulDev; __VA_ARGS__; }                                   \
+        else if ((game) == AZG_MINIVILLES && (variant) == 2) { using G = MinivillesDev<2>; __VA_ARGS__; } \
+        else if ((game) == AZG_MINIVILLES && (variant) == 3) { using G = MinivillesDev<3>; __VA_ARGS__; } \
+        else if ((game) == AZG_MINIVILLES && (variant) == 4) { using G = MinivillesDev<4>; __VA_ARGS__; } \
         else return fail("unsupported game/variant");                                              \
     } while (0)
 
@@ -41,6 +45,7 @@ static int norm_variant(int game, int variant) {
     if (game == AZG_SPLENDOR) return variant ? variant : 2;
     if (game == AZG_SANTORINI) return variant ? variant : 11;
     if (game == AZG_AZUL) return 2;
+    if (game == AZG_MINIVILLES) return variant ? variant : 2;
     return variant;
 }
 
@@ -205,7 +210,8 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     D.tempThreshold = cfg->tempThreshold;
     D.rng_seed = cfg->rng_seed; D.stream0 = cfg->stream0;
     D.max_examples = cfg->max_examples > 0 ? cfg->max_examples : 0;
-    D.max_rec = f->cfg.game == AZG_SPLENDOR ? 64 * f->P + 8 : 256;   // Azul / Santorini: plies per game are < 256 in practice
+    D.max_rec = f->cfg.game == AZG_SPLENDOR ? 64 * f->P + 8 : (f->cfg.game == AZG_MINIVILLES ? 320 : 256);   // Azul / Santorini: plies per
+                                                                                     // game < 256 in practice; Minivilles: < 126 rounds + re-rolls
     const size_t T = D.T;
     int rc = 0;
     rc |= dalloc(f, &D.hdr, T);

@@ -9,6 +9,7 @@
 namespace azg {
 
 struct AzulDev {
+    static constexpr bool STOCHASTIC = false;   // the env step is a function of (state, action, random_seed): edges are memoised
     static constexpr int P = 2;
     static constexpr int ROWS = 23, COLS = 6;
     static constexpr int S = 138;

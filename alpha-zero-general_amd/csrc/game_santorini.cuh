@@ -11,6 +11,7 @@ namespace azg {
 
 template <int NB>
 struct SantoriniDev {
+    static constexpr bool STOCHASTIC = false;   // the env step is a function of (state, action, random_seed): edges are memoised
     static constexpr int P = 2;
     static constexpr int ROWS = 25, COLS = 3;
     static constexpr int S = 75;

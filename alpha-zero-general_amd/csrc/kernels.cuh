@@ -260,7 +260,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
 template <class G, class HS>
 __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& H, typename Forest<G>::Smem& sm,
                                               uint32_t parent_node, int a, long long seed, int8_t* leaf_states,
-                                              uint8_t* leaf_valid, bool* is_new, bool* terminal, float* es,
+                                              uint8_t* leaf_valid, bool* is_new, bool* terminal, float* es, Rng& rng,
                                               bool have_state = false, uint32_t st0 = 0, uint32_t st1 = 0, uint32_t st2 = 0) {
     using FR = Forest<G>;
 #define AZG_SEG(k, d) H.cyc_seg[k] += (uint32_t)(d)
@@ -274,8 +274,7 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
     } else
         FR::load_state(sm.st, FR::nstate(F, t, parent_node));
     long long c1 = AZG_CLK(); AZG_SEG(0, c1 - c0);
-    Rng no_rng{0, 0, 0};
-    const int np = G::wave_make_move(sm.st, a, 0, seed, no_rng);
+    const int np = G::wave_make_move(sm.st, a, 0, seed, rng);      // (rng is only drawn from by STOCHASTIC games)
     c0 = AZG_CLK(); AZG_SEG(1, c0 - c1);
     if (np != 0) G::swap_players(sm.st, sm.tmp, np);
     const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
@@ -470,6 +469,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(ForestDev F, const float* 
 struct SelState {
     uint32_t n_nodes, heap_top, id_top, n_free_ids, free_units, root, root_rec, sim_idx, n_sims, is_full, forced, err, leaf_is_root, mid_sim, cur_rec,
         cur_depth, cur_pre, status, pending_leaf, path_len, leaf_nv, leaf_node, cyc_leaf, cyc_seg[4];
+    uint32_t rng_lo, rng_hi;        // the tree's RNG counter (STOCHASTIC games draw the env randomness of every simulated step)
 };
 
 // One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
@@ -508,6 +508,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     H.sim_idx = AZG_HW(hw, sim_idx); H.n_sims = AZG_HW(hw, n_sims); H.is_full = AZG_HW(hw, is_full); H.forced = AZG_HW(hw, forced);
     H.err = AZG_HW(hw, err); H.leaf_is_root = AZG_HW(hw, leaf_is_root); H.mid_sim = AZG_HW(hw, mid_sim); H.cur_rec = AZG_HW(hw, cur_rec);
     H.cur_depth = AZG_HW(hw, cur_depth); H.cur_pre = AZG_HW(hw, cur_pre);
+    H.rng_lo = hw[offsetof(TreeHdr, rng_counter) / 4]; H.rng_hi = hw[offsetof(TreeHdr, rng_counter) / 4 + 1];
     bool fresh_noise = false;
     if (pi && uni_u32(status0) == ST_WAIT_NN) {
         fresh_noise = expand_apply<G>(F, t, ein, dense, sm.path, noise_enabled, azg_stamp);
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     H.is_full = uni_u32(H.is_full); H.forced = uni_u32(H.forced); H.err = uni_u32(H.err);
     H.leaf_is_root = uni_u32(H.leaf_is_root); H.mid_sim = uni_u32(H.mid_sim); H.cur_rec = uni_u32(H.cur_rec);
     H.cur_depth = uni_u32(H.cur_depth); H.cur_pre = uni_u32(H.cur_pre);
+    Rng srng{F.rng_seed, F.stream0 + (uint64_t)t, ((uint64_t)uni_u32(H.rng_hi) << 32) | uni_u32(H.rng_lo)};
     if (expanded_here) H.sim_idx = uni_u32(ein.sim_idx) + 1u;          // the header words were requested before the expansion
     H.status = ST_SEARCHING; H.pending_leaf = AZG_NONE; H.path_len = 0; H.cyc_leaf = 0; H.leaf_nv = 0; H.leaf_node = 0;
     H.cyc_seg[0] = H.cyc_seg[1] = H.cyc_seg[2] = H.cyc_seg[3] = 0;
@@ -703,13 +705,16 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 bool is_new = false;
                 const long long t_e = AZG_CLK();
                 child = resolve_edge<G, SelState>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es,
-                                                  spec_state, ps0, ps1, ps2);
+                                                  srng, spec_state, ps0, ps1, ps2);
                 cyc_edge += AZG_CLK() - t_e;
                 if (child == AZG_NONE) { H.sim_idx = H.n_sims; break; }
                 // memoise: this universe's slot -- or every slot when the env step of `a` cannot depend on the seed (the
                 // child of (state, a, seed) is then the same node for all universes; 30 % of the simulations used to
                 // re-resolve such an edge once per universe only to find the node through the hash table)
-                if (G::move_uses_seed(a)) {
+                // STOCHASTIC games (true randomness inside make_move, MCTS.py:238 re-rolls it at every traversal): the child of
+                // (state, action) is a random variable, so the slot stays empty and every visit replays the step
+                if (G::STOCHASTIC) {
+                } else if (G::move_uses_seed(a)) {
                     if (l == 0) *(uint32_t*)((uint8_t*)rp + AZG_REC_HDR + (size_t)j * ES + AZG_E_C + 4u * (uint32_t)uidx) = child;
                 } else if (l < F.U) *(uint32_t*)((uint8_t*)rp + AZG_REC_HDR + (size_t)j * ES + AZG_E_C + 4u * (uint32_t)l) = child;
                 have_leaf = is_new;
@@ -746,6 +751,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         Hp->sim_idx = H.sim_idx; Hp->err = H.err; Hp->leaf_is_root = H.leaf_is_root; Hp->mid_sim = H.mid_sim;
         Hp->cur_rec = H.cur_rec; Hp->cur_depth = H.cur_depth; Hp->cur_pre = H.cur_pre; Hp->status = H.status;
         Hp->pending_leaf = H.pending_leaf; Hp->path_len = H.path_len; Hp->pending_nv = H.leaf_nv; Hp->pending_node = H.leaf_node;
+        if (G::STOCHASTIC) Hp->rng_counter = srng.counter;
         // statistics: no-return atomics, so the wave does not wait for a read-modify-write round trip before it retires
         atomicMax(&Hp->max_nodes_seen, H.n_nodes);
         stat_add(&Hp->c_sims, c_sims); stat_add(&Hp->c_levels, c_levels); stat_add(&Hp->c_sumvalid, c_sumvalid);

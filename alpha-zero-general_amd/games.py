@@ -75,7 +75,7 @@ class HipGame:
         return out
 
     def max_symmetries(self):
-        return {0: 10 + 2 * self.P, 1: 8, 2: 120}[self.GAME_ID]          # Splendor, Santorini, Azul
+        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles
 
     def symmetries_batch(self, boards, pi, valids, max_sym=None):
         """getSymmetries for n (board int8[n,S], pi f32[n,A], valids u8[n,A]) triples on device ->
@@ -175,6 +175,15 @@ class AzulGame(HipGame):
         super().__init__(2, **kw)
 
 
+class MinivillesGame(HipGame):
+    """minivilles/MinivillesGame.py (NUMBER_PLAYERS 2..4).  The env step rolls dice whatever random_seed says
+    (MinivillesLogicNumba.py:232-242): every getNextState / getInitBoard draws from the engine's counter RNG stream."""
+    GAME_ID = _lib.MINIVILLES
+
+    def __init__(self, num_players=2, **kw):
+        super().__init__(num_players, **kw)
+
+
 def import_game(name, **kw):
     """GameSwitcher.import_game equivalent (GameSwitcher.py:15-24) for the games on the hot path."""
     if name == 'splendor':
@@ -183,4 +192,6 @@ def import_game(name, **kw):
         return SantoriniGame(**kw)
     if name == 'azul':
         return AzulGame(**kw)
+    if name == 'minivilles':
+        return MinivillesGame(**kw)
     raise ValueError('game %r is not on the accelerated path' % name)

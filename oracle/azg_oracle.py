@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libazg_oracle.so')
 
-SPLENDOR, SANTORINI, AZUL = 0, 1, 2
+SPLENDOR, SANTORINI, AZUL, MINIVILLES = 0, 1, 2, 3
 MAXP = 4
 
 
@@ -75,6 +75,7 @@ def lib():
         L.azo_mcts_create.argtypes = [C.POINTER(Game), C.POINTER(MctsArgs), C.c_int]
         L.azo_mcts_destroy.argtypes = [vp]
         L.azo_mcts_reset.argtypes = [vp]
+        L.azo_mcts_set_rng.argtypes = [vp, C.POINTER(Rng)]
         L.azo_mcts_num_nodes.restype = C.c_size_t
         L.azo_mcts_num_nodes.argtypes = [vp]
         L.azo_hashnet_predict.argtypes = [vp, i8p, u8p, f32p, f32p]
@@ -234,6 +235,11 @@ class OracleMCTS:
         if getattr(self, 'h', None):
             lib().azo_mcts_destroy(self.h)
             self.h = None
+
+    def set_rng(self, rng):
+        """random source of the env steps inside the search (games that roll dice in make_move: Minivilles); borrowed"""
+        self._rng = rng
+        lib().azo_mcts_set_rng(self.h, C.byref(rng) if rng is not None else None)
 
     def getActionProb(self, canonicalBoard, temp=1, force_full_search=False, u_full=0.0, dir_noise=None):
         b = np.ascontiguousarray(canonicalBoard, dtype=np.int8)

@@ -57,6 +57,7 @@ int azo_episode_run(const azo_game* g, const azo_episode_cfg* cfg, const int8_t*
     if (init_board) memcpy(board, init_board, (size_t)S);
     else azo_init_board(g, board, &rng);
     azo_mcts* m = azo_mcts_create(g, &cfg->mcts, 0);
+    azo_mcts_set_rng(m, &rng);                  /* search-time env randomness (Minivilles) draws from the episode's stream */
     int cur = 0, step = 0, plies = 0;
     float r[AZO_MAX_PLAYERS];
     for (;;) {

@@ -45,6 +45,8 @@ struct azo_mcts {
     int step, nb_sims, is_full, forced;
     const double* dir_noise;
     int64_t random_seed;
+    azo_rng* search_rng;   /* env steps inside the search (games with true randomness in make_move), borrowed */
+    azo_rng own_rng;
     /* sim-in-progress */
     node** path_node;
     int* path_a;
@@ -116,8 +118,12 @@ azo_mcts* azo_mcts_create(const azo_game* g, const azo_mcts_args* args, int diri
     m->path_a = (int*)malloc(sizeof(int) * (size_t)m->path_cap);
     m->path_np = (int*)malloc(sizeof(int) * (size_t)m->path_cap);
     m->random_seed = -1;
+    memset(&m->own_rng, 0, sizeof(m->own_rng));      /* default search stream: (seed 0, stream 0), counter 0 */
+    m->search_rng = &m->own_rng;
     return m;
 }
+
+void azo_mcts_set_rng(azo_mcts* m, azo_rng* rng) { m->search_rng = rng ? rng : &m->own_rng; }
 
 void azo_mcts_reset(azo_mcts* m) {   /* reset_all_search_trees MCTS.py:199-203 */
     for (size_t i = 0; i < m->cap; i++) if (m->tab[i]) { node_free(m->tab[i]); m->tab[i] = NULL; }
@@ -318,7 +324,7 @@ int azo_mcts_sim_begin(azo_mcts* m) {
         if (m->depth >= m->path_cap) return -1;
         m->c_levels++;
         for (int i = 0; i < g->A; i++) m->c_sumvalid += nd->Vs[i];
-        int np = azo_make_move(g, m->cur, a, 0, m->random_seed, NULL);            /* :238-239 */
+        int np = azo_make_move(g, m->cur, a, 0, m->random_seed, m->search_rng);   /* :238-239 */
         if (np != 0) azo_swap_players(g, m->cur, np);                             /* :243-245 */
         m->path_node[m->depth] = nd; m->path_a[m->depth] = a; m->path_np[m->depth] = np;
         m->depth++;

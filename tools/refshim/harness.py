@@ -37,12 +37,12 @@ _tmp_roots = []
 def _purge_modules():
     for name in list(sys.modules):
         root = name.split('.')[0]
-        if root in ('splendor', 'santorini', 'azul', 'MCTS', 'Game', 'Coach', 'Arena', 'utils', 'GameSwitcher',
+        if root in ('splendor', 'santorini', 'azul', 'minivilles', 'MCTS', 'Game', 'Coach', 'Arena', 'utils', 'GameSwitcher',
                     'NeuralNet'):
             del sys.modules[name]
 
 
-def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=1):
+def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=1, minivilles_players=2):
     """Import the reference from a temp copy with the requested source-level variants.
     Returns a dict of modules."""
     tmp = tempfile.mkdtemp(prefix='azg_ref_')
@@ -50,7 +50,7 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     for name in os.listdir(REFERENCE):
         src = os.path.join(REFERENCE, name)
         if os.path.isdir(src):
-            if name in ('splendor', 'santorini', 'azul'):
+            if name in ('splendor', 'santorini', 'azul', 'minivilles'):
                 shutil.copytree(src, os.path.join(tmp, name),
                                 ignore=shutil.ignore_patterns('*.pt', '*.gif', '*.jpg', '*.png', '*.mp4', '*.csv',
                                                               '__pycache__'))
@@ -66,6 +66,7 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     sub('splendor/SplendorGame.py', 'NUMBER_PLAYERS = 2', 'NUMBER_PLAYERS = %d' % splendor_players)
     sub('santorini/SantoriniConstants.py', 'NB_GODS = 11', 'NB_GODS = %d' % santorini_gods)
     sub('santorini/SantoriniLogicNumba.py', 'INIT_METHOD = 1', 'INIT_METHOD = %d' % santorini_init_method)
+    sub('minivilles/MinivillesGame.py', 'NUMBER_PLAYERS = 2', 'NUMBER_PLAYERS = %d' % minivilles_players)
 
     _purge_modules()
     sys.dont_write_bytecode = True
@@ -94,6 +95,12 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     except Exception as e:  # pragma: no cover
         mods['AzulGame'] = None
         mods['azul_error'] = e
+    try:
+        mods['MinivillesGame'] = importlib.import_module('minivilles.MinivillesGame')
+        mods['MinivillesLogicNumba'] = importlib.import_module('minivilles.MinivillesLogicNumba')
+    except Exception as e:  # pragma: no cover
+        mods['MinivillesGame'] = None
+        mods['minivilles_error'] = e
     mods['MCTS'] = importlib.import_module('MCTS')
     mods['utils'] = importlib.import_module('utils')
     return mods
@@ -125,6 +132,52 @@ class UniformStream:
         v = self.values[self.pos]
         self.pos += 1
         return v
+
+
+def _mix64(x):
+    M = (1 << 64) - 1
+    x &= M
+    x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & M
+    x ^= x >> 27; x = (x * 0x94D049BB133111EB) & M
+    x ^= x >> 31
+    return x
+
+
+class CounterRandom:
+    """The engine's counter-based RNG contract (include/azg.h) as a drop-in for the reference's GLOBAL np.random on the paths
+    that consume it inside the env step (Minivilles: np.random.randint for the dice, np.random.random for the purple cards):
+    u01 = (mix64(mix64(mix64(seed ^ GOLD) + stream) + counter) >> 11) * 2^-53; randint(lo, hi) = lo + floor(u * (hi - lo)).
+    `with CounterRandom(seed, stream) as r:` patches np.random.random / randint for the duration; r.counter = draws consumed,
+    r.used = the uniforms in order."""
+
+    def __init__(self, seed=0, stream=0, counter=0, injected=None):
+        self.seed, self.stream, self.counter, self.used = seed, stream, counter, []
+        self.injected = None if injected is None else list(injected)
+
+    def random(self):
+        if self.injected is not None:
+            u = self.injected.pop(0) if self.injected else 0.5
+        else:
+            M = (1 << 64) - 1
+            x = _mix64((_mix64((_mix64(self.seed ^ 0x9E3779B97F4A7C15) + self.stream) & M) + self.counter) & M)
+            u = (x >> 11) * (1.0 / 9007199254740992.0)
+        self.counter += 1
+        self.used.append(u)
+        return u
+
+    def randint(self, lo, hi=None):
+        if hi is None:
+            lo, hi = 0, lo
+        v = lo + int(self.random() * (hi - lo))
+        return min(v, hi - 1)
+
+    def __enter__(self):
+        self._orig = (np.random.random, np.random.randint)
+        np.random.random, np.random.randint = self.random, self.randint
+        return self
+
+    def __exit__(self, *a):
+        np.random.random, np.random.randint = self._orig
 
 
 class HashNet:
