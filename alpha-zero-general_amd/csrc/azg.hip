@@ -293,19 +293,6 @@ static void ev_end(azg_forest* f, int which, hipStream_t s) {
     f->ev_used[which]++;
 }
 
-// k_select with args.universes baked in for the values the reference's checkpoints use (0, 1, 3); anything else reads it at run time
-template <class G>
-static void launch_select(const azg_forest* f, hipStream_t s, int8_t* leaf_states, uint8_t* leaf_valid, uint8_t* needs_eval,
-                          int wait_noise, const float* pi, const float* v, int noise) {
-    const dim3 grid(f->dev.T), block(64);
-    switch (f->dev.universes) {
-        case 0: k_select<G, 1><<<grid, block, 0, s>>>(f->dev, leaf_states, leaf_valid, needs_eval, wait_noise, pi, v, noise); break;
-        case 1: k_select<G, 2><<<grid, block, 0, s>>>(f->dev, leaf_states, leaf_valid, needs_eval, wait_noise, pi, v, noise); break;
-        case 3: k_select<G, 4><<<grid, block, 0, s>>>(f->dev, leaf_states, leaf_valid, needs_eval, wait_noise, pi, v, noise); break;
-        default: k_select<G, 0><<<grid, block, 0, s>>>(f->dev, leaf_states, leaf_valid, needs_eval, wait_noise, pi, v, noise);
-    }
-}
-
 extern "C" int azg_forest_select(azg_forest* f, int8_t* leaf_states, uint8_t* leaf_valid, uint8_t* needs_eval,
                                  const double* root_noise, int noise_stride, void* stream) {
     if (!f || !leaf_states || !leaf_valid || !needs_eval) return fail("null argument");
@@ -314,7 +301,8 @@ extern "C" int azg_forest_select(azg_forest* f, int8_t* leaf_states, uint8_t* le
     const int wait_noise = (f->cfg.dirichletAlpha != 0.0 && !root_noise && noise_stride == -2) ? 1 : 0;
     f->last_leaf_valid = leaf_valid;
     ev_begin(f, 0, (hipStream_t)stream);
-    FDISPATCH(f, launch_select<G>(f, (hipStream_t)stream, leaf_states, leaf_valid, needs_eval, wait_noise, nullptr, nullptr, 0));
+    FDISPATCH(f, k_select<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, leaf_states,
+                                     leaf_valid, needs_eval, wait_noise, nullptr, nullptr, 0));
     ev_end(f, 0, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -327,7 +315,8 @@ extern "C" int azg_forest_select_fused(azg_forest* f, int8_t* leaf_states, uint8
     const int noise = (f->cfg.dirichletAlpha != 0.0 && noise_stride == -2) ? 1 : 0;
     f->last_leaf_valid = leaf_valid;
     ev_begin(f, 0, (hipStream_t)stream);
-    FDISPATCH(f, launch_select<G>(f, (hipStream_t)stream, leaf_states, leaf_valid, needs_eval, noise, pi, v, noise));
+    FDISPATCH(f, k_select<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, leaf_states,
+                                     leaf_valid, needs_eval, noise, pi, v, noise));
     ev_end(f, 0, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;

@@ -473,19 +473,11 @@ struct SelState {
 };
 
 // One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
-// UNIV: args.universes + 1 baked in at compile time (0 = read it from ForestDev).  The entry stride, the record size, the
-// position of the action id and `sim_idx % universes` then fold to constants: ~100 scalar set-up instructions and a run-time
-// division less in every launch's prologue (the host picks the instantiation, azg.hip select_dispatch).
-template <class G, int UNIV = 0>
+template <class G>
 __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
                                                   uint8_t* needs_eval, int wait_noise, const float* pi, const float* vin,
                                                   int noise_enabled) {
     using FR = Forest<G>;
-    if (UNIV > 0) {
-        __builtin_assume(F.universes == UNIV - 1);
-        __builtin_assume(F.U == (UNIV > 1 ? UNIV - 1 : 1));
-    }
-    if (G::A <= 96) __builtin_assume(F.cls_q == G::A);          // (azg_forest_create: one record class for small action spaces)
     __shared__ typename FR::Smem sm;
     __shared__ __attribute__((aligned(16))) float dense[G::A];          // fused expansion only
     static_assert(sizeof(ForestDev) + 52 <= 448 && sizeof(ForestDev) + 52 > 0x180 + 4,
