@@ -247,20 +247,39 @@ extern "C" int azg_nn_mb1d_forward(int geometry, const int8_t* boards, const uin
 }
 
 // ---- Santorini ResNet V88/V89 (no-gods geometry: A = 162, P = 2, 5 residual blocks), one launch (nn_conv5x5.cuh) ----
-extern "C" int azg_nn_conv5_forward(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A,
-                                    int P, int B, float* pi, float* v, void* stream) {
+static int conv5_launch(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A, int P, int B,
+                        float* pi, float* v, void* stream, bool split) {
     if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_conv5_forward: null/empty argument");
     if (n_blocks != 5 || A != 162 || P != 2) return fail("azg_nn_conv5_forward: built for 5 residual blocks, A = 162, P = 2");
     Conv5NetW N{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13]};
-    constexpr size_t lds = (size_t)2 * 200 * 68 * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+    static bool attr[2] = {false, false};
+    if (split) {
+        constexpr size_t lds = (size_t)2 * 3 * 201 * 128;              // two activation tiles of three bf16 planes (+ a zero row each)
+        if (!attr[1]) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr[1] = true;
+        }
+        k_conv5_net<5, 162, 2, true><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
+    } else {
+        constexpr size_t lds = (size_t)2 * 200 * 68 * sizeof(float);
+        if (!attr[0]) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr[0] = true;
+        }
+        k_conv5_net<5, 162, 2, false><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
     }
-    k_conv5_net<5, 162, 2><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+extern "C" int azg_nn_conv5_forward(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A,
+                                    int P, int B, float* pi, float* v, void* stream) {
+    return conv5_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, false);
+}
+
+extern "C" int azg_nn_conv5_forward_split(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A,
+                                          int P, int B, float* pi, float* v, void* stream) {
+    return conv5_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, true);
 }
 
 // ---- Santorini-with-gods net V78 (10 InvertedResidual blocks, A = 1782, P = 2), one launch (nn_conv5x5.cuh) ----

@@ -94,14 +94,174 @@ __device__ __forceinline__ void conv3x3_tile(const float* __restrict__ Wfrag, co
     }
 }
 
-template <int NB, int A, int P>
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-precision variant of the trunk (the MI355X matrix cores run f32 inputs at 1/16 of the bf16 rate).  Every f32 value x is
+// carried as three bf16 numbers x = hi + mid + lo (each rounded to nearest-even from what the previous ones left over: 24
+// significant bits in all, x - (hi + mid + lo) <= 2^-25 |x|), and a product a*b is accumulated in f32 as the six partial
+// products of at least 2^-24 relative weight: lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi -- bf16 x bf16 is exact in f32,
+// so the result differs from the f32 MFMA's only by the dropped 2^-24 terms and the accumulation order (checked <= 1e-5 on the
+// net's outputs against the reference model like the f32 path).  Six v_mfma_f32_16x16x32_bf16 cover K = 32 in ~100 cycles where
+// eight v_mfma_f32_16x16x4_f32 need 256.
+//   activations in LDS: three planes [ROWS + 1][64] bf16 per tile (row = 128 B; the 16-byte chunk q of a row sits at
+//   q ^ (row & 7), which makes the ds_read_b128 of 16 consecutive rows conflict-free; row ROWS stays zero: it is what a tap that
+//   leaves the 5x5 board reads, so no select is needed on the operand registers); written split by the producing epilogue;
+//   weights: frag[ct 4][chunk 18][plane 3][lane 64][8] bf16 = W_plane[32*chunk + 8*(lane>>4) + j][16*ct + (lane&15)], K = tap*64 + ci.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t bf16_rn(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = bf16_rn(x);
+    float r = x - __uint_as_float(h << 16);
+    m = bf16_rn(r);
+    r = r - __uint_as_float(m << 16);
+    l = bf16_rn(r);
+}
+// byte offset of (row, 16-byte chunk q) inside one plane
+__device__ __forceinline__ int pl_off(int row, int q) { return row * 128 + ((q ^ (row & 7)) << 4); }
+// four consecutive channels (ch0 % 4 == 0) of one cell -> the three planes
+__device__ __forceinline__ void store_split4(uint8_t* planes, int plane_bytes, int row, int ch0, float4 o) {
+    uint32_t h[4], m[4], l[4];
+    split3(o.x, h[0], m[0], l[0]); split3(o.y, h[1], m[1], l[1]); split3(o.z, h[2], m[2], l[2]); split3(o.w, h[3], m[3], l[3]);
+    uint8_t* dst = planes + pl_off(row, ch0 >> 3) + ((ch0 & 4) << 1);
+    *(uint2*)dst = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    *(uint2*)(dst + plane_bytes) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+    *(uint2*)(dst + 2 * plane_bytes) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+__device__ __forceinline__ float bf16_lo_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi_f32(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+__device__ __forceinline__ float4 load_split4(const uint8_t* planes, int plane_bytes, int row, int ch0) {
+    const uint8_t* src = planes + pl_off(row, ch0 >> 3) + ((ch0 & 4) << 1);
+    const uint2 h = *(const uint2*)src, m = *(const uint2*)(src + plane_bytes), l = *(const uint2*)(src + 2 * plane_bytes);
+    return make_float4((bf16_lo_f32(h.x) + bf16_lo_f32(m.x)) + bf16_lo_f32(l.x), (bf16_hi_f32(h.x) + bf16_hi_f32(m.x)) + bf16_hi_f32(l.x),
+                       (bf16_lo_f32(h.y) + bf16_lo_f32(m.y)) + bf16_lo_f32(l.y), (bf16_hi_f32(h.y) + bf16_hi_f32(m.y)) + bf16_hi_f32(l.y));
+}
+
+// the first convolution (2 board planes, K = 9 x 16): f32 MFMA from the f32 staging tile, output written split
+template <int NS>
+__device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wfrag, const float* __restrict__ bias,
+                                                    const float* IN, uint8_t* OUT) {
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int ct = wave & 3, rg = wave >> 2;
+    float4 w[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) w[c] = FRAG(Wfrag, 9, ct, c);
+    const float4 b = *(const float4*)(bias + ct * 16 + 4 * g);
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) {
+        const int rt = rg + RG * i, r = rt * 16 + r16;
+        if (rt >= RT) continue;
+        const int cell = r % 25, y = cell / 5, x = cell - 5 * y;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const bool on = r < ROWS && yy >= 0 && yy < 5 && xx >= 0 && xx < 5;
+            float4 a = *(const float4*)(IN + (on ? r + (t / 3 - 1) * 5 + (t % 3 - 1) : 0) * CS + 4 * g);
+            if (!on) a = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].x, a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].w, a.w, acc, 0, 0, 0);
+        }
+        if (r < ROWS)
+            store_split4(OUT, PB, r, ct * 16 + 4 * g, make_float4(fmaxf(acc[0] + b.x, 0.f), fmaxf(acc[1] + b.y, 0.f),
+                                                                  fmaxf(acc[2] + b.z, 0.f), fmaxf(acc[3] + b.w, 0.f)));
+    }
+}
+
+struct SplitFrag { uint4 h, m, l; };                        // operand fragments of one (tile, tap, K chunk of 32)
+#define AZG_BF(x) __builtin_bit_cast(bf16x8, x)
+
+// one 64 -> 64 3x3 convolution on split activations: OUT = relu(conv(IN) + bias (+ RES)); OUT may alias RES
+template <int NS>
+__device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, const float* __restrict__ bias, const uint8_t* IN,
+                                              uint8_t* OUT, const uint8_t* RES) {
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128, KCH = 18;
+    static_assert(MAXT == 5 && RT - RG * (MAXT - 1) == 1, "step schedule: two tile pairs per wave + one odd tile in the first row group");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int ct = wave & 3, rg = wave >> 2;
+    int row[MAXT];
+    uint32_t tapmask[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) {
+        const int rt = rg + RG * i, r = rt * 16 + r16;
+        row[i] = r;
+        uint32_t m = 0;
+        if (rt < RT && r < ROWS) {
+            const int cell = r % 25, y = cell / 5, x = cell - 5 * y;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (yy >= 0 && yy < 5 && xx >= 0 && xx < 5) m |= 1u << t;
+            }
+        }
+        tapmask[i] = m;
+    }
+    f32x4 acc[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool last_slot = rg == 0;                         // wave-uniform: this wave has a tile in slot MAXT - 1
+    auto load = [&](int i, int t, int c) {
+        const bool on = (tapmask[i] >> t) & 1u;
+        const int r = on ? row[i] + (t / 3 - 1) * 5 + (t % 3 - 1) : ROWS;          // off the board: the zero row
+        const uint8_t* src = IN + pl_off(r, 4 * c + g);
+        return SplitFrag{*(const uint4*)src, *(const uint4*)(src + PB), *(const uint4*)(src + 2 * PB)};
+    };
+    // one (tile, tap, K chunk of 32): three 16-byte operand reads, six MFMAs into the tile's accumulator
+    auto step = [&](int i, int t, int c, bf16x8 wh, bf16x8 wm, bf16x8 wl) {
+        const SplitFrag a = load(i, t, c);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, AZG_BF(a.h), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, AZG_BF(a.l), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, AZG_BF(a.m), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, AZG_BF(a.h), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, AZG_BF(a.m), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, AZG_BF(a.h), acc[i], 0, 0, 0);
+    };
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ky++) {
+        uint4 w[6][3];                                      // [kx * 2 + c][plane]: the weight fragments of one kernel row
+#pragma unroll
+        for (int c6 = 0; c6 < 6; c6++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) w[c6][p] = Wfrag[(((size_t)ct * KCH + ky * 6 + c6) * 3 + p) * 64 + lane];
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const bf16x8 wh = AZG_BF(w[kx * 2 + c][0]), wm = AZG_BF(w[kx * 2 + c][1]), wl = AZG_BF(w[kx * 2 + c][2]);
+#pragma unroll
+                for (int i = 0; i < MAXT - 1; i++) step(i, ky * 3 + kx, c, wh, wm, wl);      // straight-line: consecutive tiles
+                if (last_slot) step(MAXT - 1, ky * 3 + kx, c, wh, wm, wl);                    // use different accumulators
+            }
+        }
+    }
+    const float4 b = *(const float4*)(bias + ct * 16 + 4 * g);
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) {
+        if (rg + RG * i >= RT || row[i] >= ROWS) continue;
+        float4 o = make_float4(acc[i][0] + b.x, acc[i][1] + b.y, acc[i][2] + b.z, acc[i][3] + b.w);
+        if (RES) {
+            const float4 r = load_split4(RES, PB, row[i], ct * 16 + 4 * g);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        store_split4(OUT, PB, row[i], ct * 16 + 4 * g, make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)));
+    }
+}
+#undef AZG_BF
+
+// SPLIT: the trunk on bf16 x 3 operands (above; N.Wc then points to the split fragments); LDS = 2 tiles x 3 planes x (ROWS + 1) x 128 B
+template <int NB, int A, int P, bool SPLIT = false>
 __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __restrict__ boards,
                                                    const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
                                                    float* __restrict__ v_out) {
-    constexpr int NS = 8, ROWS = NS * 25, CS = 68, CP2 = 2, AS = (A + 3) / 4 * 4 + 4;
+    constexpr int NS = 8, ROWS = NS * 25, CS = 68, CP2 = 2, AS = (A + 3) / 4 * 4 + 4, PLANE_B = (ROWS + 1) * 128, TILE_B = 3 * PLANE_B;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* X = smem;                        // [ROWS][CS]
-    float* Y = X + ROWS * CS;               // [ROWS][CS]
+    float* X = smem;                        // [ROWS][CS]   (SPLIT: three bf16 planes, TILE_B bytes)
+    float* Y = SPLIT ? (float*)((uint8_t*)smem + TILE_B) : X + ROWS * CS;               // [ROWS][CS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
     // ---- board int8 [s][y][x][3] -> Y[s*25 + cell][plane 0..1], channels 2..15 zero (the first conv reads 16) ----
@@ -112,14 +272,39 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         Y[r * CS + pl] = (float)boards[(size_t)b0 * 75 + r * 3 + pl];
     }
     __syncthreads();
-    conv3x3_tile<1, NS>(N.W0, N.b0, Y, X, nullptr);
-    __syncthreads();
+    if (SPLIT) {
+        uint8_t* XP = (uint8_t*)X;
+        uint8_t* YP = (uint8_t*)Y;
+        if (tid < 3 * 32) ((uint32_t*)(XP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // X's zero rows
+        conv3x3_first_split<NS>(N.W0, N.b0, Y, XP);           // (Y still holds the f32 board staging tile)
+        __syncthreads();
+        if (tid < 3 * 32) ((uint32_t*)(YP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // Y's (the staging tile is dead)
+        constexpr size_t CONV_U4 = (size_t)4 * 18 * 3 * 64;   // uint4 per convolution
 #pragma unroll 1
-    for (int blk = 0; blk < NB; blk++) {
-        conv3x3_tile<4, NS>(N.Wc + (size_t)(2 * blk) * (9 * 64 * 64), N.bc + (2 * blk) * 64, X, Y, nullptr);
+        for (int blk = 0; blk < NB; blk++) {
+            conv3x3_split<NS>((const uint4*)N.Wc + (size_t)(2 * blk) * CONV_U4, N.bc + (2 * blk) * 64, XP, YP, nullptr);
+            __syncthreads();
+            conv3x3_split<NS>((const uint4*)N.Wc + (size_t)(2 * blk + 1) * CONV_U4, N.bc + (2 * blk + 1) * 64, YP, XP, XP);
+            __syncthreads();
+        }
+        // the heads read f32: rebuild the trunk output as [ROWS][CS] f32 at the start of the Y tile
+        for (int i = tid; i < ROWS * 16; i += 768) {
+            const int r = i >> 4, c4 = (i & 15) * 4;
+            *(float4*)(Y + r * CS + c4) = load_split4(XP, PLANE_B, r, c4);
+        }
         __syncthreads();
-        conv3x3_tile<4, NS>(N.Wc + (size_t)(2 * blk + 1) * (9 * 64 * 64), N.bc + (2 * blk + 1) * 64, Y, X, X);
+        X = Y;
+        Y = Y + ROWS * CS;
+    } else {
+        conv3x3_tile<1, NS>(N.W0, N.b0, Y, X, nullptr);
         __syncthreads();
+#pragma unroll 1
+        for (int blk = 0; blk < NB; blk++) {
+            conv3x3_tile<4, NS>(N.Wc + (size_t)(2 * blk) * (9 * 64 * 64), N.bc + (2 * blk) * 64, X, Y, nullptr);
+            __syncthreads();
+            conv3x3_tile<4, NS>(N.Wc + (size_t)(2 * blk + 1) * (9 * 64 * 64), N.bc + (2 * blk + 1) * 64, Y, X, X);
+            __syncthreads();
+        }
     }
     // ---- heads (SimpleHead): 1x1 conv + BN + ReLU -> flatten (channel-major) -> FC ----
     float* HP = Y;                          // [NS][CP2*25]   policy head features

@@ -623,14 +623,27 @@ class SantoriniV89Hip:
     """SantoriniV89 (no-gods geometry: 5 residual blocks, A = 162) evaluated by the engine's one-launch implicit-GEMM kernel
     (azg_nn_conv5_forward, csrc/nn_conv5x5.cuh) instead of 11 MIOpen convolutions + glue ops.  Wraps a SantoriniV89."""
 
-    def __init__(self, base, max_batch=4096):
+    def __init__(self, base, max_batch=4096, split=True):
+        """split: the trunk convolutions on bf16 x 3 split-precision operands (azg_nn_conv5_forward_split: six bf16 MFMAs per
+        product at 16x the f32 MFMA rate, same 1e-5 contract); False = the f32-MFMA kernel"""
         import ctypes as C
         from . import _lib
-        self._lib, self.base, self.device = _lib, base, base.device
+        self._lib, self.base, self.device, self.split = _lib, base, base.device, bool(split)
         self.P, self.A = base.P, base.A
         assert base.dtype == torch.float32 and self.device.type == 'cuda' and len(base.blocks) == 5 and self.A == 162 and self.P == 2
         frag = SplendorV80Hip._frag
         d = self.device
+
+        def conv_split(w):                 # [co][ci][3][3] -> [4 ct][18 chunks][3 planes][64 lanes][8] bf16
+            co, ci = w.shape[0], w.shape[1]
+            m = w.permute(2, 3, 1, 0).reshape(9 * ci, co).contiguous().float()          # [K = tap*64 + ci][co]
+            hi = m.to(torch.bfloat16)
+            r1 = m - hi.float()
+            mid = r1.to(torch.bfloat16)
+            lo = (r1 - mid.float()).to(torch.bfloat16)
+            pl = torch.stack([hi, mid, lo])                                               # [3][K][co]
+            pl = pl.view(3, 18, 4, 8, 4, 16)                                              # plane, chunk, g, j, ct, r
+            return pl.permute(4, 1, 0, 2, 5, 3).contiguous().view(-1)                     # ct, chunk, plane, g, r, j
 
         def conv_mat(w, cin_pad):          # [co][ci][3][3] -> [tap*cin_pad + ci][co], fragment order
             co, ci = w.shape[0], w.shape[1]
@@ -639,7 +652,8 @@ class SantoriniV89Hip:
             return frag(m.reshape(9 * cin_pad, co).contiguous())
         convs = [c for blk in base.blocks for c in blk]
         keep = [conv_mat(base.c0[0], 16), base.c0[1].contiguous(),
-                torch.cat([conv_mat(w, 64) for w, _ in convs]).contiguous(), torch.cat([b for _, b in convs]).contiguous(),
+                torch.cat([(conv_split(w) if self.split else conv_mat(w, 64)) for w, _ in convs]).contiguous(),
+                torch.cat([b for _, b in convs]).contiguous(),
                 base.hp[0].reshape(2, 64).t().contiguous(), base.hp[1].contiguous(), base.fc_pi[0].contiguous(), base.fc_pi[1].contiguous(),
                 base.hv[0].reshape(64).contiguous(), base.hv[1].contiguous(), base.fc_v1[0].contiguous(), base.fc_v1[1].contiguous(),
                 base.fc_v2[0].contiguous(), base.fc_v2[1].contiguous()]
@@ -668,8 +682,9 @@ class SantoriniV89Hip:
         boards = boards.reshape(B, -1)
         assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda and boards.shape[1] == 75
         valids = (valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)).contiguous()
-        self._lib.check(self._lib.lib().azg_nn_conv5_forward(p(boards), p(valids), self.ptrs, 5, self.A, self.P, B, p(self.pi),
-                                                             p(self.v), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        fwd = self._lib.lib().azg_nn_conv5_forward_split if self.split else self._lib.lib().azg_nn_conv5_forward
+        self._lib.check(fwd(p(boards), p(valids), self.ptrs, 5, self.A, self.P, B, p(self.pi), p(self.v),
+                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return self.pi[:B], self.v[:B]
 
     def predict_batch(self, boards, valids):

@@ -259,6 +259,13 @@ int azg_nn_mb1d_forward(int geometry, const int8_t* boards_dev, const uint8_t* v
    Built for the no-gods geometry (n_blocks = 5, A = 162, P = 2). */
 int azg_nn_conv5_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int n_blocks, int A, int P,
                          int B, float* pi_dev, float* v_dev, void* stream);
+/* The same forward with the 2*n_blocks trunk convolutions on split-precision operands: every f32 weight / activation is carried
+   as three bf16 numbers (hi + mid + lo = 24 significant bits) and a product is the six bf16 MFMAs of weight >= 2^-24, accumulated
+   in f32 (f32-input MFMA runs at 1/16 of the bf16 rate on gfx950; outputs stay within the 1e-5 contract).  Only w[2] differs:
+   Wc = [2*n_blocks][4 column tiles][18 K chunks of 32][3 planes hi, mid, lo][64 lanes][8] bf16 with
+   element = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)], row index K = tap*64 + ci. */
+int azg_nn_conv5_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int n_blocks, int A,
+                               int P, int B, float* pi_dev, float* v_dev, void* stream);
 /* The Santorini-with-gods net (nn_version 78, SantoriniNNet.py:167-192,264-271, HeadWithMeta :42-69) in one launch.
    boards int8 [B][5][5][3] (planes 0, 1 = workers / levels, plane 2 = gods and metadata), valid u8 [B][A] -> pi, v.
    w = 19 device pointers {W0, We, be, Wd, bd, Wp, bp, Wm, bm, Whp, bhp, Wfp, bfp, Whv, bhv, Wf1, bf1, Wf2, bf2}: BatchNorm
