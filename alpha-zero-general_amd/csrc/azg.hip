@@ -13,6 +13,7 @@
 #include "game_santorini.cuh"
 #include "game_azul.cuh"
 #include "game_minivilles.cuh"
+#include "game_abalone.cuh"
 #include "selfplay.cuh"
 #include "azg_host.h"
 
@@ -35,6 +36,7 @@ extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
         else if ((game) == AZG_SANTORINI && (variant) == 1) { using G = SantoriniDev<1>; __VA_ARGS__; }   \
         else if ((game) == AZG_SANTORINI && (variant) == 11) { using G = SantoriniDev<11>; __VA_ARGS__; } \
         else if ((game) == AZG_AZUL) { using G = AzulDev; __VA_ARGS__; }                                   \
+        else if ((game) == AZG_ABALONE) { using G = AbaloneDev; __VA_ARGS__; }                             \
         else if ((game) == AZG_MINIVILLES && (variant) == 2) { using G = MinivillesDev<2>; __VA_ARGS__; } \
         else if ((game) == AZG_MINIVILLES && (variant) == 3) { using G = MinivillesDev<3>; __VA_ARGS__; } \
         else if ((game) == AZG_MINIVILLES && (variant) == 4) { using G = MinivillesDev<4>; __VA_ARGS__; } \
@@ -46,6 +48,7 @@ static int norm_variant(int game, int variant) {
     if (game == AZG_SANTORINI) return variant ? variant : 11;
     if (game == AZG_AZUL) return 2;
     if (game == AZG_MINIVILLES) return variant ? variant : 2;
+    if (game == AZG_ABALONE) return 1;
     return variant;
 }
 

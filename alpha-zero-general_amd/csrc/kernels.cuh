@@ -90,9 +90,9 @@ __global__ __launch_bounds__(64) void k_env_symmetries(const int8_t* states, con
         const size_t o = (size_t)t * max_sym + k;
         for (int i = lane_id(); i < G::S; i += 64) out_states[o * G::S + i] = G::sym_state_byte(st, c, i);
         for (int a = lane_id(); a < G::A; a += 64) {
-            const int src = G::sym_action_src(st, c, a);
-            out_pi[o * G::A + a] = pin[src];
-            out_valids[o * G::A + a] = vin[src];
+            const int src = G::sym_action_src(st, c, a);          // < 0: no action maps onto a (Abalone groups off the grid)
+            out_pi[o * G::A + a] = src >= 0 ? pin[src] : 0.f;
+            out_valids[o * G::A + a] = src >= 0 ? vin[src] : (uint8_t)0;
         }
         k++;
     }

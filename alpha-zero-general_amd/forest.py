@@ -73,7 +73,7 @@ class Forest:
         return lib().azg_forest_device_bytes(self.h)
 
     def board_shape(self):
-        return (5, 5, 3) if self.cfg.game == _lib.SANTORINI else (self.rows, self.cols)
+        return (5, 5, 3) if self.cfg.game == _lib.SANTORINI else (9, 9, 4) if self.cfg.game == _lib.ABALONE else (self.rows, self.cols)
 
     def reset(self):
         check(lib().azg_forest_reset(self.h, _stream()))

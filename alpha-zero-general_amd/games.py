@@ -75,7 +75,7 @@ class HipGame:
         return out
 
     def max_symmetries(self):
-        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles
+        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1, 4: 12}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles, Abalone
 
     def symmetries_batch(self, boards, pi, valids, max_sym=None):
         """getSymmetries for n (board int8[n,S], pi f32[n,A], valids u8[n,A]) triples on device ->
@@ -102,7 +102,7 @@ class HipGame:
         return torch.tensor([int(v)], dtype=torch.int32, device=self.device)
 
     def getBoardSize(self):
-        return (5, 5, 3) if self.GAME_ID == _lib.SANTORINI else (self.rows, self.cols)
+        return (5, 5, 3) if self.GAME_ID == _lib.SANTORINI else (9, 9, 4) if self.GAME_ID == _lib.ABALONE else (self.rows, self.cols)
 
     def getActionSize(self):
         return self.A
@@ -184,6 +184,14 @@ class MinivillesGame(HipGame):
         super().__init__(num_players, **kw)
 
 
+class AbaloneGame(HipGame):
+    """abalone/AbaloneGame.py (2 players, Belgian-Daisy layout, no dynamic komi: the shipped constants)"""
+    GAME_ID = _lib.ABALONE
+
+    def __init__(self, **kw):
+        super().__init__(1, **kw)
+
+
 def import_game(name, **kw):
     """GameSwitcher.import_game equivalent (GameSwitcher.py:15-24) for the games on the hot path."""
     if name == 'splendor':
@@ -194,4 +202,6 @@ def import_game(name, **kw):
         return AzulGame(**kw)
     if name == 'minivilles':
         return MinivillesGame(**kw)
+    if name == 'abalone':
+        return AbaloneGame(**kw)
     raise ValueError('game %r is not on the accelerated path' % name)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-enum { AZG_SPLENDOR = 0, AZG_SANTORINI = 1, AZG_AZUL = 2, AZG_MINIVILLES = 3 };
+enum { AZG_SPLENDOR = 0, AZG_SANTORINI = 1, AZG_AZUL = 2, AZG_MINIVILLES = 3, AZG_ABALONE = 4 };
 #define AZG_MAX_PLAYERS 4
 #define AZG_MAX_UNIVERSES 8
 
@@ -41,7 +41,8 @@ int azg_set_device(int device);
 
 /* GameSwitcher.import_game + Game.getBoardSize/getActionSize/getNumberOfPlayers (GameSwitcher.py:15-24, Game.py:27-42).
    variant: Splendor = NUMBER_PLAYERS (2..4, splendor/SplendorGame.py:9); Santorini = NB_GODS (1 or 11,
-   santorini/SantoriniConstants.py:19); Azul = 2 players (azul/AzulGame.py:9). */
+   santorini/SantoriniConstants.py:19); Azul = 2 players (azul/AzulGame.py:9); Minivilles = NUMBER_PLAYERS (2..4,
+   minivilles/MinivillesGame.py:9); Abalone = 2 players, Belgian-Daisy layout (abalone/AbaloneLogicNumba.py:5). */
 int azg_game_info(int game, int variant, int* state_bytes, int* action_size, int* num_players, int* rows, int* cols);
 
 /* ---- batched env step (one wavefront per state) ------------------------------------------------------------------

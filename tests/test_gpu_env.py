@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
-            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0)}
+            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0)}
 
 
 def make_game(variant):
@@ -18,6 +18,8 @@ def make_game(variant):
     assert torch.cuda.is_available()
     if name == 'azul':
         return games.AzulGame()
+    if name == 'abalone':
+        return games.AbaloneGame()
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
 
 
@@ -36,7 +38,7 @@ def test_env_vs_golden(golden_dir, variant):
     seeds = torch.from_numpy(d['seed'].astype(np.int64)).to(dev)
     act = torch.from_numpy(d['action'].astype(np.int32)).to(dev)
     nxt_state, nxt_pl = g.next_state_batch(st, pl, act, seeds)
-    det = d['seed'] != 0
+    det = (d['seed'] != 0) | (variant == 'abalone')           # Abalone's env step is deterministic for every seed
     assert det.sum() > 50
     assert np.array_equal(nxt_state.cpu().numpy()[det], d['next_state'][det])
     assert np.array_equal(nxt_pl.cpu().numpy(), d['next_player'].astype(np.int32))
@@ -99,7 +101,7 @@ def test_game_py_surface():
     assert g.stringRepresentation(b) == b.tobytes()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'splendor3', 'splendor4', 'santorini1', 'santorini11', 'azul'])
+@pytest.mark.parametrize('variant', ['splendor2', 'splendor3', 'splendor4', 'santorini1', 'santorini11', 'azul', 'abalone'])
 def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
     """Game.getSymmetries on device (azg_env_symmetries) vs the reference's own outputs (tests/golden/sym_*.npz) and, on
     states from random play, vs the oracle."""
@@ -107,9 +109,10 @@ def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
     import azg_oracle as O
     from azg_amd import games
     name, v = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
-               'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0)}[variant]
-    g = {'splendor': lambda: games.SplendorGame(v), 'santorini': lambda: games.SantoriniGame(v), 'azul': games.AzulGame}[name]()
-    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL}[name], v)
+               'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0)}[variant]
+    g = {'splendor': lambda: games.SplendorGame(v), 'santorini': lambda: games.SantoriniGame(v), 'azul': games.AzulGame,
+         'abalone': games.AbaloneGame}[name]()
+    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'abalone': O.ABALONE}[name], v)
     K = g.max_symmetries()
     path = os.path.join(golden_dir, 'sym_%s.npz' % variant)
     if os.path.exists(path):
@@ -134,8 +137,9 @@ def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
             if ply % 3 == 0:
                 c = og.getCanonicalForm(b, p)
                 states.append(c.reshape(-1).copy())
-                pis.append(rng.random(len(va)).astype(np.float32))
                 vas.append(og.getValidMoves(c, 0).astype(np.uint8))
+                # (Abalone's get_symmetries only maps the entries of valid actions: give pi the support MCTS gives it)
+                pis.append(rng.random(len(va)).astype(np.float32) * (vas[-1] if variant == 'abalone' else 1))
             b, p = og.getNextState(b, p, int(rng.choice(np.flatnonzero(va))), random_seed=31416 + ply)
             if og.getGameEnded(b, p).any():
                 break

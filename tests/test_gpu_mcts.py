@@ -10,6 +10,7 @@ from tools_args import MCTS_ARGS
 
 pytestmark = pytest.mark.gpu
 
+F4_VARIANTS = {'abalone': ('abalone', 0)}           # SURVEY.md §8 f4 games with the standard (deterministic-step) fixtures
 VARIANTS = {'splendor2': ('splendor', 2), 'splendor4': ('splendor', 4), 'santorini1': ('santorini', 1),
             'santorini11': ('santorini', 11), 'azul': ('azul', 0)}
 
@@ -20,13 +21,15 @@ class Args(dict):
 
 def make(variant):
     from azg_amd import games
-    name, v = VARIANTS[variant]
+    name, v = {**VARIANTS, **F4_VARIANTS}[variant]
     if name == 'azul':
         return games.AzulGame()
+    if name == 'abalone':
+        return games.AbaloneGame()
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
 
 
-@pytest.mark.parametrize('variant,prefix', [(v, 'mcts') for v in VARIANTS] + [(v, 'mcts800') for v in VARIANTS])
+@pytest.mark.parametrize('variant,prefix', [(v, 'mcts') for v in list(VARIANTS) + list(F4_VARIANTS)] + [(v, 'mcts800') for v in VARIANTS])
 def test_mcts_traces_vs_golden(golden_dir, variant, prefix):
     """`mcts`: 25 / 200 simulations over several argument sets; `mcts800`: the headline search size (800 simulations, the
     checkpoint's args) -- both are outputs of the reference's own MCTS.getActionProb (tools/gen_golden*.py)."""
@@ -65,7 +68,7 @@ def test_mcts_traces_vs_golden(golden_dir, variant, prefix):
         m.forest.close()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'santorini11', 'azul'])
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini11', 'azul', 'abalone'])
 def test_whole_tree_vs_oracle(variant):
     """Every node of the HIP tree equals the oracle's node with the same state key (Ns, Qs, Nsa, Qsa, Ps, Es)."""
     import torch
@@ -73,8 +76,8 @@ def test_whole_tree_vs_oracle(variant):
     from azg_amd.mcts import BatchedMCTS
     from hashnet import HashNetTorch
     g = make(variant)
-    name, v = VARIANTS[variant]
-    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL}[name], v)
+    name, v = {**VARIANTS, **F4_VARIANTS}[variant]
+    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'abalone': O.ABALONE}[name], v)
     kw = dict(MCTS_ARGS[variant])
     sims = 400
     T = 8
@@ -103,7 +106,7 @@ def test_whole_tree_vs_oracle(variant):
     m.forest.close()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'santorini1', 'azul'])
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini1', 'azul', 'abalone'])
 @pytest.mark.parametrize('small_arena', [False, True])
 def test_tree_reuse_sequence_vs_golden(golden_dir, variant, small_arena):
     """Multi-move sequence of the golden set: tree reuse across moves and fast (non-full) searches.  With a small arena

@@ -10,7 +10,7 @@ import azg_oracle as O
 
 VARIANTS = {
     'splendor2': (O.SPLENDOR, 2), 'splendor3': (O.SPLENDOR, 3), 'splendor4': (O.SPLENDOR, 4),
-    'santorini1': (O.SANTORINI, 1), 'santorini11': (O.SANTORINI, 11), 'azul': (O.AZUL, 0),
+    'santorini1': (O.SANTORINI, 1), 'santorini11': (O.SANTORINI, 11), 'azul': (O.AZUL, 0), 'abalone': (O.ABALONE, 0),
 }
 
 
@@ -75,9 +75,10 @@ def oracle_tree_digest(mc, game):
 
 
 MCTS_VARIANTS = ['splendor2', 'splendor4', 'santorini1', 'santorini11', 'azul']
+MCTS_SMALL = MCTS_VARIANTS + ['abalone']          # (no 800-simulation file for the f4 games)
 
 
-@pytest.mark.parametrize('variant,typing,prefix', [(v, t, 'mcts') for v in MCTS_VARIANTS for t in ('numpy2', 'numba')] +
+@pytest.mark.parametrize('variant,typing,prefix', [(v, t, 'mcts') for v in MCTS_SMALL for t in ('numpy2', 'numba')] +
                          [(v, 'numba', 'mcts800') for v in MCTS_VARIANTS])
 def test_mcts_traces(golden_dir, variant, typing, prefix):
     """G3: whole-tree parity (every node's Ns, Nsa, Qsa, Ps, Qs bit-exact through a SHA-256 digest); `mcts800` = the
@@ -103,7 +104,7 @@ def test_mcts_traces(golden_dir, variant, typing, prefix):
 
 
 @pytest.mark.parametrize('typing', ['numpy2', 'numba'])
-@pytest.mark.parametrize('variant', MCTS_VARIANTS)
+@pytest.mark.parametrize('variant', MCTS_SMALL)
 def test_mcts_sequence_tree_reuse(golden_dir, variant, typing):
     """G3 sequence: tree reuse across moves, fast (non-full) searches, periodic clean-up (MCTS.py:86-91)."""
     d = load(golden_dir, 'mcts_%s_%s.npz' % (variant, typing))
