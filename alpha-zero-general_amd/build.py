@@ -8,7 +8,7 @@ LIB = os.environ.get('AZG_OUT') or os.path.join(HERE, 'libazg_hip.so')          
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-Wno-pass-failed', '-I' + os.path.join(HERE, '..', 'include')]
 # Translation units of the library (compiled concurrently): the forest / env / self-play kernels with their C-ABI, and the net
-# kernels with theirs.  (Wave-uniform reads of mutable forest memory are relaxed agent-scope atomic loads -- forest.cuh
+# kernels with theirs.  (Wave-uniform reads of mutable forest memory are relaxed agent-scope atomic loads -- forest.hip.h
 # ld_agent_u32 / load_uniform -- so that the compiler cannot turn them into scalar-cache loads; the blanket alternative,
 # -mllvm -amdgpu-scalarize-global-loads=false, was tried in round 2 and miscompiled k_selfplay_advance<AzulDev>.)
 UNITS = [('azg.hip', []), ('azg_nn.hip', [])]

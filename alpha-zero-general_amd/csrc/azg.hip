@@ -9,12 +9,12 @@
 #include <vector>
 
 #include "../../include/azg.h"
-#include "game_splendor.cuh"
-#include "game_santorini.cuh"
-#include "game_azul.cuh"
-#include "game_minivilles.cuh"
-#include "game_abalone.cuh"
-#include "selfplay.cuh"
+#include "game_splendor.hip.h"
+#include "game_santorini.hip.h"
+#include "game_azul.hip.h"
+#include "game_minivilles.hip.h"
+#include "game_abalone.hip.h"
+#include "selfplay.hip.h"
 #include "azg_host.h"
 
 using namespace azg;
@@ -184,7 +184,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     while (ht < 2 * D.cap) ht <<= 1;
     D.HT = ht;
     D.U = cfg->universes > 0 ? cfg->universes : 1;
-    // record size classes (forest.cuh ForestDev::cls_q): a small action space (Splendor, A = 81) gets ONE class for all
+    // record size classes (forest.hip.h ForestDev::cls_q): a small action space (Splendor, A = 81) gets ONE class for all
     // expanded nodes -- the heap is sized for cap records of the maximum size (+ cap entry-less records) and can never
     // fragment; larger action spaces use classes of 32 entries and a heap sized for the typical record
     D.cls_q = f->A <= 96 ? f->A : 32;

@@ -1,4 +1,4 @@
-// azg_common.cuh -- wave-level primitives for the gfx950 self-play engine (one 64-lane wavefront per tree / per state).
+// azg_common.hip.h -- wave-level primitives for the gfx950 self-play engine (one 64-lane wavefront per tree / per state).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -9,10 +9,10 @@
 
 #include "../../include/azg.h"
 #include "azg_host.h"
-#include "azg_common.cuh"
-#include "nn_kernels.cuh"
-#include "nn_mb1d.cuh"
-#include "nn_conv5x5.cuh"
+#include "azg_common.hip.h"
+#include "nn_kernels.hip.h"
+#include "nn_mb1d.hip.h"
+#include "nn_conv5x5.hip.h"
 
 using namespace azg;
 
@@ -204,7 +204,7 @@ extern "C" int azg_nn_debug_phase_times(long long* out /* [4][16] */) {
 }
 #endif
 
-// ---- whole MobileNet-1d forward, any supported geometry, one launch (nn_mb1d.cuh) ----
+// ---- whole MobileNet-1d forward, any supported geometry, one launch (nn_mb1d.hip.h) ----
 //                        L   C  NS    A  P   E0   E1   E2  Q0  Q1  Q2 CO1 A0 A12 PMAX
 typedef Mb1dCfg<7, 56, 8, 81, 2, 168, 168, 168, 40, 40, 40, 56, 1, 2, 1> CfgSplendor2;
 typedef Mb1dCfg<7, 71, 8, 81, 3, 213, 213, 213, 56, 56, 56, 71, 1, 2, 1> CfgSplendor3;
@@ -246,7 +246,7 @@ extern "C" int azg_nn_mb1d_forward(int geometry, const int8_t* boards, const uin
     }
 }
 
-// ---- Santorini ResNet V88/V89 (no-gods geometry: A = 162, P = 2, 5 residual blocks), one launch (nn_conv5x5.cuh) ----
+// ---- Santorini ResNet V88/V89 (no-gods geometry: A = 162, P = 2, 5 residual blocks), one launch (nn_conv5x5.hip.h) ----
 static int conv5_launch(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A, int P, int B,
                         float* pi, float* v, void* stream, bool split) {
     if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_conv5_forward: null/empty argument");
@@ -282,7 +282,7 @@ extern "C" int azg_nn_conv5_forward_split(const int8_t* boards, const uint8_t* v
     return conv5_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, true);
 }
 
-// ---- Santorini-with-gods net V78 (10 InvertedResidual blocks, A = 1782, P = 2), one launch (nn_conv5x5.cuh) ----
+// ---- Santorini-with-gods net V78 (10 InvertedResidual blocks, A = 1782, P = 2), one launch (nn_conv5x5.hip.h) ----
 extern "C" int azg_nn_s78_forward(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A, int P,
                                   int B, float* pi, float* v, void* stream) {
     if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_s78_forward: null/empty argument");

@@ -1,4 +1,4 @@
-// forest.cuh -- struct-of-arrays MCTS forest in HBM, one 64-lane wavefront per tree.
+// forest.hip.h -- struct-of-arrays MCTS forest in HBM, one 64-lane wavefront per tree.
 //
 // What the reference does (MCTS.py): nodes_data is a dict keyed by board.tobytes() holding dense per-action arrays
 // (Ps f32[A], Qsa f64[A], Nsa i64[A]); every simulation re-plays the env step at every level and re-hashes the child
@@ -26,7 +26,7 @@
 // Numerics follow the shipped (Numba-typed) reference: UCB in f64 with f32 operands widened (MCTS.py:210-230),
 // Qsa running mean in f64, Qs in f32 scalar arithmetic (MCTS.py:178-181), no FMA contraction (-ffp-contract=off).
 #pragma once
-#include "azg_common.cuh"
+#include "azg_common.hip.h"
 
 namespace azg {
 

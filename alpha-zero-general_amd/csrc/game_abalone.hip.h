@@ -1,4 +1,4 @@
-// game_abalone.cuh -- Abalone env step on the device plugin interface: abalone/AbaloneLogicNumba.py
+// game_abalone.hip.h -- Abalone env step on the device plugin interface: abalone/AbaloneLogicNumba.py
 // (Board :166-440) as shipped: INITIAL_LAYOUT = 1 (Belgian Daisy), ENABLE_DYNAMIC_KOMI = False (:5-6).
 //
 // State int8 [9][9][4] on an axial hex grid (playable cells: 4 <= r + q <= 12): plane 0 marbles of player 0, plane 1 of player 1,
@@ -10,7 +10,7 @@
 // valid_moves is restated as a predicate of ONE action id (the reference enumerates cells, group sizes and directions with
 // early exits, :271-356), evaluated one action per lane in 54 ballots; make_move / init run on lane 0 over the LDS state.
 #pragma once
-#include "azg_common.cuh"
+#include "azg_common.hip.h"
 
 namespace azg {
 

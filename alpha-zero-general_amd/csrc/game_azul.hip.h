@@ -1,10 +1,10 @@
-// game_azul.cuh -- Azul (2 players) env step for one wavefront, state staged in LDS.
+// game_azul.hip.h -- Azul (2 players) env step for one wavefront, state staged in LDS.
 // Semantics follow azul/AzulLogicNumba.py `Board` (lines cited); state bytes = the reference's int8[23][6]:
 // scores(1) bag(1) discards(1) centre(1) factories(5) player_colours(2) player_row_numbers(2) walls(10).
 // valid_mask() is lane-parallel over the 180 actions (3 passes); make_move() (incl. round scoring and the factory
 // refill, a seeded or random draw of up to 20 tiles) is branchy integer work on 138 LDS bytes and runs on lane 0.
 #pragma once
-#include "azg_common.cuh"
+#include "azg_common.hip.h"
 
 namespace azg {
 

@@ -1,4 +1,4 @@
-// game_minivilles.cuh -- Minivilles (Machi Koro) env step on the device plugin interface:
+// game_minivilles.hip.h -- Minivilles (Machi Koro) env step on the device plugin interface:
 // minivilles/MinivillesLogicNumba.py (Board :66-372), 2-4 players.
 //
 // State int8 [18 + 20 n][2]: column 0 = current, column 1 = the state before the last "real" move (the radio-tower re-roll
@@ -7,7 +7,7 @@
 //
 // STOCHASTIC = true: make_move ignores random_seed and draws true randomness -- the dice of the next player (:232-242) and the
 // three choices of the purple cards (:49-52) -- inside MCTS simulations too (MCTS.py:238).  The forest therefore never memoises
-// an edge of this game: every descent level replays the env step with fresh uniforms of the tree's counter stream (kernels.cuh
+// an edge of this game: every descent level replays the env step with fresh uniforms of the tree's counter stream (kernels.hip.h
 // k_select), exactly like the reference, whose every traversal re-rolls.  Draws: np.random.randint(1, 6) -> 1 + floor(5 u)
 // (NumPy's upper bound is exclusive: a die shows 1..5); my_random_choice_and_normalize(mask) = searchsorted(cumsum(mask), u,
 // 'right') with u in [0, 1) = the FIRST set index, the uniform is consumed all the same.
@@ -15,7 +15,7 @@
 // The rules are a few dozen dependent scalar operations on ~100 bytes: make_move / init run on lane 0 over the LDS state
 // (lane0_make_move), the valid-move mask is one action per lane.
 #pragma once
-#include "azg_common.cuh"
+#include "azg_common.hip.h"
 
 namespace azg {
 

@@ -1,11 +1,11 @@
-// game_santorini.cuh -- Santorini 5x5 (NB_GODS = 1: no gods, 11: basic gods) env step for one wavefront.
+// game_santorini.hip.h -- Santorini 5x5 (NB_GODS = 1: no gods, 11: basic gods) env step for one wavefront.
 //
 // Semantics follow santorini/SantoriniLogicNumba.py `Board` + SantoriniConstants.py (lines cited).  State bytes are the
 // reference's int8[5][5][3] interleaved (workers, levels, gods_power).  The reference enumerates valid moves with nested
 // worker x move x build loops per god (:125-432); here every lane evaluates the SAME rules as a predicate of ONE
 // action id (worker, power, move_dir, build_dir), 64 actions per pass, and the passes' ballots are the mask words.
 #pragma once
-#include "azg_common.cuh"
+#include "azg_common.hip.h"
 
 namespace azg {
 

@@ -1,10 +1,10 @@
-// game_splendor.cuh -- Splendor (2-4 players) env step for one wavefront, state staged in LDS.
+// game_splendor.hip.h -- Splendor (2-4 players) env step for one wavefront, state staged in LDS.
 //
 // Semantics follow splendor/SplendorLogicNumba.py `Board` (line numbers cited); the byte layout of the state is the
 // reference's int8[(32+10n+n*n)][7] (copy_state :207-219).  valid_mask() is lane-parallel and branch-free (one action per lane, two
 // ballots for the 81 actions); wave_make_move() keeps the branchy rule arithmetic on the scalar unit (see below).
 #pragma once
-#include "azg_common.cuh"
+#include "azg_common.hip.h"
 #include "splendor_tables.h"
 
 namespace azg {

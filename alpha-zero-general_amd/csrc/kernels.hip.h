@@ -1,7 +1,7 @@
-// kernels.cuh -- __global__ kernels of the engine, templated on the device game (SplendorDev<n>, SantoriniDev<g>).
+// kernels.hip.h -- __global__ kernels of the engine, templated on the device game (SplendorDev<n>, SantoriniDev<g>).
 // One workgroup = one wavefront (64 threads) = one state (env kernels) or one tree (forest kernels).
 #pragma once
-#include "forest.cuh"
+#include "forest.hip.h"
 
 namespace azg {
 
@@ -328,7 +328,7 @@ struct ExpandIn {
 constexpr int AZG_HOT_WORDS = offsetof(TreeHdr, c_sims) / 4;
 #define AZG_HW(w, field) ((w)[offsetof(TreeHdr, field) / 4])
 // HOT (k_select): plain vector loads that merge into dwordx4 -- the kernel's own header stores keep the compiler from using
-// the scalar path (checked in the ISA: no s_load of the header); elsewhere agent-scope atomic loads (forest.cuh ld_agent_u32).
+// the scalar path (checked in the ISA: no s_load of the header); elsewhere agent-scope atomic loads (forest.hip.h ld_agent_u32).
 template <bool HOT>
 __device__ __forceinline__ void load_hot_header(const TreeHdr* Hp, uint32_t (&w)[AZG_HOT_WORDS]) {
     const uint32_t* p = (const uint32_t*)Hp;

@@ -1,4 +1,4 @@
-// nn_conv5x5.cuh -- the Santorini ResNet (santorini/SantoriniNNet.py nn_version 88/89: first 3x3 conv 2 -> 64 + BN + ReLU,
+// nn_conv5x5.hip.h -- the Santorini ResNet (santorini/SantoriniNNet.py nn_version 88/89: first 3x3 conv 2 -> 64 + BN + ReLU,
 // NB SimpleResBlocks :71-84 of two 3x3 convs 64 -> 64, SimpleHead policy / value heads :17-40) as ONE launch per leaf
 // batch.  A workgroup owns 8 samples = 200 board cells; the two activation tiles [200][64] f32 live in LDS, each 3x3
 // convolution is an implicit GEMM out[cell][co] = sum_{tap, ci} in[cell + tap][ci] * W[tap*64 + ci][co] on
@@ -8,8 +8,8 @@
 // the accumulators of its (at most 5) cell tiles across the three kernel rows.  The heads are a few thousand MACs per
 // sample and run on the vector ALUs.  (MIOpen's Winograd path needs 11 launches of ~100 us for the same batch.)
 #pragma once
-#include "nn_kernels.cuh"
-#include "nn_mb1d.cuh"
+#include "nn_kernels.hip.h"
+#include "nn_mb1d.hip.h"
 
 namespace azg {
 

@@ -1,4 +1,4 @@
-// nn_kernels.cuh -- fp32 policy/value net building blocks for gfx950 (the only MFMA work on the self-play path).
+// nn_kernels.hip.h -- fp32 policy/value net building blocks for gfx950 (the only MFMA work on the self-play path).
 //
 // The reference evaluates the net with ONNX Runtime / torch on the CPU, one leaf at a time or 8 at a time
 // (GenericNNetWrapper.py:94-157).  Here one lock-step round evaluates T leaves at once; the V80 network

@@ -1,5 +1,5 @@
-// nn_mb1d.cuh -- the MobileNetV3-1d policy/value net (splendor/SplendorNNet.py:259-283,397-440 for 2-4 players,
-// azul/AzulNNet.py:91-113,130-142) as ONE launch for any geometry: the generic sibling of k_v80_net (nn_kernels.cuh), which
+// nn_mb1d.hip.h -- the MobileNetV3-1d policy/value net (splendor/SplendorNNet.py:259-283,397-440 for 2-4 players,
+// azul/AzulNNet.py:91-113,130-142) as ONE launch for any geometry: the generic sibling of k_v80_net (nn_kernels.hip.h), which
 // is hand-laid-out for the 2-player Splendor shape.  Same data flow -- a workgroup owns NS samples, every activation lives
 // in LDS, all GEMMs are v_mfma_f32_16x16x4_f32 with the weight tile as the A operand (fragment order, see FRAG) and the
 // activations as the B operand read as float4 from LDS -- but tile loops instead of a fixed wave->tile map:
@@ -9,7 +9,7 @@
 // rows carry 4 floats of padding (row stride = 4 mod 8 floats: conflict-free float4 fragment reads).  The LDS is cleared
 // once at kernel start: every padding element that a K loop can reach is then a finite number times a zero weight.
 #pragma once
-#include "nn_kernels.cuh"
+#include "nn_kernels.hip.h"
 
 namespace azg {
 

@@ -1,10 +1,10 @@
-// selfplay.cuh -- Coach.executeEpisode (Coach.py:37-84) as a per-tree device state machine.
+// selfplay.hip.h -- Coach.executeEpisode (Coach.py:37-84) as a per-tree device state machine.
 // Each tree plays its own game: when its search finishes it samples the move, records the example, plays the move
 // (true-random chance via the RNG contract), detects the end of the game, emits the finished game's examples to the
 // on-device ring, restarts, canonicalises the new root and begins the next search -- no host involvement, so trees
 // run out of phase and the leaf batch for the net stays full.
 #pragma once
-#include "kernels.cuh"
+#include "kernels.hip.h"
 
 namespace azg {
 

@@ -268,7 +268,7 @@ class SplendorV80Hip(SplendorV80):
     @staticmethod
     def _frag(Wp, half_last=False):
         """zero-padded [Kp][NP] -> MFMA fragment order [NP/16][Kp/16][64 lanes][4]:
-        frag[nt][c][lane][j] = Wp[16c + 4*(lane>>4) + j][16nt + (lane&15)]  (FRAG in csrc/nn_kernels.cuh).
+        frag[nt][c][lane][j] = Wp[16c + 4*(lane>>4) + j][16nt + (lane&15)]  (FRAG in csrc/nn_kernels.hip.h).
         half_last: the last chunk holds only 8 rows of K; lane group g gets rows 16c + 2g + {0, 1} in j = 0, 1"""
         Kp, NP = Wp.shape
         assert Kp % 16 == 0 and NP % 16 == 0
@@ -526,7 +526,7 @@ class MobileNet1dHip:
         boards = boards.reshape(B, -1)
         assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda
         valids = valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)
-        if self.fused:                                  # the whole forward in one launch (nn_mb1d.cuh)
+        if self.fused:                                  # the whole forward in one launch (nn_mb1d.hip.h)
             self._lib.check(Lb.azg_nn_mb1d_forward(self.geometry, p(boards), p(valids.contiguous()), self.fused_ptrs, B,
                                                    p(self.pi), p(self.v), st))
             return self.pi[:B], self.v[:B]
@@ -621,7 +621,7 @@ class SantoriniV89:
 
 class SantoriniV89Hip:
     """SantoriniV89 (no-gods geometry: 5 residual blocks, A = 162) evaluated by the engine's one-launch implicit-GEMM kernel
-    (azg_nn_conv5_forward, csrc/nn_conv5x5.cuh) instead of 11 MIOpen convolutions + glue ops.  Wraps a SantoriniV89."""
+    (azg_nn_conv5_forward, csrc/nn_conv5x5.hip.h) instead of 11 MIOpen convolutions + glue ops.  Wraps a SantoriniV89."""
 
     def __init__(self, base, max_batch=4096, split=True):
         """split: the trunk convolutions on bf16 x 3 split-precision operands (azg_nn_conv5_forward_split: six bf16 MFMAs per
@@ -754,7 +754,7 @@ class SantoriniV78(SantoriniV89):
 
 class SantoriniV78Hip(SantoriniV89Hip):
     """SantoriniV78 (with gods: 10 InvertedResidual blocks, A = 1782) evaluated by the engine's one-launch kernel
-    (azg_nn_s78_forward, csrc/nn_conv5x5.cuh): MFMA GEMMs for the 1x1 convolutions, in-place depthwise 3x3 on the LDS tile,
+    (azg_nn_s78_forward, csrc/nn_conv5x5.hip.h): MFMA GEMMs for the 1x1 convolutions, in-place depthwise 3x3 on the LDS tile,
     heads on the vector ALUs.  Wraps a SantoriniV78."""
 
     def __init__(self, base, max_batch=4096):

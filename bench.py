@@ -182,9 +182,9 @@ def build_engine(a, game_key, T, rank, dev):
         net = getattr(_nn, og['net']).from_npz(os.path.join(ROOT, 'tests', 'golden', og['weights']), device=dev, dtype=dtype, **nkw)
         label, weights = og['label'], og['weights']
         if net_kind == 'hip' and og['net'] in ('SplendorV80', 'AzulV84') and a.net_dtype == 'fp32':
-            net = _nn.MobileNet1dHip(net, max_batch=T // a.groups)        # the whole forward in one launch (nn_mb1d.cuh)
+            net = _nn.MobileNet1dHip(net, max_batch=T // a.groups)        # the whole forward in one launch (nn_mb1d.hip.h)
         elif net_kind == 'hip' and game_key in ('santorini1', 'santorini11') and a.net_dtype == 'fp32':
-            # the ResNet / the with-gods MobileNet in one launch (nn_conv5x5.cuh)
+            # the ResNet / the with-gods MobileNet in one launch (nn_conv5x5.hip.h)
             net = (_nn.SantoriniV89Hip if game_key == 'santorini1' else _nn.SantoriniV78Hip)(net, max_batch=T // a.groups)
         else:
             net_kind = 'torch'

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Audit: which kernels of the forest unit would read GLOBAL memory through the scalar data cache?  Compiles azg.hip twice (default
 # flags / -amdgpu-scalarize-global-loads=false) and lists the kernels whose s_load count differs -- every such kernel reads some
-# wave-uniform global word with an s_load.  Mutable forest memory must not show up here (forest.cuh ld_agent_u32).
+# wave-uniform global word with an s_load.  Mutable forest memory must not show up here (forest.hip.h ld_agent_u32).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
