@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libazg_oracle.so')
 
-SPLENDOR, SANTORINI, AZUL, MINIVILLES, ABALONE = 0, 1, 2, 3, 4
+SPLENDOR, SANTORINI, AZUL, MINIVILLES, ABALONE, TLP = 0, 1, 2, 3, 4, 5
 MAXP = 4
 
 
@@ -67,6 +67,7 @@ def lib():
         L.azo_known_start.argtypes = [C.POINTER(Game), i8p, C.c_int, C.c_int]
         L.azo_canonical.argtypes = [C.POINTER(Game), i8p, C.c_int, i8p]
         L.azo_symmetries.argtypes = [C.POINTER(Game), i8p, f32p, u8p, i8p, f32p, u8p, C.c_int]
+        L.azo_symmetries_rng.argtypes = [C.POINTER(Game), i8p, f32p, u8p, i8p, f32p, u8p, C.c_int, C.POINTER(Rng)]
         L.azo_rng_u01.restype = C.c_double
         L.azo_rng_u01.argtypes = [C.POINTER(Rng)]
         L.azo_rng_raw.restype = C.c_uint64
@@ -192,14 +193,17 @@ class OracleGame:
         lib().azo_canonical(C.byref(self.g), _p(b), int(player), _p(out))
         return out
 
-    def getSymmetries(self, board, pi, valids, max_sym=16):
+    def getSymmetries(self, board, pi, valids, max_sym=16, rng=None):
         b = np.ascontiguousarray(board, dtype=np.int8)
         pi = np.ascontiguousarray(pi, dtype=np.float32)
         va = np.ascontiguousarray(valids, dtype=np.uint8)
         os_ = np.zeros((max_sym, self.S), dtype=np.int8)
         op = np.zeros((max_sym, self.A), dtype=np.float32)
         ov = np.zeros((max_sym, self.A), dtype=np.uint8)
-        k = lib().azo_symmetries(C.byref(self.g), _p(b), _p(pi), _p(va), _p(os_), _p(op), _p(ov), max_sym)
+        if rng is not None:
+            k = lib().azo_symmetries_rng(C.byref(self.g), _p(b), _p(pi), _p(va), _p(os_), _p(op), _p(ov), max_sym, C.byref(rng))
+        else:
+            k = lib().azo_symmetries(C.byref(self.g), _p(b), _p(pi), _p(va), _p(os_), _p(op), _p(ov), max_sym)
         return [(os_[i].reshape(self.shape), op[i], ov[i].astype(bool)) for i in range(k)]
 
     def stringRepresentation(self, board):

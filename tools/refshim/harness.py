@@ -37,12 +37,12 @@ _tmp_roots = []
 def _purge_modules():
     for name in list(sys.modules):
         root = name.split('.')[0]
-        if root in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'MCTS', 'Game', 'Coach', 'Arena', 'utils', 'GameSwitcher',
+        if root in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'MCTS', 'Game', 'Coach', 'Arena', 'utils', 'GameSwitcher',
                     'NeuralNet'):
             del sys.modules[name]
 
 
-def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=1, minivilles_players=2):
+def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=1, minivilles_players=2, tlp_players=3):
     """Import the reference from a temp copy with the requested source-level variants.
     Returns a dict of modules."""
     tmp = tempfile.mkdtemp(prefix='azg_ref_')
@@ -50,7 +50,7 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     for name in os.listdir(REFERENCE):
         src = os.path.join(REFERENCE, name)
         if os.path.isdir(src):
-            if name in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone'):
+            if name in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince'):
                 shutil.copytree(src, os.path.join(tmp, name),
                                 ignore=shutil.ignore_patterns('*.pt', '*.gif', '*.jpg', '*.png', '*.mp4', '*.csv',
                                                               '__pycache__'))
@@ -67,6 +67,7 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     sub('santorini/SantoriniConstants.py', 'NB_GODS = 11', 'NB_GODS = %d' % santorini_gods)
     sub('santorini/SantoriniLogicNumba.py', 'INIT_METHOD = 1', 'INIT_METHOD = %d' % santorini_init_method)
     sub('minivilles/MinivillesGame.py', 'NUMBER_PLAYERS = 2', 'NUMBER_PLAYERS = %d' % minivilles_players)
+    sub('thelittleprince/TLPGame.py', 'NUMBER_PLAYERS = 3', 'NUMBER_PLAYERS = %d' % tlp_players)
 
     _purge_modules()
     sys.dont_write_bytecode = True
@@ -107,6 +108,12 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     except Exception as e:  # pragma: no cover
         mods['AbaloneGame'] = None
         mods['abalone_error'] = e
+    try:
+        mods['TLPGame'] = importlib.import_module('thelittleprince.TLPGame')
+        mods['TLPLogicNumba'] = importlib.import_module('thelittleprince.TLPLogicNumba')
+    except Exception as e:  # pragma: no cover
+        mods['TLPGame'] = None
+        mods['tlp_error'] = e
     mods['MCTS'] = importlib.import_module('MCTS')
     mods['utils'] = importlib.import_module('utils')
     return mods
@@ -177,13 +184,20 @@ class CounterRandom:
         v = lo + int(self.random() * (hi - lo))
         return min(v, hi - 1)
 
+    def shuffle(self, arr):
+        """np.random.shuffle as the contract defines it: Fisher-Yates from the top, j = randint(0, i + 1) for i = n-1 .. 1
+        (nothing is drawn for fewer than two elements)"""
+        for i in range(len(arr) - 1, 0, -1):
+            j = self.randint(0, i + 1)
+            arr[i], arr[j] = arr[j], arr[i]
+
     def __enter__(self):
-        self._orig = (np.random.random, np.random.randint)
-        np.random.random, np.random.randint = self.random, self.randint
+        self._orig = (np.random.random, np.random.randint, np.random.shuffle)
+        np.random.random, np.random.randint, np.random.shuffle = self.random, self.randint, self.shuffle
         return self
 
     def __exit__(self, *a):
-        np.random.random, np.random.randint = self._orig
+        np.random.random, np.random.randint, np.random.shuffle = self._orig
 
 
 class HashNet:
