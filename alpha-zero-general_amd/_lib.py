@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # AZG_LIB: A/B-test another build of the same library (tools/ab_bench.sh); never a different implementation
 LIB_PATH = os.environ.get('AZG_LIB') or os.path.join(HERE, 'libazg_hip.so')
 
-SPLENDOR, SANTORINI, AZUL, MINIVILLES, ABALONE = 0, 1, 2, 3, 4
+SPLENDOR, SANTORINI, AZUL, MINIVILLES, ABALONE, TLP = 0, 1, 2, 3, 4, 5
 
 
 class ForestCfg(C.Structure):
@@ -35,7 +35,7 @@ _lib = None
 
 EXPORTS = [
     'azg_last_error', 'azg_version', 'azg_device_count', 'azg_set_device', 'azg_game_info', 'azg_env_valid_moves',
-    'azg_env_next_state', 'azg_env_game_ended', 'azg_env_canonical', 'azg_env_init_boards', 'azg_env_symmetries', 'azg_forest_create',
+    'azg_env_next_state', 'azg_env_game_ended', 'azg_env_canonical', 'azg_env_init_boards', 'azg_env_symmetries', 'azg_env_symmetries_ex', 'azg_forest_create',
     'azg_forest_destroy', 'azg_forest_device_bytes', 'azg_forest_reset', 'azg_forest_begin_search',
     'azg_forest_select', 'azg_forest_select_fused', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
     'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_forest_validate', 'azg_selfplay_start', 'azg_selfplay_start_ex', 'azg_selfplay_advance', 'azg_selfplay_active',
@@ -63,6 +63,7 @@ def lib():
     L.azg_env_canonical.argtypes = [i, i, vp, vp, i, vp, vp]
     L.azg_env_init_boards.argtypes = [i, i, i, vp, u64, u64, vp, vp]
     L.azg_env_symmetries.argtypes = [i, i, vp, vp, vp, i, i, vp, vp, vp, vp, vp]
+    L.azg_env_symmetries_ex.argtypes = [i, i, vp, vp, vp, i, i, vp, vp, vp, vp, u64, u64, vp]
     L.azg_forest_create.argtypes = [C.POINTER(ForestCfg), C.POINTER(vp)]
     L.azg_forest_destroy.argtypes = [vp]
     L.azg_forest_device_bytes.restype = C.c_size_t

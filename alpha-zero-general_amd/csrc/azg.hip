@@ -14,6 +14,7 @@
 #include "game_azul.hip.h"
 #include "game_minivilles.hip.h"
 #include "game_abalone.hip.h"
+#include "game_tlp.hip.h"
 #include "selfplay.hip.h"
 #include "azg_host.h"
 
@@ -40,6 +41,8 @@ extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
         else if ((game) == AZG_MINIVILLES && (variant) == 2) { using G = MinivillesDev<2>; __VA_ARGS__; } \
         else if ((game) == AZG_MINIVILLES && (variant) == 3) { using G = MinivillesDev<3>; __VA_ARGS__; } \
         else if ((game) == AZG_MINIVILLES && (variant) == 4) { using G = MinivillesDev<4>; __VA_ARGS__; } \
+        else if ((game) == AZG_TLP && (variant) == 3) { using G = TLPDev<3>; __VA_ARGS__; }               \
+        else if ((game) == AZG_TLP && (variant) == 4) { using G = TLPDev<4>; __VA_ARGS__; }               \
         else return fail("unsupported game/variant");                                              \
     } while (0)
 
@@ -49,6 +52,7 @@ static int norm_variant(int game, int variant) {
     if (game == AZG_AZUL) return 2;
     if (game == AZG_MINIVILLES) return variant ? variant : 2;
     if (game == AZG_ABALONE) return 1;
+    if (game == AZG_TLP) return variant ? variant : 3;
     return variant;
 }
 
@@ -116,17 +120,29 @@ extern "C" int azg_env_init_boards(int game, int variant, int n, int8_t* out_sta
     return 0;
 }
 
-extern "C" int azg_env_symmetries(int game, int variant, const int8_t* states, const float* pi, const uint8_t* valids, int n,
-                                  int max_sym, int8_t* out_states, float* out_pi, uint8_t* out_valids, int32_t* out_count,
-                                  void* stream) {
+extern "C" int azg_env_symmetries_ex(int game, int variant, const int8_t* states, const float* pi, const uint8_t* valids, int n,
+                                     int max_sym, int8_t* out_states, float* out_pi, uint8_t* out_valids, int32_t* out_count,
+                                     uint64_t rng_seed, uint64_t stream0, void* stream) {
     if (n <= 0) return 0;
     if (!states || !pi || !valids || !out_states || !out_pi || !out_valids || !out_count || max_sym <= 0)
         return fail("azg_env_symmetries: null/empty argument");
     variant = norm_variant(game, variant);
-    AZG_DISPATCH(game, variant, k_env_symmetries<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(
-                                    states, pi, valids, n, max_sym, out_states, out_pi, out_valids, out_count));
+    AZG_DISPATCH(game, variant, {
+        if constexpr (G::RANDOM_SYM)
+            k_env_symmetries_random<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(states, pi, valids, n, max_sym, out_states,
+                                                                                     out_pi, out_valids, out_count, rng_seed, stream0);
+        else
+            k_env_symmetries<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(states, pi, valids, n, max_sym, out_states, out_pi,
+                                                                              out_valids, out_count);
+    });
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+extern "C" int azg_env_symmetries(int game, int variant, const int8_t* states, const float* pi, const uint8_t* valids, int n,
+                                  int max_sym, int8_t* out_states, float* out_pi, uint8_t* out_valids, int32_t* out_count,
+                                  void* stream) {
+    return azg_env_symmetries_ex(game, variant, states, pi, valids, n, max_sym, out_states, out_pi, out_valids, out_count, 0, 0, stream);
 }
 
 // ---- forest ---------------------------------------------------------------------------------------------------------

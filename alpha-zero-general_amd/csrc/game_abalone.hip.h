@@ -22,6 +22,7 @@ struct AbaloneDev {
     static constexpr int A = 3402;
     static constexpr int AW = (A + 63) / 64;
     static constexpr bool STOCHASTIC = false;
+    static constexpr bool RANDOM_SYM = false;   // get_symmetries draws no randomness
 
     __device__ static __forceinline__ int dr(int d) { return d == 1 || d == 2 ? 1 : (d == 4 || d == 5 ? -1 : 0); }
     __device__ static __forceinline__ int dq(int d) { return d == 0 || d == 5 ? 1 : (d == 2 || d == 3 ? -1 : 0); }      // DIRECTIONS :58-65

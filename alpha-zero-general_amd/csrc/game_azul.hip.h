@@ -10,6 +10,7 @@ namespace azg {
 
 struct AzulDev {
     static constexpr bool STOCHASTIC = false;   // the env step is a function of (state, action, random_seed): edges are memoised
+    static constexpr bool RANDOM_SYM = false;   // get_symmetries draws no randomness
     static constexpr int P = 2;
     static constexpr int ROWS = 23, COLS = 6;
     static constexpr int S = 138;

@@ -28,6 +28,7 @@ struct MinivillesDev {
     static constexpr int A = 21;
     static constexpr int AW = 1;
     static constexpr bool STOCHASTIC = true;
+    static constexpr bool RANDOM_SYM = false;   // get_symmetries draws no randomness
     enum { CHAMPS, FERME, BOULANGERIE, CAFE, SUPERETTE, FORET, STADE, AFFAIRES, CHAINE, FROMAGERIE, MEUBLES, MINE, RESTAURANT,
            VERGER, MARCHE };
     enum { GARE, CENTRECOM, RADIO, PARC };

@@ -12,6 +12,7 @@ namespace azg {
 template <int NB>
 struct SantoriniDev {
     static constexpr bool STOCHASTIC = false;   // the env step is a function of (state, action, random_seed): edges are memoised
+    static constexpr bool RANDOM_SYM = false;   // get_symmetries draws no randomness
     static constexpr int P = 2;
     static constexpr int ROWS = 25, COLS = 3;
     static constexpr int S = 75;

@@ -12,6 +12,7 @@ namespace azg {
 template <int NP>
 struct SplendorDev {
     static constexpr bool STOCHASTIC = false;   // the env step is a function of (state, action, random_seed): edges are memoised
+    static constexpr bool RANDOM_SYM = false;   // get_symmetries draws no randomness
     static constexpr int P = NP;
     static constexpr int NN = NP + 1;                       // nobles in play  :145
     static constexpr int ROWS = 32 + 10 * NP + NP * NP;     // observation_size :90-92

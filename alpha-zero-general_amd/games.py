@@ -75,11 +75,12 @@ class HipGame:
         return out
 
     def max_symmetries(self):
-        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1, 4: 12}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles, Abalone
+        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1, 4: 12, 5: 2 * self.P + 1}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles, Abalone, TLP
 
-    def symmetries_batch(self, boards, pi, valids, max_sym=None):
+    def symmetries_batch(self, boards, pi, valids, max_sym=None, rng_seed=None, stream0=0):
         """getSymmetries for n (board int8[n,S], pi f32[n,A], valids u8[n,A]) triples on device ->
-        (boards int8[n,K,S], pi f32[n,K,A], valids u8[n,K,A], count i32[n]), K = max_sym; rows >= count[t] are unspecified"""
+        (boards int8[n,K,S], pi f32[n,K,A], valids u8[n,K,A], count i32[n]), K = max_sym; rows >= count[t] are unspecified.
+        Games whose symmetries are random (The Little Prince shuffles) draw triple t from stream (rng_seed, stream0 + t)."""
         n = boards.shape[0]
         K = max_sym or self.max_symmetries()
         boards = boards.reshape(n, -1)
@@ -90,8 +91,8 @@ class HipGame:
         op = torch.empty((n, K, self.A), dtype=torch.float32, device=self.device)
         ov = torch.empty((n, K, self.A), dtype=torch.uint8, device=self.device)
         cnt = torch.zeros((n,), dtype=torch.int32, device=self.device)
-        check(lib().azg_env_symmetries(self.GAME_ID, self.variant, _ptr(boards), _ptr(pi), _ptr(valids), n, K, _ptr(ob),
-                                       _ptr(op), _ptr(ov), _ptr(cnt), _stream()))
+        check(lib().azg_env_symmetries_ex(self.GAME_ID, self.variant, _ptr(boards), _ptr(pi), _ptr(valids), n, K, _ptr(ob), _ptr(op),
+                                          _ptr(ov), _ptr(cnt), self.rng_seed if rng_seed is None else rng_seed, stream0, _stream()))
         return ob, op, ov, cnt
 
     # ---- Game.py API (numpy in / numpy out, one board) ----
@@ -144,7 +145,8 @@ class HipGame:
         b = self._dev(board).reshape(1, -1)
         p = torch.as_tensor(np.asarray(pi, dtype=np.float32)).reshape(1, -1).to(self.device)
         v = torch.as_tensor(np.asarray(valid_actions).astype(np.uint8)).reshape(1, -1).to(self.device)
-        ob, op, ov, cnt = self.symmetries_batch(b, p, v)
+        self._stream_ctr += 1
+        ob, op, ov, cnt = self.symmetries_batch(b, p, v, stream0=(1 << 41) + self._stream_ctr)
         k = int(cnt[0])
         shape = tuple(self.getBoardSize())
         ob, op, ov = ob[0, :k].cpu().numpy(), op[0, :k].cpu().numpy(), ov[0, :k].cpu().numpy().astype(bool)
@@ -192,6 +194,15 @@ class AbaloneGame(HipGame):
         super().__init__(1, **kw)
 
 
+class TLPGame(HipGame):
+    """thelittleprince/TLPGame.py (NUMBER_PLAYERS 3 or 4 here; the reference also allows 5).  The market refill inside the env step
+    and getSymmetries draw true randomness (TLPLogicNumba.py:366-392, 177-272): both use the engine's counter RNG streams."""
+    GAME_ID = _lib.TLP
+
+    def __init__(self, num_players=3, **kw):
+        super().__init__(num_players, **kw)
+
+
 def import_game(name, **kw):
     """GameSwitcher.import_game equivalent (GameSwitcher.py:15-24) for the games on the hot path."""
     if name == 'splendor':
@@ -204,4 +215,6 @@ def import_game(name, **kw):
         return MinivillesGame(**kw)
     if name == 'abalone':
         return AbaloneGame(**kw)
+    if name == 'thelittleprince':
+        return TLPGame(**kw)
     raise ValueError('game %r is not on the accelerated path' % name)

@@ -186,7 +186,11 @@ class SelfPlayEngine:
         if not symmetries or ex[0].shape[0] == 0:
             return ex
         boards, pi, z, valids, q, meta = ex
-        ob, op, ov, cnt = self.game.symmetries_batch(boards.contiguous(), pi.contiguous(), valids.contiguous())
+        # games with random symmetries (The Little Prince) draw record t from stream (game.rng_seed, 2^42 + records drained so far + t)
+        self._sym_stream = getattr(self, '_sym_stream', 0)
+        ob, op, ov, cnt = self.game.symmetries_batch(boards.contiguous(), pi.contiguous(), valids.contiguous(),
+                                                     stream0=(1 << 42) + self._sym_stream)
+        self._sym_stream += int(boards.shape[0])
         K = ob.shape[1]
         keep = (torch.arange(K, device=cnt.device)[None, :] < cnt[:, None]).reshape(-1)
         rep = torch.repeat_interleave(torch.arange(boards.shape[0], device=cnt.device), cnt.to(torch.int64))

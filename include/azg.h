@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-enum { AZG_SPLENDOR = 0, AZG_SANTORINI = 1, AZG_AZUL = 2, AZG_MINIVILLES = 3, AZG_ABALONE = 4 };
+enum { AZG_SPLENDOR = 0, AZG_SANTORINI = 1, AZG_AZUL = 2, AZG_MINIVILLES = 3, AZG_ABALONE = 4, AZG_TLP = 5 };
 #define AZG_MAX_PLAYERS 4
 #define AZG_MAX_UNIVERSES 8
 
@@ -74,6 +74,13 @@ int azg_env_init_boards(int game, int variant, int n, int8_t* out_states_dev, ui
 int azg_env_symmetries(int game, int variant, const int8_t* states_dev, const float* pi_dev, const uint8_t* valids_dev, int n,
                        int max_sym, int8_t* out_states_dev, float* out_pi_dev, uint8_t* out_valids_dev,
                        int32_t* out_count_dev, void* stream);
+/* The same with a random source, for games whose get_symmetries is itself random (The Little Prince, TLPLogicNumba.py:177-272:
+   np.random.shuffle of players / market cards / planet slots, duplicate states dropped; <= 2P + 1 forms): triple t draws from
+   the RNG contract's stream (rng_seed, stream0 + t), counter from 0, with shuffle(x) = Fisher-Yates from the top
+   (j = floor(u (i + 1)) for i = len-1 .. 1).  Other games ignore the two arguments; azg_env_symmetries = (0, 0). */
+int azg_env_symmetries_ex(int game, int variant, const int8_t* states_dev, const float* pi_dev, const uint8_t* valids_dev, int n,
+                          int max_sym, int8_t* out_states_dev, float* out_pi_dev, uint8_t* out_valids_dev,
+                          int32_t* out_count_dev, uint64_t rng_seed, uint64_t stream0, void* stream);
 
 /* ---- forest: T independent MCTS trees, one wavefront per tree ----------------------------------------------------
    Replaces MCTS (MCTS.py:19-261) for a batch of trees and, in self-play mode, Coach.executeEpisode (Coach.py:37-84). */
