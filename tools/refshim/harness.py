@@ -37,7 +37,7 @@ _tmp_roots = []
 def _purge_modules():
     for name in list(sys.modules):
         root = name.split('.')[0]
-        if root in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'MCTS', 'Game', 'Coach', 'Arena', 'utils', 'GameSwitcher',
+        if root in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'botanik', 'MCTS', 'Game', 'Coach', 'Arena', 'utils', 'GameSwitcher',
                     'NeuralNet'):
             del sys.modules[name]
 
@@ -50,7 +50,7 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     for name in os.listdir(REFERENCE):
         src = os.path.join(REFERENCE, name)
         if os.path.isdir(src):
-            if name in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince'):
+            if name in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'botanik'):
                 shutil.copytree(src, os.path.join(tmp, name),
                                 ignore=shutil.ignore_patterns('*.pt', '*.gif', '*.jpg', '*.png', '*.mp4', '*.csv',
                                                               '__pycache__'))
@@ -114,6 +114,12 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     except Exception as e:  # pragma: no cover
         mods['TLPGame'] = None
         mods['tlp_error'] = e
+    try:
+        mods['BotanikGame'] = importlib.import_module('botanik.BotanikGame')
+        mods['BotanikLogicNumba'] = importlib.import_module('botanik.BotanikLogicNumba')
+    except Exception as e:  # pragma: no cover
+        mods['BotanikGame'] = None
+        mods['botanik_error'] = e
     mods['MCTS'] = importlib.import_module('MCTS')
     mods['utils'] = importlib.import_module('utils')
     return mods
