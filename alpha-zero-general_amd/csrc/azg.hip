@@ -15,6 +15,7 @@
 #include "game_minivilles.hip.h"
 #include "game_abalone.hip.h"
 #include "game_tlp.hip.h"
+#include "game_botanik.hip.h"
 #include "selfplay.hip.h"
 #include "azg_host.h"
 
@@ -43,6 +44,7 @@ extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
         else if ((game) == AZG_MINIVILLES && (variant) == 4) { using G = MinivillesDev<4>; __VA_ARGS__; } \
         else if ((game) == AZG_TLP && (variant) == 3) { using G = TLPDev<3>; __VA_ARGS__; }               \
         else if ((game) == AZG_TLP && (variant) == 4) { using G = TLPDev<4>; __VA_ARGS__; }               \
+        else if ((game) == AZG_BOTANIK) { using G = BotanikDev; __VA_ARGS__; }                             \
         else return fail("unsupported game/variant");                                              \
     } while (0)
 
@@ -53,6 +55,7 @@ static int norm_variant(int game, int variant) {
     if (game == AZG_MINIVILLES) return variant ? variant : 2;
     if (game == AZG_ABALONE) return 1;
     if (game == AZG_TLP) return variant ? variant : 3;
+    if (game == AZG_BOTANIK) return 2;
     return variant;
 }
 
@@ -129,7 +132,7 @@ extern "C" int azg_env_symmetries_ex(int game, int variant, const int8_t* states
     variant = norm_variant(game, variant);
     AZG_DISPATCH(game, variant, {
         if constexpr (G::RANDOM_SYM)
-            k_env_symmetries_random<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(states, pi, valids, n, max_sym, out_states,
+            k_env_symmetries_built<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(states, pi, valids, n, max_sym, out_states,
                                                                                      out_pi, out_valids, out_count, rng_seed, stream0);
         else
             k_env_symmetries<G><<<dim3(n), dim3(64), 0, (hipStream_t)stream>>>(states, pi, valids, n, max_sym, out_states, out_pi,

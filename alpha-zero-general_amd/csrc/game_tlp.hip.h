@@ -31,7 +31,8 @@ struct TLPDev {
     static constexpr int A = NP * NP;
     static constexpr int AW = 1;
     static constexpr bool STOCHASTIC = true;
-    static constexpr bool RANDOM_SYM = true;
+    static constexpr bool RANDOM_SYM = true;      // symmetric forms are built by lane 0 (k_env_symmetries_built) and draw randomness
+    static constexpr bool SYM_DEDUP = true;       // _add_to_list_no_duplicate :239-244
     enum { FACE_DOWN, BAOBAB, VOLCANO, SUNSET, ROSE, LAMPPOST, BOX, BIG_STAR, FOX, ELEPHANT, SNAKE, SHEEP_WHITE, SHEEP_GREY,
            SHEEP_BROWN, CARD_TYPE };
     enum { NONE, VAIN_MAN, GEOGRAPHER, ASTRONOMER, KING, LAMPLIGHTER, HUNTER, DRUNKARD, BUSINESSMAN_W, BUSINESSMAN_G, BUSINESSMAN_B,
@@ -298,6 +299,19 @@ struct TLPDev {
                 shuffle(rng, sh, len);
                 for (int i = 0; i < len; i++) row_src[R_CARDS + 16 * p + sh[i]] = (int16_t)(R_CARDS + 16 * p + list[i]);
             }
+    }
+    // lane 0: `cand` (a copy of the input state) becomes form c
+    __device__ static bool sym_build(const int8_t* st, int c, int8_t* cand, int16_t* act_src, Rng& rng) {
+        int16_t row_src[ROWS];
+        if (c == 0) {
+            for (int a = 0; a < A; a++) act_src[a] = (int16_t)a;
+            return true;
+        }
+        sym_random_maps(st, c, row_src, act_src, rng);
+        for (int r = 0; r < ROWS; r++)
+            if (row_src[r] != r)
+                for (int k = 0; k < COLS; k++) cand[r * COLS + k] = st[row_src[r] * COLS + k];
+        return true;
     }
     // (the deterministic interface is unused: k_env_symmetries takes the RANDOM_SYM path)
     __device__ static __forceinline__ bool sym_exists(const int8_t*, int c) { return c == 0; }

@@ -99,18 +99,21 @@ __global__ __launch_bounds__(64) void k_env_symmetries(const int8_t* states, con
     if (lane_id() == 0) out_count[t] = k;
 }
 
-// Games whose get_symmetries is itself random (G::RANDOM_SYM: The Little Prince shuffles players, market cards and planet slots
-// and drops duplicate states): one wave per input triple; lane 0 draws the shuffles of candidate c from the counter stream
-// (rng_seed, stream0 + t) into a row map and an action map, all lanes apply them; a form is kept when its state differs from every
-// form kept so far (kept forms stay in LDS for the comparison).
+// Games whose symmetric forms are BUILT by lane 0 (G::RANDOM_SYM): get_symmetries is itself random (The Little Prince shuffles
+// players, market cards and planet slots and drops duplicate states) or is a set of card-level edits rather than a byte map
+// (Botanik).  One wave per input triple; all lanes copy the state into the candidate buffer, lane 0 turns it into form c
+// (G::sym_build: state edits + the action map out[a] = in[act_src[a]], drawing from the counter stream (rng_seed, stream0 + t) if the
+// game shuffles), all lanes write the form out.  With G::SYM_DEDUP a form is kept only when its state differs from every form kept so
+// far (the kept forms stay in LDS for the comparison).
 template <class G>
-__global__ __launch_bounds__(64) void k_env_symmetries_random(const int8_t* states, const float* pi, const uint8_t* valids, int n,
-                                                               int max_sym, int8_t* out_states, float* out_pi, uint8_t* out_valids,
-                                                               int32_t* out_count, uint64_t rng_seed, uint64_t stream0) {
+__global__ __launch_bounds__(64) void k_env_symmetries_built(const int8_t* states, const float* pi, const uint8_t* valids, int n,
+                                                              int max_sym, int8_t* out_states, float* out_pi, uint8_t* out_valids,
+                                                              int32_t* out_count, uint64_t rng_seed, uint64_t stream0) {
+    constexpr int NKEEP = G::SYM_DEDUP ? G::NSYM_CAND : 1;
     __shared__ __attribute__((aligned(16))) int8_t st[G::SP];
-    __shared__ __attribute__((aligned(16))) int8_t kept[G::NSYM_CAND][G::SP];
-    __shared__ int16_t row_src[G::ROWS];
+    __shared__ __attribute__((aligned(16))) int8_t kept[NKEEP][G::SP];
     __shared__ int16_t act_src[G::A];
+    __shared__ int exists_s;
     const int t = blockIdx.x;
     if (t >= n) return;
     Forest<G>::load_state_unpadded(st, states + (size_t)t * G::S);
@@ -119,37 +122,27 @@ __global__ __launch_bounds__(64) void k_env_symmetries_random(const int8_t* stat
     Rng rng{rng_seed, stream0 + (uint64_t)t, 0};
     int k = 0;
     for (int c = 0; c < G::NSYM_CAND; c++) {
-        if (lane_id() == 0) {
-            if (c == 0) {
-                for (int r = 0; r < G::ROWS; r++) row_src[r] = (int16_t)r;
-                for (int a = 0; a < G::A; a++) act_src[a] = (int16_t)a;
-            } else {
-                G::sym_random_maps(st, c, row_src, act_src, rng);
-            }
-        }
+        int8_t* cand = kept[G::SYM_DEDUP ? (k < NKEEP ? k : NKEEP - 1) : 0];
+        for (int i = lane_id(); i < G::S; i += 64) cand[i] = st[i];
         __syncthreads();
-        if (k < max_sym) {
-            int8_t* cand = kept[k];
-            for (int i = lane_id(); i < G::S; i += 64) {
-                const int r = i / G::COLS;
-                cand[i] = st[row_src[r] * G::COLS + (i - r * G::COLS)];
-            }
-            __syncthreads();
-            bool dup = false;
-            for (int e = 0; e < k && !dup; e++) {
+        if (lane_id() == 0) exists_s = G::sym_build(st, c, cand, act_src, rng) ? 1 : 0;     // (draws even when the form is dropped below)
+        __syncthreads();
+        bool keep = exists_s != 0 && k < max_sym;
+        if (keep && G::SYM_DEDUP) {
+            for (int e = 0; e < k && keep; e++) {
                 bool diff = false;
                 for (int i = lane_id(); i < G::S; i += 64) diff |= kept[e][i] != cand[i];
-                dup = __ballot(diff) == 0;
+                keep = __ballot(diff) != 0;
             }
-            if (!dup) {
-                const size_t o = (size_t)t * max_sym + k;
-                for (int i = lane_id(); i < G::S; i += 64) out_states[o * G::S + i] = cand[i];
-                for (int a = lane_id(); a < G::A; a += 64) {
-                    out_pi[o * G::A + a] = pin[act_src[a]];
-                    out_valids[o * G::A + a] = vin[act_src[a]];
-                }
-                k++;
+        }
+        if (keep) {
+            const size_t o = (size_t)t * max_sym + k;
+            for (int i = lane_id(); i < G::S; i += 64) out_states[o * G::S + i] = cand[i];
+            for (int a = lane_id(); a < G::A; a += 64) {
+                out_pi[o * G::A + a] = pin[act_src[a]];
+                out_valids[o * G::A + a] = vin[act_src[a]];
             }
+            k++;
         }
         __syncthreads();
     }

@@ -73,7 +73,8 @@ class Forest:
         return lib().azg_forest_device_bytes(self.h)
 
     def board_shape(self):
-        return (5, 5, 3) if self.cfg.game == _lib.SANTORINI else (9, 9, 4) if self.cfg.game == _lib.ABALONE else (self.rows, self.cols)
+        g = self.cfg.game
+        return (5, 5, 3) if g == _lib.SANTORINI else (9, 9, 4) if g == _lib.ABALONE else (66, 5, 7) if g == _lib.BOTANIK else (self.rows, self.cols)
 
     def reset(self):
         check(lib().azg_forest_reset(self.h, _stream()))

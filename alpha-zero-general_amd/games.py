@@ -75,7 +75,7 @@ class HipGame:
         return out
 
     def max_symmetries(self):
-        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1, 4: 12, 5: 2 * self.P + 1}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles, Abalone, TLP
+        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1, 4: 12, 5: 2 * self.P + 1, 6: 14}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles, Abalone, TLP, Botanik
 
     def symmetries_batch(self, boards, pi, valids, max_sym=None, rng_seed=None, stream0=0):
         """getSymmetries for n (board int8[n,S], pi f32[n,A], valids u8[n,A]) triples on device ->
@@ -103,7 +103,8 @@ class HipGame:
         return torch.tensor([int(v)], dtype=torch.int32, device=self.device)
 
     def getBoardSize(self):
-        return (5, 5, 3) if self.GAME_ID == _lib.SANTORINI else (9, 9, 4) if self.GAME_ID == _lib.ABALONE else (self.rows, self.cols)
+        return ((5, 5, 3) if self.GAME_ID == _lib.SANTORINI else (9, 9, 4) if self.GAME_ID == _lib.ABALONE else (66, 5, 7) if self.GAME_ID == _lib.BOTANIK
+                else (self.rows, self.cols))
 
     def getActionSize(self):
         return self.A
@@ -203,6 +204,15 @@ class TLPGame(HipGame):
         super().__init__(num_players, **kw)
 
 
+class BotanikGame(HipGame):
+    """botanik/BotanikGame.py (2 players, MACHINE_SIZE = 7: the shipped constants).  Every card drawn inside the env step takes a
+    uniform of the engine's counter RNG stream (BotanikLogicNumba.py:414-438)."""
+    GAME_ID = _lib.BOTANIK
+
+    def __init__(self, **kw):
+        super().__init__(2, **kw)
+
+
 def import_game(name, **kw):
     """GameSwitcher.import_game equivalent (GameSwitcher.py:15-24) for the games on the hot path."""
     if name == 'splendor':
@@ -217,4 +227,6 @@ def import_game(name, **kw):
         return AbaloneGame(**kw)
     if name == 'thelittleprince':
         return TLPGame(**kw)
+    if name == 'botanik':
+        return BotanikGame(**kw)
     raise ValueError('game %r is not on the accelerated path' % name)
