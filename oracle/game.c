@@ -49,6 +49,15 @@ int  abalone_get_score(const azo_game*, const int8_t*, int);
 void abalone_init_board(const azo_game*, int8_t*, azo_rng*);
 int  abalone_symmetries(const azo_game*, const int8_t*, const float*, const uint8_t*, int8_t*, float*, uint8_t*, int);
 
+void akropolis_valid_moves(const azo_game*, const int8_t*, int, uint8_t*);
+int  akropolis_make_move(const azo_game*, int8_t*, int, int, int64_t, azo_rng*);
+void akropolis_game_ended(const azo_game*, const int8_t*, int, float*);
+void akropolis_swap_players(const azo_game*, int8_t*, int);
+int  akropolis_get_round(const azo_game*, const int8_t*);
+int  akropolis_get_score(const azo_game*, const int8_t*, int);
+void akropolis_init_board(const azo_game*, int8_t*, azo_rng*);
+int  akropolis_symmetries(const azo_game*, const int8_t*, const float*, const uint8_t*, int8_t*, float*, uint8_t*, int);
+
 void botanik_valid_moves(const azo_game*, const int8_t*, int, uint8_t*);
 int  botanik_make_move(const azo_game*, int8_t*, int, int, int64_t, azo_rng*);
 void botanik_game_ended(const azo_game*, const int8_t*, int, float*);
@@ -101,6 +110,14 @@ int azo_game_init(azo_game* g, int game_id, int variant) {
         g->A = 3402;                         /* :50-52 */
         return 0;
     }
+    if (game_id == AZO_AKROPOLIS) {
+        g->variant = 2;
+        g->P = 2;
+        g->rows = 169; g->cols = 8;          /* observation_size (13, 13, 8), AkropolisLogicNumba.py:66-68 (N_PLAYERS = 2) */
+        g->S = 1352;
+        g->A = 4056;                         /* :70-72 */
+        return 0;
+    }
     if (game_id == AZO_BOTANIK) {
         g->variant = 2;
         g->P = 2;
@@ -141,7 +158,8 @@ int azo_game_init(azo_game* g, int game_id, int variant) {
 }
 
 void azo_valid_moves(const azo_game* g, const int8_t* s, int p, uint8_t* out) {
-    if (g->id == AZO_BOTANIK) botanik_valid_moves(g, s, p, out);
+    if (g->id == AZO_AKROPOLIS) akropolis_valid_moves(g, s, p, out);
+    else if (g->id == AZO_BOTANIK) botanik_valid_moves(g, s, p, out);
     else if (g->id == AZO_TLP) tlp_valid_moves(g, s, p, out);
     else if (g->id == AZO_ABALONE) abalone_valid_moves(g, s, p, out);
     else if (g->id == AZO_MINIVILLES) minivilles_valid_moves(g, s, p, out);
@@ -150,6 +168,7 @@ void azo_valid_moves(const azo_game* g, const int8_t* s, int p, uint8_t* out) {
     else santorini_valid_moves(g, s, p, out);
 }
 int azo_make_move(const azo_game* g, int8_t* s, int mv, int p, int64_t seed, azo_rng* rng) {
+    if (g->id == AZO_AKROPOLIS) return akropolis_make_move(g, s, mv, p, seed, rng);
     if (g->id == AZO_BOTANIK) return botanik_make_move(g, s, mv, p, seed, rng);
     if (g->id == AZO_TLP) return tlp_make_move(g, s, mv, p, seed, rng);
     if (g->id == AZO_ABALONE) return abalone_make_move(g, s, mv, p, seed, rng);
@@ -158,7 +177,8 @@ int azo_make_move(const azo_game* g, int8_t* s, int mv, int p, int64_t seed, azo
     return g->id == AZO_SPLENDOR ? splendor_make_move(g, s, mv, p, seed, rng) : santorini_make_move(g, s, mv, p, seed, rng);
 }
 void azo_game_ended(const azo_game* g, const int8_t* s, int np, float* out) {
-    if (g->id == AZO_BOTANIK) botanik_game_ended(g, s, np, out);
+    if (g->id == AZO_AKROPOLIS) akropolis_game_ended(g, s, np, out);
+    else if (g->id == AZO_BOTANIK) botanik_game_ended(g, s, np, out);
     else if (g->id == AZO_TLP) tlp_game_ended(g, s, np, out);
     else if (g->id == AZO_ABALONE) abalone_game_ended(g, s, np, out);
     else if (g->id == AZO_MINIVILLES) minivilles_game_ended(g, s, np, out);
@@ -167,7 +187,8 @@ void azo_game_ended(const azo_game* g, const int8_t* s, int np, float* out) {
     else santorini_game_ended(g, s, np, out);
 }
 void azo_swap_players(const azo_game* g, int8_t* s, int k) {
-    if (g->id == AZO_BOTANIK) botanik_swap_players(g, s, k);
+    if (g->id == AZO_AKROPOLIS) akropolis_swap_players(g, s, k);
+    else if (g->id == AZO_BOTANIK) botanik_swap_players(g, s, k);
     else if (g->id == AZO_TLP) tlp_swap_players(g, s, k);
     else if (g->id == AZO_ABALONE) abalone_swap_players(g, s, k);
     else if (g->id == AZO_MINIVILLES) minivilles_swap_players(g, s, k);
@@ -176,6 +197,7 @@ void azo_swap_players(const azo_game* g, int8_t* s, int k) {
     else santorini_swap_players(g, s, k);
 }
 int azo_get_round(const azo_game* g, const int8_t* s) {
+    if (g->id == AZO_AKROPOLIS) return akropolis_get_round(g, s);
     if (g->id == AZO_BOTANIK) return botanik_get_round(g, s);
     if (g->id == AZO_TLP) return tlp_get_round(g, s);
     if (g->id == AZO_ABALONE) return abalone_get_round(g, s);
@@ -184,6 +206,7 @@ int azo_get_round(const azo_game* g, const int8_t* s) {
     return g->id == AZO_SPLENDOR ? splendor_get_round(g, s) : santorini_get_round(g, s);
 }
 int azo_get_score(const azo_game* g, const int8_t* s, int p) {
+    if (g->id == AZO_AKROPOLIS) return akropolis_get_score(g, s, p);
     if (g->id == AZO_BOTANIK) return botanik_get_score(g, s, p);
     if (g->id == AZO_TLP) return tlp_get_score(g, s, p);
     if (g->id == AZO_ABALONE) return abalone_get_score(g, s, p);
@@ -192,7 +215,8 @@ int azo_get_score(const azo_game* g, const int8_t* s, int p) {
     return g->id == AZO_SPLENDOR ? splendor_get_score(g, s, p) : santorini_get_score(g, s, p);
 }
 void azo_init_board(const azo_game* g, int8_t* s, azo_rng* rng) {
-    if (g->id == AZO_BOTANIK) botanik_init_board(g, s, rng);
+    if (g->id == AZO_AKROPOLIS) akropolis_init_board(g, s, rng);
+    else if (g->id == AZO_BOTANIK) botanik_init_board(g, s, rng);
     else if (g->id == AZO_TLP) tlp_init_board(g, s, rng);
     else if (g->id == AZO_ABALONE) abalone_init_board(g, s, rng);
     else if (g->id == AZO_MINIVILLES) minivilles_init_board(g, s, rng);
@@ -207,6 +231,7 @@ void azo_canonical(const azo_game* g, const int8_t* s, int player, int8_t* out) 
 }
 int azo_symmetries(const azo_game* g, const int8_t* s, const float* pi, const uint8_t* valids, int8_t* os, float* op,
                    uint8_t* ov, int max_sym) {
+    if (g->id == AZO_AKROPOLIS) return akropolis_symmetries(g, s, pi, valids, os, op, ov, max_sym);
     if (g->id == AZO_BOTANIK) return botanik_symmetries(g, s, pi, valids, os, op, ov, max_sym);
     if (g->id == AZO_TLP) return tlp_symmetries(g, s, pi, valids, os, op, ov, max_sym);
     if (g->id == AZO_ABALONE) return abalone_symmetries(g, s, pi, valids, os, op, ov, max_sym);
@@ -225,7 +250,8 @@ int azo_symmetries_rng(const azo_game* g, const int8_t* s, const float* pi, cons
 void splendor_known_start(const azo_game*, int8_t*);
 void santorini_known_start(const azo_game*, int8_t*, int, int);
 void azo_known_start(const azo_game* g, int8_t* s, int a, int b) {
-    if (g->id == AZO_BOTANIK) { azo_rng r; memset(&r, 0, sizeof(r)); botanik_init_board(g, s, &r); }
+    if (g->id == AZO_AKROPOLIS) { azo_rng r; memset(&r, 0, sizeof(r)); akropolis_init_board(g, s, &r); }
+    else if (g->id == AZO_BOTANIK) { azo_rng r; memset(&r, 0, sizeof(r)); botanik_init_board(g, s, &r); }
     else if (g->id == AZO_TLP) { azo_rng r; memset(&r, 0, sizeof(r)); tlp_init_board(g, s, &r); }                      /* first market from stream (0,0) */
     else if (g->id == AZO_ABALONE) abalone_init_board(g, s, NULL);
     else if (g->id == AZO_MINIVILLES) { azo_rng r; memset(&r, 0, sizeof(r)); minivilles_init_board(g, s, &r); }   /* first dice from stream (0,0) */

@@ -11,6 +11,7 @@ import azg_oracle as O
 VARIANTS = {
     'splendor2': (O.SPLENDOR, 2), 'splendor3': (O.SPLENDOR, 3), 'splendor4': (O.SPLENDOR, 4),
     'santorini1': (O.SANTORINI, 1), 'santorini11': (O.SANTORINI, 11), 'azul': (O.AZUL, 0), 'abalone': (O.ABALONE, 0),
+    'akropolis': (O.AKROPOLIS, 0),
 }
 
 
@@ -75,7 +76,7 @@ def oracle_tree_digest(mc, game):
 
 
 MCTS_VARIANTS = ['splendor2', 'splendor4', 'santorini1', 'santorini11', 'azul']
-MCTS_SMALL = MCTS_VARIANTS + ['abalone']          # (no 800-simulation file for the f4 games)
+MCTS_SMALL = MCTS_VARIANTS + ['abalone', 'akropolis']          # (no 800-simulation file for the f4 games)
 
 
 @pytest.mark.parametrize('variant,typing,prefix', [(v, t, 'mcts') for v in MCTS_SMALL for t in ('numpy2', 'numba')] +
@@ -123,3 +124,13 @@ def test_mcts_sequence_tree_reuse(golden_dir, variant, typing):
         assert np.array_equal(probs, d['seq_probs'][i])
         assert mc.num_nodes() == int(d['seq_nodes'][i]), (variant, i)
         assert np.array_equal(oracle_tree_digest(mc, g), d['seq_digest'][i]), (variant, i)
+
+
+def test_akropolis_init_boards(golden_dir):
+    """init_game draws the four tiles of the construction site with np.random.choice (AkropolisLogicNumba.py:294,507-508)"""
+    d = load(golden_dir, 'env_akropolis.npz')
+    g = O.OracleGame(O.AKROPOLIS)
+    for i in range(len(d['init_boards'])):
+        rng = g.rng(injected=d['init_uniforms'][i])
+        assert np.array_equal(g.getInitBoard(rng).reshape(-1), d['init_boards'][i]) and rng.pos == 4
+    assert d['score'].max() > 60 and set(d['seed'].tolist()) >= {0, -1, 31416}

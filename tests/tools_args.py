@@ -7,5 +7,6 @@ MCTS_ARGS = {
     'santorini11': dict(cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True),
     'azul': dict(cpuct=0.5, fpu=0.05, universes=1, forced_playouts=True),
     'abalone': dict(cpuct=1.0, fpu=0.0, universes=0, forced_playouts=True),
+    'akropolis': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
     'minivilles2': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
 }

@@ -37,7 +37,7 @@ _tmp_roots = []
 def _purge_modules():
     for name in list(sys.modules):
         root = name.split('.')[0]
-        if root in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'botanik', 'MCTS', 'Game', 'Coach', 'Arena', 'utils', 'GameSwitcher',
+        if root in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'botanik', 'akropolis', 'MCTS', 'Game', 'Coach', 'Arena', 'utils', 'GameSwitcher',
                     'NeuralNet'):
             del sys.modules[name]
 
@@ -50,7 +50,7 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     for name in os.listdir(REFERENCE):
         src = os.path.join(REFERENCE, name)
         if os.path.isdir(src):
-            if name in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'botanik'):
+            if name in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'botanik', 'akropolis'):
                 shutil.copytree(src, os.path.join(tmp, name),
                                 ignore=shutil.ignore_patterns('*.pt', '*.gif', '*.jpg', '*.png', '*.mp4', '*.csv',
                                                               '__pycache__'))
@@ -120,6 +120,13 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     except Exception as e:  # pragma: no cover
         mods['BotanikGame'] = None
         mods['botanik_error'] = e
+    try:
+        mods['AkropolisGame'] = importlib.import_module('akropolis.AkropolisGame')
+        mods['AkropolisLogicNumba'] = importlib.import_module('akropolis.AkropolisLogicNumba')
+        mods['AkropolisConstants'] = importlib.import_module('akropolis.AkropolisConstants')
+    except Exception as e:  # pragma: no cover
+        mods['AkropolisGame'] = None
+        mods['akropolis_error'] = e
     mods['MCTS'] = importlib.import_module('MCTS')
     mods['utils'] = importlib.import_module('utils')
     return mods
@@ -190,6 +197,12 @@ class CounterRandom:
         v = lo + int(self.random() * (hi - lo))
         return min(v, hi - 1)
 
+    def choice(self, a, p=None):
+        """np.random.choice(a) without weights as the contract defines it: a[floor(u * len(a))]"""
+        assert p is None
+        a = np.arange(a) if np.isscalar(a) else np.asarray(a)
+        return a[min(int(self.random() * len(a)), len(a) - 1)]
+
     def shuffle(self, arr):
         """np.random.shuffle as the contract defines it: Fisher-Yates from the top, j = randint(0, i + 1) for i = n-1 .. 1
         (nothing is drawn for fewer than two elements)"""
@@ -198,12 +211,12 @@ class CounterRandom:
             arr[i], arr[j] = arr[j], arr[i]
 
     def __enter__(self):
-        self._orig = (np.random.random, np.random.randint, np.random.shuffle)
-        np.random.random, np.random.randint, np.random.shuffle = self.random, self.randint, self.shuffle
+        self._orig = (np.random.random, np.random.randint, np.random.shuffle, np.random.choice)
+        np.random.random, np.random.randint, np.random.shuffle, np.random.choice = self.random, self.randint, self.shuffle, self.choice
         return self
 
     def __exit__(self, *a):
-        np.random.random, np.random.randint, np.random.shuffle = self._orig
+        np.random.random, np.random.randint, np.random.shuffle, np.random.choice = self._orig
 
 
 class HashNet:
