@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/azg.h"
@@ -16,6 +17,7 @@
 #include "game_abalone.hip.h"
 #include "game_tlp.hip.h"
 #include "game_botanik.hip.h"
+#include "game_akropolis.hip.h"
 #include "selfplay.hip.h"
 #include "azg_host.h"
 
@@ -45,8 +47,13 @@ extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
         else if ((game) == AZG_TLP && (variant) == 3) { using G = TLPDev<3>; __VA_ARGS__; }               \
         else if ((game) == AZG_TLP && (variant) == 4) { using G = TLPDev<4>; __VA_ARGS__; }               \
         else if ((game) == AZG_BOTANIK) { using G = BotanikDev; __VA_ARGS__; }                             \
+        else if ((game) == AZG_AKROPOLIS) { using G = AkropolisDev; __VA_ARGS__; }                         \
         else return fail("unsupported game/variant");                                              \
     } while (0)
+
+// games whose expanded nodes carry many more entries than the default heap sizing assumes name their typical count (REC_NV_HINT)
+template <class G, class = void> struct RecNvHint { static constexpr int value = 0; };
+template <class G> struct RecNvHint<G, std::void_t<decltype(G::REC_NV_HINT)>> { static constexpr int value = G::REC_NV_HINT; };
 
 static int norm_variant(int game, int variant) {
     if (game == AZG_SPLENDOR) return variant ? variant : 2;
@@ -56,6 +63,7 @@ static int norm_variant(int game, int variant) {
     if (game == AZG_ABALONE) return 1;
     if (game == AZG_TLP) return variant ? variant : 3;
     if (game == AZG_BOTANIK) return 2;
+    if (game == AZG_AKROPOLIS) return 2;
     return variant;
 }
 
@@ -191,7 +199,8 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     f->ms_total[0] = f->ms_total[1] = 0;
     f->launches[0] = f->launches[1] = 0;
     int game = f->cfg.game, variant = f->cfg.variant;
-    AZG_DISPATCH(game, variant, { f->S = G::S; f->SP = G::SP; f->A = G::A; f->P = G::P; });
+    int nv_hint = 0;                     // typical valid actions per expanded node (sizes the record heap of large action spaces)
+    AZG_DISPATCH(game, variant, { f->S = G::S; f->SP = G::SP; f->A = G::A; f->P = G::P; nv_hint = RecNvHint<G>::value; });
     if (cfg->n_trees <= 0 || cfg->node_capacity < 16) { delete f; return fail("bad n_trees / node_capacity"); }
     if (cfg->node_capacity > (1 << AZG_IDX_BITS) - 2) { delete f; return fail("node_capacity too large"); }
     if (cfg->universes < 0 || cfg->universes > AZG_MAX_UNIVERSES) { delete f; return fail("universes out of range"); }
@@ -210,7 +219,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
                             : (D.cls_q == f->A ? (size_t)D.cap * RecLayout(f->A, D.U).total + 4096
-                                               : (size_t)D.cap * RecLayout(f->A <= 256 ? 64 : 160, D.U).total * 5 / 4) + 8192;
+                                               : (size_t)D.cap * RecLayout(nv_hint ? nv_hint : (f->A <= 256 ? 64 : 160), D.U).total * 5 / 4) + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     D.heap_units = (uint32_t)(heap_bytes / 16);
     auto skew = [](size_t bytes) { size_t r = (bytes + 255) / 256 * 256; return ((r >> 8) & 1) ? r : r + 256; };

@@ -1,0 +1,336 @@
+// game_akropolis.hip.h -- Akropolis env step on the device plugin interface: akropolis/AkropolisLogicNumba.py
+// (Board :270-611, grid helpers :95-131, tables :184-230) with the shipped constants (AkropolisConstants.py: N_PLAYERS = 2,
+// CITY_SIZE = 13, CONSTR_SITE_SIZE = 4, N_STACKS = 11).
+//
+// State int8 [13][13][8] (:7-32), byte (r * 13 + q) * 8 + z on an odd-r offset hex grid:
+//   z = p      tile description of player p's city (0 empty, 1 quarry, 2..6 district B Y R P G, 7..11 plaza B Y R P G)
+//   z = 2 + p  height, z = 4 + p  tile id (61 = the start tile)
+//   z = 6      per-player scalars at (row, col): (p, c) plazas, (2 + p, c) districts, (4 + p, 0) total score code, (4 + p, 1) stones
+//   z = 7      globals: (i, j) construction-site tile i = three descriptions + tile id, (4, 0..7) bitfield of the tiles still in the
+//              stacks (MSB first), (5, 0) round, (5, 1) stacks left
+// Action = slot * 1014 + cell * 6 + orientation (:53-61); pattern (cell, o) covers cell + DIR[o], cell, cell + DIR[o + 1].
+//
+// The env step is a function of (state, action, random_seed) for random_seed != 0 -- the refill is (2014 (seed + round) + 42) mod 61
+// (:510-512) -- so edges are memoised like Splendor's; real moves and init (random_seed == 0) draw np.random.choice(available) =
+// available[floor(u len)] from the tree's counter stream.  get_symmetries (:472-501) rotates about cell (0, 0), the corner of the
+// grid: cells and patterns fall off the board, the scatter wraps index -1 to the last action and later writers win -- lane 0 builds
+// the forms exactly as written (BUILT symmetric forms, k_env_symmetries_built).
+//
+// Valid moves: 1014 pattern predicates in 16 ballots, expanded to the 4 slots in 64 words; make_move / init on lane 0 (district
+// scoring = flood fills over 169 cells with bitset work lists); swap_players is a byte map applied by all lanes.
+#pragma once
+#include "azg_common.hip.h"
+#include "akropolis_tables.h"
+
+namespace azg {
+
+struct AkropolisDev {
+    static constexpr int P = 2;
+    static constexpr int ROWS = 169, COLS = 8;
+    static constexpr int S = 1352;
+    static constexpr int SP = RoundUp16<S>::value;
+    static constexpr int A = 4056;
+    static constexpr int AW = (A + 63) / 64;
+    static constexpr bool STOCHASTIC = false;
+    static constexpr bool RANDOM_SYM = true;      // symmetric forms are built by lane 0 (k_env_symmetries_built); no draw is consumed
+    static constexpr bool SYM_DEDUP = false;
+    static constexpr int REC_NV_HINT = 1200;      // a few hundred placements x up to 4 affordable tiles per node (record heap sizing)
+    enum { EMPTY = 0, QUARRY = 1, DISTRICT_BLUE = 2, DISTRICT_YELLOW = 3, DISTRICT_RED = 4, DISTRICT_PURPLE = 5, DISTRICT_GREEN = 6,
+           PLAZA_BLUE = 7 };
+    enum { BLUE, YELLOW, RED, PURPLE, GREEN };
+    enum { CS = 13, AREA = 169, NPAT = 1014, NSITE = 4 };
+    enum { O_ROUND = ((NSITE + 1) * CS) * 8 + 7, O_STACKS = ((NSITE + 1) * CS + 1) * 8 + 7 };
+
+    __device__ static __forceinline__ int at(int r, int q, int z) { return ((r * CS + q) << 3) + z; }
+    __device__ static __forceinline__ int o_plazas(int p, int c) { return at(p, c, 6); }
+    __device__ static __forceinline__ int o_districts(int p, int c) { return at(2 + p, c, 6); }
+    __device__ static __forceinline__ int o_total(int p) { return at(4 + p, 0, 6); }
+    __device__ static __forceinline__ int o_stones(int p) { return at(4 + p, 1, 6); }
+    __device__ static __forceinline__ int o_site(int i, int j) { return at(i, j, 7); }
+    __device__ static __forceinline__ int o_bitpack(int j) { return at(NSITE, j, 7); }
+    __device__ static __forceinline__ int stars(int c) { return c == 0 ? 1 : (c == 4 ? 3 : 2); }                 // PLAZA_STARS
+    __device__ static __forceinline__ int type_of(int d) { return d == 0 ? 0 : (d == 1 ? 1 : (d <= 6 ? 2 : 3)); }   // DESCR_TO_TYPE_COLOR
+    __device__ static __forceinline__ int color_of(int d) { return d <= 1 ? 0 : (d <= 6 ? d - 2 : d - 7); }
+
+    // the cell in direction d (SW SE E NE NW W, AkropolisConstants.py:77-80), or -1 off the board
+    __device__ static __forceinline__ int neighbor(int idx, int d) {
+        const int r = idx / CS, q = idx - r * CS;
+        // (dq, dr) even rows: (-1,1) (0,1) (1,0) (0,-1) (-1,-1) (-1,0); odd rows: (0,1) (1,1) (1,0) (1,-1) (0,-1) (-1,0)
+        const int dr = d < 2 ? 1 : ((d == 2 || d == 5) ? 0 : -1);
+        const int dq_even = (d == 0 || d >= 4) ? -1 : (d == 2 ? 1 : 0);
+        const int dq = (d == 2 || d == 5) ? dq_even : dq_even + (r & 1);
+        const int nq = q + dq, nr = r + dr;
+        return (nq >= 0 && nq < CS && nr >= 0 && nr < CS) ? nr * CS + nq : -1;
+    }
+    // PATTERNS[p] :198-216
+    __device__ static __forceinline__ bool pattern_cells(int p, int* c) {
+        const int s = p / 6, o = p - 6 * s;
+        c[0] = neighbor(s, o); c[1] = s; c[2] = neighbor(s, o == 5 ? 0 : o + 1);
+        if (c[0] < 0 || c[2] < 0) { c[0] = c[1] = c[2] = -1; return false; }
+        return true;
+    }
+
+    __device__ static int get_score(const int8_t* st, int p) {                 // :421-424
+        int t = 0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) t += (int)st[o_districts(p, c)] * st[o_plazas(p, c)] * stars(c);
+        return t + st[o_stones(p)];
+    }
+    __device__ static __forceinline__ int get_round(const int8_t* st) { return st[O_ROUND]; }
+    __device__ static __forceinline__ int gc_age(const int8_t* st) { return (int)(uint8_t)st[O_ROUND]; }
+    __device__ static __forceinline__ bool move_uses_seed(int) { return true; }     // a move refills when one tile is left: state-dependent
+
+    __device__ static void draw_tiles(int8_t* st, long long seed, bool initial, Rng& rng) {       // :503-518
+        for (int i = initial ? 0 : 1; i < NSITE; i++) {
+            uint64_t bits = 0;
+            for (int j = 0; j < 8; j++) bits |= (uint64_t)(uint8_t)st[o_bitpack(j)] << (8 * (7 - j));     // tile t = bit 63 - t
+            const int n = __popcll((unsigned long long)bits);
+            int k;
+            if (initial || seed == 0) {
+                k = (int)(rng.u01() * (double)n);
+                k = k >= n ? n - 1 : k;
+            } else {
+                long long v = (2014ll * (seed + (long long)st[O_ROUND]) + 42ll) % 61ll;
+                if (v < 0) v += 61;
+                k = (int)(v % n);
+            }
+            int tile = 0;
+            for (int t = 0; t < 64; t++)
+                if ((bits >> (63 - t)) & 1ull) { if (k == 0) { tile = t; break; } k--; }
+            const uint32_t w = AKRO_TILES[tile];
+            for (int j = 0; j < 3; j++) st[o_site(i, j)] = (int8_t)((w >> (4 * j)) & 15u);
+            st[o_site(i, 3)] = (int8_t)tile;
+            st[o_bitpack(tile >> 3)] = (int8_t)(((uint8_t)st[o_bitpack(tile >> 3)]) & ~(128u >> (tile & 7)));
+        }
+    }
+
+    struct Bits169 {
+        uint64_t w[3];
+        __device__ void clear() { w[0] = w[1] = w[2] = 0; }
+        __device__ bool get(int i) const { return (w[i >> 6] >> (i & 63)) & 1ull; }
+        __device__ void set(int i) { w[i >> 6] |= 1ull << (i & 63); }
+    };
+    __device__ static void update_districts(int8_t* st, int p) {               // :520-611
+        int district[5] = {0, 0, 0, 0, 0};
+        Bits169 outer, seen;
+        uint8_t stack[AREA];
+        int n = 0;
+        outer.clear(); seen.clear();
+        for (int i = 0; i < AREA; i++) {
+            const int d = st[(i << 3) + p], h = st[(i << 3) + 2 + p];
+            if (d == DISTRICT_GREEN) district[GREEN] += h;
+            else if (d == DISTRICT_YELLOW) {
+                bool isolated = true;
+                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb >= 0 && st[(nb << 3) + p] == DISTRICT_YELLOW) isolated = false; }
+                if (isolated) district[YELLOW] += h;
+            } else if (d == DISTRICT_PURPLE) {
+                bool ok = true;
+                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || st[(nb << 3) + 2 + p] == 0) ok = false; }
+                if (ok) district[PURPLE] += h;
+            } else if (d == EMPTY) {
+                bool border = false;
+                for (int k = 0; k < 6; k++) border = border || neighbor(i, k) < 0;
+                if (border) { outer.set(i); stack[n++] = (uint8_t)i; }
+            }
+        }
+        for (int k0 = 0; k0 < n; k0++)                                         // flood fill of the empty cells from the border
+            for (int k = 0; k < 6; k++) {
+                const int nb = neighbor(stack[k0], k);
+                if (nb < 0 || outer.get(nb) || st[(nb << 3) + p] != EMPTY) continue;
+                outer.set(nb); stack[n++] = (uint8_t)nb;
+            }
+        for (int i = 0; i < AREA; i++)
+            if (st[(i << 3) + p] == DISTRICT_RED)
+                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || outer.get(nb)) { district[RED] += st[(i << 3) + 2 + p]; break; } }
+        int best = 0;
+        for (int s0 = 0; s0 < AREA; s0++) {                                    // heaviest chain of houses
+            if (st[(s0 << 3) + p] != DISTRICT_BLUE || seen.get(s0)) continue;
+            int chain = 0, top = 0;
+            stack[top++] = (uint8_t)s0; seen.set(s0);
+            while (top) {
+                const int cur = stack[--top];
+                chain += st[(cur << 3) + 2 + p];
+                for (int k = 0; k < 6; k++) {
+                    const int nb = neighbor(cur, k);
+                    if (nb < 0 || seen.get(nb) || st[(nb << 3) + p] != DISTRICT_BLUE) continue;
+                    seen.set(nb); stack[top++] = (uint8_t)nb;
+                }
+            }
+            best = chain > best ? chain : best;
+        }
+        district[BLUE] = best;
+        for (int c = 0; c < 5; c++) st[o_districts(p, c)] = (int8_t)district[c];
+    }
+
+    // valid_moves :358-398 for one pattern
+    __device__ static bool pattern_valid(const int8_t* st, int pat, int player) {
+        int c[3];
+        if (!pattern_cells(pat, c)) return false;
+        const int ha = st[(c[0] << 3) + 2 + player];
+        if (ha != st[(c[1] << 3) + 2 + player] || ha != st[(c[2] << 3) + 2 + player]) return false;
+        if (ha == 0) {
+            bool connected = false;
+#pragma unroll 1
+            for (int j = 0; j < 3; j++)
+                for (int k = 0; k < 6; k++) {
+                    const int nb = neighbor(c[j], k);
+                    connected = connected || (nb >= 0 && st[(nb << 3) + 2 + player] > 0);      // (the triple itself has height 0)
+                }
+            return connected;
+        }
+        const int ta = st[(c[0] << 3) + 4 + player];
+        return !(ta == st[(c[1] << 3) + 4 + player] && ta == st[(c[2] << 3) + 4 + player]);
+    }
+    // Board.valid_moves :354-413: the pattern predicates go to mask_lds[0..15] first, then every action looks its pattern up; words are
+    // finalised from the top so that a word is overwritten only after its last reader
+    __device__ static void valid_mask(const int8_t* st, int player, uint64_t* mask_lds) {
+        const int l = lane_id();
+#pragma unroll 1
+        for (int k = 0; k < 16; k++) {
+            const int p = k * 64 + l;
+            const uint64_t m = __ballot(p < NPAT && pattern_valid(st, p < NPAT ? p : 0, player));
+            if (l == 0) mask_lds[k] = m;
+        }
+        wave_sync();
+        int slots = st[o_stones(player)] + 1;
+        slots = slots > NSITE ? NSITE : slots;
+#pragma unroll 1
+        for (int k = AW - 1; k >= 0; k--) {
+            const int a = k * 64 + l;
+            const int slot = a / NPAT, pat = a - slot * NPAT;
+            bool v = a < A && slot < slots && st[o_site(slot < NSITE ? slot : 0, 0)] != EMPTY;
+            v = v && ((mask_lds[pat >> 6] >> (pat & 63)) & 1ull);
+            const uint64_t m = __ballot(v);
+            wave_sync();
+            if (l == 0) mask_lds[k] = m;
+            wave_sync();
+        }
+    }
+
+    __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
+        return lane0_make_move<AkropolisDev>(st, move, player, seed, rng);
+    }
+    // Board.make_move :314-352 -- lane 0 only
+    __device__ static int make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
+        const int slot = move / NPAT, pat = move - slot * NPAT;
+        int8_t tile[4];
+        int c[3];
+        for (int j = 0; j < 4; j++) tile[j] = st[o_site(slot, j)];
+        for (int i = slot; i < NSITE - 1; i++)
+            for (int j = 0; j < 4; j++) st[o_site(i, j)] = st[o_site(i + 1, j)];
+        for (int j = 0; j < 4; j++) st[o_site(NSITE - 1, j)] = EMPTY;
+        pattern_cells(pat, c);
+        for (int j = 0; j < 3; j++) {
+            const int under = st[(c[j] << 3) + player];
+            if (type_of(under) == 3) st[o_plazas(player, color_of(under))] = (int8_t)(st[o_plazas(player, color_of(under))] - 1);
+            if (type_of(under) == 1) st[o_stones(player)] = (int8_t)(st[o_stones(player)] + 1);
+            st[(c[j] << 3) + player] = tile[j];
+            st[(c[j] << 3) + 2 + player] = (int8_t)(st[(c[j] << 3) + 2 + player] + 1);
+            st[(c[j] << 3) + 4 + player] = tile[3];
+            if (type_of(tile[j]) == 3) st[o_plazas(player, color_of(tile[j]))] = (int8_t)(st[o_plazas(player, color_of(tile[j]))] + 1);
+        }
+        st[o_stones(player)] = (int8_t)(st[o_stones(player)] - slot);
+        update_districts(st, player);
+        st[o_total(player)] = (int8_t)(get_score(st, player) / 2 - 128);        // encode_score_to_int8 :239-248
+        st[O_ROUND] = (int8_t)(st[O_ROUND] + 1);
+        if (st[o_site(1, 0)] == EMPTY && st[O_STACKS] > 0) {
+            draw_tiles(st, seed, false, rng);
+            st[O_STACKS] = (int8_t)(st[O_STACKS] - 1);
+        }
+        return (player + 1) & 1;
+    }
+
+    // Board.check_end_game :426-437 (uniform)
+    __device__ static bool game_ended(const int8_t* st, int next_player, float* out, uint64_t* mask_scratch) {
+        (void)next_player; (void)mask_scratch;
+        if (!(st[O_STACKS] <= 0 && st[o_site(1, 0)] == EMPTY)) { out[0] = 0.f; out[1] = 0.f; return false; }
+        const long long a = (long long)get_score(st, 0) * 1000 + st[o_stones(0)], b = (long long)get_score(st, 1) * 1000 + st[o_stones(1)];
+        out[0] = a > b ? 1.f : (a < b ? -1.f : 0.001f);
+        out[1] = b > a ? 1.f : (b < a ? -1.f : 0.001f);
+        return true;
+    }
+
+    // Board.swap_players :439-470 (k odd): the per-player planes and scalars trade places
+    __device__ static void swap_players(int8_t* st, int8_t* tmp, int k) {
+        if ((k & 1) == 0) return;
+        for (int i = lane_id(); i < S; i += 64) tmp[i] = st[i];
+        wave_sync();
+        for (int i = lane_id(); i < S; i += 64) {
+            const int cell = i >> 3, z = i & 7;
+            int src = i;
+            if (z < 6) src = i ^ 1;
+            else if (z == 6) {
+                const int r = cell / CS, q = cell - r * CS;
+                if (r < 6 && (r < 4 ? q < 5 : q < 2)) src = at(r ^ 1, q, 6);
+            }
+            st[i] = tmp[src];
+        }
+        wave_sync();
+    }
+
+    // init_game :275-295 -- lane 0; state zeroed by the caller
+    __device__ static void init_board(int8_t* st, Rng& rng) {
+        st[o_stones(0)] = 1; st[o_stones(1)] = 2;
+        for (int t = 0; t < 61; t++)
+            if ((AKRO_TILES[t] >> 12) <= 2) st[o_bitpack(t >> 3)] = (int8_t)(((uint8_t)st[o_bitpack(t >> 3)]) | (128u >> (t & 7)));
+        st[O_STACKS] = 11;
+        for (int p = 0; p < 2; p++) st[o_total(p)] = (int8_t)(st[o_stones(p)] / 2 - 128);
+        const int centre = (CS / 2) * CS + CS / 2;
+        for (int p = 0; p < 2; p++) {
+            st[(centre << 3) + p] = PLAZA_BLUE; st[(centre << 3) + 2 + p] = 1; st[(centre << 3) + 4 + p] = 61;
+            st[o_plazas(p, BLUE)] = 1;
+            for (int d = 0; d < 6; d += 2) {                                   // NEIGHBORS[centre, ::2]
+                const int nb = neighbor(centre, d);
+                st[(nb << 3) + p] = QUARRY; st[(nb << 3) + 2 + p] = 1; st[(nb << 3) + 4 + p] = 61;
+            }
+        }
+        draw_tiles(st, 0, true, rng);
+    }
+
+    // ---- get_symmetries :472-501: six rotations about cell (0, 0), built by lane 0 as written ----
+    static constexpr int NSYM_CAND = 6;
+    __device__ static int rotate_cell(int idx, int k) {                        // :95-114
+        if (idx < 0) return -1;
+        const int r = idx / CS, q = idx - r * CS;
+        int x = q - ((r - (r & 1)) / 2), z = r, y = -x - z;
+        for (int i = 0; i < k; i++) { const int nx = -z, ny = -x, nz = -y; x = nx; y = ny; z = nz; }
+        const int r2 = z, q2 = x + ((r2 - (r2 & 1)) / 2);
+        return (r2 >= 0 && r2 < CS && q2 >= 0 && q2 < CS) ? r2 * CS + q2 : -1;
+    }
+    __device__ static int rotate_pattern(int pat, int k) {                     // :116-129: the FIRST pattern with the rotated cells
+        int c[3], t[3], rc[3];
+        pattern_cells(pat, c);
+        for (int j = 0; j < 3; j++) rc[j] = rotate_cell(c[j], k);
+        if (rc[0] < 0 && rc[1] < 0 && rc[2] < 0) return 0;                      // pattern 0 is (-1, -1, -1)
+        if (rc[1] < 0) return -1;
+        for (int o = 0; o < 6; o++) {
+            if (!pattern_cells(rc[1] * 6 + o, t)) continue;
+            if (t[0] == rc[0] && t[2] == rc[2]) return rc[1] * 6 + o;
+        }
+        return -1;
+    }
+    __device__ static bool sym_build(const int8_t* st, int c, int8_t* cand, int16_t* act_src, Rng& rng, const uint8_t* valids) {
+        (void)rng;
+        for (int i = 0; i < S; i++) cand[i] = (i & 7) >= 6 ? st[i] : 0;          // the scalar layers z = 6, 7 are kept (:486)
+        for (int i = 0; i < AREA; i++) {
+            const int nb = rotate_cell(i, c);
+            if (nb >= 0)
+                for (int z = 0; z < 6; z++) cand[(nb << 3) + z] = st[(i << 3) + z];
+        }
+        for (int a = 0; a < A; a++) act_src[a] = -1;
+        for (int a = 0; a < A; a++)
+            if (valids[a]) {
+                const int slot = a / NPAT;
+                int ni = slot * NPAT + rotate_pattern(a - slot * NPAT, c);
+                if (ni < 0) ni += A;                                            // new_p[-1]: Python's wrap-around
+                act_src[ni] = (int16_t)a;                                       // ascending scan: the last writer wins
+            }
+        return true;
+    }
+    // (the deterministic per-byte interface is unused: k_env_symmetries takes the built path)
+    __device__ static __forceinline__ bool sym_exists(const int8_t*, int c) { return c == 0; }
+    __device__ static __forceinline__ int8_t sym_state_byte(const int8_t* st, int, int i) { return st[i]; }
+    __device__ static __forceinline__ int sym_action_src(const int8_t*, int, int a) { return a; }
+};
+
+}  // namespace azg

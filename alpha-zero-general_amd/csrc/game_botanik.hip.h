@@ -426,8 +426,8 @@ struct BotanikDev {
             if (c != EMPTY && c != SOURCE) cards[7 * i] = (int8_t)((c - 2 + nroll) % 5 + 2);
         }
     }
-    __device__ static bool sym_build(const int8_t* st, int c, int8_t* cand, int16_t* act_src, Rng& rng) {
-        (void)rng;
+    __device__ static bool sym_build(const int8_t* st, int c, int8_t* cand, int16_t* act_src, Rng& rng, const uint8_t* valids) {
+        (void)rng; (void)valids;
         for (int a = 0; a < A; a++) act_src[a] = (int16_t)a;
         if (c == 0) return true;
         if (c == 1) {                                                           // mirror of machine 0 + policy / valids (:307-324)

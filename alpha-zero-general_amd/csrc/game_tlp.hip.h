@@ -301,7 +301,8 @@ struct TLPDev {
             }
     }
     // lane 0: `cand` (a copy of the input state) becomes form c
-    __device__ static bool sym_build(const int8_t* st, int c, int8_t* cand, int16_t* act_src, Rng& rng) {
+    __device__ static bool sym_build(const int8_t* st, int c, int8_t* cand, int16_t* act_src, Rng& rng, const uint8_t* valids) {
+        (void)valids;
         int16_t row_src[ROWS];
         if (c == 0) {
             for (int a = 0; a < A; a++) act_src[a] = (int16_t)a;

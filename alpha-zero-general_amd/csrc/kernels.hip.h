@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) void k_env_symmetries(const int8_t* states, con
 // Games whose symmetric forms are BUILT by lane 0 (G::RANDOM_SYM): get_symmetries is itself random (The Little Prince shuffles
 // players, market cards and planet slots and drops duplicate states) or is a set of card-level edits rather than a byte map
 // (Botanik).  One wave per input triple; all lanes copy the state into the candidate buffer, lane 0 turns it into form c
-// (G::sym_build: state edits + the action map out[a] = in[act_src[a]], drawing from the counter stream (rng_seed, stream0 + t) if the
+// (G::sym_build: state edits + the action map out[a] = in[act_src[a]] (0 where act_src[a] < 0), drawing from the counter stream (rng_seed, stream0 + t) if the
 // game shuffles), all lanes write the form out.  With G::SYM_DEDUP a form is kept only when its state differs from every form kept so
 // far (the kept forms stay in LDS for the comparison).
 template <class G>
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void k_env_symmetries_built(const int8_t* state
         int8_t* cand = kept[G::SYM_DEDUP ? (k < NKEEP ? k : NKEEP - 1) : 0];
         for (int i = lane_id(); i < G::S; i += 64) cand[i] = st[i];
         __syncthreads();
-        if (lane_id() == 0) exists_s = G::sym_build(st, c, cand, act_src, rng) ? 1 : 0;     // (draws even when the form is dropped below)
+        if (lane_id() == 0) exists_s = G::sym_build(st, c, cand, act_src, rng, vin) ? 1 : 0;     // (draws even when the form is dropped below)
         __syncthreads();
         bool keep = exists_s != 0 && k < max_sym;
         if (keep && G::SYM_DEDUP) {
@@ -139,8 +139,9 @@ __global__ __launch_bounds__(64) void k_env_symmetries_built(const int8_t* state
             const size_t o = (size_t)t * max_sym + k;
             for (int i = lane_id(); i < G::S; i += 64) out_states[o * G::S + i] = cand[i];
             for (int a = lane_id(); a < G::A; a += 64) {
-                out_pi[o * G::A + a] = pin[act_src[a]];
-                out_valids[o * G::A + a] = vin[act_src[a]];
+                const int src = act_src[a];                          // < 0: nothing maps onto a
+                out_pi[o * G::A + a] = src >= 0 ? pin[src] : 0.f;
+                out_valids[o * G::A + a] = src >= 0 ? vin[src] : (uint8_t)0;
             }
             k++;
         }

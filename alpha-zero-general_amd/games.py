@@ -75,7 +75,7 @@ class HipGame:
         return out
 
     def max_symmetries(self):
-        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1, 4: 12, 5: 2 * self.P + 1, 6: 14}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles, Abalone, TLP, Botanik
+        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1, 4: 12, 5: 2 * self.P + 1, 6: 14, 7: 6}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles, Abalone, TLP, Botanik, Akropolis
 
     def symmetries_batch(self, boards, pi, valids, max_sym=None, rng_seed=None, stream0=0):
         """getSymmetries for n (board int8[n,S], pi f32[n,A], valids u8[n,A]) triples on device ->
@@ -104,7 +104,7 @@ class HipGame:
 
     def getBoardSize(self):
         return ((5, 5, 3) if self.GAME_ID == _lib.SANTORINI else (9, 9, 4) if self.GAME_ID == _lib.ABALONE else (66, 5, 7) if self.GAME_ID == _lib.BOTANIK
-                else (self.rows, self.cols))
+                else (13, 13, 8) if self.GAME_ID == _lib.AKROPOLIS else (self.rows, self.cols))
 
     def getActionSize(self):
         return self.A
@@ -213,6 +213,14 @@ class BotanikGame(HipGame):
         super().__init__(2, **kw)
 
 
+class AkropolisGame(HipGame):
+    """akropolis/AkropolisGame.py (2 players, 13 x 13 city: the shipped constants)"""
+    GAME_ID = _lib.AKROPOLIS
+
+    def __init__(self, **kw):
+        super().__init__(2, **kw)
+
+
 def import_game(name, **kw):
     """GameSwitcher.import_game equivalent (GameSwitcher.py:15-24) for the games on the hot path."""
     if name == 'splendor':
@@ -229,4 +237,6 @@ def import_game(name, **kw):
         return TLPGame(**kw)
     if name == 'botanik':
         return BotanikGame(**kw)
+    if name == 'akropolis':
+        return AkropolisGame(**kw)
     raise ValueError('game %r is not on the accelerated path' % name)

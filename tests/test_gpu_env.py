@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
-            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0)}
+            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0)}
 
 
 def make_game(variant):
@@ -20,6 +20,8 @@ def make_game(variant):
         return games.AzulGame()
     if name == 'abalone':
         return games.AbaloneGame()
+    if name == 'akropolis':
+        return games.AkropolisGame()
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
 
 
@@ -52,7 +54,7 @@ def test_env_vs_golden(golden_dir, variant):
     assert np.array_equal(canon.cpu().numpy(), d['canonical'])
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'splendor4', 'santorini11', 'azul'])
+@pytest.mark.parametrize('variant', ['splendor2', 'splendor4', 'santorini11', 'azul', 'akropolis'])
 def test_true_random_moves_and_init_vs_oracle(golden_dir, variant):
     """random_seed == 0 (Coach.py:71) and Board.init_game consume the shared counter-based RNG exactly like the oracle."""
     import torch
@@ -60,7 +62,7 @@ def test_true_random_moves_and_init_vs_oracle(golden_dir, variant):
     d = np.load(os.path.join(golden_dir, 'env_%s.npz' % variant))
     g = make_game(variant)
     name, v = VARIANTS[variant]
-    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL}[name], v)
+    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'akropolis': O.AKROPOLIS}[name], v)
     dev = g.device
     n = min(len(d['state']), 400)
     st = torch.from_numpy(d['state'][:n]).to(dev)
@@ -101,7 +103,7 @@ def test_game_py_surface():
     assert g.stringRepresentation(b) == b.tobytes()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'splendor3', 'splendor4', 'santorini1', 'santorini11', 'azul', 'abalone'])
+@pytest.mark.parametrize('variant', ['splendor2', 'splendor3', 'splendor4', 'santorini1', 'santorini11', 'azul', 'abalone', 'akropolis'])
 def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
     """Game.getSymmetries on device (azg_env_symmetries) vs the reference's own outputs (tests/golden/sym_*.npz) and, on
     states from random play, vs the oracle."""
@@ -109,10 +111,10 @@ def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
     import azg_oracle as O
     from azg_amd import games
     name, v = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
-               'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0)}[variant]
+               'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0)}[variant]
     g = {'splendor': lambda: games.SplendorGame(v), 'santorini': lambda: games.SantoriniGame(v), 'azul': games.AzulGame,
-         'abalone': games.AbaloneGame}[name]()
-    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'abalone': O.ABALONE}[name], v)
+         'abalone': games.AbaloneGame, 'akropolis': games.AkropolisGame}[name]()
+    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'abalone': O.ABALONE, 'akropolis': O.AKROPOLIS}[name], v)
     K = g.max_symmetries()
     path = os.path.join(golden_dir, 'sym_%s.npz' % variant)
     if os.path.exists(path):
@@ -138,8 +140,8 @@ def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
                 c = og.getCanonicalForm(b, p)
                 states.append(c.reshape(-1).copy())
                 vas.append(og.getValidMoves(c, 0).astype(np.uint8))
-                # (Abalone's get_symmetries only maps the entries of valid actions: give pi the support MCTS gives it)
-                pis.append(rng.random(len(va)).astype(np.float32) * (vas[-1] if variant == 'abalone' else 1))
+                # (Abalone's / Akropolis's get_symmetries only map the entries of valid actions: give pi the support MCTS gives it)
+                pis.append(rng.random(len(va)).astype(np.float32) * (vas[-1] if variant in ('abalone', 'akropolis') else 1))
             b, p = og.getNextState(b, p, int(rng.choice(np.flatnonzero(va))), random_seed=31416 + ply)
             if og.getGameEnded(b, p).any():
                 break

@@ -10,7 +10,7 @@ from tools_args import MCTS_ARGS
 
 pytestmark = pytest.mark.gpu
 
-F4_VARIANTS = {'abalone': ('abalone', 0)}           # SURVEY.md §8 f4 games with the standard (deterministic-step) fixtures
+F4_VARIANTS = {'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0)}           # SURVEY.md §8 f4 games with the standard (deterministic-step) fixtures
 VARIANTS = {'splendor2': ('splendor', 2), 'splendor4': ('splendor', 4), 'santorini1': ('santorini', 1),
             'santorini11': ('santorini', 11), 'azul': ('azul', 0)}
 
@@ -26,6 +26,8 @@ def make(variant):
         return games.AzulGame()
     if name == 'abalone':
         return games.AbaloneGame()
+    if name == 'akropolis':
+        return games.AkropolisGame()
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
 
 
@@ -68,7 +70,7 @@ def test_mcts_traces_vs_golden(golden_dir, variant, prefix):
         m.forest.close()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'santorini11', 'azul', 'abalone'])
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini11', 'azul', 'abalone', 'akropolis'])
 def test_whole_tree_vs_oracle(variant):
     """Every node of the HIP tree equals the oracle's node with the same state key (Ns, Qs, Nsa, Qsa, Ps, Es)."""
     import torch
@@ -77,7 +79,7 @@ def test_whole_tree_vs_oracle(variant):
     from hashnet import HashNetTorch
     g = make(variant)
     name, v = {**VARIANTS, **F4_VARIANTS}[variant]
-    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'abalone': O.ABALONE}[name], v)
+    og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'abalone': O.ABALONE, 'akropolis': O.AKROPOLIS}[name], v)
     kw = dict(MCTS_ARGS[variant])
     sims = 400
     T = 8
@@ -106,7 +108,7 @@ def test_whole_tree_vs_oracle(variant):
     m.forest.close()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'santorini1', 'azul', 'abalone'])
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini1', 'azul', 'abalone', 'akropolis'])
 @pytest.mark.parametrize('small_arena', [False, True])
 def test_tree_reuse_sequence_vs_golden(golden_dir, variant, small_arena):
     """Multi-move sequence of the golden set: tree reuse across moves and fast (non-full) searches.  With a small arena
