@@ -49,6 +49,16 @@ int  abalone_get_score(const azo_game*, const int8_t*, int);
 void abalone_init_board(const azo_game*, int8_t*, azo_rng*);
 int  abalone_symmetries(const azo_game*, const int8_t*, const float*, const uint8_t*, int8_t*, float*, uint8_t*, int);
 
+void smallworld_valid_moves(const azo_game*, const int8_t*, int, uint8_t*);
+int  smallworld_make_move(const azo_game*, int8_t*, int, int, int64_t, azo_rng*);
+void smallworld_game_ended(const azo_game*, const int8_t*, int, float*);
+void smallworld_swap_players(const azo_game*, int8_t*, int);
+int  smallworld_get_round(const azo_game*, const int8_t*);
+int  smallworld_get_score(const azo_game*, const int8_t*, int);
+void smallworld_init_board(const azo_game*, int8_t*, azo_rng*);
+int  smallworld_symmetries(const azo_game*, const int8_t*, const float*, const uint8_t*, int8_t*, float*, uint8_t*, int);
+int  smallworld_symmetries_rng(const azo_game*, const int8_t*, const float*, const uint8_t*, int8_t*, float*, uint8_t*, int, azo_rng*);
+
 void akropolis_valid_moves(const azo_game*, const int8_t*, int, uint8_t*);
 int  akropolis_make_move(const azo_game*, int8_t*, int, int, int64_t, azo_rng*);
 void akropolis_game_ended(const azo_game*, const int8_t*, int, float*);
@@ -110,6 +120,14 @@ int azo_game_init(azo_game* g, int game_id, int variant) {
         g->A = 3402;                         /* :50-52 */
         return 0;
     }
+    if (game_id == AZO_SMALLWORLD) {
+        g->variant = 2;
+        g->P = 2;
+        g->rows = 40; g->cols = 8;           /* observation_size (NB_AREAS + 5 NUMBER_PLAYERS + 7, 8), SmallworldLogicNumba.py:92-94 */
+        g->S = 320;
+        g->A = 131;                          /* :96-98 */
+        return 0;
+    }
     if (game_id == AZO_AKROPOLIS) {
         g->variant = 2;
         g->P = 2;
@@ -158,7 +176,8 @@ int azo_game_init(azo_game* g, int game_id, int variant) {
 }
 
 void azo_valid_moves(const azo_game* g, const int8_t* s, int p, uint8_t* out) {
-    if (g->id == AZO_AKROPOLIS) akropolis_valid_moves(g, s, p, out);
+    if (g->id == AZO_SMALLWORLD) smallworld_valid_moves(g, s, p, out);
+    else if (g->id == AZO_AKROPOLIS) akropolis_valid_moves(g, s, p, out);
     else if (g->id == AZO_BOTANIK) botanik_valid_moves(g, s, p, out);
     else if (g->id == AZO_TLP) tlp_valid_moves(g, s, p, out);
     else if (g->id == AZO_ABALONE) abalone_valid_moves(g, s, p, out);
@@ -168,6 +187,7 @@ void azo_valid_moves(const azo_game* g, const int8_t* s, int p, uint8_t* out) {
     else santorini_valid_moves(g, s, p, out);
 }
 int azo_make_move(const azo_game* g, int8_t* s, int mv, int p, int64_t seed, azo_rng* rng) {
+    if (g->id == AZO_SMALLWORLD) return smallworld_make_move(g, s, mv, p, seed, rng);
     if (g->id == AZO_AKROPOLIS) return akropolis_make_move(g, s, mv, p, seed, rng);
     if (g->id == AZO_BOTANIK) return botanik_make_move(g, s, mv, p, seed, rng);
     if (g->id == AZO_TLP) return tlp_make_move(g, s, mv, p, seed, rng);
@@ -177,7 +197,8 @@ int azo_make_move(const azo_game* g, int8_t* s, int mv, int p, int64_t seed, azo
     return g->id == AZO_SPLENDOR ? splendor_make_move(g, s, mv, p, seed, rng) : santorini_make_move(g, s, mv, p, seed, rng);
 }
 void azo_game_ended(const azo_game* g, const int8_t* s, int np, float* out) {
-    if (g->id == AZO_AKROPOLIS) akropolis_game_ended(g, s, np, out);
+    if (g->id == AZO_SMALLWORLD) smallworld_game_ended(g, s, np, out);
+    else if (g->id == AZO_AKROPOLIS) akropolis_game_ended(g, s, np, out);
     else if (g->id == AZO_BOTANIK) botanik_game_ended(g, s, np, out);
     else if (g->id == AZO_TLP) tlp_game_ended(g, s, np, out);
     else if (g->id == AZO_ABALONE) abalone_game_ended(g, s, np, out);
@@ -187,7 +208,8 @@ void azo_game_ended(const azo_game* g, const int8_t* s, int np, float* out) {
     else santorini_game_ended(g, s, np, out);
 }
 void azo_swap_players(const azo_game* g, int8_t* s, int k) {
-    if (g->id == AZO_AKROPOLIS) akropolis_swap_players(g, s, k);
+    if (g->id == AZO_SMALLWORLD) smallworld_swap_players(g, s, k);
+    else if (g->id == AZO_AKROPOLIS) akropolis_swap_players(g, s, k);
     else if (g->id == AZO_BOTANIK) botanik_swap_players(g, s, k);
     else if (g->id == AZO_TLP) tlp_swap_players(g, s, k);
     else if (g->id == AZO_ABALONE) abalone_swap_players(g, s, k);
@@ -197,6 +219,7 @@ void azo_swap_players(const azo_game* g, int8_t* s, int k) {
     else santorini_swap_players(g, s, k);
 }
 int azo_get_round(const azo_game* g, const int8_t* s) {
+    if (g->id == AZO_SMALLWORLD) return smallworld_get_round(g, s);
     if (g->id == AZO_AKROPOLIS) return akropolis_get_round(g, s);
     if (g->id == AZO_BOTANIK) return botanik_get_round(g, s);
     if (g->id == AZO_TLP) return tlp_get_round(g, s);
@@ -206,6 +229,7 @@ int azo_get_round(const azo_game* g, const int8_t* s) {
     return g->id == AZO_SPLENDOR ? splendor_get_round(g, s) : santorini_get_round(g, s);
 }
 int azo_get_score(const azo_game* g, const int8_t* s, int p) {
+    if (g->id == AZO_SMALLWORLD) return smallworld_get_score(g, s, p);
     if (g->id == AZO_AKROPOLIS) return akropolis_get_score(g, s, p);
     if (g->id == AZO_BOTANIK) return botanik_get_score(g, s, p);
     if (g->id == AZO_TLP) return tlp_get_score(g, s, p);
@@ -215,7 +239,8 @@ int azo_get_score(const azo_game* g, const int8_t* s, int p) {
     return g->id == AZO_SPLENDOR ? splendor_get_score(g, s, p) : santorini_get_score(g, s, p);
 }
 void azo_init_board(const azo_game* g, int8_t* s, azo_rng* rng) {
-    if (g->id == AZO_AKROPOLIS) akropolis_init_board(g, s, rng);
+    if (g->id == AZO_SMALLWORLD) smallworld_init_board(g, s, rng);
+    else if (g->id == AZO_AKROPOLIS) akropolis_init_board(g, s, rng);
     else if (g->id == AZO_BOTANIK) botanik_init_board(g, s, rng);
     else if (g->id == AZO_TLP) tlp_init_board(g, s, rng);
     else if (g->id == AZO_ABALONE) abalone_init_board(g, s, rng);
@@ -231,6 +256,7 @@ void azo_canonical(const azo_game* g, const int8_t* s, int player, int8_t* out) 
 }
 int azo_symmetries(const azo_game* g, const int8_t* s, const float* pi, const uint8_t* valids, int8_t* os, float* op,
                    uint8_t* ov, int max_sym) {
+    if (g->id == AZO_SMALLWORLD) return smallworld_symmetries(g, s, pi, valids, os, op, ov, max_sym);
     if (g->id == AZO_AKROPOLIS) return akropolis_symmetries(g, s, pi, valids, os, op, ov, max_sym);
     if (g->id == AZO_BOTANIK) return botanik_symmetries(g, s, pi, valids, os, op, ov, max_sym);
     if (g->id == AZO_TLP) return tlp_symmetries(g, s, pi, valids, os, op, ov, max_sym);
@@ -244,13 +270,15 @@ int azo_symmetries(const azo_game* g, const int8_t* s, const float* pi, const ui
 int azo_symmetries_rng(const azo_game* g, const int8_t* s, const float* pi, const uint8_t* valids, int8_t* os, float* op,
                        uint8_t* ov, int max_sym, azo_rng* rng) {
     if (g->id == AZO_TLP) return tlp_symmetries_rng(g, s, pi, valids, os, op, ov, max_sym, rng);
+    if (g->id == AZO_SMALLWORLD) return smallworld_symmetries_rng(g, s, pi, valids, os, op, ov, max_sym, rng);
     return azo_symmetries(g, s, pi, valids, os, op, ov, max_sym);
 }
 
 void splendor_known_start(const azo_game*, int8_t*);
 void santorini_known_start(const azo_game*, int8_t*, int, int);
 void azo_known_start(const azo_game* g, int8_t* s, int a, int b) {
-    if (g->id == AZO_AKROPOLIS) { azo_rng r; memset(&r, 0, sizeof(r)); akropolis_init_board(g, s, &r); }
+    if (g->id == AZO_SMALLWORLD) { azo_rng r; memset(&r, 0, sizeof(r)); smallworld_init_board(g, s, &r); }
+    else if (g->id == AZO_AKROPOLIS) { azo_rng r; memset(&r, 0, sizeof(r)); akropolis_init_board(g, s, &r); }
     else if (g->id == AZO_BOTANIK) { azo_rng r; memset(&r, 0, sizeof(r)); botanik_init_board(g, s, &r); }
     else if (g->id == AZO_TLP) { azo_rng r; memset(&r, 0, sizeof(r)); tlp_init_board(g, s, &r); }                      /* first market from stream (0,0) */
     else if (g->id == AZO_ABALONE) abalone_init_board(g, s, NULL);

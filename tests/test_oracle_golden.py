@@ -11,7 +11,7 @@ import azg_oracle as O
 VARIANTS = {
     'splendor2': (O.SPLENDOR, 2), 'splendor3': (O.SPLENDOR, 3), 'splendor4': (O.SPLENDOR, 4),
     'santorini1': (O.SANTORINI, 1), 'santorini11': (O.SANTORINI, 11), 'azul': (O.AZUL, 0), 'abalone': (O.ABALONE, 0),
-    'akropolis': (O.AKROPOLIS, 0),
+    'akropolis': (O.AKROPOLIS, 0), 'smallworld': (O.SMALLWORLD, 0),
 }
 
 
@@ -45,7 +45,7 @@ def test_env_transitions(golden_dir, variant):
     assert n_seed0 > 10
 
 
-@pytest.mark.parametrize('variant', list(VARIANTS))
+@pytest.mark.parametrize('variant', [v for v in VARIANTS if v != 'smallworld'])      # (Smallworld's are random: test below)
 def test_symmetries(golden_dir, variant):
     d = load(golden_dir, 'sym_%s.npz' % variant)
     g = O.OracleGame(*VARIANTS[variant])
@@ -76,7 +76,7 @@ def oracle_tree_digest(mc, game):
 
 
 MCTS_VARIANTS = ['splendor2', 'splendor4', 'santorini1', 'santorini11', 'azul']
-MCTS_SMALL = MCTS_VARIANTS + ['abalone', 'akropolis']          # (no 800-simulation file for the f4 games)
+MCTS_SMALL = MCTS_VARIANTS + ['abalone', 'akropolis', 'smallworld']          # (no 800-simulation file for the f4 games)
 
 
 @pytest.mark.parametrize('variant,typing,prefix', [(v, t, 'mcts') for v in MCTS_SMALL for t in ('numpy2', 'numba')] +
@@ -134,3 +134,23 @@ def test_akropolis_init_boards(golden_dir):
         rng = g.rng(injected=d['init_uniforms'][i])
         assert np.array_equal(g.getInitBoard(rng).reshape(-1), d['init_boards'][i]) and rng.pos == 4
     assert d['score'].max() > 60 and set(d['seed'].tolist()) >= {0, -1, 31416}
+
+
+def test_smallworld_init_boards_and_random_symmetries(golden_dir):
+    """init_game draws six (people, power) pairs with np.random.choice (SmallworldLogicNumba.py:1339-1356); get_symmetries shifts both
+    scores by two np.random.randint offsets (:281-299), drawn here from the recorded counter streams"""
+    d = load(golden_dir, 'env_smallworld.npz')
+    g = O.OracleGame(O.SMALLWORLD)
+    for i in range(len(d['init_boards'])):
+        rng = g.rng(injected=d['init_uniforms'][i])
+        assert np.array_equal(g.getInitBoard(rng).reshape(-1), d['init_boards'][i]) and rng.pos == 12
+    st = d['next_state'].reshape(-1, 40, 8)
+    assert len(set(np.abs(st[:, 23:29, 1]).reshape(-1).tolist())) == 15 and len(set(np.abs(st[:, 23:29, 2]).reshape(-1).tolist())) >= 19
+    s = load(golden_dir, 'sym_smallworld.npz')
+    for j in range(len(s['state'])):
+        rng = g.rng(seed=int(s['seed']), stream=j)
+        sy = g.getSymmetries(s['state'][j], s['pi'][j], s['valids'][j], max_sym=3, rng=rng)
+        assert len(sy) == int(s['count'][j]) == 3 and rng.counter == int(s['draws'][j]) == 2
+        for k, (s_, p_, v_) in enumerate(sy):
+            assert np.array_equal(s_.reshape(-1), s['out_state'][j, k]) and np.array_equal(p_, s['out_pi'][j, k])
+            assert np.array_equal(v_, s['out_valids'][j, k].astype(bool))

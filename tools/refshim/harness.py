@@ -37,7 +37,7 @@ _tmp_roots = []
 def _purge_modules():
     for name in list(sys.modules):
         root = name.split('.')[0]
-        if root in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'botanik', 'akropolis', 'MCTS', 'Game', 'Coach', 'Arena', 'utils', 'GameSwitcher',
+        if root in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'botanik', 'akropolis', 'smallworld', 'MCTS', 'Game', 'Coach', 'Arena', 'utils', 'GameSwitcher',
                     'NeuralNet'):
             del sys.modules[name]
 
@@ -50,7 +50,7 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     for name in os.listdir(REFERENCE):
         src = os.path.join(REFERENCE, name)
         if os.path.isdir(src):
-            if name in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'botanik', 'akropolis'):
+            if name in ('splendor', 'santorini', 'azul', 'minivilles', 'abalone', 'thelittleprince', 'botanik', 'akropolis', 'smallworld'):
                 shutil.copytree(src, os.path.join(tmp, name),
                                 ignore=shutil.ignore_patterns('*.pt', '*.gif', '*.jpg', '*.png', '*.mp4', '*.csv',
                                                               '__pycache__'))
@@ -127,6 +127,13 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     except Exception as e:  # pragma: no cover
         mods['AkropolisGame'] = None
         mods['akropolis_error'] = e
+    try:
+        mods['SmallworldGame'] = importlib.import_module('smallworld.SmallworldGame')
+        mods['SmallworldLogicNumba'] = importlib.import_module('smallworld.SmallworldLogicNumba')
+        mods['SmallworldConstants'] = importlib.import_module('smallworld.SmallworldConstants')
+    except Exception as e:  # pragma: no cover
+        mods['SmallworldGame'] = None
+        mods['smallworld_error'] = e
     mods['MCTS'] = importlib.import_module('MCTS')
     mods['utils'] = importlib.import_module('utils')
     return mods
