@@ -18,6 +18,7 @@
 #include "game_tlp.hip.h"
 #include "game_botanik.hip.h"
 #include "game_akropolis.hip.h"
+#include "game_smallworld.hip.h"
 #include "selfplay.hip.h"
 #include "azg_host.h"
 
@@ -48,6 +49,7 @@ extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
         else if ((game) == AZG_TLP && (variant) == 4) { using G = TLPDev<4>; __VA_ARGS__; }               \
         else if ((game) == AZG_BOTANIK) { using G = BotanikDev; __VA_ARGS__; }                             \
         else if ((game) == AZG_AKROPOLIS) { using G = AkropolisDev; __VA_ARGS__; }                         \
+        else if ((game) == AZG_SMALLWORLD) { using G = SmallworldDev; __VA_ARGS__; }                       \
         else return fail("unsupported game/variant");                                              \
     } while (0)
 
@@ -64,6 +66,7 @@ static int norm_variant(int game, int variant) {
     if (game == AZG_TLP) return variant ? variant : 3;
     if (game == AZG_BOTANIK) return 2;
     if (game == AZG_AKROPOLIS) return 2;
+    if (game == AZG_SMALLWORLD) return 2;
     return variant;
 }
 

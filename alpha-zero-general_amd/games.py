@@ -75,7 +75,7 @@ class HipGame:
         return out
 
     def max_symmetries(self):
-        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1, 4: 12, 5: 2 * self.P + 1, 6: 14, 7: 6}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles, Abalone, TLP, Botanik, Akropolis
+        return {0: 10 + 2 * self.P, 1: 8, 2: 120, 3: 1, 4: 12, 5: 2 * self.P + 1, 6: 14, 7: 6, 8: 3}[self.GAME_ID]    # Splendor, Santorini, Azul, Minivilles, Abalone, TLP, Botanik, Akropolis, Smallworld
 
     def symmetries_batch(self, boards, pi, valids, max_sym=None, rng_seed=None, stream0=0):
         """getSymmetries for n (board int8[n,S], pi f32[n,A], valids u8[n,A]) triples on device ->
@@ -221,6 +221,15 @@ class AkropolisGame(HipGame):
         super().__init__(2, **kw)
 
 
+class SmallworldGame(HipGame):
+    """smallworld/SmallworldGame.py (NUMBER_PLAYERS 2 with its 23-area map: the shipped constants).  getSymmetries draws two random
+    score offsets (SmallworldLogicNumba.py:281-299) from the engine's counter RNG streams."""
+    GAME_ID = _lib.SMALLWORLD
+
+    def __init__(self, **kw):
+        super().__init__(2, **kw)
+
+
 def import_game(name, **kw):
     """GameSwitcher.import_game equivalent (GameSwitcher.py:15-24) for the games on the hot path."""
     if name == 'splendor':
@@ -239,4 +248,6 @@ def import_game(name, **kw):
         return BotanikGame(**kw)
     if name == 'akropolis':
         return AkropolisGame(**kw)
+    if name == 'smallworld':
+        return SmallworldGame(**kw)
     raise ValueError('game %r is not on the accelerated path' % name)

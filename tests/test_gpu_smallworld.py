@@ -1,0 +1,27 @@
+"""GPU parity of the Smallworld plugin's random symmetries: get_symmetries shifts both scores by two
+np.random.randint offsets (SmallworldLogicNumba.py:281-299); the engine draws them from the counter streams the reference drew from
+(tools/gen_golden_smallworld.py).  Everything else of the plugin runs through the standard parametrised tests (test_gpu_env / _mcts /
+_selfplay with variant 'smallworld')."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_smallworld_random_symmetries_vs_golden(golden_dir):
+    from azg_amd import games
+    d = np.load(os.path.join(golden_dir, 'sym_smallworld.npz'))
+    g = games.SmallworldGame()
+    dev = g.device
+    assert g.max_symmetries() == 3 and (g.S, g.A, g.P) == (320, 131, 2)
+    ob, op, ov, cnt = g.symmetries_batch(torch.from_numpy(d['state']).to(dev), torch.from_numpy(d['pi']).to(dev),
+                                         torch.from_numpy(d['valids']).to(dev), rng_seed=int(d['seed']), stream0=0)
+    assert np.array_equal(cnt.cpu().numpy(), d['count'])
+    assert np.array_equal(ob.cpu().numpy(), d['out_state']) and np.array_equal(op.cpu().numpy(), d['out_pi'])
+    assert np.array_equal(ov.cpu().numpy(), d['out_valids'])
+    b0 = d['state'][3].reshape(g.getBoardSize())
+    syms = g.getSymmetries(b0, d['pi'][3], d['valids'][3].astype(bool))
+    assert len(syms) == 3 and np.array_equal(syms[0][0], b0) and not np.array_equal(syms[1][0], b0)
