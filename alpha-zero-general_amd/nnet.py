@@ -795,3 +795,27 @@ class SantoriniV78Hip(SantoriniV89Hip):
         self._lib.check(self._lib.lib().azg_nn_s78_forward(p(boards), p(valids), self.ptrs, 10, self.A, self.P, B, p(self.pi),
                                                            p(self.v), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return self.pi[:B], self.v[:B]
+
+
+
+class TorchModuleEvaluator:
+    """Leaf evaluator around ANY torch module with the reference's forward signature
+    `module(board f32[B, *board_shape], valid_actions bool[B, A]) -> (log_pi f32[B, A], v f32[B, P])` -- the torch branch of
+    GenericNNetWrapper.predict (:111-120) batched on PyTorch-ROCm.  It is the evaluator of the games whose nets have no engine
+    kernel: the six f4 games with the reference's own `<G>NNet` modules (import them from the reference, load their checkpoints
+    as usual) or a user's architecture.  Same `predict_batch` contract as the engine-kernel nets, so SelfPlayEngine / BatchedMCTS /
+    BatchedArena / Coach take it unchanged (HIP-graph capture included: the module runs inside the captured round)."""
+
+    def __init__(self, module, game, max_batch=None):
+        self.module = module.to(game.device).eval()
+        self.shape = tuple(game.getBoardSize())
+        self.device = game.device
+
+    def predict_batch(self, boards, valids):
+        with torch.no_grad():
+            b = boards.reshape((boards.shape[0],) + self.shape).to(torch.float32)
+            log_pi, v = self.module(b, valids.bool())
+            return torch.exp(log_pi).to(torch.float32).contiguous(), v.to(torch.float32).contiguous()
+
+    def clone_buffers(self):
+        return self

@@ -46,6 +46,8 @@ def evaluator_for(module, game, max_batch):
     """engine-kernel evaluator (one launch per leaf batch) of a trainable module's current weights"""
     sd = {k: v.detach().cpu() for k, v in module.state_dict().items()}
     dev, ver = str(game.device), getattr(module, 'version', 80)
+    if not isinstance(module, (_train.SplendorV80Module, _train.AzulV84Module, _train.SantoriniV89Module, _train.SantoriniV78Module)):
+        return _nn.TorchModuleEvaluator(module, game, max_batch)
     if ver == 84:
         return _nn.MobileNet1dHip(_nn.AzulV84(sd, num_players=game.P, device=dev), max_batch=max_batch)
     if ver in (88, 89):
@@ -64,14 +66,18 @@ def decode_examples(examples):
 
 
 class NNetWrapper:
-    def __init__(self, game, nn_args):
+    def __init__(self, game, nn_args, module=None):
+        """module: a torch module with the reference's forward signature for a game / architecture without an engine net (the f4
+        games with the reference's <G>NNet classes); inference then runs it on PyTorch-ROCm (nnet.TorchModuleEvaluator)"""
         self.game = game
         self.args = nn_args
         self.board_size, self.action_size, self.num_players = game.getBoardSize(), game.getActionSize(), game.num_players
         self.requestKnowledgeTransfer = False
         ver = self._arg('nn_version', -1)
-        self.nnet = None
-        if ver is not None and ver > 0:
+        self.nnet, self._custom = module, module is not None
+        if module is not None:
+            pass
+        elif ver is not None and ver > 0:
             self.nnet = _module_for(game, ver, float(self._arg('dropout', 0.0) or 0.0))
         else:
             # pit.py:44 builds the wrapper with nn_version = -1 and lets load_checkpoint bring the model (:258-260)
@@ -109,7 +115,7 @@ class NNetWrapper:
         lr = self._arg('learn_rate', self._arg('lr', 3e-3))
         hist = _train.train(self.nnet, cols, learn_rate=float(lr), batch_size=int(self._arg('batch_size', 32)),
                             epochs=int(self._arg('epochs', 1)), q_weight=float(self._arg('q_weight', 0.5)),
-                            device=str(self.game.device), seed=seed, log=log)
+                            device=str(self.game.device), seed=seed, log=log, board_shape=self.board_size if self._custom else None)
         self._eval = None
         return hist
 
@@ -143,11 +149,11 @@ class NNetWrapper:
                 return None
         ver = getattr(ck.get('full_model'), 'version', ck.get('nn_version'))
         want = self._arg('nn_version', -1)
-        if want is not None and want > 0 and ver is not None and ver != want:          # :250-253
+        if not self._custom and want is not None and want > 0 and ver is not None and ver != want:          # :250-253
             print('Checkpoint includes NN version', ver, ', but you ask version', want, ' so not loading it and initiate knowledge transfer')
             self.requestKnowledgeTransfer = True
             return ck
-        if self.nnet is None or getattr(self.nnet, 'version', None) != ver:
+        if not self._custom and (self.nnet is None or getattr(self.nnet, 'version', None) != ver):
             self.nnet = _module_for(self.game, ver, float(self._arg('dropout', 0.0) or 0.0))
         sd = {k: torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v for k, v in ck['state_dict'].items()}
         self.nnet.load_state_dict(sd, strict=True)

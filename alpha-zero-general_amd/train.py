@@ -215,11 +215,15 @@ def loss_v(target_z, target_q, out_v, q_weight):                               #
     return torch.sum((t - out_v) ** 2) / (target_z.shape[0] * target_z.shape[-1])
 
 
-def train(module, examples, learn_rate=3e-3, batch_size=512, epochs=2, q_weight=0.5, device='cuda:0', seed=None, log=None):
+def train(module, examples, learn_rate=3e-3, batch_size=512, epochs=2, q_weight=0.5, device='cuda:0', seed=None, log=None, board_shape=None):
     """examples = (boards int8[n,S], pi f32[n,A], z f32[n,P], valids u8/bool[n,A], q f32[n,P]) tensors or arrays.
-    Returns the list of (pi loss, v loss) per step."""
+    board_shape: give it for a module that expects the reference's inputs (float boards of getBoardSize(), bool valids:
+    GenericNNetWrapper.py:60-63) instead of the engine modules' flat int8 boards.  Returns the list of (pi loss, v loss) per step."""
     boards, pi, z, valids, q = [torch.as_tensor(np.asarray(x.cpu()) if hasattr(x, 'cpu') else x).to(device) for x in examples[:5]]
     n = boards.shape[0]
+    valids = valids.bool()
+    if board_shape is not None:
+        boards = boards.reshape((n,) + tuple(board_shape)).to(torch.float32)
     steps_per_epoch = n // batch_size
     if steps_per_epoch == 0:
         raise ValueError('fewer examples (%d) than batch_size (%d)' % (n, batch_size))

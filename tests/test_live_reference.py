@@ -111,3 +111,47 @@ def test_checkpoints_cross_load(ref, tmp_path):
     got = rw2.load_checkpoint(str(tmp_path), 'from_engine.pt')
     assert got is not None and got['cpuct'] == 0.8 and not rw2.requestKnowledgeTransfer
     assert all(torch.equal(v, ref_sd[k]) for k, v in rw2.nnet.state_dict().items())
+
+
+def test_reference_f4_module_through_torch_evaluator():
+    """A game without an engine net runs on the reference's OWN module: thelittleprince/TLPNNet.py + pretrained_3players.pt behind
+    nnet.TorchModuleEvaluator give the policies / values of the reference's wrapper (GenericNNetWrapper.predict, torch branch)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools', 'refshim'))
+    import importlib
+    import harness as H
+    from azg_amd.nnet import TorchModuleEvaluator
+    from azg_amd.nnet_wrapper import NNetWrapper
+    m = H.load_reference(tlp_players=3)
+    try:
+        with H.CounterRandom(seed=1, stream=0):
+            game = m['TLPGame'].TLPGame()
+        RefWrapper = importlib.import_module('thelittleprince.NNet').NNetWrapper
+        ref = RefWrapper(game, {'nn_version': -1, 'no_compression': False, 'learn_rate': 1e-3, 'dropout': 0., 'epochs': 1, 'batch_size': 8,
+                                'q_weight': 0.5, 'vl_weight': 0.})
+        ck = ref.load_checkpoint(os.path.join(REFERENCE, 'thelittleprince'), 'pretrained_3players.pt')
+        assert ck is not None
+        ref.current_mode = 'cpu'                              # torch branch of predict (no ONNX export)
+        ref.switch_target = lambda *_a, **_k: None
+
+        class CpuGame:
+            GAME_ID, variant, P, A, num_players, device = 5, 3, 3, 9, 3, 'cpu'
+
+            def getBoardSize(self):
+                return (55, 15)
+
+            def getActionSize(self):
+                return 9
+        ev = TorchModuleEvaluator(ref.nnet, CpuGame())
+        d = np.load(os.path.join(GOLDEN, 'env_tlp3.npz'))
+        idx = np.arange(0, len(d['canonical']), 9)
+        boards = torch.from_numpy(d['canonical'][idx])
+        valids = torch.from_numpy(np.stack([game.getValidMoves(d['canonical'][i].reshape(55, 15), 0) for i in idx]).astype(np.uint8))
+        pi, v = ev.predict_batch(boards, valids)
+        for k, i in enumerate(idx):
+            rp, rv = ref.predict(d['canonical'][i].reshape(55, 15), valids[k].numpy().astype(bool))
+            assert np.allclose(pi[k].numpy(), rp, atol=2e-6) and np.allclose(v[k].numpy(), rv, atol=2e-6), i
+        # the NeuralNet plugin object takes the same module (inference object only checked for its type here: no GPU)
+        w = NNetWrapper(CpuGame(), {'nn_version': -1}, module=ref.nnet)
+        assert w.nnet is ref.nnet and w._custom
+    finally:
+        H.cleanup()
