@@ -14,6 +14,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fP
 UNITS = [('azg.hip', []), ('azg_nn.hip', [])]
 # debugging builds: AZG_DEFINES="AZG_CYC_COUNTERS AZG_NN_PHASE_TIMES" python alpha-zero-general_amd/build.py
 FLAGS += ['-D' + d for d in os.environ.get('AZG_DEFINES', '').split()]
+FLAGS += os.environ.get('AZG_EXTRA_FLAGS', '').split()            # e.g. -ftrivial-auto-var-init=pattern when hunting an uninitialised local
 
 
 def sources():

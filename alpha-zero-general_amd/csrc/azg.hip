@@ -159,6 +159,28 @@ extern "C" int azg_env_symmetries(int game, int variant, const int8_t* states, c
     return azg_env_symmetries_ex(game, variant, states, pi, valids, n, max_sym, out_states, out_pi, out_valids, out_count, 0, 0, stream);
 }
 
+// debugging aid: leave a known pattern in the LDS of every CU and in the scratch (private) memory of the queue, so that a kernel that reads
+// LDS or a local variable it never wrote changes its results with the pattern instead of with whatever ran before it
+__global__ __launch_bounds__(1024) void k_debug_poison(uint32_t pattern, uint32_t* sink, int mode) {
+    __shared__ uint32_t lds[16000];
+    volatile uint32_t priv[512];
+    if (mode & 1) for (int i = threadIdx.x; i < 16000; i += 1024) lds[i] = pattern;
+    if (mode & 2) for (int i = 0; i < 512; i++) priv[i] = pattern;
+    __syncthreads();
+    uint32_t acc = lds[(threadIdx.x * 7) % 16000];
+    for (int i = 0; i < 512; i += 37) acc ^= priv[i];
+    if (acc == 0x12345u) sink[0] = acc;
+}
+extern "C" int azg_debug_poison_onchip(uint32_t pattern, void* stream) {
+    static uint32_t* sink = nullptr;
+    if (!sink) HIPCHK(hipMalloc(&sink, 64));
+    const int mode = getenv("AZG_POISON_MODE") ? atoi(getenv("AZG_POISON_MODE")) : 3;      // 1 LDS, 2 scratch
+    k_debug_poison<<<dim3(4096), dim3(1024), 0, (hipStream_t)stream>>>(pattern, sink, mode);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
 // ---- forest ---------------------------------------------------------------------------------------------------------
 struct azg_forest {
     azg_forest_cfg cfg;
@@ -185,6 +207,11 @@ static int dalloc(azg_forest* f, T** p, size_t count) {
         (void)hipGetLastError();        // clear the sticky error: the caller may retry with a smaller forest
         return fail(std::string("hipMalloc(") + std::to_string(b) + "): " + hipGetErrorString(e));
     }
+    // debugging aid: AZG_DEBUG_POISON = bit mask over the allocations in order (hdr 0, node_hdr 1, node_state 2, heap 3, htab 4, free_ids 5,
+    // rec_free 6, path 7, root_state 8, board 9, rec_* 10..15, ex_* 16..21, ex_count 22) -> filled with 0xA5 before first use, so that a
+    // read of memory the engine never wrote changes results instead of depending on what the allocator hands out
+    static const unsigned long long poison = getenv("AZG_DEBUG_POISON") ? strtoull(getenv("AZG_DEBUG_POISON"), nullptr, 0) : 0ull;
+    if ((poison >> f->allocs.size()) & 1ull) (void)hipMemset(q, 0xA5, b);
     f->allocs.push_back(q);
     f->bytes += b;
     *p = (T*)q;
@@ -377,7 +404,7 @@ extern "C" int azg_forest_active(azg_forest* f, int* n_active) {
     for (auto& x : h) { n += (x.status == ST_SEARCHING || x.status == ST_WAIT_NN); err |= x.err; }
     *n_active = n;
     if (err) return fail("forest error flags: " + std::to_string(err) +
-                         " (1=node overflow 2=row-heap overflow 4=depth overflow 16/32=example overflow)");
+                         " (1=node overflow 2=row-heap overflow 4=depth overflow 16/32=example overflow 64=all pruned root counts are 0)");
     return 0;
 }
 
@@ -555,6 +582,11 @@ extern "C" int azg_selfplay_advance(azg_forest* f, void* stream) {
     FDISPATCH(f, k_gc<G><<<dim3(f->dev.T), dim3(1024), 0, (hipStream_t)stream>>>(f->dev));
     if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "[azg] k_after_gc\n"); fflush(stderr); }
     FDISPATCH(f, k_after_gc<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev));
+    // root Dirichlet noise (device sampler) of the searches that just began on an existing root and of the roots that simulation 0
+    // expanded since the last advance (MCTS.py:64,147-149,156-160): ONE piece of code applies it, in its own kernel, so that the f64
+    // pow / log / cos of the Gamma sampler weigh on no other kernel's registers
+    if (f->cfg.dirichletAlpha != 0.0)
+        FDISPATCH(f, k_root_noise<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev, nullptr, -1));
     if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "[azg] advance done\n"); fflush(stderr); }
     HIPCHK(hipGetLastError());
     return 0;

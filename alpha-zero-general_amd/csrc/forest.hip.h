@@ -36,7 +36,8 @@ enum : uint32_t { ST_IDLE = 0, ST_SEARCHING = 1, ST_WAIT_NN = 2, ST_DONE = 3,
 enum : uint8_t { NF_TERMINAL = 1, NF_EXPANDED = 2, NF_FREE = 4 };   // NF_FREE: node id on the free stack (NodeHdr only)
 enum : uint32_t {
     ERR_NODE_OVERFLOW = 1, ERR_HEAP_OVERFLOW = 2, ERR_DEPTH_OVERFLOW = 4, ERR_BAD_STATE = 8, ERR_EXAMPLE_OVERFLOW = 16,
-    ERR_REC_OVERFLOW = 32
+    ERR_REC_OVERFLOW = 32,
+    ERR_EMPTY_POLICY = 64      // every pruned root count is 0: the reference divides 0 / 0 here (MCTS.py:77-80,100-102)
 };
 
 // phase cycle counters of k_select (azg_selfplay_stats.cyc_*): compiled in only with -DAZG_CYC_COUNTERS (tools/dbg_cycles.py),

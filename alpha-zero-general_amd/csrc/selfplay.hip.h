@@ -192,8 +192,9 @@ __device__ __forceinline__ void begin_next_search(const ForestDev& F, int t, Tre
     begin_search_from_lds<G>(F, t, H, sm, u_full < F.prob_fullMCTS);
     H.rng_counter = rng.counter;
     if (H.n_nodes > H.max_nodes_seen) H.max_nodes_seen = H.n_nodes;
-    // an EXISTING root gets its noise before simulation 0 (MCTS.py:64,156-160)
-    if (H.noise_pending && root_noise_tree<G>(F, t, H.root_rec, H.c_sims, nullptr, -1, dense, sm.mask)) H.noise_pending = 0u;
+    // an EXISTING root gets its noise before simulation 0 (MCTS.py:64,156-160): begin_search_from_lds left noise_pending set, the
+    // k_root_noise launch that follows the advance kernels (azg_selfplay_advance) applies it
+    (void)dense;
 }
 
 // Self-play clean-up, one workgroup of 16 wavefronts per tree that asked for it (status ST_GC): the header scan is a chain
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(64) void k_begin_search(ForestDev F, const int8_t* 
 }
 
 template <class G>
-__global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
+__global__ __launch_bounds__(64) void k_selfplay_advance(ForestDev F) {
     using FR = Forest<G>;
     __shared__ typename FR::Smem sm;
     __shared__ int cnt[G::A];
@@ -259,10 +260,7 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     const uint32_t status0 = ld_agent_u32(&F.hdr[t].status);
     if (status0 != ST_DONE) {
         // nothing to advance; a root expanded by simulation 0 may still be waiting for its Dirichlet noise (MCTS.py:147-149)
-        if (!ld_agent_u32(&F.hdr[t].noise_pending) || status0 != ST_SEARCHING) return;
-        const uint32_t root_rec = ld_agent_u32(&F.hdr[t].root_rec);
-        const uint64_t c_sims = ld_agent_u64(&F.hdr[t].c_sims);
-        if (root_noise_tree<G>(F, t, root_rec, c_sims, nullptr, -1, dense, sm.mask) && l == 0) F.hdr[t].noise_pending = 0u;
+        // (k_root_noise, launched right after, serves it)
         return;
     }
     TreeHdr H = load_uniform(&F.hdr[t]);
@@ -275,6 +273,12 @@ __global__ __launch_bounds__(64, 4) void k_selfplay_advance(ForestDev F) {
     // ---- pi with temp = 1 (MCTS.py:100-103), then random_pick with the self-play temperature (Coach.py:62-63) ----
     long long tot = 0;
     for (int a = 0; a < G::A; a++) tot += cnt[a];
+    if (tot == 0) {
+        // policy-target pruning left no count above 1 (too few simulations for the number of valid actions): the reference computes 0 / 0 and
+        // raises at MCTS.py:100-102.  Park the tree with an error flag instead of playing an arbitrary move.
+        if (l == 0) atomicOr(&F.hdr[t].err, (uint32_t)ERR_EMPTY_POLICY);
+        return;
+    }
     const double T = temp_for_selfplay(F, (int)H.step + 1);
     const double u_pick = rng.u01();
     for (int a = l; a < G::A; a += 64) {

@@ -165,6 +165,9 @@ int azg_forest_root_stats(azg_forest* f, int32_t* Ns_dev, float* Qs_dev, int32_t
 int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8_t* states, int32_t* Ns, float* Qs, float* Es,
                          int32_t* Nsa, double* Qsa, float* Ps, uint8_t* has_policy);
 
+/* debug: fill the LDS of every CU and the queue's scratch memory with `pattern` (a kernel that reads on-chip memory it never wrote then
+   depends on the pattern, not on what ran before) */
+int azg_debug_poison_onchip(uint32_t pattern, void* stream);
 /* debug / tests: check the structural invariants of every tree on the host; returns the number of violations */
 int azg_forest_validate(azg_forest* f, int verbose);
 
@@ -185,7 +188,10 @@ int azg_selfplay_start_ex(azg_forest* f, const int8_t* init_boards_dev /* or NUL
 int azg_selfplay_advance(azg_forest* f, void* stream);
 /* trees that are still playing (synchronises): 0 once every tree has used up its episode quota (or stopped on an error) */
 int azg_selfplay_active(azg_forest* f, int* n_active);
-/* counters (synchronises): plies executed, games finished, simulations run, examples stored, error flags */
+/* counters (synchronises): plies executed, games finished, simulations run, examples stored, error flags.
+   errors = OR over trees: 1 node arena full, 2 record heap full, 4 descent deeper than 256, 8 bad state, 16 / 32 example ring / per-game
+   record buffer full, 64 every pruned root count was 0 (numMCTSSims too small for the game's number of valid actions with
+   forced_playouts: the reference divides 0 / 0 at MCTS.py:77-80,100-102 and raises).  A tree with an error is parked. */
 typedef struct azg_selfplay_stats {
     uint64_t plies, games, sims, levels, expansions, sum_valid_visited, terminal_hits, examples, gc_runs, max_nodes,
         errors, sum_depth_at_expand,

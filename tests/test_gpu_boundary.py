@@ -167,7 +167,7 @@ def test_nnet_wrapper_predict_checkpoints_and_coach_call_sequence(tmp_path):
     pi1, v1 = w.predict(d['boards'][3], d['masks'][3].astype(bool))
     assert np.array_equal(pi1, pi2) and np.array_equal(v1, v2)
     assert p.load_checkpoint(str(tmp_path), 'missing.pt') is None
-    args = Args(numMCTSSims=8, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, dirichletAlpha=0.3, prob_fullMCTS=1.0,
+    args = Args(numMCTSSims=8, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=False, dirichletAlpha=0.3, prob_fullMCTS=1.0,
                 ratio_fullMCTS=5, temperature=[1.25, 0.8, 1.0], tempThreshold=6, numIters=1, numEps=12, numItersHistory=2,
                 maxlenOfQueue=100000, arenaCompare=4, updateThreshold=0.6, checkpoint=str(tmp_path), n_games=8,
                 stop_after_N_fail=5, load_folder_file=[str(tmp_path), 'best.pt'])

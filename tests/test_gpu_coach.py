@@ -21,7 +21,7 @@ def test_coach_learn_two_iterations(tmp_path):
     z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'weights_splendor2_v80.npz'))
     m = SplendorV80Module(2)
     m.load_state_dict({k[3:]: torch.as_tensor(z[k]) for k in z.files if k.startswith('sd/')})
-    args = Args(numMCTSSims=8, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True, dirichletAlpha=0.3, prob_fullMCTS=1.0,
+    args = Args(numMCTSSims=8, cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=False, dirichletAlpha=0.3, prob_fullMCTS=1.0,
                 ratio_fullMCTS=5, temperature=[1.25, 0.8, 1.0], tempThreshold=6, numIters=2, numEps=16, numItersHistory=2,
                 maxlenOfQueue=100000, learn_rate=1e-3, batch_size=64, epochs=1, q_weight=0.5, arenaCompare=8,
                 updateThreshold=0.6, checkpoint=str(tmp_path))
@@ -47,7 +47,7 @@ def test_coach_learn_azul_one_iteration(tmp_path):
     z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'weights_azul_v84.npz'))
     m = AzulV84Module()
     m.load_state_dict({k[3:]: torch.as_tensor(z[k]) for k in z.files if k.startswith('sd/')})
-    args = Args(numMCTSSims=8, cpuct=0.5, fpu=0.05, universes=1, forced_playouts=True, dirichletAlpha=-1, prob_fullMCTS=1.0,
+    args = Args(numMCTSSims=8, cpuct=0.5, fpu=0.05, universes=1, forced_playouts=False, dirichletAlpha=-1, prob_fullMCTS=1.0,
                 ratio_fullMCTS=5, temperature=[1.25, 0.8, 1.0], tempThreshold=10, numIters=1, numEps=8, numItersHistory=2,
                 maxlenOfQueue=100000, learn_rate=1e-3, batch_size=64, epochs=1, q_weight=1.0, arenaCompare=4,
                 updateThreshold=0.6, checkpoint=str(tmp_path))

@@ -126,7 +126,13 @@ def test_advance_cadence_does_not_change_results():
                 tempThreshold=6, **MCTS_ARGS['splendor2'])
     T = 32
     res = []
+    import ctypes
+    from azg_amd._lib import lib
+    lib().azg_debug_poison_onchip.argtypes = [ctypes.c_uint32, ctypes.c_void_p]
     for K, graph, fused in ((1, False, False), (5, True, True), (3, True, False), (1, False, True)):
+        # a different pattern in every CU's LDS and in the queue's scratch memory before each run: a kernel that reads on-chip memory it
+        # never wrote (this test once depended on stale spill slots) shows up as a cadence dependence
+        lib().azg_debug_poison_onchip((0x7FC00000, 0xFFFFFFFF, 0xA5A5A5A5, 0x00010001)[len(res)], None)
         e = SelfPlayEngine(g, HashNetTorch(2), args, T, node_capacity=2048, max_examples=T * 400, rng_seed=99, stream0=7,
                            use_graph=graph, advance_every=K, fused=fused)
         e.start()
@@ -262,8 +268,9 @@ def _mini_engine(T=16, sims=12, max_examples=None, rng_seed=11):
     from azg_amd.selfplay import SelfPlayEngine
     from hashnet import HashNetTorch
     g = games.SplendorGame(2)
+    # (no policy-target pruning: with a dozen simulations it often leaves no count above 1, see test_empty_pruned_policy_...)
     args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0],
-                tempThreshold=6, **MCTS_ARGS['splendor2'])
+                tempThreshold=6, **{**MCTS_ARGS['splendor2'], 'forced_playouts': False})
     return SelfPlayEngine(g, HashNetTorch(2), args, T, node_capacity=1024, max_examples=max_examples or T * 400,
                           rng_seed=rng_seed, use_graph=False)
 
@@ -336,3 +343,29 @@ def test_example_ring_overflow_is_loud_and_never_truncates_a_game():
             assert np.array_equal(plies, np.arange(len(plies)))
     for grp in e.groups:
         grp.f.close()
+
+
+def test_empty_pruned_policy_is_an_error_not_a_move():
+    """With a dozen simulations and policy-target pruning a root often has no count above 1: the reference's pruned policy is then
+    0 / 0 (MCTS.py:77-80,100-102 raises ZeroDivisionError); the engine parks the tree with error bit 64 instead of playing an
+    arbitrary move."""
+    from azg_amd import games
+    from azg_amd.forest import Forest
+    from hashnet import HashNetTorch
+    g = games.SplendorGame(2)
+    T = 16
+    args = Args(numMCTSSims=12, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1.0, 1.0, 1.0], tempThreshold=6,
+                cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True)
+    f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=512, max_examples=T * 64)
+    net = HashNetTorch(2)
+    f.selfplay_start()
+    for rnd in range(2000):
+        f.select()
+        pi, vv = net.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid.bool())
+        f.expand_backup(pi, vv)
+        f.selfplay_advance()
+        if rnd % 100 == 99 and f.stats()['errors']:
+            break
+    st = f.stats()
+    assert st['errors'] == 64, st
+    f.close()
