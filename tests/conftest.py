@@ -19,3 +19,13 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+
+def poison_onchip(pattern=0xFFFFFFFF):
+    """debug hook of the engine: leave `pattern` in every CU's LDS and in the default queue's scratch memory, so that a kernel reading
+    on-chip memory it never wrote fails its parity test instead of depending on what ran before"""
+    import ctypes
+    from azg_amd._lib import lib
+    lib().azg_debug_poison_onchip.argtypes = [ctypes.c_uint32, ctypes.c_void_p]
+    lib().azg_debug_poison_onchip(pattern, None)

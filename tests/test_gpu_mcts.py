@@ -79,6 +79,8 @@ def test_whole_tree_vs_oracle(variant):
     import azg_oracle as O
     from azg_amd.mcts import BatchedMCTS
     from hashnet import HashNetTorch
+    from conftest import poison_onchip
+    poison_onchip(0xFFFFFFFF)
     g = make(variant)
     name, v = {**VARIANTS, **F4_VARIANTS}[variant]
     og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'abalone': O.ABALONE, 'akropolis': O.AKROPOLIS, 'smallworld': O.SMALLWORLD}[name], v)
