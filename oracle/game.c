@@ -121,11 +121,13 @@ int azo_game_init(azo_game* g, int game_id, int variant) {
         return 0;
     }
     if (game_id == AZO_SMALLWORLD) {
-        g->variant = 2;
-        g->P = 2;
-        g->rows = 40; g->cols = 8;           /* observation_size (NB_AREAS + 5 NUMBER_PLAYERS + 7, 8), SmallworldLogicNumba.py:92-94 */
-        g->S = 320;
-        g->A = 131;                          /* :96-98 */
+        const int n = variant ? variant : 2, na = n == 2 ? 23 : (n == 3 ? 30 : 39);      /* SmallworldMaps_<n>pl.py NB_AREAS */
+        if (n < 2 || n > 4) return -1;
+        g->variant = n;
+        g->P = n;
+        g->rows = na + 5 * n + 7; g->cols = 8;   /* observation_size, SmallworldLogicNumba.py:92-94 */
+        g->S = g->rows * 8;
+        g->A = 5 * na + 16;                  /* action_size :96-98 */
         return 0;
     }
     if (game_id == AZO_AKROPOLIS) {

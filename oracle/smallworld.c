@@ -1,7 +1,8 @@
 /* ORACLE (test infrastructure).  Smallworld env step: a scalar restatement of smallworld/SmallworldLogicNumba.py (Board :141-1508)
- * for the shipped configuration (smallworld/SmallworldConstants.py: NUMBER_PLAYERS = 2, SmallworldMaps_2pl.py: 23 areas, 10 rounds).
+ * for NUMBER_PLAYERS = 2 (the shipped constant), 3 and 4 with their maps (smallworld/SmallworldMaps_<n>pl.py: 23 / 30 / 39 areas,
+ * 10 / 10 / 9 rounds).
  *
- * State = int8 [40][8] (:11-60): rows 0..22 territories {nb people, people type (negative in decline, -15 lost tribe), power, defence
+ * State = int8 [NB_AREAS + 5 n + 7][8] (:11-60; indices below for 2 players): rows 0..22 territories {nb people, people type (negative in decline, -15 lost tribe), power, defence
  * due to the people, defence due to the power, total defence, points if scored now, owner (-1 none)}; rows 23 + 3 p + id peoples of
  * player p (id 0 declined-spirit, 1 declined, 2 active) {nb in hand, type, power, people data, power data, -, points, player};
  * rows 29..34 visible deck {nb, type, power, -, -, -, coins, -1}; rows 35 + p round status {people on the map, -, -, #NETWDT, phase,
@@ -19,7 +20,17 @@
 #include "smallworld_tables.h"
 
 enum { FORESTT, FARMLAND, HILLT, SWAMPT, MOUNTAIN, WATER };
-enum { NA = 23, NP = 2, DECK_SIZE = 6, SCORE_INIT = 5, IMMUNITY = 20, MAX_REDEPLOY = 8, MAX_DICE = 3, NB_ROUNDS = 10 };
+enum { DECK_SIZE = 6, SCORE_INIT = 5, IMMUNITY = 20, MAX_REDEPLOY = 8, MAX_DICE = 3, MAXNA = 39, MAXNP = 4 };
+/* the map of the bound game (NUMBER_PLAYERS picks it, SmallworldMaps.py): set by sw_bind() at every entry point */
+static __thread int NA = SW_NA_2, NP = 2, NB_ROUNDS = SW_ROUNDS_2;
+static __thread const uint8_t* SW_DESCR = SW_DESCR_2;
+static __thread const uint64_t* SW_CONN = SW_CONN_2;
+static void sw_bind(const azo_game* g) {
+    NP = g->P;
+    if (NP == 2) { NA = SW_NA_2; NB_ROUNDS = SW_ROUNDS_2; SW_DESCR = SW_DESCR_2; SW_CONN = SW_CONN_2; }
+    else if (NP == 3) { NA = SW_NA_3; NB_ROUNDS = SW_ROUNDS_3; SW_DESCR = SW_DESCR_3; SW_CONN = SW_CONN_3; }
+    else { NA = SW_NA_4; NB_ROUNDS = SW_ROUNDS_4; SW_DESCR = SW_DESCR_4; SW_CONN = SW_CONN_4; }
+}
 enum { DECLINED_SPIRIT = 0, DECLINED = 1, ACTIVE = 2 };
 enum { PHASE_READY = 1, PHASE_CHOOSE, PHASE_ABANDON, PHASE_CONQUEST, PHASE_CONQ_WITH_DICE, PHASE_ABANDON_AMAZONS, PHASE_REDEPLOY,
        PHASE_STOUT_TO_DECLINE, PHASE_WAIT };
@@ -55,9 +66,9 @@ static int choice_idx(ctx* c, int n) {                                     /* np
 static int64_t pmod64(int64_t a, int64_t m) { int64_t r = a % m; return r < 0 ? r + m : r; }
 
 static int8_t* current_ppl(int8_t* s, int player) { return PPL(s, player, GS(s, player)[4]); }      /* :956-960 */
-static uint32_t occupied_by(const int8_t* s, const int8_t* ppl) {                                     /* _are_occupied_by :973-974 */
-    uint32_t m = 0;
-    for (int a = 0; a < NA; a++) if (T(s, a)[1] == ppl[1]) m |= 1u << a;
+static uint64_t occupied_by(const int8_t* s, const int8_t* ppl) {                                     /* _are_occupied_by :973-974 */
+    uint64_t m = 0;
+    for (int a = 0; a < NA; a++) if (T(s, a)[1] == ppl[1]) m |= 1ull << a;
     return m;
 }
 static int8_t* ppl_owner_of(int8_t* s, int area, int* owner) {                                        /* :962-968 */
@@ -82,21 +93,21 @@ static int minimum_ppl_for_attack(const int8_t* s, int area, const int8_t* cp) {
     if (cp[2] == UNDERWORLD && CAVERN(area)) m--;
     return m > 1 ? m : 1;
 }
-static int total_number_of_ppl(const int8_t* s, const int8_t* cp, uint32_t terr) {                     /* :1047-1053 */
+static int total_number_of_ppl(const int8_t* s, const int8_t* cp, uint64_t terr) {                     /* :1047-1053 */
     int n = cp[0];
     for (int a = 0; a < NA; a++) if ((terr >> a) & 1) n += T(s, a)[0];
     return n;
 }
-static int limit_added_ppl(const int8_t* s, const int8_t* cp, int addition, int maximum, uint32_t terr) {   /* :1055-1057 */
+static int limit_added_ppl(const int8_t* s, const int8_t* cp, int addition, int maximum, uint64_t terr) {   /* :1055-1057 */
     const int room = maximum - total_number_of_ppl(s, cp, terr);
     return addition < room ? addition : room;
 }
-static int surplus_on_board(const int8_t* s, uint32_t terr) {               /* my_dot(max(territories[:,0] - 1, 0), territories_of_player) */
+static int surplus_on_board(const int8_t* s, uint64_t terr) {               /* my_dot(max(territories[:,0] - 1, 0), territories_of_player) */
     int n = 0;
     for (int a = 0; a < NA; a++) if (((terr >> a) & 1) && T(s, a)[0] > 1) n += T(s, a)[0] - 1;
     return n;
 }
-static int ppl_virtually_available(const int8_t* s, int player, const int8_t* cp, int next_status, uint32_t terr) {   /* :1206-1233 */
+static int ppl_virtually_available(const int8_t* s, int player, const int8_t* cp, int next_status, uint64_t terr) {   /* :1206-1233 */
     const int old = RS((int8_t*)s, player)[4];
     int n = cp[0];
     if (old == PHASE_READY && in3(next_status, PHASE_ABANDON, PHASE_CONQUEST, PHASE_CONQ_WITH_DICE)) n += surplus_on_board(s, terr);
@@ -322,11 +333,11 @@ static void valids_attack(int8_t* s, int player, uint8_t* v) {                  
     const int phase = RS(s, player)[4];
     if (cp[1] == NOPPL) return;
     if (!(phase == PHASE_READY || phase == PHASE_CHOOSE || phase == PHASE_ABANDON || phase == PHASE_CONQUEST)) return;
-    const uint32_t terr = occupied_by(s, cp);
+    const uint64_t terr = occupied_by(s, cp);
     int avail = ppl_virtually_available(s, player, cp, PHASE_CONQUEST, terr);
     if (avail <= 0) return;
     if (cp[2] == BERSERK && split_b(cp[4])) avail += split_a(cp[4]);
-    uint32_t neigh = 0;
+    uint64_t neigh = 0;
     int cavern_owned = 0;
     for (int a = 0; a < NA; a++) if ((terr >> a) & 1) { neigh |= SW_CONN[a]; cavern_owned |= CAVERN(a); }
     for (int a = 0; a < NA; a++) {
@@ -349,8 +360,8 @@ static void valids_redeploy(int8_t* s, int player, uint8_t* v) {                
     const int phase = RS(s, player)[4];
     if (cp[1] == NOPPL) return;
     if (phase == PHASE_WAIT || phase == PHASE_ABANDON_AMAZONS) return;
-    const uint32_t terr = occupied_by(s, cp);
-    const int nt = __builtin_popcount(terr);
+    const uint64_t terr = occupied_by(s, cp);
+    const int nt = __builtin_popcountll(terr);
     if (nt == 0) { if (phase != PHASE_REDEPLOY) v[0] = 1; return; }
     const int avail = ppl_virtually_available(s, player, cp, PHASE_REDEPLOY, terr);
     if (avail == 0) { if (phase != PHASE_REDEPLOY) v[0] = 1; return; }
@@ -385,7 +396,7 @@ static void valids_special_ppl(int8_t* s, int player, uint8_t* v) {             
     const int phase = RS(s, player)[4];
     if (cp[1] != SORCERER) return;
     if (!(phase == PHASE_READY || phase == PHASE_CHOOSE || phase == PHASE_ABANDON || phase == PHASE_CONQUEST)) return;
-    const uint32_t terr = occupied_by(s, cp);
+    const uint64_t terr = occupied_by(s, cp);
     if (total_number_of_ppl(s, cp, terr) + 1 > MAX_SORCERERS) return;
     for (int a = 0; a < NA; a++) {
         const int8_t* t = T(s, a);
@@ -408,7 +419,7 @@ static int valid_special_pwr_area(int8_t* s, int player, int area, const int8_t*
     case FORTIFIED: case HEROIC: return t[1] == cp[1] && !(t[4] > 0);
     case DIPLOMAT: return !(cp[4] & (1 << PMOD(player - area)));
     case DRAGONMASTER: {
-        const uint32_t terr = occupied_by(s, cp);
+        const uint64_t terr = occupied_by(s, cp);
         if (TERRAIN(area) == WATER || ((terr >> area) & 1)) return 0;
         if (t[3] >= IMMUNITY || t[4] >= IMMUNITY) return 0;
         return (SW_CONN[area] & terr) != 0;
@@ -439,6 +450,7 @@ static int valid_end_aux(int8_t* s, int player, const int8_t* cp) {             
 }
 
 void smallworld_valid_moves(const azo_game* g, const int8_t* cs, int player, uint8_t* out) {             /* :197-208 */
+    sw_bind(g);
     int8_t* s = (int8_t*)cs;                      /* (read-only use) */
     memset(out, 0, (size_t)g->A);
     valids_abandon(s, player, out);
@@ -491,8 +503,8 @@ static void do_redeploy(ctx* c, int player, int param) {                        
     RS(s, player)[4] = PHASE_REDEPLOY;
     if (param != 0) {
         if (param < MAX_REDEPLOY) {
-            const uint32_t terr = occupied_by(s, cp);
-            cp[0] = (int8_t)(cp[0] - param * __builtin_popcount(terr));
+            const uint64_t terr = occupied_by(s, cp);
+            cp[0] = (int8_t)(cp[0] - param * __builtin_popcountll(terr));
             for (int a = 0; a < NA; a++) if ((terr >> a) & 1) { T(s, a)[0] = (int8_t)(T(s, a)[0] + param); T(s, a)[5] = (int8_t)(T(s, a)[5] + param); }
         } else {
             const int a = param - MAX_REDEPLOY;
@@ -659,7 +671,7 @@ static void do_special_pwr(ctx* c, int player, int area) {                      
 }
 
 int smallworld_make_move(const azo_game* g, int8_t* s, int move, int player, int64_t seed, azo_rng* rng) {   /* :210-240 */
-    (void)g;
+    sw_bind(g);
     ctx c = {s, seed, rng};
     if (move < NA) do_abandon(&c, player, move);
     else if (move < 2 * NA) do_attack(&c, player, move - NA);
@@ -673,12 +685,12 @@ int smallworld_make_move(const azo_game* g, int8_t* s, int move, int player, int
 }
 
 int smallworld_get_round(const azo_game* g, const int8_t* s) {                                           /* :245-246 */
-    (void)g;
+    sw_bind(g);
     int r = GS((int8_t*)s, 0)[3];
     for (int p = 1; p < NP; p++) if (GS((int8_t*)s, p)[3] < r) r = GS((int8_t*)s, p)[3];
     return r;
 }
-int smallworld_get_score(const azo_game* g, const int8_t* s, int p) { (void)g; return GS((int8_t*)s, p)[6] + 128; }
+int smallworld_get_score(const azo_game* g, const int8_t* s, int p) { sw_bind(g); return GS((int8_t*)s, p)[6] + 128; }
 
 void smallworld_game_ended(const azo_game* g, const int8_t* s, int next_player, float* out) {            /* :248-257 */
     (void)next_player;
@@ -691,11 +703,11 @@ void smallworld_game_ended(const azo_game* g, const int8_t* s, int next_player, 
 }
 
 void smallworld_swap_players(const azo_game* g, int8_t* s, int k) {                                      /* :260-279 */
-    (void)g;
+    sw_bind(g);
     k = PMOD(k);
     if (k == 0) return;
     for (int a = 0; a < NA; a++) if (T(s, a)[7] >= 0) T(s, a)[7] = (int8_t)PMOD(T(s, a)[7] - k);
-    int8_t tmp[3 * NP * 8];
+    int8_t tmp[3 * MAXNP * 8];
     memcpy(tmp, RS(s, 0), NP * 8);
     for (int p = 0; p < NP; p++) memcpy(RS(s, p), tmp + 8 * ((p + k) % NP), 7);
     memcpy(tmp, GS(s, 0), NP * 8);
@@ -706,6 +718,7 @@ void smallworld_swap_players(const azo_game* g, int8_t* s, int k) {             
 }
 
 void smallworld_init_board(const azo_game* g, int8_t* s, azo_rng* rng) {                                 /* :150-174, 1339-1356 */
+    sw_bind(g);
     memset(s, 0, (size_t)g->S);
     ctx c = {s, 0, rng};
     for (int a = 0; a < NA; a++) {
@@ -737,6 +750,7 @@ void smallworld_init_board(const azo_game* g, int8_t* s, azo_rng* rng) {        
 int smallworld_symmetries_rng(const azo_game* g, const int8_t* s, const float* pi, const uint8_t* valids, int8_t* os, float* op, uint8_t* ov,
                               int max_sym, azo_rng* rng) {
     const int S = g->S, A = g->A;
+    sw_bind(g);
     int k = 0;
     for (int f = 0; f < 3; f++) {
         int off = 0;

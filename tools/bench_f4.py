@@ -1,0 +1,70 @@
+"""Throughput of the six f4 game plugins on one MI355X ("each to the same parity + measurement bar"): batched
+self-play on the engine with the integer hash-net of SURVEY Appendix C.3 as the leaf evaluator (these games have no engine net; the
+figure is the env step + tree side of the plugin, `nnet.TorchModuleEvaluator` adds the user's PyTorch-ROCm module on top).
+    python tools/bench_f4.py [--games 1024 --sims 200 --plies 12]
+One JSON line per game: plies/s, simulations/s, ms per round, levels per simulation, valid actions per level, engine errors,
+structural validation of the forest afterwards."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from azg_amd import games  # noqa: E402
+from azg_amd.selfplay import SelfPlayEngine  # noqa: E402
+from hashnet import HashNetTorch  # noqa: E402
+
+
+class Args(dict):
+    __getattr__ = dict.get
+
+
+GAMES = [('minivilles', lambda: games.MinivillesGame(2), 1.0), ('abalone', games.AbaloneGame, 1.0), ('thelittleprince', lambda: games.TLPGame(3), 1.0),
+         ('botanik', games.BotanikGame, 1.0), ('akropolis', games.AkropolisGame, 0.25), ('smallworld', games.SmallworldGame, 1.0)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--games', type=int, default=1024)
+    ap.add_argument('--sims', type=int, default=200)
+    ap.add_argument('--plies', type=int, default=12, help='timed ply waves (one wave = `sims` lock-step rounds)')
+    ap.add_argument('--only', default=None)
+    a = ap.parse_args()
+    for name, make, scale in GAMES:
+        if a.only and a.only != name:
+            continue
+        g = make()
+        T = max(64, int(a.games * scale))
+        args = Args(numMCTSSims=a.sims, cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True, prob_fullMCTS=1.0, ratio_fullMCTS=5,
+                    dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0], tempThreshold=6)
+        eng = SelfPlayEngine(g, HashNetTorch(g.P), args, n_games=T, node_capacity=max(2048, 8 * a.sims), max_examples=T * 256)
+        eng.start()
+        eng.run(2 * a.sims)                                    # warm-up: two ply waves (also captures the HIP graph)
+        torch.cuda.synchronize()
+        s0 = eng.stats()
+        t0 = time.perf_counter()
+        eng.run(a.plies * a.sims)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        s1 = eng.stats()
+        sims, plies = s1['sims'] - s0['sims'], s1['plies'] - s0['plies']
+        bad = sum(grp.f.validate() for grp in eng.groups) if T <= 1024 else -1
+        print(json.dumps(dict(game=name, players=g.P, state_bytes=g.S, actions=g.A, games=T, sims_per_move=a.sims, plies_per_s=plies / dt,
+                              sims_per_s=sims / dt, ms_per_round=dt / (a.plies * a.sims) * 1e3,
+                              levels_per_sim=(s1['levels'] - s0['levels']) / max(sims, 1),
+                              valid_per_level=(s1['sum_valid_visited'] - s0['sum_valid_visited']) / max(s1['levels'] - s0['levels'], 1),
+                              games_finished=s1['games'], errors=s1['errors'], validate_violations=bad,
+                              forest_gb=eng.device_bytes / 1e9, evaluator='hash-net (torch ops)')), flush=True)
+        for grp in eng.groups:
+            grp.f.close()
+        del eng
+        torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    main()
