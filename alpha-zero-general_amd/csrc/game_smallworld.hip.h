@@ -1,7 +1,8 @@
 // game_smallworld.hip.h -- Smallworld env step on the device plugin interface: smallworld/SmallworldLogicNumba.py
-// (Board :141-1508) for the shipped configuration (SmallworldConstants.py: NUMBER_PLAYERS = 2; SmallworldMaps_2pl.py: 23 areas, 10 rounds).
+// (Board :141-1508) for NUMBER_PLAYERS = 2 (the shipped constant), 3 and 4 with their maps (SmallworldMaps_<n>pl.py: 23 / 30 / 39 areas,
+// 10 / 10 / 9 rounds).
 //
-// State int8 [40][8] (:11-60): rows 0..22 territories {nb people, people type (negative in decline, -15 lost tribe), power, defence due
+// State int8 [NB_AREAS + 5 n + 7][8] (:11-60; indices below for 2 players): rows 0..22 territories {nb people, people type (negative in decline, -15 lost tribe), power, defence due
 // to the people, defence due to the power, total defence, points if scored now, owner (-1 none)}; rows 23 + 3 p + id peoples of player p
 // (id 0 declined-spirit, 1 declined, 2 active) {nb in hand, type, power, people data, power data, -, points, player}; rows 29..34 visible
 // deck {nb, type, power, -, -, -, coins, -1}; rows 35 + p round status {people on the map, -, -, #NETWDT, phase, total defence, points
@@ -23,18 +24,21 @@
 
 namespace azg {
 
+template <int NPL>
 struct SmallworldDev {
-    static constexpr int P = 2;
-    static constexpr int ROWS = 40, COLS = 8;
-    static constexpr int S = 320;
+    static constexpr int NP = NPL, NA = NPL == 2 ? SW_NA_2 : (NPL == 3 ? SW_NA_3 : SW_NA_4);
+    static constexpr int NB_ROUNDS = NPL == 2 ? SW_ROUNDS_2 : (NPL == 3 ? SW_ROUNDS_3 : SW_ROUNDS_4);
+    static constexpr int P = NPL;
+    static constexpr int ROWS = NA + 5 * NPL + 7, COLS = 8;
+    static constexpr int S = ROWS * 8;
     static constexpr int SP = RoundUp16<S>::value;
-    static constexpr int A = 131;
+    static constexpr int A = 5 * NA + 16;
     static constexpr int AW = (A + 63) / 64;
     static constexpr bool STOCHASTIC = false;
     static constexpr bool RANDOM_SYM = true;      // symmetric forms are built by lane 0 (k_env_symmetries_built) and draw randomness
     static constexpr bool SYM_DEDUP = false;
     enum { FORESTT, FARMLAND, HILLT, SWAMPT, MOUNTAIN, WATER };
-    enum { NA = 23, NP = 2, DECK_SIZE = 6, SCORE_INIT = 5, IMMUNITY = 20, MAX_REDEPLOY = 8, MAX_DICE = 3, NB_ROUNDS = 10 };
+    enum { DECK_SIZE = 6, SCORE_INIT = 5, IMMUNITY = 20, MAX_REDEPLOY = 8, MAX_DICE = 3 };
     enum { DECLINED_SPIRIT = 0, DECLINED = 1, ACTIVE = 2 };
     enum { PHASE_READY = 1, PHASE_CHOOSE, PHASE_ABANDON, PHASE_CONQUEST, PHASE_CONQ_WITH_DICE, PHASE_ABANDON_AMAZONS, PHASE_REDEPLOY,
            PHASE_STOUT_TO_DECLINE, PHASE_WAIT };
@@ -50,12 +54,14 @@ struct SmallworldDev {
     template <class T_> __device__ static __forceinline__ T_* RS(T_* s, int p) { return s + 8 * (NA + 3 * NP + DECK_SIZE + p); }
     template <class T_> __device__ static __forceinline__ T_* GS(T_* s, int p) { return s + 8 * (NA + 4 * NP + DECK_SIZE + p); }
     template <class T_> __device__ static __forceinline__ T_* INV(T_* s) { return s + 8 * (NA + 5 * NP + DECK_SIZE); }
-    __device__ static __forceinline__ int TERRAIN(int a) { return SW_DESCR[a] & 7; }
-    __device__ static __forceinline__ int CAVERN(int a) { return (SW_DESCR[a] >> 3) & 1; }
-    __device__ static __forceinline__ int MAGIC(int a) { return (SW_DESCR[a] >> 4) & 1; }
-    __device__ static __forceinline__ int MINE(int a) { return (SW_DESCR[a] >> 5) & 1; }
-    __device__ static __forceinline__ int HAS_TRIBE(int a) { return (SW_DESCR[a] >> 6) & 1; }
-    __device__ static __forceinline__ int AT_EDGE(int a) { return (SW_DESCR[a] >> 7) & 1; }
+    __device__ static __forceinline__ int SW_DESCR_(int a) { if constexpr (NPL == 2) return SW_DESCR_2[a]; else if constexpr (NPL == 3) return SW_DESCR_3[a]; else return SW_DESCR_4[a]; }
+    __device__ static __forceinline__ uint64_t SW_CONN_(int a) { if constexpr (NPL == 2) return SW_CONN_2[a]; else if constexpr (NPL == 3) return SW_CONN_3[a]; else return SW_CONN_4[a]; }
+    __device__ static __forceinline__ int TERRAIN(int a) { return SW_DESCR_(a) & 7; }
+    __device__ static __forceinline__ int CAVERN(int a) { return (SW_DESCR_(a) >> 3) & 1; }
+    __device__ static __forceinline__ int MAGIC(int a) { return (SW_DESCR_(a) >> 4) & 1; }
+    __device__ static __forceinline__ int MINE(int a) { return (SW_DESCR_(a) >> 5) & 1; }
+    __device__ static __forceinline__ int HAS_TRIBE(int a) { return (SW_DESCR_(a) >> 6) & 1; }
+    __device__ static __forceinline__ int AT_EDGE(int a) { return (SW_DESCR_(a) >> 7) & 1; }
     __device__ static __forceinline__ int PMOD(int x) { return ((x % NP) + NP) % NP; }
     __device__ static __forceinline__ int dice_value(int i) { return i < 3 ? 0 : i - 2; }        // DICE_VALUES = {0, 0, 0, 1, 2, 3}
 
@@ -69,9 +75,9 @@ struct SmallworldDev {
     __device__ static long long pmod64(long long a, long long m) { long long r = a % m; return r < 0 ? r + m : r; }
 
     __device__ static int8_t* current_ppl(int8_t* s, int player) { return PPL(s, player, GS(s, player)[4]); }      /* :956-960 */
-    __device__ static uint32_t occupied_by(const int8_t* s, const int8_t* ppl) {                                     /* _are_occupied_by :973-974 */
-        uint32_t m = 0;
-        for (int a = 0; a < NA; a++) if (T(s, a)[1] == ppl[1]) m |= 1u << a;
+    __device__ static uint64_t occupied_by(const int8_t* s, const int8_t* ppl) {                                     /* _are_occupied_by :973-974 */
+        uint64_t m = 0;
+        for (int a = 0; a < NA; a++) if (T(s, a)[1] == ppl[1]) m |= 1ull << a;
         return m;
     }
     __device__ static int8_t* ppl_owner_of(int8_t* s, int area, int* owner) {                                        /* :962-968 */
@@ -84,7 +90,7 @@ struct SmallworldDev {
         return nullptr;
     }
     __device__ static int border_of(int area, int terrain) {                                                         /* _is_area_border_of :976-980 */
-        for (int a = 0; a < NA; a++) if (((SW_CONN[area] >> a) & 1) && TERRAIN(a) == terrain) return 1;
+        for (int a = 0; a < NA; a++) if (((SW_CONN_(area) >> a) & 1) && TERRAIN(a) == terrain) return 1;
         return 0;
     }
     __device__ static int minimum_ppl_for_attack(const int8_t* s, int area, const int8_t* cp) {                       /* :982-998 */
@@ -96,21 +102,21 @@ struct SmallworldDev {
         if (cp[2] == UNDERWORLD && CAVERN(area)) m--;
         return m > 1 ? m : 1;
     }
-    __device__ static int total_number_of_ppl(const int8_t* s, const int8_t* cp, uint32_t terr) {                     /* :1047-1053 */
+    __device__ static int total_number_of_ppl(const int8_t* s, const int8_t* cp, uint64_t terr) {                     /* :1047-1053 */
         int n = cp[0];
         for (int a = 0; a < NA; a++) if ((terr >> a) & 1) n += T(s, a)[0];
         return n;
     }
-    __device__ static int limit_added_ppl(const int8_t* s, const int8_t* cp, int addition, int maximum, uint32_t terr) {   /* :1055-1057 */
+    __device__ static int limit_added_ppl(const int8_t* s, const int8_t* cp, int addition, int maximum, uint64_t terr) {   /* :1055-1057 */
         const int room = maximum - total_number_of_ppl(s, cp, terr);
         return addition < room ? addition : room;
     }
-    __device__ static int surplus_on_board(const int8_t* s, uint32_t terr) {               /* my_dot(max(territories[:,0] - 1, 0), territories_of_player) */
+    __device__ static int surplus_on_board(const int8_t* s, uint64_t terr) {               /* my_dot(max(territories[:,0] - 1, 0), territories_of_player) */
         int n = 0;
         for (int a = 0; a < NA; a++) if (((terr >> a) & 1) && T(s, a)[0] > 1) n += T(s, a)[0] - 1;
         return n;
     }
-    __device__ static int ppl_virtually_available(const int8_t* s, int player, const int8_t* cp, int next_status, uint32_t terr) {   /* :1206-1233 */
+    __device__ static int ppl_virtually_available(const int8_t* s, int player, const int8_t* cp, int next_status, uint64_t terr) {   /* :1206-1233 */
         const int old = RS(s, player)[4];
         int n = cp[0];
         if (old == PHASE_READY && in3(next_status, PHASE_ABANDON, PHASE_CONQUEST, PHASE_CONQ_WITH_DICE)) n += surplus_on_board(s, terr);
@@ -337,10 +343,10 @@ struct SmallworldDev {
         case FORTIFIED: case HEROIC: return t[1] == cp[1] && !(t[4] > 0);
         case DIPLOMAT: return !(cp[4] & (1 << PMOD(player - area)));
         case DRAGONMASTER: {
-            const uint32_t terr = occupied_by(s, cp);
+            const uint64_t terr = occupied_by(s, cp);
             if (TERRAIN(area) == WATER || ((terr >> area) & 1)) return 0;
             if (t[3] >= IMMUNITY || t[4] >= IMMUNITY) return 0;
-            return (SW_CONN[area] & terr) != 0;
+            return (SW_CONN_(area) & terr) != 0;
         }
         default: return 0;
         }
@@ -393,8 +399,8 @@ struct SmallworldDev {
         RS(s, player)[4] = PHASE_REDEPLOY;
         if (param != 0) {
             if (param < MAX_REDEPLOY) {
-                const uint32_t terr = occupied_by(s, cp);
-                cp[0] = (int8_t)(cp[0] - param * __popc(terr));
+                const uint64_t terr = occupied_by(s, cp);
+                cp[0] = (int8_t)(cp[0] - param * __popcll((unsigned long long)terr));
                 for (int a = 0; a < NA; a++) if ((terr >> a) & 1) { T(s, a)[0] = (int8_t)(T(s, a)[0] + param); T(s, a)[5] = (int8_t)(T(s, a)[5] + param); }
             } else {
                 const int a = param - MAX_REDEPLOY;
@@ -576,7 +582,7 @@ struct SmallworldDev {
         if (a < 2 * NA) {                                                    // _valids_attack :342-391
             const int area = a - NA;
             if (cp[1] == NOPPL || !early) return false;
-            const uint32_t terr = occupied_by(s, cp);
+            const uint64_t terr = occupied_by(s, cp);
             int avail = ppl_virtually_available(s, player, cp, PHASE_CONQUEST, terr);
             if (avail <= 0) return false;
             if (cp[2] == BERSERK && split_b(cp[4])) avail += split_a(cp[4]);
@@ -586,9 +592,9 @@ struct SmallworldDev {
             if (cp[2] != FLYING) {
                 if (terr == 0) { if (cp[1] != HALFLING && !AT_EDGE(area)) return false; }
                 else {
-                    uint32_t neigh = 0;
+                    uint64_t neigh = 0;
                     int cavern_owned = 0;
-                    for (int i = 0; i < NA; i++) if ((terr >> i) & 1) { neigh |= SW_CONN[i]; cavern_owned |= CAVERN(i); }
+                    for (int i = 0; i < NA; i++) if ((terr >> i) & 1) { neigh |= SW_CONN_(i); cavern_owned |= CAVERN(i); }
                     int nb = (neigh >> area) & 1;
                     if (cp[2] == UNDERWORLD && cavern_owned && CAVERN(area)) nb = 1;
                     if (!nb) return false;
@@ -599,13 +605,13 @@ struct SmallworldDev {
         if (a < 3 * NA) {                                                    // _valids_special_actionppl :651-701 (sorcerer)
             const int area = a - 2 * NA;
             if (cp[1] != SORCERER || !early) return false;
-            const uint32_t terr = occupied_by(s, cp);
+            const uint64_t terr = occupied_by(s, cp);
             if (total_number_of_ppl(s, cp, terr) + 1 > MAX_SORCERERS) return false;
             const int8_t* t = T(s, area);
             if (TERRAIN(area) == WATER && cp[2] != SEAFARING) return false;
             if (t[0] != 1 || t[1] <= 0 || t[1] == cp[1]) return false;
             if (t[3] >= IMMUNITY || t[4] >= IMMUNITY) return false;
-            if (cp[2] != FLYING && !(SW_CONN[area] & terr)) return false;
+            if (cp[2] != FLYING && !(SW_CONN_(area) & terr)) return false;
             int loser;
             const int8_t* lp = ppl_owner_of(s, area, &loser);
             if (cp[3] & (1 << PMOD(player - loser))) return false;
@@ -627,8 +633,8 @@ struct SmallworldDev {
         if (a < 5 * NA + MAX_REDEPLOY) {                                     // _valids_redeploy :451-488
             const int i = a - 4 * NA;
             if (cp[1] == NOPPL || phase == PHASE_WAIT || phase == PHASE_ABANDON_AMAZONS) return false;
-            const uint32_t terr = occupied_by(s, cp);
-            const int nt = __popc(terr);
+            const uint64_t terr = occupied_by(s, cp);
+            const int nt = __popcll((unsigned long long)terr);
             const int avail = nt == 0 ? 0 : ppl_virtually_available(s, player, cp, PHASE_REDEPLOY, terr);
             if (nt == 0 || avail == 0) return i == 0 && phase != PHASE_REDEPLOY;     // nothing to deploy: only "skip", once
             if (avail < 0 || i == 0) return false;                                    // (a territory is always a valid target: no skip)
@@ -659,14 +665,16 @@ struct SmallworldDev {
 
     __device__ static __forceinline__ int get_score(const int8_t* st, int p) { return GS(st, p)[6] + 128; }
     __device__ static __forceinline__ int get_round(const int8_t* st) {        // :245-246
-        const int r0 = GS(st, 0)[3], r1 = GS(st, 1)[3];
-        return r0 < r1 ? r0 : r1;
+        int r = GS(st, 0)[3];
+#pragma unroll
+        for (int p = 1; p < NP; p++) r = GS(st, p)[3] < r ? GS(st, p)[3] : r;
+        return r;
     }
     __device__ static __forceinline__ int gc_age(const int8_t* st) { return get_round(st) & 255; }     // the round only grows
     __device__ static __forceinline__ bool move_uses_seed(int) { return true; }     // dice / deck draws depend on the state: be conservative
 
     __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
-        return lane0_make_move<SmallworldDev>(st, move, player, seed, rng);
+        return lane0_make_move<SmallworldDev<NPL>>(st, move, player, seed, rng);
     }
     // Board.make_move :210-240 -- lane 0 only
     __device__ static int make_move(int8_t* s, int move, int player, long long seed, Rng& rng) {
@@ -685,26 +693,36 @@ struct SmallworldDev {
     // Board.check_end_game :248-257 (uniform)
     __device__ static bool game_ended(const int8_t* st, int next_player, float* out, uint64_t* mask_scratch) {
         (void)next_player; (void)mask_scratch;
-        if (get_round(st) <= NB_ROUNDS) { out[0] = 0.f; out[1] = 0.f; return false; }
-        const int a = GS(st, 0)[6], b = GS(st, 1)[6];
-        out[0] = a > b ? 1.f : (a < b ? -1.f : 0.01f);
-        out[1] = b > a ? 1.f : (b < a ? -1.f : 0.01f);
+        if (get_round(st) <= NB_ROUNDS) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) out[p] = 0.f;
+            return false;
+        }
+        int best = -1000, cnt = 0;
+#pragma unroll
+        for (int p = 0; p < NP; p++) best = GS(st, p)[6] > best ? GS(st, p)[6] : best;
+#pragma unroll
+        for (int p = 0; p < NP; p++) cnt += GS(st, p)[6] == best;
+#pragma unroll
+        for (int p = 0; p < NP; p++) out[p] = GS(st, p)[6] == best ? (cnt > 1 ? 0.01f : 1.f) : -1.f;
         return true;
     }
 
-    // Board.swap_players :260-279 (k odd, 2 players): owners flip, the status rows and the people rows trade places except their
-    // last column (the player id)
+    // Board.swap_players :260-279: owners shift by k, the status rows and the people rows of player p come from player (p + k) mod n
+    // except their last column (the player id)
     __device__ static void swap_players(int8_t* st, int8_t* tmp, int k) {
-        if ((k & 1) == 0) return;
+        k = PMOD(k);
+        if (k == 0) return;
         for (int i = lane_id(); i < S; i += 64) tmp[i] = st[i];
         wave_sync();
         for (int i = lane_id(); i < S; i += 64) {
             const int r = i >> 3, z = i & 7;
             int8_t v = tmp[i];
-            if (r < NA) { if (z == 7 && v >= 0) v = (int8_t)(1 - v); }
+            if (r < NA) { if (z == 7 && v >= 0) v = (int8_t)PMOD(v - k); }
             else if (z < 7) {
-                if (r < NA + 6) v = tmp[(r < NA + 3 ? r + 3 : r - 3) * 8 + z];                        // peoples
-                else if (r >= NA + 6 + DECK_SIZE && r < NA + 6 + DECK_SIZE + 4) v = tmp[(((r - (NA + 6 + DECK_SIZE)) ^ 1) + NA + 6 + DECK_SIZE) * 8 + z];
+                if (r < NA + 3 * NP) { const int p = (r - NA) / 3, id = (r - NA) - 3 * p; v = tmp[(NA + 3 * ((p + k) % NP) + id) * 8 + z]; }
+                else if (r >= NA + 3 * NP + DECK_SIZE && r < NA + 4 * NP + DECK_SIZE) v = tmp[(NA + 3 * NP + DECK_SIZE + (r - (NA + 3 * NP + DECK_SIZE) + k) % NP) * 8 + z];
+                else if (r >= NA + 4 * NP + DECK_SIZE && r < NA + 5 * NP + DECK_SIZE) v = tmp[(NA + 4 * NP + DECK_SIZE + (r - (NA + 4 * NP + DECK_SIZE) + k) % NP) * 8 + z];
             }
             st[i] = v;
         }
@@ -743,8 +761,9 @@ struct SmallworldDev {
         (void)valids;
         for (int a = 0; a < A; a++) act_src[a] = (int16_t)a;
         if (c == 0) return true;
-        const int s0 = GS(st, 0)[6], s1 = GS(st, 1)[6];
-        const int lo = -127 - (s0 < s1 ? s0 : s1), hi = 127 - (s0 > s1 ? s0 : s1);
+        int mn = 1000, mx = -1000;
+        for (int p = 0; p < NP; p++) { const int v = GS(st, p)[6]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        const int lo = -127 - mn, hi = 127 - mx;
         if (lo >= hi) return false;
         int d = (int)(rng.u01() * (double)(hi - lo));
         d = d > hi - lo - 1 ? hi - lo - 1 : d;

@@ -222,12 +222,12 @@ class AkropolisGame(HipGame):
 
 
 class SmallworldGame(HipGame):
-    """smallworld/SmallworldGame.py (NUMBER_PLAYERS 2 with its 23-area map: the shipped constants).  getSymmetries draws two random
+    """smallworld/SmallworldGame.py (NUMBER_PLAYERS 2 -- the shipped constant -- 3 or 4, each with its own map).  getSymmetries draws two random
     score offsets (SmallworldLogicNumba.py:281-299) from the engine's counter RNG streams."""
     GAME_ID = _lib.SMALLWORLD
 
-    def __init__(self, **kw):
-        super().__init__(2, **kw)
+    def __init__(self, num_players=2, **kw):
+        super().__init__(num_players, **kw)
 
 
 def import_game(name, **kw):

@@ -8,7 +8,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
-            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0), 'smallworld': ('smallworld', 0)}
+            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
+            'smallworld4': ('smallworld', 4)}
 
 
 def make_game(variant):
@@ -23,7 +24,7 @@ def make_game(variant):
     if name == 'akropolis':
         return games.AkropolisGame()
     if name == 'smallworld':
-        return games.SmallworldGame()
+        return games.SmallworldGame(v)
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
 
 
@@ -56,7 +57,7 @@ def test_env_vs_golden(golden_dir, variant):
     assert np.array_equal(canon.cpu().numpy(), d['canonical'])
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'splendor4', 'santorini11', 'azul', 'akropolis', 'smallworld'])
+@pytest.mark.parametrize('variant', ['splendor2', 'splendor4', 'santorini11', 'azul', 'akropolis', 'smallworld', 'smallworld4'])
 def test_true_random_moves_and_init_vs_oracle(golden_dir, variant):
     """random_seed == 0 (Coach.py:71) and Board.init_game consume the shared counter-based RNG exactly like the oracle."""
     import torch
@@ -113,7 +114,8 @@ def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
     import azg_oracle as O
     from azg_amd import games
     name, v = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
-               'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0), 'smallworld': ('smallworld', 0)}[variant]
+               'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
+            'smallworld4': ('smallworld', 4)}[variant]
     g = {'splendor': lambda: games.SplendorGame(v), 'santorini': lambda: games.SantoriniGame(v), 'azul': games.AzulGame,
          'abalone': games.AbaloneGame, 'akropolis': games.AkropolisGame}[name]()
     og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'abalone': O.ABALONE, 'akropolis': O.AKROPOLIS}[name], v)

@@ -10,7 +10,8 @@ from tools_args import MCTS_ARGS
 
 pytestmark = pytest.mark.gpu
 
-F4_VARIANTS = {'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0), 'smallworld': ('smallworld', 0)}           # SURVEY.md §8 f4 games with the standard (deterministic-step) fixtures
+F4_VARIANTS = {'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
+               'smallworld4': ('smallworld', 4)}           # SURVEY.md §8 f4 games with the standard (deterministic-step) fixtures
 VARIANTS = {'splendor2': ('splendor', 2), 'splendor4': ('splendor', 4), 'santorini1': ('santorini', 1),
             'santorini11': ('santorini', 11), 'azul': ('azul', 0)}
 
@@ -29,7 +30,7 @@ def make(variant):
     if name == 'akropolis':
         return games.AkropolisGame()
     if name == 'smallworld':
-        return games.SmallworldGame()
+        return games.SmallworldGame(v)
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
 
 
@@ -72,7 +73,7 @@ def test_mcts_traces_vs_golden(golden_dir, variant, prefix):
         m.forest.close()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'santorini11', 'azul', 'abalone', 'akropolis', 'smallworld'])
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini11', 'azul', 'abalone', 'akropolis', 'smallworld', 'smallworld3', 'smallworld4'])
 def test_whole_tree_vs_oracle(variant):
     """Every node of the HIP tree equals the oracle's node with the same state key (Ns, Qs, Nsa, Qsa, Ps, Es)."""
     import torch
@@ -130,7 +131,7 @@ def test_tree_reuse_sequence_vs_golden(golden_dir, variant, small_arena):
     # the arena must hold a few plies' worth of nodes: tight for Splendor (round == ply counter), half the sequence for
     # Santorini / Azul (Azul's round only advances every few plies)
     small_cap = 2 * sims + 72 if variant == 'splendor2' else (sims * n) // 2
-    if variant == 'smallworld':
+    if variant.startswith('smallworld'):
         small_cap = sims * n + 64       # a Smallworld round spans a whole turn of both players: nothing is reclaimable within 12 plies
     m = BatchedMCTS(g, HashNetTorch(g.P), args, 1, node_capacity=small_cap if small_arena else (sims * n + 64))
     for i in range(n):

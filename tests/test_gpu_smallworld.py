@@ -11,12 +11,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_smallworld_random_symmetries_vs_golden(golden_dir):
+@pytest.mark.parametrize('n', [2, 3, 4])
+def test_smallworld_random_symmetries_vs_golden(golden_dir, n):
     from azg_amd import games
-    d = np.load(os.path.join(golden_dir, 'sym_smallworld.npz'))
-    g = games.SmallworldGame()
+    d = np.load(os.path.join(golden_dir, 'sym_smallworld%s.npz' % ('' if n == 2 else n)))
+    g = games.SmallworldGame(n)
     dev = g.device
-    assert g.max_symmetries() == 3 and (g.S, g.A, g.P) == (320, 131, 2)
+    assert g.max_symmetries() == 3 and (g.S, g.A, g.P) == ({2: 320, 3: 416, 4: 528}[n], {2: 131, 3: 166, 4: 211}[n], n)
     ob, op, ov, cnt = g.symmetries_batch(torch.from_numpy(d['state']).to(dev), torch.from_numpy(d['pi']).to(dev),
                                          torch.from_numpy(d['valids']).to(dev), rng_seed=int(d['seed']), stream0=0)
     assert np.array_equal(cnt.cpu().numpy(), d['count'])

@@ -11,7 +11,7 @@ import azg_oracle as O
 VARIANTS = {
     'splendor2': (O.SPLENDOR, 2), 'splendor3': (O.SPLENDOR, 3), 'splendor4': (O.SPLENDOR, 4),
     'santorini1': (O.SANTORINI, 1), 'santorini11': (O.SANTORINI, 11), 'azul': (O.AZUL, 0), 'abalone': (O.ABALONE, 0),
-    'akropolis': (O.AKROPOLIS, 0), 'smallworld': (O.SMALLWORLD, 0),
+    'akropolis': (O.AKROPOLIS, 0), 'smallworld': (O.SMALLWORLD, 0), 'smallworld3': (O.SMALLWORLD, 3), 'smallworld4': (O.SMALLWORLD, 4),
 }
 
 
@@ -45,7 +45,7 @@ def test_env_transitions(golden_dir, variant):
     assert n_seed0 > 10
 
 
-@pytest.mark.parametrize('variant', [v for v in VARIANTS if v != 'smallworld'])      # (Smallworld's are random: test below)
+@pytest.mark.parametrize('variant', [v for v in VARIANTS if not v.startswith('smallworld')])      # (Smallworld's are random: test below)
 def test_symmetries(golden_dir, variant):
     d = load(golden_dir, 'sym_%s.npz' % variant)
     g = O.OracleGame(*VARIANTS[variant])
@@ -80,7 +80,7 @@ MCTS_SMALL = MCTS_VARIANTS + ['abalone', 'akropolis', 'smallworld']          # (
 
 
 @pytest.mark.parametrize('variant,typing,prefix', [(v, t, 'mcts') for v in MCTS_SMALL for t in ('numpy2', 'numba')] +
-                         [(v, 'numba', 'mcts800') for v in MCTS_VARIANTS])
+                         [(v, 'numba', 'mcts') for v in ('smallworld3', 'smallworld4')] + [(v, 'numba', 'mcts800') for v in MCTS_VARIANTS])
 def test_mcts_traces(golden_dir, variant, typing, prefix):
     """G3: whole-tree parity (every node's Ns, Nsa, Qsa, Ps, Qs bit-exact through a SHA-256 digest); `mcts800` = the
     headline search size (800 simulations, tools/gen_golden_800.py)."""
@@ -104,8 +104,7 @@ def test_mcts_traces(golden_dir, variant, typing, prefix):
         assert np.array_equal(oracle_tree_digest(mc, g), d['case_digest'][i]), (variant, i)
 
 
-@pytest.mark.parametrize('typing', ['numpy2', 'numba'])
-@pytest.mark.parametrize('variant', MCTS_SMALL)
+@pytest.mark.parametrize('variant,typing', [(v, t) for v in MCTS_SMALL for t in ('numpy2', 'numba')] + [('smallworld3', 'numba'), ('smallworld4', 'numba')])
 def test_mcts_sequence_tree_reuse(golden_dir, variant, typing):
     """G3 sequence: tree reuse across moves, fast (non-full) searches, periodic clean-up (MCTS.py:86-91)."""
     d = load(golden_dir, 'mcts_%s_%s.npz' % (variant, typing))
@@ -136,17 +135,21 @@ def test_akropolis_init_boards(golden_dir):
     assert d['score'].max() > 60 and set(d['seed'].tolist()) >= {0, -1, 31416}
 
 
-def test_smallworld_init_boards_and_random_symmetries(golden_dir):
+@pytest.mark.parametrize('n', [2, 3, 4])
+def test_smallworld_init_boards_and_random_symmetries(golden_dir, n):
     """init_game draws six (people, power) pairs with np.random.choice (SmallworldLogicNumba.py:1339-1356); get_symmetries shifts both
     scores by two np.random.randint offsets (:281-299), drawn here from the recorded counter streams"""
-    d = load(golden_dir, 'env_smallworld.npz')
-    g = O.OracleGame(O.SMALLWORLD)
+    tag = 'smallworld' if n == 2 else 'smallworld%d' % n
+    d = load(golden_dir, 'env_%s.npz' % tag)
+    g = O.OracleGame(O.SMALLWORLD, n)
+    na = (g.A - 16) // 5
     for i in range(len(d['init_boards'])):
         rng = g.rng(injected=d['init_uniforms'][i])
         assert np.array_equal(g.getInitBoard(rng).reshape(-1), d['init_boards'][i]) and rng.pos == 12
-    st = d['next_state'].reshape(-1, 40, 8)
-    assert len(set(np.abs(st[:, 23:29, 1]).reshape(-1).tolist())) == 15 and len(set(np.abs(st[:, 23:29, 2]).reshape(-1).tolist())) >= 19
-    s = load(golden_dir, 'sym_smallworld.npz')
+    st = d['next_state'].reshape(-1, g.S // 8, 8)
+    seen_ppl, seen_pwr = set(np.abs(st[:, na:na + 3 * n, 1]).reshape(-1).tolist()), set(np.abs(st[:, na:na + 3 * n, 2]).reshape(-1).tolist())
+    assert (len(seen_ppl) == 15 and len(seen_pwr) >= 19) if n == 2 else (len(seen_ppl) >= 11 and len(seen_pwr) >= 12)
+    s = load(golden_dir, 'sym_%s.npz' % tag)
     for j in range(len(s['state'])):
         rng = g.rng(seed=int(s['seed']), stream=j)
         sy = g.getSymmetries(s['state'][j], s['pi'][j], s['valids'][j], max_sym=3, rng=rng)

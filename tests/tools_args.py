@@ -9,5 +9,7 @@ MCTS_ARGS = {
     'abalone': dict(cpuct=1.0, fpu=0.0, universes=0, forced_playouts=True),
     'akropolis': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
     'smallworld': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
+    'smallworld3': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
+    'smallworld4': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
     'minivilles2': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
 }

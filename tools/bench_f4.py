@@ -24,25 +24,29 @@ class Args(dict):
     __getattr__ = dict.get
 
 
-GAMES = [('minivilles', lambda: games.MinivillesGame(2), 1.0), ('abalone', games.AbaloneGame, 1.0), ('thelittleprince', lambda: games.TLPGame(3), 1.0),
-         ('botanik', games.BotanikGame, 1.0), ('akropolis', games.AkropolisGame, 0.25), ('smallworld', games.SmallworldGame, 1.0)]
+# (name, constructor, share of --games, node capacity in units of numMCTSSims: a Smallworld round spans both players' whole turns, so
+#  the round-based clean-up keeps ~30 plies of nodes)
+GAMES = [('minivilles', lambda: games.MinivillesGame(2), 1.0, 10), ('abalone', games.AbaloneGame, 1.0, 10), ('thelittleprince', lambda: games.TLPGame(3), 1.0, 10),
+         ('botanik', games.BotanikGame, 1.0, 10), ('akropolis', games.AkropolisGame, 0.25, 10), ('smallworld', lambda: games.SmallworldGame(2), 1.0, 80),
+         ('smallworld4', lambda: games.SmallworldGame(4), 0.5, 80)]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--games', type=int, default=1024)
     ap.add_argument('--sims', type=int, default=200)
-    ap.add_argument('--plies', type=int, default=12, help='timed ply waves (one wave = `sims` lock-step rounds)')
+    ap.add_argument('--plies', type=int, default=40, help='timed ply waves (one wave = `sims` lock-step rounds)')
     ap.add_argument('--only', default=None)
     a = ap.parse_args()
-    for name, make, scale in GAMES:
+    for name, make, scale, capf in GAMES:
         if a.only and a.only != name:
             continue
         g = make()
         T = max(64, int(a.games * scale))
-        args = Args(numMCTSSims=a.sims, cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True, prob_fullMCTS=1.0, ratio_fullMCTS=5,
+        # (Akropolis offers hundreds of placements: with 200 simulations policy-target pruning leaves no count above 1, error bit 64)
+        args = Args(numMCTSSims=a.sims, cpuct=1.0, fpu=0.0, universes=1, forced_playouts=name != 'akropolis', prob_fullMCTS=1.0, ratio_fullMCTS=5,
                     dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0], tempThreshold=6)
-        eng = SelfPlayEngine(g, HashNetTorch(g.P), args, n_games=T, node_capacity=max(2048, 8 * a.sims), max_examples=T * 256)
+        eng = SelfPlayEngine(g, HashNetTorch(g.P), args, n_games=T, node_capacity=max(2048, capf * a.sims), max_examples=T * 256)
         eng.start()
         eng.run(2 * a.sims)                                    # warm-up: two ply waves (also captures the HIP graph)
         torch.cuda.synchronize()

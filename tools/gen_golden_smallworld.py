@@ -20,13 +20,14 @@ import harness as H  # noqa: E402
 
 G.VARIANTS['smallworld'] = (dict(), 'SmallworldGame', 'SmallworldGame')
 G.MCTS_ARGS['smallworld'] = dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True)
-NU, NU_INIT, A, SYM_SEED = 4, 12, 131, 808
+NU, NU_INIT, SYM_SEED = 4, 12, 808
 
 
-def gen_env(n_traj, rng):
-    m = H.load_reference()
+def gen_env(n_traj, rng, n=2):
+    m = H.load_reference(smallworld_players=n)
     with H.CounterRandom(injected=[0.5] * NU_INIT):
         game = m['SmallworldGame'].SmallworldGame()
+    A = game.getActionSize()
     keys = ('state', 'player', 'valid', 'action', 'seed', 'next_state', 'next_player', 'ended', 'score', 'round', 'canonical', 'uniforms',
             'n_uniforms', 'traj')
     rec = {k: [] for k in keys}
@@ -42,7 +43,7 @@ def gen_env(n_traj, rng):
             valid = game.getValidMoves(board, player).copy()
             idx = np.flatnonzero(valid)
             # conquests / people and power actions three times as often, rarely end or decline early
-            w = np.ones(len(idx)); w[idx == 130] = 0.15; w[idx == 129] = 0.1; w[(idx >= 23) & (idx < 92)] = 3.0
+            w = np.ones(len(idx)); w[idx == A - 1] = 0.15; w[idx == A - 2] = 0.1; w[(idx >= (A - 16) // 5) & (idx < 4 * ((A - 16) // 5))] = 3.0
             a = int(rng.choice(idx, p=w / w.sum()))
             r = rng.random()
             seed = 0 if r < 0.3 else (-1 if r < 0.4 else H.MAGIC_SEEDS[int(rng.integers(8))])
@@ -57,7 +58,7 @@ def gen_env(n_traj, rng):
             rec['valid'].append(np.packbits(valid.astype(np.uint8))); rec['action'].append(a); rec['seed'].append(seed)
             rec['next_state'].append(nb.reshape(-1).copy()); rec['next_player'].append(npl)
             rec['ended'].append(ended.astype(np.float32))
-            rec['score'].append([int(game.getScore(nb, p)) for p in range(2)])
+            rec['score'].append([int(game.getScore(nb, p)) for p in range(n)])
             rec['round'].append(int(game.getRound(nb)))
             rec['canonical'].append(game.getCanonicalForm(nb, npl).reshape(-1).copy())
             rec['uniforms'].append((used + [0.5] * NU)[:NU]); rec['n_uniforms'].append(len(used))
@@ -74,11 +75,12 @@ def gen_env(n_traj, rng):
         canonical=np.array(rec['canonical'], dtype=np.int8), uniforms=np.array(rec['uniforms'], dtype=np.float64),
         n_uniforms=np.array(rec['n_uniforms'], dtype=np.int8), traj=np.array(rec['traj'], dtype=np.int16),
         init_boards=np.array([b.reshape(-1) for b in inits], dtype=np.int8), init_uniforms=np.array(init_u, dtype=np.float64),
-        shape=np.array(game.getBoardSize()), A=np.array(A), P=np.array(2))
+        shape=np.array(game.getBoardSize()), A=np.array(A), P=np.array(n))
     return out, m, game
 
 
 def gen_sym(env, game, every):
+    A = int(env['A'])
     rng = np.random.default_rng(79)
     shape = tuple(env['shape'])
     rows = np.arange(0, len(env['canonical']), every)
@@ -104,22 +106,27 @@ def gen_sym(env, game, every):
 
 
 def main():
-    rng = np.random.default_rng(sum(map(ord, 'smallworld')))
-    env, m, game = gen_env(24, rng)
-    np.savez_compressed(os.path.join(G.GOLDEN, 'env_smallworld.npz'), **env)
-    st = env['next_state'].reshape((-1, 40, 8))
-    print('smallworld env transitions', len(env['state']), 'ended', int(env['ended'].any(axis=1).sum()), 'max score', int(env['score'].max()),
-          'peoples', len(set(np.abs(st[:, 23:29, 1]).reshape(-1).tolist())) - 1, 'powers', len(set(np.abs(st[:, 23:29, 2]).reshape(-1).tolist())) - 1,
-          'phases', sorted(set(st[:, 35:37, 4].reshape(-1).tolist())), 'seed-0 draws', int(((env['seed'] == 0) & (env['n_uniforms'] > 0)).sum()),
-          'max uniforms', int(env['n_uniforms'].max()))
-    sym = gen_sym(env, game, 40)
-    np.savez_compressed(os.path.join(G.GOLDEN, 'sym_smallworld.npz'), **sym)
-    print('  sym cases', len(sym['count']), 'forms', int(sym['count'].sum()))
-    for typed in (0, 1):
-        mc = G.gen_mcts('smallworld', env, m, game, rng, sims_list=[25, 200], n_roots=2, seq_moves=12, typed=typed)
-        np.savez_compressed(os.path.join(G.GOLDEN, 'mcts_smallworld_%s.npz' % ('numba' if typed else 'numpy2')), **mc)
-        print('smallworld mcts cases', len(mc['case_sims']), 'seq', len(mc['seq_action']), 'typed', typed)
-    H.cleanup()
+    for n in (2, 3, 4):
+        tag = 'smallworld' if n == 2 else 'smallworld%d' % n
+        G.VARIANTS[tag] = (dict(smallworld_players=n), 'SmallworldGame', 'SmallworldGame')
+        G.MCTS_ARGS[tag] = G.MCTS_ARGS['smallworld']
+        rng = np.random.default_rng(sum(map(ord, tag)))
+        env, m, game = gen_env(24 if n == 2 else 6, rng, n)
+        np.savez_compressed(os.path.join(G.GOLDEN, 'env_%s.npz' % tag), **env)
+        na = (int(env['A']) - 16) // 5
+        st = env['next_state'].reshape((-1,) + tuple(env['shape']))
+        print(tag, 'env transitions', len(env['state']), 'ended', int(env['ended'].any(axis=1).sum()), 'max score', int(env['score'].max()),
+              'peoples', len(set(np.abs(st[:, na:na + 3 * n, 1]).reshape(-1).tolist())) - 1, 'powers',
+              len(set(np.abs(st[:, na:na + 3 * n, 2]).reshape(-1).tolist())) - 1, 'seed-0 draws',
+              int(((env['seed'] == 0) & (env['n_uniforms'] > 0)).sum()), 'max uniforms', int(env['n_uniforms'].max()))
+        sym = gen_sym(env, game, 40)
+        np.savez_compressed(os.path.join(G.GOLDEN, 'sym_%s.npz' % tag), **sym)
+        print('  sym cases', len(sym['count']), 'forms', int(sym['count'].sum()))
+        for typed in ((0, 1) if n == 2 else (1,)):
+            mc = G.gen_mcts(tag, env, m, game, rng, sims_list=[25, 200], n_roots=2, seq_moves=12, typed=typed)
+            np.savez_compressed(os.path.join(G.GOLDEN, 'mcts_%s_%s.npz' % (tag, 'numba' if typed else 'numpy2')), **mc)
+            print(tag, 'mcts cases', len(mc['case_sims']), 'seq', len(mc['seq_action']), 'typed', typed)
+        H.cleanup()
 
 
 if __name__ == '__main__':
