@@ -286,3 +286,35 @@ def test_santorini_v78_one_launch_gpu():
         pr, vr = base64.predict_batch(boards.reshape(B, 5, 5, 3), rm)
         assert float((pi - pr).abs().max()) < 1e-5 and float((v - vr).abs().max()) < 1e-5
         assert float(pi[~rm].abs().max()) == 0.0 and abs(float(pi.sum(dim=1).mean()) - 1.0) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['splendor2_v80', 'splendor4_v80', 'azul_v84', 'santorini1_v89', 'santorini11_v78'])
+def test_net_kernels_do_not_depend_on_stale_onchip_memory(tag):
+    """every one-launch net kernel gives bit-identical outputs whatever the LDS of the CUs and the scratch memory of the queue held
+    before (azg_debug_poison_onchip): no read of on-chip memory the kernel did not write"""
+    from azg_amd import nnet
+    from conftest import poison_onchip
+    root = os.path.join(os.path.dirname(__file__), 'golden')
+    w = os.path.join(root, 'weights_%s.npz' % tag)
+    if tag == 'splendor2_v80':
+        net = nnet.SplendorV80Hip.from_npz(w, device='cuda:0', max_batch=256)
+    elif tag == 'splendor4_v80':
+        net = nnet.MobileNet1dHip(nnet.SplendorV80.from_npz(w, num_players=4, device='cuda:0'), max_batch=256)
+    elif tag == 'azul_v84':
+        net = nnet.MobileNet1dHip(nnet.AzulV84.from_npz(w, device='cuda:0'), max_batch=256)
+    elif tag == 'santorini1_v89':
+        net = nnet.SantoriniV89Hip(nnet.SantoriniV89.from_npz(w, device='cuda:0'), max_batch=256)
+    else:
+        net = nnet.SantoriniV78Hip(nnet.SantoriniV78.from_npz(w, device='cuda:0'), max_batch=256)
+    d = np.load(os.path.join(root, 'netfwd_%s.npz' % tag))
+    reps = -(-203 // len(d['boards']))
+    boards = torch.from_numpy(np.concatenate([d['boards']] * reps)[:203]).to('cuda:0').to(torch.int8)
+    masks = torch.from_numpy(np.concatenate([d['masks']] * reps)[:203]).to('cuda:0')
+    outs = []
+    for pattern in (0x0, 0xFFFFFFFF, 0x7FC00000, 0xA5A5A5A5):
+        poison_onchip(pattern)
+        pi, v = net.predict_batch(boards, masks)
+        outs.append((pi.clone(), v.clone()))
+    for pi, v in outs[1:]:
+        assert torch.equal(pi, outs[0][0]) and torch.equal(v, outs[0][1])
