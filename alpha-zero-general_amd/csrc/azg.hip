@@ -47,6 +47,7 @@ extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
         else if ((game) == AZG_MINIVILLES && (variant) == 4) { using G = MinivillesDev<4>; __VA_ARGS__; } \
         else if ((game) == AZG_TLP && (variant) == 3) { using G = TLPDev<3>; __VA_ARGS__; }               \
         else if ((game) == AZG_TLP && (variant) == 4) { using G = TLPDev<4>; __VA_ARGS__; }               \
+        else if ((game) == AZG_TLP && (variant) == 5) { using G = TLPDev<5>; __VA_ARGS__; }               \
         else if ((game) == AZG_BOTANIK) { using G = BotanikDev; __VA_ARGS__; }                             \
         else if ((game) == AZG_AKROPOLIS) { using G = AkropolisDev; __VA_ARGS__; }                         \
         else if ((game) == AZG_SMALLWORLD && (variant) == 2) { using G = SmallworldDev<2>; __VA_ARGS__; } \
@@ -253,6 +254,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
                             : (D.cls_q == f->A ? (size_t)D.cap * RecLayout(f->A, D.U).total + 4096
                                                : (size_t)D.cap * RecLayout(nv_hint ? nv_hint : (f->A <= 256 ? 64 : 160), D.U).total * 5 / 4) + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
+    if (heap_bytes / 16 > (size_t)AZG_CHILD_IDX_MASK) { delete f; return fail("record heap per tree exceeds the 29-bit record offset (8 GiB)"); }
     D.heap_units = (uint32_t)(heap_bytes / 16);
     auto skew = [](size_t bytes) { size_t r = (bytes + 255) / 256 * 256; return ((r >> 8) & 1) ? r : r + 256; };
     D.s_heap = skew(heap_bytes);
@@ -456,7 +458,7 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
         const RecHdr* rh = (const RecHdr*)rec;
         Ns[i] = (int32_t)rh->Ns;
         Qs[i] = rh->Qs;
-        for (int p = 0; p < P; p++) Es[(size_t)i * P + p] = (rh->flags & NF_TERMINAL) ? rh->Es[p] : 0.f;
+        for (int p = 0; p < P; p++) Es[(size_t)i * P + p] = (rh->flags & NF_TERMINAL) ? rec_es(*rh, p) : 0.f;
         has_policy[i] = (rh->flags & NF_EXPANDED) ? 1 : 0;
         for (int a = 0; a < A; a++) { Nsa[(size_t)i * A + a] = 0; Qsa[(size_t)i * A + a] = AZG_NANQ; Ps[(size_t)i * A + a] = 0.f; }
         if (has_policy[i]) {

@@ -17,7 +17,7 @@
 //   htab[HT]             u32      open-addressing table: (10-bit tag | 22-bit node id), probed 64 slots per wave load
 //   path[MAXD]           8 B      the descent of the pending simulation (record, entry index, next_player, roll prefix)
 //
-// child[u] of entry j caches the RECORD OFFSET (| next_player << 30) of the node reached through valid action j in universe u (u = sim index mod universes, the
+// child[u] of entry j caches the RECORD OFFSET (| next_player << 29) of the node reached through valid action j in universe u (u = sim index mod universes, the
 // reference's seeded-chance mechanism MCTS.py:14,63).  It is pure memoisation of the reference's "replay env step +
 // dict lookup": the child of (state, action, seed) is a deterministic function, node identity stays the full state
 // (transpositions are found through the hash table exactly like the dict), and nodes are only ever dropped when they
@@ -52,7 +52,8 @@ enum : uint32_t {
 #define AZG_MAXD 256
 #define AZG_IDX_BITS 22
 #define AZG_IDX_MASK ((1u << AZG_IDX_BITS) - 1u)
-#define AZG_CHILD_IDX_MASK 0x3FFFFFFFu
+#define AZG_CHILD_NP_SHIFT 29            /* child slot = record offset (29 bits of 16-byte units) | next_player << 29 (3 bits: up to 5 players) */
+#define AZG_CHILD_IDX_MASK 0x1FFFFFFFu
 
 struct __attribute__((aligned(16))) NodeHdr {          // cold per-node data
     uint64_t hash;
@@ -70,10 +71,13 @@ struct __attribute__((aligned(16))) RecHdr {           // first 32 bytes of ever
     uint8_t flags;
     uint8_t round;
     union {
-        float Es[AZG_MAX_PLAYERS_DEV];     // terminal node: game result (MCTS.py:131-135)
+        float Es[AZG_MAX_PLAYERS_DEV];     // terminal node: game result (MCTS.py:131-135) of players 0..3; a fifth player's (The Little
+                                           // Prince with 5 players) rides in Qs, which a terminal node does not use: rec_es()
         double sq[2];                      // otherwise: sqrt(Ns), sqrt(Ns + EPS) -- kept by the backup so that a descent
     };                                     // level does not recompute two f64 square roots (MCTS.py:213-214)
 };
+
+__host__ __device__ inline float rec_es(const RecHdr& rh, int p) { return p < AZG_MAX_PLAYERS_DEV ? rh.Es[p] : rh.Qs; }
 
 struct __attribute__((aligned(16))) TreeHdr {
     uint32_t n_nodes, heap_top, root, status;          // n_nodes = LIVE nodes; heap_top = bump pointer of the record heap;

@@ -1,5 +1,5 @@
 // game_tlp.hip.h -- The Little Prince ("Make me a planet") env step on the device plugin interface:
-// thelittleprince/TLPLogicNumba.py (Board :95-412), 3-4 players (AZG_MAX_PLAYERS is 4; the reference also allows 5).
+// thelittleprince/TLPLogicNumba.py (Board :95-412), 3-5 players (a fifth player's terminal result rides in RecHdr.Qs, forest.hip.h rec_es).
 //
 // State int8 [18 n + 1][15] (copy_state :147-156): row 0 = round_and_state (col 0 round, col 1 current player, col 2 bitfield of
 // who can still play this turn (player p = bit 128 >> p), cols 3..12 bitfield of the 80 cards still in the deck, MSB first);

@@ -291,6 +291,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
         rh.Ns = 0; rh.Qs = 0.f; rh.node_id = id; rh.nv = (uint16_t)nv; rh.flags = ended ? NF_TERMINAL : 0; rh.round = round;
 #pragma unroll
         for (int p = 0; p < AZG_MAX_PLAYERS_DEV; p++) rh.Es[p] = (ended && p < G::P) ? es[p] : 0.f;
+        if (G::P > AZG_MAX_PLAYERS_DEV && ended) rh.Qs = es[G::P > AZG_MAX_PLAYERS_DEV ? AZG_MAX_PLAYERS_DEV : 0];
         if (!ended) { rh.sq[0] = 0.0; rh.sq[1] = sqrt(0.0 + AZG_EPS); }
         *(RecHdr*)rec = rh;
         NodeHdr* nh = FR::nhdr(F, t, id);
@@ -307,7 +308,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
 
 // Resolve the child of (parent record, entry j, universe): replay the env step from the parent's state
 // (get_next_best_action_and_canonical_state, MCTS.py:233-248), look the state up, create it if new.
-// Returns child slot value (record offset | next_player << 30) or AZG_NONE on overflow.
+// Returns child slot value (record offset | next_player << AZG_CHILD_NP_SHIFT) or AZG_NONE on overflow.
 template <class G, class HS>
 __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& H, typename Forest<G>::Smem& sm,
                                               uint32_t parent_node, int a, long long seed, int8_t* leaf_states,
@@ -344,7 +345,7 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
         if (crec == AZG_NONE) return AZG_NONE;
         *is_new = true;
     }
-    return crec | ((uint32_t)np << 30);
+    return crec | ((uint32_t)np << AZG_CHILD_NP_SHIFT);
 }
 
 __device__ __forceinline__ void stat_add(uint64_t* p, uint64_t v) {
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 c_term++;
                 float v[G::P];
 #pragma unroll
-                for (int p = 0; p < G::P; p++) v[p] = rh.Es[p];
+                for (int p = 0; p < G::P; p++) v[p] = rec_es(rh, p);
                 FR::backup(F, t, sm.path, depth, v);
                 H.sim_idx++;
                 break;
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 } else if (l < F.U) *(uint32_t*)((uint8_t*)rp + AZG_REC_HDR + (size_t)j * ES + AZG_E_C + 4u * (uint32_t)l) = child;
                 have_leaf = is_new;
             }
-            const int np = (int)(child >> 30);
+            const int np = (int)(child >> AZG_CHILD_NP_SHIFT);
             if (l == 0) {
                 PathEnt e; e.rec = rec; e.j = (uint16_t)j; e.np = (uint8_t)np; e.pre = (uint8_t)pre;
                 sm.path[depth] = e;

@@ -196,7 +196,7 @@ class AbaloneGame(HipGame):
 
 
 class TLPGame(HipGame):
-    """thelittleprince/TLPGame.py (NUMBER_PLAYERS 3 or 4 here; the reference also allows 5).  The market refill inside the env step
+    """thelittleprince/TLPGame.py (NUMBER_PLAYERS 3, 4 or 5).  The market refill inside the env step
     and getSymmetries draw true randomness (TLPLogicNumba.py:366-392, 177-272): both use the engine's counter RNG streams."""
     GAME_ID = _lib.TLP
 

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 enum { AZG_SPLENDOR = 0, AZG_SANTORINI = 1, AZG_AZUL = 2, AZG_MINIVILLES = 3, AZG_ABALONE = 4, AZG_TLP = 5, AZG_BOTANIK = 6, AZG_AKROPOLIS = 7, AZG_SMALLWORLD = 8 };
-#define AZG_MAX_PLAYERS 4
+#define AZG_MAX_PLAYERS 5
 #define AZG_MAX_UNIVERSES 8
 
 const char* azg_last_error(void);

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libazg_oracle.so')
 
 SPLENDOR, SANTORINI, AZUL, MINIVILLES, ABALONE, TLP, BOTANIK, AKROPOLIS, SMALLWORLD = 0, 1, 2, 3, 4, 5, 6, 7, 8
-MAXP = 4
+MAXP = 5
 
 
 def build(force=False):

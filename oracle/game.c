@@ -148,7 +148,7 @@ int azo_game_init(azo_game* g, int game_id, int variant) {
     }
     if (game_id == AZO_TLP) {
         int n = variant ? variant : 3;
-        if (n < 3 || n > 4) return -1;       /* the reference allows 5; AZO_MAX_PLAYERS is 4 */
+        if (n < 3 || n > 5) return -1;
         g->variant = n;
         g->P = n;
         g->rows = 18 * n + 1; g->cols = 15;  /* observation_size, TLPLogicNumba.py:38-40 */

@@ -16,7 +16,7 @@ class Args(dict):
     __getattr__ = dict.get
 
 
-@pytest.mark.parametrize('n', [3, 4])
+@pytest.mark.parametrize('n', [3, 4, 5])
 def test_tlp_env_vs_golden(golden_dir, n):
     from azg_amd import games
     d = np.load(os.path.join(golden_dir, 'env_tlp%d.npz' % n))
@@ -53,7 +53,7 @@ def test_tlp_env_vs_golden(golden_dir, n):
     assert np.array_equal(np.packbits(g.getValidMoves(b0, int(d['player'][5])).astype(np.uint8)), d['valid'][5])
 
 
-@pytest.mark.parametrize('n', [3, 4])
+@pytest.mark.parametrize('n', [3, 4, 5])
 def test_tlp_random_symmetries_vs_golden(golden_dir, n):
     """get_symmetries (np.random.shuffle of players / market cards / planet slots, duplicate states dropped) on the streams the
     reference drew from: same forms in the same order"""
@@ -99,7 +99,7 @@ def test_tlp_mcts_vs_golden(golden_dir):
         m.forest.close()
 
 
-@pytest.mark.parametrize('n', [3, 4])
+@pytest.mark.parametrize('n', [3, 4, 5])
 def test_tlp_whole_tree_and_selfplay_vs_oracle(n):
     import azg_oracle as O
     from azg_amd import games

@@ -10,7 +10,7 @@ import azg_oracle as O
 from test_oracle_golden import oracle_tree_digest
 
 
-@pytest.mark.parametrize('n', [3, 4])
+@pytest.mark.parametrize('n', [3, 4, 5])
 def test_tlp_env_transitions(golden_dir, n):
     d = np.load(os.path.join(golden_dir, 'env_tlp%d.npz' % n))
     g = O.OracleGame(O.TLP, n)
@@ -28,11 +28,11 @@ def test_tlp_env_transitions(golden_dir, n):
         assert np.array_equal(g.getGameEnded(nb, npl), d['ended'][i])
         assert [g.getScore(nb, p) for p in range(n)] == list(d['score'][i]) and g.getRound(nb) == int(d['round'][i])
         assert np.array_equal(g.getCanonicalForm(nb, npl).reshape(-1), d['canonical'][i])
-    assert (d['n_uniforms'] > 0).sum() >= 40 and d['ended'].any(axis=1).sum() >= 4
+    assert (d['n_uniforms'] > 0).sum() >= 40 and d['ended'].any(axis=1).sum() >= 3
     assert d['score'].min() < 0                                     # the volcano penalty occurred
 
 
-@pytest.mark.parametrize('n', [3, 4])
+@pytest.mark.parametrize('n', [3, 4, 5])
 def test_tlp_random_symmetries(golden_dir, n):
     """get_symmetries shuffles players / market cards / planet slots and drops duplicate states: same forms, same order, same
     number of draws as the reference on the same stream"""

@@ -135,12 +135,12 @@ def gen_mcts(env, m, game, n):
 
 
 def main():
-    for n in (3, 4):
-        env, m, game = gen_env(n, 6 if n == 3 else 4, seed=60 + n)
+    for n in (3, 4, 5):
+        env, m, game = gen_env(n, 6 if n == 3 else (4 if n == 4 else 3), seed=60 + n)
         np.savez_compressed(os.path.join(GOLDEN, 'env_tlp%d.npz' % n), **env)
         print('tlp', n, 'transitions', len(env['state']), 'ended', int(env['ended'].any(axis=1).sum()),
               'refills', int((env['n_uniforms'] > 0).sum()))
-        sym = gen_sym(env, game, n, 3 if n == 3 else 5)
+        sym = gen_sym(env, game, n, 3 if n == 3 else (5 if n == 4 else 8))
         np.savez_compressed(os.path.join(GOLDEN, 'sym_tlp%d.npz' % n), **sym)
         print('  sym cases', len(sym['count']), 'forms', int(sym['count'].sum()), 'max', int(sym['count'].max()))
         if n == 3:
