@@ -49,7 +49,9 @@ extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
         else if ((game) == AZG_TLP && (variant) == 4) { using G = TLPDev<4>; __VA_ARGS__; }               \
         else if ((game) == AZG_TLP && (variant) == 5) { using G = TLPDev<5>; __VA_ARGS__; }               \
         else if ((game) == AZG_BOTANIK) { using G = BotanikDev; __VA_ARGS__; }                             \
-        else if ((game) == AZG_AKROPOLIS) { using G = AkropolisDev; __VA_ARGS__; }                         \
+        else if ((game) == AZG_AKROPOLIS && (variant) == 2) { using G = AkropolisDev<2>; __VA_ARGS__; }   \
+        else if ((game) == AZG_AKROPOLIS && (variant) == 3) { using G = AkropolisDev<3>; __VA_ARGS__; }   \
+        else if ((game) == AZG_AKROPOLIS && (variant) == 4) { using G = AkropolisDev<4>; __VA_ARGS__; }   \
         else if ((game) == AZG_SMALLWORLD && (variant) == 2) { using G = SmallworldDev<2>; __VA_ARGS__; } \
         else if ((game) == AZG_SMALLWORLD && (variant) == 3) { using G = SmallworldDev<3>; __VA_ARGS__; } \
         else if ((game) == AZG_SMALLWORLD && (variant) == 4) { using G = SmallworldDev<4>; __VA_ARGS__; } \
@@ -68,7 +70,7 @@ static int norm_variant(int game, int variant) {
     if (game == AZG_ABALONE) return 1;
     if (game == AZG_TLP) return variant ? variant : 3;
     if (game == AZG_BOTANIK) return 2;
-    if (game == AZG_AKROPOLIS) return 2;
+    if (game == AZG_AKROPOLIS) return variant ? variant : 2;
     if (game == AZG_SMALLWORLD) return variant ? variant : 2;
     return variant;
 }

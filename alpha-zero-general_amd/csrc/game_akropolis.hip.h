@@ -1,13 +1,14 @@
 // game_akropolis.hip.h -- Akropolis env step on the device plugin interface: akropolis/AkropolisLogicNumba.py
-// (Board :270-611, grid helpers :95-131, tables :184-230) with the shipped constants (AkropolisConstants.py: N_PLAYERS = 2,
-// CITY_SIZE = 13, CONSTR_SITE_SIZE = 4, N_STACKS = 11).
+// (Board :270-611, grid helpers :95-131, tables :184-230) for N = N_PLAYERS = 2 (the shipped constant), 3 and 4
+// (AkropolisConstants.py: CITY_SIZE = 13, CONSTR_SITE_SIZE = N + 2, N_STACKS = 11; the tile set grows with N).
 //
-// State int8 [13][13][8] (:7-32), byte (r * 13 + q) * 8 + z on an odd-r offset hex grid:
-//   z = p      tile description of player p's city (0 empty, 1 quarry, 2..6 district B Y R P G, 7..11 plaza B Y R P G)
-//   z = 2 + p  height, z = 4 + p  tile id (61 = the start tile)
-//   z = 6      per-player scalars at (row, col): (p, c) plazas, (2 + p, c) districts, (4 + p, 0) total score code, (4 + p, 1) stones
-//   z = 7      globals: (i, j) construction-site tile i = three descriptions + tile id, (4, 0..7) bitfield of the tiles still in the
-//              stacks (MSB first), (5, 0) round, (5, 1) stacks left
+// State int8 [13][13][3 N + 2] (:7-32), byte (r * 13 + q) * (3 N + 2) + z on an odd-r offset hex grid:
+//   z = p          tile description of player p's city (0 empty, 1 quarry, 2..6 district B Y R P G, 7..11 plaza B Y R P G)
+//   z = N + p      height, z = 2 N + p  tile id (61 = the start tile)
+//   z = 3 N        per-player scalars at (row, col): (p, c) plazas, (N + p, c) districts, (2 N + p, 0) total score code,
+//                  (2 N + p, 1) stones
+//   z = 3 N + 1    globals: (i, j) construction-site tile i = three descriptions + tile id, (N + 2, 0..7) bitfield of the tiles still
+//                  in the stacks (MSB first), (N + 3, 0) round, (N + 3, 1) stacks left
 // Action = slot * 1014 + cell * 6 + orientation (:53-61); pattern (cell, o) covers cell + DIR[o], cell, cell + DIR[o + 1].
 //
 // The env step is a function of (state, action, random_seed) for random_seed != 0 -- the refill is (2014 (seed + round) + 42) mod 61
@@ -16,38 +17,43 @@
 // grid: cells and patterns fall off the board, the scatter wraps index -1 to the last action and later writers win -- lane 0 builds
 // the forms exactly as written (BUILT symmetric forms, k_env_symmetries_built).
 //
-// Valid moves: 1014 pattern predicates in 16 ballots, expanded to the 4 slots in 64 words; make_move / init on lane 0 (district
-// scoring = flood fills over 169 cells with bitset work lists); swap_players is a byte map applied by all lanes.
+// Valid moves: 1014 pattern predicates in 16 ballots, expanded to the N + 2 slots in 64..96 words; make_move / init on lane 0
+// (district scoring = flood fills over 169 cells with bitset work lists); swap_players is a byte map applied by all lanes.
 #pragma once
 #include "azg_common.hip.h"
 #include "akropolis_tables.h"
 
 namespace azg {
 
+template <int NPL>
 struct AkropolisDev {
-    static constexpr int P = 2;
-    static constexpr int ROWS = 169, COLS = 8;
-    static constexpr int S = 1352;
+    static constexpr int P = NPL;
+    static constexpr int ST = 3 * NPL + 2;         // bytes per cell
+    static constexpr int ROWS = 169, COLS = ST;
+    static constexpr int S = 169 * ST;
     static constexpr int SP = RoundUp16<S>::value;
-    static constexpr int A = 4056;
+    static constexpr int A = (NPL + 2) * 1014;
     static constexpr int AW = (A + 63) / 64;
     static constexpr bool STOCHASTIC = false;
     static constexpr bool RANDOM_SYM = true;      // symmetric forms are built by lane 0 (k_env_symmetries_built); no draw is consumed
     static constexpr bool SYM_DEDUP = false;
-    static constexpr int REC_NV_HINT = 1200;      // a few hundred placements x up to 4 affordable tiles per node (record heap sizing)
+    static constexpr int REC_NV_HINT = 1200;      // a few hundred placements x the affordable tiles per node (record heap sizing)
     enum { EMPTY = 0, QUARRY = 1, DISTRICT_BLUE = 2, DISTRICT_YELLOW = 3, DISTRICT_RED = 4, DISTRICT_PURPLE = 5, DISTRICT_GREEN = 6,
            PLAZA_BLUE = 7 };
     enum { BLUE, YELLOW, RED, PURPLE, GREEN };
-    enum { CS = 13, AREA = 169, NPAT = 1014, NSITE = 4 };
-    enum { O_ROUND = ((NSITE + 1) * CS) * 8 + 7, O_STACKS = ((NSITE + 1) * CS + 1) * 8 + 7 };
+    enum { CS = 13, AREA = 169, NPAT = 1014, NSITE = NPL + 2, ZS = 3 * NPL, ZG = 3 * NPL + 1 };
+    enum { O_ROUND = ((NSITE + 1) * CS) * ST + ZG, O_STACKS = ((NSITE + 1) * CS + 1) * ST + ZG };
 
-    __device__ static __forceinline__ int at(int r, int q, int z) { return ((r * CS + q) << 3) + z; }
-    __device__ static __forceinline__ int o_plazas(int p, int c) { return at(p, c, 6); }
-    __device__ static __forceinline__ int o_districts(int p, int c) { return at(2 + p, c, 6); }
-    __device__ static __forceinline__ int o_total(int p) { return at(4 + p, 0, 6); }
-    __device__ static __forceinline__ int o_stones(int p) { return at(4 + p, 1, 6); }
-    __device__ static __forceinline__ int o_site(int i, int j) { return at(i, j, 7); }
-    __device__ static __forceinline__ int o_bitpack(int j) { return at(NSITE, j, 7); }
+    __device__ static __forceinline__ int at(int r, int q, int z) { return (r * CS + q) * ST + z; }
+    __device__ static __forceinline__ int o_descr(int idx, int p) { return idx * ST + p; }
+    __device__ static __forceinline__ int o_height(int idx, int p) { return idx * ST + NPL + p; }
+    __device__ static __forceinline__ int o_tileid(int idx, int p) { return idx * ST + 2 * NPL + p; }
+    __device__ static __forceinline__ int o_plazas(int p, int c) { return at(p, c, ZS); }
+    __device__ static __forceinline__ int o_districts(int p, int c) { return at(NPL + p, c, ZS); }
+    __device__ static __forceinline__ int o_total(int p) { return at(2 * NPL + p, 0, ZS); }
+    __device__ static __forceinline__ int o_stones(int p) { return at(2 * NPL + p, 1, ZS); }
+    __device__ static __forceinline__ int o_site(int i, int j) { return at(i, j, ZG); }
+    __device__ static __forceinline__ int o_bitpack(int j) { return at(NSITE, j, ZG); }
     __device__ static __forceinline__ int stars(int c) { return c == 0 ? 1 : (c == 4 ? 3 : 2); }                 // PLAZA_STARS
     __device__ static __forceinline__ int type_of(int d) { return d == 0 ? 0 : (d == 1 ? 1 : (d <= 6 ? 2 : 3)); }   // DESCR_TO_TYPE_COLOR
     __device__ static __forceinline__ int color_of(int d) { return d <= 1 ? 0 : (d <= 6 ? d - 2 : d - 7); }
@@ -117,15 +123,15 @@ struct AkropolisDev {
         int n = 0;
         outer.clear(); seen.clear();
         for (int i = 0; i < AREA; i++) {
-            const int d = st[(i << 3) + p], h = st[(i << 3) + 2 + p];
+            const int d = st[o_descr(i, p)], h = st[o_height(i, p)];
             if (d == DISTRICT_GREEN) district[GREEN] += h;
             else if (d == DISTRICT_YELLOW) {
                 bool isolated = true;
-                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb >= 0 && st[(nb << 3) + p] == DISTRICT_YELLOW) isolated = false; }
+                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb >= 0 && st[o_descr(nb, p)] == DISTRICT_YELLOW) isolated = false; }
                 if (isolated) district[YELLOW] += h;
             } else if (d == DISTRICT_PURPLE) {
                 bool ok = true;
-                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || st[(nb << 3) + 2 + p] == 0) ok = false; }
+                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || st[o_height(nb, p)] == 0) ok = false; }
                 if (ok) district[PURPLE] += h;
             } else if (d == EMPTY) {
                 bool border = false;
@@ -136,23 +142,23 @@ struct AkropolisDev {
         for (int k0 = 0; k0 < n; k0++)                                         // flood fill of the empty cells from the border
             for (int k = 0; k < 6; k++) {
                 const int nb = neighbor(stack[k0], k);
-                if (nb < 0 || outer.get(nb) || st[(nb << 3) + p] != EMPTY) continue;
+                if (nb < 0 || outer.get(nb) || st[o_descr(nb, p)] != EMPTY) continue;
                 outer.set(nb); stack[n++] = (uint8_t)nb;
             }
         for (int i = 0; i < AREA; i++)
-            if (st[(i << 3) + p] == DISTRICT_RED)
-                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || outer.get(nb)) { district[RED] += st[(i << 3) + 2 + p]; break; } }
+            if (st[o_descr(i, p)] == DISTRICT_RED)
+                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || outer.get(nb)) { district[RED] += st[o_height(i, p)]; break; } }
         int best = 0;
         for (int s0 = 0; s0 < AREA; s0++) {                                    // heaviest chain of houses
-            if (st[(s0 << 3) + p] != DISTRICT_BLUE || seen.get(s0)) continue;
+            if (st[o_descr(s0, p)] != DISTRICT_BLUE || seen.get(s0)) continue;
             int chain = 0, top = 0;
             stack[top++] = (uint8_t)s0; seen.set(s0);
             while (top) {
                 const int cur = stack[--top];
-                chain += st[(cur << 3) + 2 + p];
+                chain += st[o_height(cur, p)];
                 for (int k = 0; k < 6; k++) {
                     const int nb = neighbor(cur, k);
-                    if (nb < 0 || seen.get(nb) || st[(nb << 3) + p] != DISTRICT_BLUE) continue;
+                    if (nb < 0 || seen.get(nb) || st[o_descr(nb, p)] != DISTRICT_BLUE) continue;
                     seen.set(nb); stack[top++] = (uint8_t)nb;
                 }
             }
@@ -166,20 +172,20 @@ struct AkropolisDev {
     __device__ static bool pattern_valid(const int8_t* st, int pat, int player) {
         int c[3];
         if (!pattern_cells(pat, c)) return false;
-        const int ha = st[(c[0] << 3) + 2 + player];
-        if (ha != st[(c[1] << 3) + 2 + player] || ha != st[(c[2] << 3) + 2 + player]) return false;
+        const int ha = st[o_height(c[0], player)];
+        if (ha != st[o_height(c[1], player)] || ha != st[o_height(c[2], player)]) return false;
         if (ha == 0) {
             bool connected = false;
 #pragma unroll 1
             for (int j = 0; j < 3; j++)
                 for (int k = 0; k < 6; k++) {
                     const int nb = neighbor(c[j], k);
-                    connected = connected || (nb >= 0 && st[(nb << 3) + 2 + player] > 0);      // (the triple itself has height 0)
+                    connected = connected || (nb >= 0 && st[o_height(nb, player)] > 0);      // (the triple itself has height 0)
                 }
             return connected;
         }
-        const int ta = st[(c[0] << 3) + 4 + player];
-        return !(ta == st[(c[1] << 3) + 4 + player] && ta == st[(c[2] << 3) + 4 + player]);
+        const int ta = st[o_tileid(c[0], player)];
+        return !(ta == st[o_tileid(c[1], player)] && ta == st[o_tileid(c[2], player)]);
     }
     // Board.valid_moves :354-413: the pattern predicates go to mask_lds[0..15] first, then every action looks its pattern up; words are
     // finalised from the top so that a word is overwritten only after its last reader
@@ -208,7 +214,7 @@ struct AkropolisDev {
     }
 
     __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
-        return lane0_make_move<AkropolisDev>(st, move, player, seed, rng);
+        return lane0_make_move<AkropolisDev<NPL>>(st, move, player, seed, rng);
     }
     // Board.make_move :314-352 -- lane 0 only
     __device__ static int make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
@@ -221,12 +227,12 @@ struct AkropolisDev {
         for (int j = 0; j < 4; j++) st[o_site(NSITE - 1, j)] = EMPTY;
         pattern_cells(pat, c);
         for (int j = 0; j < 3; j++) {
-            const int under = st[(c[j] << 3) + player];
+            const int under = st[o_descr(c[j], player)];
             if (type_of(under) == 3) st[o_plazas(player, color_of(under))] = (int8_t)(st[o_plazas(player, color_of(under))] - 1);
             if (type_of(under) == 1) st[o_stones(player)] = (int8_t)(st[o_stones(player)] + 1);
-            st[(c[j] << 3) + player] = tile[j];
-            st[(c[j] << 3) + 2 + player] = (int8_t)(st[(c[j] << 3) + 2 + player] + 1);
-            st[(c[j] << 3) + 4 + player] = tile[3];
+            st[o_descr(c[j], player)] = tile[j];
+            st[o_height(c[j], player)] = (int8_t)(st[o_height(c[j], player)] + 1);
+            st[o_tileid(c[j], player)] = tile[3];
             if (type_of(tile[j]) == 3) st[o_plazas(player, color_of(tile[j]))] = (int8_t)(st[o_plazas(player, color_of(tile[j]))] + 1);
         }
         st[o_stones(player)] = (int8_t)(st[o_stones(player)] - slot);
@@ -237,31 +243,45 @@ struct AkropolisDev {
             draw_tiles(st, seed, false, rng);
             st[O_STACKS] = (int8_t)(st[O_STACKS] - 1);
         }
-        return (player + 1) & 1;
+        return player + 1 == NPL ? 0 : player + 1;
     }
 
     // Board.check_end_game :426-437 (uniform)
     __device__ static bool game_ended(const int8_t* st, int next_player, float* out, uint64_t* mask_scratch) {
         (void)next_player; (void)mask_scratch;
-        if (!(st[O_STACKS] <= 0 && st[o_site(1, 0)] == EMPTY)) { out[0] = 0.f; out[1] = 0.f; return false; }
-        const long long a = (long long)get_score(st, 0) * 1000 + st[o_stones(0)], b = (long long)get_score(st, 1) * 1000 + st[o_stones(1)];
-        out[0] = a > b ? 1.f : (a < b ? -1.f : 0.001f);
-        out[1] = b > a ? 1.f : (b < a ? -1.f : 0.001f);
+        if (!(st[O_STACKS] <= 0 && st[o_site(1, 0)] == EMPTY)) {
+#pragma unroll
+            for (int p = 0; p < NPL; p++) out[p] = 0.f;
+            return false;
+        }
+        int proxy[NPL], m = -1, nmax = 0;
+#pragma unroll
+        for (int p = 0; p < NPL; p++) { proxy[p] = get_score(st, p) * 1000 + st[o_stones(p)]; m = proxy[p] > m ? proxy[p] : m; }
+#pragma unroll
+        for (int p = 0; p < NPL; p++) nmax += proxy[p] == m;
+#pragma unroll
+        for (int p = 0; p < NPL; p++) out[p] = proxy[p] == m ? (nmax == 1 ? 1.f : 0.001f) : -1.f;
         return true;
     }
 
-    // Board.swap_players :439-470 (k odd): the per-player planes and scalars trade places
+    // Board.swap_players :439-470: new[p] = old[(p + k) % N] in the per-player planes and scalars
     __device__ static void swap_players(int8_t* st, int8_t* tmp, int k) {
-        if ((k & 1) == 0) return;
+        k = ((k % NPL) + NPL) % NPL;
+        if (k == 0) return;
         for (int i = lane_id(); i < S; i += 64) tmp[i] = st[i];
         wave_sync();
         for (int i = lane_id(); i < S; i += 64) {
-            const int cell = i >> 3, z = i & 7;
+            const int cell = i / ST, z = i - cell * ST;
             int src = i;
-            if (z < 6) src = i ^ 1;
-            else if (z == 6) {
+            if (z < ZS) {
+                const int b = z / NPL, p = z - b * NPL;
+                src = cell * ST + b * NPL + (p + k) % NPL;
+            } else if (z == ZS) {
                 const int r = cell / CS, q = cell - r * CS;
-                if (r < 6 && (r < 4 ? q < 5 : q < 2)) src = at(r ^ 1, q, 6);
+                if (r < 3 * NPL && (r < 2 * NPL ? q < 5 : q < 2)) {
+                    const int b = r / NPL, p = r - b * NPL;
+                    src = at(b * NPL + (p + k) % NPL, q, ZS);
+                }
             }
             st[i] = tmp[src];
         }
@@ -270,18 +290,18 @@ struct AkropolisDev {
 
     // init_game :275-295 -- lane 0; state zeroed by the caller
     __device__ static void init_board(int8_t* st, Rng& rng) {
-        st[o_stones(0)] = 1; st[o_stones(1)] = 2;
+        for (int p = 0; p < NPL; p++) st[o_stones(p)] = (int8_t)(p + 1);
         for (int t = 0; t < 61; t++)
-            if ((AKRO_TILES[t] >> 12) <= 2) st[o_bitpack(t >> 3)] = (int8_t)(((uint8_t)st[o_bitpack(t >> 3)]) | (128u >> (t & 7)));
+            if ((int)(AKRO_TILES[t] >> 12) <= NPL) st[o_bitpack(t >> 3)] = (int8_t)(((uint8_t)st[o_bitpack(t >> 3)]) | (128u >> (t & 7)));
         st[O_STACKS] = 11;
-        for (int p = 0; p < 2; p++) st[o_total(p)] = (int8_t)(st[o_stones(p)] / 2 - 128);
+        for (int p = 0; p < NPL; p++) st[o_total(p)] = (int8_t)(st[o_stones(p)] / 2 - 128);
         const int centre = (CS / 2) * CS + CS / 2;
-        for (int p = 0; p < 2; p++) {
-            st[(centre << 3) + p] = PLAZA_BLUE; st[(centre << 3) + 2 + p] = 1; st[(centre << 3) + 4 + p] = 61;
+        for (int p = 0; p < NPL; p++) {
+            st[o_descr(centre, p)] = PLAZA_BLUE; st[o_height(centre, p)] = 1; st[o_tileid(centre, p)] = 61;
             st[o_plazas(p, BLUE)] = 1;
             for (int d = 0; d < 6; d += 2) {                                   // NEIGHBORS[centre, ::2]
                 const int nb = neighbor(centre, d);
-                st[(nb << 3) + p] = QUARRY; st[(nb << 3) + 2 + p] = 1; st[(nb << 3) + 4 + p] = 61;
+                st[o_descr(nb, p)] = QUARRY; st[o_height(nb, p)] = 1; st[o_tileid(nb, p)] = 61;
             }
         }
         draw_tiles(st, 0, true, rng);
@@ -311,11 +331,11 @@ struct AkropolisDev {
     }
     __device__ static bool sym_build(const int8_t* st, int c, int8_t* cand, int16_t* act_src, Rng& rng, const uint8_t* valids) {
         (void)rng;
-        for (int i = 0; i < S; i++) cand[i] = (i & 7) >= 6 ? st[i] : 0;          // the scalar layers z = 6, 7 are kept (:486)
+        for (int i = 0; i < S; i++) cand[i] = (i % ST) >= ZS ? st[i] : 0;        // the scalar layers z = 3 N, 3 N + 1 are kept (:486)
         for (int i = 0; i < AREA; i++) {
             const int nb = rotate_cell(i, c);
             if (nb >= 0)
-                for (int z = 0; z < 6; z++) cand[(nb << 3) + z] = st[(i << 3) + z];
+                for (int z = 0; z < ZS; z++) cand[nb * ST + z] = st[i * ST + z];
         }
         for (int a = 0; a < A; a++) act_src[a] = -1;
         for (int a = 0; a < A; a++)

@@ -74,7 +74,7 @@ class Forest:
 
     def board_shape(self):
         g = self.cfg.game
-        return (5, 5, 3) if g == _lib.SANTORINI else (9, 9, 4) if g == _lib.ABALONE else (66, 5, 7) if g == _lib.BOTANIK else (13, 13, 8) if g == _lib.AKROPOLIS else (self.rows, self.cols)
+        return (5, 5, 3) if g == _lib.SANTORINI else (9, 9, 4) if g == _lib.ABALONE else (66, 5, 7) if g == _lib.BOTANIK else (13, 13, self.cols) if g == _lib.AKROPOLIS else (self.rows, self.cols)
 
     def reset(self):
         check(lib().azg_forest_reset(self.h, _stream()))

@@ -104,7 +104,7 @@ class HipGame:
 
     def getBoardSize(self):
         return ((5, 5, 3) if self.GAME_ID == _lib.SANTORINI else (9, 9, 4) if self.GAME_ID == _lib.ABALONE else (66, 5, 7) if self.GAME_ID == _lib.BOTANIK
-                else (13, 13, 8) if self.GAME_ID == _lib.AKROPOLIS else (self.rows, self.cols))
+                else (13, 13, self.cols) if self.GAME_ID == _lib.AKROPOLIS else (self.rows, self.cols))
 
     def getActionSize(self):
         return self.A
@@ -214,11 +214,11 @@ class BotanikGame(HipGame):
 
 
 class AkropolisGame(HipGame):
-    """akropolis/AkropolisGame.py (2 players, 13 x 13 city: the shipped constants)"""
+    """akropolis/AkropolisGame.py (N_PLAYERS 2 -- the shipped constant -- 3 or 4; 13 x 13 cities, N + 2 tiles on the construction site)"""
     GAME_ID = _lib.AKROPOLIS
 
-    def __init__(self, **kw):
-        super().__init__(2, **kw)
+    def __init__(self, num_players=2, **kw):
+        super().__init__(num_players, **kw)
 
 
 class SmallworldGame(HipGame):

@@ -42,7 +42,9 @@ int azg_set_device(int device);
 /* GameSwitcher.import_game + Game.getBoardSize/getActionSize/getNumberOfPlayers (GameSwitcher.py:15-24, Game.py:27-42).
    variant: Splendor = NUMBER_PLAYERS (2..4, splendor/SplendorGame.py:9); Santorini = NB_GODS (1 or 11,
    santorini/SantoriniConstants.py:19); Azul = 2 players (azul/AzulGame.py:9); Minivilles = NUMBER_PLAYERS (2..4,
-   minivilles/MinivillesGame.py:9); Abalone = 2 players, Belgian-Daisy layout (abalone/AbaloneLogicNumba.py:5). */
+   minivilles/MinivillesGame.py:9); Abalone = 2 players, Belgian-Daisy layout (abalone/AbaloneLogicNumba.py:5); The Little Prince =
+   NUMBER_PLAYERS (3..5, thelittleprince/TLPGame.py:9); Botanik = 2 players; Akropolis = N_PLAYERS (2..4,
+   akropolis/AkropolisConstants.py:3); Smallworld = NUMBER_PLAYERS (2..4, smallworld/SmallworldConstants.py).  0 = the shipped constant. */
 int azg_game_info(int game, int variant, int* state_bytes, int* action_size, int* num_players, int* rows, int* cols);
 
 /* ---- batched env step (one wavefront per state) ------------------------------------------------------------------

@@ -1,13 +1,14 @@
 /* ORACLE (test infrastructure).  Akropolis env step: a scalar restatement of akropolis/AkropolisLogicNumba.py (Board :270-611, grid
- * helpers :95-131, tables :184-230) with the shipped constants (akropolis/AkropolisConstants.py: N_PLAYERS = 2, CITY_SIZE = 13,
- * CONSTR_SITE_SIZE = 4, N_STACKS = 11).
+ * helpers :95-131, tables :184-230) for N = N_PLAYERS = 2 (the shipped constant), 3 and 4 (akropolis/AkropolisConstants.py:
+ * CITY_SIZE = 13, CONSTR_SITE_SIZE = N + 2, N_STACKS = 11; the tile set grows with N, TILES_DATA[:, 3] <= N).
  *
- * State = int8 [13][13][8] (:7-32), byte index (r * 13 + q) * 8 + z, odd-r offset hex grid:
- *   z = p      tile description of player p's city (0 empty, 1 quarry, 2..6 district B Y R P G, 7..11 plaza B Y R P G)
- *   z = 2 + p  height, z = 4 + p  tile id (61 = the start tile)
- *   z = 6      per-player scalars at (row, col): (p, c) plazas, (2 + p, c) districts, (4 + p, 0) total score code, (4 + p, 1) stones
- *   z = 7      globals: (i, j) construction site tile i = three descriptions + tile id, (4, 0..7) bitfield of the tiles still in the
- *              stacks (MSB first), (5, 0) round, (5, 1) stacks left
+ * State = int8 [13][13][3 N + 2] (:7-32), byte index (r * 13 + q) * (3 N + 2) + z, odd-r offset hex grid:
+ *   z = p          tile description of player p's city (0 empty, 1 quarry, 2..6 district B Y R P G, 7..11 plaza B Y R P G)
+ *   z = N + p      height, z = 2 N + p  tile id (61 = the start tile)
+ *   z = 3 N        per-player scalars at (row, col): (p, c) plazas, (N + p, c) districts, (2 N + p, 0) total score code,
+ *                  (2 N + p, 1) stones
+ *   z = 3 N + 1    globals: (i, j) construction site tile i = three descriptions + tile id, (N + 2, 0..7) bitfield of the tiles still
+ *                  in the stacks (MSB first), (N + 3, 0) round, (N + 3, 1) stacks left
  * Action = slot * 1014 + cell * 6 + orientation (:53-61); pattern (cell, o) covers cell + DIR[o], cell, cell + DIR[o + 1] (:198-216).
  *
  * Randomness (_draw_tiles_constr_site :503-518): with random_seed != 0 (MCTS simulations) the refill is the function
@@ -25,17 +26,22 @@ enum { BLUE, YELLOW, RED, PURPLE, GREEN };
 #define CS 13
 #define AREA 169
 #define NPAT 1014
-#define NSITE 4
-#define AT(s, r, q, z) ((s)[(((r) * CS + (q)) << 3) + (z)])
-#define FLAT(s, idx, z) ((s)[((idx) << 3) + (z)])
-#define PLAZAS(s, p, c) AT(s, p, c, 6)
-#define DISTRICTS(s, p, c) AT(s, 2 + (p), c, 6)
-#define TOTAL(s, p) AT(s, 4 + (p), 0, 6)
-#define STONES(s, p) AT(s, 4 + (p), 1, 6)
-#define SITE(s, i, j) AT(s, i, j, 7)
-#define BITPACK(s, j) AT(s, NSITE, j, 7)
-#define ROUND_(s) AT(s, NSITE + 1, 0, 7)
-#define STACKS(s) AT(s, NSITE + 1, 1, 7)
+/* the bound game's player count (N_PLAYERS): set by ak_bind() at every entry point; cell stride ST = 3 NP + 2 bytes */
+static __thread int NP = 2, ST = 8, NSITE = 4;
+static void ak_bind(const azo_game* g) { NP = g->P; ST = 3 * NP + 2; NSITE = NP + 2; }
+#define AT(s, r, q, z) ((s)[((r) * CS + (q)) * ST + (z)])
+#define FLAT(s, idx, z) ((s)[(idx) * ST + (z)])
+#define DESCR(s, idx, p) FLAT(s, idx, p)
+#define HEIGHT(s, idx, p) FLAT(s, idx, NP + (p))
+#define TILEID(s, idx, p) FLAT(s, idx, 2 * NP + (p))
+#define PLAZAS(s, p, c) AT(s, p, c, 3 * NP)
+#define DISTRICTS(s, p, c) AT(s, NP + (p), c, 3 * NP)
+#define TOTAL(s, p) AT(s, 2 * NP + (p), 0, 3 * NP)
+#define STONES(s, p) AT(s, 2 * NP + (p), 1, 3 * NP)
+#define SITE(s, i, j) AT(s, i, j, 3 * NP + 1)
+#define BITPACK(s, j) AT(s, NSITE, j, 3 * NP + 1)
+#define ROUND_(s) AT(s, NSITE + 1, 0, 3 * NP + 1)
+#define STACKS(s) AT(s, NSITE + 1, 1, 3 * NP + 1)
 static const int PLAZA_STARS[5] = {1, 2, 2, 2, 3};
 /* (dq, dr): SW SE E NE NW W (AkropolisConstants.py:77-80) */
 static const int DIR_EVEN[6][2] = {{-1, 1}, {0, 1}, {1, 0}, {0, -1}, {-1, -1}, {-1, 0}};
@@ -88,7 +94,7 @@ static void update_districts(int8_t* s, int p) {                                
     int stack[AREA], n = 0;
     memset(outer, 0, sizeof(outer)); memset(seen, 0, sizeof(seen));
     for (int i = 0; i < AREA; i++) {
-        const int d = FLAT(s, i, p), h = FLAT(s, i, 2 + p);
+        const int d = FLAT(s, i, p), h = HEIGHT(s, i, p);
         if (d == DISTRICT_GREEN) district[GREEN] += h;
         else if (d == DISTRICT_YELLOW) {
             int isolated = 1;
@@ -96,7 +102,7 @@ static void update_districts(int8_t* s, int p) {                                
             if (isolated) district[YELLOW] += h;
         } else if (d == DISTRICT_PURPLE) {
             int ok = 1;
-            for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || FLAT(s, nb, 2 + p) == 0) ok = 0; }
+            for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || HEIGHT(s, nb, p) == 0) ok = 0; }
             if (ok) district[PURPLE] += h;
         } else if (d == EMPTY) {
             for (int k = 0; k < 6; k++) if (neighbor(i, k) < 0) { outer[i] = 1; break; }
@@ -111,7 +117,7 @@ static void update_districts(int8_t* s, int p) {                                
         }
     for (int i = 0; i < AREA; i++)
         if (FLAT(s, i, p) == DISTRICT_RED)
-            for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || outer[nb]) { district[RED] += FLAT(s, i, 2 + p); break; } }
+            for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || outer[nb]) { district[RED] += HEIGHT(s, i, p); break; } }
     int best = 0;
     for (int st0 = 0; st0 < AREA; st0++) {                                                 /* heaviest chain of houses */
         if (FLAT(s, st0, p) != DISTRICT_BLUE || seen[st0]) continue;
@@ -119,7 +125,7 @@ static void update_districts(int8_t* s, int p) {                                
         stack[top++] = st0; seen[st0] = 1;
         while (top) {
             const int cur = stack[--top];
-            chain += FLAT(s, cur, 2 + p);
+            chain += HEIGHT(s, cur, p);
             for (int k = 0; k < 6; k++) {
                 const int nb = neighbor(cur, k);
                 if (nb < 0 || seen[nb] || FLAT(s, nb, p) != DISTRICT_BLUE) continue;
@@ -135,21 +141,22 @@ static void update_districts(int8_t* s, int p) {                                
 static int pattern_valid(const int8_t* s, int pat, int player) {                           /* valid_moves :358-398 */
     int c[3];
     if (!pattern_cells(pat, c)) return 0;
-    const int ha = FLAT(s, c[0], 2 + player);
-    if (ha != FLAT(s, c[1], 2 + player) || ha != FLAT(s, c[2], 2 + player)) return 0;
+    const int ha = HEIGHT(s, c[0], player);
+    if (ha != HEIGHT(s, c[1], player) || ha != HEIGHT(s, c[2], player)) return 0;
     if (ha == 0) {
         for (int j = 0; j < 3; j++)
             for (int k = 0; k < 6; k++) {
                 const int nb = neighbor(c[j], k);
-                if (nb >= 0 && FLAT(s, nb, 2 + player) > 0) return 1;                      /* (the triple itself has height 0) */
+                if (nb >= 0 && HEIGHT(s, nb, player) > 0) return 1;                      /* (the triple itself has height 0) */
             }
         return 0;
     }
-    const int ta = FLAT(s, c[0], 4 + player);
-    return !(ta == FLAT(s, c[1], 4 + player) && ta == FLAT(s, c[2], 4 + player));
+    const int ta = TILEID(s, c[0], player);
+    return !(ta == TILEID(s, c[1], player) && ta == TILEID(s, c[2], player));
 }
 
 void akropolis_valid_moves(const azo_game* g, const int8_t* s, int player, uint8_t* out) {  /* :354-413 */
+    ak_bind(g);
     memset(out, 0, (size_t)g->A);
     int slots = STONES(s, player) + 1;
     if (slots > NSITE) slots = NSITE;
@@ -160,7 +167,7 @@ void akropolis_valid_moves(const azo_game* g, const int8_t* s, int player, uint8
 }
 
 int akropolis_make_move(const azo_game* g, int8_t* s, int move, int player, int64_t seed, azo_rng* rng) {   /* :314-352 */
-    (void)g;
+    ak_bind(g);
     const int slot = move / NPAT, pat = move % NPAT;
     int8_t tile[4];
     int c[3];
@@ -174,8 +181,8 @@ int akropolis_make_move(const azo_game* g, int8_t* s, int move, int player, int6
         if (type_of(under) == 3) PLAZAS(s, player, color_of(under)) = (int8_t)(PLAZAS(s, player, color_of(under)) - 1);
         if (type_of(under) == 1) STONES(s, player) = (int8_t)(STONES(s, player) + 1);
         FLAT(s, c[j], player) = tile[j];
-        FLAT(s, c[j], 2 + player) = (int8_t)(FLAT(s, c[j], 2 + player) + 1);
-        FLAT(s, c[j], 4 + player) = tile[3];
+        HEIGHT(s, c[j], player) = (int8_t)(HEIGHT(s, c[j], player) + 1);
+        TILEID(s, c[j], player) = tile[3];
         if (type_of(tile[j]) == 3) PLAZAS(s, player, color_of(tile[j])) = (int8_t)(PLAZAS(s, player, color_of(tile[j])) + 1);
     }
     STONES(s, player) = (int8_t)(STONES(s, player) - slot);
@@ -186,50 +193,57 @@ int akropolis_make_move(const azo_game* g, int8_t* s, int move, int player, int6
         draw_tiles(s, seed, 0, rng);
         STACKS(s) = (int8_t)(STACKS(s) - 1);
     }
-    return (player + 1) % 2;
+    return (player + 1) % NP;
 }
 
 void akropolis_game_ended(const azo_game* g, const int8_t* s, int next_player, float* out) { /* :426-437 */
-    (void)g; (void)next_player;
-    out[0] = out[1] = 0.f;
+    (void)next_player;
+    ak_bind(g);
+    for (int p = 0; p < NP; p++) out[p] = 0.f;
     if (!(STACKS(s) <= 0 && SITE(s, 1, 0) == EMPTY)) return;
-    long proxy[2];
-    for (int p = 0; p < 2; p++) proxy[p] = (long)score_of(s, p) * 1000 + STONES(s, p);
-    const long m = proxy[0] > proxy[1] ? proxy[0] : proxy[1];
-    const int single = (proxy[0] == m) + (proxy[1] == m) == 1;
-    for (int p = 0; p < 2; p++) out[p] = proxy[p] == m ? (single ? 1.f : 0.001f) : -1.f;
+    long proxy[4], m = -1;
+    int nmax = 0;
+    for (int p = 0; p < NP; p++) { proxy[p] = (long)score_of(s, p) * 1000 + STONES(s, p); if (proxy[p] > m) m = proxy[p]; }
+    for (int p = 0; p < NP; p++) nmax += proxy[p] == m;
+    for (int p = 0; p < NP; p++) out[p] = proxy[p] == m ? (nmax == 1 ? 1.f : 0.001f) : -1.f;
 }
 
 void akropolis_swap_players(const azo_game* g, int8_t* s, int k) {                          /* :439-470 */
-    (void)g;
-    if (k % 2 == 0) return;
-    for (int i = 0; i < AREA; i++)
-        for (int z = 0; z < 6; z += 2) { const int8_t t = FLAT(s, i, z); FLAT(s, i, z) = FLAT(s, i, z + 1); FLAT(s, i, z + 1) = t; }
-    for (int c = 0; c < 5; c++) {
-        int8_t t = PLAZAS(s, 0, c); PLAZAS(s, 0, c) = PLAZAS(s, 1, c); PLAZAS(s, 1, c) = t;
-        t = DISTRICTS(s, 0, c); DISTRICTS(s, 0, c) = DISTRICTS(s, 1, c); DISTRICTS(s, 1, c) = t;
+    ak_bind(g);
+    k = ((k % NP) + NP) % NP;
+    if (k == 0) return;
+    int8_t t[12];
+    for (int i = 0; i < AREA; i++) {                                                       /* new[p] = old[(p + k) % NP] in every plane */
+        for (int z = 0; z < 3 * NP; z++) t[z] = FLAT(s, i, z);
+        for (int b = 0; b < 3; b++)
+            for (int p = 0; p < NP; p++) FLAT(s, i, b * NP + p) = t[b * NP + (p + k) % NP];
     }
-    int8_t t = TOTAL(s, 0); TOTAL(s, 0) = TOTAL(s, 1); TOTAL(s, 1) = t;
-    t = STONES(s, 0); STONES(s, 0) = STONES(s, 1); STONES(s, 1) = t;
+    for (int c = 0; c < 5; c++) {
+        for (int p = 0; p < NP; p++) { t[p] = PLAZAS(s, p, c); t[4 + p] = DISTRICTS(s, p, c); }
+        for (int p = 0; p < NP; p++) { PLAZAS(s, p, c) = t[(p + k) % NP]; DISTRICTS(s, p, c) = t[4 + (p + k) % NP]; }
+    }
+    for (int p = 0; p < NP; p++) { t[p] = TOTAL(s, p); t[4 + p] = STONES(s, p); }
+    for (int p = 0; p < NP; p++) { TOTAL(s, p) = t[(p + k) % NP]; STONES(s, p) = t[4 + (p + k) % NP]; }
 }
 
-int akropolis_get_round(const azo_game* g, const int8_t* s) { (void)g; return ROUND_(s); }
-int akropolis_get_score(const azo_game* g, const int8_t* s, int p) { (void)g; return score_of(s, p); }
+int akropolis_get_round(const azo_game* g, const int8_t* s) { ak_bind(g); return ROUND_(s); }
+int akropolis_get_score(const azo_game* g, const int8_t* s, int p) { ak_bind(g); return score_of(s, p); }
 
 void akropolis_init_board(const azo_game* g, int8_t* s, azo_rng* rng) {                     /* :275-295 */
+    ak_bind(g);
     memset(s, 0, (size_t)g->S);
-    STONES(s, 0) = 1; STONES(s, 1) = 2;
+    for (int p = 0; p < NP; p++) STONES(s, p) = (int8_t)(p + 1);
     for (int t = 0; t < 61; t++)
-        if ((AKRO_TILES[t] >> 12) <= 2) BITPACK(s, t >> 3) = (int8_t)((uint8_t)BITPACK(s, t >> 3) | (128u >> (t & 7)));
+        if ((int)(AKRO_TILES[t] >> 12) <= NP) BITPACK(s, t >> 3) = (int8_t)((uint8_t)BITPACK(s, t >> 3) | (128u >> (t & 7)));
     STACKS(s) = 11;
-    for (int p = 0; p < 2; p++) TOTAL(s, p) = (int8_t)(STONES(s, p) / 2 - 128);
+    for (int p = 0; p < NP; p++) TOTAL(s, p) = (int8_t)(STONES(s, p) / 2 - 128);
     const int centre = (CS / 2) * CS + CS / 2;
-    for (int p = 0; p < 2; p++) {
-        FLAT(s, centre, p) = PLAZA_BLUE; FLAT(s, centre, 2 + p) = 1; FLAT(s, centre, 4 + p) = 61;
+    for (int p = 0; p < NP; p++) {
+        DESCR(s, centre, p) = PLAZA_BLUE; HEIGHT(s, centre, p) = 1; TILEID(s, centre, p) = 61;
         PLAZAS(s, p, BLUE) = 1;
         for (int d = 0; d < 6; d += 2) {                                                  /* NEIGHBORS[centre, ::2] */
             const int nb = neighbor(centre, d);
-            FLAT(s, nb, p) = QUARRY; FLAT(s, nb, 2 + p) = 1; FLAT(s, nb, 4 + p) = 61;
+            DESCR(s, nb, p) = QUARRY; HEIGHT(s, nb, p) = 1; TILEID(s, nb, p) = 61;
         }
     }
     draw_tiles(s, 0, 1, rng);
@@ -259,6 +273,7 @@ static int rotate_pattern(int pat, int k) {                                     
 
 int akropolis_symmetries(const azo_game* g, const int8_t* s, const float* pi, const uint8_t* valids, int8_t* os, float* op,
                          uint8_t* ov, int max_sym) {
+    ak_bind(g);
     const int S = g->S, A = g->A;
     int k = 0;
     for (int rot = 0; rot < 6 && k < max_sym; rot++, k++) {
@@ -268,9 +283,9 @@ int akropolis_symmetries(const azo_game* g, const int8_t* s, const float* pi, co
         memset(st, 0, (size_t)S); memset(p, 0, sizeof(float) * (size_t)A); memset(v, 0, (size_t)A);
         for (int i = 0; i < AREA; i++) {
             const int nb = rotate_cell(i, rot);
-            if (nb >= 0) memcpy(st + 8 * nb, s + 8 * i, 8);
+            if (nb >= 0) memcpy(st + ST * nb, s + ST * i, (size_t)ST);
         }
-        for (int i = 0; i < AREA; i++) { st[8 * i + 6] = s[8 * i + 6]; st[8 * i + 7] = s[8 * i + 7]; }
+        for (int i = 0; i < AREA; i++) { FLAT(st, i, 3 * NP) = FLAT(s, i, 3 * NP); FLAT(st, i, 3 * NP + 1) = FLAT(s, i, 3 * NP + 1); }
         for (int a = 0; a < A; a++)
             if (valids[a]) {
                 int ni = (a / NPAT) * NPAT + rotate_pattern(a % NPAT, rot);

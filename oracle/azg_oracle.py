@@ -133,7 +133,7 @@ class OracleGame:
             raise ValueError('bad game/variant')
         self.S, self.A, self.P = self.g.S, self.g.A, self.g.P
         self.num_players = self.P
-        self.shape = (5, 5, 3) if game_id == SANTORINI else (9, 9, 4) if game_id == ABALONE else (66, 5, 7) if game_id == BOTANIK else (13, 13, 8) if game_id == AKROPOLIS else (self.g.rows, self.g.cols)   # Azul: (23, 6)
+        self.shape = (5, 5, 3) if game_id == SANTORINI else (9, 9, 4) if game_id == ABALONE else (66, 5, 7) if game_id == BOTANIK else (13, 13, self.g.cols) if game_id == AKROPOLIS else (self.g.rows, self.g.cols)   # Azul: (23, 6)
 
     def getBoardSize(self):
         return self.shape

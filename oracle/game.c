@@ -131,11 +131,13 @@ int azo_game_init(azo_game* g, int game_id, int variant) {
         return 0;
     }
     if (game_id == AZO_AKROPOLIS) {
-        g->variant = 2;
-        g->P = 2;
-        g->rows = 169; g->cols = 8;          /* observation_size (13, 13, 8), AkropolisLogicNumba.py:66-68 (N_PLAYERS = 2) */
-        g->S = 1352;
-        g->A = 4056;                         /* :70-72 */
+        const int n = variant ? variant : 2;                                            /* AkropolisConstants.py N_PLAYERS */
+        if (n < 2 || n > 4) return -1;
+        g->variant = n;
+        g->P = n;
+        g->rows = 169; g->cols = 3 * n + 2;  /* observation_size (13, 13, 3 n + 2), AkropolisLogicNumba.py:66-68 */
+        g->S = 169 * g->cols;
+        g->A = (n + 2) * 1014;               /* :70-72 */
         return 0;
     }
     if (game_id == AZO_BOTANIK) {

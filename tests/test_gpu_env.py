@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
-            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
+            'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 2), 'akropolis3': ('akropolis', 3), 'akropolis4': ('akropolis', 4), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
             'smallworld4': ('smallworld', 4)}
 
 
@@ -22,7 +22,7 @@ def make_game(variant):
     if name == 'abalone':
         return games.AbaloneGame()
     if name == 'akropolis':
-        return games.AkropolisGame()
+        return games.AkropolisGame(v)
     if name == 'smallworld':
         return games.SmallworldGame(v)
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
@@ -57,7 +57,7 @@ def test_env_vs_golden(golden_dir, variant):
     assert np.array_equal(canon.cpu().numpy(), d['canonical'])
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'splendor4', 'santorini11', 'azul', 'akropolis', 'smallworld', 'smallworld4'])
+@pytest.mark.parametrize('variant', ['splendor2', 'splendor4', 'santorini11', 'azul', 'akropolis', 'akropolis4', 'smallworld', 'smallworld4'])
 def test_true_random_moves_and_init_vs_oracle(golden_dir, variant):
     """random_seed == 0 (Coach.py:71) and Board.init_game consume the shared counter-based RNG exactly like the oracle."""
     import torch
@@ -106,7 +106,7 @@ def test_game_py_surface():
     assert g.stringRepresentation(b) == b.tobytes()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'splendor3', 'splendor4', 'santorini1', 'santorini11', 'azul', 'abalone', 'akropolis'])
+@pytest.mark.parametrize('variant', ['splendor2', 'splendor3', 'splendor4', 'santorini1', 'santorini11', 'azul', 'abalone', 'akropolis', 'akropolis3', 'akropolis4'])
 def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
     """Game.getSymmetries on device (azg_env_symmetries) vs the reference's own outputs (tests/golden/sym_*.npz) and, on
     states from random play, vs the oracle."""
@@ -114,10 +114,10 @@ def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
     import azg_oracle as O
     from azg_amd import games
     name, v = {'splendor2': ('splendor', 2), 'splendor3': ('splendor', 3), 'splendor4': ('splendor', 4),
-               'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
+               'santorini1': ('santorini', 1), 'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 2), 'akropolis3': ('akropolis', 3), 'akropolis4': ('akropolis', 4), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
             'smallworld4': ('smallworld', 4)}[variant]
     g = {'splendor': lambda: games.SplendorGame(v), 'santorini': lambda: games.SantoriniGame(v), 'azul': games.AzulGame,
-         'abalone': games.AbaloneGame, 'akropolis': games.AkropolisGame}[name]()
+         'abalone': games.AbaloneGame, 'akropolis': lambda: games.AkropolisGame(v)}[name]()
     og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'abalone': O.ABALONE, 'akropolis': O.AKROPOLIS}[name], v)
     K = g.max_symmetries()
     path = os.path.join(golden_dir, 'sym_%s.npz' % variant)
@@ -145,7 +145,7 @@ def test_symmetries_vs_golden_and_oracle(golden_dir, variant):
                 states.append(c.reshape(-1).copy())
                 vas.append(og.getValidMoves(c, 0).astype(np.uint8))
                 # (Abalone's / Akropolis's get_symmetries only map the entries of valid actions: give pi the support MCTS gives it)
-                pis.append(rng.random(len(va)).astype(np.float32) * (vas[-1] if variant in ('abalone', 'akropolis') else 1))
+                pis.append(rng.random(len(va)).astype(np.float32) * (vas[-1] if name in ('abalone', 'akropolis') else 1))
             b, p = og.getNextState(b, p, int(rng.choice(np.flatnonzero(va))), random_seed=31416 + ply)
             if og.getGameEnded(b, p).any():
                 break

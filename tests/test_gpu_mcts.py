@@ -10,7 +10,7 @@ from tools_args import MCTS_ARGS
 
 pytestmark = pytest.mark.gpu
 
-F4_VARIANTS = {'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
+F4_VARIANTS = {'abalone': ('abalone', 0), 'akropolis': ('akropolis', 2), 'akropolis3': ('akropolis', 3), 'akropolis4': ('akropolis', 4), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
                'smallworld4': ('smallworld', 4)}           # SURVEY.md §8 f4 games with the standard (deterministic-step) fixtures
 VARIANTS = {'splendor2': ('splendor', 2), 'splendor4': ('splendor', 4), 'santorini1': ('santorini', 1),
             'santorini11': ('santorini', 11), 'azul': ('azul', 0)}
@@ -28,7 +28,7 @@ def make(variant):
     if name == 'abalone':
         return games.AbaloneGame()
     if name == 'akropolis':
-        return games.AkropolisGame()
+        return games.AkropolisGame(v)
     if name == 'smallworld':
         return games.SmallworldGame(v)
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
@@ -73,7 +73,7 @@ def test_mcts_traces_vs_golden(golden_dir, variant, prefix):
         m.forest.close()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'santorini11', 'azul', 'abalone', 'akropolis', 'smallworld', 'smallworld3', 'smallworld4'])
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini11', 'azul', 'abalone', 'akropolis', 'akropolis3', 'akropolis4', 'smallworld', 'smallworld3', 'smallworld4'])
 def test_whole_tree_vs_oracle(variant):
     """Every node of the HIP tree equals the oracle's node with the same state key (Ns, Qs, Nsa, Qsa, Ps, Es)."""
     import torch
@@ -113,7 +113,7 @@ def test_whole_tree_vs_oracle(variant):
     m.forest.close()
 
 
-@pytest.mark.parametrize('variant', ['splendor2', 'santorini1', 'azul', 'abalone', 'akropolis', 'smallworld'])
+@pytest.mark.parametrize('variant', ['splendor2', 'santorini1', 'azul', 'abalone', 'akropolis', 'akropolis4', 'smallworld'])
 @pytest.mark.parametrize('small_arena', [False, True])
 def test_tree_reuse_sequence_vs_golden(golden_dir, variant, small_arena):
     """Multi-move sequence of the golden set: tree reuse across moves and fast (non-full) searches.  With a small arena

@@ -13,7 +13,7 @@ class Args(dict):
 
 
 @pytest.mark.parametrize('variant,prob_full', [('splendor2', 1.0), ('splendor2', 0.5), ('splendor4', 1.0), ('santorini1', 1.0),
-                                                ('santorini11', 1.0), ('azul', 1.0), ('abalone', 1.0), ('akropolis', 1.0), ('smallworld', 1.0), ('smallworld3', 1.0), ('smallworld4', 1.0)])
+                                                ('santorini11', 1.0), ('azul', 1.0), ('abalone', 1.0), ('akropolis', 1.0), ('akropolis3', 1.0), ('akropolis4', 1.0), ('smallworld', 1.0), ('smallworld3', 1.0), ('smallworld4', 1.0)])
 def test_selfplay_first_games_vs_oracle(variant, prob_full):
     import torch
     import azg_oracle as O
@@ -21,16 +21,16 @@ def test_selfplay_first_games_vs_oracle(variant, prob_full):
     from azg_amd.forest import Forest
     from hashnet import HashNetTorch
     name, v = {'splendor2': ('splendor', 2), 'splendor4': ('splendor', 4), 'santorini1': ('santorini', 1),
-               'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 0), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
+               'santorini11': ('santorini', 11), 'azul': ('azul', 0), 'abalone': ('abalone', 0), 'akropolis': ('akropolis', 2), 'akropolis3': ('akropolis', 3), 'akropolis4': ('akropolis', 4), 'smallworld': ('smallworld', 2), 'smallworld3': ('smallworld', 3),
                'smallworld4': ('smallworld', 4)}[variant]
     g = {'splendor': lambda: games.SplendorGame(v), 'santorini': lambda: games.SantoriniGame(v), 'azul': games.AzulGame,
-         'abalone': games.AbaloneGame, 'akropolis': games.AkropolisGame, 'smallworld': lambda: games.SmallworldGame(v)}[name]()
+         'abalone': games.AbaloneGame, 'akropolis': lambda: games.AkropolisGame(v), 'smallworld': lambda: games.SmallworldGame(v)}[name]()
     og = O.OracleGame({'splendor': O.SPLENDOR, 'santorini': O.SANTORINI, 'azul': O.AZUL, 'abalone': O.ABALONE, 'akropolis': O.AKROPOLIS, 'smallworld': O.SMALLWORLD}[name], v)
     from conftest import poison_onchip
     poison_onchip(0x7FC00000)
     kw = dict(MCTS_ARGS[variant])
     sims, T, seed, stream0 = 40, 16, 4242, 1000
-    if variant == 'akropolis':
+    if name == 'akropolis':
         # hundreds of valid placements: with policy-target pruning a 40-simulation root has no count above 1 and the reference's
         # pruned policy is 0 / 0 (MCTS.py:77-80,100-102); the raw counts are always a distribution
         sims, kw['forced_playouts'] = 60, False

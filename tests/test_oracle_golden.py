@@ -11,7 +11,7 @@ import azg_oracle as O
 VARIANTS = {
     'splendor2': (O.SPLENDOR, 2), 'splendor3': (O.SPLENDOR, 3), 'splendor4': (O.SPLENDOR, 4),
     'santorini1': (O.SANTORINI, 1), 'santorini11': (O.SANTORINI, 11), 'azul': (O.AZUL, 0), 'abalone': (O.ABALONE, 0),
-    'akropolis': (O.AKROPOLIS, 0), 'smallworld': (O.SMALLWORLD, 0), 'smallworld3': (O.SMALLWORLD, 3), 'smallworld4': (O.SMALLWORLD, 4),
+    'akropolis': (O.AKROPOLIS, 0), 'akropolis3': (O.AKROPOLIS, 3), 'akropolis4': (O.AKROPOLIS, 4), 'smallworld': (O.SMALLWORLD, 0), 'smallworld3': (O.SMALLWORLD, 3), 'smallworld4': (O.SMALLWORLD, 4),
 }
 
 
@@ -80,7 +80,7 @@ MCTS_SMALL = MCTS_VARIANTS + ['abalone', 'akropolis', 'smallworld']          # (
 
 
 @pytest.mark.parametrize('variant,typing,prefix', [(v, t, 'mcts') for v in MCTS_SMALL for t in ('numpy2', 'numba')] +
-                         [(v, 'numba', 'mcts') for v in ('smallworld3', 'smallworld4')] + [(v, 'numba', 'mcts800') for v in MCTS_VARIANTS])
+                         [(v, 'numba', 'mcts') for v in ('smallworld3', 'smallworld4', 'akropolis3', 'akropolis4')] + [(v, 'numba', 'mcts800') for v in MCTS_VARIANTS])
 def test_mcts_traces(golden_dir, variant, typing, prefix):
     """G3: whole-tree parity (every node's Ns, Nsa, Qsa, Ps, Qs bit-exact through a SHA-256 digest); `mcts800` = the
     headline search size (800 simulations, tools/gen_golden_800.py)."""
@@ -104,7 +104,7 @@ def test_mcts_traces(golden_dir, variant, typing, prefix):
         assert np.array_equal(oracle_tree_digest(mc, g), d['case_digest'][i]), (variant, i)
 
 
-@pytest.mark.parametrize('variant,typing', [(v, t) for v in MCTS_SMALL for t in ('numpy2', 'numba')] + [('smallworld3', 'numba'), ('smallworld4', 'numba')])
+@pytest.mark.parametrize('variant,typing', [(v, t) for v in MCTS_SMALL for t in ('numpy2', 'numba')] + [('smallworld3', 'numba'), ('smallworld4', 'numba'), ('akropolis3', 'numba'), ('akropolis4', 'numba')])
 def test_mcts_sequence_tree_reuse(golden_dir, variant, typing):
     """G3 sequence: tree reuse across moves, fast (non-full) searches, periodic clean-up (MCTS.py:86-91)."""
     d = load(golden_dir, 'mcts_%s_%s.npz' % (variant, typing))
@@ -125,14 +125,16 @@ def test_mcts_sequence_tree_reuse(golden_dir, variant, typing):
         assert np.array_equal(oracle_tree_digest(mc, g), d['seq_digest'][i]), (variant, i)
 
 
-def test_akropolis_init_boards(golden_dir):
-    """init_game draws the four tiles of the construction site with np.random.choice (AkropolisLogicNumba.py:294,507-508)"""
-    d = load(golden_dir, 'env_akropolis.npz')
-    g = O.OracleGame(O.AKROPOLIS)
+@pytest.mark.parametrize('n', [2, 3, 4])
+def test_akropolis_init_boards(golden_dir, n):
+    """init_game draws the n + 2 tiles of the construction site with np.random.choice (AkropolisLogicNumba.py:294,507-508)"""
+    d = load(golden_dir, 'env_akropolis%s.npz' % ('' if n == 2 else n))
+    g = O.OracleGame(O.AKROPOLIS, n)
+    assert g.getBoardSize() == (13, 13, 3 * n + 2) and g.A == 1014 * (n + 2) and g.P == n
     for i in range(len(d['init_boards'])):
         rng = g.rng(injected=d['init_uniforms'][i])
-        assert np.array_equal(g.getInitBoard(rng).reshape(-1), d['init_boards'][i]) and rng.pos == 4
-    assert d['score'].max() > 60 and set(d['seed'].tolist()) >= {0, -1, 31416}
+        assert np.array_equal(g.getInitBoard(rng).reshape(-1), d['init_boards'][i]) and rng.pos == n + 2
+    assert d['score'].max() > (60 if n == 2 else 40) and set(d['seed'].tolist()) >= {0, -1, 31416}
 
 
 @pytest.mark.parametrize('n', [2, 3, 4])

@@ -8,6 +8,8 @@ MCTS_ARGS = {
     'azul': dict(cpuct=0.5, fpu=0.05, universes=1, forced_playouts=True),
     'abalone': dict(cpuct=1.0, fpu=0.0, universes=0, forced_playouts=True),
     'akropolis': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
+    'akropolis3': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
+    'akropolis4': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
     'smallworld': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
     'smallworld3': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),
     'smallworld4': dict(cpuct=1.0, fpu=0.0, universes=1, forced_playouts=True),

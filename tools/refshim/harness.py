@@ -42,7 +42,7 @@ def _purge_modules():
             del sys.modules[name]
 
 
-def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=1, minivilles_players=2, tlp_players=3, smallworld_players=2):
+def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=1, minivilles_players=2, tlp_players=3, smallworld_players=2, akropolis_players=2):
     """Import the reference from a temp copy with the requested source-level variants.
     Returns a dict of modules."""
     tmp = tempfile.mkdtemp(prefix='azg_ref_')
@@ -69,6 +69,7 @@ def load_reference(splendor_players=2, santorini_gods=11, santorini_init_method=
     sub('minivilles/MinivillesGame.py', 'NUMBER_PLAYERS = 2', 'NUMBER_PLAYERS = %d' % minivilles_players)
     sub('thelittleprince/TLPGame.py', 'NUMBER_PLAYERS = 3', 'NUMBER_PLAYERS = %d' % tlp_players)
     sub('smallworld/SmallworldConstants.py', 'NUMBER_PLAYERS = 2', 'NUMBER_PLAYERS = %d' % smallworld_players)
+    sub('akropolis/AkropolisConstants.py', 'N_PLAYERS = 2', 'N_PLAYERS = %d' % akropolis_players)
 
     _purge_modules()
     sys.dont_write_bytecode = True
