@@ -282,7 +282,7 @@ extern "C" int azg_nn_conv5_forward_split(const int8_t* boards, const uint8_t* v
     return conv5_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, true);
 }
 
-// ---- Santorini-with-gods net V78 (10 InvertedResidual blocks, A = 1782, P = 2), one launch (nn_conv5x5.hip.h) ----
+// ---- Santorini-with-gods net V78 (10 InvertedResidual blocks, A = 1782, P = 2): trunk + value head, then the policy FC (nn_conv5x5.hip.h) ----
 extern "C" int azg_nn_s78_forward(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A, int P,
                                   int B, float* pi, float* v, void* stream) {
     if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_s78_forward: null/empty argument");
@@ -295,6 +295,14 @@ extern "C" int azg_nn_s78_forward(const int8_t* boards, const uint8_t* valid, co
         attr = true;
     }
     k_s78_net<10, 1782, 2><<<dim3((B + 3) / 4), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
+    HIPCHK(hipGetLastError());
+    constexpr size_t lds_pi = (size_t)(16 * (144 + 4) + 16 * (112 * 16 + 4)) * sizeof(float);
+    static bool attr_pi = false;
+    if (!attr_pi) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_s78_policy<1782, 132>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pi));
+        attr_pi = true;
+    }
+    k_s78_policy<1782, 132><<<dim3((B + 15) / 16), dim3(768), lds_pi, (hipStream_t)stream>>>(N.Wfp, N.bfp, valid, B, pi);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -370,9 +370,11 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
 // 1x1 project 192->64 + BN, residual) -> 1x1-conv heads whose flattened features are concatenated with a 32-wide embedding
 // of the gods / metadata plane (Linear(25,32) + ReLU) -> FC.  One launch; a workgroup owns 4 samples = 100 board cells:
 // X [112][68] and the expanded tile H [112][196] live in LDS, the two 1x1 convolutions are MFMA GEMMs (mb_gemm), the
-// depthwise convolution runs in place -- one thread owns the 5x5 plane of one (sample, channel) -- and the heads
-// (132 x 1782 policy FC included) run on the vector ALUs.  (As PyTorch ops MIOpen falls back to its naive kernel for the
-// depthwise convolutions: 3 ms per batch of 1024.)
+// depthwise convolution runs in place -- one thread owns the 5x5 plane of one (sample, channel) -- and the small heads run on
+// the vector ALUs.  The 132 x 1782 policy FC is a second launch (k_s78_policy): with four samples per workgroup every
+// workgroup streamed the 940 KB matrix for 0.9 MFLOP of work (20 % of the forward); the trunk leaves the 132 policy features
+// of a sample at the start of its pi row, and k_s78_policy multiplies 16 samples at a time on the MFMAs, logits in LDS, masked
+// softmax in place.  (As PyTorch ops MIOpen falls back to its naive kernel for the depthwise convolutions: 3 ms per batch of 1024.)
 struct S78NetW {
     const float *W0;                  // first conv [9*16][64] fragment order, no bias
     const float *We, *be;             // NB x [64][192] fragment order, bias [NB][192]
@@ -380,7 +382,7 @@ struct S78NetW {
     const float *Wp, *bp;             // NB x [192][64] fragment order, bias [NB][64]
     const float *Wm, *bm;             // meta Linear [25][32], bias [32]
     const float *Whp, *bhp;           // policy 1x1 conv [64][4], bias [4]
-    const float *Wfp, *bfp;           // policy FC [132][A] (rows: c*25 + cell, then the 32 meta features), bias [A]
+    const float *Wfp, *bfp;           // policy FC [144][1792] zero padded, MFMA fragment order (rows: c*25 + cell, then the 32 meta features), bias [1792]
     const float *Whv, *bhv;           // value 1x1 conv [64][2], bias [2]
     const float *Wf1, *bf1;           // value fc1 [82][64], bias [64]
     const float *Wf2, *bf2;           // value fc2 [64][P], bias [P]
@@ -491,23 +493,73 @@ __global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __rest
         FEAT_V[s * FV + CV * 25 + j] = META[i];
     }
     __syncthreads();
-    for (int a = tid; a < A; a += 768) {                      // policy FC: every thread one action for all NS samples
-        float acc[NS];
-#pragma unroll
-        for (int s = 0; s < NS; s++) acc[s] = N.bfp[a];
-        for (int k = 0; k < FP; k++) {
-            const float w = N.Wfp[(size_t)k * A + a];
-#pragma unroll
-            for (int s = 0; s < NS; s++) acc[s] += FEAT_P[s * FP + k] * w;
-        }
-#pragma unroll
-        for (int s = 0; s < NS; s++) LG[s * AS + a] = acc[s];
+    for (int i = tid; i < nb * FP; i += 768) {                 // the policy features go to the head of the sample's pi row (k_s78_policy)
+        const int s = i / FP, k = i - s * FP;
+        pi_out[(size_t)(b0 + s) * A + k] = FEAT_P[s * FP + k];
     }
     for (int i = tid; i < NS * 64; i += 768) {
         const int s = i >> 6, j = i & 63;
         float acc = N.bf1[j];
         for (int k = 0; k < FV; k++) acc += FEAT_V[s * FV + k] * N.Wf1[k * 64 + j];
         H1[s * 64 + j] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    if (tid < nb * P) {
+        const int s = tid / P, p = tid - s * P;
+        float acc = N.bf2[p];
+        for (int j = 0; j < 64; j++) acc += H1[s * 64 + j] * N.Wf2[j * P + p];
+        v_out[(size_t)(b0 + s) * P + p] = tanhf(acc);
+    }
+}
+
+// Policy FC + masked softmax of the with-gods net for 16 samples per workgroup: logits[s][a] = bfp[a] + sum_k feat[s][k] Wfp[k][a]
+// (HeadWithMeta :62-69), pi = exp(log_softmax(where(valid, logits, -1e8))).  feat = the first FP floats of each pi row (written by
+// k_s78_net), K padded to 144.  The activation fragments of the 16 samples stay in registers, the 12 waves stream the weight
+// fragments of their column tiles (1 KB per K chunk), logits live in LDS [16][LS].
+template <int A, int FP>
+__global__ __launch_bounds__(768) void k_s78_policy(const float* __restrict__ Wfrag, const float* __restrict__ bias,
+                                                    const uint8_t* __restrict__ valid, int B, float* __restrict__ pi) {
+    constexpr int KCH = (FP + 15) / 16, KP = KCH * 16, FS = KP + 4, NT = (A + 15) / 16, LS = NT * 16 + 4, NW = 12;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* FEAT = smem;                     // [16][FS]
+    float* LG = FEAT + 16 * FS;             // [16][LS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const int b0 = blockIdx.x * 16, nb = min(16, B - b0);
+    for (int i = tid; i < 16 * FS; i += 768) {
+        const int s = i / FS, k = i - s * FS;
+        FEAT[i] = (s < nb && k < FP) ? pi[(size_t)(b0 + s) * A + k] : 0.f;
+    }
+    __syncthreads();
+    float4 a[KCH];
+#pragma unroll
+    for (int c = 0; c < KCH; c++) a[c] = *(const float4*)(FEAT + r16 * FS + 16 * c + 4 * g);
+    // a wave's column tiles ct = wave, wave + NW, ...: the fragments of the next tile are requested before the MFMAs of this one
+    auto wload = [&](int ct, float4* w) {
+#pragma unroll
+        for (int c = 0; c < KCH; c++) w[c] = FRAG(Wfrag, KCH, ct < NT ? ct : 0, c);
+    };
+    auto tile = [&](int ct, const float4* w) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KCH; c++) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].x, a[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].y, a[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].z, a[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c].w, a[c].w, acc, 0, 0, 0);
+        }
+        const float4 b = *(const float4*)(bias + ct * 16 + 4 * g);
+        *(float4*)(LG + r16 * LS + ct * 16 + 4 * g) = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
+    };
+    float4 w0[KCH], w1[KCH];
+    wload(wave, w0);
+#pragma unroll 1
+    for (int ct = wave; ct < NT; ct += 2 * NW) {
+        wload(ct + NW, w1);
+        tile(ct, w0);
+        if (ct + NW < NT) {
+            wload(ct + 2 * NW, w0);
+            tile(ct + NW, w1);
+        }
     }
     __syncthreads();
     for (int s = wave; s < nb; s += NW) {                      // masked softmax, one wave per sample
@@ -517,9 +569,9 @@ __global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __rest
         float mx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < NK; k++) {
-            const int a = lane + 64 * k;
+            const int ai = lane + 64 * k;
             x[k] = -INFINITY;
-            if (a < A) x[k] = valid[(size_t)b * A + a] ? LG[s * AS + a] : -1e8f;
+            if (ai < A) x[k] = valid[(size_t)b * A + ai] ? LG[s * LS + ai] : -1e8f;
             mx = fmaxf(mx, x[k]);
         }
         mx = nn_wave_max(mx);
@@ -529,13 +581,7 @@ __global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __rest
         sum = nn_wave_sum(sum);
 #pragma unroll
         for (int k = 0; k < NK; k++)
-            if (lane + 64 * k < A) pi_out[(size_t)b * A + lane + 64 * k] = x[k] / sum;
-    }
-    if (tid < nb * P) {
-        const int s = tid / P, p = tid - s * P;
-        float acc = N.bf2[p];
-        for (int j = 0; j < 64; j++) acc += H1[s * 64 + j] * N.Wf2[j * P + p];
-        v_out[(size_t)(b0 + s) * P + p] = tanhf(acc);
+            if (lane + 64 * k < A) pi[(size_t)b * A + lane + 64 * k] = x[k] / sum;
     }
 }
 

@@ -753,9 +753,9 @@ class SantoriniV78(SantoriniV89):
 
 
 class SantoriniV78Hip(SantoriniV89Hip):
-    """SantoriniV78 (with gods: 10 InvertedResidual blocks, A = 1782) evaluated by the engine's one-launch kernel
-    (azg_nn_s78_forward, csrc/nn_conv5x5.hip.h): MFMA GEMMs for the 1x1 convolutions, in-place depthwise 3x3 on the LDS tile,
-    heads on the vector ALUs.  Wraps a SantoriniV78."""
+    """SantoriniV78 (with gods: 10 InvertedResidual blocks, A = 1782) evaluated by the engine's kernels (azg_nn_s78_forward,
+    csrc/nn_conv5x5.hip.h): one launch for the trunk (MFMA GEMMs for the 1x1 convolutions, in-place depthwise 3x3 on the LDS
+    tile) and the value head, one for the 132 x 1782 policy FC (MFMA, 16 samples per workgroup) + masked softmax.  Wraps a SantoriniV78."""
 
     def __init__(self, base, max_batch=4096):
         import ctypes as C
@@ -769,12 +769,16 @@ class SantoriniV78Hip(SantoriniV89Hip):
         m0[:, :2] = base.c0[0].permute(2, 3, 1, 0).reshape(9, 2, 64)
         assert float(base.c0[1].abs().max()) == 0.0          # the first conv of V78 has no bias and no BatchNorm
         cat = lambda ts: torch.cat([t.reshape(-1) for t in ts]).contiguous()  # noqa: E731
+        wfp = torch.zeros((144, 1792), dtype=torch.float32, device=d)      # the policy FC for k_s78_policy: K 132 -> 144, N 1782 -> 1792
+        wfp[:132, :1782] = base.fc_pi[0]
+        bfp = torch.zeros(1792, dtype=torch.float32, device=d)
+        bfp[:1782] = base.fc_pi[1]
         keep = [frag(m0.reshape(144, 64).contiguous()),
                 cat([frag(we.reshape(192, 64).t().contiguous()) for (we, _), _, _ in base.blocks]), cat([be for (_, be), _, _ in base.blocks]),
                 cat([wd.reshape(192, 9) for _, (wd, _), _ in base.blocks]), cat([bd for _, (_, bd), _ in base.blocks]),
                 cat([frag(wp.reshape(64, 192).t().contiguous()) for _, _, (wp, _) in base.blocks]), cat([bp for _, _, (_, bp) in base.blocks]),
                 base.meta[0].contiguous(), base.meta[1].contiguous(),
-                base.hp[0].reshape(4, 64).t().contiguous(), base.hp[1].contiguous(), base.fc_pi[0].contiguous(), base.fc_pi[1].contiguous(),
+                base.hp[0].reshape(4, 64).t().contiguous(), base.hp[1].contiguous(), frag(wfp), bfp,
                 base.hv[0].reshape(2, 64).t().contiguous(), base.hv[1].contiguous(), base.fc_v1[0].contiguous(), base.fc_v1[1].contiguous(),
                 base.fc_v2[0].contiguous(), base.fc_v2[1].contiguous()]
         assert len(keep) == 19 and tuple(base.fc_pi[0].shape) == (132, 1782) and tuple(base.fc_v1[0].shape) == (82, 64)

@@ -282,13 +282,14 @@ int azg_nn_conv5_forward(const int8_t* boards_dev, const uint8_t* valid_dev, con
    element = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)], row index K = tap*64 + ci. */
 int azg_nn_conv5_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int n_blocks, int A,
                                int P, int B, float* pi_dev, float* v_dev, void* stream);
-/* The Santorini-with-gods net (nn_version 78, SantoriniNNet.py:167-192,264-271, HeadWithMeta :42-69) in one launch.
+/* The Santorini-with-gods net (nn_version 78, SantoriniNNet.py:167-192,264-271, HeadWithMeta :42-69): two launches on `stream`
+   (trunk + value head; policy FC + masked softmax -- the pi rows carry the 132 policy features in between).
    boards int8 [B][5][5][3] (planes 0, 1 = workers / levels, plane 2 = gods and metadata), valid u8 [B][A] -> pi, v.
    w = 19 device pointers {W0, We, be, Wd, bd, Wp, bp, Wm, bm, Whp, bhp, Wfp, bfp, Whv, bhv, Wf1, bf1, Wf2, bf2}: BatchNorm
    folded; W0 [9*16][64], the n_blocks expand matrices We [64][192] and project matrices Wp [192][64] in MFMA fragment order,
    back to back; Wd [n_blocks][192][9] (channel, tap = ky*3 + kx); biases [n_blocks][192 / 192 / 64]; Wm [25][32];
-   Whp [64][4], Wfp [132][A] (rows: channel*25 + cell, then the 32 metadata features), Whv [64][2], Wf1 [82][64], Wf2 [64][P]
-   plain row-major.  Built for n_blocks = 10, A = 1782, P = 2. */
+   Whp [64][4], Whv [64][2], Wf1 [82][64], Wf2 [64][P] plain row-major; Wfp [132][A] (rows: channel*25 + cell, then the 32
+   metadata features) zero padded to [144][1792] in MFMA fragment order, bfp padded to 1792.  Built for n_blocks = 10, A = 1782, P = 2. */
 int azg_nn_s78_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int n_blocks, int A, int P,
                        int B, float* pi_dev, float* v_dev, void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
