@@ -119,16 +119,29 @@ __device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32
     r = r - __uint_as_float(m << 16);
     l = bf16_rn(r);
 }
+// two values at once on the hardware converter (v_cvt_pk_bf16_f32, round to nearest even like bf16_rn): word = bf16(a) | bf16(b) << 16
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pk(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+__device__ __forceinline__ void split3x2(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = bf16_pk(a, b);
+    a -= __uint_as_float(h << 16); b -= __uint_as_float(h & 0xFFFF0000u);
+    m = bf16_pk(a, b);
+    a -= __uint_as_float(m << 16); b -= __uint_as_float(m & 0xFFFF0000u);
+    l = bf16_pk(a, b);
+}
 // byte offset of (row, 16-byte chunk q) inside one plane
 __device__ __forceinline__ int pl_off(int row, int q) { return row * 128 + ((q ^ (row & 7)) << 4); }
 // four consecutive channels (ch0 % 4 == 0) of one cell -> the three planes
 __device__ __forceinline__ void store_split4(uint8_t* planes, int plane_bytes, int row, int ch0, float4 o) {
-    uint32_t h[4], m[4], l[4];
-    split3(o.x, h[0], m[0], l[0]); split3(o.y, h[1], m[1], l[1]); split3(o.z, h[2], m[2], l[2]); split3(o.w, h[3], m[3], l[3]);
+    uint32_t h[2], m[2], l[2];
+    split3x2(o.x, o.y, h[0], m[0], l[0]); split3x2(o.z, o.w, h[1], m[1], l[1]);
     uint8_t* dst = planes + pl_off(row, ch0 >> 3) + ((ch0 & 4) << 1);
-    *(uint2*)dst = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    *(uint2*)(dst + plane_bytes) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-    *(uint2*)(dst + 2 * plane_bytes) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    *(uint2*)dst = make_uint2(h[0], h[1]);
+    *(uint2*)(dst + plane_bytes) = make_uint2(m[0], m[1]);
+    *(uint2*)(dst + 2 * plane_bytes) = make_uint2(l[0], l[1]);
 }
 __device__ __forceinline__ float bf16_lo_f32(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi_f32(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
@@ -140,7 +153,7 @@ __device__ __forceinline__ float4 load_split4(const uint8_t* planes, int plane_b
 }
 
 // the first convolution (2 board planes, K = 9 x 16): f32 MFMA from the f32 staging tile, output written split
-template <int NS>
+template <int NS, bool RELU = true>
 __device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wfrag, const float* __restrict__ bias,
                                                     const float* IN, uint8_t* OUT) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
@@ -162,14 +175,16 @@ __device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wf
             const bool on = r < ROWS && yy >= 0 && yy < 5 && xx >= 0 && xx < 5;
             float4 a = *(const float4*)(IN + (on ? r + (t / 3 - 1) * 5 + (t % 3 - 1) : 0) * CS + 4 * g);
             if (!on) a = make_float4(0.f, 0.f, 0.f, 0.f);
+            // component j of the fragments covers K = j, 4 + j, 8 + j, 12 + j of the tap: the two board planes are K = 0 and 1,
+            // the other fourteen channels of the staging tile are zero padding -> components z and w contribute nothing
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].x, a.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].y, a.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].z, a.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].w, a.w, acc, 0, 0, 0);
         }
-        if (r < ROWS)
-            store_split4(OUT, PB, r, ct * 16 + 4 * g, make_float4(fmaxf(acc[0] + b.x, 0.f), fmaxf(acc[1] + b.y, 0.f),
-                                                                  fmaxf(acc[2] + b.z, 0.f), fmaxf(acc[3] + b.w, 0.f)));
+        if (r < ROWS) {
+            float4 o = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
+            if (RELU) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+            store_split4(OUT, PB, r, ct * 16 + 4 * g, o);
+        }
     }
 }
 
@@ -249,6 +264,40 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         store_split4(OUT, PB, row[i], ct * 16 + 4 * g, make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)));
+    }
+}
+
+// One 64 x 64 GEMM phase on split activations (a 1x1 convolution over 64 input channels): acc[i] += IN[tile i] * W for the
+// wave's row tiles rt = rg + 3 i and its output-channel tile ct (12 waves = 4 ct x 3 rg, as conv3x3_split).
+// Wfrag: [4 ct][2 K chunks of 32][3 planes][64 lanes] uint4; rows >= ROWS read the zero row.
+// (the weight fragments w[chunk * 3 + plane] are requested by gemm64_wload a phase ahead)
+__device__ __forceinline__ void gemm64_wload(const uint4* __restrict__ Wfrag, uint4 (&w)[6]) {
+    const int lane = threadIdx.x & 63, ct = (threadIdx.x >> 6) & 3;
+#pragma unroll
+    for (int k = 0; k < 6; k++) w[k] = Wfrag[((size_t)ct * 6 + k) * 64 + lane];
+}
+template <int NS>
+__device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t* IN, f32x4 (&acc)[(NS * 25 + 15) / 16 / 3 + 1]) {
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
+    static_assert(MAXT == RT / 3 + 1 && RT - RG * (MAXT - 1) == 1, "tile schedule: MAXT - 1 tiles per wave + one odd tile in the first row group");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int rg = wave >> 2;
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) {
+        if (i == MAXT - 1 && rg != 0) continue;             // (wave-uniform)
+        const int r = (rg + RG * i) * 16 + r16, rr = r < ROWS ? r : ROWS;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint8_t* src = IN + pl_off(rr, 4 * c + g);
+            const bf16x8 ah = AZG_BF(*(const uint4*)src), am = AZG_BF(*(const uint4*)(src + PB)), al = AZG_BF(*(const uint4*)(src + 2 * PB));
+            const bf16x8 wh = AZG_BF(w[c * 3]), wm = AZG_BF(w[c * 3 + 1]), wl = AZG_BF(w[c * 3 + 2]);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc[i], 0, 0, 0);
+        }
     }
 }
 #undef AZG_BF
@@ -388,6 +437,52 @@ struct S78NetW {
     const float *Wf2, *bf2;           // value fc2 [64][P], bias [P]
 };
 
+// The heads of the with-gods net on the f32 trunk output X [NS * 25][CS] (HeadWithMeta :42-69): 1x1 convolutions + ReLU, the
+// flattened features joined by the 32 metadata features; the policy features go to the head of each sample's pi row
+// (k_s78_policy), the value head (fc1 + ReLU, fc2, tanh) finishes here.  SCR: NS * (132 + 82 + 64) floats of scratch.
+template <int NS, int A, int P>
+__device__ __forceinline__ void s78_heads(const S78NetW& N, const float* X, const float* META, float* SCR, int b0, int nb,
+                                          float* __restrict__ pi_out, float* __restrict__ v_out) {
+    constexpr int CS = 68, CPI = 4, CV = 2, FP = CPI * 25 + 32, FV = CV * 25 + 32;
+    const int tid = threadIdx.x;
+    float* FEAT_P = SCR;                    // [NS][FP]   policy features: 4 x 25 conv outputs (channel-major) + meta
+    float* FEAT_V = FEAT_P + NS * FP;       // [NS][FV]
+    float* H1 = FEAT_V + NS * FV;           // [NS][64]
+    for (int i = tid; i < NS * 25 * (CPI + CV); i += 768) {
+        const int r = i / (CPI + CV), c = i - r * (CPI + CV);
+        const float* xr = X + r * CS;
+        float a = c < CPI ? N.bhp[c] : N.bhv[c - CPI];
+#pragma unroll 8
+        for (int k = 0; k < 64; k++) a += xr[k] * (c < CPI ? N.Whp[k * CPI + c] : N.Whv[k * CV + (c - CPI)]);
+        a = fmaxf(a, 0.f);
+        const int s = r / 25, cell = r - 25 * s;
+        if (c < CPI) FEAT_P[s * FP + c * 25 + cell] = a; else FEAT_V[s * FV + (c - CPI) * 25 + cell] = a;
+    }
+    for (int i = tid; i < NS * 32; i += 768) {
+        const int s = i >> 5, j = i & 31;
+        FEAT_P[s * FP + CPI * 25 + j] = META[i];
+        FEAT_V[s * FV + CV * 25 + j] = META[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < nb * FP; i += 768) {                 // the policy features go to the head of the sample's pi row (k_s78_policy)
+        const int s = i / FP, k = i - s * FP;
+        pi_out[(size_t)(b0 + s) * A + k] = FEAT_P[s * FP + k];
+    }
+    for (int i = tid; i < NS * 64; i += 768) {
+        const int s = i >> 6, j = i & 63;
+        float acc = N.bf1[j];
+        for (int k = 0; k < FV; k++) acc += FEAT_V[s * FV + k] * N.Wf1[k * 64 + j];
+        H1[s * 64 + j] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    if (tid < nb * P) {
+        const int s = tid / P, p = tid - s * P;
+        float acc = N.bf2[p];
+        for (int j = 0; j < 64; j++) acc += H1[s * 64 + j] * N.Wf2[j * P + p];
+        v_out[(size_t)(b0 + s) * P + p] = tanhf(acc);
+    }
+}
+
 template <int NB, int A, int P>
 __global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid,
                                                  int B, float* __restrict__ pi_out, float* __restrict__ v_out) {
@@ -472,44 +567,146 @@ __global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __rest
             });
         __syncthreads();
     }
-    // ---- heads ----
-    float* FEAT_P = H;                      // [NS][FP]   policy features: 4 x 25 conv outputs (channel-major) + meta
-    float* FEAT_V = FEAT_P + NS * FP;       // [NS][FV]
-    float* LG = FEAT_V + NS * FV;           // [NS][AS]
-    float* H1 = LG + NS * AS;               // [NS][64]
-    for (int i = tid; i < NS * 25 * (CPI + CV); i += 768) {
-        const int r = i / (CPI + CV), c = i - r * (CPI + CV);
-        const float* xr = X + r * CS;
-        float a = c < CPI ? N.bhp[c] : N.bhv[c - CPI];
-#pragma unroll 8
-        for (int k = 0; k < 64; k++) a += xr[k] * (c < CPI ? N.Whp[k * CPI + c] : N.Whv[k * CV + (c - CPI)]);
-        a = fmaxf(a, 0.f);
-        const int s = r / 25, cell = r - 25 * s;
-        if (c < CPI) FEAT_P[s * FP + c * 25 + cell] = a; else FEAT_V[s * FV + (c - CPI) * 25 + cell] = a;
+    s78_heads<NS, A, P>(N, X, META, H, b0, nb, pi_out, v_out);
+}
+
+// The same trunk on split-precision operands (bf16 x 3, see conv3x3_split): a workgroup owns 8 samples = 200 cells; X [200][64] and
+// one THIRD of the expanded tile (64 of the 192 channels) live in LDS as three bf16 planes each (2 x 77 KB, the layout of
+// k_conv5_net<SPLIT>).  InvertedResidual has no squeeze-excite, so a block runs as three passes
+//   expand 64 -> 64 (third t of We) + BN + ReLU -> H;  depthwise 3x3 + BN + ReLU on H in place;  project acc += H * Wp[third t]
+// with the project accumulators kept in registers across the passes; every GEMM is the 64 x 64 gemm64_split (six bf16 MFMAs per
+// product).  N.We / N.Wp point to the split fragments [NB][3 thirds][4 ct][2 chunks][3 planes][64 lanes][8] bf16.
+template <int NB, int A, int P>
+__global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid,
+                                                       int B, float* __restrict__ pi_out, float* __restrict__ v_out) {
+    constexpr int NS = 8, ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, CS = 68, E = 192;
+    constexpr int PLANE_B = (ROWS + 1) * 128, TILE_B = 3 * PLANE_B;
+    constexpr size_t G64_U4 = (size_t)4 * 2 * 3 * 64;          // uint4 per 64 x 64 matrix
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint8_t* XP = (uint8_t*)smem;                               // X: three bf16 planes [ROWS + 1][64]
+    uint8_t* HP = XP + TILE_B;                                  // one third of the expanded tile, same layout
+    float* META = (float*)(HP + TILE_B);                        // [NS][32]
+    float* STG = (float*)HP;                                    // f32 [ROWS][CS]: the board staging tile, later the trunk output for the heads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const int ct = wave & 3, rg = wave >> 2;
+    const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
+    for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(STG + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 3 * 32) ((uint32_t*)(XP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;        // X's zero row
+    __syncthreads();
+    for (int i = tid; i < nb * 25 * 2; i += 768) {
+        const int r = i >> 1, pl = i & 1;
+        STG[r * CS + pl] = (float)boards[(size_t)b0 * 75 + r * 3 + pl];
     }
     for (int i = tid; i < NS * 32; i += 768) {
         const int s = i >> 5, j = i & 31;
-        FEAT_P[s * FP + CPI * 25 + j] = META[i];
-        FEAT_V[s * FV + CV * 25 + j] = META[i];
+        float acc = N.bm[j];
+        if (s < nb)
+            for (int k = 0; k < 25; k++) acc += (float)boards[(size_t)(b0 + s) * 75 + k * 3 + 2] * N.Wm[k * 32 + j];
+        META[s * 32 + j] = fmaxf(acc, 0.f);
+    }
+    __shared__ float zero_bias[64];
+    if (tid < 64) zero_bias[tid] = 0.f;
+    __syncthreads();
+    conv3x3_first_split<NS, false>(N.W0, zero_bias, STG, XP);
+    __syncthreads();
+    if (tid < 3 * 32) ((uint32_t*)(HP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;        // H's zero row (the staging tile is dead)
+#pragma unroll 1
+    for (int blk = 0; blk < NB; blk++) {
+        f32x4 pacc[MAXT];
+#pragma unroll
+        for (int i = 0; i < MAXT; i++) pacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int t = 0; t < 3; t++) {
+            // ---- 1x1 expand (channels 64 t .. 64 t + 63) + BN + ReLU -> H ----
+            {
+                f32x4 e[MAXT];
+#pragma unroll
+                for (int i = 0; i < MAXT; i++) e[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                uint4 we[6];
+                gemm64_wload((const uint4*)N.We + (size_t)(blk * 3 + t) * G64_U4, we);
+                gemm64_split<NS>(we, XP, e);
+                const float4 b = *(const float4*)(N.be + blk * E + t * 64 + ct * 16 + 4 * g);
+#pragma unroll
+                for (int i = 0; i < MAXT; i++) {
+                    const int r = (rg + RG * i) * 16 + r16;
+                    if (rg + RG * i >= RT || r >= ROWS) continue;
+                    store_split4(HP, PLANE_B, r, ct * 16 + 4 * g, make_float4(fmaxf(e[i][0] + b.x, 0.f), fmaxf(e[i][1] + b.y, 0.f),
+                                                                               fmaxf(e[i][2] + b.z, 0.f), fmaxf(e[i][3] + b.w, 0.f)));
+                }
+            }
+            __syncthreads();
+            // ---- depthwise 3x3 + BN + ReLU in place: one thread = the 5x5 plane of one (sample, channel) ----
+            if (tid < NS * 64) {
+                const int s = tid >> 6, c = tid & 63, ec = blk * E + t * 64 + c;
+                float in[25], w[9];
+                const int q = c >> 3, cb = (c & 7) << 1, r0 = s * 25;
+                auto off = [&](int k) { return (r0 + k) * 128 + ((q ^ ((r0 + k) & 7)) << 4) + cb; };
+#pragma unroll
+                for (int k = 0; k < 25; k++) {
+                    const uint8_t* src = HP + off(k);
+                    in[k] = (bf16_lo_f32(*(const uint16_t*)src) + bf16_lo_f32(*(const uint16_t*)(src + PLANE_B))) +
+                            bf16_lo_f32(*(const uint16_t*)(src + 2 * PLANE_B));
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) w[k] = N.Wd[(size_t)ec * 9 + k];
+                const float bias = N.bd[ec];
+                float out[26];
+#pragma unroll
+                for (int y = 0; y < 5; y++)
+#pragma unroll
+                    for (int x = 0; x < 5; x++) {
+                        float a = bias;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                            for (int kx = 0; kx < 3; kx++) {
+                                const int yy = y + ky - 1, xx = x + kx - 1;
+                                if (yy >= 0 && yy < 5 && xx >= 0 && xx < 5) a += w[ky * 3 + kx] * in[yy * 5 + xx];
+                            }
+                        out[y * 5 + x] = fmaxf(a, 0.f);
+                    }
+                out[25] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 26; k += 2) {                  // two cells per conversion
+                    uint32_t h, m, l;
+                    split3x2(out[k], out[k + 1], h, m, l);
+                    uint8_t* d0 = HP + off(k);
+                    *(uint16_t*)d0 = (uint16_t)h; *(uint16_t*)(d0 + PLANE_B) = (uint16_t)m; *(uint16_t*)(d0 + 2 * PLANE_B) = (uint16_t)l;
+                    if (k + 1 < 25) {
+                        uint8_t* d1 = HP + off(k + 1);
+                        *(uint16_t*)d1 = (uint16_t)(h >> 16); *(uint16_t*)(d1 + PLANE_B) = (uint16_t)(m >> 16);
+                        *(uint16_t*)(d1 + 2 * PLANE_B) = (uint16_t)(l >> 16);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- 1x1 project, K = this third of the expanded channels ----
+            {
+                uint4 wp[6];
+                gemm64_wload((const uint4*)N.Wp + (size_t)(blk * 3 + t) * G64_U4, wp);
+                gemm64_split<NS>(wp, HP, pacc);
+            }
+            __syncthreads();
+        }
+        // ---- + BN bias + residual -> X, in place (a lane reads and writes its own elements) ----
+        const float4 b = *(const float4*)(N.bp + blk * 64 + ct * 16 + 4 * g);
+#pragma unroll
+        for (int i = 0; i < MAXT; i++) {
+            const int r = (rg + RG * i) * 16 + r16;
+            if (rg + RG * i >= RT || r >= ROWS) continue;
+            const float4 x = load_split4(XP, PLANE_B, r, ct * 16 + 4 * g);
+            store_split4(XP, PLANE_B, r, ct * 16 + 4 * g, make_float4(pacc[i][0] + b.x + x.x, pacc[i][1] + b.y + x.y,
+                                                                       pacc[i][2] + b.z + x.z, pacc[i][3] + b.w + x.w));
+        }
+        __syncthreads();
+    }
+    // ---- the heads read f32: rebuild the trunk output as [ROWS][CS] f32 over the H region ----
+    for (int i = tid; i < ROWS * 16; i += 768) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        *(float4*)(STG + r * CS + c4) = load_split4(XP, PLANE_B, r, c4);
     }
     __syncthreads();
-    for (int i = tid; i < nb * FP; i += 768) {                 // the policy features go to the head of the sample's pi row (k_s78_policy)
-        const int s = i / FP, k = i - s * FP;
-        pi_out[(size_t)(b0 + s) * A + k] = FEAT_P[s * FP + k];
-    }
-    for (int i = tid; i < NS * 64; i += 768) {
-        const int s = i >> 6, j = i & 63;
-        float acc = N.bf1[j];
-        for (int k = 0; k < FV; k++) acc += FEAT_V[s * FV + k] * N.Wf1[k * 64 + j];
-        H1[s * 64 + j] = fmaxf(acc, 0.f);
-    }
-    __syncthreads();
-    if (tid < nb * P) {
-        const int s = tid / P, p = tid - s * P;
-        float acc = N.bf2[p];
-        for (int j = 0; j < 64; j++) acc += H1[s * 64 + j] * N.Wf2[j * P + p];
-        v_out[(size_t)(b0 + s) * P + p] = tanhf(acc);
-    }
+    s78_heads<NS, A, P>(N, STG, META, STG + ROWS * CS, b0, nb, pi_out, v_out);
 }
 
 // Policy FC + masked softmax of the with-gods net for 16 samples per workgroup: logits[s][a] = bfp[a] + sum_k feat[s][k] Wfp[k][a]

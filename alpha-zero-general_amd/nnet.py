@@ -757,12 +757,26 @@ class SantoriniV78Hip(SantoriniV89Hip):
     csrc/nn_conv5x5.hip.h): one launch for the trunk (MFMA GEMMs for the 1x1 convolutions, in-place depthwise 3x3 on the LDS
     tile) and the value head, one for the 132 x 1782 policy FC (MFMA, 16 samples per workgroup) + masked softmax.  Wraps a SantoriniV78."""
 
-    def __init__(self, base, max_batch=4096):
+    def __init__(self, base, max_batch=4096, split=True):
+        """split: the 1x1 convolutions of the trunk on bf16 x 3 split-precision operands (azg_nn_s78_forward_split, 8 samples per
+        workgroup, the expanded tile in thirds); False = the f32-MFMA kernel (4 samples per workgroup)"""
         import ctypes as C
         from . import _lib
-        self._lib, self.base, self.device = _lib, base, base.device
+        self._lib, self.base, self.device, self.split = _lib, base, base.device, bool(split)
         self.P, self.A = base.P, base.A
         assert base.dtype == torch.float32 and self.device.type == 'cuda' and len(base.blocks) == 10 and self.A == 1782 and self.P == 2
+
+        def split64(m):                    # [64 K][64 N] f32 -> [4 ct][2 chunks of 32][3 planes hi, mid, lo][64 lanes][8] bf16
+            m = m.contiguous().float()
+            hi = m.to(torch.bfloat16)
+            r1 = m - hi.float()
+            mid = r1.to(torch.bfloat16)
+            lo = (r1 - mid.float()).to(torch.bfloat16)
+            pl = torch.stack([hi, mid, lo]).view(3, 2, 4, 8, 4, 16)                       # plane, chunk, g, j, ct, r
+            return pl.permute(4, 1, 0, 2, 5, 3).contiguous().view(-1)                     # ct, chunk, plane, g, r, j
+
+        def thirds(ms, of_k):              # the three 64 x 64 pieces of each [64][192] expand / [192][64] project matrix
+            return torch.cat([split64(m[64 * t:64 * t + 64] if of_k else m[:, 64 * t:64 * t + 64]) for m in ms for t in range(3)]).contiguous()
         frag = SplendorV80Hip._frag
         d = self.device
         m0 = torch.zeros((9, 16, 64), dtype=torch.float32, device=d)
@@ -774,9 +788,11 @@ class SantoriniV78Hip(SantoriniV89Hip):
         bfp = torch.zeros(1792, dtype=torch.float32, device=d)
         bfp[:1782] = base.fc_pi[1]
         keep = [frag(m0.reshape(144, 64).contiguous()),
-                cat([frag(we.reshape(192, 64).t().contiguous()) for (we, _), _, _ in base.blocks]), cat([be for (_, be), _, _ in base.blocks]),
+                (thirds([we.reshape(192, 64).t() for (we, _), _, _ in base.blocks], False) if self.split else
+                 cat([frag(we.reshape(192, 64).t().contiguous()) for (we, _), _, _ in base.blocks])), cat([be for (_, be), _, _ in base.blocks]),
                 cat([wd.reshape(192, 9) for _, (wd, _), _ in base.blocks]), cat([bd for _, (_, bd), _ in base.blocks]),
-                cat([frag(wp.reshape(64, 192).t().contiguous()) for _, _, (wp, _) in base.blocks]), cat([bp for _, _, (_, bp) in base.blocks]),
+                (thirds([wp.reshape(64, 192).t() for _, _, (wp, _) in base.blocks], True) if self.split else
+                 cat([frag(wp.reshape(64, 192).t().contiguous()) for _, _, (wp, _) in base.blocks])), cat([bp for _, _, (_, bp) in base.blocks]),
                 base.meta[0].contiguous(), base.meta[1].contiguous(),
                 base.hp[0].reshape(4, 64).t().contiguous(), base.hp[1].contiguous(), frag(wfp), bfp,
                 base.hv[0].reshape(2, 64).t().contiguous(), base.hv[1].contiguous(), base.fc_v1[0].contiguous(), base.fc_v1[1].contiguous(),
@@ -796,8 +812,9 @@ class SantoriniV78Hip(SantoriniV89Hip):
         boards = boards.reshape(B, -1)
         assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda and boards.shape[1] == 75
         valids = (valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)).contiguous()
-        self._lib.check(self._lib.lib().azg_nn_s78_forward(p(boards), p(valids), self.ptrs, 10, self.A, self.P, B, p(self.pi),
-                                                           p(self.v), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        fwd = self._lib.lib().azg_nn_s78_forward_split if self.split else self._lib.lib().azg_nn_s78_forward
+        self._lib.check(fwd(p(boards), p(valids), self.ptrs, 10, self.A, self.P, B, p(self.pi), p(self.v),
+                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return self.pi[:B], self.v[:B]
 
 

@@ -292,6 +292,12 @@ int azg_nn_conv5_forward_split(const int8_t* boards_dev, const uint8_t* valid_de
    metadata features) zero padded to [144][1792] in MFMA fragment order, bfp padded to 1792.  Built for n_blocks = 10, A = 1782, P = 2. */
 int azg_nn_s78_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int n_blocks, int A, int P,
                        int B, float* pi_dev, float* v_dev, void* stream);
+/* The same net with the 1x1 convolutions of the trunk on split-precision operands (bf16 x 3, as azg_nn_conv5_forward_split): 8
+   samples per workgroup, the expanded tile processed in thirds of 64 channels.  Only w[1] and w[5] differ:
+   We / Wp = [n_blocks][3 thirds][4 column tiles][2 K chunks of 32][3 planes hi, mid, lo][64 lanes][8] bf16 with
+   element = M_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)], M = We[:, 64 t .. 64 t + 63] resp. Wp[64 t .. 64 t + 63, :]. */
+int azg_nn_s78_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int n_blocks, int A, int P,
+                             int B, float* pi_dev, float* v_dev, void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
 int azg_nn_board_to_x(const int8_t* boards_dev, float* x_dev, int B, int C, void* stream);
 /* boards int8 [B][C][L] -> x f32 [B][L][ldx], columns C..ldx-1 zeroed (row stride padded to a multiple of 4 floats) */
