@@ -365,15 +365,36 @@ struct Forest {
         return AZG_NONE;
     }
 
+    // What creating a leaf reads from the tree's allocator state -- the top of the free-id stack, the heads of the record free
+    // lists and the link word of each head -- requested when the env step of a frontier edge starts, so that the three dependent
+    // round trips have landed when create_node / alloc_record need them.  Only this wave changes that state, and a prefetch is
+    // consumed by the create_leaf of the same edge, so the values are never stale.
+    struct LeafPf {
+        uint32_t id_v, head_v, next_v;      // per-lane loaded values: id (same in every lane), head / link of class = lane
+        bool lists;                         // the record free lists are covered (several classes, at most 64 of them)
+    };
+    template <class HS>
+    __device__ static __forceinline__ LeafPf leaf_pf_begin(const ForestDev& F, int t, const HS& H) {
+        LeafPf pf;
+        pf.id_v = H.n_free_ids > 0 ? (F.free_ids + (size_t)t * F.s_free)[H.n_free_ids - 1] : 0u;
+        pf.lists = F.cls_q != A && n_classes(F) <= 64;
+        pf.head_v = (pf.lists && lane_id() < n_classes(F)) ? rec_free(F, t)[lane_id()] : AZG_NONE;
+        pf.next_v = AZG_NONE;
+        return pf;
+    }
+    __device__ static __forceinline__ void leaf_pf_links(const ForestDev& F, int t, LeafPf& pf) {
+        if (pf.lists && pf.head_v != AZG_NONE) pf.next_v = *(const uint32_t*)(heap(F, t) + (size_t)pf.head_v * 16u);
+    }
+
     // Allocate a node for the state in LDS, write key + hash, insert in the table.  Returns AZG_NONE on overflow.
     template <class HS>
     __device__ static uint32_t create_node(const ForestDev& F, int t, HS& H, const int8_t* st_lds, uint64_t h,
-                                           uint32_t free_slot) {
+                                           uint32_t free_slot, const LeafPf* pf = nullptr) {
         if (free_slot == AZG_NONE) { H.err |= ERR_NODE_OVERFLOW; return AZG_NONE; }
         uint32_t id;
         if (H.n_free_ids > 0) {                                      // reuse the id of a node the clean-up dropped
             H.n_free_ids--;
-            id = uni_u32((F.free_ids + (size_t)t * F.s_free)[H.n_free_ids]);     // (k_select only: plain vector load)
+            id = uni_u32(pf ? pf->id_v : (F.free_ids + (size_t)t * F.s_free)[H.n_free_ids]);     // (k_select only: plain vector load)
         } else {
             if (H.id_top >= (uint32_t)F.cap) { H.err |= ERR_NODE_OVERFLOW; return AZG_NONE; }
             id = H.id_top++;
@@ -401,7 +422,7 @@ struct Forest {
     // Entry-less records (terminal nodes) only recycle their own class.  AZG_NONE on overflow.
     template <class HS>
     __device__ static __forceinline__ uint32_t alloc_record(const ForestDev& F, int t, HS& H, int nv, uint32_t node_id,
-                                                            int* cls_out) {
+                                                            int* cls_out, const LeafPf* pf = nullptr) {
         if (F.cls_q == A) {
             // one class for every expanded node: the record slot IS the node id (no list, no load); heap = cap slots
             *cls_out = cls_of(F, nv);
@@ -409,6 +430,25 @@ struct Forest {
         }
         uint32_t* heads = rec_free(F, t);
         const int c = cls_of(F, nv), nc = n_classes(F);
+        if (pf && pf->lists) {              // heads and links are in registers (lane = class): the same closest-fit choice
+            const int l = lane_id();
+            const uint64_t m = __ballot(pf->head_v != AZG_NONE && l < nc && (c > 0 ? l >= c : l == 0));
+            if (m) {
+                const int src = first_lane(m);
+                const uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)pf->head_v, src);
+                const uint32_t next = (uint32_t)__builtin_amdgcn_readlane((int)pf->next_v, src);
+                if (l == 0) heads[src] = next;
+                H.free_units -= cls_units(F, src);
+                *cls_out = src;
+                return head;
+            }
+            const uint32_t units = cls_units(F, c);
+            if (H.heap_top + units + 256u > F.heap_units) { H.err |= ERR_HEAP_OVERFLOW; return AZG_NONE; }
+            const uint32_t off = H.heap_top;
+            H.heap_top += units;
+            *cls_out = c;
+            return off;
+        }
         const int idx = c + lane_id();
         const uint32_t v = (idx < nc && (c > 0 || lane_id() == 0)) ? heads[idx] : AZG_NONE;
         const uint64_t m = __ballot(v != AZG_NONE);

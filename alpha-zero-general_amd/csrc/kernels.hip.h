@@ -266,10 +266,10 @@ __device__ __forceinline__ double ucb_score(float p, uint32_t n, double q, doubl
 template <class G, class HS>
 __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H, typename Forest<G>::Smem& sm,
                                              uint64_t h, uint32_t free_slot, int8_t* leaf_states, uint8_t* leaf_valid,
-                                             bool* terminal, float* es) {
+                                             bool* terminal, float* es, const typename Forest<G>::LeafPf* pf = nullptr) {
     using FR = Forest<G>;
     const int l = lane_id();
-    const uint32_t id = FR::create_node(F, t, H, sm.st, h, free_slot);
+    const uint32_t id = FR::create_node(F, t, H, sm.st, h, free_slot, pf);
     if (id == AZG_NONE) return AZG_NONE;
     const bool ended = G::game_ended(sm.st, 0, es, sm.mask);                                     // MCTS.py:131
     int nv = 0;
@@ -282,7 +282,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
     H.leaf_nv = (uint32_t)nv; H.leaf_node = id;
     const RecLayout L(nv, F.U);
     int alloc_cls = 0;
-    const uint32_t rec_off = FR::alloc_record(F, t, H, nv, id, &alloc_cls);
+    const uint32_t rec_off = FR::alloc_record(F, t, H, nv, id, &alloc_cls, pf);
     if (rec_off == AZG_NONE) return AZG_NONE;
     uint8_t* rec = FR::rec_ptr(F, t, rec_off);
     const uint8_t round = (uint8_t)G::gc_age(sm.st);          // the node's age tag for the clean-up (NodeHdr / RecHdr .round)
@@ -317,6 +317,7 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
     using FR = Forest<G>;
 #define AZG_SEG(k, d) H.cyc_seg[k] += (uint32_t)(d)
     long long c0 = AZG_CLK();
+    typename FR::LeafPf pf = FR::leaf_pf_begin(F, t, H);     // allocator state for a possible new leaf: lands during the env step
     if (have_state) {                       // the level already fetched the parent's state with its entries (one-class forests)
         uint32_t* dst = (uint32_t*)sm.st;
         dst[lane_id()] = st0;
@@ -328,6 +329,7 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
     long long c1 = AZG_CLK(); AZG_SEG(0, c1 - c0);
     const int np = G::wave_make_move(sm.st, a, 0, seed, rng);      // (rng is only drawn from by STOCHASTIC games)
     c0 = AZG_CLK(); AZG_SEG(1, c0 - c1);
+    FR::leaf_pf_links(F, t, pf);
     if (np != 0) G::swap_players(sm.st, sm.tmp, np);
     const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
     c1 = AZG_CLK(); AZG_SEG(2, c1 - c0);
@@ -340,7 +342,7 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
     if (found != AZG_NONE) crec = found_rec;
     else {
         const long long t_l = AZG_CLK();
-        crec = create_leaf<G, HS>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, terminal, es);
+        crec = create_leaf<G, HS>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, terminal, es, &pf);
         H.cyc_leaf += (uint32_t)(AZG_CLK() - t_l);
         if (crec == AZG_NONE) return AZG_NONE;
         *is_new = true;
