@@ -166,8 +166,8 @@ extern "C" int azg_nn_v80_block(const float* xin, float* xout, const float* cons
     return fail("azg_nn_v80_block: act must be 1 (ReLU) or 2 (Hardswish)");
 }
 
-extern "C" int azg_nn_v80_forward(const int8_t* boards, const uint8_t* valid, const float* const* w /* 43 */, int B,
-                                  int P, float* x_trunk, float* pi, float* v, void* stream) {
+static int v80_forward(const int8_t* boards, const uint8_t* valid, const float* const* w /* 43 */, int B,
+                       int P, float* x_trunk, float* pi, float* v, void* stream, bool split) {
     if (!boards || !valid || !w || !x_trunk || !pi || !v || B <= 0) return fail("azg_nn_v80_forward: null/empty argument");
     if (P < 2 || P > 4) return fail("azg_nn_v80_forward: 2 <= P <= 4");
     V80BlockW Wt{w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12]};
@@ -178,6 +178,17 @@ extern "C" int azg_nn_v80_forward(const int8_t* boards, const uint8_t* valid, co
     V80NetW Nv{nullptr, nullptr, w[39], w[40], w[41], w[42]};
     hipStream_t s = (hipStream_t)stream;
     // V80 geometry (SplendorNNet.py:262-283): trunk ReLU + mean-SE, both heads Hardswish + max-SE
+    if (split) {
+        static bool attr_s = false;
+        constexpr size_t lds_s = (size_t)3 * 112 * 128 + (V80_LDS - (size_t)112 * 60 * sizeof(float)) + 12288;
+        if (!attr_s) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_v80_net_spx, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_s = true;
+        }
+        k_v80_net_spx<<<dim3((B + 15) / 16), dim3(768), lds_s, s>>>(Wt, Wp, Wv, N0, Np, Nv, boards, valid, B, P, pi, v);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (getenv("AZG_NN_THREE_LAUNCHES")) {       // the per-block path (kept for A/B measurements)
         if (launch_v80<1, 0, 1>(nullptr, x_trunk, Wt, B, boards, N0, nullptr, nullptr, nullptr, P, s)) return -1;
         if (launch_v80<2, 1, 2>(x_trunk, nullptr, Wp, B, nullptr, Np, valid, pi, nullptr, P, s)) return -1;
@@ -195,6 +206,16 @@ extern "C" int azg_nn_v80_forward(const int8_t* boards, const uint8_t* valid, co
     return 0;
 }
 
+
+extern "C" int azg_nn_v80_forward(const int8_t* boards, const uint8_t* valid, const float* const* w /* 43 */, int B,
+                                  int P, float* x_trunk, float* pi, float* v, void* stream) {
+    return v80_forward(boards, valid, w, B, P, x_trunk, pi, v, stream, false);
+}
+
+extern "C" int azg_nn_v80_forward_split(const int8_t* boards, const uint8_t* valid, const float* const* w /* 43 */, int B,
+                                        int P, float* x_trunk, float* pi, float* v, void* stream) {
+    return v80_forward(boards, valid, w, B, P, x_trunk, pi, v, stream, true);
+}
 
 #ifdef AZG_NN_PHASE_TIMES
 extern "C" int azg_nn_debug_phase_times(long long* out /* [4][16] */) {

@@ -106,51 +106,7 @@ __device__ __forceinline__ void conv3x3_tile(const float* __restrict__ Wfrag, co
 //   q ^ (row & 7), which makes the ds_read_b128 of 16 consecutive rows conflict-free; row ROWS stays zero: it is what a tap that
 //   leaves the 5x5 board reads, so no select is needed on the operand registers); written split by the producing epilogue;
 //   weights: frag[ct 4][chunk 18][plane 3][lane 64][8] bf16 = W_plane[32*chunk + 8*(lane>>4) + j][16*ct + (lane&15)], K = tap*64 + ci.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ uint32_t bf16_rn(float x) {
-    const uint32_t u = __float_as_uint(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = bf16_rn(x);
-    float r = x - __uint_as_float(h << 16);
-    m = bf16_rn(r);
-    r = r - __uint_as_float(m << 16);
-    l = bf16_rn(r);
-}
-// two values at once on the hardware converter (v_cvt_pk_bf16_f32, round to nearest even like bf16_rn): word = bf16(a) | bf16(b) << 16
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t bf16_pk(float a, float b) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
-}
-__device__ __forceinline__ void split3x2(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = bf16_pk(a, b);
-    a -= __uint_as_float(h << 16); b -= __uint_as_float(h & 0xFFFF0000u);
-    m = bf16_pk(a, b);
-    a -= __uint_as_float(m << 16); b -= __uint_as_float(m & 0xFFFF0000u);
-    l = bf16_pk(a, b);
-}
-// byte offset of (row, 16-byte chunk q) inside one plane
-__device__ __forceinline__ int pl_off(int row, int q) { return row * 128 + ((q ^ (row & 7)) << 4); }
-// four consecutive channels (ch0 % 4 == 0) of one cell -> the three planes
-__device__ __forceinline__ void store_split4(uint8_t* planes, int plane_bytes, int row, int ch0, float4 o) {
-    uint32_t h[2], m[2], l[2];
-    split3x2(o.x, o.y, h[0], m[0], l[0]); split3x2(o.z, o.w, h[1], m[1], l[1]);
-    uint8_t* dst = planes + pl_off(row, ch0 >> 3) + ((ch0 & 4) << 1);
-    *(uint2*)dst = make_uint2(h[0], h[1]);
-    *(uint2*)(dst + plane_bytes) = make_uint2(m[0], m[1]);
-    *(uint2*)(dst + 2 * plane_bytes) = make_uint2(l[0], l[1]);
-}
-__device__ __forceinline__ float bf16_lo_f32(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf16_hi_f32(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
-__device__ __forceinline__ float4 load_split4(const uint8_t* planes, int plane_bytes, int row, int ch0) {
-    const uint8_t* src = planes + pl_off(row, ch0 >> 3) + ((ch0 & 4) << 1);
-    const uint2 h = *(const uint2*)src, m = *(const uint2*)(src + plane_bytes), l = *(const uint2*)(src + 2 * plane_bytes);
-    return make_float4((bf16_lo_f32(h.x) + bf16_lo_f32(m.x)) + bf16_lo_f32(l.x), (bf16_hi_f32(h.x) + bf16_hi_f32(m.x)) + bf16_hi_f32(l.x),
-                       (bf16_lo_f32(h.y) + bf16_lo_f32(m.y)) + bf16_lo_f32(l.y), (bf16_hi_f32(h.y) + bf16_hi_f32(m.y)) + bf16_hi_f32(l.y));
-}
+// (bf16x8, split3x2, pl_off, store_split4, load_split4: nn_kernels.hip.h)
 
 // the first convolution (2 board planes, K = 9 x 16): f32 MFMA from the f32 staging tile, output written split
 template <int NS, bool RELU = true>

@@ -26,6 +26,53 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));     // v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 operands
 
 // wave-wide f32 max / sum through DPP butterflies (rows of 16) + four readlanes; every lane gets the result
+// ---- split-precision operand helpers (bf16 x 3, see nn_conv5x5.hip.h) ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t bf16_rn(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = bf16_rn(x);
+    float r = x - __uint_as_float(h << 16);
+    m = bf16_rn(r);
+    r = r - __uint_as_float(m << 16);
+    l = bf16_rn(r);
+}
+// two values at once on the hardware converter (v_cvt_pk_bf16_f32, round to nearest even like bf16_rn): word = bf16(a) | bf16(b) << 16
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pk(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2_t));
+}
+__device__ __forceinline__ void split3x2(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = bf16_pk(a, b);
+    a -= __uint_as_float(h << 16); b -= __uint_as_float(h & 0xFFFF0000u);
+    m = bf16_pk(a, b);
+    a -= __uint_as_float(m << 16); b -= __uint_as_float(m & 0xFFFF0000u);
+    l = bf16_pk(a, b);
+}
+// byte offset of (row, 16-byte chunk q) inside one plane
+__device__ __forceinline__ int pl_off(int row, int q) { return row * 128 + ((q ^ (row & 7)) << 4); }
+// four consecutive channels (ch0 % 4 == 0) of one cell -> the three planes
+__device__ __forceinline__ void store_split4(uint8_t* planes, int plane_bytes, int row, int ch0, float4 o) {
+    uint32_t h[2], m[2], l[2];
+    split3x2(o.x, o.y, h[0], m[0], l[0]); split3x2(o.z, o.w, h[1], m[1], l[1]);
+    uint8_t* dst = planes + pl_off(row, ch0 >> 3) + ((ch0 & 4) << 1);
+    *(uint2*)dst = make_uint2(h[0], h[1]);
+    *(uint2*)(dst + plane_bytes) = make_uint2(m[0], m[1]);
+    *(uint2*)(dst + 2 * plane_bytes) = make_uint2(l[0], l[1]);
+}
+__device__ __forceinline__ float bf16_lo_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi_f32(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+__device__ __forceinline__ float4 load_split4(const uint8_t* planes, int plane_bytes, int row, int ch0) {
+    const uint8_t* src = planes + pl_off(row, ch0 >> 3) + ((ch0 & 4) << 1);
+    const uint2 h = *(const uint2*)src, m = *(const uint2*)(src + plane_bytes), l = *(const uint2*)(src + 2 * plane_bytes);
+    return make_float4((bf16_lo_f32(h.x) + bf16_lo_f32(m.x)) + bf16_lo_f32(l.x), (bf16_hi_f32(h.x) + bf16_hi_f32(m.x)) + bf16_hi_f32(l.x),
+                       (bf16_lo_f32(h.y) + bf16_lo_f32(m.y)) + bf16_lo_f32(l.y), (bf16_hi_f32(h.y) + bf16_hi_f32(m.y)) + bf16_hi_f32(l.y));
+}
+
+
 __device__ __forceinline__ float nn_wave_max(float x) {
     x = fmaxf(x, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(x)))); x = fmaxf(x, __uint_as_float(dpp_u32<0x4E>(__float_as_uint(x))));
     x = fmaxf(x, __uint_as_float(dpp_u32<0x141>(__float_as_uint(x)))); x = fmaxf(x, __uint_as_float(dpp_u32<0x140>(__float_as_uint(x))));
@@ -341,17 +388,27 @@ __device__ long long g_v80_phase[4][16];
 // f32 buffer in LDS, H = the rest of the workgroup's LDS ([112][172] + 2 x [16][172] + [16][52] + 64 floats).
 //   INLDS:  the input tile is already in X (whole-net kernel) instead of xin in HBM
 //   OUTLDS: the block output replaces X in place (always the case for the head MODEs); SAVE: and is copied to xsave
-template <int ACT, int POOLMAX, int MODE, bool INLDS, bool OUTLDS, bool SAVE>
+//   SPX:    the input tile lives in LDS as three bf16 planes [112][64] (hi + mid + lo, the layout of nn_conv5x5.hip.h) instead of
+//           the f32 [112][60] tile, written split once by the producing epilogue, and the expand GEMM runs on bf16 x 3 operands (six
+//           v_mfma_f32_16x16x32_bf16 per product; W.We = [11 tiles][2 K chunks of 32][3 planes][64 lanes][8] bf16).  The trunk block
+//           rewrites the planes in place; the head blocks leave them alone (the value head reuses the trunk output) and put their
+//           f32 output O [112][60] over the dead pooled / SE-hidden buffers for the head tail.
+template <int ACT, int POOLMAX, int MODE, bool INLDS, bool OUTLDS, bool SAVE, bool SPX = false>
 __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave, const float* __restrict__ xin,
                                                float* __restrict__ xout, const V80BlockW& W, int B,
                                                const int8_t* __restrict__ boards, const V80NetW& N,
                                                const uint8_t* __restrict__ valid, float* __restrict__ pi_out,
                                                float* __restrict__ v_out, int P) {
     constexpr int C = 56, E = 168, NS = 16, ROWS = NS * 7, XS = 60, HS = 172, QS = 52, FK = 7 * XS /* 420 */, A = 81;
-    float* PL = H + ROWS * HS;          // pooled [NS][HS]
-    float* SC = PL + NS * HS;           // scales [NS][HS]
-    float* SH = SC + NS * HS;           // SE hidden [NS][QS]
+    static_assert(!SPX || ((MODE == 1 || INLDS) && !SAVE), "SPX: whole-net kernel only");
+    // (SPX: SC first, so that pooled + SE hidden + depthwise weights + 12 KB behind them form the 26.9 KB of the head blocks' output tile)
+    float* SC = SPX ? H + ROWS * HS : H + ROWS * HS + NS * HS;          // scales [NS][HS]
+    float* PL = SPX ? SC + NS * HS : H + ROWS * HS;                     // pooled [NS][HS]
+    float* SH = SPX ? PL + NS * HS : SC + NS * HS;                      // SE hidden [NS][QS]
     float* WD = SH + NS * QS;           // [49]
+    float* OT = PL;                     // SPX, head blocks: the block output O [ROWS][XS] f32 (PL, SH, WD are dead by the project phase)
+    uint8_t* XPL = (uint8_t*)X;         // SPX: the three planes
+    constexpr int PB = ROWS * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
     const int b0 = blockIdx.x * NS;
@@ -360,10 +417,16 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
     AZG_PH(0);
 
     float4 we[4], w2r[3], w1r[11], wpr[11];
+    uint4 weS[6];                       // SPX: [K chunk][plane] fragments of the wave's expand tile
     const int nt_e = wave < 11 ? wave : 0, nt_1 = wave < 3 ? wave : 0;
     auto load_we = [&]() {
+        if (SPX) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) we[c] = FRAG(W.We, 4, nt_e, c);
+            for (int k = 0; k < 6; k++) weS[k] = ((const uint4*)W.We)[((size_t)nt_e * 6 + k) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) we[c] = FRAG(W.We, 4, nt_e, c);
+        }
     };
     auto load_w2_wp = [&]() {
 #pragma unroll
@@ -416,7 +479,9 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[3].y, a.y, acc, 0, 0, 0);
             }
             const int col0 = nt_p * 16 + 4 * g;
-            if (col0 < XS)            // columns 56..59 get 0 (zero-padded W0 / b0)
+            if (SPX)                  // all 64 columns of the planes (56..63 get 0: zero-padded W0 / b0)
+                store_split4(XPL, PB, rt * 16 + r16, col0, make_float4(acc[0] + b04.x, acc[1] + b04.y, acc[2] + b04.z, acc[3] + b04.w));
+            else if (col0 < XS)       // columns 56..59 get 0 (zero-padded W0 / b0)
                 *(float4*)(X + (rt * 16 + r16) * XS + col0) =
                     make_float4(acc[0] + b04.x, acc[1] + b04.y, acc[2] + b04.z, acc[3] + b04.w);
         }
@@ -459,6 +524,22 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
         for (int rt = 0; rt < 7; rt++) {
             const float* xr = X + (rt * 16 + r16) * XS + 4 * g;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (SPX) {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const uint8_t* src = XPL + pl_off(rt * 16 + r16, 4 * c + g);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)src), am = __builtin_bit_cast(bf16x8, *(const uint4*)(src + PB)),
+                                 al = __builtin_bit_cast(bf16x8, *(const uint4*)(src + 2 * PB));
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, weS[3 * c]), wm = __builtin_bit_cast(bf16x8, weS[3 * c + 1]),
+                                 wl = __builtin_bit_cast(bf16x8, weS[3 * c + 2]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const float4 a = *(const float4*)(xr + 16 * c);
@@ -471,6 +552,7 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
                 const f32x2 a = *(const f32x2*)(xr + 48 - 2 * g);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[3].x, a.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[3].y, a.y, acc, 0, 0, 0);
+            }
             }
             const int col0 = nt_e * 16 + 4 * g;
             if (col0 < E) {
@@ -600,7 +682,12 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[10].y, a.y, acc, 0, 0, 0);
         }
         const int col0 = nt_p * 16 + 4 * g;
-        if (MODE >= 2 || OUTLDS) {
+        if (SPX) {
+            const float4 xr = load_split4(XPL, PB, row, col0);       // (columns 56..63 of the planes are zero)
+            const float4 o4 = make_float4(acc[0] + bp4.x + xr.x, acc[1] + bp4.y + xr.y, acc[2] + bp4.z + xr.z, acc[3] + bp4.w + xr.w);
+            if (MODE == 1) store_split4(XPL, PB, row, col0, o4);     // trunk: in place, a lane rewrites the elements it read
+            else if (col0 < XS) *(float4*)(OT + row * XS + col0) = o4;
+        } else if (MODE >= 2 || OUTLDS) {
             if (col0 < XS) {          // each element is read (residual) and overwritten by the same lane
                 float* xp = X + row * XS + col0;
                 const float4 xr = *(const float4*)xp;
@@ -634,7 +721,7 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
             for (int cc = 0; cc < 14; cc++) {
                 const int k0 = 16 * (c_beg + cc) + 4 * g;
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cc < n_c && k0 < FK) a = *(const float4*)(X + r16 * FK + k0);
+                if (cc < n_c && k0 < FK) a = *(const float4*)((SPX ? OT : X) + r16 * FK + k0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc].x, a.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc].y, a.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cc].z, a.z, acc, 0, 0, 0);
@@ -698,7 +785,7 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
                 float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (c < 27) {
                     w4 = FRAG(N.Wh1, 27, 0, c);
-                    if (k0 < FK) a = *(const float4*)(X + r16 * FK + k0);
+                    if (k0 < FK) a = *(const float4*)((SPX ? OT : X) + r16 * FK + k0);
                 }
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, a.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, a.y, acc, 0, 0, 0);
@@ -748,6 +835,21 @@ __global__ __launch_bounds__(768) void k_v80_net(V80BlockW Wt, V80BlockW Wp, V80
     v80_block_body<2, 1, 2, true, false, false>(X, H, nullptr, nullptr, nullptr, Wp, B, nullptr, Np, valid, pi_out, nullptr, P);
     __syncthreads();
     v80_block_body<2, 1, 3, true, false, false>(XT, H, nullptr, nullptr, nullptr, Wv, B, nullptr, Nv, nullptr, nullptr, v_out, P);
+}
+
+// The same forward with the tile the three blocks read kept as bf16 planes and the expand GEMMs on bf16 x 3 operands (SPX above):
+// LDS = 3 x [112][64] bf16 + the block's buffers + 12 KB = 154.3 KB; one copy of the trunk output serves both heads.
+__global__ __launch_bounds__(768) void k_v80_net_spx(V80BlockW Wt, V80BlockW Wp, V80BlockW Wv, V80NetW N0, V80NetW Np, V80NetW Nv,
+                                                     const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid, int B,
+                                                     int P, float* __restrict__ pi_out, float* __restrict__ v_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                                  // three bf16 planes [112][64]
+    float* H = X + 3 * 112 * 128 / 4;
+    v80_block_body<1, 0, 1, false, true, false, true>(X, H, nullptr, nullptr, nullptr, Wt, B, boards, N0, nullptr, nullptr, nullptr, P);
+    __syncthreads();
+    v80_block_body<2, 1, 2, true, false, false, true>(X, H, nullptr, nullptr, nullptr, Wp, B, nullptr, Np, valid, pi_out, nullptr, P);
+    __syncthreads();
+    v80_block_body<2, 1, 3, true, false, false, true>(X, H, nullptr, nullptr, nullptr, Wv, B, nullptr, Nv, nullptr, nullptr, v_out, P);
 }
 
 // boards int8 [B][C][L] (reference layout) -> x f32 [B][L][ldx] (channels-last; columns C..ldx-1 zeroed)

@@ -156,10 +156,13 @@ class SplendorV80Hip(SplendorV80):
     ~70 torch ops: 9 skinny fp32 MFMA GEMMs (k_linear, with bias / activation / residual / SE-scale fused), 3
     depthwise+BN+act+pool kernels, 3 SE kernels, one layout kernel and one softmax/value kernel per leaf batch."""
 
-    def __init__(self, state_dict, num_players=2, device='cuda:0', max_batch=4096):
+    def __init__(self, state_dict, num_players=2, device='cuda:0', max_batch=4096, split=True):
+        """split: the one-launch forward keeps the tile the blocks read as three bf16 planes and runs the expand GEMMs on bf16 x 3
+        split-precision operands (azg_nn_v80_forward_split, same 1e-5 contract); False = f32 MFMAs throughout"""
         super().__init__(state_dict, num_players=num_players, device=device, dtype=torch.float32)
         from . import _lib
         self._lib = _lib
+        self.split = bool(split)
         self.C = self.nb_vect
         self.E = 3 * self.C
         self.Q = self.trunk.W1.shape[1]
@@ -246,6 +249,21 @@ class SplendorV80Hip(SplendorV80):
         assert len(self._net_keep) == 43
         self.net_ptrs = (C.c_void_p * 43)(*[t.data_ptr() for t in self._net_keep])
 
+        def split_frag(Wp):                # zero-padded [K][N], K % 32 == 0 -> [N/16 tiles][K/32 chunks][3 planes hi, mid, lo][64 lanes][8] bf16
+            K, N = Wp.shape
+            m = Wp.contiguous().float()
+            hi = m.to(torch.bfloat16)
+            r1 = m - hi.float()
+            mid = r1.to(torch.bfloat16)
+            lo = (r1 - mid.float()).to(torch.bfloat16)
+            pl = torch.stack([hi, mid, lo]).view(3, K // 32, 4, 8, N // 16, 16)           # plane, chunk, g, j, tile, r
+            return pl.permute(4, 1, 0, 2, 5, 3).contiguous().view(-1)                     # tile, chunk, plane, g, r, j
+        keep = list(self._net_keep)
+        for bi, blk in enumerate((self.trunk, self.head_pi, self.head_v)):
+            keep[2 + 11 * bi] = split_frag(blk.pWe)              # [64][176] (K 56 -> 64 zero padded)
+        self._net_keep_split = keep
+        self.net_ptrs_split = (C.c_void_p * 43)(*[t.data_ptr() for t in keep])
+
     def _linear(self, A, lda, Wp, bias, out, ldc, M, K, N, act=0, R=None, ldr=0, rowscale=None, rpg=0, ksplit=0):
         import ctypes as C
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
@@ -325,8 +343,8 @@ class SplendorV80Hip(SplendorV80):
         assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda
         valids = valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)
         if self.fused_net:
-            self._lib.check(L.azg_nn_v80_forward(p(boards), p(valids), self.net_ptrs, B, self.P, p(self.x2), p(self.pi),
-                                                 p(self.v), self._stream()))
+            fwd, ptrs = (L.azg_nn_v80_forward_split, self.net_ptrs_split) if self.split else (L.azg_nn_v80_forward, self.net_ptrs)
+            self._lib.check(fwd(p(boards), p(valids), ptrs, B, self.P, p(self.x2), p(self.pi), p(self.v), self._stream()))
             return self.pi[:B], self.v[:B]
         self._lib.check(L.azg_nn_board_to_x(p(boards), p(self.x0), B, self.C, self._stream()))
         self._linear(self.x0, self.C, self.pW0, self.b0, self.x1, self.C, B * 7, self.C, self.C)           # first_layer

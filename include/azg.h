@@ -254,6 +254,13 @@ int azg_nn_v80_block(const float* xin_dev, float* xout_dev, const float* const* 
    padded; every matrix except Wv2 is in the fragment order described at azg_nn_v80_block.  Fixed to the V80 activations (trunk ReLU + mean squeeze, heads Hardswish + max squeeze). */
 int azg_nn_v80_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int B, int P,
                        float* x_trunk_dev, float* pi_dev, float* v_dev, void* stream);
+/* The same forward with the expand GEMM of the three blocks on split-precision operands (every f32 value as three bf16 numbers
+   hi + mid + lo, a product = the six bf16 MFMAs of relative weight >= 2^-24; f32-input MFMA runs at 1/16 of the bf16 rate on
+   gfx950): the tile the blocks read lives in LDS as three bf16 planes, written split once by the producing epilogue; one copy of
+   the trunk output serves both heads.  Only We (w[2], w[13], w[24]) differs: [11 column tiles][2 K chunks of 32][3 planes]
+   [64 lanes][8] bf16 with element = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)], K zero padded 56 -> 64. */
+int azg_nn_v80_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int B, int P,
+                             float* x_trunk_dev, float* pi_dev, float* v_dev, void* stream);
 /* The whole MobileNetV3-1d forward (first layer, trunk block, policy block + head, value block + head) in one launch for
    the geometries of the reference's Splendor (SplendorNNet.py:259-283, n players: C = 32 + 10n + n^2 channels x 7 tokens)
    and Azul (AzulNNet.py:91-113: 23 channels x 6 tokens) nets -- the generic sibling of azg_nn_v80_forward.

@@ -6,7 +6,7 @@ import torch
 from azg_amd import _lib
 from azg_amd.nnet import SplendorV80Hip
 B = 4096
-net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=B)
+net = SplendorV80Hip.from_npz(os.path.join(ROOT, 'tests/golden/weights_splendor2_v80.npz'), max_batch=B, split=os.environ.get('SPLIT', '1') == '1')
 boards = torch.randint(0, 5, (B, 56, 7), dtype=torch.int8, device='cuda')
 valid = torch.ones((B, 81), dtype=torch.uint8, device='cuda')
 for _ in range(5):
