@@ -372,3 +372,67 @@ def test_empty_pruned_policy_is_an_error_not_a_move():
     st = f.stats()
     assert st['errors'] == 64, st
     f.close()
+
+
+import glob as _glob
+import os as _os
+_EP_CASES = sorted(_os.path.basename(p)[len('episode_'):-len('.npz')]
+                   for p in _glob.glob(_os.path.join(_os.path.dirname(__file__), 'golden', 'episode_*.npz')))
+
+
+@pytest.mark.parametrize('case', _EP_CASES)
+def test_selfplay_vs_reference_executeEpisode(case, golden_dir):
+    """Device-resident self-play against an episode the REFERENCE's own Coach.executeEpisode played (Coach.py:37-84; fixture from
+    tools/gen_golden_episode.py): same init board, same counter stream -> the recorded plies (canonical board, pi,
+    q, player), z = roll(r, -player), and the symmetry-expanded example list in the reference's order."""
+    import torch
+    from azg_amd import games
+    from azg_amd.forest import Forest
+    from hashnet import HashNetTorch
+    d = np.load(_os.path.join(golden_dir, 'episode_%s.npz' % case))
+    variant = case.split('_')[0]
+    g = {'splendor2': lambda: games.SplendorGame(2), 'santorini11': lambda: games.SantoriniGame(11), 'azul': games.AzulGame}[variant]()
+    T = 2                                   # tree 0 replays the fixture's stream; tree 1 is a bystander on the next stream
+    args = Args(numMCTSSims=int(d['sims']), prob_fullMCTS=float(d['prob_full']), ratio_fullMCTS=5, dirichletAlpha=0,
+                temperature=[float(x) for x in d['temperature']], tempThreshold=float(d['tempThreshold']), cpuct=float(d['cpuct']),
+                fpu=float(d['fpu']), universes=int(d['universes']), forced_playouts=bool(d['forced']))
+    f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=4096, max_examples=T * 1200, rng_seed=int(d['seed']),
+               stream0=int(d['stream']))
+    net = HashNetTorch(g.P)
+    ib = torch.from_numpy(np.stack([d['init_board'], d['init_board']])).cuda()
+    f.selfplay_start(init_boards=ib)
+    shape = f.board_shape()
+    for rnd in range(400000):
+        f.select()
+        pi, vv = net.predict_batch(f.leaf_states.view((T,) + shape), f.leaf_valid.bool())
+        f.expand_backup(pi, vv)
+        f.selfplay_advance()
+        if rnd % 256 == 255:
+            st = f.stats()
+            assert st['errors'] == 0
+            if st['games'] >= 2 * T:
+                break
+    boards, pis, zs, valids, qs, meta = f.drain_examples()
+    m = meta.cpu().numpy()
+    sel = np.flatnonzero((m[:, 0] == int(d['stream'])) & (m[:, 1] == 0))
+    sel = sel[np.argsort(m[sel, 2])]
+    full_plies = np.flatnonzero(d['full'])
+    assert len(sel) == len(full_plies)
+    assert np.array_equal(m[sel, 2], full_plies) and np.array_equal(m[sel, 3], d['player'][full_plies])
+    idx = torch.from_numpy(sel).cuda()
+    b_, p_, z_, v_, q_ = [x[idx].contiguous() for x in (boards, pis, zs, valids, qs)]
+    assert np.array_equal(b_.cpu().numpy(), d['canonical'][full_plies])
+    assert np.array_equal(p_.cpu().numpy(), d['pi'][full_plies].astype(np.float32))
+    assert np.array_equal(q_.cpu().numpy(), d['q'][full_plies])
+    # the example list as executeEpisode returns it: all symmetric forms of a ply, in order (Coach.py:66-69,76-82)
+    ob, op, ov, cnt = g.symmetries_batch(b_, p_, v_)
+    K = ob.shape[1]
+    keep = (torch.arange(K, device=cnt.device)[None, :] < cnt[:, None]).reshape(-1)
+    rep = torch.repeat_interleave(torch.arange(b_.shape[0], device=cnt.device), cnt.to(torch.int64))
+    assert int(keep.sum()) == len(d['ex_board'])
+    assert np.array_equal(ob.reshape(-1, ob.shape[2])[keep].cpu().numpy(), d['ex_board'])
+    assert np.array_equal(op.reshape(-1, op.shape[2])[keep].cpu().numpy(), d['ex_pi'].astype(np.float32))
+    assert np.array_equal(ov.reshape(-1, ov.shape[2])[keep].cpu().numpy(), d['ex_valid'])
+    assert np.array_equal(z_[rep].cpu().numpy(), d['ex_z'])
+    assert np.array_equal(q_[rep].cpu().numpy(), d['ex_q'])
+    f.close()
