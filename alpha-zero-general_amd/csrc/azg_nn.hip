@@ -11,6 +11,7 @@
 #include "azg_host.h"
 #include "azg_common.hip.h"
 #include "nn_kernels.hip.h"
+#include "nn_v80_h2.hip.h"
 #include "nn_mb1d.hip.h"
 #include "nn_conv5x5.hip.h"
 
@@ -217,10 +218,41 @@ extern "C" int azg_nn_v80_forward_split(const int8_t* boards, const uint8_t* val
     return v80_forward(boards, valid, w, B, P, x_trunk, pi, v, stream, true);
 }
 
+// The V80 forward on fp16 hi+lo split operands with token-major tiles (nn_v80_h2.hip.h): one launch, one workgroup per 16 samples
+extern "C" int azg_nn_v80_forward_h2(const int8_t* boards, const uint8_t* valid, const void* const* w /* 43 */,
+                                     const float* descale /* 16, host */, int B, int P, float* pi, float* v, void* stream) {
+    if (!boards || !valid || !w || !descale || !pi || !v || B <= 0) return fail("azg_nn_v80_forward_h2: null/empty argument");
+    if (P < 2 || P > 4) return fail("azg_nn_v80_forward_h2: 2 <= P <= 4");
+    auto blk = [&](int o, int d) {
+        return H2BlockW{(const uint4*)w[o], (const uint4*)w[o + 5], (const uint4*)w[o + 7], (const uint4*)w[o + 9],
+                        (const float*)w[o + 1], (const float*)w[o + 2], (const float*)w[o + 3], (const float*)w[o + 4],
+                        (const float*)w[o + 6], (const float*)w[o + 8], (const float*)w[o + 10],
+                        descale[d], descale[d + 1], descale[d + 2], descale[d + 3]};
+    };
+    const H2BlockW Wt = blk(2, 1), Wp = blk(13, 5), Wv = blk(24, 9);
+    const H2NetW N{(const uint4*)w[0], (const uint4*)w[35], (const uint4*)w[37], (const uint4*)w[39],
+                   (const float*)w[1], (const float*)w[36], (const float*)w[38], (const float*)w[40], (const float*)w[41],
+                   (const float*)w[42], descale[0], descale[13], descale[14], descale[15]};
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_h2 = false;
+    if (!attr_h2) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_v80_net_h2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_h2 = true;
+    }
+    k_v80_net_h2<<<dim3((B + 15) / 16), dim3(768), H2_LDS, s>>>(Wt, Wp, Wv, N, boards, valid, B, P, pi, v);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 #ifdef AZG_NN_PHASE_TIMES
 extern "C" int azg_nn_debug_phase_times(long long* out /* [4][16] */) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v80_phase), sizeof(long long) * 64));
+    return 0;
+}
+extern "C" int azg_nn_debug_phase_times_h2(long long* out /* [4][16] */) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h2_phase), sizeof(long long) * 64));
     return 0;
 }
 #endif

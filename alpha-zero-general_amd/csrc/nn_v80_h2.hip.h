@@ -1,0 +1,404 @@
+// nn_v80_h2.hip.h -- the V80 policy/value forward (splendor/SplendorNNet.py:262-283,397-440; NeuralNet.predict for a leaf batch,
+// GenericNNetWrapper.py:94-120) designed around two facts of gfx950:
+//
+//  1. f32-input MFMA runs at 1/16 of the 16-bit rate.  Every f32 operand (weight or activation) is carried as TWO f16 numbers,
+//     hi = rn16(x) and lo = rn16(x - hi): 22 significant bits.  A product is three v_mfma_f32_16x16x32_f16 (lo*hi, hi*lo, hi*hi;
+//     lo*lo is 2^-22 of the product) accumulated in f32.  Weights are pre-scaled by a power of two per matrix so that their lo
+//     parts stay normal f16 numbers, activations by 2^6; the epilogue multiplies the accumulator by the exact inverse.
+//     An activation tile lives in LDS as two f16 planes (hi, lo) -- the footprint of the f32 tile -- written split once by the
+//     epilogue that produces it.
+//  2. The block's depthwise Linear(7 -> 7) mixes the 7 TOKENS of one (sample, channel) (SplendorNNet.py:148-187).  With the
+//     tile's rows ordered TOKEN-MAJOR (row = token * 16 + sample) a 16-row MFMA tile is one token of the 16 samples, so the wave that
+//     owns a 16-channel column tile of the expand GEMM ends up with all 7 tokens of (sample = lane & 15, 4 channels) in ITS OWN
+//     accumulator registers: the depthwise layer, its BN + activation and the squeeze (mean / max over tokens) are per-lane
+//     register arithmetic on MFMA results, the SE scale comes out of the fc2 MFMA in the same lane layout, and the expanded
+//     activations are written to LDS once -- already scaled -- as the project GEMM's operand.
+//
+// One workgroup = 16 samples, 12 waves; one pass = first layer + trunk block + policy block/head + value block/head; nothing but
+// boards, valid masks, weights and pi / v crosses HBM.  Four workgroup barriers per block.
+#pragma once
+#include "nn_kernels.hip.h"
+
+#pragma clang fp contract(fast)
+
+namespace azg {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr float H2_AS = 64.f, H2_IAS = 1.f / 64.f;        // activation planes hold 64 * x
+
+// device pointer tables (weights in h2 fragment order: [N/16 col tiles][K/32 chunks][2 planes hi, lo][64 lanes] x 16 bytes,
+// halves j = 0..7 of lane = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)] * 2^k; s* = 2^-k / 64 undoes both scales)
+struct H2BlockW {
+    const uint4 *We, *W1, *W2, *Wp;                       // [64][176], [192][48], [64][176], [192][64] (zero padded)
+    const float *be, *Wd, *sd, *bd, *b1, *b2, *bp;        // [176], [49], [176], [176], [48], [176], [64]
+    float se, s1, s2, sp;
+};
+struct H2NetW {
+    const uint4 *W0, *Wpi1, *Wpi2, *Wv1;                  // [64][64], [448][96] (k = token*64 + c), [96][96], [448][16]
+    const float *b0, *bpi1, *bpi2, *bv1, *Wv2, *bv2;      // [64], [96], [96], [16], [P][P] plain, [P]
+    float s0, spi1, spi2, sv1;
+};
+
+// byte offset of (row, 16-byte chunk q = 8 halves) in a plane of row stride RS (RS = 128 mod 256: with the XOR the ds_read_b128
+// lane groups of an MFMA operand fetch -- 16 rows x 4 adjacent chunks -- hit 16 distinct 16-byte bank columns)
+__device__ __forceinline__ int h2_off(int row, int q, int RS) { return row * RS + ((q ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ void h2_split2(float a, float b, uint32_t& h, uint32_t& l) {
+    const f16x2_t hh = __builtin_convertvector(f32x2{a, b}, f16x2_t);            // v_cvt_pk_f16_f32 (round to nearest even)
+    const f32x2 back = __builtin_convertvector(hh, f32x2);
+    const f16x2_t ll = __builtin_convertvector(f32x2{a - back.x, b - back.y}, f16x2_t);
+    h = __builtin_bit_cast(uint32_t, hh);
+    l = __builtin_bit_cast(uint32_t, ll);
+}
+// four consecutive channels (ch0 % 4 == 0) of one row -> both planes (PD = byte distance hi plane -> lo plane); o is UNSCALED
+__device__ __forceinline__ void h2_store4(uint8_t* hi, int PD, int RS, int row, int ch0, f32x4 o) {
+    o = o * H2_AS;
+    uint32_t h0, l0, h1, l1;
+    h2_split2(o[0], o[1], h0, l0);
+    h2_split2(o[2], o[3], h1, l1);
+    uint8_t* dst = hi + h2_off(row, ch0 >> 3, RS) + ((ch0 & 4) << 1);
+    *(uint2*)dst = make_uint2(h0, h1);
+    *(uint2*)(dst + PD) = make_uint2(l0, l1);
+}
+__device__ __forceinline__ f32x4 h2_load4(const uint8_t* hi, int PD, int RS, int row, int ch0) {
+    const uint8_t* src = hi + h2_off(row, ch0 >> 3, RS) + ((ch0 & 4) << 1);
+    const uint2 h = *(const uint2*)src, l = *(const uint2*)(src + PD);
+    const f32x2 h0 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, h.x), f32x2), h1 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, h.y), f32x2);
+    const f32x2 l0 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, l.x), f32x2), l1 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, l.y), f32x2);
+    return f32x4{h0.x + l0.x, h0.y + l0.y, h1.x + l1.x, h1.y + l1.y} * H2_IAS;
+}
+// acc += W * A for one K chunk of 32: the three products of relative weight >= 2^-11, smallest first
+__device__ __forceinline__ f32x4 h2_mma(uint4 wh, uint4 wl, uint4 ah, uint4 al, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl), __builtin_bit_cast(f16x8, ah), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, al), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, ah), acc, 0, 0, 0);
+    return acc;
+}
+// weight fragment (tile nt, chunk c, plane p) of a matrix with NCH chunks
+#define H2FRAG(ptr, NCH, nt, c, p) ((ptr)[((((size_t)(nt) * (NCH) + (c)) * 2 + (p)) << 6) + lane])
+
+__device__ __forceinline__ f32x4 h2_act(f32x4 x, int act) {
+    const f32x2 a = act_apply2(f32x2{x[0], x[1]}, act), b = act_apply2(f32x2{x[2], x[3]}, act);
+    return f32x4{a.x, a.y, b.x, b.y};
+}
+
+// LDS map (bytes).  X: the tile the three blocks read; O: a head block's output (and the int8 board tile before the first layer);
+// H: the SE-scaled expanded activations = the project operand (the head tails put their small buffers over it afterwards)
+constexpr int H2_RSX = 128, H2_RSH = 384;
+constexpr int H2_XH = 0, H2_XL = 14336, H2_OH = 28672, H2_OL = 43008, H2_HH = 57344, H2_HL = 100352, H2_PLH = 143360, H2_PLL = 149504,
+              H2_SHH = 155648, H2_SHL = 157696, H2_LDS = 159744;
+constexpr int H2_PDX = H2_XL - H2_XH, H2_PDH = H2_HL - H2_HH, H2_PDP = H2_PLL - H2_PLH, H2_PDS = H2_SHL - H2_SHH;
+// head tails (inside H): RED partial sums, HID planes (row stride 384), LG logits
+constexpr int H2_RED = H2_HH, H2_HIDH = H2_HH + 12288, H2_HIDL = H2_HIDH + 6144, H2_LG = H2_HIDL + 6144, H2_LS = 100;
+
+#ifdef AZG_NN_PHASE_TIMES
+__device__ long long g_h2_phase[4][16];
+#define H2_PH(k) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_h2_phase[MODE][k] = clock64(); } while (0)
+#else
+#define H2_PH(k)
+#endif
+
+// One InvertedResidual1d block (SplendorNNet.py:189-202) on the tile in the X planes.  MODE 1: trunk (output replaces X);
+// MODE 2 / 3: policy / value head block (output -> O planes, X stays for the other head) followed by the head's tail.
+template <int ACT, int POOLMAX, int MODE>
+__device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const H2NetW& N, int B, int P,
+                                         const uint8_t* __restrict__ valid, float* __restrict__ pi_out, float* __restrict__ v_out) {
+    constexpr int NS = 16, A = 81;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int b0 = blockIdx.x * NS;
+    uint8_t* const XH = lds + H2_XH;
+    uint8_t* const OH = lds + H2_OH;
+    uint8_t* const HH = lds + H2_HH;
+    uint8_t* const PLH = lds + H2_PLH;
+    uint8_t* const SHH = lds + H2_SHH;
+    H2_PH(0);
+
+    // ---- weights of the early phases, requested up front (they arrive while the X operands are read) ----
+    const int nt = wave < 11 ? wave : 0;
+    uint4 weh[2], wel[2], w2h[2], w2l[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) { weh[c] = H2FRAG(W.We, 2, nt, c, 0); wel[c] = H2FRAG(W.We, 2, nt, c, 1); }
+    const int ch0 = nt * 16 + 4 * g;                          // this lane's 4 expanded channels
+    const f32x4 be4 = *(const f32x4*)(W.be + ch0), sd4 = *(const f32x4*)(W.sd + ch0), bd4 = *(const f32x4*)(W.bd + ch0);
+    const float wdv = W.Wd[lane < 49 ? lane : 0];             // the 7x7 token mix: one load per wave, moved to SGPRs below
+    uint4 w1h[6], w1l[6];
+    const int nt1 = wave < 3 ? wave : 0;
+    if (wave < 3) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) { w1h[c] = H2FRAG(W.W1, 6, nt1, c, 0); w1l[c] = H2FRAG(W.W1, 6, nt1, c, 1); }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) { w2h[c] = H2FRAG(W.W2, 2, nt, c, 0); w2l[c] = H2FRAG(W.W2, 2, nt, c, 1); }
+    const f32x4 b14 = *(const f32x4*)(W.b1 + nt1 * 16 + 4 * g), b24 = *(const f32x4*)(W.b2 + ch0);
+    // the H planes' pad columns 176..191 (chunks 22, 23) must read as zeros; a head tail may have left its buffers there
+    if (tid < 448) {
+        const int row = tid >> 2, q = 22 + (tid & 1), pl = (tid >> 1) & 1;
+        *(uint4*)(HH + pl * H2_PDH + h2_off(row, q, H2_RSH)) = make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    // ---- E: expand GEMM (+BN+act) -> depthwise token mix (+BN+act) -> squeeze, all in this wave's registers ----
+    f32x4 dw[7];
+    if (wave < 11) {
+        f32x4 in[7];
+#pragma unroll
+        for (int t = 0; t < 7; t++) {
+            const int row = t * 16 + r;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int off = h2_off(row, 4 * c + g, H2_RSX);
+                acc = h2_mma(weh[c], wel[c], *(const uint4*)(XH + off), *(const uint4*)(XH + H2_PDX + off), acc);
+            }
+            in[t] = h2_act(acc * W.se + be4, ACT);
+        }
+        float wd[49];
+#pragma unroll
+        for (int k = 0; k < 49; k++) wd[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wdv), k));
+        f32x4 pool = POOLMAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 7; m++) {
+            f32x4 a = wd[m * 7] * in[0];
+#pragma unroll
+            for (int l = 1; l < 7; l++) a += wd[m * 7 + l] * in[l];
+            a = h2_act(a * sd4 + bd4, ACT);
+            dw[m] = a;
+            if (POOLMAX) pool = f32x4{fmaxf(pool[0], a[0]), fmaxf(pool[1], a[1]), fmaxf(pool[2], a[2]), fmaxf(pool[3], a[3])};
+            else pool += a;
+        }
+        if (!POOLMAX) pool = pool * (1.f / 7.f);
+        h2_store4(PLH, H2_PDP, H2_RSH, r, ch0, pool);
+    }
+    __syncthreads();
+    H2_PH(1);
+
+    // ---- S1: SE fc1 + ReLU -> SH (3 column tiles, waves 0..2) ----
+    if (wave < 3) {
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {
+            const int o0 = h2_off(r, 4 * c + g, H2_RSH), o1 = h2_off(r, 4 * c + 4 + g, H2_RSH);
+            a0 = h2_mma(w1h[c], w1l[c], *(const uint4*)(PLH + o0), *(const uint4*)(PLH + H2_PDP + o0), a0);
+            a1 = h2_mma(w1h[c + 1], w1l[c + 1], *(const uint4*)(PLH + o1), *(const uint4*)(PLH + H2_PDP + o1), a1);
+        }
+        const f32x4 hv = (a0 + a1) * W.s1 + b14;
+        h2_store4(SHH, H2_PDS, H2_RSX, r, nt1 * 16 + 4 * g, f32x4{fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f)});
+    }
+    // project weights: requested now (the fc1 fragments are dead), they land during S2
+    constexpr int PG = 3;                                     // row-tile groups of the project GEMM: 4 column tiles x PG waves
+    const int ntp = wave & 3, rt0 = wave >> 2;
+    uint4 wph[6], wpl[6];
+    if (wave < 4 * PG) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) { wph[c] = H2FRAG(W.Wp, 6, ntp, c, 0); wpl[c] = H2FRAG(W.Wp, 6, ntp, c, 1); }
+    }
+    const f32x4 bp4 = *(const f32x4*)(W.bp + ntp * 16 + 4 * g);
+    __syncthreads();
+    H2_PH(2);
+
+    // ---- S2: SE fc2 + Hardsigmoid: the scale of (sample r, this lane's 4 channels) lands in this lane -> H = 64 * dw * scale ----
+    if (wave < 11) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int off = h2_off(r, 4 * c + g, H2_RSX);
+            acc = h2_mma(w2h[c], w2l[c], *(const uint4*)(SHH + off), *(const uint4*)(SHH + H2_PDS + off), acc);
+        }
+        const f32x4 y = acc * W.s2 + b24;
+        const f32x4 sc = f32x4{hardsigmoid(y[0]), hardsigmoid(y[1]), hardsigmoid(y[2]), hardsigmoid(y[3])};
+#pragma unroll
+        for (int t = 0; t < 7; t++) h2_store4(HH, H2_PDH, H2_RSH, t * 16 + r, ch0, dw[t] * sc);
+    }
+    __syncthreads();
+    H2_PH(3);
+
+    // head tails: the first Linear's weight fragments stream in while the project GEMM runs
+    uint4 wfh[7], wfl[7], wgh[3], wgl[3];
+    const int ht_nt = wave % 6, ht_half = wave / 6;
+    if (MODE == 2) {
+#pragma unroll
+        for (int cc = 0; cc < 7; cc++) { wfh[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 0); wfl[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 1); }
+    }
+    if (MODE == 3) {
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            const int c = wave + 12 * cc;
+            wfh[cc] = c < 14 ? H2FRAG(N.Wv1, 14, 0, c, 0) : make_uint4(0u, 0u, 0u, 0u);
+            wfl[cc] = c < 14 ? H2FRAG(N.Wv1, 14, 0, c, 1) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+
+    // ---- P: project GEMM + BN + residual -> X (trunk, in place: a lane rewrites the cells it read) or O (heads) ----
+    if (wave < 4 * PG) {
+#pragma unroll 1
+        for (int rt = rt0; rt < 7; rt += PG) {
+            const int row = rt * 16 + r;
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+            for (int c = 0; c < 6; c += 2) {
+                const int o0 = h2_off(row, 4 * c + g, H2_RSH), o1 = h2_off(row, 4 * c + 4 + g, H2_RSH);
+                a0 = h2_mma(wph[c], wpl[c], *(const uint4*)(HH + o0), *(const uint4*)(HH + H2_PDH + o0), a0);
+                a1 = h2_mma(wph[c + 1], wpl[c + 1], *(const uint4*)(HH + o1), *(const uint4*)(HH + H2_PDH + o1), a1);
+            }
+            const int col0 = ntp * 16 + 4 * g;
+            const f32x4 o4 = (a0 + a1) * W.sp + bp4 + h2_load4(XH, H2_PDX, H2_RSX, row, col0);
+            h2_store4(MODE == 1 ? XH : OH, H2_PDX, H2_RSX, row, col0, o4);       // (columns 56..63: zero weights + zero bias + zero x)
+        }
+    }
+    if (MODE == 2 && wave < 6) {                              // second policy Linear: requested now (the project fragments are dead)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { wgh[c] = H2FRAG(N.Wpi2, 3, wave, c, 0); wgl[c] = H2FRAG(N.Wpi2, 3, wave, c, 1); }
+    }
+    __syncthreads();
+    H2_PH(4);
+
+    if (MODE == 2) {
+        // ---- policy tail: Flatten -> Linear(392, 81) + ReLU -> Linear(81, 81) -> masked softmax ----
+        float* RED = (float*)(lds + H2_RED);                  // [2 K halves][16][96]
+        float* LG = (float*)(lds + H2_LG);                    // [16][H2_LS]
+        uint8_t* const HIDH = lds + H2_HIDH;
+        {
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+            for (int cc = 0; cc < 7; cc++) {
+                const int c = ht_half * 7 + cc;               // K chunk of 32 = half a token row of the O planes
+                const int off = h2_off((c >> 1) * 16 + r, 4 * (c & 1) + g, H2_RSX);
+                if (cc & 1) a1 = h2_mma(wfh[cc], wfl[cc], *(const uint4*)(OH + off), *(const uint4*)(OH + H2_PDX + off), a1);
+                else a0 = h2_mma(wfh[cc], wfl[cc], *(const uint4*)(OH + off), *(const uint4*)(OH + H2_PDX + off), a0);
+            }
+            *(f32x4*)(RED + (ht_half * 16 + r) * 96 + ht_nt * 16 + 4 * g) = a0 + a1;
+        }
+        __syncthreads();
+        if (tid < 16 * 24) {
+            const int s = tid / 24, col = 4 * (tid - s * 24);
+            const f32x4 p = (*(const f32x4*)(RED + s * 96 + col) + *(const f32x4*)(RED + (16 + s) * 96 + col)) * N.spi1 + *(const f32x4*)(N.bpi1 + col);
+            h2_store4(HIDH, H2_HIDL - H2_HIDH, H2_RSH, s, col, f32x4{fmaxf(p[0], 0.f), fmaxf(p[1], 0.f), fmaxf(p[2], 0.f), fmaxf(p[3], 0.f)});
+        }
+        __syncthreads();
+        if (wave < 6) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int off = h2_off(r, 4 * c + g, H2_RSH);
+                acc = h2_mma(wgh[c], wgl[c], *(const uint4*)(HIDH + off), *(const uint4*)(HIDH + (H2_HIDL - H2_HIDH) + off), acc);
+            }
+            *(f32x4*)(LG + r * H2_LS + wave * 16 + 4 * g) = acc * N.spi2 + *(const f32x4*)(N.bpi2 + wave * 16 + 4 * g);
+        }
+        __syncthreads();
+        H2_PH(5);
+        // masked softmax == exp(log_softmax(where(valid, logits, -1e8))) (GenericNNetWrapper.py:105-107), one wave per sample
+        for (int s = wave; s < NS; s += 12) {
+            const int b = b0 + s;
+            if (b >= B) continue;
+            const int a1i = lane + 64;
+            float x0 = valid[(size_t)b * A + lane] ? LG[s * H2_LS + lane] : -1e8f;
+            float x1 = a1i < A ? (valid[(size_t)b * A + a1i] ? LG[s * H2_LS + a1i] : -1e8f) : -INFINITY;
+            const float mx = nn_wave_max(fmaxf(x0, x1));
+            x0 = expf(x0 - mx);
+            x1 = a1i < A ? expf(x1 - mx) : 0.f;
+            const float sum = nn_wave_sum(x0 + x1);
+            pi_out[(size_t)b * A + lane] = x0 / sum;
+            if (a1i < A) pi_out[(size_t)b * A + a1i] = x1 / sum;
+        }
+        __syncthreads();                                      // the value block re-zeroes H's pad columns under LG / HID
+        H2_PH(6);
+    }
+
+    if (MODE == 3) {
+        // ---- value tail: Flatten -> Linear(392, P) + ReLU -> Linear(P, P) -> tanh ----
+        float* RED = (float*)(lds + H2_RED);                  // [12 waves][16][16]
+        {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                const int c = wave + 12 * cc;
+                if (c < 14) {
+                    const int off = h2_off((c >> 1) * 16 + r, 4 * (c & 1) + g, H2_RSX);
+                    acc = h2_mma(wfh[cc], wfl[cc], *(const uint4*)(OH + off), *(const uint4*)(OH + H2_PDX + off), acc);
+                }
+            }
+            *(f32x4*)(RED + (wave * 16 + r) * 16 + 4 * g) = acc;
+        }
+        __syncthreads();
+        if (tid < NS * P) {
+            const int s = tid / P, p = tid - s * P, b = b0 + s;
+            if (b < B) {
+                float a = N.bv2[p];
+                for (int j = 0; j < P; j++) {
+                    float h = 0.f;
+                    for (int w = 0; w < 12; w++) h += RED[(w * 16 + s) * 16 + j];
+                    a += fmaxf(h * N.sv1 + N.bv1[j], 0.f) * N.Wv2[j * P + p];
+                }
+                v_out[(size_t)b * P + p] = tanhf(a);
+            }
+        }
+        H2_PH(5);
+    }
+}
+
+__global__ __launch_bounds__(768) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2BlockW Wv, H2NetW N, const int8_t* __restrict__ boards,
+                                                    const uint8_t* __restrict__ valid, int B, int P, float* __restrict__ pi_out,
+                                                    float* __restrict__ v_out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int NS = 16, C = 56;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int b0 = blockIdx.x * NS;
+    const int nb = min(NS, B - b0);
+    uint8_t* const XH = lds + H2_XH;
+    uint8_t* const X0 = lds + H2_OH;                          // the board tile as ONE f16 plane (64 * int8 is exact): O is free until the heads
+
+    // ---- board tile int8 [s][c][l] -> X0[l*16 + s][c] = 64 * board, requested before any weight ----
+    const uint32_t* bsrc = (const uint32_t*)(boards + (size_t)b0 * (7 * C));
+    uint32_t bv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int i = tid + 768 * k; bv[k] = (i < NS * (7 * C / 4) && i / (7 * C / 4) < nb) ? bsrc[i] : 0u; }
+    const int ntp = wave & 3, rt0 = wave >> 2;
+    uint4 w0h[2], w0l[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) { w0h[c] = H2FRAG(N.W0, 2, ntp, c, 0); w0l[c] = H2FRAG(N.W0, 2, ntp, c, 1); }
+    const f32x4 b04 = *(const f32x4*)(N.b0 + ntp * 16 + 4 * g);
+    // zero what is read but never written: the pooled / SE-hidden planes (pad columns) and X0's columns 56..63
+    *(uint4*)(lds + H2_PLH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);                      // 768 x 16 B = both PL planes
+    if (tid < 256) *(uint4*)(lds + H2_SHH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);       // both SH planes
+    if (tid < 112) *(uint4*)(X0 + h2_off(tid, 7, H2_RSX)) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();                                           // (the zeroing of X0's last chunk precedes the scatter below: none overlap, but PL/SH need it anyway)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = tid + 768 * k;
+        if (i < NS * (7 * C / 4)) {
+            const int s = i / (7 * C / 4), d = i - s * (7 * C / 4);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int idx = 4 * d + q, c = idx / 7, l = idx - c * 7;
+                const _Float16 hv = (_Float16)(float)((int)(int8_t)(bv[k] >> (8 * q)) * 64);
+                *(_Float16*)(X0 + h2_off(l * 16 + s, c >> 3, H2_RSX) + ((c & 7) << 1)) = hv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- first layer Linear(56, 56) + BN (SplendorNNet.py:397-401) -> X planes; the operand has no lo part ----
+#pragma unroll 1
+    for (int rt = rt0; rt < 7; rt += 3) {
+        const int row = rt * 16 + r;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const f16x8 a = __builtin_bit_cast(f16x8, *(const uint4*)(X0 + h2_off(row, 4 * c + g, H2_RSX)));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0l[c]), a, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0h[c]), a, acc, 0, 0, 0);
+        }
+        h2_store4(XH, H2_PDX, H2_RSX, row, ntp * 16 + 4 * g, acc * N.s0 + b04);
+    }
+    __syncthreads();
+    // V80 geometry (SplendorNNet.py:262-283): trunk ReLU + mean squeeze, both heads Hardswish + max squeeze
+    h2_block<1, 0, 1>(lds, Wt, N, B, P, valid, pi_out, v_out);
+    h2_block<2, 1, 2>(lds, Wp, N, B, P, valid, pi_out, v_out);
+    h2_block<2, 1, 3>(lds, Wv, N, B, P, valid, pi_out, v_out);
+}
+
+}  // namespace azg
+
+#pragma clang fp contract(off)

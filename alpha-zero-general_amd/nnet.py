@@ -156,13 +156,15 @@ class SplendorV80Hip(SplendorV80):
     ~70 torch ops: 9 skinny fp32 MFMA GEMMs (k_linear, with bias / activation / residual / SE-scale fused), 3
     depthwise+BN+act+pool kernels, 3 SE kernels, one layout kernel and one softmax/value kernel per leaf batch."""
 
-    def __init__(self, state_dict, num_players=2, device='cuda:0', max_batch=4096, split=True):
-        """split: the one-launch forward keeps the tile the blocks read as three bf16 planes and runs the expand GEMMs on bf16 x 3
-        split-precision operands (azg_nn_v80_forward_split, same 1e-5 contract); False = f32 MFMAs throughout"""
+    def __init__(self, state_dict, num_players=2, device='cuda:0', max_batch=4096, split=True, h2=None):
+        """h2 (default for the 2-player geometry): the one-launch forward on fp16 hi+lo split operands with token-major tiles
+        (azg_nn_v80_forward_h2, csrc/nn_v80_h2.hip.h; same 1e-5 contract).  Otherwise split: the tile the blocks read is kept as
+        three bf16 planes and the expand GEMMs run on bf16 x 3 operands (azg_nn_v80_forward_split); False = f32 MFMAs throughout"""
         super().__init__(state_dict, num_players=num_players, device=device, dtype=torch.float32)
         from . import _lib
         self._lib = _lib
         self.split = bool(split)
+        self.h2 = (self.nb_vect == 56) if h2 is None else bool(h2)
         self.C = self.nb_vect
         self.E = 3 * self.C
         self.Q = self.trunk.W1.shape[1]
@@ -263,6 +265,55 @@ class SplendorV80Hip(SplendorV80):
             keep[2 + 11 * bi] = split_frag(blk.pWe)              # [64][176] (K 56 -> 64 zero padded)
         self._net_keep_split = keep
         self.net_ptrs_split = (C.c_void_p * 43)(*[t.data_ptr() for t in keep])
+        self._h2_ptrs()
+
+    def _h2_ptrs(self):
+        """pointer table + descale factors of azg_nn_v80_forward_h2 (include/azg.h): every matrix zero padded to K % 32 == 0,
+        N % 16 == 0, scaled by 2^k (max |w| * 2^k in [2^12, 2^13)) and split into f16 hi / lo fragments"""
+        import ctypes as C
+        import math
+        d, f = self.device, torch.float32
+
+        def pad(t, shape):
+            out = torch.zeros(shape, dtype=f, device=d)
+            out[tuple(slice(0, n) for n in t.shape)] = t
+            return out.contiguous()
+
+        def frag(W, K, N):
+            m = pad(W.to(f), (K, N))
+            k = 12 - int(math.ceil(math.log2(float(m.abs().max()))))
+            m = m * (2.0 ** k)
+            hi = m.to(torch.float16)
+            lo = (m - hi.float()).to(torch.float16)
+            assert bool(torch.isfinite(hi.float()).all())
+            pl = torch.stack([hi, lo]).view(2, K // 32, 4, 8, N // 16, 16)                 # plane, chunk, g, j, tile, r
+            return pl.permute(4, 1, 0, 2, 5, 3).contiguous().view(-1), (2.0 ** -k) / 64.0   # tile, chunk, plane, g, r, j
+
+        def flat64(Wf, N):            # [7*56][N] (k = l*56 + c) -> [448][N] (k = l*64 + c)
+            out = torch.zeros((448, Wf.shape[1]), dtype=f, device=d)
+            out.view(7, 64, Wf.shape[1])[:, :56, :] = Wf.view(7, 56, Wf.shape[1])
+            return out
+        keep, desc = [], []
+        t, s = frag(self.W0, 64, 64)
+        keep += [t, pad(self.b0, (64,))]
+        desc.append(s)
+        for blk in (self.trunk, self.head_pi, self.head_v):
+            we, se = frag(blk.We, 64, 176)
+            w1, s1 = frag(blk.W1, 192, 48)
+            w2, s2 = frag(blk.W2, 64, 176)
+            wp, sp = frag(blk.Wp, 192, 64)
+            keep += [we, pad(blk.be, (176,)), blk.Wd.contiguous().to(f), pad(blk.sd, (176,)), pad(blk.bd, (176,)), w1, pad(blk.b1, (48,)),
+                     w2, pad(blk.b2, (176,)), wp, pad(blk.bp, (64,))]
+            desc += [se, s1, s2, sp]
+        wpi1, spi1 = frag(flat64(self.Wpi1, 96), 448, 96)
+        wpi2, spi2 = frag(self.Wpi2, 96, 96)
+        wv1, sv1 = frag(flat64(self.Wv1, 16), 448, 16)
+        keep += [wpi1, pad(self.bpi1, (96,)), wpi2, pad(self.bpi2, (96,)), wv1, pad(self.bv1, (16,)), self.Wv2.contiguous(), self.bv2.contiguous()]
+        desc += [spi1, spi2, sv1]
+        assert len(keep) == 43 and len(desc) == 16
+        self._net_keep_h2 = keep
+        self.net_ptrs_h2 = (C.c_void_p * 43)(*[t.data_ptr() for t in keep])
+        self.descale_h2 = (C.c_float * 16)(*desc)
 
     def _linear(self, A, lda, Wp, bias, out, ldc, M, K, N, act=0, R=None, ldr=0, rowscale=None, rpg=0, ksplit=0):
         import ctypes as C
@@ -342,6 +393,10 @@ class SplendorV80Hip(SplendorV80):
         boards = boards.reshape(B, -1)
         assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda
         valids = valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)
+        if self.fused_net and self.h2:
+            self._lib.check(L.azg_nn_v80_forward_h2(p(boards), p(valids), self.net_ptrs_h2, self.descale_h2, B, self.P, p(self.pi), p(self.v),
+                                                    self._stream()))
+            return self.pi[:B], self.v[:B]
         if self.fused_net:
             fwd, ptrs = (L.azg_nn_v80_forward_split, self.net_ptrs_split) if self.split else (L.azg_nn_v80_forward, self.net_ptrs)
             self._lib.check(fwd(p(boards), p(valids), ptrs, B, self.P, p(self.x2), p(self.pi), p(self.v), self._stream()))

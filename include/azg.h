@@ -261,6 +261,18 @@ int azg_nn_v80_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const
    [64 lanes][8] bf16 with element = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)], K zero padded 56 -> 64. */
 int azg_nn_v80_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int B, int P,
                              float* x_trunk_dev, float* pi_dev, float* v_dev, void* stream);
+/* The same forward (NeuralNet.predict for a leaf batch, SplendorNNet.py:397-440 / GenericNNetWrapper.py:94-110) on fp16 hi+lo
+   split operands (every f32 weight / activation as hi = rn16(x), lo = rn16(x - hi): 22 significant bits; a product = three
+   v_mfma_f32_16x16x32_f16) with TOKEN-MAJOR tiles, so that the depthwise token mix, its BN + activation, the squeeze and the SE
+   scale run on MFMA accumulators in registers (csrc/nn_v80_h2.hip.h).  Same 1e-5 contract as azg_nn_v80_forward.
+   w = the 43 slots of azg_nn_v80_forward with every matrix except Wd / Wv2 as h2 fragments: zero padded to K % 32 == 0,
+   N % 16 == 0 -- W0[64][64], We[64][176], W1[192][48], W2[64][176], Wp[192][64], Wpi1[448][96] and Wv1[448][16] (row k =
+   token*64 + c), Wpi2[96][96] -- scaled by a power of two 2^k per matrix and stored as
+   [N/16 tiles][K/32 chunks][2 planes hi, lo][64 lanes][8] f16, element = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)];
+   vectors zero padded f32: b0[64], be / sd / bd / b2[176], b1[48], bp[64], bpi1 / bpi2[96], bv1[16].
+   descale (HOST array of 16 floats) = 2^-k / 64 for W0, {We, W1, W2, Wp} x (trunk, policy, value), Wpi1, Wpi2, Wv1. */
+int azg_nn_v80_forward_h2(const int8_t* boards_dev, const uint8_t* valid_dev, const void* const* w, const float* descale_host,
+                          int B, int P, float* pi_dev, float* v_dev, void* stream);
 /* The whole MobileNetV3-1d forward (first layer, trunk block, policy block + head, value block + head) in one launch for
    the geometries of the reference's Splendor (SplendorNNet.py:259-283, n players: C = 32 + 10n + n^2 channels x 7 tokens)
    and Azul (AzulNNet.py:91-113: 23 channels x 6 tokens) nets -- the generic sibling of azg_nn_v80_forward.

@@ -56,14 +56,15 @@ def test_v80_forward_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('path', ['fused_net', 'fused_net_f32', 'fused_blocks', 'unfused'])
+@pytest.mark.parametrize('path', ['fused_net_h2', 'fused_net', 'fused_net_f32', 'fused_blocks', 'unfused'])
 def test_v80_hip_kernels_forward_gpu(path):
     """The engine's own gfx950 net kernels vs the reference model's outputs: the 3-launch whole-net fusion
     (azg_nn_v80_forward), the per-block fusion (azg_nn_v80_block + skinny GEMMs) and the unfused kernel chain."""
     from azg_amd.nnet import SplendorV80Hip, SplendorV80
     root = os.path.join(os.path.dirname(__file__), 'golden')
-    net = SplendorV80Hip.from_npz(os.path.join(root, 'weights_splendor2_v80.npz'), device='cuda:0', max_batch=512, split=path != 'fused_net_f32')
-    net.fused_net = path.startswith('fused_net')      # one launch: split-precision expand (default) or f32 MFMAs throughout
+    net = SplendorV80Hip.from_npz(os.path.join(root, 'weights_splendor2_v80.npz'), device='cuda:0', max_batch=512, split=path != 'fused_net_f32',
+                                  h2=path == 'fused_net_h2')
+    net.fused_net = path.startswith('fused_net')      # one launch: fp16 hi+lo operands on token-major tiles (default), bf16 x 3 expand, or f32 MFMAs throughout
     net.fused_blocks = path != 'unfused'
     d = np.load(os.path.join(root, 'netfwd_splendor2_v80.npz'))
     boards = torch.from_numpy(d['boards']).cuda()
