@@ -15,7 +15,7 @@
 //     activations are written to LDS once -- already scaled -- as the project GEMM's operand.
 //
 // One workgroup = 16 samples, 12 waves; one pass = first layer + trunk block + policy block/head + value block/head; nothing but
-// boards, valid masks, weights and pi / v crosses HBM.  Four workgroup barriers per block.
+// boards, valid masks, weights and pi / v crosses HBM.  Five workgroup barriers per block.
 #pragma once
 #include "nn_kernels.hip.h"
 
@@ -32,7 +32,7 @@ constexpr float H2_AS = 64.f, H2_IAS = 1.f / 64.f;        // activation planes h
 // halves j = 0..7 of lane = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)] * 2^k; s* = 2^-k / 64 undoes both scales)
 struct H2BlockW {
     const uint4 *We, *W1, *W2, *Wp;                       // [64][176], [192][48], [64][176], [192][64] (zero padded)
-    const float *be, *Wd, *sd, *bd, *b1, *b2, *bp;        // [176], [49], [176], [176], [48], [176], [64]
+    const float *be, *Wd, *sd, *bd, *b1, *b2, *bp;        // [176], [49] (Hardswish blocks: Wd / 6), [176], [176], [48], [176], [64]
     float se, s1, s2, sp;
 };
 struct H2NetW {
@@ -53,8 +53,8 @@ __device__ __forceinline__ void h2_split2(float a, float b, uint32_t& h, uint32_
     l = __builtin_bit_cast(uint32_t, ll);
 }
 // four consecutive channels (ch0 % 4 == 0) of one row -> both planes (PD = byte distance hi plane -> lo plane); o is UNSCALED
-__device__ __forceinline__ void h2_store4(uint8_t* hi, int PD, int RS, int row, int ch0, f32x4 o) {
-    o = o * H2_AS;
+__device__ __forceinline__ void h2_store4(uint8_t* hi, int PD, int RS, int row, int ch0, f32x4 o, float mul = H2_AS) {
+    o = o * mul;
     uint32_t h0, l0, h1, l1;
     h2_split2(o[0], o[1], h0, l0);
     h2_split2(o[2], o[3], h1, l1);
@@ -79,9 +79,28 @@ __device__ __forceinline__ f32x4 h2_mma(uint4 wh, uint4 wl, uint4 ah, uint4 al, 
 // weight fragment (tile nt, chunk c, plane p) of a matrix with NCH chunks
 #define H2FRAG(ptr, NCH, nt, c, p) ((ptr)[((((size_t)(nt) * (NCH) + (c)) * 2 + (p)) << 6) + lane])
 
-__device__ __forceinline__ f32x4 h2_act(f32x4 x, int act) {
-    const f32x2 a = act_apply2(f32x2{x[0], x[1]}, act), b = act_apply2(f32x2{x[2], x[3]}, act);
-    return f32x4{a.x, a.y, b.x, b.y};
+// ReLU, or 6 * Hardswish = x * clamp(x + 3, 0, 6): the 1/6 is folded into the next linear step (the token-mix weights the host
+// passes for a Hardswish block are Wd / 6; the pooled value and the project operand take it with their plane scale)
+__device__ __forceinline__ f32x4 h2_act6(f32x4 x, int act) {
+    if (act == ACT_RELU) return f32x4{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f), fmaxf(x[2], 0.f), fmaxf(x[3], 0.f)};
+    const f32x4 t = x + 3.f;
+    return x * f32x4{__builtin_amdgcn_fmed3f(t[0], 0.f, 6.f), __builtin_amdgcn_fmed3f(t[1], 0.f, 6.f), __builtin_amdgcn_fmed3f(t[2], 0.f, 6.f),
+                     __builtin_amdgcn_fmed3f(t[3], 0.f, 6.f)};
+}
+
+// phase-E operands of one block for this lane (column tile nt of the expand GEMM): requested one phase ahead -- during the
+// previous block's project GEMM -- so that a block never starts by waiting for its first weights
+struct H2EW {
+    uint4 weh[2], wel[2];
+    f32x4 be4, sd4, bd4;
+    float wdv;                                            // the 7x7 token mix: element `lane` (rows move to SGPRs as they are used)
+};
+__device__ __forceinline__ void h2_load_ew(H2EW& e, const H2BlockW& W, int nt, int g, int lane) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) { e.weh[c] = H2FRAG(W.We, 2, nt, c, 0); e.wel[c] = H2FRAG(W.We, 2, nt, c, 1); }
+    const int ch0 = nt * 16 + 4 * g;
+    e.be4 = *(const f32x4*)(W.be + ch0); e.sd4 = *(const f32x4*)(W.sd + ch0); e.bd4 = *(const f32x4*)(W.bd + ch0);
+    e.wdv = W.Wd[lane < 49 ? lane : 0];
 }
 
 // LDS map (bytes).  X: the tile the three blocks read; O: a head block's output (and the int8 board tile before the first layer);
@@ -104,7 +123,9 @@ __device__ long long g_h2_phase[4][16];
 // MODE 2 / 3: policy / value head block (output -> O planes, X stays for the other head) followed by the head's tail.
 template <int ACT, int POOLMAX, int MODE>
 __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const H2NetW& N, int B, int P,
-                                         const uint8_t* __restrict__ valid, float* __restrict__ pi_out, float* __restrict__ v_out) {
+                                         const uint8_t* __restrict__ valid, float* __restrict__ pi_out, float* __restrict__ v_out,
+                                         H2EW& ew /* in: this block's phase-E operands; out: the next block's */,
+                                         const H2BlockW& Wnext) {
     constexpr int NS = 16, A = 81;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
@@ -116,23 +137,19 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
     uint8_t* const SHH = lds + H2_SHH;
     H2_PH(0);
 
-    // ---- weights of the early phases, requested up front (they arrive while the X operands are read) ----
+    // ---- weights of the SE phases: requested now, behind the phase-E operands `ew` that are already on their way ----
     const int nt = wave < 11 ? wave : 0;
-    uint4 weh[2], wel[2], w2h[2], w2l[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++) { weh[c] = H2FRAG(W.We, 2, nt, c, 0); wel[c] = H2FRAG(W.We, 2, nt, c, 1); }
+    uint4 w2h[2], w2l[2];
     const int ch0 = nt * 16 + 4 * g;                          // this lane's 4 expanded channels
-    const f32x4 be4 = *(const f32x4*)(W.be + ch0), sd4 = *(const f32x4*)(W.sd + ch0), bd4 = *(const f32x4*)(W.bd + ch0);
-    const float wdv = W.Wd[lane < 49 ? lane : 0];             // the 7x7 token mix: one load per wave, moved to SGPRs below
-    uint4 w1h[6], w1l[6];
-    const int nt1 = wave < 3 ? wave : 0;
-    if (wave < 3) {
-#pragma unroll
-        for (int c = 0; c < 6; c++) { w1h[c] = H2FRAG(W.W1, 6, nt1, c, 0); w1l[c] = H2FRAG(W.W1, 6, nt1, c, 1); }
-    }
-#pragma unroll
-    for (int c = 0; c < 2; c++) { w2h[c] = H2FRAG(W.W2, 2, nt, c, 0); w2l[c] = H2FRAG(W.W2, 2, nt, c, 1); }
-    const f32x4 b14 = *(const f32x4*)(W.b1 + nt1 * 16 + 4 * g), b24 = *(const f32x4*)(W.b2 + ch0);
+    const uint4 weh0 = ew.weh[0], weh1 = ew.weh[1], wel0 = ew.wel[0], wel1 = ew.wel[1];
+    const f32x4 be4 = ew.be4, sd4 = ew.sd4, bd4 = ew.bd4;
+    const float wdv = ew.wdv;
+    // SE fc1 (K = 192 = 6 chunks, 3 column tiles): 9 waves, wave w takes column tile w % 3 and the chunk pair w / 3; the three
+    // K groups of a tile are added up through LDS (a 3-wave fc1 would hold 48 registers of fragments per wave through phase E)
+    uint4 w1h[2], w1l[2];
+    const int nt1 = wave % 3, kg1 = wave < 9 ? wave / 3 : 0;
+    const int cs1 = tid / 12, cc1 = 4 * (tid - cs1 * 12);     // the fc1 combine step: (sample, 4 hidden units) of thread tid < 192
+    f32x4 b24, b14;
     // the H planes' pad columns 176..191 (chunks 22, 23) must read as zeros; a head tail may have left its buffers there
     if (tid < 448) {
         const int row = tid >> 2, q = 22 + (tid & 1), pl = (tid >> 1) & 1;
@@ -147,47 +164,44 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         for (int t = 0; t < 7; t++) {
             const int row = t * 16 + r;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                const int off = h2_off(row, 4 * c + g, H2_RSX);
-                acc = h2_mma(weh[c], wel[c], *(const uint4*)(XH + off), *(const uint4*)(XH + H2_PDX + off), acc);
+            {
+                const int o0 = h2_off(row, g, H2_RSX), o1 = h2_off(row, 4 + g, H2_RSX);
+                acc = h2_mma(weh0, wel0, *(const uint4*)(XH + o0), *(const uint4*)(XH + H2_PDX + o0), acc);
+                acc = h2_mma(weh1, wel1, *(const uint4*)(XH + o1), *(const uint4*)(XH + H2_PDX + o1), acc);
             }
-            in[t] = h2_act(acc * W.se + be4, ACT);
+            in[t] = h2_act6(acc * W.se + be4, ACT);
+            if (t == 0) H2_PH(10);
         }
-        float wd[49];
+        H2_PH(11);
+        // the SE weights: requested behind the expand GEMM's operands (the vector-memory pipe of the CU takes ~30 cycles per 1 KiB
+        // wave request when every wave is asking), they land during the token mix
 #pragma unroll
-        for (int k = 0; k < 49; k++) wd[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wdv), k));
+        for (int c = 0; c < 2; c++) { w1h[c] = H2FRAG(W.W1, 6, nt1, 2 * kg1 + c, 0); w1l[c] = H2FRAG(W.W1, 6, nt1, 2 * kg1 + c, 1); }
+#pragma unroll
+        for (int c = 0; c < 2; c++) { w2h[c] = H2FRAG(W.W2, 2, nt, c, 0); w2l[c] = H2FRAG(W.W2, 2, nt, c, 1); }
+        b24 = *(const f32x4*)(W.b2 + ch0);
+        b14 = *(const f32x4*)(W.b1 + (tid < 192 ? cc1 : 0));
         f32x4 pool = POOLMAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 7; m++) {
-            f32x4 a = wd[m * 7] * in[0];
+            float wd[7];
 #pragma unroll
-            for (int l = 1; l < 7; l++) a += wd[m * 7 + l] * in[l];
-            a = h2_act(a * sd4 + bd4, ACT);
+            for (int l = 0; l < 7; l++) wd[l] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wdv), m * 7 + l));
+            f32x4 a = wd[0] * in[0];
+#pragma unroll
+            for (int l = 1; l < 7; l++) a += wd[l] * in[l];
+            a = h2_act6(a * sd4 + bd4, ACT);
             dw[m] = a;
             if (POOLMAX) pool = f32x4{fmaxf(pool[0], a[0]), fmaxf(pool[1], a[1]), fmaxf(pool[2], a[2]), fmaxf(pool[3], a[3])};
             else pool += a;
         }
-        if (!POOLMAX) pool = pool * (1.f / 7.f);
-        h2_store4(PLH, H2_PDP, H2_RSH, r, ch0, pool);
+        H2_PH(12);
+        constexpr float ACT_DIV = ACT == ACT_HSWISH ? 6.f : 1.f;                 // dw holds 6 * Hardswish(.)
+        h2_store4(PLH, H2_PDP, H2_RSH, r, ch0, pool, H2_AS / ACT_DIV / (POOLMAX ? 1.f : 7.f));
     }
-    __syncthreads();
-    H2_PH(1);
-
-    // ---- S1: SE fc1 + ReLU -> SH (3 column tiles, waves 0..2) ----
-    if (wave < 3) {
-        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-#pragma unroll
-        for (int c = 0; c < 6; c += 2) {
-            const int o0 = h2_off(r, 4 * c + g, H2_RSH), o1 = h2_off(r, 4 * c + 4 + g, H2_RSH);
-            a0 = h2_mma(w1h[c], w1l[c], *(const uint4*)(PLH + o0), *(const uint4*)(PLH + H2_PDP + o0), a0);
-            a1 = h2_mma(w1h[c + 1], w1l[c + 1], *(const uint4*)(PLH + o1), *(const uint4*)(PLH + H2_PDP + o1), a1);
-        }
-        const f32x4 hv = (a0 + a1) * W.s1 + b14;
-        h2_store4(SHH, H2_PDS, H2_RSX, r, nt1 * 16 + 4 * g, f32x4{fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f)});
-    }
-    // project weights: requested now (the fc1 fragments are dead), they land during S2
-    constexpr int PG = 3;                                     // row-tile groups of the project GEMM: 4 column tiles x PG waves
+    // project weights: requested when the phase-E arithmetic is done, they land during the SE phases
+    constexpr int PG = 3;                                     // row-tile groups of the project GEMM: 4 column tiles x PG waves (1: every weight
+                                                              // fragment enters the CU once; the four waves sit on the four SIMDs)
     const int ntp = wave & 3, rt0 = wave >> 2;
     uint4 wph[6], wpl[6];
     if (wave < 4 * PG) {
@@ -195,6 +209,27 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         for (int c = 0; c < 6; c++) { wph[c] = H2FRAG(W.Wp, 6, ntp, c, 0); wpl[c] = H2FRAG(W.Wp, 6, ntp, c, 1); }
     }
     const f32x4 bp4 = *(const f32x4*)(W.bp + ntp * 16 + 4 * g);
+    __syncthreads();
+    H2_PH(1);
+
+    // ---- S1: SE fc1 partial sums (9 waves) -> RED1, then bias + ReLU -> SH ----
+    float* const RED1 = (float*)(lds + H2_OH);                // [3 K groups][16][48] f32: the O planes are free until phase P
+    if (wave < 9) {
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        const int o0 = h2_off(r, 8 * kg1 + g, H2_RSH), o1 = h2_off(r, 8 * kg1 + 4 + g, H2_RSH);
+        a0 = h2_mma(w1h[0], w1l[0], *(const uint4*)(PLH + o0), *(const uint4*)(PLH + H2_PDP + o0), a0);
+        a1 = h2_mma(w1h[1], w1l[1], *(const uint4*)(PLH + o1), *(const uint4*)(PLH + H2_PDP + o1), a1);
+        *(f32x4*)(RED1 + (kg1 * 16 + r) * 48 + nt1 * 16 + 4 * g) = a0 + a1;
+    }
+    H2_PH(13);
+    H2_PH(14);
+    __syncthreads();
+    H2_PH(15);
+    if (tid < 192) {
+        const int s = cs1, col = cc1;
+        const f32x4 hv = (*(const f32x4*)(RED1 + s * 48 + col) + *(const f32x4*)(RED1 + (16 + s) * 48 + col) + *(const f32x4*)(RED1 + (32 + s) * 48 + col)) * W.s1 + b14;
+        h2_store4(SHH, H2_PDS, H2_RSX, s, col, f32x4{fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f)});
+    }
     __syncthreads();
     H2_PH(2);
 
@@ -209,17 +244,22 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         const f32x4 y = acc * W.s2 + b24;
         const f32x4 sc = f32x4{hardsigmoid(y[0]), hardsigmoid(y[1]), hardsigmoid(y[2]), hardsigmoid(y[3])};
 #pragma unroll
-        for (int t = 0; t < 7; t++) h2_store4(HH, H2_PDH, H2_RSH, t * 16 + r, ch0, dw[t] * sc);
+        for (int t = 0; t < 7; t++) h2_store4(HH, H2_PDH, H2_RSH, t * 16 + r, ch0, dw[t] * sc, H2_AS / (ACT == ACT_HSWISH ? 6.f : 1.f));
     }
     __syncthreads();
     H2_PH(3);
 
-    // head tails: the first Linear's weight fragments stream in while the project GEMM runs
+    // the next block's phase-E operands and the head tail's first fragments stream in while the project GEMM runs
+    if (MODE != 2) h2_load_ew(ew, Wnext, nt, g, lane);        // (policy block: after the tail's first GEMM, whose 56 fragment registers come first)
     uint4 wfh[7], wfl[7], wgh[3], wgl[3];
     const int ht_nt = wave % 6, ht_half = wave / 6;
+    f32x4 bt1 = f32x4{0.f, 0.f, 0.f, 0.f}, bt2 = bt1;         // the tails' biases: requested with the fragments
+    const int ts = tid / 24, tcol = 4 * (tid - ts * 24);      // policy tail combine step: (sample, 4 hidden units) of thread tid < 384
     if (MODE == 2) {
+        bt1 = *(const f32x4*)(N.bpi1 + (tid < 384 ? tcol : 0));
+        bt2 = *(const f32x4*)(N.bpi2 + (wave < 6 ? wave : 0) * 16 + 4 * g);
 #pragma unroll
-        for (int cc = 0; cc < 7; cc++) { wfh[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 0); wfl[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 1); }
+        for (int cc = 0; cc < 4; cc++) { wfh[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 0); wfl[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 1); }
     }
     if (MODE == 3) {
 #pragma unroll
@@ -247,7 +287,11 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
             h2_store4(MODE == 1 ? XH : OH, H2_PDX, H2_RSX, row, col0, o4);       // (columns 56..63: zero weights + zero bias + zero x)
         }
     }
-    if (MODE == 2 && wave < 6) {                              // second policy Linear: requested now (the project fragments are dead)
+    if (MODE == 2) {                                          // the rest of the first policy Linear's fragments (the project fragments are dead)
+#pragma unroll
+        for (int cc = 4; cc < 7; cc++) { wfh[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 0); wfl[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 1); }
+    }
+    if (MODE == 2 && wave < 6) {                              // second policy Linear
 #pragma unroll
         for (int c = 0; c < 3; c++) { wgh[c] = H2FRAG(N.Wpi2, 3, wave, c, 0); wgl[c] = H2FRAG(N.Wpi2, 3, wave, c, 1); }
     }
@@ -270,10 +314,11 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
             }
             *(f32x4*)(RED + (ht_half * 16 + r) * 96 + ht_nt * 16 + 4 * g) = a0 + a1;
         }
+        h2_load_ew(ew, Wnext, nt, g, lane);
         __syncthreads();
         if (tid < 16 * 24) {
-            const int s = tid / 24, col = 4 * (tid - s * 24);
-            const f32x4 p = (*(const f32x4*)(RED + s * 96 + col) + *(const f32x4*)(RED + (16 + s) * 96 + col)) * N.spi1 + *(const f32x4*)(N.bpi1 + col);
+            const int s = ts, col = tcol;
+            const f32x4 p = (*(const f32x4*)(RED + s * 96 + col) + *(const f32x4*)(RED + (16 + s) * 96 + col)) * N.spi1 + bt1;
             h2_store4(HIDH, H2_HIDL - H2_HIDH, H2_RSH, s, col, f32x4{fmaxf(p[0], 0.f), fmaxf(p[1], 0.f), fmaxf(p[2], 0.f), fmaxf(p[3], 0.f)});
         }
         __syncthreads();
@@ -284,7 +329,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
                 const int off = h2_off(r, 4 * c + g, H2_RSH);
                 acc = h2_mma(wgh[c], wgl[c], *(const uint4*)(HIDH + off), *(const uint4*)(HIDH + (H2_HIDL - H2_HIDH) + off), acc);
             }
-            *(f32x4*)(LG + r * H2_LS + wave * 16 + 4 * g) = acc * N.spi2 + *(const f32x4*)(N.bpi2 + wave * 16 + 4 * g);
+            *(f32x4*)(LG + r * H2_LS + wave * 16 + 4 * g) = acc * N.spi2 + bt2;
         }
         __syncthreads();
         H2_PH(5);
@@ -360,6 +405,8 @@ __global__ __launch_bounds__(768) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2
 #pragma unroll
     for (int c = 0; c < 2; c++) { w0h[c] = H2FRAG(N.W0, 2, ntp, c, 0); w0l[c] = H2FRAG(N.W0, 2, ntp, c, 1); }
     const f32x4 b04 = *(const f32x4*)(N.b0 + ntp * 16 + 4 * g);
+    H2EW ew;
+    h2_load_ew(ew, Wt, wave < 11 ? wave : 0, g, lane);       // the trunk block's first operands, behind the board tile and W0
     // zero what is read but never written: the pooled / SE-hidden planes (pad columns) and X0's columns 56..63
     *(uint4*)(lds + H2_PLH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);                      // 768 x 16 B = both PL planes
     if (tid < 256) *(uint4*)(lds + H2_SHH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);       // both SH planes
@@ -394,9 +441,9 @@ __global__ __launch_bounds__(768) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2
     }
     __syncthreads();
     // V80 geometry (SplendorNNet.py:262-283): trunk ReLU + mean squeeze, both heads Hardswish + max squeeze
-    h2_block<1, 0, 1>(lds, Wt, N, B, P, valid, pi_out, v_out);
-    h2_block<2, 1, 2>(lds, Wp, N, B, P, valid, pi_out, v_out);
-    h2_block<2, 1, 3>(lds, Wv, N, B, P, valid, pi_out, v_out);
+    h2_block<1, 0, 1>(lds, Wt, N, B, P, valid, pi_out, v_out, ew, Wp);
+    h2_block<2, 1, 2>(lds, Wp, N, B, P, valid, pi_out, v_out, ew, Wv);
+    h2_block<2, 1, 3>(lds, Wv, N, B, P, valid, pi_out, v_out, ew, Wv);       // (the last prefetch is unused)
 }
 
 }  // namespace azg

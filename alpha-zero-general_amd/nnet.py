@@ -302,7 +302,7 @@ class SplendorV80Hip(SplendorV80):
             w1, s1 = frag(blk.W1, 192, 48)
             w2, s2 = frag(blk.W2, 64, 176)
             wp, sp = frag(blk.Wp, 192, 64)
-            keep += [we, pad(blk.be, (176,)), blk.Wd.contiguous().to(f), pad(blk.sd, (176,)), pad(blk.bd, (176,)), w1, pad(blk.b1, (48,)),
+            keep += [we, pad(blk.be, (176,)), (blk.Wd / 6.0 if blk.use_hs else blk.Wd).contiguous().to(f), pad(blk.sd, (176,)), pad(blk.bd, (176,)), w1, pad(blk.b1, (48,)),
                      w2, pad(blk.b2, (176,)), wp, pad(blk.bp, (64,))]
             desc += [se, s1, s2, sp]
         wpi1, spi1 = frag(flat64(self.Wpi1, 96), 448, 96)

@@ -270,6 +270,8 @@ int azg_nn_v80_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev,
    token*64 + c), Wpi2[96][96] -- scaled by a power of two 2^k per matrix and stored as
    [N/16 tiles][K/32 chunks][2 planes hi, lo][64 lanes][8] f16, element = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)];
    vectors zero padded f32: b0[64], be / sd / bd / b2[176], b1[48], bp[64], bpi1 / bpi2[96], bv1[16].
+   The token-mix matrices Wd[7][7] of the two Hardswish blocks (policy, value head) are passed DIVIDED BY 6: the kernel computes
+   6 * Hardswish and leaves the 1/6 to the next linear step.
    descale (HOST array of 16 floats) = 2^-k / 64 for W0, {We, W1, W2, Wp} x (trunk, policy, value), Wpi1, Wpi2, Wv1. */
 int azg_nn_v80_forward_h2(const int8_t* boards_dev, const uint8_t* valid_dev, const void* const* w, const float* descale_host,
                           int B, int P, float* pi_dev, float* v_dev, void* stream);
