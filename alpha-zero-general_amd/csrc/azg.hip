@@ -250,11 +250,11 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     // record size classes (forest.hip.h ForestDev::cls_q): a small action space (Splendor, A = 81) gets ONE class for all
     // expanded nodes -- the heap is sized for cap records of the maximum size (+ cap entry-less records) and can never
     // fragment; larger action spaces use classes of 32 entries and a heap sized for the typical record
-    D.cls_q = f->A <= 96 ? f->A : 32;
+    D.cls_q = f->A <= 96 ? f->A : AZG_CLS_Q_MULTI;
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
-                            : (D.cls_q == f->A ? (size_t)D.cap * RecLayout(f->A, D.U).total + 4096
-                                               : (size_t)D.cap * RecLayout(nv_hint ? nv_hint : (f->A <= 256 ? 64 : 160), D.U).total * 5 / 4) + 8192;
+                            : (D.cls_q == f->A ? (size_t)D.cap * RecGeom(D.cls_q, D.U).total(f->A) + 4096
+                                               : (size_t)D.cap * RecGeom(D.cls_q, D.U).total(nv_hint ? nv_hint : (f->A <= 256 ? 64 : 160)) * 5 / 4) + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     if (heap_bytes / 16 > (size_t)AZG_CHILD_IDX_MASK) { delete f; return fail("record heap per tree exceeds the 29-bit record offset (8 GiB)"); }
     D.heap_units = (uint32_t)(heap_bytes / 16);
@@ -443,7 +443,8 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
     if (n > max_nodes) return n;
     std::vector<NodeHdr> nh(top);
     std::vector<int8_t> st((size_t)top * f->SP);
-    const size_t heap_used = D.cls_q == f->A ? (size_t)top * (RecLayout(f->A, D.U).total / 16u) : (size_t)H.heap_top;
+    const RecGeom RG(D.cls_q, D.U);
+    const size_t heap_used = D.cls_q == f->A ? (size_t)top * (RG.total(f->A) / 16u) : (size_t)H.heap_top;
     std::vector<uint8_t> hp(heap_used * 16);
     if (top) {
         HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)tree * D.s_nhdr, sizeof(NodeHdr) * top, hipMemcpyDeviceToHost));
@@ -464,14 +465,13 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
         has_policy[i] = (rh->flags & NF_EXPANDED) ? 1 : 0;
         for (int a = 0; a < A; a++) { Nsa[(size_t)i * A + a] = 0; Qsa[(size_t)i * A + a] = AZG_NANQ; Ps[(size_t)i * A + a] = 0.f; }
         if (has_policy[i]) {
-            RecLayout L(rh->nv, D.U);
-            const RecIds ids(rec, f->dev.U);
+            const RecIds ids(rec, RG);
             for (int j = 0; j < rh->nv; j++) {
-                const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
+                const uint8_t* ent = rec + RG.hot((uint32_t)j);
                 const int a = ids[j];
-                Nsa[(size_t)i * A + a] = (int32_t)*(const uint32_t*)(ent + AZG_E_N);
-                Qsa[(size_t)i * A + a] = *(const double*)(ent + AZG_E_Q);
-                Ps[(size_t)i * A + a] = *(const float*)(ent + AZG_E_P);
+                Nsa[(size_t)i * A + a] = (int32_t)*(const uint32_t*)(ent + AZG_H_N);
+                Qsa[(size_t)i * A + a] = *(const double*)(ent + AZG_H_Q);
+                Ps[(size_t)i * A + a] = *(const float*)(ent + AZG_H_P);
             }
         }
         i++;
@@ -497,7 +497,8 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
         if (top > (uint32_t)D.cap || n > top || H.heap_top > D.heap_units) { VBAD("[validate] t=%d n=%u id_top=%u heap_top=%u\n", t, n, top, H.heap_top); continue; }
         if (H.root != AZG_NONE && H.root >= top) VBAD("[validate] t=%d root=%u id_top=%u\n", t, H.root, top);
         HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)t * D.s_nhdr, sizeof(NodeHdr) * top, hipMemcpyDeviceToHost));
-        const uint32_t heap_used = D.cls_q == f->A ? (uint32_t)(top * (RecLayout(f->A, D.U).total / 16u)) : H.heap_top;
+        const RecGeom RG(D.cls_q, D.U);
+        const uint32_t heap_used = D.cls_q == f->A ? (uint32_t)(top * (RG.total(f->A) / 16u)) : H.heap_top;
         HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)t * D.s_heap, (size_t)heap_used * 16, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(tab.data(), D.htab + (size_t)t * D.s_htab, sizeof(uint32_t) * D.HT, hipMemcpyDeviceToHost));
         if (H.root != AZG_NONE && H.root < top && nh[H.root].rec_off != H.root_rec)
@@ -506,19 +507,17 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
         for (uint32_t i = 0; i < top; i++) {
             if (nh[i].flags & NF_FREE) { n_free++; continue; }
             live++;
-            const int cap_nv = (int)nh[i].nv * D.cls_q < f->A ? (int)nh[i].nv * D.cls_q : f->A;
-            RecLayout L(cap_nv, D.U);
-            if (nh[i].rec_off + L.total / 16u > heap_used) { VBAD("[validate] t=%d node=%u record beyond heap_top %u (gc=%u)\n", t, i, H.heap_top, H.gc_runs); continue; }
+            const int cap_nv = (int)nh[i].nv * D.cls_q;                      // NodeHdr.nv = size class = pages of cls_q entries
+            if (nh[i].rec_off + (AZG_REC_HDR + (uint32_t)nh[i].nv * RG.PAGE) / 16u > heap_used) { VBAD("[validate] t=%d node=%u record beyond heap_top %u (gc=%u)\n", t, i, H.heap_top, H.gc_runs); continue; }
             const uint8_t* rec = hp.data() + (size_t)nh[i].rec_off * 16;
             const RecHdr* rh = (const RecHdr*)rec;
             if (rh->node_id != i || (int)rh->nv > cap_nv || rh->round != nh[i].round)
                 VBAD("[validate] t=%d node=%u header mismatch (rec node_id=%u nv=%u)\n", t, i, rh->node_id, rh->nv);
             if (!(rh->flags & NF_EXPANDED)) continue;
-            const RecIds ids(rec, f->dev.U);
+            const RecIds ids(rec, RG);
             for (int j = 0; j < rh->nv; j++) {
-                const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
                 for (int u = 0; u < D.U; u++) {
-                    const uint32_t c = *(const uint32_t*)(ent + AZG_E_C + 4 * u);
+                    const uint32_t c = *(const uint32_t*)(rec + RG.child((uint32_t)j, (uint32_t)u));
                     if (c == AZG_NONE) continue;
                     const uint32_t cr = c & AZG_CHILD_IDX_MASK;
                     if (cr >= heap_used) { VBAD("[validate] t=%d node=%u child[%d][%d]=%08x beyond heap\n", t, i, j, u, c); continue; }
@@ -660,6 +659,17 @@ extern "C" int azg_selfplay_drain_examples(azg_forest* f, int max_records, int8_
 }
 
 // ---- measurement ----------------------------------------------------------------------------------------------------
+// Change the search size / playout-cap probability of a forest between launches (MCTS.py:58-59 reads args.numMCTSSims and
+// args.prob_fullMCTS at every getActionProb call, so the reference's args may change between moves as well).  Both are kernel
+// arguments: HIP graphs that captured this forest's launches must be captured again.  Searches in flight keep their n_sims.
+extern "C" int azg_forest_set_search_params(azg_forest* f, int numMCTSSims, double prob_fullMCTS) {
+    if (!f) return fail("null forest");
+    if (numMCTSSims <= 0 || !(prob_fullMCTS >= 0.0 && prob_fullMCTS <= 1.0)) return fail("azg_forest_set_search_params: bad argument");
+    f->dev.numMCTSSims = numMCTSSims;
+    f->dev.prob_fullMCTS = prob_fullMCTS;
+    return 0;
+}
+
 extern "C" int azg_forest_enable_timing(azg_forest* f, int enable) {
     if (!f) return fail("null forest");
     if (enable) {

@@ -8,10 +8,13 @@
 // visibility protocol are needed inside a launch):
 //   record heap          bytes    one contiguous, 16-B aligned RECORD per node -- everything a descent level touches:
 //                                   RecHdr 32 B  { Ns u32, Qs f32, node id, n_valid, flags, round, Es f32[4] }
-//                                   entry[nv]    VALID-ACTION-COMPACTED, fixed stride ES = 18 + 4U (rounded to 8):
-//                                                { P f32, N u32, Q f64, child u32[U], action id u16 }
+//                                   pages of PC = cls_q VALID-ACTION-COMPACTED entries, struct-of-arrays inside a page:
+//                                     hot[PC]      16 B  { P f32, N u32, Q f64 }   -- all a PUCT evaluation reads
+//                                     child[U][PC]  4 B  child slot per universe   -- a level reads only the current universe's
+//                                     id[PC]        2 B  action id                  -- read when an edge is resolved
 //                                 entry j of a record sits at a position that does not depend on n_valid, so a wave
-//                                 requests the header and every lane's entry in ONE round trip per level
+//                                 requests the header, every lane's hot part and child slot in ONE round trip per level:
+//                                 20 bytes per lane in two dense runs (16 + 4) instead of a 32-byte array-of-structs entry
 //   NodeHdr[cap]         16 B     cold: 64-bit state hash, record offset, n_valid, round, flags (probe / GC / dumps)
 //   state[cap][SP]       int8     the node's canonical state = the dict KEY of the reference (full-key verified)
 //   htab[HT]             u32      open-addressing table: (10-bit tag | 22-bit node id), probed 64 slots per wave load
@@ -177,26 +180,28 @@ __device__ __constant__ long long AZG_MAGIC_SEEDS[8] = {31416, 1, 14142, 42, 271
 
 __host__ __device__ __forceinline__ uint32_t align16u(uint32_t x) { return (x + 15u) & ~15u; }
 
-// record geometry: RecHdr | entry[nv] (stride ES); entry = { P f32, N u32, Q f64, child u32[U], action id u16 }
+// record geometry: RecHdr | page[pages(nv)], page = hot[PC] (16 B: P f32, N u32, Q f64) | child[U][PC] (u32) | id[PC] (u16),
+// PC = cls_q entries per page (one-class forests: PC = A, a single page)
 #define AZG_REC_HDR 32u
-__host__ __device__ __forceinline__ uint32_t entry_stride(int U) { return (18u + 4u * (uint32_t)U + 7u) & ~7u; }
-struct RecLayout {
-    uint32_t ES, total;   // bytes
-    __host__ __device__ RecLayout(int nv, int U) {
-        ES = entry_stride(U);
-        total = AZG_REC_HDR + align16u((uint32_t)nv * ES);
-    }
+#define AZG_CLS_Q_MULTI 32      /* entries per page / size class of multi-class forests (one-class forests: A) */
+#define AZG_H_P 0u
+#define AZG_H_N 4u
+#define AZG_H_Q 8u
+struct RecGeom {
+    uint32_t PC, U, PAGE;                 // entries per page, universes, bytes per page
+    __host__ __device__ RecGeom(int pc, int u) : PC((uint32_t)pc), U((uint32_t)u), PAGE(align16u((uint32_t)pc * (18u + 4u * (uint32_t)u))) {}
+    __host__ __device__ __forceinline__ uint32_t pages(int nv) const { return nv == 0 ? 0u : 1u + ((uint32_t)nv - 1u) / PC; }
+    __host__ __device__ __forceinline__ uint32_t total(int nv) const { return AZG_REC_HDR + pages(nv) * PAGE; }      // bytes
+    __host__ __device__ __forceinline__ uint32_t page_of(uint32_t j) const { return AZG_REC_HDR + (j / PC) * PAGE; }
+    __host__ __device__ __forceinline__ uint32_t hot(uint32_t j) const { return page_of(j) + (j % PC) * 16u; }
+    __host__ __device__ __forceinline__ uint32_t child(uint32_t j, uint32_t u) const { return page_of(j) + PC * (16u + 4u * u) + (j % PC) * 4u; }
+    __host__ __device__ __forceinline__ uint32_t id(uint32_t j) const { return page_of(j) + PC * (16u + 4u * U) + (j % PC) * 2u; }
 };
-#define AZG_E_P 0u
-#define AZG_E_N 4u
-#define AZG_E_Q 8u
-#define AZG_E_C 16u
-#define AZG_E_ID(U) (16u + 4u * (uint32_t)(U))
 // read-only view of a record's action ids (ids[j] = action of valid-action-compacted entry j)
 struct RecIds {
-    const uint8_t* base; uint32_t ES;
-    __host__ __device__ RecIds(const uint8_t* rec, int U) : base(rec + AZG_REC_HDR + AZG_E_ID(U)), ES(entry_stride(U)) {}
-    __host__ __device__ __forceinline__ uint16_t operator[](int j) const { return *(const uint16_t*)(base + (size_t)j * ES); }
+    const uint8_t* rec; RecGeom G;
+    __host__ __device__ RecIds(const uint8_t* r, const RecGeom& g) : rec(r), G(g) {}
+    __host__ __device__ __forceinline__ uint16_t operator[](int j) const { return *(const uint16_t*)(rec + G.id((uint32_t)j)); }
 };
 
 // NumPy's pairwise float32 summation order (np.sum called by `normalise`, MCTS.py:250-253) for n <= 128 elements,
@@ -410,9 +415,9 @@ struct Forest {
 
     // ---- record size classes ----
     __device__ static __forceinline__ int cls_of(const ForestDev& F, int nv) { return nv == 0 ? 0 : 1 + (nv - 1) / F.cls_q; }
-    __device__ static __forceinline__ uint32_t cls_units(const ForestDev& F, int c) {
-        const int cap_nv = c * F.cls_q < A ? c * F.cls_q : A;
-        return RecLayout(cap_nv, F.U).total / 16u;
+    __device__ static __forceinline__ RecGeom geom(const ForestDev& F) { return RecGeom(F.cls_q, F.U); }
+    __device__ static __forceinline__ uint32_t cls_units(const ForestDev& F, int c) {      // class c = c pages
+        return (AZG_REC_HDR + (uint32_t)c * geom(F).PAGE) / 16u;
     }
     __device__ static __forceinline__ int n_classes(const ForestDev& F) { return 2 + (A - 1) / F.cls_q; }
 
@@ -462,7 +467,7 @@ struct Forest {
             return head;
         }
         const uint32_t units = cls_units(F, c);
-        // 256 units (4 KB) of slack: a level's speculative entry loads may reach 64 entries past a short record
+        // 256 units (4 KB) of slack: a level's speculative loads may reach two pages past the header of a short record
         if (H.heap_top + units + 256u > F.heap_units) { H.err |= ERR_HEAP_OVERFLOW; return AZG_NONE; }
         const uint32_t off = H.heap_top;
         H.heap_top += units;
@@ -479,7 +484,7 @@ struct Forest {
             tot = (last.pre + last.np) % P;
         }
         uint8_t* hp = heap(F, t);
-        const uint32_t ES = entry_stride(F.U);
+        const RecGeom RG = geom(F);
         for (int base = 0; base < depth; base += 64) {
             int d = base + lane_id();
             if (d < depth) {
@@ -498,15 +503,15 @@ struct Forest {
                 }
                 uint8_t* rec = hp + (size_t)e.rec * 16u;
                 RecHdr* rh = (RecHdr*)rec;
-                uint8_t* ent = rec + AZG_REC_HDR + (size_t)e.j * ES;
-                uint32_t n = *(uint32_t*)(ent + AZG_E_N);
-                double q = *(double*)(ent + AZG_E_Q);
-                *(double*)(ent + AZG_E_Q) = ((double)n * q + (double)v0) / (double)(n + 1u);
+                uint8_t* ent = rec + RG.hot(e.j);
+                uint32_t n = *(uint32_t*)(ent + AZG_H_N);
+                double q = *(double*)(ent + AZG_H_Q);
+                *(double*)(ent + AZG_H_Q) = ((double)n * q + (double)v0) / (double)(n + 1u);
                 uint32_t ns = rh->Ns;
                 float tq = (float)(ns + 1u) * rh->Qs;
                 tq = tq + v0;
                 rh->Qs = tq / (float)(ns + 2u);
-                *(uint32_t*)(ent + AZG_E_N) = n + 1u;
+                *(uint32_t*)(ent + AZG_H_N) = n + 1u;
                 rh->Ns = ns + 1u;
                 rh->sq[0] = sqrt((double)(ns + 1u));
                 rh->sq[1] = sqrt((double)(ns + 1u) + AZG_EPS);

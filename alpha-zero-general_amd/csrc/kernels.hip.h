@@ -224,19 +224,19 @@ __device__ __forceinline__ bool root_noise_tree(const ForestDev& F, int t, uint3
     if (!(rh.flags & NF_EXPANDED)) return false;
     const int nv = rh.nv;
 
-    const RecLayout L(nv, F.U);
-    const RecIds ids(rec, F.U);
+    const RecGeom RG = FR::geom(F);
+    const RecIds ids(rec, RG);
     for (int i = l; i < G::A; i += 64) dense[i] = 0.f;
     if (l < G::AW) mask[l] = 0ull;
     wave_sync();
-    for (int j = l; j < nv; j += 64) dense[ids[j]] = *(const float*)(rec + AZG_REC_HDR + (size_t)j * L.ES + AZG_E_P);
+    for (int j = l; j < nv; j += 64) dense[ids[j]] = *(const float*)(rec + RG.hot((uint32_t)j) + AZG_H_P);
     if (l == 0)
         for (int j = 0; j < nv; j++) mask[ids[j] >> 6] |= 1ull << (ids[j] & 63);
     wave_sync();
     const double* nz = root_noise ? root_noise + (size_t)t * (noise_stride < 0 ? -noise_stride : noise_stride) : nullptr;
     FR::root_noise_dense(dense, mask, F.temp_root, nz, root_noise != nullptr && noise_stride < 0, F.dirichletAlpha,
                          mix64(mix64(forest_seed(F) ^ 0xA5A5A5A55A5A5A5AULL) + F.stream0 + (uint64_t)t), c_sims << 20);
-    for (int j = l; j < nv; j += 64) *(float*)(rec + AZG_REC_HDR + (size_t)j * L.ES + AZG_E_P) = dense[ids[j]];
+    for (int j = l; j < nv; j += 64) *(float*)(rec + RG.hot((uint32_t)j) + AZG_H_P) = dense[ids[j]];
     return true;
 }
 
@@ -280,7 +280,6 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
         for (int k = 0; k < G::AW; k++) nv += __popcll(sm.mask[k]);
     }
     H.leaf_nv = (uint32_t)nv; H.leaf_node = id;
-    const RecLayout L(nv, F.U);
     int alloc_cls = 0;
     const uint32_t rec_off = FR::alloc_record(F, t, H, nv, id, &alloc_cls, pf);
     if (rec_off == AZG_NONE) return AZG_NONE;
@@ -446,7 +445,7 @@ __device__ __forceinline__ bool expand_apply(const ForestDev& F, int t, const Ex
     const uint32_t sim = uni_u32(in.sim_idx);
     uint8_t* rec = FR::rec_ptr(F, t, uni_u32(in.pending_leaf));
     RecHdr* rhp = (RecHdr*)rec;
-    const RecLayout L(nv, F.U);
+    const RecGeom RG = FR::geom(F);
     const PathEnt* gp = F.path + (size_t)t * AZG_MAXD;
     path[l] = in.pe0;
     for (int d = l + 64; d < depth; d += 64) path[d] = gp[d];
@@ -465,18 +464,13 @@ __device__ __forceinline__ bool expand_apply(const ForestDev& F, int t, const Ex
     for (int k = 0; k < NA; k++) {                                                               // :40-41,150-152
         const uint64_t m = __ballot(in.va[k] != 0);
         if (in.va[k]) {
-            const int j = base_rank + __popcll(m & ((1ull << l) - 1ull));
-            uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
+            const uint32_t j = (uint32_t)(base_rank + __popcll(m & ((1ull << l) - 1ull)));
             uint4 e0;
             e0.x = __float_as_uint(dir_now ? in.pv[k] : in.pv[k] / s); e0.y = 0u;                 // P, N = 0
             e0.z = (uint32_t)__double_as_longlong(AZG_NANQ); e0.w = (uint32_t)((uint64_t)__double_as_longlong(AZG_NANQ) >> 32);
-            *(uint4*)(ent + AZG_E_P) = e0;
-            const uint32_t aid = (uint32_t)(l + 64 * k);                                          // the entry's action id
-            if (F.U == 3) *(uint4*)(ent + AZG_E_C) = make_uint4(AZG_NONE, AZG_NONE, AZG_NONE, aid);   // child[3], id + pad
-            else {
-                for (int u = 0; u < F.U; u++) *(uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)u) = AZG_NONE;
-                *(uint16_t*)(ent + AZG_E_ID(F.U)) = (uint16_t)aid;
-            }
+            *(uint4*)(rec + RG.hot(j)) = e0;
+            for (int u = 0; u < F.U; u++) *(uint32_t*)(rec + RG.child(j, (uint32_t)u)) = AZG_NONE;
+            *(uint16_t*)(rec + RG.id(j)) = (uint16_t)(l + 64 * k);                                // the entry's action id
         }
         base_rank += __popcll(m);
     }
@@ -586,7 +580,19 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     H.status = ST_SEARCHING; H.pending_leaf = AZG_NONE; H.path_len = 0; H.cyc_leaf = 0; H.leaf_nv = 0; H.leaf_node = 0;
     H.cyc_seg[0] = H.cyc_seg[1] = H.cyc_seg[2] = H.cyc_seg[3] = 0;
     uint8_t* hp = FR::heap(F, t);
-    const uint32_t ES = entry_stride(F.U);
+    // this lane's byte offsets inside a record (entry l of the first 64): constant over the launch.  One-class forests have a single
+    // page of A entries, the others pages of AZG_CLS_Q_MULTI = 32 entries (forest.hip.h RecGeom)
+    const RecGeom RG = FR::geom(F);
+    const bool one_page = F.cls_q == G::A;
+    auto hot_off = [&](uint32_t j) { return one_page ? AZG_REC_HDR + j * 16u : AZG_REC_HDR + (j >> 5) * RG.PAGE + (j & 31u) * 16u; };
+    auto child_off = [&](uint32_t j, uint32_t u) {
+        return one_page ? AZG_REC_HDR + RG.PC * (16u + 4u * u) + j * 4u : AZG_REC_HDR + (j >> 5) * RG.PAGE + 32u * (16u + 4u * u) + (j & 31u) * 4u;
+    };
+    auto id_off = [&](uint32_t j) {
+        return one_page ? AZG_REC_HDR + RG.PC * (16u + 4u * RG.U) + j * 2u : AZG_REC_HDR + (j >> 5) * RG.PAGE + 32u * (16u + 4u * RG.U) + (j & 31u) * 2u;
+    };
+    const uint32_t l_hot = hot_off((uint32_t)l), l_child0 = child_off((uint32_t)l, 0u), l_id = id_off((uint32_t)l);
+    const uint32_t child_ustride = (one_page ? RG.PC : 32u) * 4u;
     const bool spec_state = F.cls_q == G::A && FR::SPW <= 192;
     const float inv_units1 = 1.0f / (float)FR::cls_units(F, 1);
     bool need_nn = false;
@@ -652,11 +658,11 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             const long long t_lvl = AZG_CLK();
             // ---- one level: header + this lane's entry requested together (entry position is independent of nv) ----
             const uint8_t* rp = hp + (size_t)rec * 16u;
-            const uint8_t* ent = rp + AZG_REC_HDR + (size_t)l * ES;
-            const uint2 pn = *(const uint2*)(ent + AZG_E_P);
-            const double q0 = *(const double*)(ent + AZG_E_Q);
-            const uint32_t ch0 = *(const uint32_t*)(ent + AZG_E_C + 4u * (uint32_t)uidx);
-            const uint32_t id0 = *(const uint16_t*)(ent + AZG_E_ID(F.U));
+            const uint4 hot0 = *(const uint4*)(rp + l_hot);                                     // { P, N, Q } of entry l
+            const uint32_t ch0 = *(const uint32_t*)(rp + l_child0 + child_ustride * (uint32_t)uidx);
+            const uint32_t id0 = *(const uint16_t*)(rp + l_id);
+            const uint2 pn = make_uint2(hot0.x, hot0.y);
+            const double q0 = __longlong_as_double((long long)(((uint64_t)hot0.w << 32) | hot0.z));
             // one-class forests: record slot == node id, so the node's state is addressable before its header arrives --
             // fetch it with the entries (this level is the frontier of ~20 % of the descents; saves that round trip)
             uint32_t ps0 = 0, ps1 = 0, ps2 = 0;
@@ -698,12 +704,13 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     if (base > 0) {
                         const int jj = base + l;
                         a_ok = jj < nv;
-                        const uint8_t* e2 = rp + AZG_REC_HDR + (size_t)(a_ok ? jj : 0) * ES;
-                        p = *(const float*)(e2 + AZG_E_P);
-                        n = *(const uint32_t*)(e2 + AZG_E_N);
-                        q = *(const double*)(e2 + AZG_E_Q);
-                        chv = *(const uint32_t*)(e2 + AZG_E_C + 4u * (uint32_t)uidx);
-                        idv = *(const uint16_t*)(e2 + AZG_E_ID(F.U));
+                        const uint32_t j2 = (uint32_t)(a_ok ? jj : 0);
+                        const uint4 h2 = *(const uint4*)(rp + hot_off(j2));
+                        p = __uint_as_float(h2.x);
+                        n = h2.y;
+                        q = __longlong_as_double((long long)(((uint64_t)h2.w << 32) | h2.z));
+                        chv = *(const uint32_t*)(rp + child_off(j2, (uint32_t)uidx));
+                        idv = *(const uint16_t*)(rp + id_off(j2));
                     }
                     if (forced) {                                                 // :218-220 first deficient action wins
                         const double thr = sqrt(0.5 * (double)p * (double)H.sim_idx);
@@ -769,8 +776,8 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 // (state, action) is a random variable, so the slot stays empty and every visit replays the step
                 if (G::STOCHASTIC) {
                 } else if (G::move_uses_seed(a)) {
-                    if (l == 0) *(uint32_t*)((uint8_t*)rp + AZG_REC_HDR + (size_t)j * ES + AZG_E_C + 4u * (uint32_t)uidx) = child;
-                } else if (l < F.U) *(uint32_t*)((uint8_t*)rp + AZG_REC_HDR + (size_t)j * ES + AZG_E_C + 4u * (uint32_t)l) = child;
+                    if (l == 0) *(uint32_t*)((uint8_t*)rp + child_off((uint32_t)j, (uint32_t)uidx)) = child;
+                } else if (l < F.U) *(uint32_t*)((uint8_t*)rp + child_off((uint32_t)j, (uint32_t)l)) = child;
                 have_leaf = is_new;
             }
             const int np = (int)(child >> AZG_CHILD_NP_SHIFT);
@@ -845,20 +852,20 @@ __device__ bool root_counts(const ForestDev& F, int t, const TreeHdr& H, int* cn
 #pragma unroll
     for (int p = 0; p < G::P; p++) q[p] = p == 0 ? q0 : -q0 / (float)(G::P - 1);
     if (!(rh.flags & NF_EXPANDED)) return false;
-    const RecLayout L(rh.nv, F.U);
-    const RecIds ids(rec, F.U);
+    const RecGeom RG = FR::geom(F);
+    const RecIds ids(rec, RG);
     int best = 0;
     for (int j = l; j < rh.nv; j += 64) {
-        int n = (int)*(const uint32_t*)(rec + AZG_REC_HDR + (size_t)j * L.ES + AZG_E_N);
+        int n = (int)*(const uint32_t*)(rec + RG.hot((uint32_t)j) + AZG_H_N);
         best = n > best ? n : best;
     }
     best = wave_max_i32(best);
     for (int j = l; j < rh.nv; j += 64) {
-        const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
-        int c = (int)*(const uint32_t*)(ent + AZG_E_N);
+        const uint8_t* ent = rec + RG.hot((uint32_t)j);
+        int c = (int)*(const uint32_t*)(ent + AZG_H_N);
         if (H.forced) {                                                                          // :75-80
             if (c != best) {
-                float tq = (0.5f * *(const float*)(ent + AZG_E_P)) * (float)H.n_sims;   // plain-Python NumPy scalar typing
+                float tq = (0.5f * *(const float*)(ent + AZG_H_P)) * (float)H.n_sims;   // plain-Python NumPy scalar typing
                 c = c - (int)sqrt((double)tq);
             }
             c = c > 1 ? c : 0;
@@ -930,14 +937,14 @@ __global__ __launch_bounds__(64) void k_root_stats(ForestDev F, int32_t* Ns, flo
     if (l == 0) { if (Ns) Ns[t] = (int32_t)rh.Ns; if (Qs) Qs[t] = rh.Qs; }
     if (!(rh.flags & NF_EXPANDED)) return;
     __syncthreads();
-    const RecLayout L(rh.nv, F.U);
-    const RecIds ids(rec, F.U);
+    const RecGeom RG = FR::geom(F);
+    const RecIds ids(rec, RG);
     for (int j = l; j < rh.nv; j += 64) {
-        const uint8_t* ent = rec + AZG_REC_HDR + (size_t)j * L.ES;
+        const uint8_t* ent = rec + RG.hot((uint32_t)j);
         const int a = ids[j];
-        if (Nsa) Nsa[(size_t)t * G::A + a] = (int32_t)*(const uint32_t*)(ent + AZG_E_N);
-        if (Qsa) Qsa[(size_t)t * G::A + a] = *(const double*)(ent + AZG_E_Q);
-        if (Ps) Ps[(size_t)t * G::A + a] = *(const float*)(ent + AZG_E_P);
+        if (Nsa) Nsa[(size_t)t * G::A + a] = (int32_t)*(const uint32_t*)(ent + AZG_H_N);
+        if (Qsa) Qsa[(size_t)t * G::A + a] = *(const double*)(ent + AZG_H_Q);
+        if (Ps) Ps[(size_t)t * G::A + a] = *(const float*)(ent + AZG_H_P);
     }
 }
 

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) void k_selfplay_advance(ForestDev F) {
                 const uint8_t* rrec = FR::rec_ptr(F, t, H.root_rec);
                 const RecHdr rh = load_uniform((const RecHdr*)rrec);
                 if (rh.flags & NF_EXPANDED) {
-                    const RecIds ids(rrec, F.U);
+                    const RecIds ids(rrec, FR::geom(F));
                     for (int j = l; j < rh.nv; j += 64) F.rec_valid[r * G::A + ids[j]] = 1;
                 }
             }

@@ -199,6 +199,11 @@ class Forest:
         n = n.value
         return boards[:n], pi[:n], z[:n], valids[:n], q[:n], meta[:n]
 
+    def set_search_params(self, numMCTSSims, prob_fullMCTS):
+        """args.numMCTSSims / args.prob_fullMCTS for the searches that begin from now on (the reference reads both at every
+        getActionProb call, MCTS.py:58-59); captured HIP graphs of this forest are stale afterwards"""
+        check(lib().azg_forest_set_search_params(self.h, int(numMCTSSims), float(prob_fullMCTS)))
+
     def enable_timing(self, on=True):
         check(lib().azg_forest_enable_timing(self.h, int(on)))
 

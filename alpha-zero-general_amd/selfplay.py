@@ -87,13 +87,13 @@ class SelfPlayEngine:
         replay the same games); episode_quota = numEps of Coach.executeEpisodes: exactly that many games are played, each to
         its end (0 = trees restart forever; the caller decides when to stop)"""
         Tg = self.T // self.G
+        if episode_quota and episode_quota < self.G:
+            # a group without episodes cannot be expressed to the forest (its quota 0 means "restart forever"): refuse before
+            # anything is launched
+            raise ValueError('episode_quota %d is smaller than the number of groups %d' % (episode_quota, self.G))
         for g, grp in enumerate(self.groups):
             q = episode_quota // self.G + (1 if g < episode_quota % self.G else 0)
-            if episode_quota and q == 0:
-                q = -1                       # this group plays nothing (handled below)
-            grp.f.selfplay_start(None if init_boards is None else init_boards[g * Tg:(g + 1) * Tg], epoch=epoch,
-                                 episode_quota=max(q, 0) if q >= 0 else 0)
-            assert q >= 0, 'episode_quota smaller than the number of groups'
+            grp.f.selfplay_start(None if init_boards is None else init_boards[g * Tg:(g + 1) * Tg], epoch=epoch, episode_quota=q)
         if (epoch, episode_quota) != getattr(self, '_epoch_quota', (0, 0)):
             self.graph = None                # seed and quota are kernel arguments: the captured rounds are stale
         self._epoch_quota = (epoch, episode_quota)
@@ -103,6 +103,13 @@ class SelfPlayEngine:
             if g % 2 == 1:
                 grp.select()
         torch.cuda.synchronize()
+
+    def set_search_params(self, numMCTSSims, prob_fullMCTS):
+        """args.numMCTSSims / args.prob_fullMCTS for the searches that begin from now on (MCTS.py:58-59 reads them per move);
+        the captured rounds are stale afterwards"""
+        for grp in self.groups:
+            grp.f.set_search_params(numMCTSSims, prob_fullMCTS)
+        self.graph = None
 
     def _round(self, advance=True):
         """one round of every group; group g's stage order is rotated by g (software-pipeline skew)"""
@@ -203,7 +210,10 @@ def gather_examples(tensors, group=None):
     ROCm): all_gather the counts, pad to the maximum, all_gather the padded blocks, trim.  With games sharded
     embarrassingly this is the ONLY collective on the path."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensors
+    if dist.get_world_size(group) == 1 and not os.environ.get('AZG_FORCE_DIST'):     # AZG_FORCE_DIST: run the collectives at world 1 too
         return tensors
     world = dist.get_world_size(group)
     n = torch.tensor([tensors[0].shape[0]], dtype=torch.int64, device=tensors[0].device)

@@ -53,6 +53,13 @@ OTHER_GAMES = {
                  weights='weights_azul_v84.npz', net='AzulV84', label='Azul 2p, V84 net'),
 }
 HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK_TFLOPS = {'f16': 2500.0, 'bf16': 2500.0, 'f32': 157.3}      # dense, same guide
+# algorithmic FLOPs of one leaf evaluation = 2 x MACs of the reference module
+NET_MFLOP_PER_LEAF = {'splendor2': 1.042, 'azul': 0.408, 'santorini1': 18.52, 'santorini11': 13.8}
+# how far the games are moved away from the opening before the warm-up (plies played with the reference's own FAST searches,
+# numMCTSSims // ratio_fullMCTS simulations, MCTS.py:58-59), so that games END inside a short timed window and the episode-end
+# example gather carries data; about 3/4 of a typical game
+PREROLL_PLIES = {'splendor2': 40, 'splendor4': 70, 'santorini1': 14, 'santorini11': 16, 'azul': 50}
 
 
 def algorithmic_bytes_per_sim(S, A, P, d, vbar, e):
@@ -61,18 +68,25 @@ def algorithmic_bytes_per_sim(S, A, P, d, vbar, e):
     return d * (mask + 12.0 * vbar + 8 + S + 16) + e * (S + mask + 12.0 * vbar + 8 + 4 * A + 4 * P)
 
 
-def cpu_baseline(sims, seconds=12.0, n_par=8):
-    """The oracle (C restatement of MCTS.py + SplendorLogicNumba, pinned against the reference) with the PyTorch-CPU net,
+CPU_GAMES = {   # game key -> (oracle game id name, variant, torch-CPU net class, weights, MCTS settings)
+    'splendor2': ('SPLENDOR', 2, 'SplendorV80', 'weights_splendor2_v80.npz', dict(cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True)),
+    'santorini1': ('SANTORINI', 1, 'SantoriniV89', 'weights_santorini1_v89.npz', dict(cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True)),
+}
+
+
+def cpu_baseline(sims, seconds=12.0, n_par=8, game_key='splendor2'):
+    """The oracle (C restatement of MCTS.py + the game's *LogicNumba, pinned against the reference) with the PyTorch-CPU net,
     one host thread, leaves batched over n_par games like --parallel-inferences 8 (Coach.py:117-144)."""
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import azg_oracle as O
-    from azg_amd.nnet import SplendorV80
+    from azg_amd import nnet as _nn
     torch.set_num_threads(1)
-    og = O.OracleGame(O.SPLENDOR, 2)
-    net = SplendorV80.from_npz(WEIGHTS, device='cpu') if os.path.exists(WEIGHTS) else SplendorV80.random_init(device='cpu')
-    kw = dict(cpuct=0.8, fpu=0.0593, universes=3, forced_playouts=True)
+    gid, variant, net_cls, wfile, kw = CPU_GAMES[game_key]
+    og = O.OracleGame(getattr(O, gid), variant)
+    net = getattr(_nn, net_cls).from_npz(os.path.join(ROOT, 'tests', 'golden', wfile), device='cpu')
+    shape = tuple(og.shape)
     trees = [O.OracleMCTS(og, O.make_args(numMCTSSims=sims, **kw)) for _ in range(n_par)]
     boards = [og.getInitBoard(og.rng(seed=99, stream=i)) for i in range(n_par)]
     players = [0] * n_par
@@ -104,23 +118,23 @@ def cpu_baseline(sims, seconds=12.0, n_par=8):
                     lb[i], lv[i] = b, v
                     need.append(i)
                     break
-        pi, vv = net.predict_batch(torch.from_numpy(lb), torch.from_numpy(lv))
+        pi, vv = net.predict_batch(torch.from_numpy(lb).view((n_par,) + shape), torch.from_numpy(lv))
         pi, vv = pi.numpy(), vv.numpy()
         for i in need:
             trees[i].sim_finish(pi[i], vv[i])
     dt = time.perf_counter() - t0
     return dict(value=sims_done / sims / dt, unit='env-steps/sec', cores=1, kind='port',
-                sample='%d concurrent games, %.0f s wall, %d sims (=%d plies completed) of the same Splendor-2p/800-sim '
-                       'workload; C oracle tree+env, PyTorch-CPU V80 net batched over %d leaves, 1 thread'
-                       % (n_par, dt, sims_done, plies, n_par),
+                sample='%d concurrent games, %.0f s wall, %d sims (=%d plies completed) of the same %s/%d-sim '
+                       'workload; C oracle tree+env, PyTorch-CPU %s net batched over %d leaves, 1 thread'
+                       % (n_par, dt, sims_done, plies, game_key, sims, net_cls, n_par),
                 sims_per_sec=sims_done / dt, host_cores_available=os.cpu_count())
 
 
-def cpu_baseline_multi(sims, seconds, procs):
+def cpu_baseline_multi(sims, seconds, procs, game_key='splendor2'):
     """the CPU path on several host cores = `procs` independent single-thread copies of cpu_baseline (one
     process per core, 8 games each, like the reference's one-process-per-core self-play), summed."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', '--sims', str(sims), '--cpu-seconds', str(seconds)]
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', '--sims', str(sims), '--cpu-seconds', str(seconds), '--game', game_key]
     ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
                            env=dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1')) for _ in range(procs)]
     rs = []
@@ -131,7 +145,7 @@ def cpu_baseline_multi(sims, seconds, procs):
         except Exception:
             pass
     if not rs:
-        return cpu_baseline(sims, seconds)
+        return cpu_baseline(sims, seconds, game_key=game_key)
     one = rs[0]
     return dict(value=sum(r['value'] for r in rs), unit='env-steps/sec', cores=len(rs), kind='port',
                 sample='%d processes x (%s)' % (len(rs), one['sample']),
@@ -254,6 +268,38 @@ def measure_roofline(a, eng, T):
                 d_levels_per_sim=d, v_valid_per_level=vbar, e_expansions_per_sim=e)
 
 
+def measure_net(a, eng, T, game_key, net_kind):
+    """the other kernel of a round: one NeuralNet.predict_batch over the T leaves, timed with events on the stream it is launched on
+    (the net kernels go to torch's current stream); achieved = algorithmic FLOPs (2 x MACs of the reference module) / time"""
+    import torch
+    if game_key not in NET_MFLOP_PER_LEAF:
+        return None
+    grp = eng.groups[0]
+    f = grp.f
+    x, m = f.leaf_states.view(grp.shape), f.leaf_valid
+    for _ in range(5):
+        grp.net.predict_batch(x, m)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 50
+    e0.record()
+    for _ in range(n):
+        grp.net.predict_batch(x, m)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    Tg = T // a.groups
+    flops = NET_MFLOP_PER_LEAF[game_key] * 1e6 * Tg
+    h2 = net_kind == 'hip' and getattr(grp.net, 'h2', False)
+    dt = 'f16' if h2 else ('bf16' if net_kind == 'hip' and game_key in ('santorini1', 'santorini11') else 'f32')
+    ach = flops / (ms * 1e-3) / 1e12
+    return dict(bound='mfma', kernel={True: 'k_v80_net_h2'}.get(h2, 'net forward (%s)' % net_kind), achieved=ach,
+                peak=MFMA_PEAK_TFLOPS[dt], unit='TFLOP/s', frac=ach / MFMA_PEAK_TFLOPS[dt], traffic=None,
+                mfma_input_dtype=dt, frac_of_f32_mfma_peak=ach / MFMA_PEAK_TFLOPS['f32'],
+                note='fp32-accurate (<= 1e-5 of the reference outputs): every f32 operand is a hi + lo pair of 16-bit numbers, one '
+                     'algorithmic product = 3 (f16 pair) or 6 (bf16 triple) MFMAs; achieved counts ALGORITHMIC flops only',
+                flops_per_launch=flops, leaves_per_launch=Tg, net_ms=ms, launches=n)
+
+
 def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roofline=True):
     """warm-up ply waves, then exactly `steps` timed ply waves bracketed by barrier + synchronize; -> result dict (rank-reduced)"""
     import torch
@@ -263,6 +309,12 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
     eng.game_key = game_key
     sims = a.sims
     eng.start()
+    preroll = PREROLL_PLIES.get(game_key, 0) if a.preroll_plies < 0 else a.preroll_plies
+    if preroll > 0:
+        fast = max(1, sims // int(margs.get('ratio_fullMCTS', 5)))
+        eng.set_search_params(sims, 0.0)                     # every ply a fast search: no examples, no forced playouts
+        eng.run(preroll * (fast + eng.K))
+        eng.set_search_params(sims, a.prob_full)
     eng.run(warmup * sims)
     torch.cuda.synchronize()
     if use_dist:
@@ -300,8 +352,10 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
                engine_errors=errs, forest_bytes_per_gpu=eng.device_bytes,
                max_live_after_gc=int(s1.get('max_live_after_gc', 0)), max_nodes_per_tree=s1['max_nodes'],
                gc_runs=s1['gc_runs'], hip_graph=eng.graph is not None, rounds_timed=steps * sims,
-               ms_per_round=dt / (steps * sims) * 1e3)
+               ms_per_round=dt / (steps * sims) * 1e3, preroll_plies=preroll, node_capacity=eng.forest.cfg.node_capacity,
+               max_live_frac=int(s1.get('max_live_after_gc', 0)) / max(1, eng.forest.cfg.node_capacity))
     res['roofline'] = measure_roofline(a, eng, T) if roofline and a.roofline_rounds > 0 else None
+    res['roofline_net'] = measure_net(a, eng, T, game_key, net_kind) if roofline and a.roofline_rounds > 0 else None
     del ex
     for grp in eng.groups:
         grp.f.close()
@@ -336,15 +390,22 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--cpu-procs', type=int, default=0,
                     help='cpu_baseline on this many host cores (independent single-thread processes, summed); 0 = min(64, host '
-                         'cores) -- SURVEY.md §8d asks for the host cores, not one')
+                         'cores / 2): one process per physical core -- SURVEY.md §8d asks for the host cores, not one')
     ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--roofline-rounds', type=int, default=300)
-    ap.add_argument('--traffic-json', default=os.path.join(ROOT, 'profiles', 'r02_traffic.json'))
+    ap.add_argument('--traffic-json', default=None, help='PMC traffic summary of an earlier profiled run (default: the newest profiles/r*_traffic.json)')
+    ap.add_argument('--preroll-plies', type=int, default=-1,
+                    help='plies played with fast searches before the warm-up (-1 = per-game default, about 3/4 of a game; 0 = start from '
+                         'the opening): moves the games to where they end inside a short timed window, so the example gather is not empty')
     ap.add_argument('--no-secondary', action='store_true', help='skip the Santorini no-gods leg (north star\'s second target)')
     ap.add_argument('--secondary-steps', type=int, default=0, help='timed ply waves of the secondary leg (0 = max(3, steps // 5))')
     a = ap.parse_args()
+    if a.traffic_json is None:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+        a.traffic_json = cands[-1] if cands else os.path.join(ROOT, 'profiles', 'none.json')
     if a.cpu_worker:
-        print(json.dumps(cpu_baseline(a.sims, a.cpu_seconds)))
+        print(json.dumps(cpu_baseline(a.sims, a.cpu_seconds, game_key=a.game if a.game in CPU_GAMES else 'splendor2')))
         return
     if (a.gpus > 1 or os.environ.get('AZG_BENCH_SPAWN')) and 'WORLD_SIZE' not in os.environ:   # AZG_BENCH_SPAWN: test the self-launch on one GPU
         sys.exit(respawn_ranks(a.gpus))
@@ -367,7 +428,8 @@ def main():
     r = run_workload(a, a.game, T, a.steps, a.warmup, rank, world, dev, use_dist)
     search_mix = ('every ply a full search' if a.prob_full >= 1.0 else
                   'prob_fullMCTS=%g: full searches mixed with numMCTSSims//5 fast ones (reference default mix, secondary figure)' % a.prob_full)
-    net_txt = 'engine MFMA-f32 kernels' if r['net_kind'] == 'hip' else 'PyTorch-ROCm ops'
+    net_txt = ('engine kernel, fp32-accurate: f16 hi+lo split-precision MFMA on token-major tiles' if r['net_kind'] == 'hip' and a.game == 'splendor2'
+               else 'engine MFMA kernels, fp32-accurate' if r['net_kind'] == 'hip' else 'PyTorch-ROCm ops')
     workload = ('Splendor 2p, numMCTSSims=%d, %d concurrent self-play games per GPU, V80 net %s (%s), args of pretrained_2players.pt '
                 '(cpuct 0.8 fpu 0.0593 universes 3 forced playouts dirichlet 0.3), %s' % (a.sims, T, a.net_dtype, net_txt, search_mix)
                 if a.game == 'splendor2' else
@@ -382,10 +444,16 @@ def main():
                            hip_graph=r['hip_graph']),
                groups=a.groups)
     for k in ('value_from_sims', 'sims_per_sec', 'plies_completed', 'games_finished', 'examples_gathered', 'examples_dropped',
-              'engine_errors', 'forest_bytes_per_gpu', 'max_live_after_gc', 'max_nodes_per_tree', 'gc_runs', 'rounds_timed', 'ms_per_round'):
+              'engine_errors', 'forest_bytes_per_gpu', 'node_capacity', 'max_live_after_gc', 'max_live_frac', 'max_nodes_per_tree', 'gc_runs',
+              'rounds_timed', 'ms_per_round', 'preroll_plies'):
         out[k] = r[k]
+    out['config']['preroll'] = ('%d plies of fast searches (numMCTSSims // ratio_fullMCTS, MCTS.py:58-59) before the warm-up, untimed: games end '
+                                'inside the timed window (max_nodes_per_tree hugs node_capacity by design -- the clean-up is lazy; '
+                                'max_live_frac = nodes surviving a clean-up / node_capacity is the headroom figure)' % r['preroll_plies'])
     if r['roofline']:
         out['roofline'] = r['roofline']
+    if r.get('roofline_net'):
+        out['roofline_net'] = r['roofline_net']
     if use_dist:
         dist.barrier()
     # ---- secondary: the north star's second target (Santorini no-gods), same engine, shorter window, own roofline ----
@@ -400,12 +468,19 @@ def main():
                                                          % (r2['label'], 'engine MFMA-f32 kernel' if r2['net_kind'] == 'hip' else 'PyTorch-ROCm ops', a.sims, T)),
                                     value_from_sims=r2['value_from_sims'], plies_completed=r2['plies_completed'],
                                     games_finished=r2['games_finished'], engine_errors=r2['engine_errors'],
-                                    ms_per_round=r2['ms_per_round'], roofline=r2['roofline'])
+                                    ms_per_round=r2['ms_per_round'], roofline=r2['roofline'], roofline_net=r2.get('roofline_net'),
+                                    examples_gathered=r2['examples_gathered'], preroll_plies=r2['preroll_plies'])
         except Exception as ex:                       # the headline line must still be printed
             out['secondary'] = dict(error=repr(ex))
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.game == 'splendor2':
-        procs = a.cpu_procs or min(64, os.cpu_count() or 1)
-        out['cpu_baseline'] = cpu_baseline_multi(a.sims, a.cpu_seconds, procs) if procs > 1 else cpu_baseline(a.sims, a.cpu_seconds)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.game in CPU_GAMES:
+        # one single-thread process per PHYSICAL core (the SMT siblings share the core's units; 64 processes measured 6.4
+        # env-steps/s each)
+        procs = a.cpu_procs or max(1, min(128, (os.cpu_count() or 2) // 2))
+        out['cpu_baseline'] = (cpu_baseline_multi(a.sims, a.cpu_seconds, procs, a.game) if procs > 1
+                               else cpu_baseline(a.sims, a.cpu_seconds, game_key=a.game))
+        if a.game == 'splendor2' and isinstance(out.get('secondary'), dict) and 'value' in out['secondary']:
+            out['secondary']['cpu_baseline'] = (cpu_baseline_multi(a.sims, a.cpu_seconds, procs, 'santorini1') if procs > 1
+                                                else cpu_baseline(a.sims, a.cpu_seconds, game_key='santorini1'))
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

@@ -333,6 +333,10 @@ int azg_nn_heads_out(const float* logits_dev, int ldl, const uint8_t* valid_dev,
    (state is mutated like normal rounds); returns average milliseconds per launch. */
 int azg_forest_last_kernel_ms(azg_forest* f, int which, double* avg_ms, uint64_t* launches);
 int azg_forest_enable_timing(azg_forest* f, int enable);
+/* args.numMCTSSims / args.prob_fullMCTS for the searches that BEGIN after this call (MCTS.py:58-59 reads both at every
+   getActionProb call); searches in flight keep their size.  Both are kernel arguments: HIP graphs that captured this forest's
+   launches must be captured again (SelfPlayEngine.set_search_params does). */
+int azg_forest_set_search_params(azg_forest* f, int numMCTSSims, double prob_fullMCTS);
 
 #ifdef __cplusplus
 }
