@@ -86,7 +86,8 @@ def lib():
     L.azg_selfplay_drain_examples.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, ip, vp]
     L.azg_forest_last_kernel_ms.argtypes = [vp, i, C.POINTER(dbl), C.POINTER(u64)]
     L.azg_forest_enable_timing.argtypes = [vp, i]
-    L.azg_forest_set_search_params.argtypes = [vp, i, dbl]
+    if hasattr(L, 'azg_forest_set_search_params'):          # (absent from older builds loaded through AZG_LIB for A/B runs)
+        L.azg_forest_set_search_params.argtypes = [vp, i, dbl]
     L.azg_nn_linear.argtypes = [vp, i, vp, i, i, vp, vp, i, vp, i, vp, i, i, i, i, i, i, vp]
     L.azg_nn_linear_ws.argtypes = [vp, i, vp, i, i, vp, vp, i, vp, i, vp, i, i, i, i, i, vp]
     L.azg_nn_v80_block.argtypes = [vp, vp, vp, i, i, i, vp]

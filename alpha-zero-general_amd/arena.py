@@ -17,13 +17,16 @@ from .mcts import BatchedMCTS
 
 
 class BatchedArena:
-    def __init__(self, game, nnet1, nnet2, args1, args2=None, n_parallel=64, node_capacity=None, stream0=0, temp_for_game=None):
+    def __init__(self, game, nnet1, nnet2, args1, args2=None, n_parallel=64, node_capacity=None, stream0=0, temp_for_game=None,
+                 first_game_index=0):
         """temp_for_game(turn) -> temperature of getActionProb at that turn (Coach.temp_for_game, Coach.py:273-276, or pit.py's
-        variant); None = 1 at every turn (plain argmax of the visit counts)"""
+        variant); None = 1 at every turn (plain argmax of the visit counts).  first_game_index: index of the game tree 0 plays when
+        a match is dealt out over several ranks -- the trees' own random streams (ties at temperature <= 0.02) follow the game index"""
         self.game, self.T, self.stream0 = game, n_parallel, stream0
         self.temp_for_game = temp_for_game
-        self.mcts = [BatchedMCTS(game, nnet1, args1, n_parallel, node_capacity=node_capacity),
-                     BatchedMCTS(game, nnet2, args2 if args2 is not None else args1, n_parallel, node_capacity=node_capacity)]
+        kw = [dict(rng_seed=int(getattr(game, 'rng_seed', 0)), stream0=stream0 + (c + 1) * (1 << 30) + first_game_index) for c in (0, 1)]
+        self.mcts = [BatchedMCTS(game, nnet1, args1, n_parallel, node_capacity=node_capacity, **kw[0]),
+                     BatchedMCTS(game, nnet2, args2 if args2 is not None else args1, n_parallel, node_capacity=node_capacity, **kw[1])]
         self.max_plies = 4096
 
     def play_wave(self, first_game_index=0, n_games=None, record=None):
@@ -71,11 +74,13 @@ class BatchedArena:
             done = done | fin
         return result[:n], one_vs_two[:n]
 
-    def playGames(self, num):
-        """-> (oneWon, twoWon, draws) like Arena.playGames (Arena.py:103-140)"""
+    def playGames(self, num, first_game_index=0):
+        """-> (oneWon, twoWon, draws) like Arena.playGames (Arena.py:103-140).  first_game_index: this object plays games
+        [first_game_index, first_game_index + num) of a match that is dealt out over several ranks (the seating and the random
+        streams of a game are functions of its index)"""
         one = two = draws = 0
-        for first in range(0, num, self.T):
-            n = min(self.T, num - first)
+        for first in range(first_game_index, first_game_index + num, self.T):
+            n = min(self.T, first_game_index + num - first)
             res, ovt = self.play_wave(first, n)
             win_first_seat, win_other = res == 1.0, res == -1.0
             one += int(((ovt & win_first_seat) | (~ovt & win_other)).sum().item())

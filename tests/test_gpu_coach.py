@@ -58,3 +58,30 @@ def test_coach_learn_azul_one_iteration(tmp_path):
     assert hist[0][0][0].shape == (23, 6) and len(hist[0][0][1]) == 180
     ck = torch.load(os.path.join(tmp_path, 'temp.pt'), map_location='cpu', weights_only=False)
     assert ck['full_model'].version == 84 and set(ck['state_dict'].keys()) == set(m.state_dict().keys())
+
+
+def test_coach_learn_world2_equals_world1(tmp_path):
+    """SURVEY.md §8e / BASELINE config 5: Coach.learn over two ranks (episodes and arena games sharded by index, the examples
+    all_gathered, rank 0 trains, weights broadcast, tallies all_reduced) reproduces the single-process run: same examples, same
+    arena tallies, same accept / reject sequence, same final weights on every rank.  (Both ranks share cuda:0; collectives over gloo.)"""
+    import socket
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), 'coach_worker.py')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    subprocess.check_call([sys.executable, worker, str(tmp_path)], env={k: v for k, v in env.items() if k not in ('WORLD_SIZE', 'RANK')})
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                           '--master-port', str(port), worker, str(tmp_path)], env=env)
+    one = torch.load(os.path.join(tmp_path, 'result_w1_r0.pt'), weights_only=False)
+    two = [torch.load(os.path.join(tmp_path, 'result_w2_r%d.pt' % r), weights_only=False) for r in (0, 1)]
+    keys = ('iteration', 'nwins', 'pwins', 'draws', 'accepted')
+    assert len(one['results']) == 2
+    for t in two:
+        assert [tuple(r[k] for k in keys) for r in t['results']] == [tuple(r[k] for k in keys) for r in one['results']]
+    assert [r['examples'] for r in two[0]['results']] == [r['examples'] for r in one['results']] and one['results'][0]['examples'] > 64
+    for k, v in one['state_dict'].items():
+        assert torch.equal(two[0]['state_dict'][k], two[1]['state_dict'][k]), k          # every rank ends with the same weights
+        assert torch.equal(two[0]['state_dict'][k], v), k                                 # ... the single-process run's
