@@ -301,25 +301,34 @@ extern "C" int azg_nn_mb1d_forward(int geometry, const int8_t* boards, const uin
 
 // ---- Santorini ResNet V88/V89 (no-gods geometry: A = 162, P = 2, 5 residual blocks), one launch (nn_conv5x5.hip.h) ----
 static int conv5_launch(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A, int P, int B,
-                        float* pi, float* v, void* stream, bool split) {
+                        float* pi, float* v, void* stream, int split /* 0 f32, 3 bf16 x 3, 2 f16 x 2 */, float descale = 1.f) {
     if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_conv5_forward: null/empty argument");
     if (n_blocks != 5 || A != 162 || P != 2) return fail("azg_nn_conv5_forward: built for 5 residual blocks, A = 162, P = 2");
     Conv5NetW N{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13]};
-    static bool attr[2] = {false, false};
-    if (split) {
+    static bool attr[3] = {false, false, false};
+    if (split == 2) {
+        // two activation tiles of two f16 planes (+ a zero row each); the second tile also holds the f32 board staging tile at the
+        // start and the f32 trunk output + head buffers at the end of the kernel (54.4 KB + 9.8 KB)
+        constexpr size_t lds = (size_t)2 * 201 * 128 + 65536;
+        if (!attr[2]) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr[2] = true;
+        }
+        k_conv5_net<5, 162, 2, 2><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v, descale);
+    } else if (split) {
         constexpr size_t lds = (size_t)2 * 3 * 201 * 128;              // two activation tiles of three bf16 planes (+ a zero row each)
         if (!attr[1]) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr[1] = true;
         }
-        k_conv5_net<5, 162, 2, true><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
+        k_conv5_net<5, 162, 2, 3><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v, 1.f);
     } else {
         constexpr size_t lds = (size_t)2 * 200 * 68 * sizeof(float);
         if (!attr[0]) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr[0] = true;
         }
-        k_conv5_net<5, 162, 2, false><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
+        k_conv5_net<5, 162, 2, 0><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v, 1.f);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -327,12 +336,17 @@ static int conv5_launch(const int8_t* boards, const uint8_t* valid, const float*
 
 extern "C" int azg_nn_conv5_forward(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A,
                                     int P, int B, float* pi, float* v, void* stream) {
-    return conv5_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, false);
+    return conv5_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, 0);
 }
 
 extern "C" int azg_nn_conv5_forward_split(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A,
                                           int P, int B, float* pi, float* v, void* stream) {
-    return conv5_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, true);
+    return conv5_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, 3);
+}
+
+extern "C" int azg_nn_conv5_forward_h2(const int8_t* boards, const uint8_t* valid, const float* const* w, float descale, int n_blocks,
+                                       int A, int P, int B, float* pi, float* v, void* stream) {
+    return conv5_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, 2, descale);
 }
 
 // ---- Santorini-with-gods net V78 (10 InvertedResidual blocks, A = 1782, P = 2): trunk + value head, then the policy FC (nn_conv5x5.hip.h) ----

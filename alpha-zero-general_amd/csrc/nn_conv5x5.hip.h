@@ -109,7 +109,7 @@ __device__ __forceinline__ void conv3x3_tile(const float* __restrict__ Wfrag, co
 // (bf16x8, split3x2, pl_off, store_split4, load_split4: nn_kernels.hip.h)
 
 // the first convolution (2 board planes, K = 9 x 16): f32 MFMA from the f32 staging tile, output written split
-template <int NS, bool RELU = true>
+template <int NS, bool RELU = true, int NPL = 3>
 __device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wfrag, const float* __restrict__ bias,
                                                     const float* IN, uint8_t* OUT) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
@@ -139,7 +139,8 @@ __device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wf
         if (r < ROWS) {
             float4 o = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
             if (RELU) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-            store_split4(OUT, PB, r, ct * 16 + 4 * g, o);
+            if (NPL == 2) h2_store4(OUT, PB, 128, r, ct * 16 + 4 * g, f32x4{o.x, o.y, o.z, o.w});
+            else store_split4(OUT, PB, r, ct * 16 + 4 * g, o);
         }
     }
 }
@@ -148,9 +149,12 @@ struct SplitFrag { uint4 h, m, l; };                        // operand fragments
 #define AZG_BF(x) __builtin_bit_cast(bf16x8, x)
 
 // one 64 -> 64 3x3 convolution on split activations: OUT = relu(conv(IN) + bias (+ RES)); OUT may alias RES
-template <int NS>
+// NPL = 3: bf16 x 3 (hi + mid + lo, six MFMAs per product).  NPL = 2: f16 x 2 (hi + lo: 22 significant bits, three
+// v_mfma_f32_16x16x32_f16 per product -- lo*hi, hi*lo, hi*hi; nn_v80_h2.hip.h): two planes per tile, the activation planes hold
+// 64 * x, the weight fragments W * 2^k, `descale` = 2^-k / 64 brings the accumulator back
+template <int NS, int NPL = 3>
 __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, const float* __restrict__ bias, const uint8_t* IN,
-                                              uint8_t* OUT, const uint8_t* RES) {
+                                              uint8_t* OUT, const uint8_t* RES, float descale = 1.f) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128, KCH = 18;
     static_assert(MAXT == 5 && RT - RG * (MAXT - 1) == 1, "step schedule: two tile pairs per wave + one odd tile in the first row group");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
@@ -180,11 +184,15 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
         const bool on = (tapmask[i] >> t) & 1u;
         const int r = on ? row[i] + (t / 3 - 1) * 5 + (t % 3 - 1) : ROWS;          // off the board: the zero row
         const uint8_t* src = IN + pl_off(r, 4 * c + g);
-        return SplitFrag{*(const uint4*)src, *(const uint4*)(src + PB), *(const uint4*)(src + 2 * PB)};
+        return SplitFrag{*(const uint4*)src, *(const uint4*)(src + PB), NPL == 3 ? *(const uint4*)(src + 2 * PB) : make_uint4(0u, 0u, 0u, 0u)};
     };
     // one (tile, tap, K chunk of 32): three 16-byte operand reads, six MFMAs into the tile's accumulator
     auto step = [&](int i, int t, int c, bf16x8 wh, bf16x8 wm, bf16x8 wl) {
         const SplitFrag a = load(i, t, c);
+        if (NPL == 2) {                                      // planes: h = hi, m = lo (f16)
+            acc[i] = h2_mma(__builtin_bit_cast(uint4, wh), __builtin_bit_cast(uint4, wm), a.h, a.m, acc[i]);
+            return;
+        }
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, AZG_BF(a.h), acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, AZG_BF(a.l), acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, AZG_BF(a.m), acc[i], 0, 0, 0);
@@ -198,7 +206,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 #pragma unroll
         for (int c6 = 0; c6 < 6; c6++)
 #pragma unroll
-            for (int p = 0; p < 3; p++) w[c6][p] = Wfrag[(((size_t)ct * KCH + ky * 6 + c6) * 3 + p) * 64 + lane];
+            for (int p = 0; p < 3; p++) w[c6][p] = p < NPL ? Wfrag[(((size_t)ct * KCH + ky * 6 + c6) * NPL + p) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
 #pragma unroll
@@ -214,6 +222,12 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 #pragma unroll
     for (int i = 0; i < MAXT; i++) {
         if (rg + RG * i >= RT || row[i] >= ROWS) continue;
+        if (NPL == 2) {
+            f32x4 o = acc[i] * descale + f32x4{b.x, b.y, b.z, b.w};
+            if (RES) o += h2_load4(RES, PB, 128, row[i], ct * 16 + 4 * g);
+            h2_store4(OUT, PB, 128, row[i], ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});
+            continue;
+        }
         float4 o = make_float4(acc[i][0] + b.x, acc[i][1] + b.y, acc[i][2] + b.z, acc[i][3] + b.w);
         if (RES) {
             const float4 r = load_split4(RES, PB, row[i], ct * 16 + 4 * g);
@@ -259,11 +273,12 @@ __device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t*
 #undef AZG_BF
 
 // SPLIT: the trunk on bf16 x 3 operands (above; N.Wc then points to the split fragments); LDS = 2 tiles x 3 planes x (ROWS + 1) x 128 B
-template <int NB, int A, int P, bool SPLIT = false>
+template <int NB, int A, int P, int SPLIT = 0>
 __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __restrict__ boards,
                                                    const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
-                                                   float* __restrict__ v_out) {
-    constexpr int NS = 8, ROWS = NS * 25, CS = 68, CP2 = 2, AS = (A + 3) / 4 * 4 + 4, PLANE_B = (ROWS + 1) * 128, TILE_B = 3 * PLANE_B;
+                                                   float* __restrict__ v_out, float descale) {
+    constexpr int NPL = SPLIT ? SPLIT : 3;                  // planes per tile: 3 = bf16 x 3, 2 = f16 x 2
+    constexpr int NS = 8, ROWS = NS * 25, CS = 68, CP2 = 2, AS = (A + 3) / 4 * 4 + 4, PLANE_B = (ROWS + 1) * 128, TILE_B = NPL * PLANE_B;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;                        // [ROWS][CS]   (SPLIT: three bf16 planes, TILE_B bytes)
     float* Y = SPLIT ? (float*)((uint8_t*)smem + TILE_B) : X + ROWS * CS;               // [ROWS][CS]
@@ -280,22 +295,23 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     if (SPLIT) {
         uint8_t* XP = (uint8_t*)X;
         uint8_t* YP = (uint8_t*)Y;
-        if (tid < 3 * 32) ((uint32_t*)(XP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // X's zero rows
-        conv3x3_first_split<NS>(N.W0, N.b0, Y, XP);           // (Y still holds the f32 board staging tile)
+        if (tid < NPL * 32) ((uint32_t*)(XP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // X's zero rows
+        conv3x3_first_split<NS, true, NPL>(N.W0, N.b0, Y, XP);   // (Y still holds the f32 board staging tile)
         __syncthreads();
-        if (tid < 3 * 32) ((uint32_t*)(YP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // Y's (the staging tile is dead)
-        constexpr size_t CONV_U4 = (size_t)4 * 18 * 3 * 64;   // uint4 per convolution
+        if (tid < NPL * 32) ((uint32_t*)(YP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // Y's (the staging tile is dead)
+        constexpr size_t CONV_U4 = (size_t)4 * 18 * NPL * 64;   // uint4 per convolution
 #pragma unroll 1
         for (int blk = 0; blk < NB; blk++) {
-            conv3x3_split<NS>((const uint4*)N.Wc + (size_t)(2 * blk) * CONV_U4, N.bc + (2 * blk) * 64, XP, YP, nullptr);
+            conv3x3_split<NS, NPL>((const uint4*)N.Wc + (size_t)(2 * blk) * CONV_U4, N.bc + (2 * blk) * 64, XP, YP, nullptr, descale);
             __syncthreads();
-            conv3x3_split<NS>((const uint4*)N.Wc + (size_t)(2 * blk + 1) * CONV_U4, N.bc + (2 * blk + 1) * 64, YP, XP, XP);
+            conv3x3_split<NS, NPL>((const uint4*)N.Wc + (size_t)(2 * blk + 1) * CONV_U4, N.bc + (2 * blk + 1) * 64, YP, XP, XP, descale);
             __syncthreads();
         }
         // the heads read f32: rebuild the trunk output as [ROWS][CS] f32 at the start of the Y tile
         for (int i = tid; i < ROWS * 16; i += 768) {
             const int r = i >> 4, c4 = (i & 15) * 4;
-            *(float4*)(Y + r * CS + c4) = load_split4(XP, PLANE_B, r, c4);
+            if (NPL == 2) { const f32x4 o = h2_load4(XP, PLANE_B, 128, r, c4); *(float4*)(Y + r * CS + c4) = make_float4(o[0], o[1], o[2], o[3]); }
+            else *(float4*)(Y + r * CS + c4) = load_split4(XP, PLANE_B, r, c4);
         }
         __syncthreads();
         X = Y;

@@ -696,12 +696,14 @@ class SantoriniV89Hip:
     """SantoriniV89 (no-gods geometry: 5 residual blocks, A = 162) evaluated by the engine's one-launch implicit-GEMM kernel
     (azg_nn_conv5_forward, csrc/nn_conv5x5.hip.h) instead of 11 MIOpen convolutions + glue ops.  Wraps a SantoriniV89."""
 
-    def __init__(self, base, max_batch=4096, split=True):
-        """split: the trunk convolutions on bf16 x 3 split-precision operands (azg_nn_conv5_forward_split: six bf16 MFMAs per
-        product at 16x the f32 MFMA rate, same 1e-5 contract); False = the f32-MFMA kernel"""
+    def __init__(self, base, max_batch=4096, split=True, h2=True):
+        """h2 (default): the trunk convolutions on f16 x 2 split-precision operands (azg_nn_conv5_forward_h2: three f16 MFMAs per
+        product, 22-bit operands, same 1e-5 contract).  Otherwise split: bf16 x 3 (azg_nn_conv5_forward_split, six MFMAs per
+        product); False = the f32-MFMA kernel"""
         import ctypes as C
+        import math
         from . import _lib
-        self._lib, self.base, self.device, self.split = _lib, base, base.device, bool(split)
+        self._lib, self.base, self.device, self.split, self.h2 = _lib, base, base.device, bool(split), bool(h2)
         self.P, self.A = base.P, base.A
         assert base.dtype == torch.float32 and self.device.type == 'cuda' and len(base.blocks) == 5 and self.A == 162 and self.P == 2
         frag = SplendorV80Hip._frag
@@ -724,8 +726,19 @@ class SantoriniV89Hip:
             m[:, :ci] = w.permute(2, 3, 1, 0).reshape(9, ci, co)
             return frag(m.reshape(9 * cin_pad, co).contiguous())
         convs = [c for blk in base.blocks for c in blk]
+        wmax = max(float(w.abs().max()) for w, _ in convs)
+        k2 = 12 - int(math.ceil(math.log2(wmax)))               # one power-of-two scale for the whole trunk: max |w| * 2^k in [2^11, 2^12]
+        self.descale = (2.0 ** -k2) / 64.0
+
+        def conv_h2(w):                    # [co][ci][3][3] -> [4 ct][18 chunks][2 planes hi, lo][64 lanes][8] f16 of W * 2^k
+            co, ci = w.shape[0], w.shape[1]
+            m = w.permute(2, 3, 1, 0).reshape(9 * ci, co).contiguous().float() * (2.0 ** k2)
+            hi = m.to(torch.float16)
+            lo = (m - hi.float()).to(torch.float16)
+            pl = torch.stack([hi, lo]).view(2, 18, 4, 8, 4, 16)                          # plane, chunk, g, j, ct, r
+            return pl.permute(4, 1, 0, 2, 5, 3).contiguous().view(-1)                     # ct, chunk, plane, g, r, j
         keep = [conv_mat(base.c0[0], 16), base.c0[1].contiguous(),
-                torch.cat([(conv_split(w) if self.split else conv_mat(w, 64)) for w, _ in convs]).contiguous(),
+                torch.cat([(conv_h2(w) if self.h2 else conv_split(w) if self.split else conv_mat(w, 64)) for w, _ in convs]).contiguous(),
                 torch.cat([b for _, b in convs]).contiguous(),
                 base.hp[0].reshape(2, 64).t().contiguous(), base.hp[1].contiguous(), base.fc_pi[0].contiguous(), base.fc_pi[1].contiguous(),
                 base.hv[0].reshape(64).contiguous(), base.hv[1].contiguous(), base.fc_v1[0].contiguous(), base.fc_v1[1].contiguous(),
@@ -755,6 +768,10 @@ class SantoriniV89Hip:
         boards = boards.reshape(B, -1)
         assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda and boards.shape[1] == 75
         valids = (valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)).contiguous()
+        if self.h2:
+            self._lib.check(self._lib.lib().azg_nn_conv5_forward_h2(p(boards), p(valids), self.ptrs, self.descale, 5, self.A, self.P, B, p(self.pi),
+                                                                    p(self.v), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return self.pi[:B], self.v[:B]
         fwd = self._lib.lib().azg_nn_conv5_forward_split if self.split else self._lib.lib().azg_nn_conv5_forward
         self._lib.check(fwd(p(boards), p(valids), self.ptrs, 5, self.A, self.P, B, p(self.pi), p(self.v),
                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))

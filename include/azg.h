@@ -303,6 +303,12 @@ int azg_nn_conv5_forward(const int8_t* boards_dev, const uint8_t* valid_dev, con
    element = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)], row index K = tap*64 + ci. */
 int azg_nn_conv5_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int n_blocks, int A,
                                int P, int B, float* pi_dev, float* v_dev, void* stream);
+/* The same net with the trunk on f16 x 2 split-precision operands (hi = rn16(x), lo = rn16(x - hi): 22 significant bits, three
+   v_mfma_f32_16x16x32_f16 per product instead of the six of bf16 x 3; two activation planes per tile holding 64 * x).
+   w[2] = the ten 64 -> 64 convolutions as [4 ct][18 chunks][2 planes hi, lo][64 lanes][8] f16 of W * 2^k (one k for the whole net),
+   element = W_plane[32*chunk + 8*(lane>>4) + j][16*ct + (lane&15)], K = tap*64 + ci; descale = 2^-k / 64.  Same 1e-5 contract. */
+int azg_nn_conv5_forward_h2(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, float descale, int n_blocks,
+                            int A, int P, int B, float* pi_dev, float* v_dev, void* stream);
 /* The Santorini-with-gods net (nn_version 78, SantoriniNNet.py:167-192,264-271, HeadWithMeta :42-69): two launches on `stream`
    (trunk + value head; policy FC + masked softmax -- the pi rows carry the 132 policy features in between).
    boards int8 [B][5][5][3] (planes 0, 1 = workers / levels, plane 2 = gods and metadata), valid u8 [B][A] -> pi, v.

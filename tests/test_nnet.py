@@ -239,14 +239,15 @@ def test_mobilenet1d_engine_kernels_gpu(tag, fused):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('split', [True, False])
+@pytest.mark.parametrize('split', ['h2', True, False])
 def test_santorini_v89_one_launch_gpu(split):
     """SantoriniV89Hip (implicit-GEMM 3x3 convolutions + heads in one launch) vs the reference model's golden outputs and,
     on a ragged random batch, vs the MIOpen evaluation of the same weights."""
     from azg_amd import nnet
     root = os.path.join(os.path.dirname(__file__), 'golden')
     base = nnet.SantoriniV89.from_npz(os.path.join(root, 'weights_santorini1_v89.npz'), device='cuda:0')
-    net = nnet.SantoriniV89Hip(base, max_batch=64, split=split)      # split: bf16 x 3 split-precision trunk / f32 MFMA
+    # trunk on f16 x 2 split-precision operands (default) / bf16 x 3 / f32 MFMA
+    net = nnet.SantoriniV89Hip(base, max_batch=64, split=split is True, h2=split == 'h2')
     d = np.load(os.path.join(root, 'netfwd_santorini1_v89.npz'))
     boards = torch.from_numpy(d['boards']).to('cuda:0').to(torch.int8)
     masks = torch.from_numpy(d['masks']).to('cuda:0')
