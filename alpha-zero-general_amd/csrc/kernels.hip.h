@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     };
     const uint32_t l_hot = hot_off((uint32_t)l), l_child0 = child_off((uint32_t)l, 0u), l_id = id_off((uint32_t)l);
     const uint32_t child_ustride = (one_page ? RG.PC : 32u) * 4u;
-    const bool spec_state = F.cls_q == G::A && FR::SPW <= 192;
+    const bool spec_state = F.spec_state && F.cls_q == G::A && FR::SPW <= 192;
     const float inv_units1 = 1.0f / (float)FR::cls_units(F, 1);
     bool need_nn = false;
     uint32_t c_sims = 0, c_levels = 0, c_sumvalid = 0, c_term = 0, levels_this_launch = 0, edges_this_launch = 0, work_units = 0;

@@ -292,7 +292,9 @@ def measure_net(a, eng, T, game_key, net_kind):
     h2 = net_kind == 'hip' and getattr(grp.net, 'h2', False)
     dt = 'f16' if h2 else ('bf16' if net_kind == 'hip' and game_key in ('santorini1', 'santorini11') else 'f32')
     ach = flops / (ms * 1e-3) / 1e12
-    return dict(bound='mfma', kernel={True: 'k_v80_net_h2'}.get(h2, 'net forward (%s)' % net_kind), achieved=ach,
+    kname = ({'splendor2': 'k_v80_net_h2', 'santorini1': 'k_conv5_net<5, 162, 2, 2> (f16 x 2 trunk)'}.get(game_key) if h2 else None) or \
+        'net forward (%s, %s)' % (net_kind, type(grp.net).__name__)
+    return dict(bound='mfma', kernel=kname, achieved=ach,
                 peak=MFMA_PEAK_TFLOPS[dt], unit='TFLOP/s', frac=ach / MFMA_PEAK_TFLOPS[dt], traffic=None,
                 mfma_input_dtype=dt, frac_of_f32_mfma_peak=ach / MFMA_PEAK_TFLOPS['f32'],
                 note='fp32-accurate (<= 1e-5 of the reference outputs): every f32 operand is a hi + lo pair of 16-bit numbers, one '
@@ -390,7 +392,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--cpu-procs', type=int, default=0,
                     help='cpu_baseline on this many host cores (independent single-thread processes, summed); 0 = min(64, host '
-                         'cores / 2): one process per physical core -- SURVEY.md §8d asks for the host cores, not one')
+                         'cores): the count with the highest total on the 256-thread host -- SURVEY.md §8d asks for the host cores, not one')
     ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--roofline-rounds', type=int, default=300)
     ap.add_argument('--traffic-json', default=None, help='PMC traffic summary of an earlier profiled run (default: the newest profiles/r*_traffic.json)')
@@ -465,7 +467,8 @@ def main():
                                     unit='env-steps/sec', steps=st, ms_per_step=r2['dt'] / st * 1e3,
                                     config=dict(workload='%s (%s), numMCTSSims=%d, %d concurrent self-play games per GPU, args of '
                                                          'santorini/pretrained.pt (cpuct 1.1 fpu 0.03 universes 0 dirichlet 0.2)'
-                                                         % (r2['label'], 'engine MFMA-f32 kernel' if r2['net_kind'] == 'hip' else 'PyTorch-ROCm ops', a.sims, T)),
+                                                         % (r2['label'], 'engine kernel, fp32-accurate: f16 hi+lo split-precision MFMA trunk' if r2['net_kind'] == 'hip'
+                                                            else 'PyTorch-ROCm ops', a.sims, T)),
                                     value_from_sims=r2['value_from_sims'], plies_completed=r2['plies_completed'],
                                     games_finished=r2['games_finished'], engine_errors=r2['engine_errors'],
                                     ms_per_round=r2['ms_per_round'], roofline=r2['roofline'], roofline_net=r2.get('roofline_net'),
@@ -473,9 +476,9 @@ def main():
         except Exception as ex:                       # the headline line must still be printed
             out['secondary'] = dict(error=repr(ex))
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.game in CPU_GAMES:
-        # one single-thread process per PHYSICAL core (the SMT siblings share the core's units; 64 processes measured 6.4
-        # env-steps/s each)
-        procs = a.cpu_procs or max(1, min(128, (os.cpu_count() or 2) // 2))
+        # 64 single-thread processes: the count that gives the HIGHEST total on the 256-thread host (measured: 64 processes
+        # 393 env-steps/s in total, 128 processes 297 -- they contend for memory bandwidth and the SMT siblings' units)
+        procs = a.cpu_procs or max(1, min(64, os.cpu_count() or 1))
         out['cpu_baseline'] = (cpu_baseline_multi(a.sims, a.cpu_seconds, procs, a.game) if procs > 1
                                else cpu_baseline(a.sims, a.cpu_seconds, game_key=a.game))
         if a.game == 'splendor2' and isinstance(out.get('secondary'), dict) and 'value' in out['secondary']:

@@ -34,7 +34,7 @@ def make(variant):
     return games.SplendorGame(v) if name == 'splendor' else games.SantoriniGame(v)
 
 
-@pytest.mark.parametrize('variant,prefix', [(v, 'mcts') for v in list(VARIANTS) + list(F4_VARIANTS)] + [(v, 'mcts800') for v in VARIANTS])
+@pytest.mark.parametrize('variant,prefix', [(v, 'mcts') for v in list(VARIANTS) + list(F4_VARIANTS)] + [(v, 'mcts800') for v in VARIANTS] + [('azul', 'mcts1600')])
 def test_mcts_traces_vs_golden(golden_dir, variant, prefix):
     """`mcts`: 25 / 200 simulations over several argument sets; `mcts800`: the headline search size (800 simulations, the
     checkpoint's args) -- both are outputs of the reference's own MCTS.getActionProb (tools/gen_golden*.py)."""
@@ -146,6 +146,44 @@ def test_tree_reuse_sequence_vs_golden(golden_dir, variant, small_arena):
     if small_arena and variant == 'splendor2':
         assert m.forest.stats()['gc_runs'] > 0
     m.forest.close()
+
+
+def test_mcts1600_azul_auto_alpha_noise_vs_golden(golden_dir):
+    """BASELINE config 5 (Azul, 1600 simulations, dirichletAlpha = -1: alpha = 10 / n_valid, MCTS.py:188-192): the reference's own
+    search with the Dirichlet sample it drew recorded in the fixture (tools/gen_golden_800.py --sims 1600 --noise); the forest gets the
+    same sample injected."""
+    import torch
+    from azg_amd.forest import Forest
+    from hashnet import HashNetTorch
+    d = np.load(os.path.join(golden_dir, 'mcts1600_azul_numba.npz'))
+    g = make('azul')
+    T = len(d['noise_root'])
+    args = Args(numMCTSSims=int(d['case_sims'][0]), cpuct=float(d['case_cpuct'][0]), fpu=float(d['case_fpu'][0]),
+                universes=int(d['case_universes'][0]), forced_playouts=bool(d['case_forced'][0]), prob_fullMCTS=1.0, ratio_fullMCTS=5,
+                dirichletAlpha=-1, temperature=[1.0, 1.0, 1.0])
+    f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=int(d['case_sims'][0]) + 64)
+    net = HashNetTorch(g.P)
+    nz = torch.from_numpy(d['noise_sample']).to(g.device)
+    f.begin_search(torch.from_numpy(d['noise_root']).to(g.device))
+    while True:
+        f.select(nz, normalised=True)
+        if not bool(f.needs_eval.any().item()):
+            if f.active() == 0:
+                break
+            continue
+        pi, v = net.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid.bool())
+        f.expand_backup(pi, v, nz, normalised=True)
+    rs = f.root_stats()
+    probs, q, _ = f.action_probs(1.0)
+    for t in range(T):
+        assert int(rs['Ns'][t]) == int(d['noise_Ns'][t])
+        assert np.array_equal(rs['Nsa'][t].cpu().numpy(), d['noise_Nsa'][t].astype(np.int32))
+        assert np.array_equal(rs['Qsa'][t].cpu().numpy(), d['noise_Qsa'][t])
+        va = d['noise_Ps'][t] > 0
+        assert np.array_equal(rs['Ps'][t].cpu().numpy()[va], d['noise_Ps'][t][va])
+        assert np.array_equal(probs[t].cpu().numpy(), d['noise_probs'][t])
+        assert int(rs['n_nodes'][t]) == int(d['noise_nodes'][t])
+    f.close()
 
 
 @pytest.mark.parametrize('temp_root', [1.0, 1.1])

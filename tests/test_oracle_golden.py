@@ -80,10 +80,10 @@ MCTS_SMALL = MCTS_VARIANTS + ['abalone', 'akropolis', 'smallworld']          # (
 
 
 @pytest.mark.parametrize('variant,typing,prefix', [(v, t, 'mcts') for v in MCTS_SMALL for t in ('numpy2', 'numba')] +
-                         [(v, 'numba', 'mcts') for v in ('smallworld3', 'smallworld4', 'akropolis3', 'akropolis4')] + [(v, 'numba', 'mcts800') for v in MCTS_VARIANTS])
+                         [(v, 'numba', 'mcts') for v in ('smallworld3', 'smallworld4', 'akropolis3', 'akropolis4')] + [(v, 'numba', 'mcts800') for v in MCTS_VARIANTS] + [('azul', 'numba', 'mcts1600')])
 def test_mcts_traces(golden_dir, variant, typing, prefix):
     """G3: whole-tree parity (every node's Ns, Nsa, Qsa, Ps, Qs bit-exact through a SHA-256 digest); `mcts800` = the
-    headline search size (800 simulations, tools/gen_golden_800.py)."""
+    headline search size (800 simulations, tools/gen_golden_800.py); `mcts1600` = BASELINE config 5's (Azul, 1600 simulations)."""
     d = load(golden_dir, '%s_%s_%s.npz' % (prefix, variant, typing))
     g = O.OracleGame(*VARIANTS[variant])
     for i in range(len(d['case_sims'])):
@@ -102,6 +102,26 @@ def test_mcts_traces(golden_dir, variant, typing, prefix):
         assert np.array_equal(probs, d['case_probs'][i])
         assert np.array_equal(q, d['case_q'][i])
         assert np.array_equal(oracle_tree_digest(mc, g), d['case_digest'][i]), (variant, i)
+
+
+def test_mcts1600_azul_auto_alpha_noise(golden_dir):
+    """BASELINE config 5: Azul, 1600 simulations, root Dirichlet noise with the automatic alpha = 10 / n_valid (MCTS.py:188-192) --
+    the reference's own search with the sample its rng.dirichlet drew recorded; the oracle is handed the same sample."""
+    d = load(golden_dir, 'mcts1600_azul_numba.npz')
+    g = O.OracleGame(*VARIANTS['azul'])
+    for i in range(len(d['noise_root'])):
+        nv = int(d['noise_n_valid'][i])
+        assert int(g.getValidMoves(d['noise_root'][i], 0).sum()) == nv and float(d['noise_alpha'][i]) == 10.0 / nv
+        args = O.make_args(numMCTSSims=int(d['case_sims'][0]), cpuct=float(d['case_cpuct'][0]), fpu=float(d['case_fpu'][0]),
+                           universes=int(d['case_universes'][0]), forced_playouts=bool(d['case_forced'][0]), dirichletAlpha=-1.0,
+                           temperature=(1.0, 1.0, 1.0))
+        mc = O.OracleMCTS(g, args, dirichlet_noise=True)
+        probs, q, full = mc.getActionProb(d['noise_root'][i], temp=1, force_full_search=True, dir_noise=d['noise_sample'][i][:nv])
+        nd = mc.node(d['noise_root'][i])
+        assert nd['Ns'] == int(d['noise_Ns'][i]) and np.array_equal(nd['Nsa'], d['noise_Nsa'][i])
+        assert np.array_equal(nd['Qsa'], d['noise_Qsa'][i]) and np.array_equal(nd['Ps'], d['noise_Ps'][i])
+        assert np.array_equal(probs, d['noise_probs'][i]) and mc.num_nodes() == int(d['noise_nodes'][i])
+        assert np.array_equal(oracle_tree_digest(mc, g), d['noise_digest'][i])
 
 
 @pytest.mark.parametrize('variant,typing', [(v, t) for v in MCTS_SMALL for t in ('numpy2', 'numba')] + [('smallworld3', 'numba'), ('smallworld4', 'numba'), ('akropolis3', 'numba'), ('akropolis4', 'numba')])
