@@ -29,7 +29,7 @@ python bench.py --prob-full 0.25 --no-cpu-baseline --no-secondary --roofline-rou
 for g in azul splendor4 santorini1 santorini11; do
   python bench.py --game $g --steps $([ $g = santorini11 ] && echo 25 || echo 50) --warmup 5 --no-cpu-baseline --roofline-rounds 100 2>/dev/null | tail -1 > $O/bench_$g.json
 done
-python bench.py --game azul --sims 1600 --steps 25 --warmup 5 --no-cpu-baseline --roofline-rounds 100 2>/dev/null | tail -1 > $O/bench_azul1600.json
+python bench.py --game azul --sims 1600 --games 2048 --node-capacity 56000 --steps 25 --warmup 5 --no-cpu-baseline --roofline-rounds 100 2>/dev/null | tail -1 > $O/bench_azul1600.json
 python tools/time_v80.py > $O/time_v80.txt 2>&1
 python tools/time_v89.py > $O/time_v89.txt 2>&1
 tail -c 600 $O/bench.json
