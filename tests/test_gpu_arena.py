@@ -54,3 +54,25 @@ def test_batched_arena_vs_oracle():
     exp_one = sum(1 for i in range(T) if res[i] == (1.0 if ovt[i] else -1.0))
     exp_two = sum(1 for i in range(T) if res[i] == (-1.0 if ovt[i] else 1.0))
     assert (one, two, draws) == (exp_one, exp_two, T - exp_one - exp_two)
+
+
+def test_arena_shards_reproduce_the_whole_match():
+    """a match dealt out by game index (Coach.learn over several ranks): games [2, 5) played by their own arena object with
+    first_game_index = 2 end like games 2..4 of the arena that plays all of [0, 6)"""
+    from azg_amd import games
+    from azg_amd.arena import BatchedArena
+    from hashnet import HashNetTorch
+    g = games.SplendorGame(2)
+    kw = dict(MCTS_ARGS['splendor2'])
+    a1 = Args(numMCTSSims=16, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1, 1, 1], **kw)
+    a2 = Args(numMCTSSims=8, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1, 1, 1], **kw)
+    temp = lambda n: 0.5 * 0.5 ** (n / 6.0)                      # noqa: E731  (reaches the random tie-break branch late in a game)
+    whole = BatchedArena(g, HashNetTorch(2), HashNetTorch(2), a1, a2, n_parallel=6, node_capacity=1024, stream0=1 << 32, temp_for_game=temp)
+    res_w, ovt_w = whole.play_wave(0, 6)
+    part = BatchedArena(g, HashNetTorch(2), HashNetTorch(2), a1, a2, n_parallel=3, node_capacity=1024, stream0=1 << 32, temp_for_game=temp,
+                        first_game_index=2)
+    res_p, ovt_p = part.play_wave(2, 3)
+    assert np.array_equal(res_w.cpu().numpy()[2:5], res_p.cpu().numpy()) and np.array_equal(ovt_w.cpu().numpy()[2:5], ovt_p.cpu().numpy())
+    assert part.playGames(3, first_game_index=2) == tuple(
+        int(x) for x in (((ovt_p & (res_p == 1.0)) | (~ovt_p & (res_p == -1.0))).sum(), ((ovt_p & (res_p == -1.0)) | (~ovt_p & (res_p == 1.0))).sum(),
+                         (~((res_p == 1.0) | (res_p == -1.0))).sum()))

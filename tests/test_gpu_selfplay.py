@@ -436,3 +436,31 @@ def test_selfplay_vs_reference_executeEpisode(case, golden_dir):
     assert np.array_equal(z_[rep].cpu().numpy(), d['ex_z'])
     assert np.array_equal(q_[rep].cpu().numpy(), d['ex_q'])
     f.close()
+
+
+def test_set_search_params_between_moves():
+    """args.numMCTSSims / args.prob_fullMCTS are read at every getActionProb call in the reference (MCTS.py:58-59); the forest takes
+    new values for the searches that begin after azg_forest_set_search_params: a stretch of fast searches records no example, the
+    full searches that follow do, and an engine that switches plays on without errors (bench.py's pre-roll)"""
+    from azg_amd import games
+    from azg_amd.selfplay import SelfPlayEngine
+    from hashnet import HashNetTorch
+    g = games.SplendorGame(2)
+    T, sims = 16, 40
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1.25, 0.8, 1.0], tempThreshold=6,
+                **MCTS_ARGS['splendor2'])
+    eng = SelfPlayEngine(g, HashNetTorch(2), args, T, node_capacity=2048, max_examples=T * 400, rng_seed=3)
+    eng.start()
+    eng.set_search_params(sims, 0.0)                       # fast searches only: sims // 5 simulations, no examples (Coach.py:65)
+    eng.run(20 * (sims // 5 + eng.K))
+    s0 = eng.stats()
+    assert s0['errors'] == 0 and s0['plies'] >= 10 * T and s0['examples'] == 0
+    eng.set_search_params(sims, 1.0)
+    eng.run(12 * (sims + eng.K))
+    s1 = eng.stats()
+    assert s1['errors'] == 0 and s1['plies'] > s0['plies']
+    # the sims counter: a full search costs `sims` simulations, a fast one sims // 5
+    assert (s1['sims'] - s0['sims']) / max(1, s1['plies'] - s0['plies']) > 0.7 * sims > (s0['sims'] / s0['plies'])
+    eng.run(120 * (sims + eng.K))                          # games end: the plies played with full searches were recorded
+    s2 = eng.stats()
+    assert s2['errors'] == 0 and s2['games'] > 0 and s2['examples'] > 0

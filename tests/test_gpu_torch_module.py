@@ -68,3 +68,23 @@ def test_torch_module_behind_the_plugin_surface(tmp_path):
     pi2, _ = w2.predict(b, va)
     pi1, _ = w.predict(b, va)
     assert np.allclose(pi1, pi2, atol=1e-6)
+
+
+def test_coach_learn_with_a_custom_module(tmp_path):
+    """Coach.learn with a caller-supplied module (no engine net for this game): the competitor network is a copy of the module
+    (Coach.py:30 rebuilds it from args, which cannot know the module), training sees boards in the game's shape, the arena gate runs"""
+    from azg_amd import games
+    from azg_amd.coach import Coach
+    from azg_amd.nnet_wrapper import NNetWrapper
+    torch.manual_seed(5)
+    g = games.TLPGame(3, rng_seed=13)
+    for bare in (False, True):
+        mod = TinyNet(g.getBoardSize(), g.A, g.P)
+        nnet = mod if bare else NNetWrapper(g, dict(nn_version=-1, learn_rate=1e-3, batch_size=64, epochs=1), module=mod)
+        args = Args(numMCTSSims=16, cpuct=1.0, fpu=0.0, universes=1, forced_playouts=False, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0,
+                    temperature=[1.25, 0.8, 1.0], tempThreshold=6, numIters=1, numEps=8, numItersHistory=2, maxlenOfQueue=100000, learn_rate=1e-3,
+                    batch_size=64, epochs=1, q_weight=0.5, arenaCompare=4, updateThreshold=0.5, checkpoint=str(tmp_path / ('bare' if bare else 'wrapped')))
+        c = Coach(g, nnet, args, n_games=8, node_capacity=1024, log=lambda s: None)
+        assert c.pnet.nnet is not c.nnet.nnet and isinstance(c.pnet.nnet, TinyNet) and c.nnet._custom and c.pnet._custom
+        res = c.learn()
+        assert len(res) == 1 and res[0]['nwins'] + res[0]['pwins'] + res[0]['draws'] == 4 and res[0]['examples'] > 32
