@@ -546,7 +546,9 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     uint32_t hw[AZG_HOT_WORDS];
     load_hot_header<true>(Hp, hw);
     if (pi) expand_load<G>(F, t, pi, vin, leaf_valid, ein, hw);         // pi != nullptr: the previous round's expansion first
+#ifdef AZG_PIN_HEADER
     pin_hot_header(hw);
+#endif
     AZG_STAMP(1);
     expand_header<G>(ein, hw);
     uint32_t status0 = AZG_HW(hw, status);
@@ -569,12 +571,16 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         if (l == 0) needs_eval[t] = 0;
         return;
     }
+#ifdef AZG_PIN_HEADER
     H.id_top = uni_u32(H.id_top); H.n_free_ids = uni_u32(H.n_free_ids); H.free_units = uni_u32(H.free_units);
     H.n_nodes = uni_u32(H.n_nodes); H.heap_top = uni_u32(H.heap_top); H.root = uni_u32(H.root);
-    H.root_rec = uni_u32(H.root_rec); H.sim_idx = uni_u32(H.sim_idx); H.n_sims = uni_u32(H.n_sims);
-    H.is_full = uni_u32(H.is_full); H.forced = uni_u32(H.forced); H.err = uni_u32(H.err);
-    H.leaf_is_root = uni_u32(H.leaf_is_root); H.mid_sim = uni_u32(H.mid_sim); H.cur_rec = uni_u32(H.cur_rec);
+    H.err = uni_u32(H.err); H.leaf_is_root = uni_u32(H.leaf_is_root); H.cur_rec = uni_u32(H.cur_rec);
     H.cur_depth = uni_u32(H.cur_depth); H.cur_pre = uni_u32(H.cur_pre);
+#endif
+    // the allocator state, the error flags and the parked-descent state are touched once per simulation at most: they stay in VGPRs
+    // (every lane holds the same value) instead of taking scalar registers from the descent loop (k_select spilled 547 SGPRs)
+    H.root_rec = uni_u32(H.root_rec); H.sim_idx = uni_u32(H.sim_idx); H.n_sims = uni_u32(H.n_sims);
+    H.is_full = uni_u32(H.is_full); H.forced = uni_u32(H.forced); H.mid_sim = uni_u32(H.mid_sim); H.err = uni_u32(H.err);
     Rng srng{F.rng_seed, F.stream0 + (uint64_t)t, ((uint64_t)uni_u32(H.rng_hi) << 32) | uni_u32(H.rng_lo)};
     if (expanded_here) H.sim_idx = uni_u32(ein.sim_idx) + 1u;          // the header words were requested before the expansion
     H.status = ST_SEARCHING; H.pending_leaf = AZG_NONE; H.path_len = 0; H.cyc_leaf = 0; H.leaf_nv = 0; H.leaf_node = 0;
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #endif
     long long cyc_levels = 0, cyc_edge = 0;
     while (true) {
-        if (H.sim_idx >= H.n_sims || H.err) { H.status = ST_DONE; break; }
+        if (H.sim_idx >= H.n_sims || uni_u32(H.err)) { H.status = ST_DONE; break; }
         const int uidx = F.universes > 0 ? (int)(H.sim_idx % (uint32_t)F.universes) : 0;
         const long long seed = F.universes > 0 ? AZG_MAGIC_SEEDS[uidx] : -1ll;                 // MCTS.py:63
         int depth = 0, pre = 0;
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         if (H.mid_sim) {
             // resume a descent that the level budget paused in an earlier launch
             H.mid_sim = 0;
-            rec = H.cur_rec; depth = (int)H.cur_depth; pre = (int)H.cur_pre;
+            rec = uni_u32(H.cur_rec); depth = (int)uni_u32(H.cur_depth); pre = (int)uni_u32(H.cur_pre);
             const PathEnt* gp0 = F.path + (size_t)t * AZG_MAXD;
             for (int d = l; d < depth; d += 64) sm.path[d] = gp0[d];
             wave_sync();
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 uint32_t found_rec = AZG_NONE;
                 const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
                 if (found == AZG_NONE) {
-                    rec = create_leaf<G, SelState>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, &leaf_terminal, es);
+                    rec = uni_u32(create_leaf<G, SelState>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, &leaf_terminal, es));
                     if (rec == AZG_NONE) continue;
                     H.root = uni_u32(((const RecHdr*)(hp + (size_t)rec * 16u))->node_id);
                     H.root_rec = rec;
@@ -765,8 +771,8 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 const int a = a_sel;
                 bool is_new = false;
                 const long long t_e = AZG_CLK();
-                child = resolve_edge<G, SelState>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es,
-                                                  srng, spec_state, ps0, ps1, ps2);
+                child = uni_u32(resolve_edge<G, SelState>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es,
+                                                          srng, spec_state, ps0, ps1, ps2));
                 cyc_edge += AZG_CLK() - t_e;
                 if (child == AZG_NONE) { H.sim_idx = H.n_sims; break; }
                 // memoise: this universe's slot -- or every slot when the env step of `a` cannot depend on the seed (the
