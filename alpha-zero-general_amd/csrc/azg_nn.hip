@@ -351,18 +351,26 @@ extern "C" int azg_nn_conv5_forward_h2(const int8_t* boards, const uint8_t* vali
 
 // ---- Santorini-with-gods net V78 (10 InvertedResidual blocks, A = 1782, P = 2): trunk + value head, then the policy FC (nn_conv5x5.hip.h) ----
 static int s78_launch(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A, int P, int B, float* pi,
-                      float* v, void* stream, bool split) {
+                      float* v, void* stream, int split /* 0 f32, 3 bf16 x 3, 2 f16 x 2 */, float ds_e = 1.f, float ds_p = 1.f) {
     if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_s78_forward: null/empty argument");
     if (n_blocks != 10 || A != 1782 || P != 2) return fail("azg_nn_s78_forward: built for 10 blocks, A = 1782, P = 2");
     S78NetW N{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15], w[16], w[17], w[18]};
-    if (split) {
+    if (split == 2) {
+        constexpr size_t lds = (size_t)(2 + 3) * 201 * 128 + 8 * 32 * sizeof(float);      // X: two f16 planes; the H region keeps three planes' room
+        static bool attr = false;
+        if (!attr) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_s78_net_split<10, 1782, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        k_s78_net_split<10, 1782, 2, 2><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v, ds_e, ds_p);
+    } else if (split) {
         constexpr size_t lds = (size_t)2 * 3 * 201 * 128 + 8 * 32 * sizeof(float);
         static bool attr = false;
         if (!attr) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_s78_net_split<10, 1782, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute((const void*)k_s78_net_split<10, 1782, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = true;
         }
-        k_s78_net_split<10, 1782, 2><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
+        k_s78_net_split<10, 1782, 2, 3><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v, 1.f, 1.f);
     } else {
         constexpr size_t lds = (size_t)(112 * 68 + 112 * 196 + 4 * 32) * sizeof(float);
         static bool attr = false;
@@ -386,12 +394,17 @@ static int s78_launch(const int8_t* boards, const uint8_t* valid, const float* c
 
 extern "C" int azg_nn_s78_forward(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A, int P,
                                   int B, float* pi, float* v, void* stream) {
-    return s78_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, false);
+    return s78_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, 0);
 }
 
 extern "C" int azg_nn_s78_forward_split(const int8_t* boards, const uint8_t* valid, const float* const* w, int n_blocks, int A, int P,
                                         int B, float* pi, float* v, void* stream) {
-    return s78_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, true);
+    return s78_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, 3);
+}
+
+extern "C" int azg_nn_s78_forward_h2(const int8_t* boards, const uint8_t* valid, const float* const* w, float ds_e, float ds_p, int n_blocks,
+                                     int A, int P, int B, float* pi, float* v, void* stream) {
+    return s78_launch(boards, valid, w, n_blocks, A, P, B, pi, v, stream, 2, ds_e, ds_p);
 }
 
 extern "C" int azg_nn_board_to_x_ld(const int8_t* boards, float* x, int B, int C, int L, int ldx, void* stream) {

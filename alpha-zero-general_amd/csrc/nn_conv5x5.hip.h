@@ -241,12 +241,16 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 // wave's row tiles rt = rg + 3 i and its output-channel tile ct (12 waves = 4 ct x 3 rg, as conv3x3_split).
 // Wfrag: [4 ct][2 K chunks of 32][3 planes][64 lanes] uint4; rows >= ROWS read the zero row.
 // (the weight fragments w[chunk * 3 + plane] are requested by gemm64_wload a phase ahead)
+// (NPL = 2: f16 x 2 operands, [4 ct][2 chunks][2 planes]; w[c * 3 + plane], the third slot unused)
+template <int NPL = 3>
 __device__ __forceinline__ void gemm64_wload(const uint4* __restrict__ Wfrag, uint4 (&w)[6]) {
     const int lane = threadIdx.x & 63, ct = (threadIdx.x >> 6) & 3;
 #pragma unroll
-    for (int k = 0; k < 6; k++) w[k] = Wfrag[((size_t)ct * 6 + k) * 64 + lane];
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) w[c * 3 + p] = p < NPL ? Wfrag[(((size_t)ct * 2 + c) * NPL + p) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
 }
-template <int NS>
+template <int NS, int NPL = 3>
 __device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t* IN, f32x4 (&acc)[(NS * 25 + 15) / 16 / 3 + 1]) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
     static_assert(MAXT == RT / 3 + 1 && RT - RG * (MAXT - 1) == 1, "tile schedule: MAXT - 1 tiles per wave + one odd tile in the first row group");
@@ -259,6 +263,10 @@ __device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t*
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const uint8_t* src = IN + pl_off(rr, 4 * c + g);
+            if (NPL == 2) {
+                acc[i] = h2_mma(w[c * 3], w[c * 3 + 1], *(const uint4*)src, *(const uint4*)(src + PB), acc[i]);
+                continue;
+            }
             const bf16x8 ah = AZG_BF(*(const uint4*)src), am = AZG_BF(*(const uint4*)(src + PB)), al = AZG_BF(*(const uint4*)(src + 2 * PB));
             const bf16x8 wh = AZG_BF(w[c * 3]), wm = AZG_BF(w[c * 3 + 1]), wl = AZG_BF(w[c * 3 + 2]);
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc[i], 0, 0, 0);
@@ -548,22 +556,25 @@ __global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __rest
 //   expand 64 -> 64 (third t of We) + BN + ReLU -> H;  depthwise 3x3 + BN + ReLU on H in place;  project acc += H * Wp[third t]
 // with the project accumulators kept in registers across the passes; every GEMM is the 64 x 64 gemm64_split (six bf16 MFMAs per
 // product).  N.We / N.Wp point to the split fragments [NB][3 thirds][4 ct][2 chunks][3 planes][64 lanes][8] bf16.
-template <int NB, int A, int P>
+// NPL = 2: f16 x 2 operands (hi + lo, three MFMAs per product, two planes per tile holding 64 * x; N.We / N.Wp then hold
+// [NB][3 thirds][4 ct][2 chunks][2 planes][64 lanes][8] f16 of W * 2^k, ds_e / ds_p = 2^-k / 64 of the two matrix families)
+template <int NB, int A, int P, int NPL = 3>
 __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid,
-                                                       int B, float* __restrict__ pi_out, float* __restrict__ v_out) {
+                                                       int B, float* __restrict__ pi_out, float* __restrict__ v_out, float ds_e, float ds_p) {
     constexpr int NS = 8, ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, CS = 68, E = 192;
-    constexpr int PLANE_B = (ROWS + 1) * 128, TILE_B = 3 * PLANE_B;
-    constexpr size_t G64_U4 = (size_t)4 * 2 * 3 * 64;          // uint4 per 64 x 64 matrix
+    // (the f32 staging / head tile [ROWS][CS] + head buffers live in the H region: it keeps the size of three planes)
+    constexpr int PLANE_B = (ROWS + 1) * 128, TILE_B = NPL * PLANE_B, HREG_B = 3 * PLANE_B;
+    constexpr size_t G64_U4 = (size_t)4 * 2 * NPL * 64;        // uint4 per 64 x 64 matrix
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint8_t* XP = (uint8_t*)smem;                               // X: three bf16 planes [ROWS + 1][64]
     uint8_t* HP = XP + TILE_B;                                  // one third of the expanded tile, same layout
-    float* META = (float*)(HP + TILE_B);                        // [NS][32]
+    float* META = (float*)(HP + HREG_B);                        // [NS][32]
     float* STG = (float*)HP;                                    // f32 [ROWS][CS]: the board staging tile, later the trunk output for the heads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
     const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
     for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(STG + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 3 * 32) ((uint32_t*)(XP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;        // X's zero row
+    if (tid < NPL * 32) ((uint32_t*)(XP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;      // X's zero row
     __syncthreads();
     for (int i = tid; i < nb * 25 * 2; i += 768) {
         const int r = i >> 1, pl = i & 1;
@@ -579,9 +590,9 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     __shared__ float zero_bias[64];
     if (tid < 64) zero_bias[tid] = 0.f;
     __syncthreads();
-    conv3x3_first_split<NS, false>(N.W0, zero_bias, STG, XP);
+    conv3x3_first_split<NS, false, NPL>(N.W0, zero_bias, STG, XP);
     __syncthreads();
-    if (tid < 3 * 32) ((uint32_t*)(HP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;        // H's zero row (the staging tile is dead)
+    if (tid < NPL * 32) ((uint32_t*)(HP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;      // H's zero row (the staging tile is dead)
 #pragma unroll 1
     for (int blk = 0; blk < NB; blk++) {
         f32x4 pacc[MAXT];
@@ -595,13 +606,18 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
 #pragma unroll
                 for (int i = 0; i < MAXT; i++) e[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 uint4 we[6];
-                gemm64_wload((const uint4*)N.We + (size_t)(blk * 3 + t) * G64_U4, we);
-                gemm64_split<NS>(we, XP, e);
+                gemm64_wload<NPL>((const uint4*)N.We + (size_t)(blk * 3 + t) * G64_U4, we);
+                gemm64_split<NS, NPL>(we, XP, e);
                 const float4 b = *(const float4*)(N.be + blk * E + t * 64 + ct * 16 + 4 * g);
 #pragma unroll
                 for (int i = 0; i < MAXT; i++) {
                     const int r = (rg + RG * i) * 16 + r16;
                     if (rg + RG * i >= RT || r >= ROWS) continue;
+                    if (NPL == 2) {
+                        const f32x4 o = e[i] * ds_e + f32x4{b.x, b.y, b.z, b.w};
+                        h2_store4(HP, PLANE_B, 128, r, ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});
+                        continue;
+                    }
                     store_split4(HP, PLANE_B, r, ct * 16 + 4 * g, make_float4(fmaxf(e[i][0] + b.x, 0.f), fmaxf(e[i][1] + b.y, 0.f),
                                                                                fmaxf(e[i][2] + b.z, 0.f), fmaxf(e[i][3] + b.w, 0.f)));
                 }
@@ -616,8 +632,9 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
 #pragma unroll
                 for (int k = 0; k < 25; k++) {
                     const uint8_t* src = HP + off(k);
-                    in[k] = (bf16_lo_f32(*(const uint16_t*)src) + bf16_lo_f32(*(const uint16_t*)(src + PLANE_B))) +
-                            bf16_lo_f32(*(const uint16_t*)(src + 2 * PLANE_B));
+                    if (NPL == 2) in[k] = ((float)*(const _Float16*)src + (float)*(const _Float16*)(src + PLANE_B)) * H2_IAS;
+                    else in[k] = (bf16_lo_f32(*(const uint16_t*)src) + bf16_lo_f32(*(const uint16_t*)(src + PLANE_B))) +
+                                 bf16_lo_f32(*(const uint16_t*)(src + 2 * PLANE_B));
                 }
 #pragma unroll
                 for (int k = 0; k < 9; k++) w[k] = N.Wd[(size_t)ec * 9 + k];
@@ -641,6 +658,16 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
 #pragma unroll
                 for (int k = 0; k < 26; k += 2) {                  // two cells per conversion
                     uint32_t h, m, l;
+                    if (NPL == 2) {
+                        h2_split2(out[k] * H2_AS, out[k + 1] * H2_AS, h, m);
+                        uint8_t* e0 = HP + off(k);
+                        *(uint16_t*)e0 = (uint16_t)h; *(uint16_t*)(e0 + PLANE_B) = (uint16_t)m;
+                        if (k + 1 < 25) {
+                            uint8_t* e1 = HP + off(k + 1);
+                            *(uint16_t*)e1 = (uint16_t)(h >> 16); *(uint16_t*)(e1 + PLANE_B) = (uint16_t)(m >> 16);
+                        }
+                        continue;
+                    }
                     split3x2(out[k], out[k + 1], h, m, l);
                     uint8_t* d0 = HP + off(k);
                     *(uint16_t*)d0 = (uint16_t)h; *(uint16_t*)(d0 + PLANE_B) = (uint16_t)m; *(uint16_t*)(d0 + 2 * PLANE_B) = (uint16_t)l;
@@ -655,8 +682,8 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
             // ---- 1x1 project, K = this third of the expanded channels ----
             {
                 uint4 wp[6];
-                gemm64_wload((const uint4*)N.Wp + (size_t)(blk * 3 + t) * G64_U4, wp);
-                gemm64_split<NS>(wp, HP, pacc);
+                gemm64_wload<NPL>((const uint4*)N.Wp + (size_t)(blk * 3 + t) * G64_U4, wp);
+                gemm64_split<NS, NPL>(wp, HP, pacc);
             }
             __syncthreads();
         }
@@ -666,6 +693,10 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
         for (int i = 0; i < MAXT; i++) {
             const int r = (rg + RG * i) * 16 + r16;
             if (rg + RG * i >= RT || r >= ROWS) continue;
+            if (NPL == 2) {
+                h2_store4(XP, PLANE_B, 128, r, ct * 16 + 4 * g, pacc[i] * ds_p + f32x4{b.x, b.y, b.z, b.w} + h2_load4(XP, PLANE_B, 128, r, ct * 16 + 4 * g));
+                continue;
+            }
             const float4 x = load_split4(XP, PLANE_B, r, ct * 16 + 4 * g);
             store_split4(XP, PLANE_B, r, ct * 16 + 4 * g, make_float4(pacc[i][0] + b.x + x.x, pacc[i][1] + b.y + x.y,
                                                                        pacc[i][2] + b.z + x.z, pacc[i][3] + b.w + x.w));
@@ -675,7 +706,8 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     // ---- the heads read f32: rebuild the trunk output as [ROWS][CS] f32 over the H region ----
     for (int i = tid; i < ROWS * 16; i += 768) {
         const int r = i >> 4, c4 = (i & 15) * 4;
-        *(float4*)(STG + r * CS + c4) = load_split4(XP, PLANE_B, r, c4);
+        if (NPL == 2) { const f32x4 o = h2_load4(XP, PLANE_B, 128, r, c4); *(float4*)(STG + r * CS + c4) = make_float4(o[0], o[1], o[2], o[3]); }
+        else *(float4*)(STG + r * CS + c4) = load_split4(XP, PLANE_B, r, c4);
     }
     __syncthreads();
     s78_heads<NS, A, P>(N, STG, META, STG + ROWS * CS, b0, nb, pi_out, v_out);

@@ -847,14 +847,26 @@ class SantoriniV78Hip(SantoriniV89Hip):
     csrc/nn_conv5x5.hip.h): one launch for the trunk (MFMA GEMMs for the 1x1 convolutions, in-place depthwise 3x3 on the LDS
     tile) and the value head, one for the 132 x 1782 policy FC (MFMA, 16 samples per workgroup) + masked softmax.  Wraps a SantoriniV78."""
 
-    def __init__(self, base, max_batch=4096, split=True):
-        """split: the 1x1 convolutions of the trunk on bf16 x 3 split-precision operands (azg_nn_s78_forward_split, 8 samples per
+    def __init__(self, base, max_batch=4096, split=True, h2=True):
+        """h2 (default): the 1x1 convolutions of the trunk and the depthwise pass on f16 x 2 split-precision operands
+        (azg_nn_s78_forward_h2: three MFMAs per product).  Otherwise split: bf16 x 3 (azg_nn_s78_forward_split, 8 samples per
         workgroup, the expanded tile in thirds); False = the f32-MFMA kernel (4 samples per workgroup)"""
         import ctypes as C
+        import math
         from . import _lib
-        self._lib, self.base, self.device, self.split = _lib, base, base.device, bool(split)
+        self._lib, self.base, self.device, self.split, self.h2 = _lib, base, base.device, bool(split) or bool(h2), bool(h2)
         self.P, self.A = base.P, base.A
         assert base.dtype == torch.float32 and self.device.type == 'cuda' and len(base.blocks) == 10 and self.A == 1782 and self.P == 2
+        ke = 12 - int(math.ceil(math.log2(max(float(we.abs().max()) for (we, _), _, _ in base.blocks))))
+        kp = 12 - int(math.ceil(math.log2(max(float(wp.abs().max()) for _, _, (wp, _) in base.blocks))))
+        self.ds_e, self.ds_p = (2.0 ** -ke) / 64.0, (2.0 ** -kp) / 64.0
+
+        def h2_64(m, k):                   # [64 K][64 N] f32 -> [4 ct][2 chunks of 32][2 planes hi, lo][64 lanes][8] f16 of W * 2^k
+            m = m.contiguous().float() * (2.0 ** k)
+            hi = m.to(torch.float16)
+            lo = (m - hi.float()).to(torch.float16)
+            pl = torch.stack([hi, lo]).view(2, 2, 4, 8, 4, 16)                            # plane, chunk, g, j, ct, r
+            return pl.permute(4, 1, 0, 2, 5, 3).contiguous().view(-1)                     # ct, chunk, plane, g, r, j
 
         def split64(m):                    # [64 K][64 N] f32 -> [4 ct][2 chunks of 32][3 planes hi, mid, lo][64 lanes][8] bf16
             m = m.contiguous().float()
@@ -866,7 +878,8 @@ class SantoriniV78Hip(SantoriniV89Hip):
             return pl.permute(4, 1, 0, 2, 5, 3).contiguous().view(-1)                     # ct, chunk, plane, g, r, j
 
         def thirds(ms, of_k):              # the three 64 x 64 pieces of each [64][192] expand / [192][64] project matrix
-            return torch.cat([split64(m[64 * t:64 * t + 64] if of_k else m[:, 64 * t:64 * t + 64]) for m in ms for t in range(3)]).contiguous()
+            pack = (lambda m: h2_64(m, kp if of_k else ke)) if self.h2 else split64
+            return torch.cat([pack(m[64 * t:64 * t + 64] if of_k else m[:, 64 * t:64 * t + 64]) for m in ms for t in range(3)]).contiguous()
         frag = SplendorV80Hip._frag
         d = self.device
         m0 = torch.zeros((9, 16, 64), dtype=torch.float32, device=d)
@@ -902,6 +915,10 @@ class SantoriniV78Hip(SantoriniV89Hip):
         boards = boards.reshape(B, -1)
         assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda and boards.shape[1] == 75
         valids = (valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)).contiguous()
+        if self.h2:
+            self._lib.check(self._lib.lib().azg_nn_s78_forward_h2(p(boards), p(valids), self.ptrs, self.ds_e, self.ds_p, 10, self.A, self.P, B,
+                                                                  p(self.pi), p(self.v), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return self.pi[:B], self.v[:B]
         fwd = self._lib.lib().azg_nn_s78_forward_split if self.split else self._lib.lib().azg_nn_s78_forward
         self._lib.check(fwd(p(boards), p(valids), self.ptrs, 10, self.A, self.P, B, p(self.pi), p(self.v),
                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))

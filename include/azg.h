@@ -325,6 +325,11 @@ int azg_nn_s78_forward(const int8_t* boards_dev, const uint8_t* valid_dev, const
    element = M_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)], M = We[:, 64 t .. 64 t + 63] resp. Wp[64 t .. 64 t + 63, :]. */
 int azg_nn_s78_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int n_blocks, int A, int P,
                              int B, float* pi_dev, float* v_dev, void* stream);
+/* The same with the trunk's 1x1 convolutions and the depthwise pass on f16 x 2 split-precision operands (hi + lo, three
+   v_mfma_f32_16x16x32_f16 per product, two planes per tile holding 64 * x): We / Wp = [n_blocks][3 thirds][4 ct][2 chunks]
+   [2 planes hi, lo][64 lanes][8] f16 of W * 2^k (one k per family), ds_e / ds_p = 2^-k / 64.  Same 1e-5 contract. */
+int azg_nn_s78_forward_h2(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, float ds_e, float ds_p, int n_blocks,
+                          int A, int P, int B, float* pi_dev, float* v_dev, void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
 int azg_nn_board_to_x(const int8_t* boards_dev, float* x_dev, int B, int C, void* stream);
 /* boards int8 [B][C][L] -> x f32 [B][L][ldx], columns C..ldx-1 zeroed (row stride padded to a multiple of 4 floats) */

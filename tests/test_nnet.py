@@ -264,7 +264,7 @@ def test_santorini_v89_one_launch_gpu(split):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('split', [False, True])
+@pytest.mark.parametrize('split', ['h2', False, True])
 def test_santorini_v78_one_launch_gpu(split):
     """SantoriniV78Hip (trunk launch: MFMA 1x1 convolutions -- f32 or split-precision bf16 x 3 --, in-place depthwise 3x3, value head;
     policy FC launch) vs the reference model's own
@@ -273,7 +273,7 @@ def test_santorini_v78_one_launch_gpu(split):
     from azg_amd import nnet
     root = os.path.join(os.path.dirname(__file__), 'golden')
     base = nnet.SantoriniV78.from_npz(os.path.join(root, 'weights_santorini11_v78.npz'), device='cuda:0')
-    net = nnet.SantoriniV78Hip(base, max_batch=64, split=split)
+    net = nnet.SantoriniV78Hip(base, max_batch=64, split=split is True, h2=split == 'h2')    # f16 x 2 (default) / f32 / bf16 x 3 trunk
     d = np.load(os.path.join(root, 'netfwd_santorini11_v78.npz'))
     pi, v = net.predict_batch(torch.from_numpy(d['boards']).to('cuda:0').to(torch.int8).reshape(-1, 75),
                               torch.from_numpy(d['masks']).to('cuda:0'))
