@@ -40,7 +40,7 @@ EXPORTS = [
     'azg_forest_select', 'azg_forest_select_fused', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
     'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_forest_validate', 'azg_selfplay_start', 'azg_selfplay_start_ex', 'azg_selfplay_advance', 'azg_selfplay_active',
     'azg_selfplay_stats_get', 'azg_selfplay_drain_examples', 'azg_forest_last_kernel_ms', 'azg_forest_enable_timing', 'azg_forest_set_search_params', 'azg_nn_linear', 'azg_nn_linear_ws', 'azg_nn_dw_pool', 'azg_nn_v80_block', 'azg_nn_v80_forward', 'azg_nn_v80_forward_split', 'azg_nn_v80_forward_h2',
-    'azg_nn_board_to_x', 'azg_nn_heads_out', 'azg_nn_dw_pool_l', 'azg_nn_board_to_x_ld', 'azg_nn_mb1d_forward', 'azg_nn_conv5_forward', 'azg_nn_conv5_forward_split', 'azg_nn_conv5_forward_h2', 'azg_nn_s78_forward', 'azg_nn_s78_forward_split', 'azg_nn_s78_forward_h2',
+    'azg_nn_board_to_x', 'azg_nn_heads_out', 'azg_nn_dw_pool_l', 'azg_nn_board_to_x_ld', 'azg_nn_mb1d_forward', 'azg_nn_mb1d_forward_h2', 'azg_nn_conv5_forward', 'azg_nn_conv5_forward_split', 'azg_nn_conv5_forward_h2', 'azg_nn_s78_forward', 'azg_nn_s78_forward_split', 'azg_nn_s78_forward_h2',
 ]
 
 
@@ -103,6 +103,7 @@ def lib():
     L.azg_nn_conv5_forward_split.argtypes = [vp, vp, vp, i, i, i, i, vp, vp, vp]
     L.azg_nn_conv5_forward_h2.argtypes = [vp, vp, vp, C.c_float, i, i, i, i, vp, vp, vp]
     L.azg_nn_mb1d_forward.argtypes = [i, vp, vp, vp, i, vp, vp, vp]
+    L.azg_nn_mb1d_forward_h2.argtypes = [i, vp, vp, vp, vp, i, vp, vp, vp]
     L.azg_nn_board_to_x_ld.argtypes = [vp, vp, i, i, i, i, vp]
     L.azg_nn_dw_pool_l.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, i, i, vp]
     L.azg_nn_heads_out.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, i, i, i, vp]

@@ -264,24 +264,26 @@ typedef Mb1dCfg<7, 71, 8, 81, 3, 213, 213, 213, 56, 56, 56, 71, 1, 2, 1> CfgSple
 typedef Mb1dCfg<7, 88, 8, 81, 4, 264, 264, 264, 64, 64, 64, 88, 1, 2, 1> CfgSplendor4;
 typedef Mb1dCfg<6, 23, 16, 180, 2, 115, 115, 46, 32, 32, 16, 46, 1, 2, 0> CfgAzul;
 
-template <class CF>
+template <class CF, bool H2>
 static int launch_mb1d(const Mb1dNetW& N, const int8_t* boards, const uint8_t* valid, int B, float* pi, float* v, hipStream_t s) {
     constexpr size_t lds = (size_t)CF::LDS_FLOATS * sizeof(float);
     static_assert(lds <= 160 * 1024, "geometry does not fit the LDS of a CU");
     static bool attr = false;
     if (!attr) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_mb1d_net<CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_mb1d_net<CF, H2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    k_mb1d_net<CF><<<dim3((B + CF::NS - 1) / CF::NS), dim3(768), lds, s>>>(N, boards, valid, B, pi, v);
+    k_mb1d_net<CF, H2><<<dim3((B + CF::NS - 1) / CF::NS), dim3(768), lds, s>>>(N, boards, valid, B, pi, v);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-extern "C" int azg_nn_mb1d_forward(int geometry, const int8_t* boards, const uint8_t* valid, const float* const* w, int B,
-                                   float* pi, float* v, void* stream) {
-    if (!boards || !valid || !w || !pi || !v || B <= 0) return fail("azg_nn_mb1d_forward: null/empty argument");
+template <bool H2>
+static int mb1d_forward(int geometry, const int8_t* boards, const uint8_t* valid, const float* const* w, const float* descale,
+                        int B, float* pi, float* v, void* stream) {
+    if (!boards || !valid || !w || !pi || !v || B <= 0 || (H2 && !descale)) return fail("azg_nn_mb1d_forward: null/empty argument");
     Mb1dNetW N;
+    for (int i = 0; i < 16; i++) N.ds[i] = H2 ? descale[i] : 1.f;
     N.W0 = w[0]; N.b0 = w[1];
     for (int b = 0; b < 3; b++) {
         const float* const* q = w + 2 + 11 * b;
@@ -291,12 +293,23 @@ extern "C" int azg_nn_mb1d_forward(int geometry, const int8_t* boards, const uin
     N.Wpi1 = h[0]; N.bpi1 = h[1]; N.Wpi2 = h[2]; N.bpi2 = h[3]; N.Wv1 = h[4]; N.bv1 = h[5]; N.Wv2 = h[6]; N.bv2 = h[7];
     hipStream_t s = (hipStream_t)stream;
     switch (geometry) {
-        case AZG_NET_SPLENDOR2: return launch_mb1d<CfgSplendor2>(N, boards, valid, B, pi, v, s);
-        case AZG_NET_SPLENDOR3: return launch_mb1d<CfgSplendor3>(N, boards, valid, B, pi, v, s);
-        case AZG_NET_SPLENDOR4: return launch_mb1d<CfgSplendor4>(N, boards, valid, B, pi, v, s);
-        case AZG_NET_AZUL: return launch_mb1d<CfgAzul>(N, boards, valid, B, pi, v, s);
+        case AZG_NET_SPLENDOR2: return launch_mb1d<CfgSplendor2, H2>(N, boards, valid, B, pi, v, s);
+        case AZG_NET_SPLENDOR3: return launch_mb1d<CfgSplendor3, H2>(N, boards, valid, B, pi, v, s);
+        case AZG_NET_SPLENDOR4: return launch_mb1d<CfgSplendor4, H2>(N, boards, valid, B, pi, v, s);
+        case AZG_NET_AZUL: return launch_mb1d<CfgAzul, H2>(N, boards, valid, B, pi, v, s);
         default: return fail("azg_nn_mb1d_forward: unknown geometry");
     }
+}
+
+extern "C" int azg_nn_mb1d_forward(int geometry, const int8_t* boards, const uint8_t* valid, const float* const* w, int B,
+                                   float* pi, float* v, void* stream) {
+    return mb1d_forward<false>(geometry, boards, valid, w, nullptr, B, pi, v, stream);
+}
+
+// the same forward with the GEMM phases on f16 x 2 split-precision operands: matrices as h2 fragments, descale[16] on the host
+extern "C" int azg_nn_mb1d_forward_h2(int geometry, const int8_t* boards, const uint8_t* valid, const void* const* w,
+                                      const float* descale, int B, float* pi, float* v, void* stream) {
+    return mb1d_forward<true>(geometry, boards, valid, (const float* const*)w, descale, B, pi, v, stream);
 }
 
 // ---- Santorini ResNet V88/V89 (no-gods geometry: A = 162, P = 2, 5 residual blocks), one launch (nn_conv5x5.hip.h) ----

@@ -10,6 +10,7 @@
 // once at kernel start: every padding element that a K loop can reach is then a finite number times a zero weight.
 #pragma once
 #include "nn_kernels.hip.h"
+#include "nn_v80_h2.hip.h"
 
 namespace azg {
 
@@ -21,6 +22,10 @@ struct Mb1dNetW {
     Mb1dBlockW blk[3];                                  // trunk, policy head, value head
     const float *Wpi1, *bpi1, *Wpi2, *bpi2;             // [L*OS -> A] (rows l*OS + c), [A -> A]      fragment order
     const float *Wv1, *bv1, *Wv2, *bv2;                 // [L*OS -> P] fragment order; Wv2 [P][P] plain (in, out)
+    // H2 kernels (k_mb1d_net<CF, true>): every matrix above except Wd / Wv2 is an h2 fragment array (nn_v80_h2.hip.h: K zero-padded
+    // to a multiple of 32, [N/16][K/32][2 planes hi, lo][64 lanes][8] f16 of W * 2^k) and ds[] holds 2^-k / 64 per matrix:
+    // W0, {We, W1, W2, Wp} x 3 blocks, Wpi1, Wpi2, Wv1
+    float ds[16];
 };
 
 constexpr int mb_r16(int n) { return (n + 15) / 16 * 16; }
@@ -82,6 +87,66 @@ __device__ __forceinline__ void mb_gemm(const float* __restrict__ Wfrag, LoadB l
     }
 }
 
+// The same phase on f16 x 2 split-precision operands (nn_v80_h2.hip.h: three v_mfma_f32_16x16x32_f16 per K chunk of 32 instead of
+// eight f32 MFMAs of a quarter of the rate each).  The activations stay f32 in LDS (this kernel's layout is generic) and are split
+// as they are read: 8 values = 20 VALU instructions per three MFMAs, which makes the phase VALU-bound at about a third of the f32
+// MFMA time.  loadB(rt, k0) returns the float4 at K offset k0; KCH32 chunks of 32 (the weights are zero beyond the real K, the LDS
+// holds finite numbers everywhere); `ds` = 2^-k / 64 brings the accumulator back.
+__device__ __forceinline__ void mb_split8(float4 a, float4 b, uint4& hi, uint4& lo) {
+    h2_split2(a.x * H2_AS, a.y * H2_AS, hi.x, lo.x); h2_split2(a.z * H2_AS, a.w * H2_AS, hi.y, lo.y);
+    h2_split2(b.x * H2_AS, b.y * H2_AS, hi.z, lo.z); h2_split2(b.z * H2_AS, b.w * H2_AS, hi.w, lo.w);
+}
+template <int KCH32, int NT, int RTN, int NW, class LoadB, class Epi>
+__device__ __forceinline__ void mb_gemm_h2(const float* __restrict__ Wfrag_, float ds, LoadB loadB, Epi epi) {
+    const uint4* __restrict__ Wfrag = (const uint4*)Wfrag_;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    constexpr int U = NT * RTN;
+    const int u0 = wave * U / NW, u1 = (wave + 1) * U / NW;
+    uint4 wh[KCH32], wl[KCH32];
+    int cur = -1;
+#pragma unroll 1
+    for (int u = u0; u < u1; u++) {
+        const int ct = u / RTN, rt = u - ct * RTN;
+        if (ct != cur) {
+#pragma unroll
+            for (int c = 0; c < KCH32; c++) { wh[c] = H2FRAG(Wfrag, KCH32, ct, c, 0); wl[c] = H2FRAG(Wfrag, KCH32, ct, c, 1); }
+            cur = ct;
+        }
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int c = 0; c < KCH32; c++) {
+            uint4 ah, al;
+            mb_split8(loadB(rt, 32 * c + 8 * g), loadB(rt, 32 * c + 8 * g + 4), ah, al);
+            if (c & 1) a1 = h2_mma(wh[c], wl[c], ah, al, a1); else a0 = h2_mma(wh[c], wl[c], ah, al, a0);
+        }
+        epi(ct, rt, (a0 + a1) * ds);
+    }
+}
+template <int KCH32, int NT, int NW, int AS, int NROWS>
+__device__ __forceinline__ int mb_head_gemm_h2(const float* __restrict__ Wfrag_, float ds, const float* __restrict__ in, int ldi,
+                                               float* __restrict__ RED) {
+    const uint4* __restrict__ Wfrag = (const uint4*)Wfrag_;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int rr = r16 < NROWS ? r16 : 0;
+    constexpr int KS = NT >= NW ? 1 : NW / NT;
+    constexpr int PER = (KCH32 + KS - 1) / KS;
+    for (int u = wave; u < NT * KS; u += NW) {
+        const int ct = u % NT, ks = u / NT;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c_end = (ks + 1) * PER < KCH32 ? (ks + 1) * PER : KCH32;
+#pragma unroll 2
+        for (int c = ks * PER; c < c_end; c++) {
+            const uint4 wh = H2FRAG(Wfrag, KCH32, ct, c, 0), wl = H2FRAG(Wfrag, KCH32, ct, c, 1);
+            uint4 ah, al;
+            mb_split8(*(const float4*)(in + rr * ldi + 32 * c + 8 * g), *(const float4*)(in + rr * ldi + 32 * c + 8 * g + 4), ah, al);
+            acc = h2_mma(wh, wl, ah, al, acc);
+        }
+        acc = acc * ds;
+        *(float4*)(RED + (ks * 16 + r16) * AS + ct * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    return KS;
+}
+
 // Flatten -> Linear on one 16-row tile (rows = samples): K is long and every weight is used once, so the fragments are
 // streamed; the NW waves split (column tile, K slice) and leave partial sums in RED[slice][16][AS].  Returns the slice count.
 template <int KCH, int NT, int NW, int AS, int NROWS>
@@ -110,17 +175,26 @@ __device__ __forceinline__ int mb_head_gemm(const float* __restrict__ Wfrag, con
 }
 
 // InvertedResidual1d block bi (SplendorNNet.py:189-202): IN [ROWSP][XS] -> OUT [..][OSTRIDE]
-template <class CF, int BI, int CIN_P, int OSTRIDE>
+// one GEMM phase in either arithmetic: K16 chunks of 16 for the f32 path, (K16 + 1) / 2 chunks of 32 for the f16 x 2 path
+template <bool H2, int K16, int NT, int RTN, int NW, class LoadK, class Epi>
+__device__ __forceinline__ void mb_gemm_any(const float* __restrict__ Wfrag, float ds, LoadK loadK, Epi epi) {
+    const int g = (threadIdx.x & 63) >> 4;
+    if (H2) mb_gemm_h2<(K16 + 1) / 2, NT, RTN, NW>(Wfrag, ds, loadK, epi);
+    else mb_gemm<K16, NT, RTN, NW>(Wfrag, [&](int rt, int c) { return loadK(rt, 16 * c + 4 * g); }, epi);
+}
+
+template <class CF, int BI, int CIN_P, int OSTRIDE, bool H2 = false>
 __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, float* OUT, float* H, float* PL, float* SC,
-                                         float* SH, float* WD, bool residual) {
+                                         float* SH, float* WD, bool residual, const float* ds = nullptr) {
     constexpr int L = CF::L, NS = CF::NS, NW = CF::NW, RT = CF::RT, XS = CF::XS, HS = CF::HS, QS = CF::QS;
     constexpr int EP = mb_r16(CF::E[BI]), QP = mb_r16(CF::Q[BI]), COP = mb_r16(CF::CO[BI]);
     constexpr int ACT = CF::ACT[BI], PMAX = CF::PMAX[BI];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
     if (tid < L * L) WD[tid] = W.Wd[tid];
     // ---- expand + BN + act -> H ----
-    mb_gemm<CIN_P / 16, EP / 16, RT, NW>(
-        W.We, [&](int rt, int c) { return *(const float4*)(IN + (rt * 16 + r16) * XS + 16 * c + 4 * g); },
+    (void)g;
+    mb_gemm_any<H2, CIN_P / 16, EP / 16, RT, NW>(
+        W.We, H2 ? ds[0] : 1.f, [&](int rt, int k0) { return *(const float4*)(IN + (rt * 16 + r16) * XS + k0); },
         [&](int ct, int rt, f32x4 acc) {
             const float4 b = *(const float4*)(W.be + ct * 16 + 4 * g);
             const f32x2 lo = act_apply2(f32x2{acc[0] + b.x, acc[1] + b.y}, ACT), hi = act_apply2(f32x2{acc[2] + b.z, acc[3] + b.w}, ACT);
@@ -155,16 +229,16 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
     }
     __syncthreads();
     // ---- SE fc1 + ReLU -> SH[16][QS];  SE fc2 + Hardsigmoid -> SC[.][HS]  (rows = samples; rows >= NS are scratch) ----
-    mb_gemm<EP / 16, QP / 16, 1, NW>(
-        W.W1, [&](int, int c) { return *(const float4*)(PL + r16 * HS + 16 * c + 4 * g); },
+    mb_gemm_any<H2, EP / 16, QP / 16, 1, NW>(
+        W.W1, H2 ? ds[1] : 1.f, [&](int, int k0) { return *(const float4*)(PL + r16 * HS + k0); },
         [&](int ct, int, f32x4 acc) {
             const float4 b = *(const float4*)(W.b1 + ct * 16 + 4 * g);
             *(float4*)(SH + r16 * QS + ct * 16 + 4 * g) =
                 make_float4(fmaxf(acc[0] + b.x, 0.f), fmaxf(acc[1] + b.y, 0.f), fmaxf(acc[2] + b.z, 0.f), fmaxf(acc[3] + b.w, 0.f));
         });
     __syncthreads();
-    mb_gemm<QP / 16, EP / 16, 1, NW>(
-        W.W2, [&](int, int c) { return *(const float4*)(SH + r16 * QS + 16 * c + 4 * g); },
+    mb_gemm_any<H2, QP / 16, EP / 16, 1, NW>(
+        W.W2, H2 ? ds[2] : 1.f, [&](int, int k0) { return *(const float4*)(SH + r16 * QS + k0); },
         [&](int ct, int, f32x4 acc) {
             if (r16 < NS) {
                 const float4 b = *(const float4*)(W.b2 + ct * 16 + 4 * g);
@@ -174,12 +248,12 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
         });
     __syncthreads();
     // ---- project (SE-scaled operand) + BN (+ residual) -> OUT ----
-    mb_gemm<EP / 16, COP / 16, RT, NW>(
-        W.Wp,
-        [&](int rt, int c) {
+    mb_gemm_any<H2, EP / 16, COP / 16, RT, NW>(
+        W.Wp, H2 ? ds[3] : 1.f,
+        [&](int rt, int k0) {
             const int row = rt * 16 + r16;
-            float4 a = *(const float4*)(H + row * HS + 16 * c + 4 * g);
-            const float4 s4 = *(const float4*)(SC + (row / L) * HS + 16 * c + 4 * g);
+            float4 a = *(const float4*)(H + row * HS + k0);
+            const float4 s4 = *(const float4*)(SC + (row / L) * HS + k0);
             a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
             return a;
         },
@@ -196,7 +270,7 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
     __syncthreads();
 }
 
-template <class CF>
+template <class CF, bool H2 = false>
 __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __restrict__ boards,
                                                   const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
                                                   float* __restrict__ v_out) {
@@ -225,22 +299,24 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
         }
     }
     __syncthreads();
-    mb_gemm<CP / 16, CP / 16, RT, NW>(
-        N.W0, [&](int rt, int c) { return *(const float4*)(X0 + (rt * 16 + r16) * XS + 16 * c + 4 * g); },
+    (void)g;
+    mb_gemm_any<H2, CP / 16, CP / 16, RT, NW>(
+        N.W0, N.ds[0], [&](int rt, int k0) { return *(const float4*)(X0 + (rt * 16 + r16) * XS + k0); },
         [&](int ct, int rt, f32x4 acc) {
             const float4 b = *(const float4*)(N.b0 + ct * 16 + 4 * g);
             *(float4*)(XA + (rt * 16 + r16) * XS + ct * 16 + 4 * g) = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
         });
     __syncthreads();
-    mb_block<CF, 0, CP, XS>(N.blk[0], XA, X2, H, PL, SC, SH, WD, true);
+    mb_block<CF, 0, CP, XS, H2>(N.blk[0], XA, X2, H, PL, SC, SH, WD, true, N.ds + 1);
 
     // ================= policy head =================
-    mb_block<CF, 1, CP, OS>(N.blk[1], X2, XA, H, PL, SC, SH, WD, CF::CO[1] == C);
+    mb_block<CF, 1, CP, OS, H2>(N.blk[1], X2, XA, H, PL, SC, SH, WD, CF::CO[1] == C, N.ds + 5);
     {
         constexpr int KCH1 = (L * OS + 15) / 16, NT1 = CF::AP / 16;
         float* RED = H;
         float* HID = RED + CF::KS_PI * 16 * AS;
-        const int ks1 = mb_head_gemm<KCH1, NT1, NW, AS, NS>(N.Wpi1, XA, L * OS, RED);
+        const int ks1 = H2 ? mb_head_gemm_h2<(KCH1 + 1) / 2, NT1, NW, AS, NS>(N.Wpi1, N.ds[13], XA, L * OS, RED)
+                           : mb_head_gemm<KCH1, NT1, NW, AS, NS>(N.Wpi1, XA, L * OS, RED);
         __syncthreads();
         for (int i = tid; i < 16 * (CF::AP / 4); i += NW * 64) {
             const int s = i / (CF::AP / 4), col = 4 * (i - s * (CF::AP / 4));
@@ -252,7 +328,8 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
             *(float4*)(HID + s * AS + col) = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         }
         __syncthreads();
-        const int ks2 = mb_head_gemm<NT1, NT1, NW, AS, 16>(N.Wpi2, HID, AS, RED);
+        const int ks2 = H2 ? mb_head_gemm_h2<(NT1 + 1) / 2, NT1, NW, AS, 16>(N.Wpi2, N.ds[14], HID, AS, RED)
+                           : mb_head_gemm<NT1, NT1, NW, AS, 16>(N.Wpi2, HID, AS, RED);
         __syncthreads();
         // masked softmax == exp(log_softmax(where(valid, logits, -1e8))) (GenericNNetWrapper.py:105-107), one wave per sample
         for (int s = wave; s < nb; s += NW) {
@@ -283,11 +360,12 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
     }
 
     // ================= value head =================
-    mb_block<CF, 2, CP, OS>(N.blk[2], X2, XA, H, PL, SC, SH, WD, true);
+    mb_block<CF, 2, CP, OS, H2>(N.blk[2], X2, XA, H, PL, SC, SH, WD, true, N.ds + 9);
     {
         constexpr int KCH1 = (L * OS + 15) / 16;
         float* RED = H;                      // [NW][16][20]
-        const int ks = mb_head_gemm<KCH1, 1, NW, 20, NS>(N.Wv1, XA, L * OS, RED);
+        const int ks = H2 ? mb_head_gemm_h2<(KCH1 + 1) / 2, 1, NW, 20, NS>(N.Wv1, N.ds[15], XA, L * OS, RED)
+                          : mb_head_gemm<KCH1, 1, NW, 20, NS>(N.Wv1, XA, L * OS, RED);
         __syncthreads();
         if (tid < nb * P) {
             const int s = tid / P, p = tid - s * P;

@@ -464,10 +464,11 @@ class MobileNet1dHip:
 
     _WS_CHUNKS = (1, 2, 3, 4, 6, 8, 11, 17, 25)
 
-    def __init__(self, base, max_batch=4096, fused=True):
+    def __init__(self, base, max_batch=4096, fused=True, h2=True):
         from . import _lib
         self._lib = _lib
         self.base = base
+        self.h2 = h2
         self.device = base.device
         self.P, self.A, self.C = base.P, base.A, base.nb_vect
         self.L = getattr(base, 'L', 7)
@@ -541,6 +542,37 @@ class MobileNet1dHip:
         assert len(keep) == 43
         self._fused_keep = keep
         self.fused_ptrs = (C.c_void_p * 43)(*[t.data_ptr() for t in keep])
+        # azg_nn_mb1d_forward_h2: the same table with the matrices as f16 x 2 fragments (K padded to multiples of 32)
+        import math
+        r32 = lambda n: (r16(n) + 31) // 32 * 32  # noqa: E731
+        desc = []
+
+        def fh(W):
+            m = padw(W, r32(W.shape[0]), r16(W.shape[1]))
+            K, N = m.shape
+            k = 12 - int(math.ceil(math.log2(max(float(m.abs().max()), 1e-30))))
+            m = m * (2.0 ** k)
+            hi = m.to(torch.float16)
+            lo = (m - hi.float()).to(torch.float16)
+            assert bool(torch.isfinite(hi.float()).all())
+            desc.append((2.0 ** -k) / 64.0)
+            pl = torch.stack([hi, lo]).view(2, K // 32, 4, 8, N // 16, 16)                # plane, chunk, g, j, tile, r
+            return pl.permute(4, 1, 0, 2, 5, 3).contiguous().view(-1)                      # tile, chunk, plane, g, r, j
+
+        def flat_rows(W, cout):
+            w = torch.zeros((L, OS, W.shape[1]), dtype=torch.float32, device=W.device)
+            w[:, :cout] = W.view(L, cout, W.shape[1])
+            return w.view(L * OS, W.shape[1])
+        k2 = list(keep)
+        k2[0] = fh(base.W0)
+        for b, blk in enumerate((base.trunk, base.head_pi, base.head_v)):
+            o = 2 + 11 * b
+            k2[o], k2[o + 5], k2[o + 7], k2[o + 9] = fh(blk.We), fh(blk.W1), fh(blk.W2), fh(blk.Wp)
+        k2[35], k2[37], k2[39] = fh(flat_rows(base.Wpi1, co_pi)), fh(base.Wpi2), fh(flat_rows(base.Wv1, co_v))
+        assert len(desc) == 16
+        self._fused_keep_h2 = k2
+        self.fused_ptrs_h2 = (C.c_void_p * 43)(*[t.data_ptr() for t in k2])
+        self.descale_h2 = (C.c_float * 16)(*desc)
 
     def _alloc(self, B):
         d, f = self.device, torch.float32
@@ -600,8 +632,12 @@ class MobileNet1dHip:
         assert boards.dtype == torch.int8 and boards.is_contiguous() and boards.is_cuda
         valids = valids if valids.dtype == torch.uint8 else valids.to(torch.uint8)
         if self.fused:                                  # the whole forward in one launch (nn_mb1d.hip.h)
-            self._lib.check(Lb.azg_nn_mb1d_forward(self.geometry, p(boards), p(valids.contiguous()), self.fused_ptrs, B,
-                                                   p(self.pi), p(self.v), st))
+            if self.h2:
+                self._lib.check(Lb.azg_nn_mb1d_forward_h2(self.geometry, p(boards), p(valids.contiguous()), self.fused_ptrs_h2,
+                                                          self.descale_h2, B, p(self.pi), p(self.v), st))
+            else:
+                self._lib.check(Lb.azg_nn_mb1d_forward(self.geometry, p(boards), p(valids.contiguous()), self.fused_ptrs, B,
+                                                       p(self.pi), p(self.v), st))
             return self.pi[:B], self.v[:B]
         self._lib.check(Lb.azg_nn_board_to_x_ld(p(boards), p(self.x0), B, self.C, self.L, self.Cp, st))
         self._lin(self.x0, self.Cp, self.pW0, self.pb0, self.x1, self.Cp, B * self.L, self.Cp, self.C)       # first_layer

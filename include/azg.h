@@ -287,6 +287,12 @@ int azg_nn_v80_forward_h2(const int8_t* boards_dev, const uint8_t* valid_dev, co
 enum { AZG_NET_SPLENDOR2 = 0, AZG_NET_SPLENDOR3 = 1, AZG_NET_SPLENDOR4 = 2, AZG_NET_AZUL = 3 };
 int azg_nn_mb1d_forward(int geometry, const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int B,
                         float* pi_dev, float* v_dev, void* stream);
+/* The same forward with every GEMM phase on f16 x 2 split-precision operands (hi + lo halves, three v_mfma_f32_16x16x32_f16 per
+   K chunk of 32, fp32 accumulation: <= 1e-5 of the fp32 forward); the activations stay fp32 in the LDS and are split as they
+   are read.  w: the same 43 pointers, every matrix but Wd / Wv2 as an azg_nn_v80_forward_h2 fragment array (K zero-padded to a
+   multiple of 32: 16*ceil(K/16) rounded up; N to a multiple of 16); descale_host[16] as there. */
+int azg_nn_mb1d_forward_h2(int geometry, const int8_t* boards_dev, const uint8_t* valid_dev, const void* const* w,
+                           const float* descale_host, int B, float* pi_dev, float* v_dev, void* stream);
 /* The Santorini ResNet (santorini/SantoriniNNet.py nn_version 88/89 :194-219,273-281: conv3x3(2->64)+BN+ReLU, n_blocks
    SimpleResBlocks :71-84, SimpleHead heads :17-40) in one launch.  boards int8 [B][5][5][3] (planes 0, 1 are the net's
    input), valid u8 [B][A] -> pi f32 [B][A], v f32 [B][P].  w = 14 device pointers {W0, b0, Wc, bc, Wp, bp, Wfp, bfp, Wv, bv,

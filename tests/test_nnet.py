@@ -208,7 +208,7 @@ def test_v80_4p_forward_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('fused', [False, True], ids=['launches17', 'fused'])
+@pytest.mark.parametrize('fused', [False, True, 'h2'], ids=['launches17', 'fused_f32', 'fused_h2'])
 @pytest.mark.parametrize('tag', ['splendor2_v80', 'splendor4_v80', 'azul_v84'])
 def test_mobilenet1d_engine_kernels_gpu(tag, fused):
     """MobileNet1dHip (engine GEMM / depthwise / head kernels, any geometry) vs the reference models' golden outputs, and at
@@ -220,8 +220,9 @@ def test_mobilenet1d_engine_kernels_gpu(tag, fused):
     else:
         npl = 4 if tag.startswith('splendor4') else 2
         base = nnet.SplendorV80.from_npz(os.path.join(root, 'weights_%s.npz' % tag), num_players=npl, device='cuda:0')
-    net = nnet.MobileNet1dHip(base, max_batch=64, fused=fused)
-    assert net.fused == fused
+    # one launch with the GEMM phases on f16 x 2 split-precision operands (default) / on f32 MFMAs / 17 launches
+    net = nnet.MobileNet1dHip(base, max_batch=64, fused=bool(fused), h2=fused == 'h2')
+    assert net.fused == bool(fused)
     d = np.load(os.path.join(root, 'netfwd_%s.npz' % tag))
     boards = torch.from_numpy(d['boards']).to('cuda:0')
     masks = torch.from_numpy(d['masks']).to('cuda:0')

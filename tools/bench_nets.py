@@ -28,7 +28,8 @@ for tag, mk, shape, A in [('splendor2', lambda: nnet.SplendorV80.from_npz(G + '/
     valids[:, -1] = 1
     row = {'torch ops': timed(base, boards, valids.bool(), 10),
            '17 launches': timed(nnet.MobileNet1dHip(base, max_batch=T, fused=False), boards, valids),
-           'k_mb1d_net': timed(nnet.MobileNet1dHip(base, max_batch=T, fused=True), boards, valids)}
+           'k_mb1d_net f32': timed(nnet.MobileNet1dHip(base, max_batch=T, fused=True, h2=False), boards, valids),
+           'k_mb1d_net h2': timed(nnet.MobileNet1dHip(base, max_batch=T, fused=True, h2=True), boards, valids)}
     if tag == 'splendor2':
         row['k_v80_net'] = timed(nnet.SplendorV80Hip.from_npz(G + '/weights_splendor2_v80.npz', max_batch=T), boards, valids)
     print(tag, 'T=%d' % T, '  '.join('%s %.1f us' % kv for kv in row.items()), flush=True)
