@@ -271,7 +271,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     D.forced_playouts = cfg->forced_playouts;
     D.level_budget = cfg->level_budget;
     D.work_budget = cfg->work_budget;
-    { const char* e = getenv("AZG_SPEC_STATE"); D.spec_state = e ? atoi(e) : 1; }
+    { const char* e = getenv("AZG_SPEC_STATE"); D.spec_state = e ? atoi(e) : 8; }
     D.cpuct = cfg->cpuct; D.fpu = cfg->fpu; D.prob_fullMCTS = cfg->prob_fullMCTS;
     D.dirichletAlpha = cfg->dirichletAlpha;
     D.temp_begin = cfg->temperature[0]; D.temp_end = cfg->temperature[1]; D.temp_root = cfg->temperature[2];

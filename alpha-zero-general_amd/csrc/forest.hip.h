@@ -121,8 +121,9 @@ struct ForestDev {
                                        // node's record the same size, so a freed record fits any later node
     int level_budget;                  // max descent levels per tree per k_select launch (0 = unlimited)
     int work_budget;                   // max work units (level = 1, edge resolution = AZG_EDGE_UNITS) per tree per launch
-    int spec_state;                    // one-class forests: fetch the node's state with its entries at every level (the frontier edge then finds
-                                       // its parent state in registers); 0 = fetch it when an edge is resolved (AZG_SPEC_STATE=0, A/B runs)
+    int spec_state;                    // one-class forests: fetch the node's state with its entries (the frontier edge then finds its parent
+                                       // state in registers): 1 = at every level, N >= 2 = at nodes reached over an edge with < N visits
+                                       // (default 8), 0 = never, i.e. when an edge is resolved (AZG_SPEC_STATE, A/B runs)
     uint32_t episode_quota;            // self-play: total games this forest plays (azg_selfplay_start_ex), 0 = restart forever
     double cpuct, fpu, prob_fullMCTS, dirichletAlpha, temp_begin, temp_end, temp_root, tempThreshold;
     uint64_t rng_seed, stream0;

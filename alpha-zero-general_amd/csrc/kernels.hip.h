@@ -599,7 +599,11 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     };
     const uint32_t l_hot = hot_off((uint32_t)l), l_child0 = child_off((uint32_t)l, 0u), l_id = id_off((uint32_t)l);
     const uint32_t child_ustride = (one_page ? RG.PC : 32u) * 4u;
+    // F.spec_state: 0 = never, 1 = at every level, N >= 2 = only at nodes reached over an edge with fewer than N visits (a node
+    // with few visits is where the descent meets the frontier; the much-visited top of the tree almost never is, and its 3 x 128-B
+    // state lines per level were a quarter of the kernel's fetches)
     const bool spec_state = F.spec_state && F.cls_q == G::A && FR::SPW <= 192;
+    const uint32_t spec_below = F.spec_state >= 2 ? (uint32_t)F.spec_state : 0xFFFFFFFFu;
     const float inv_units1 = 1.0f / (float)FR::cls_units(F, 1);
     bool need_nn = false;
     uint32_t c_sims = 0, c_levels = 0, c_sumvalid = 0, c_term = 0, levels_this_launch = 0, edges_this_launch = 0, work_units = 0;
@@ -617,6 +621,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         bool have_leaf = false, leaf_terminal = false;
         float es[G::P];
         uint32_t rec;
+        uint32_t n_in = H.sim_idx;                           // visits of the edge the descent came over (root: simulations so far)
         if (H.mid_sim) {
             // resume a descent that the level budget paused in an earlier launch
             H.mid_sim = 0;
@@ -672,7 +677,8 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             // one-class forests: record slot == node id, so the node's state is addressable before its header arrives --
             // fetch it with the entries (this level is the frontier of ~20 % of the descents; saves that round trip)
             uint32_t ps0 = 0, ps1 = 0, ps2 = 0;
-            if (spec_state) {
+            const bool spec_now = spec_state && n_in < spec_below;
+            if (spec_now) {
                 const uint32_t nid = (uint32_t)((float)rec * inv_units1 + 0.5f);
                 const uint32_t* nsp = (const uint32_t*)FR::nstate(F, t, nid);
                 ps0 = nsp[l];
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 const bool act = l < nv;
                 double best_u = -INFINITY;
                 int best_j = 0x7FFFFFFF;
-                uint32_t best_ch = AZG_NONE, best_id = 0;
+                uint32_t best_ch = AZG_NONE, best_id = 0, best_n = 0;
                 for (int base = 0; base < nv; base += 64) {
                     uint32_t chv = ch0, idv = id0;
                     bool a_ok = act;
@@ -726,6 +732,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                             j = base + src;
                             child = (uint32_t)__builtin_amdgcn_readlane((int)chv, src);
                             a_sel = __builtin_amdgcn_readlane((int)idv, src);
+                            n_in = (uint32_t)__builtin_amdgcn_readlane((int)n, src);
                             break;
                         }
                     }
@@ -737,6 +744,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     best_j = take ? jj : best_j;
                     best_ch = take ? chv : best_ch;
                     best_id = take ? idv : best_id;
+                    best_n = take ? n : best_n;
                 }
                 if (j < 0) {
                     // wave arg-max, lowest index on ties (== ascending scan with strict '>', MCTS.py:216-228): reduce the
@@ -755,6 +763,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     j = __builtin_amdgcn_readlane(best_j, src);
                     child = (uint32_t)__builtin_amdgcn_readlane((int)best_ch, src);
                     a_sel = __builtin_amdgcn_readlane((int)best_id, src);
+                    n_in = (uint32_t)__builtin_amdgcn_readlane((int)best_n, src);
                 }
             }
             c_levels++;
@@ -772,7 +781,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 bool is_new = false;
                 const long long t_e = AZG_CLK();
                 child = uni_u32(resolve_edge<G, SelState>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es,
-                                                          srng, spec_state, ps0, ps1, ps2));
+                                                          srng, spec_now, ps0, ps1, ps2));
                 cyc_edge += AZG_CLK() - t_e;
                 if (child == AZG_NONE) { H.sim_idx = H.n_sims; break; }
                 // memoise: this universe's slot -- or every slot when the env step of `a` cannot depend on the seed (the

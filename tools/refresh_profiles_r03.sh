@@ -32,5 +32,7 @@ done
 python bench.py --game azul --sims 1600 --games 2048 --node-capacity 56000 --steps 25 --warmup 5 --no-cpu-baseline --roofline-rounds 100 2>/dev/null | tail -1 > $O/bench_azul1600.json
 python tools/time_v80.py > $O/time_v80.txt 2>&1
 python tools/time_v89.py > $O/time_v89.txt 2>&1
+python tools/time_v78.py > $O/time_v78.txt 2>&1
+python tools/bench_nets.py 4096 2>/dev/null > $O/bench_nets.txt
 tail -c 600 $O/bench.json
 cat $O/pytest.txt
