@@ -250,6 +250,11 @@ extern "C" int azg_nn_debug_phase_times(long long* out /* [4][16] */) {
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v80_phase), sizeof(long long) * 64));
     return 0;
 }
+extern "C" int azg_nn_debug_phase_times_c5(long long* out /* [32] */) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c5_phase), sizeof(long long) * 32));
+    return 0;
+}
 extern "C" int azg_nn_debug_phase_times_h2(long long* out /* [4][16] */) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h2_phase), sizeof(long long) * 64));

@@ -8,6 +8,7 @@
 // the accumulators of its (at most 5) cell tiles across the three kernel rows.  The heads are a few thousand MACs per
 // sample and run on the vector ALUs.  (MIOpen's Winograd path needs 11 launches of ~100 us for the same batch.)
 #pragma once
+#include <type_traits>
 #include "nn_kernels.hip.h"
 #include "nn_mb1d.hip.h"
 
@@ -145,6 +146,93 @@ __device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wf
     }
 }
 
+// The first convolution on one f16 MFMA chunk: K = 9 taps x 2 board planes = 18 of the 32 (k = 2 * tap + plane).  The board values are
+// small integers (exact in f16, no lo half), the weights split hi + lo on the fly from the f32 fragments: two v_mfma_f32_16x16x32_f16 per
+// row tile instead of eighteen v_mfma_f32_16x16x4_f32 (a sixteenth of the rate each).  Output written as f16 x 2 planes.
+template <int NS, bool RELU = true>
+__device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag, const float* __restrict__ bias,
+                                                 const float* IN, uint8_t* OUT) {
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
+    constexpr float WS = 256.f;                             // weight scale (|w| < 255 keeps the hi half finite)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int ct = wave & 3, rg = wave >> 2;
+    uint4 wh, wl;
+    {
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int tap = 4 * g + (j >> 1);
+            wv[j] = tap < 9 ? Wfrag[((((size_t)ct * 9 + tap) * 64 + r16) << 2) + (j & 1)] * WS : 0.f;
+        }
+        h2_split2(wv[0], wv[1], wh.x, wl.x); h2_split2(wv[2], wv[3], wh.y, wl.y);
+        h2_split2(wv[4], wv[5], wh.z, wl.z); h2_split2(wv[6], wv[7], wh.w, wl.w);
+    }
+    const float4 b = *(const float4*)(bias + ct * 16 + 4 * g);
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) {
+        const int rt = rg + RG * i, r = rt * 16 + r16;
+        if (rt >= RT) continue;
+        const int cell = r % 25, y = cell / 5, x = cell - 5 * y;
+        uint32_t bv[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int tap = 4 * g + jj, dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+            const bool on = r < ROWS && tap < 9 && y + dy >= 0 && y + dy < 5 && x + dx >= 0 && x + dx < 5;
+            const float2 v = *(const float2*)(IN + (on ? r + dy * 5 + dx : 0) * CS);
+            bv[jj] = on ? __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{v.x, v.y}, f16x2_t)) : 0u;
+        }
+        const f16x8 bh = __builtin_bit_cast(f16x8, make_uint4(bv[0], bv[1], bv[2], bv[3]));
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl), bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), bh, acc, 0, 0, 0);
+        if (r < ROWS) {
+            f32x4 o = acc * (1.f / WS) + f32x4{b.x, b.y, b.z, b.w};
+            if (RELU) o = f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
+            h2_store4(OUT, PB, 128, r, ct * 16 + 4 * g, o);
+        }
+    }
+}
+
+// The two 1x1-convolution heads of the SimpleHead pair (policy: 64 -> 2 channels, value: 64 -> 1; + folded BN + ReLU) on the trunk's
+// f16 x 2 planes: one MFMA column tile (channels 0, 1 = policy, 2 = value, the rest zero), weights split on the fly from the f32
+// matrices Wp [64][2] / Wv [64][1]; wave w owns row tile w (wave 0 the 13th as well).  HP [NS][2 * 25] (channel-major), HV [NS][25].
+template <int NS>
+__device__ __forceinline__ void heads1x1_h2(const float* __restrict__ Wp, const float* __restrict__ bp, const float* __restrict__ Wv,
+                                            const float* __restrict__ bv, const uint8_t* IN, float* HP, float* HV) {
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, PB = (ROWS + 1) * 128;
+    constexpr float WS = 256.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    uint4 wh[2], wl[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = 32 * c + 8 * g + j;
+            wv[j] = (r16 < 2 ? Wp[k * 2 + r16] : r16 == 2 ? Wv[k] : 0.f) * WS;
+        }
+        h2_split2(wv[0], wv[1], wh[c].x, wl[c].x); h2_split2(wv[2], wv[3], wh[c].y, wl[c].y);
+        h2_split2(wv[4], wv[5], wh[c].z, wl[c].z); h2_split2(wv[6], wv[7], wh[c].w, wl[c].w);
+    }
+    const float b0 = bp[0], b1 = bp[1], b2 = bv[0];
+    for (int rt = wave; rt < RT; rt += 12) {
+        const int r = rt * 16 + r16, rr = r < ROWS ? r : ROWS;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint8_t* src = IN + pl_off(rr, 4 * c + g);
+            acc = h2_mma(wh[c], wl[c], *(const uint4*)src, *(const uint4*)(src + PB), acc);
+        }
+        if (g == 0 && r < ROWS) {                           // lanes of g = 0 hold output channels 0..3 of row r
+            const float ds = 1.f / (WS * H2_AS);
+            const int smp = r / 25, cell = r - 25 * smp;
+            HP[smp * 50 + cell] = fmaxf(acc[0] * ds + b0, 0.f);
+            HP[smp * 50 + 25 + cell] = fmaxf(acc[1] * ds + b1, 0.f);
+            HV[smp * 25 + cell] = fmaxf(acc[2] * ds + b2, 0.f);
+        }
+    }
+}
+
 struct SplitFrag { uint4 h, m, l; };                        // operand fragments of one (tile, tap, K chunk of 32)
 #define AZG_BF(x) __builtin_bit_cast(bf16x8, x)
 
@@ -152,9 +240,10 @@ struct SplitFrag { uint4 h, m, l; };                        // operand fragments
 // NPL = 3: bf16 x 3 (hi + mid + lo, six MFMAs per product).  NPL = 2: f16 x 2 (hi + lo: 22 significant bits, three
 // v_mfma_f32_16x16x32_f16 per product -- lo*hi, hi*lo, hi*hi; nn_v80_h2.hip.h): two planes per tile, the activation planes hold
 // 64 * x, the weight fragments W * 2^k, `descale` = 2^-k / 64 brings the accumulator back
-template <int NS, int NPL = 3>
+template <int NS, int NPL = 3, bool PRELOADED = false>
 __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, const float* __restrict__ bias, const uint8_t* IN,
-                                              uint8_t* OUT, const uint8_t* RES, float descale = 1.f) {
+                                              uint8_t* OUT, const uint8_t* RES, float descale = 1.f,
+                                              const uint4* __restrict__ WNEXT = nullptr, uint4 (*wio)[6][3] = nullptr) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128, KCH = 18;
     static_assert(MAXT == 5 && RT - RG * (MAXT - 1) == 1, "step schedule: two tile pairs per wave + one odd tile in the first row group");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
@@ -200,13 +289,67 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, AZG_BF(a.m), acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, AZG_BF(a.h), acc[i], 0, 0, 0);
     };
-#pragma unroll 1
-    for (int ky = 0; ky < 3; ky++) {
-        uint4 w[6][3];                                      // [kx * 2 + c][plane]: the weight fragments of one kernel row
+    // the weight fragments of one kernel row, [kx * 2 + c][plane].  NPL == 2: a fragment's registers are refilled with the next
+    // kernel row's fragment as soon as its tiles are issued (rolling prefetch: the L2 round trip of a row's weights hides behind
+    // the five other fragments' MFMAs instead of stalling all twelve waves at the top of every kernel row); WNEXT = the next
+    // convolution's fragments, whose first row is requested during the last row of this one and handed over in `w`
+    uint4 w[6][3];
+    auto wfrag = [&](const uint4* __restrict__ W, int ky, int c6, int p) { return W[(((size_t)ct * KCH + ky * 6 + c6) * NPL + p) * 64 + lane]; };
+    if (!PRELOADED) {
 #pragma unroll
         for (int c6 = 0; c6 < 6; c6++)
 #pragma unroll
-            for (int p = 0; p < 3; p++) w[c6][p] = p < NPL ? Wfrag[(((size_t)ct * KCH + ky * 6 + c6) * NPL + p) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+            for (int p = 0; p < 3; p++) w[c6][p] = p < NPL ? wfrag(Wfrag, 0, c6, p) : make_uint4(0u, 0u, 0u, 0u);
+    } else {
+#pragma unroll
+        for (int c6 = 0; c6 < 6; c6++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) w[c6][p] = (*wio)[c6][p];
+    }
+    if constexpr (NPL == 2) {
+        // software pipeline: the operands of step s + 2 are requested before the MFMAs of step s are issued (hipcc emits
+        // ds_read pair -> s_waitcnt -> three MFMAs per step otherwise, i.e. every step waits out an LDS round trip), across the
+        // kernel rows as well; a step = (fragment k6 = s / NT: tap ky * 3 + k6 / 2, K chunk k6 & 1; tile s % NT).  The waves with
+        // the odd 13th row tile run the NT = MAXT instance, the others NT = MAXT - 1 (wave-uniform branch)
+        auto run = [&](auto nt_tag) {
+            constexpr int NT = decltype(nt_tag)::value, S = 6 * NT;
+            auto ld = [&](int ky, int sidx) {
+                const int k6 = sidx / NT, i = sidx % NT, kx = k6 >> 1, c = k6 & 1;
+                const bool on = (tapmask[i] >> (ky * 3 + kx)) & 1u;
+                const int r = on ? row[i] + (ky - 1) * 5 + (kx - 1) : ROWS;
+                const uint8_t* src = IN + pl_off(r, 4 * c + g);
+                return SplitFrag{*(const uint4*)src, *(const uint4*)(src + PB), make_uint4(0u, 0u, 0u, 0u)};
+            };
+            SplitFrag f0 = ld(0, 0), f1 = ld(0, 1);
+#pragma unroll 1
+            for (int ky = 0; ky < 3; ky++) {
+                const uint4* __restrict__ Wn = ky < 2 ? Wfrag : (WNEXT ? WNEXT : Wfrag);
+                const int kyn = ky < 2 ? ky + 1 : 0;
+                const int kyl = ky < 2 ? ky + 1 : 2;            // (the two look-ahead reads past the last row are not used)
+#pragma unroll
+                for (int sidx = 0; sidx < S; sidx++) {
+                    const SplitFrag fn = sidx + 2 < S ? ld(ky, sidx + 2) : ld(kyl, sidx + 2 - S);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int k6 = sidx / NT, i = sidx % NT;
+                    acc[i] = h2_mma(w[k6][0], w[k6][1], f0.h, f0.m, acc[i]);
+                    if (i == NT - 1) { w[k6][0] = wfrag(Wn, kyn, k6, 0); w[k6][1] = wfrag(Wn, kyn, k6, 1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    f0 = f1; f1 = fn;
+                }
+            }
+        };
+        if (last_slot) run(std::integral_constant<int, MAXT>{}); else run(std::integral_constant<int, MAXT - 1>{});
+    } else
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ky++) {
+        if (NPL == 3 && ky > 0) {
+#pragma unroll
+            for (int c6 = 0; c6 < 6; c6++)
+#pragma unroll
+                for (int p = 0; p < 3; p++) w[c6][p] = wfrag(Wfrag, ky, c6, p);
+        }
+        const uint4* __restrict__ Wn = ky < 2 ? Wfrag : WNEXT;
+        const int kyn = ky < 2 ? ky + 1 : 0;
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
 #pragma unroll
@@ -215,8 +358,18 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 #pragma unroll
                 for (int i = 0; i < MAXT - 1; i++) step(i, ky * 3 + kx, c, wh, wm, wl);      // straight-line: consecutive tiles
                 if (last_slot) step(MAXT - 1, ky * 3 + kx, c, wh, wm, wl);                    // use different accumulators
+                if (NPL == 2 && Wn) {
+                    w[kx * 2 + c][0] = wfrag(Wn, kyn, kx * 2 + c, 0);
+                    w[kx * 2 + c][1] = wfrag(Wn, kyn, kx * 2 + c, 1);
+                }
             }
         }
+    }
+    if (wio) {
+#pragma unroll
+        for (int c6 = 0; c6 < 6; c6++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) (*wio)[c6][p] = w[c6][p];
     }
     const float4 b = *(const float4*)(bias + ct * 16 + 4 * g);
 #pragma unroll
@@ -280,6 +433,12 @@ __device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t*
 }
 #undef AZG_BF
 
+#ifdef AZG_NN_PHASE_TIMES
+__device__ long long g_c5_phase[32];
+#define C5_PH(k) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_c5_phase[k] = clock64(); } while (0)
+#else
+#define C5_PH(k) do { } while (0)
+#endif
 // SPLIT: the trunk on bf16 x 3 operands (above; N.Wc then points to the split fragments); LDS = 2 tiles x 3 planes x (ROWS + 1) x 128 B
 template <int NB, int A, int P, int SPLIT = 0>
 __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __restrict__ boards,
@@ -292,6 +451,8 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     float* Y = SPLIT ? (float*)((uint8_t*)smem + TILE_B) : X + ROWS * CS;               // [ROWS][CS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
+    bool heads_done = false;
+    C5_PH(0);
     // ---- board int8 [s][y][x][3] -> Y[s*25 + cell][plane 0..1], channels 2..15 zero (the first conv reads 16) ----
     for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(Y + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -300,30 +461,62 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         Y[r * CS + pl] = (float)boards[(size_t)b0 * 75 + r * 3 + pl];
     }
     __syncthreads();
+    C5_PH(1);
     if (SPLIT) {
         uint8_t* XP = (uint8_t*)X;
         uint8_t* YP = (uint8_t*)Y;
         if (tid < NPL * 32) ((uint32_t*)(XP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // X's zero rows
-        conv3x3_first_split<NS, true, NPL>(N.W0, N.b0, Y, XP);   // (Y still holds the f32 board staging tile)
-        __syncthreads();
-        if (tid < NPL * 32) ((uint32_t*)(YP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // Y's (the staging tile is dead)
         constexpr size_t CONV_U4 = (size_t)4 * 18 * NPL * 64;   // uint4 per convolution
+        uint4 wreg[6][3];                                        // NPL == 2: the trunk's weight fragments travel from one convolution
+        if (NPL == 2) {                                          // to the next in registers (conv3x3_split, rolling prefetch)
+            const int ct = wave & 3;
+#pragma unroll
+            for (int c6 = 0; c6 < 6; c6++) {
+                wreg[c6][0] = ((const uint4*)N.Wc)[(((size_t)ct * 18 + c6) * 2 + 0) * 64 + lane];
+                wreg[c6][1] = ((const uint4*)N.Wc)[(((size_t)ct * 18 + c6) * 2 + 1) * 64 + lane];
+                wreg[c6][2] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        if (NPL == 2) conv3x3_first_h2<NS, true>(N.W0, N.b0, Y, XP);
+        else conv3x3_first_split<NS, true, NPL>(N.W0, N.b0, Y, XP);   // (Y still holds the f32 board staging tile)
+        __syncthreads();
+        C5_PH(2);
+        if (tid < NPL * 32) ((uint32_t*)(YP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // Y's (the staging tile is dead)
 #pragma unroll 1
         for (int blk = 0; blk < NB; blk++) {
-            conv3x3_split<NS, NPL>((const uint4*)N.Wc + (size_t)(2 * blk) * CONV_U4, N.bc + (2 * blk) * 64, XP, YP, nullptr, descale);
+            const uint4* W1 = (const uint4*)N.Wc + (size_t)(2 * blk) * CONV_U4;
+            if (NPL == 2) {
+                conv3x3_split<NS, NPL, true>(W1, N.bc + (2 * blk) * 64, XP, YP, nullptr, descale, W1 + CONV_U4, &wreg);
+                __syncthreads();
+                conv3x3_split<NS, NPL, true>(W1 + CONV_U4, N.bc + (2 * blk + 1) * 64, YP, XP, XP, descale,
+                                             blk + 1 < NB ? W1 + 2 * CONV_U4 : nullptr, &wreg);
+                __syncthreads();
+                C5_PH(3 + blk);
+                continue;
+            }
+            conv3x3_split<NS, NPL>(W1, N.bc + (2 * blk) * 64, XP, YP, nullptr, descale);
             __syncthreads();
-            conv3x3_split<NS, NPL>((const uint4*)N.Wc + (size_t)(2 * blk + 1) * CONV_U4, N.bc + (2 * blk + 1) * 64, YP, XP, XP, descale);
+            conv3x3_split<NS, NPL>(W1 + CONV_U4, N.bc + (2 * blk + 1) * 64, YP, XP, XP, descale);
             __syncthreads();
+            C5_PH(3 + blk);
         }
-        // the heads read f32: rebuild the trunk output as [ROWS][CS] f32 at the start of the Y tile
-        for (int i = tid; i < ROWS * 16; i += 768) {
-            const int r = i >> 4, c4 = (i & 15) * 4;
-            if (NPL == 2) { const f32x4 o = h2_load4(XP, PLANE_B, 128, r, c4); *(float4*)(Y + r * CS + c4) = make_float4(o[0], o[1], o[2], o[3]); }
-            else *(float4*)(Y + r * CS + c4) = load_split4(XP, PLANE_B, r, c4);
+        if (NPL == 2) {
+            // f16 x 2: the 1x1 head convolutions run on the MFMAs straight from the planes (the Y tile is dead: head buffers go there)
+            C5_PH(20);
+            heads1x1_h2<NS>(N.Wp, N.bp, N.Wv, N.bv, XP, Y, Y + NS * CP2 * 25);
+            __syncthreads();
+            heads_done = true;
+        } else {
+            // the heads read f32: rebuild the trunk output as [ROWS][CS] f32 at the start of the Y tile
+            for (int i = tid; i < ROWS * 16; i += 768) {
+                const int r = i >> 4, c4 = (i & 15) * 4;
+                *(float4*)(Y + r * CS + c4) = load_split4(XP, PLANE_B, r, c4);
+            }
+            __syncthreads();
+            C5_PH(20);
+            X = Y;
+            Y = Y + ROWS * CS;
         }
-        __syncthreads();
-        X = Y;
-        Y = Y + ROWS * CS;
     } else {
         conv3x3_tile<1, NS>(N.W0, N.b0, Y, X, nullptr);
         __syncthreads();
@@ -340,6 +533,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     float* HV = HP + NS * CP2 * 25;         // [NS][25]       value head features
     float* LG = HV + NS * 25;               // [NS][AS]       logits
     float* H1 = LG + NS * AS;               // [NS][64]       value fc1
+    if (!heads_done)
     for (int i = tid; i < NS * 25 * (CP2 + 1); i += 768) {
         const int r = i / (CP2 + 1), c = i - r * (CP2 + 1);
         const float* xr = X + r * CS;
@@ -351,6 +545,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         if (c < CP2) HP[s * (CP2 * 25) + c * 25 + cell] = a; else HV[s * 25 + cell] = a;
     }
     __syncthreads();
+    C5_PH(21);
     for (int i = tid; i < NS * A; i += 768) {
         const int s = i / A, a = i - s * A;
         float acc = N.bfp[a];
@@ -364,6 +559,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         H1[s * 64 + j] = fmaxf(acc, 0.f);
     }
     __syncthreads();
+    C5_PH(22);
     // masked softmax == exp(log_softmax(where(valid, logits, -1e8))), one wave per sample
     for (int s = wave; s < nb; s += 12) {
         const int b = b0 + s;
@@ -391,6 +587,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         for (int j = 0; j < 64; j++) acc += H1[s * 64 + j] * N.Wf2[j * P + p];
         v_out[(size_t)(b0 + s) * P + p] = tanhf(acc);
     }
+    C5_PH(23);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -590,7 +787,8 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     __shared__ float zero_bias[64];
     if (tid < 64) zero_bias[tid] = 0.f;
     __syncthreads();
-    conv3x3_first_split<NS, false, NPL>(N.W0, zero_bias, STG, XP);
+    if (NPL == 2) conv3x3_first_h2<NS, false>(N.W0, zero_bias, STG, XP);
+    else conv3x3_first_split<NS, false, NPL>(N.W0, zero_bias, STG, XP);
     __syncthreads();
     if (tid < NPL * 32) ((uint32_t*)(HP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;      // H's zero row (the staging tile is dead)
 #pragma unroll 1
