@@ -309,6 +309,10 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     }
     rc |= dalloc(f, &D.ex_count, 4);
     if (rc) { azg_forest_destroy(f); return -1; }
+    if (getenv("AZG_DEBUG_PTRS"))
+        fprintf(stderr, "azg forest: hdr %p node_hdr %p node_state %p heap %p htab %p free_ids %p rec_free %p path %p root_state %p (strides: nhdr %zu nstate %zu heap %zu htab %zu)\n",
+                (void*)D.hdr, (void*)D.node_hdr, (void*)D.node_state, (void*)D.heap, (void*)D.htab, (void*)D.free_ids, (void*)D.rec_free, (void*)D.path,
+                (void*)D.root_state, (size_t)D.s_nhdr * sizeof(*D.node_hdr), (size_t)D.s_nstate, (size_t)D.s_heap, (size_t)D.s_htab * sizeof(*D.htab));
     hipError_t e = hipMemset(D.hdr, 0, T * sizeof(TreeHdr));
     if (e == hipSuccess) {
         const unsigned long long init[4] = {0ull, 0ull, 0ull, 0ull};
