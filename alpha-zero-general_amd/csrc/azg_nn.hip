@@ -327,7 +327,9 @@ static int conv5_launch(const int8_t* boards, const uint8_t* valid, const float*
     if (split == 2) {
         // two activation tiles of two f16 planes (+ a zero row each); the second tile also holds the f32 board staging tile at the
         // start and the f32 trunk output + head buffers at the end of the kernel (54.4 KB + 9.8 KB)
-        constexpr size_t lds = (size_t)2 * 201 * 128 + 65536;
+        // + the LDS copies of the head / FC matrices (k_conv5_net: WST_N floats)
+        constexpr size_t lds = (size_t)2 * 201 * 128 + 65536 + (size_t)(2 * 25 * 162 + 25 * 64 + 64 * 2 + 64) * sizeof(float);
+        static_assert(lds <= 160 * 1024, "k_conv5_net<.., 2>: LDS");
         if (!attr[2]) {
             HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr[2] = true;

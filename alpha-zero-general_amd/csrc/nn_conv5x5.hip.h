@@ -149,9 +149,12 @@ __device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wf
 // The first convolution on one f16 MFMA chunk: K = 9 taps x 2 board planes = 18 of the 32 (k = 2 * tap + plane).  The board values are
 // small integers (exact in f16, no lo half), the weights split hi + lo on the fly from the f32 fragments: two v_mfma_f32_16x16x32_f16 per
 // row tile instead of eighteen v_mfma_f32_16x16x4_f32 (a sixteenth of the rate each).  Output written as f16 x 2 planes.
-template <int NS, bool RELU = true>
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+// `prefetch` is called once this convolution's own weights are requested: whatever it asks for travels behind them and lands during
+// the tile loop (which only touches LDS) instead of delaying the first MFMAs
+template <int NS, bool RELU = true, class Prefetch = NoPrefetch>
 __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag, const float* __restrict__ bias,
-                                                 const float* IN, uint8_t* OUT) {
+                                                 const float* IN, uint8_t* OUT, Prefetch prefetch = Prefetch()) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
     constexpr float WS = 256.f;                             // weight scale (|w| < 255 keeps the hi half finite)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
@@ -162,12 +165,16 @@ __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int tap = 4 * g + (j >> 1);
-            wv[j] = tap < 9 ? Wfrag[((((size_t)ct * 9 + tap) * 64 + r16) << 2) + (j & 1)] * WS : 0.f;
+            wv[j] = tap < 9 ? Wfrag[((((size_t)ct * 9 + tap) * 64 + r16) << 2) + (j & 1)] : 0.f;
         }
+        prefetch();
+#pragma unroll
+        for (int j = 0; j < 8; j++) wv[j] *= WS;
         h2_split2(wv[0], wv[1], wh.x, wl.x); h2_split2(wv[2], wv[3], wh.y, wl.y);
         h2_split2(wv[4], wv[5], wh.z, wl.z); h2_split2(wv[6], wv[7], wh.w, wl.w);
     }
     const float4 b = *(const float4*)(bias + ct * 16 + 4 * g);
+    __builtin_amdgcn_sched_barrier(0);                      // (keeps the prefetch requests behind this convolution's own)
 #pragma unroll
     for (int i = 0; i < MAXT; i++) {
         const int rt = rg + RG * i, r = rt * 16 + r16;
@@ -233,6 +240,12 @@ __device__ __forceinline__ void heads1x1_h2(const float* __restrict__ Wp, const 
     }
 }
 
+#ifdef AZG_NN_PHASE_TIMES
+__device__ long long g_c5_phase[32];
+#define C5_PH(k) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_c5_phase[k] = clock64(); } while (0)
+#else
+#define C5_PH(k) do { } while (0)
+#endif
 struct SplitFrag { uint4 h, m, l; };                        // operand fragments of one (tile, tap, K chunk of 32)
 #define AZG_BF(x) __builtin_bit_cast(bf16x8, x)
 
@@ -248,6 +261,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
     static_assert(MAXT == 5 && RT - RG * (MAXT - 1) == 1, "step schedule: two tile pairs per wave + one odd tile in the first row group");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
+    C5_PH(24);
     int row[MAXT];
     uint32_t tapmask[MAXT];
 #pragma unroll
@@ -306,6 +320,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 #pragma unroll
             for (int p = 0; p < 3; p++) w[c6][p] = (*wio)[c6][p];
     }
+    C5_PH(25);
     if constexpr (NPL == 2) {
         // software pipeline: the operands of step s + 2 are requested before the MFMAs of step s are issued (hipcc emits
         // ds_read pair -> s_waitcnt -> three MFMAs per step otherwise, i.e. every step waits out an LDS round trip), across the
@@ -365,6 +380,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
             }
         }
     }
+    C5_PH(26);
     if (wio) {
 #pragma unroll
         for (int c6 = 0; c6 < 6; c6++)
@@ -388,6 +404,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
         }
         store_split4(OUT, PB, row[i], ct * 16 + 4 * g, make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)));
     }
+    C5_PH(27);
 }
 
 // One 64 x 64 GEMM phase on split activations (a 1x1 convolution over 64 input channels): acc[i] += IN[tile i] * W for the
@@ -433,12 +450,6 @@ __device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t*
 }
 #undef AZG_BF
 
-#ifdef AZG_NN_PHASE_TIMES
-__device__ long long g_c5_phase[32];
-#define C5_PH(k) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_c5_phase[k] = clock64(); } while (0)
-#else
-#define C5_PH(k) do { } while (0)
-#endif
 // SPLIT: the trunk on bf16 x 3 operands (above; N.Wc then points to the split fragments); LDS = 2 tiles x 3 planes x (ROWS + 1) x 128 B
 template <int NB, int A, int P, int SPLIT = 0>
 __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __restrict__ boards,
@@ -452,6 +463,9 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
     bool heads_done = false;
+    // f16 x 2 kernel: LDS copies of Wfp [50][A], Wf1 [25][64], Wp [64][2], Wv [64] behind the two tiles (the second is 64 KB)
+    constexpr int WST_FP = CP2 * 25 * A, WST_F1 = WST_FP + 25 * 64, WST_P = WST_F1 + 64 * CP2, WST_N = WST_P + 64;
+    float* const WST = (float*)((uint8_t*)smem + TILE_B + 65536);
     C5_PH(0);
     // ---- board int8 [s][y][x][3] -> Y[s*25 + cell][plane 0..1], channels 2..15 zero (the first conv reads 16) ----
     for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(Y + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -469,16 +483,31 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         constexpr size_t CONV_U4 = (size_t)4 * 18 * NPL * 64;   // uint4 per convolution
         uint4 wreg[6][3];                                        // NPL == 2: the trunk's weight fragments travel from one convolution
         if (NPL == 2) {                                          // to the next in registers (conv3x3_split, rolling prefetch)
-            const int ct = wave & 3;
+            // requested behind the first convolution's own weights, landing during its tile loop: the first kernel row of the trunk's
+            // weights, and the matrices of the heads and FCs (39 KB, kept in LDS behind the tiles: the phases at the end of the kernel
+            // then never wait for a first touch of global memory)
+            conv3x3_first_h2<NS, true>(N.W0, N.b0, Y, XP, [&]() {
+                const int ct = wave & 3;
 #pragma unroll
-            for (int c6 = 0; c6 < 6; c6++) {
-                wreg[c6][0] = ((const uint4*)N.Wc)[(((size_t)ct * 18 + c6) * 2 + 0) * 64 + lane];
-                wreg[c6][1] = ((const uint4*)N.Wc)[(((size_t)ct * 18 + c6) * 2 + 1) * 64 + lane];
-                wreg[c6][2] = make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
-        if (NPL == 2) conv3x3_first_h2<NS, true>(N.W0, N.b0, Y, XP);
-        else conv3x3_first_split<NS, true, NPL>(N.W0, N.b0, Y, XP);   // (Y still holds the f32 board staging tile)
+                for (int c6 = 0; c6 < 6; c6++) {
+                    wreg[c6][0] = ((const uint4*)N.Wc)[(((size_t)ct * 18 + c6) * 2 + 0) * 64 + lane];
+                    wreg[c6][1] = ((const uint4*)N.Wc)[(((size_t)ct * 18 + c6) * 2 + 1) * 64 + lane];
+                    wreg[c6][2] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                // global -> LDS DMA, 1 KiB per wave instruction (destination = uniform base + 16 * lane), no registers: waited for
+                // (vmcnt) before the head phase only
+                auto dma = [&](const float* src, int dst, int bytes) {
+                    for (int c = wave; c * 1024 < bytes; c += 12) {
+                        const int off = c * 1024 + lane * 16;
+                        if (off < bytes)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const uint8_t*)src + off),
+                                                             (__attribute__((address_space(3))) void*)((uint8_t*)(WST + dst) + c * 1024), 16, 0, 0);
+                    }
+                };
+                dma(N.Wfp, 0, WST_FP * 4); dma(N.Wf1, WST_FP, (WST_F1 - WST_FP) * 4); dma(N.Wp, WST_F1, (WST_P - WST_F1) * 4);
+                dma(N.Wv, WST_P, (WST_N - WST_P) * 4);
+            });
+        } else conv3x3_first_split<NS, true, NPL>(N.W0, N.b0, Y, XP);   // (Y still holds the f32 board staging tile)
         __syncthreads();
         C5_PH(2);
         if (tid < NPL * 32) ((uint32_t*)(YP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // Y's (the staging tile is dead)
@@ -503,7 +532,9 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         if (NPL == 2) {
             // f16 x 2: the 1x1 head convolutions run on the MFMAs straight from the planes (the Y tile is dead: head buffers go there)
             C5_PH(20);
-            heads1x1_h2<NS>(N.Wp, N.bp, N.Wv, N.bv, XP, Y, Y + NS * CP2 * 25);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the LDS copies of the head / FC matrices (DMA issued at the start)
+            __syncthreads();
+            heads1x1_h2<NS>(WST + WST_F1, N.bp, WST + WST_P, N.bv, XP, Y, Y + NS * CP2 * 25);
             __syncthreads();
             heads_done = true;
         } else {
@@ -546,18 +577,22 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     }
     __syncthreads();
     C5_PH(21);
-    for (int i = tid; i < NS * A; i += 768) {
-        const int s = i / A, a = i - s * A;
-        float acc = N.bfp[a];
-        for (int k = 0; k < CP2 * 25; k++) acc += HP[s * (CP2 * 25) + k] * N.Wfp[k * A + a];
-        LG[s * AS + a] = acc;
-    }
-    for (int i = tid; i < NS * 64; i += 768) {
-        const int s = i >> 6, j = i & 63;
-        float acc = N.bf1[j];
-        for (int k = 0; k < 25; k++) acc += HV[s * 25 + k] * N.Wf1[k * 64 + j];
-        H1[s * 64 + j] = fmaxf(acc, 0.f);
-    }
+    auto fcs = [&](const float* __restrict__ Wfp, const float* __restrict__ Wf1) {
+        for (int i = tid; i < NS * A; i += 768) {
+            const int s = i / A, a = i - s * A;
+            float acc = N.bfp[a];
+#pragma unroll 10
+            for (int k = 0; k < CP2 * 25; k++) acc += HP[s * (CP2 * 25) + k] * Wfp[k * A + a];
+            LG[s * AS + a] = acc;
+        }
+        for (int i = tid; i < NS * 64; i += 768) {
+            const int s = i >> 6, j = i & 63;
+            float acc = N.bf1[j];
+            for (int k = 0; k < 25; k++) acc += HV[s * 25 + k] * Wf1[k * 64 + j];
+            H1[s * 64 + j] = fmaxf(acc, 0.f);
+        }
+    };
+    if constexpr (NPL == 2 && SPLIT == 2) fcs(WST, WST + WST_FP); else fcs(N.Wfp, N.Wf1);
     __syncthreads();
     C5_PH(22);
     // masked softmax == exp(log_softmax(where(valid, logits, -1e8))), one wave per sample

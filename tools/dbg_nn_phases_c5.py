@@ -23,3 +23,4 @@ for k in sorted(names):
     print('%-12s %7d cycles (100 MHz ticks x ? -- clock64)' % (names[k], t[k] - prev))
     prev = t[k]
 print('total', t[23] - t[0])
+print('last convolution, wave 0 (5 row tiles): prologue (tap masks, weights) %d  main loop %d  epilogue %d  barrier %d' % (t[25] - t[24], t[26] - t[25], t[27] - t[26], t[7] - t[27]))
