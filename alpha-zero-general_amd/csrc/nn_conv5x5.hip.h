@@ -322,7 +322,9 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
     }
     C5_PH(25);
     if constexpr (NPL == 2) {
-        // software pipeline: the operands of step s + 2 are requested before the MFMAs of step s are issued (hipcc emits
+        // software pipeline: the operands of step s + AH are requested before the MFMAs of step s are issued (AH = 1, 2, 3 measure the
+        // same 220-230 us per 4096 leaves, 4 spills; interleaving the MFMAs of two tiles so that consecutive ones never share an
+        // accumulator is 4 % SLOWER -- back-to-back MFMAs on one accumulator are the cheap case) (hipcc emits
         // ds_read pair -> s_waitcnt -> three MFMAs per step otherwise, i.e. every step waits out an LDS round trip), across the
         // kernel rows as well; a step = (fragment k6 = s / NT: tap ky * 3 + k6 / 2, K chunk k6 & 1; tile s % NT).  The waves with
         // the odd 13th row tile run the NT = MAXT instance, the others NT = MAXT - 1 (wave-uniform branch)
@@ -335,21 +337,29 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
                 const uint8_t* src = IN + pl_off(r, 4 * c + g);
                 return SplitFrag{*(const uint4*)src, *(const uint4*)(src + PB), make_uint4(0u, 0u, 0u, 0u)};
             };
-            SplitFrag f0 = ld(0, 0), f1 = ld(0, 1);
+#ifndef AZG_C5_AHEAD
+#define AZG_C5_AHEAD 1
+#endif
+            constexpr int AH = AZG_C5_AHEAD;
+            SplitFrag f[AH];
+#pragma unroll
+            for (int k = 0; k < AH; k++) f[k] = ld(0, k);
 #pragma unroll 1
             for (int ky = 0; ky < 3; ky++) {
                 const uint4* __restrict__ Wn = ky < 2 ? Wfrag : (WNEXT ? WNEXT : Wfrag);
                 const int kyn = ky < 2 ? ky + 1 : 0;
-                const int kyl = ky < 2 ? ky + 1 : 2;            // (the two look-ahead reads past the last row are not used)
+                const int kyl = ky < 2 ? ky + 1 : 2;            // (the look-ahead reads past the last row are not used)
 #pragma unroll
                 for (int sidx = 0; sidx < S; sidx++) {
-                    const SplitFrag fn = sidx + 2 < S ? ld(ky, sidx + 2) : ld(kyl, sidx + 2 - S);
-                    __builtin_amdgcn_sched_barrier(0);
                     const int k6 = sidx / NT, i = sidx % NT;
-                    acc[i] = h2_mma(w[k6][0], w[k6][1], f0.h, f0.m, acc[i]);
+                    const SplitFrag fn = sidx + AH < S ? ld(ky, sidx + AH) : ld(kyl, sidx + AH - S);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i] = h2_mma(w[k6][0], w[k6][1], f[0].h, f[0].m, acc[i]);
                     if (i == NT - 1) { w[k6][0] = wfrag(Wn, kyn, k6, 0); w[k6][1] = wfrag(Wn, kyn, k6, 1); }
                     __builtin_amdgcn_sched_barrier(0);
-                    f0 = f1; f1 = fn;
+#pragma unroll
+                    for (int k = 0; k + 1 < AH; k++) f[k] = f[k + 1];
+                    f[AH - 1] = fn;
                 }
             }
         };
