@@ -562,6 +562,9 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     bool fresh_noise = false;
     if (pi && uni_u32(status0) == ST_WAIT_NN) {
         fresh_noise = expand_apply<G>(F, t, ein, dense, sm.path, noise_enabled, azg_stamp);
+#ifdef AZG_STAMP_DRAIN
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // debug: charge the drain of the expansion's stores to stamp 4 -> 5
+#endif
         AZG_STAMP(5);
         status0 = ST_SEARCHING;
     }
@@ -571,6 +574,7 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         if (l == 0) needs_eval[t] = 0;
         return;
     }
+    AZG_STAMP(7);
 #ifdef AZG_PIN_HEADER
     H.id_top = uni_u32(H.id_top); H.n_free_ids = uni_u32(H.n_free_ids); H.free_units = uni_u32(H.free_units);
     H.n_nodes = uni_u32(H.n_nodes); H.heap_top = uni_u32(H.heap_top); H.root = uni_u32(H.root);
@@ -842,8 +846,9 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         stat_add(&Hp->cyc_select, (uint64_t)(AZG_CLK() - t_start)); stat_add(&Hp->cyc_levels, (uint64_t)cyc_levels);
         stat_add(&Hp->cyc_edge, (uint64_t)cyc_edge); stat_add(&Hp->cyc_leaf, (uint64_t)H.cyc_leaf);
         H.cyc_seg[0] += (uint32_t)(t_start - t_first);          // prologue: header round trip + fused expansion + backup
-        if (azg_stamp[5]) for (int k = 1; k < 7; k++) atomicAdd(&g_prolog[k], (unsigned long long)(azg_stamp[k] - azg_stamp[k - 1]));
-        if (azg_stamp[5]) atomicAdd(&g_prolog[0], 1ull);
+        if (azg_stamp[5] && (t & 63) == 0) for (int k = 1; k < 7; k++) atomicAdd(&g_prolog[k], (unsigned long long)(azg_stamp[k] - azg_stamp[k - 1]));
+        if (azg_stamp[5] && (t & 63) == 0) atomicAdd(&g_prolog[7], (unsigned long long)(azg_stamp[7] - azg_stamp[5]));   // end of expansion -> status checks done
+        if (azg_stamp[5] && (t & 63) == 0) atomicAdd(&g_prolog[0], 1ull);     // (a sample of the trees: 4096 waves on one word serialise)
         for (int k = 0; k < 4; k++) stat_add(&Hp->cyc_seg[k], (uint64_t)H.cyc_seg[k]);
 #else
         (void)t_start; (void)t_first; (void)cyc_levels; (void)cyc_edge; (void)azg_stamp;

@@ -27,6 +27,9 @@ else:
     g = games.SplendorGame(2)
     net = SplendorV80Hip.from_npz(G + '/weights_splendor2_v80.npz', max_batch=T)
     cap = 13312
+if os.environ.get('HASHNET'):           # a leaf evaluator with a tiny code footprint (does the net kernel evict k_select's code from the I-cache?)
+    from hashnet import HashNetTorch
+    net = HashNetTorch(g.P)
 e = SelfPlayEngine(g, net, a, T, node_capacity=cap, max_examples=T*160, use_graph=False, fused=os.environ.get('FUSED', '1') == '1')
 e.start(); e.run(1200)
 s0 = e.stats(); e.run(300); s1 = e.stats()
@@ -48,5 +51,6 @@ try:
     n = max(1, out[0])
     print('prologue stamps per expansion (cycles): hdr+pi arrive %.0f | to np_sum done %.0f | entries written %.0f | backup %.0f | tail of expand_apply %.0f | to loop start %.0f'
           % tuple(out[k] / n for k in range(1, 7)))
+    print('   of which end of expansion -> after the status checks: %.0f' % (out[7] / n))
 except Exception as ex:
     print('no prologue stamps:', ex)
