@@ -17,8 +17,8 @@
 // grid: cells and patterns fall off the board, the scatter wraps index -1 to the last action and later writers win -- lane 0 builds
 // the forms exactly as written (BUILT symmetric forms, k_env_symmetries_built).
 //
-// Valid moves: 1014 pattern predicates in 16 ballots, expanded to the N + 2 slots in 64..96 words; make_move / init on lane 0
-// (district scoring = flood fills over 169 cells with bitset work lists); swap_players is a byte map applied by all lanes.
+// Valid moves: 1014 pattern predicates in 16 ballots, expanded to the N + 2 slots in 64..96 words; init and the tile placement of make_move
+// on lane 0, the district scoring (per-cell rules + flood fill over 169 cells) on all lanes; swap_players is a byte map applied by all lanes.
 #pragma once
 #include "azg_common.hip.h"
 #include "akropolis_tables.h"
@@ -116,56 +116,94 @@ struct AkropolisDev {
         __device__ bool get(int i) const { return (w[i >> 6] >> (i & 63)) & 1ull; }
         __device__ void set(int i) { w[i >> 6] |= 1ull << (i & 63); }
     };
-    __device__ static void update_districts(int8_t* st, int p) {               // :520-611
-        int district[5] = {0, 0, 0, 0, 0};
-        Bits169 outer, seen;
-        uint8_t stack[AREA];
-        int n = 0;
-        outer.clear(); seen.clear();
-        for (int i = 0; i < AREA; i++) {
-            const int d = st[o_descr(i, p)], h = st[o_height(i, p)];
-            if (d == DISTRICT_GREEN) district[GREEN] += h;
-            else if (d == DISTRICT_YELLOW) {
-                bool isolated = true;
-                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb >= 0 && st[o_descr(nb, p)] == DISTRICT_YELLOW) isolated = false; }
-                if (isolated) district[YELLOW] += h;
-            } else if (d == DISTRICT_PURPLE) {
-                bool ok = true;
-                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || st[o_height(nb, p)] == 0) ok = false; }
-                if (ok) district[PURPLE] += h;
-            } else if (d == EMPTY) {
-                bool border = false;
-                for (int k = 0; k < 6; k++) border = border || neighbor(i, k) < 0;
-                if (border) { outer.set(i); stack[n++] = (uint8_t)i; }
-            }
-        }
-        for (int k0 = 0; k0 < n; k0++)                                         // flood fill of the empty cells from the border
-            for (int k = 0; k < 6; k++) {
-                const int nb = neighbor(stack[k0], k);
-                if (nb < 0 || outer.get(nb) || st[o_descr(nb, p)] != EMPTY) continue;
-                outer.set(nb); stack[n++] = (uint8_t)nb;
-            }
-        for (int i = 0; i < AREA; i++)
-            if (st[o_descr(i, p)] == DISTRICT_RED)
-                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); if (nb < 0 || outer.get(nb)) { district[RED] += st[o_height(i, p)]; break; } }
-        int best = 0;
-        for (int s0 = 0; s0 < AREA; s0++) {                                    // heaviest chain of houses
-            if (st[o_descr(s0, p)] != DISTRICT_BLUE || seen.get(s0)) continue;
-            int chain = 0, top = 0;
-            stack[top++] = (uint8_t)s0; seen.set(s0);
-            while (top) {
-                const int cur = stack[--top];
-                chain += st[o_height(cur, p)];
+    // update_districts :520-611, all lanes: a lane owns cells l, l + 64, l + 128.  The per-cell rules (green, isolated yellow, enclosed
+    // purple, red next to the outside) are independent; the "outside" = the empty cells connected to the border is a flood fill done as
+    // frontier sweeps over three 64-bit ballot words until nothing changes; the heaviest chain of houses (blue) is a connected-component
+    // search over the blue cells only, left to lane 0 (a handful of cells).  Integer sums: any order gives the reference's numbers.
+    __device__ static void update_districts(int8_t* st, int p) {
+        const int l = lane_id();
+        int green = 0, yellow = 0, purple = 0;
+        uint64_t outer[3], empty[3], blue[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int i = 64 * c + l;
+            const bool in = i < AREA;
+            const int d = in ? st[o_descr(i, p)] : -1, h = in ? st[o_height(i, p)] : 0;
+            bool border = false, yel_nb = false, open_nb = false;
+            if (in) {
+#pragma unroll
                 for (int k = 0; k < 6; k++) {
-                    const int nb = neighbor(cur, k);
-                    if (nb < 0 || seen.get(nb) || st[o_descr(nb, p)] != DISTRICT_BLUE) continue;
-                    seen.set(nb); stack[top++] = (uint8_t)nb;
+                    const int nb = neighbor(i, k);
+                    border = border || nb < 0;
+                    if (nb >= 0) {
+                        yel_nb = yel_nb || st[o_descr(nb, p)] == DISTRICT_YELLOW;
+                        open_nb = open_nb || st[o_height(nb, p)] == 0;
+                    }
                 }
             }
-            best = chain > best ? chain : best;
+            if (d == DISTRICT_GREEN) green += h;
+            if (d == DISTRICT_YELLOW && !yel_nb) yellow += h;
+            if (d == DISTRICT_PURPLE && !border && !open_nb) purple += h;
+            empty[c] = __ballot(d == EMPTY);
+            outer[c] = __ballot(d == EMPTY && border);
+            blue[c] = __ballot(d == DISTRICT_BLUE);
         }
-        district[BLUE] = best;
-        for (int c = 0; c < 5; c++) st[o_districts(p, c)] = (int8_t)district[c];
+        auto get = [](const uint64_t (&w)[3], int i) { return (w[i >> 6] >> (i & 63)) & 1ull; };
+        // flood fill of the empty cells from the border
+        for (;;) {
+            uint64_t grow[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int i = 64 * c + l;
+                bool g = false;
+                if (i < AREA && ((empty[c] & ~outer[c]) >> l) & 1ull) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); g = g || (nb >= 0 && get(outer, nb)); }
+                }
+                grow[c] = __ballot(g);
+            }
+            if (!(grow[0] | grow[1] | grow[2])) break;
+            outer[0] |= grow[0]; outer[1] |= grow[1]; outer[2] |= grow[2];
+        }
+        int red = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int i = 64 * c + l;
+            if (i < AREA && st[o_descr(i, p)] == DISTRICT_RED) {
+                bool edge = false;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { const int nb = neighbor(i, k); edge = edge || nb < 0 || get(outer, nb); }
+                if (edge) red += st[o_height(i, p)];
+            }
+        }
+        green = wave_sum_i32(green); yellow = wave_sum_i32(yellow); purple = wave_sum_i32(purple); red = wave_sum_i32(red);
+        if (l == 0) {
+            int best = 0;                                                          // heaviest chain of houses
+            uint64_t todo[3] = {blue[0], blue[1], blue[2]};
+            uint8_t stack[AREA];
+            for (int c = 0; c < 3; c++)
+                while (todo[c]) {
+                    const int s0 = 64 * c + (__ffsll((unsigned long long)todo[c]) - 1);
+                    int chain = 0, top = 0;
+                    stack[top++] = (uint8_t)s0; todo[c] &= todo[c] - 1;
+                    while (top) {
+                        const int cur = stack[--top];
+                        chain += st[o_height(cur, p)];
+                        for (int k = 0; k < 6; k++) {
+                            const int nb = neighbor(cur, k);
+                            if (nb < 0 || !((todo[nb >> 6] >> (nb & 63)) & 1ull)) continue;
+                            todo[nb >> 6] &= ~(1ull << (nb & 63)); stack[top++] = (uint8_t)nb;
+                        }
+                    }
+                    best = chain > best ? chain : best;
+                }
+            st[o_districts(p, BLUE)] = (int8_t)best;
+            st[o_districts(p, YELLOW)] = (int8_t)yellow;
+            st[o_districts(p, RED)] = (int8_t)red;
+            st[o_districts(p, PURPLE)] = (int8_t)purple;
+            st[o_districts(p, GREEN)] = (int8_t)green;
+        }
+        wave_sync();
     }
 
     // valid_moves :358-398 for one pattern
@@ -213,11 +251,20 @@ struct AkropolisDev {
         }
     }
 
+    // Board.make_move :314-352: lane 0 places the tile, all lanes rescore the player's districts, lane 0 finishes (score, round, refill)
     __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
-        return lane0_make_move<AkropolisDev<NPL>>(st, move, player, seed, rng);
+        if (lane_id() == 0) place_tile(st, move, player);
+        wave_sync();
+        update_districts(st, player);
+        int np = 0;
+        if (lane_id() == 0) np = finish_move(st, player, seed, rng);
+        np = __builtin_amdgcn_readfirstlane(np);
+        rng.counter = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rng.counter >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rng.counter);
+        wave_sync();
+        return np;
     }
-    // Board.make_move :314-352 -- lane 0 only
-    __device__ static int make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
+    __device__ static void place_tile(int8_t* st, int move, int player) {
         const int slot = move / NPAT, pat = move - slot * NPAT;
         int8_t tile[4];
         int c[3];
@@ -236,7 +283,8 @@ struct AkropolisDev {
             if (type_of(tile[j]) == 3) st[o_plazas(player, color_of(tile[j]))] = (int8_t)(st[o_plazas(player, color_of(tile[j]))] + 1);
         }
         st[o_stones(player)] = (int8_t)(st[o_stones(player)] - slot);
-        update_districts(st, player);
+    }
+    __device__ static int finish_move(int8_t* st, int player, long long seed, Rng& rng) {
         st[o_total(player)] = (int8_t)(get_score(st, player) / 2 - 128);        // encode_score_to_int8 :239-248
         st[O_ROUND] = (int8_t)(st[O_ROUND] + 1);
         if (st[o_site(1, 0)] == EMPTY && st[O_STACKS] > 0) {
