@@ -31,8 +31,29 @@ GAMES = [('minivilles', lambda: games.MinivillesGame(2), 1.0, 10), ('abalone', g
          ('smallworld4', lambda: games.SmallworldGame(4), 0.5, 80)]
 
 
+class MlpNet(torch.nn.Module):
+    """A PyTorch module with the reference's forward signature and the size of its small per-game nets (flatten -> 256 -> 256 -> 128 with
+    LayerNorm + SiLU, two-layer policy and value heads: the shape of MinivillesNNet V83; the reference ships 2-8 architectures per game,
+    they are not restated here).  Random weights: the figure is the cost of a real module per round through nnet.TorchModuleEvaluator."""
+
+    def __init__(self, n_in, A, P):
+        super().__init__()
+        nn = torch.nn
+        self.trunk = nn.Sequential(nn.Linear(n_in, 256), nn.LayerNorm(256), nn.SiLU(), nn.Linear(256, 256), nn.LayerNorm(256), nn.SiLU(),
+                                   nn.Linear(256, 128), nn.LayerNorm(128), nn.SiLU())
+        self.pi = nn.Sequential(nn.Linear(128, 64), nn.SiLU(), nn.Linear(64, A))
+        self.v = nn.Sequential(nn.Linear(128, 64), nn.SiLU(), nn.Linear(64, P))
+
+    def forward(self, x, valid):
+        h = self.trunk(x.flatten(1))
+        pi = torch.where(valid, self.pi(h), torch.full((), -1e8, device=x.device))
+        return torch.log_softmax(pi, dim=1), torch.tanh(self.v(h))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--net', default='hash', choices=['hash', 'mlp'], help='leaf evaluator: integer hash-net (torch ops) or MlpNet through TorchModuleEvaluator')
+    ap.add_argument('--md', action='store_true', help='markdown table row instead of JSON')
     ap.add_argument('--games', type=int, default=1024)
     ap.add_argument('--sims', type=int, default=200)
     ap.add_argument('--plies', type=int, default=40, help='timed ply waves (one wave = `sims` lock-step rounds)')
@@ -46,7 +67,13 @@ def main():
         # (Akropolis offers hundreds of placements: with 200 simulations policy-target pruning leaves no count above 1, error bit 64)
         args = Args(numMCTSSims=a.sims, cpuct=1.0, fpu=0.0, universes=1, forced_playouts=name != 'akropolis', prob_fullMCTS=1.0, ratio_fullMCTS=5,
                     dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0], tempThreshold=6)
-        eng = SelfPlayEngine(g, HashNetTorch(g.P), args, n_games=T, node_capacity=max(2048, capf * a.sims), max_examples=T * 256)
+        if a.net == 'mlp':
+            from azg_amd.nnet import TorchModuleEvaluator
+            torch.manual_seed(0)
+            net = TorchModuleEvaluator(MlpNet(int(g.S), g.A, g.P), g)
+        else:
+            net = HashNetTorch(g.P)
+        eng = SelfPlayEngine(g, net, args, n_games=T, node_capacity=max(2048, capf * a.sims), max_examples=T * 256)
         eng.start()
         eng.run(2 * a.sims)                                    # warm-up: two ply waves (also captures the HIP graph)
         torch.cuda.synchronize()
@@ -58,12 +85,17 @@ def main():
         s1 = eng.stats()
         sims, plies = s1['sims'] - s0['sims'], s1['plies'] - s0['plies']
         bad = sum(grp.f.validate() for grp in eng.groups) if T <= 1024 else -1
-        print(json.dumps(dict(game=name, players=g.P, state_bytes=g.S, actions=g.A, games=T, sims_per_move=a.sims, plies_per_s=plies / dt,
-                              sims_per_s=sims / dt, ms_per_round=dt / (a.plies * a.sims) * 1e3,
-                              levels_per_sim=(s1['levels'] - s0['levels']) / max(sims, 1),
-                              valid_per_level=(s1['sum_valid_visited'] - s0['sum_valid_visited']) / max(s1['levels'] - s0['levels'], 1),
-                              games_finished=s1['games'], errors=s1['errors'], validate_violations=bad,
-                              forest_gb=eng.device_bytes / 1e9, evaluator='hash-net (torch ops)')), flush=True)
+        if a.md:
+            print('| %s | %d | %d | %d | %d | %s | %.0f | %.2f | %.3f | %.2f | %.1f | %d | %d | %.1f |' % (
+                name, g.P, g.S, g.A, T, a.net, plies / dt, sims / dt / 1e6, dt / (a.plies * a.sims) * 1e3, (s1['levels'] - s0['levels']) / max(sims, 1),
+                (s1['sum_valid_visited'] - s0['sum_valid_visited']) / max(s1['levels'] - s0['levels'], 1), s1['errors'], bad, eng.device_bytes / 1e9), flush=True)
+        else:
+            print(json.dumps(dict(game=name, players=g.P, state_bytes=g.S, actions=g.A, games=T, sims_per_move=a.sims, plies_per_s=plies / dt,
+                                  sims_per_s=sims / dt, ms_per_round=dt / (a.plies * a.sims) * 1e3,
+                                  levels_per_sim=(s1['levels'] - s0['levels']) / max(sims, 1),
+                                  valid_per_level=(s1['sum_valid_visited'] - s0['sum_valid_visited']) / max(s1['levels'] - s0['levels'], 1),
+                                  games_finished=s1['games'], errors=s1['errors'], validate_violations=bad,
+                                  forest_gb=eng.device_bytes / 1e9, evaluator=a.net)), flush=True)
         for grp in eng.groups:
             grp.f.close()
         del eng
