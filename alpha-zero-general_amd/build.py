@@ -11,7 +11,11 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fP
 # kernels with theirs.  (Wave-uniform reads of mutable forest memory are relaxed agent-scope atomic loads -- forest.hip.h
 # ld_agent_u32 / load_uniform -- so that the compiler cannot turn them into scalar-cache loads; the blanket alternative,
 # -mllvm -amdgpu-scalarize-global-loads=false, was tried in round 2 and miscompiled k_selfplay_advance<AzulDev>.)
-UNITS = [('azg.hip', []), ('azg_nn.hip', [])]
+# -disable-promote-alloca-to-lds: hipcc's AMDGPUPromoteAlloca pass moves small private arrays with a run-time index (a player's value
+# block, ...) into LDS, one slot per work-item, and computes the work-item's linear id from the work-group sizes in the AQL DISPATCH PACKET
+# -- a scalar load from the queue ring in HOST memory at the top of k_select's descent: 10-30 k cycles per launch, and the whole of the
+# kernel's "slow / fast mode" (47-50 vs 57-62 us; 41.7 us without the load).  With the pass off those 32 bytes are scratch.
+UNITS = [('azg.hip', ['-mllvm', '-disable-promote-alloca-to-lds']), ('azg_nn.hip', ['-mllvm', '-disable-promote-alloca-to-lds'])]
 # debugging builds: AZG_DEFINES="AZG_CYC_COUNTERS AZG_NN_PHASE_TIMES" python alpha-zero-general_amd/build.py
 FLAGS += ['-D' + d for d in os.environ.get('AZG_DEFINES', '').split()]
 FLAGS += os.environ.get('AZG_EXTRA_FLAGS', '').split()            # e.g. -ftrivial-auto-var-init=pattern when hunting an uninitialised local

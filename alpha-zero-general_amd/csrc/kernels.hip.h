@@ -575,6 +575,13 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         return;
     }
     AZG_STAMP(7);
+#ifdef AZG_PAD_CODE
+    {   // experiment: AZG_PAD_CODE straight-line scalar instructions (4 bytes each) executed once per launch -- what does cold code cost?
+        uint32_t pad_x = 0;
+        asm volatile(".rept %1\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(pad_x) : "n"(AZG_PAD_CODE) : "scc");
+        if (pad_x == 0xFFFFFFFFu) needs_eval[t] = 3;
+    }
+#endif
 #ifdef AZG_PIN_HEADER
     H.id_top = uni_u32(H.id_top); H.n_free_ids = uni_u32(H.n_free_ids); H.free_units = uni_u32(H.free_units);
     H.n_nodes = uni_u32(H.n_nodes); H.heap_top = uni_u32(H.heap_top); H.root = uni_u32(H.root);

@@ -113,3 +113,47 @@ def test_coach_shares_do_not_depend_on_world_size():
             rs = [split_range(n, world, r) for r in range(world)]
             assert rs[0][0] == 0 and sum(c for _, c in rs) == n
             assert all(rs[i][0] + rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+
+
+def _amdgpu_kernel_descriptors(path):
+    """(kernel name, kernel_code_properties) of every kernel in the gfx950 code objects embedded in the library (plain ELF64 parsing:
+    symbols `<kernel>.kd` point at the 64-byte AMDHSA kernel descriptors, kernel_code_properties = u16 at byte 56)"""
+    import struct
+    blob = open(path, 'rb').read()
+    out, i = [], 0
+    while True:
+        i = blob.find(b'\x7fELF', i)
+        if i < 0:
+            break
+        if struct.unpack_from('<H', blob, i + 18)[0] != 224:        # EM_AMDGPU
+            i += 4
+            continue
+        e = blob[i:]
+        shoff, = struct.unpack_from('<Q', e, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from('<HHH', e, 0x3A)
+        secs = [struct.unpack_from('<IIQQQQIIQQ', e, shoff + k * shentsize) for k in range(shnum)]
+        for s in secs:
+            if s[1] != 2:                                               # SHT_SYMTAB
+                continue
+            stroff = secs[s[6]][4]
+            for k in range(s[5] // 24):
+                st_name, st_info, st_other, st_shndx, st_value, st_size = struct.unpack_from('<IBBHQQ', e, s[4] + 24 * k)
+                name = e[stroff + st_name:e.index(b'\0', stroff + st_name)].decode()
+                if name.endswith('.kd') and 0 < st_shndx < shnum:
+                    sec = secs[st_shndx]
+                    kd = sec[4] + (st_value - sec[3])
+                    out.append((name[:-3], struct.unpack_from('<H', e, kd + 56)[0]))
+        i += 4
+    return out
+
+
+def test_no_kernel_reads_the_dispatch_packet():
+    """hipcc's promote-alloca-to-LDS pass makes a kernel read the work-group sizes from the AQL dispatch packet -- a scalar load from the
+    queue ring in host memory -- which cost k_select 10-30 k cycles per launch (build.py turns the pass off).  Guard: no
+    kernel of the built library has ENABLE_SGPR_DISPATCH_PTR (bit 1 of kernel_code_properties) or the queue pointer (bit 2) set."""
+    from azg_amd import _lib
+    kds = _amdgpu_kernel_descriptors(_lib.LIB_PATH)
+    assert len(kds) > 100, len(kds)
+    assert any('k_select' in n for n, _ in kds)
+    bad = [n for n, p in kds if p & 0x6]
+    assert not bad, bad[:5]
