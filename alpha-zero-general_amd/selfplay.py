@@ -52,7 +52,7 @@ class _Group:
 
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
-                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=20, fused=True):
+                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=None, fused=True):
         self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
@@ -61,9 +61,17 @@ class SelfPlayEngine:
         assert n_games % groups == 0
         self.T, self.G = n_games, groups
         self.fused = bool(fused) and groups == 1
-        # cadence of the advance launch: idle share (K-1)/numMCTSSims kept under ~1 %
-        self.K = max(1, min(16, sims // 50)) if advance_every is None else int(advance_every)
+        # defaults per game family, from whole-game sweeps at 4096 games x 800 sims (tools/sweep_budget_games.sh; the timings repeat to
+        # 0.1 % since k_select stopped reading the dispatch packet): Splendor 2p / 4p prefer short launches and a rarer advance (work
+        # budget 10, every 48 rounds: +8 % / +3 % over 20 / 16), Azul and Santorini the opposite (20 / 16: 42.5 k vs 35.5 k, 21.6 k vs 20.9 k)
+        from . import _lib
+        splendor = getattr(game, 'GAME_ID', None) == _lib.SPLENDOR
+        if work_budget is None:
+            work_budget = 10 if splendor else 20
+        # cadence of the advance launch: idle share (K-1)/numMCTSSims kept to a few per cent
+        self.K = max(1, min(48, sims // 16) if splendor else min(16, sims // 50)) if advance_every is None else int(advance_every)
         assert self.K == 1 or groups == 1
+        self.work_budget = int(work_budget)
         Tg = n_games // groups
         alpha = float(get('dirichletAlpha', 0.0)) if dirichlet is None else float(dirichlet)
         # Coach passes dirichlet_noise=(dirichletAlpha != 0) (Coach.py:31,96).  The Gamma variates of

@@ -212,7 +212,7 @@ def build_engine(a, game_key, T, rank, dev):
         try:
             eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
                                  stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups,
-                                 work_budget=a.work_budget, advance_every=a.advance_every or None)
+                                 work_budget=None if a.work_budget < 0 else a.work_budget, advance_every=a.advance_every or None)
             break
         except Exception as ex:        # azg_amd.AzgError: hipMalloc failed
             if a.node_capacity or attempt == 2:
@@ -354,7 +354,7 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
                engine_errors=errs, forest_bytes_per_gpu=eng.device_bytes,
                max_live_after_gc=int(s1.get('max_live_after_gc', 0)), max_nodes_per_tree=s1['max_nodes'],
                gc_runs=s1['gc_runs'], hip_graph=eng.graph is not None, rounds_timed=steps * sims,
-               ms_per_round=dt / (steps * sims) * 1e3, preroll_plies=preroll, node_capacity=eng.forest.cfg.node_capacity,
+               ms_per_round=dt / (steps * sims) * 1e3, preroll_plies=preroll, work_budget=eng.work_budget, advance_every=eng.K, node_capacity=eng.forest.cfg.node_capacity,
                max_live_frac=int(s1.get('max_live_after_gc', 0)) / max(1, eng.forest.cfg.node_capacity))
     res['roofline'] = measure_roofline(a, eng, T) if roofline and a.roofline_rounds > 0 else None
     res['roofline_net'] = measure_net(a, eng, T, game_key, net_kind) if roofline and a.roofline_rounds > 0 else None
@@ -382,7 +382,7 @@ def main():
     ap.add_argument('--groups', type=int, default=1, help='independent forests with skewed rounds on separate streams')
     ap.add_argument('--level-budget', type=int, default=0, help='max descent levels per tree per select launch (0 = unlimited)')
     ap.add_argument('--advance-every', type=int, default=0, help='rounds per selfplay_advance launch / HIP graph (0 = engine default)')
-    ap.add_argument('--work-budget', type=int, default=20, help='per-launch work cap per tree (level units), 0 = off')
+    ap.add_argument('--work-budget', type=int, default=-1, help='per-launch work cap per tree (level units), 0 = off, -1 = the engine default for the game')
     ap.add_argument('--net-dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--net', default='hip', choices=['hip', 'torch'], help='hip: engine MFMA kernels; torch: PyTorch-ROCm ops')
     ap.add_argument('--prob-full', type=float, default=1.0,
@@ -447,7 +447,7 @@ def main():
                groups=a.groups)
     for k in ('value_from_sims', 'sims_per_sec', 'plies_completed', 'games_finished', 'examples_gathered', 'examples_dropped',
               'engine_errors', 'forest_bytes_per_gpu', 'node_capacity', 'max_live_after_gc', 'max_live_frac', 'max_nodes_per_tree', 'gc_runs',
-              'rounds_timed', 'ms_per_round', 'preroll_plies'):
+              'rounds_timed', 'ms_per_round', 'preroll_plies', 'work_budget', 'advance_every'):
         out[k] = r[k]
     out['config']['preroll'] = ('%d plies of fast searches (numMCTSSims // ratio_fullMCTS, MCTS.py:58-59) before the warm-up, untimed: games end '
                                 'inside the timed window (max_nodes_per_tree hugs node_capacity by design -- the clean-up is lazy; '
