@@ -8,8 +8,9 @@ finished (or whose fresh root waits for its Dirichlet noise) sits out up to adva
 numMCTSSims of its time -- in exchange for one launch less per round; per-tree results do not depend on the cadence.
 `work_budget` caps the work of a tree in one select launch (a launch lasts as long as its slowest tree): near the end of a
 game most simulations end on terminal nodes and would otherwise all run inside one launch (measured: 0.65 ms rounds).
-Whole-game sweep at 4096 x 800 sims (env-steps/s): budget 0 -> 21.3 k, 96 -> 30.9 k, 48 -> 33.8 k, 32 -> 35.1 k, 20 -> 37.2 k;
-advance every 4 / 8 / 16 / 32 rounds -> 32.5 / 33.8 / 34.4 / 34.7 k.
+Whole-game sweep at 4096 x 800 sims (env-steps/s), round 1: budget 0 -> 21.3 k, 96 -> 30.9 k, 48 -> 33.8 k, 32 -> 35.1 k, 20 -> 37.2 k;
+advance every 4 / 8 / 16 / 32 rounds -> 32.5 / 33.8 / 34.4 / 34.7 k.  Round 3 (tools/sweep_budget_games.sh): Splendor 10 / 48 -> 68.1 k
+against 63.0 k for 20 / 16; Azul and Santorini keep 20 / 16 -- the defaults below are per game family.
 
 The descent kernel is a latency chain (few waves, each waiting on dependent loads) while the net is throughput bound, so
 the games are split into `groups` independent forests whose rounds are skewed by one stage and run on separate HIP
