@@ -10,7 +10,7 @@ one of the pieces above.  Engine-only knobs (concurrent games, node capacity) ar
 
 Several GPUs (BASELINE config 5): with torch.distributed initialised (one process per GPU) every rank owns a
 contiguous range of the n_games concurrent game streams and of the numEps episodes, the finished games' records are exchanged
-once per iteration (selfplay.gather_examples: all_gather of counts + padded records), rank 0 trains and writes the files, the new
+once per iteration (selfplay.gather_examples: all_gather of the counts + ONE grouped send / receive of the packed records to rank 0), rank 0 trains and writes the files, the new
 weights are broadcast, the arena games are sharded by game index and the three tallies all_reduced -- every rank takes the same
 accept / reject decision.  The global game streams, the episodes each stream plays and the arena games do not depend on the world
 size, and the gathered records are put in a canonical order before training, so a run on W ranks reproduces the run on one."""
@@ -108,7 +108,7 @@ class Coach:
     def executeEpisodes(self, as_tensors=False):
         """numEps finished games of self-play with the current net -> one iteration's examples (a deque in the reference's
         layout; as_tensors=True: device tensors (boards, pi, z, valids, q, meta) with the symmetries applied).  Collective when
-        the Coach is distributed: every rank returns the examples of ALL ranks."""
+        the Coach is distributed: rank 0 returns the examples of ALL ranks (it trains, Coach.py:150-215), the other ranks return none."""
         num_eps = int(_get(self.args, 'numEps', self.T))
         my_eps = episode_share(num_eps, self.T, self.world, self.rank)
         sims = int(_get(self.args, 'numMCTSSims', 800))
@@ -159,7 +159,14 @@ class Coach:
                   torch.empty((0, P), dtype=torch.float32, device=dev), torch.empty((0, A), dtype=torch.uint8, device=dev),
                   torch.empty((0, P), dtype=torch.float32, device=dev), torch.empty((0, 4), dtype=torch.int32, device=dev)]
         if self.dist:
-            ex = gather_examples(ex)
+            # rank 0 alone consumes the records (history, training: Coach.py:150-215): gather to root -- the count all_gather, then one
+            # grouped send / receive of exactly the finished records; the other ranks only advance the symmetry stream counter
+            info = {}
+            ex = gather_examples(ex, dst=0, info=info)
+            self.last_gather = info
+            if self.rank != 0:
+                self._sym_stream += int(sum(info.get('counts', [])))
+                return tuple(ex)
         boards, pi, z, valids, q, meta = ex
         if boards.shape[0] == 0:
             return tuple(ex)

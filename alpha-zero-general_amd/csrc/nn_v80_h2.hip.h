@@ -383,6 +383,9 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
     }
 }
 
+#ifdef AZG_NET_W4          /* experiment: cap the kernel at 128 VGPRs (4 waves per SIMD), the budget of a 16-wave workgroup */
+__attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 __global__ __launch_bounds__(768) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2BlockW Wv, H2NetW N, const int8_t* __restrict__ boards,
                                                     const uint8_t* __restrict__ valid, int B, int P, float* __restrict__ pi_out,
                                                     float* __restrict__ v_out) {

@@ -214,31 +214,85 @@ class SelfPlayEngine:
                 ov.reshape(-1, ov.shape[2])[keep], q[rep], meta[rep])
 
 
-def gather_examples(tensors, group=None):
-    """Multi-GPU episode-end gather of variable-length example records over RCCL (torch.distributed 'nccl' backend on
-    ROCm): all_gather the counts, pad to the maximum, all_gather the padded blocks, trim.  With games sharded
-    embarrassingly this is the ONLY collective on the path."""
-    import torch.distributed as dist
+def pack_records(tensors):
+    """(boards, pi, z, valids, q, meta, ...) with a common first dimension n -> ONE uint8 tensor [n, row_bytes]: every record is one
+    byte row (fields at 4-byte aligned offsets), so that the episode-end exchange is a single collective on a single buffer"""
+    n = int(tensors[0].shape[0])
+    layout, off = [], 0
+    for t in tensors:
+        nb = int(t[0].numel() if n else torch.empty((1,) + tuple(t.shape[1:]), dtype=t.dtype).numel()) * t.element_size()
+        layout.append((off, nb, t.dtype, tuple(t.shape[1:])))
+        off += (nb + 3) // 4 * 4
+    rows = torch.zeros((n, off), dtype=torch.uint8, device=tensors[0].device)
+    for t, (o, nb, _, _) in zip(tensors, layout):
+        if n:
+            rows[:, o:o + nb] = t.contiguous().view(n, -1).view(torch.uint8).view(n, nb)
+    return rows, layout
+
+
+def unpack_records(rows, layout):
+    n = int(rows.shape[0])
+    return [rows[:, o:o + nb].contiguous().view(dt).view((n,) + shape) for (o, nb, dt, shape) in layout]
+
+
+def gather_examples(tensors, group=None, dst=None, info=None):
+    """Multi-GPU episode-end gather of variable-length example records over RCCL (torch.distributed 'nccl' backend on ROCm).  With
+    games sharded embarrassingly this is the ONLY exchange on the path: an all_gather of the record COUNTS (8 bytes
+    per rank), then ONE data collective on the records packed as byte rows (pack_records):
+      dst = r    -> only rank r receives (Coach.py:150-215 trains in one place): one grouped send / receive of exactly count[k]
+                    rows from every rank k (torch.distributed.batch_isend_irecv = one ncclGroup on RCCL) -- no padding, nothing
+                    replicated; the other ranks get empty tensors back;
+      dst = None -> every rank receives every record: one all_gather of the rows padded to the largest count.
+    info (a dict, optional) receives world, counts per rank, bytes received by this rank and the wall time of the exchange."""
     import os
+    import time
+    import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return tensors
     if dist.get_world_size(group) == 1 and not os.environ.get('AZG_FORCE_DIST'):     # AZG_FORCE_DIST: run the collectives at world 1 too
         return tensors
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = tensors[0].device
     if dist.get_backend(group) == 'gloo' and dev.type != 'cpu':       # (CPU collectives: the world-2 tests on one GPU)
-        out = gather_examples([t.cpu() for t in tensors], group)
+        out = gather_examples([t.cpu() for t in tensors], group, dst, info)
         return [t.to(dev) for t in out]
-    n = torch.tensor([tensors[0].shape[0]], dtype=torch.int64, device=tensors[0].device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    m = max(counts)
-    out = []
-    for t in tensors:
-        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        pad[:t.shape[0]] = t
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad, group=group)
-        out.append(torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0))
+    if dev.type == 'cuda':
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n = torch.tensor([tensors[0].shape[0]], dtype=torch.int64, device=dev)
+    cnt = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(cnt, n, group=group) if dist.get_backend(group) != 'gloo' else dist.all_gather(list(cnt.split(1)), n, group=group)
+    counts = [int(c) for c in cnt.tolist()]
+    rows, layout = pack_records(tensors)
+    rb = int(rows.shape[1])
+    if dst is None:
+        m = max(counts)
+        pad = torch.zeros((m, rb), dtype=torch.uint8, device=dev)
+        pad[:rows.shape[0]] = rows
+        allr = torch.empty((world, m, rb), dtype=torch.uint8, device=dev)
+        if dist.get_backend(group) != 'gloo':
+            dist.all_gather_into_tensor(allr.view(world * m, rb), pad, group=group)
+        else:
+            dist.all_gather(list(allr.unbind(0)), pad, group=group)
+        got = torch.cat([allr[k, :c] for k, c in enumerate(counts)], dim=0)
+    elif rank == dst:
+        got = torch.empty((sum(counts), rb), dtype=torch.uint8, device=dev)
+        offs = [sum(counts[:k]) for k in range(world)]
+        got[offs[rank]:offs[rank] + counts[rank]] = rows
+        ops = [dist.P2POp(dist.irecv, got[offs[k]:offs[k] + counts[k]], k if group is None else dist.get_global_rank(group, k), group)
+               for k in range(world) if k != rank and counts[k] > 0]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+    else:
+        got = rows[:0]
+        if counts[rank] > 0:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, rows, dst if group is None else dist.get_global_rank(group, dst), group)]):
+                w.wait()
+    out = unpack_records(got, layout)
+    if dev.type == 'cuda':
+        torch.cuda.synchronize(dev)
+    if info is not None:
+        info.update(world=world, counts=counts, row_bytes=rb, bytes_received=int(got.shape[0]) * rb if (dst is None or rank == dst) else 0,
+                    ms=(time.perf_counter() - t0) * 1e3, mode='all_gather (padded)' if dst is None else 'grouped send/recv to rank %d' % dst,
+                    backend=dist.get_backend(group))
     return out

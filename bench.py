@@ -327,8 +327,11 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
     eng.run(steps * sims)
     ex = eng.drain_examples()
     n_local_examples = int(ex[0].shape[0])
+    ginfo = {}
     if use_dist:
-        ex = gather_examples(list(ex))           # the one RCCL collective of the path (episode-end example gather)
+        # the one RCCL exchange of the path (episode-end example gather): counts all_gather + ONE grouped send / receive of the packed
+        # records to rank 0, which is where Coach.learn consumes them (Coach.py:150-215)
+        ex = gather_examples(list(ex), dst=0, info=ginfo)
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -356,6 +359,12 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
                gc_runs=s1['gc_runs'], hip_graph=eng.graph is not None, rounds_timed=steps * sims,
                ms_per_round=dt / (steps * sims) * 1e3, preroll_plies=preroll, work_budget=eng.work_budget, advance_every=eng.K, node_capacity=eng.forest.cfg.node_capacity,
                max_live_frac=int(s1.get('max_live_after_gc', 0)) / max(1, eng.forest.cfg.node_capacity))
+    if use_dist:
+        # proof that the collective saw every rank, and what it cost (inside the timed region): world size as the process group reports
+        # it, the record count every rank contributed (from the count all_gather), the bytes rank 0 received, the wall time of the exchange
+        res.update(rccl_world=dist.get_world_size(), rccl_backend=dist.get_backend(), examples_per_rank=ginfo.get('counts'),
+                   gather_ms=ginfo.get('ms'), gather_bytes_received_rank0=ginfo.get('bytes_received'), gather_mode=ginfo.get('mode'),
+                   gather_row_bytes=ginfo.get('row_bytes'))
     res['roofline'] = measure_roofline(a, eng, T) if roofline and a.roofline_rounds > 0 else None
     res['roofline_net'] = measure_net(a, eng, T, game_key, net_kind) if roofline and a.roofline_rounds > 0 else None
     del ex
@@ -442,13 +451,16 @@ def main():
                ms_per_step=r['dt'] / a.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
                data='synthetic (Board.init_game boards from the counter RNG; net weights: reference checkpoint converted (%s))' % r['weights'],
                config=dict(workload=workload, games_per_gpu=T, step='one ply wave = %d lock-step rounds' % a.sims,
-                           parallelism='games sharded x%d, 1 RCCL example all_gather at episode end' % world if world > 1 else 'single GPU',
+                           parallelism='games sharded x%d by game index, no data-path collective; 1 RCCL example gather to rank 0 at episode end' % world if world > 1 else 'single GPU',
                            hip_graph=r['hip_graph']),
                groups=a.groups)
     for k in ('value_from_sims', 'sims_per_sec', 'plies_completed', 'games_finished', 'examples_gathered', 'examples_dropped',
               'engine_errors', 'forest_bytes_per_gpu', 'node_capacity', 'max_live_after_gc', 'max_live_frac', 'max_nodes_per_tree', 'gc_runs',
               'rounds_timed', 'ms_per_round', 'preroll_plies', 'work_budget', 'advance_every'):
         out[k] = r[k]
+    for k in ('rccl_world', 'rccl_backend', 'examples_per_rank', 'gather_ms', 'gather_bytes_received_rank0', 'gather_mode', 'gather_row_bytes'):
+        if k in r:
+            out[k] = r[k]
     out['config']['preroll'] = ('%d plies of fast searches (numMCTSSims // ratio_fullMCTS, MCTS.py:58-59) before the warm-up, untimed: games end '
                                 'inside the timed window (max_nodes_per_tree hugs node_capacity by design -- the clean-up is lazy; '
                                 'max_live_frac = nodes surviving a clean-up / node_capacity is the headroom figure)' % r['preroll_plies'])

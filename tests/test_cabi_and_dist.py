@@ -63,6 +63,23 @@ assert (out[0][:3] == 1).all() and (out[0][3:] == 2).all()
 assert torch.equal(out[1][3:], torch.arange(5 * 81, dtype=torch.float32).reshape(5, 81) + 1000)
 empty = gather_examples([torch.zeros((0 if rank == 0 else 2, 4), dtype=torch.float32)])
 assert empty[0].shape == (2, 4)
+# gather-to-root (what Coach.learn and bench.py use: Coach.py:150-215 consumes the examples on one rank): ONE grouped send / receive
+# of exactly count[k] packed byte rows per rank after the count all_gather, nothing for the other ranks
+info = {}
+valids = (torch.arange(n * 81).reshape(n, 81) %% 3 == rank).to(torch.uint8)
+meta = torch.arange(n * 4, dtype=torch.int32).reshape(n, 4) - 7 * rank
+root = gather_examples([boards, pi, z, valids, meta], dst=0, info=info)
+assert info['world'] == 2 and info['counts'] == [3, 5] and info['row_bytes'] == 392 + 324 + 8 + 84 + 16
+if rank == 0:
+    assert [tuple(t.shape) for t in root] == [(8, 392), (8, 81), (8, 2), (8, 81), (8, 4)] and info['bytes_received'] == 8 * info['row_bytes']
+    assert (root[0][:3] == 1).all() and (root[0][3:] == 2).all() and root[0].dtype == torch.int8
+    assert torch.equal(root[1][3:], torch.arange(5 * 81, dtype=torch.float32).reshape(5, 81) + 1000)
+    assert torch.equal(root[3][3:], (torch.arange(5 * 81).reshape(5, 81) %% 3 == 1).to(torch.uint8))
+    assert torch.equal(root[4][3:], torch.arange(20, dtype=torch.int32).reshape(5, 4) - 7) and torch.equal(root[4][:3], meta)
+else:
+    assert all(t.shape[0] == 0 for t in root) and root[1].dtype == torch.float32 and tuple(root[1].shape[1:]) == (81,)
+none = gather_examples([torch.zeros((0, 4), dtype=torch.float32)], dst=0)        # nobody has a record: no data exchange at all
+assert none[0].shape == (0, 4)
 dist.destroy_process_group()
 import sys
 sys.stdout.write('rank ' + str(rank) + ' ok' + chr(10)); sys.stdout.flush()      # one write: the two ranks share the pipe
