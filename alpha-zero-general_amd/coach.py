@@ -116,6 +116,7 @@ class Coach:
         # replays the games of the previous one (the reference draws fresh randomness every iteration)
         self.n_selfplay_waves += 1
         parts = []
+        failure = None
         if my_eps > 0:
             net = self.nnet.evaluator(self.T_local)
             if self.engine is None:
@@ -133,12 +134,24 @@ class Coach:
                 self.engine.run(8 * max(8, sims))
                 st = self.engine.stats()
                 if st['errors']:
-                    raise RuntimeError('engine error flags %d (16 = example ring overflow: %d records dropped; raise args.max_examples)'
-                                       % (st['errors'], st['examples_dropped']))
+                    failure = ('rank %d: engine error flags %d (16 = example ring overflow: %d records dropped; raise args.max_examples)'
+                               % (self.rank, st['errors'], st['examples_dropped']))
+                    break
                 parts.append(self.engine.drain_examples())
                 if st['active'] == 0:
+                    if st['games'] != my_eps:
+                        failure = 'rank %d: %d games finished, %d expected' % (self.rank, st['games'], my_eps)
                     break
-            assert st['games'] == my_eps, (st['games'], my_eps)
+        # a failure on one rank must stop every rank BEFORE the collectives of _collect (the others would wait in them forever):
+        # one MAX all_reduce of the failure flag, then the same exception everywhere
+        if self.dist:
+            flag = torch.tensor([1 if failure else 0], dtype=torch.int64)
+            flag = flag if self.dist.get_backend() == 'gloo' else flag.to(self.game.device)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            if int(flag.item()) and not failure:
+                failure = 'self-play failed on another rank'
+        if failure:
+            raise RuntimeError(failure)
         ex = self._collect(parts)
         if as_tensors:
             return ex
@@ -219,6 +232,7 @@ class Coach:
         if lead:
             os.makedirs(ckpt, exist_ok=True)
         seed = _get(a, 'seed', None)
+        self._sync_resume_state()
         for i in range(1, int(_get(a, 'numIters', 1)) + 1):
             it = self.iter_base + i
             if not self.skipFirstSelfPlay or i > 1:
@@ -281,6 +295,18 @@ class Coach:
                 self.consecutive_failures = 0
         return self.results
 
+    def _sync_resume_state(self):
+        """rank 0's resume state (loadTrainExamples: RNG epoch of the next self-play wave, iterations already played, symmetry stream,
+        skipFirstSelfPlay) -> every rank.  The checkpoint folder may be visible to rank 0 only; ranks that disagreed on these would
+        draw different random streams for the shards of one iteration and break "W ranks reproduce one rank"."""
+        if not self.dist:
+            return
+        t = torch.tensor([self.n_selfplay_waves, self.iter_base, self._sym_stream, int(self.skipFirstSelfPlay)], dtype=torch.int64)
+        t = t if self.dist.get_backend() == 'gloo' else t.to(self.game.device)
+        self.dist.broadcast(t, src=0)
+        self.n_selfplay_waves, self.iter_base, self._sym_stream, skip = [int(x) for x in t.tolist()]
+        self.skipFirstSelfPlay = bool(skip)
+
     @staticmethod
     def _copy_weights(src, dst):
         """dst's module <- src's module (the in-memory form of save_checkpoint('temp.pt') + load_checkpoint('temp.pt'))"""
@@ -307,6 +333,8 @@ class Coach:
         model_file = _get(self.args, 'load_folder_file', None)
         model_file = os.path.join(*model_file) if isinstance(model_file, (list, tuple)) else model_file
         path = os.path.join(os.path.dirname(model_file or ''), 'checkpoint.examples')
+        if self.rank != 0:
+            return          # rank 0 keeps the history and trains; its resume state reaches the other ranks in learn() (_sync_resume_state)
         if not os.path.isfile(path):
             self.log('File "%s" with trainExamples not found!' % path)
             return

@@ -186,6 +186,50 @@ extern "C" int azg_debug_poison_onchip(uint32_t pattern, void* stream) {
     return 0;
 }
 
+// ---- XCD-pinned streams ---------------------------------------------------------------------------------------------
+// MI355X = 8 XCDs x 32 CUs, one L2 per XCD.  A stream whose hardware queue is masked to the CUs of one XCD (or a few) keeps a group
+// of trees, its leaf batch and its pi / v on one L2 and lets the groups run as independent pipelines (selfplay.py).  The CU mask of a
+// queue is a bit vector over the device's CUs in the driver's enumeration, where consecutive bits go round-robin over the XCDs: bit b
+// is CU b / n_xcd of XCD b % n_xcd (checked on the box by azg_debug_placement: every workgroup reports its XCC_ID).
+extern "C" int azg_stream_create_xcd(int xcd_first, int xcd_count, void** out_stream) {
+    if (!out_stream || xcd_count <= 0) return fail("azg_stream_create_xcd: bad arguments");
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t pr;
+    HIPCHK(hipGetDeviceProperties(&pr, dev));
+    const int n_cu = pr.multiProcessorCount;
+    const int n_xcd = getenv("AZG_N_XCD") ? atoi(getenv("AZG_N_XCD")) : 8;
+    if (n_cu % n_xcd || xcd_first < 0 || xcd_first + xcd_count > n_xcd) return fail("azg_stream_create_xcd: XCD range does not fit the device");
+    std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+    for (int b = 0; b < n_cu; b++) {
+        const int x = b % n_xcd;
+        if (x >= xcd_first && x < xcd_first + xcd_count) mask[(size_t)b / 32] |= 1u << (b % 32);
+    }
+    hipStream_t st = nullptr;
+    HIPCHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    *out_stream = (void*)st;
+    return 0;
+}
+extern "C" int azg_stream_destroy(void* stream) {
+    if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+// where did the workgroups of a launch on `stream` run?  out[i] = XCC_ID | HW_ID cu_id << 8 | se_id << 16 of workgroup i
+__global__ __launch_bounds__(64) void k_debug_placement(uint32_t* out, int spin) {
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));              // HW_REG_XCC_ID
+    asm volatile("s_getreg_b32 %0, hwreg(4, 0, 32)" : "=s"(hw));               // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+    long long t0 = clock64();
+    while (clock64() - t0 < spin) {}                                           // keep the wave resident so that the launch spreads out
+    if (threadIdx.x == 0) out[blockIdx.x] = (xcc & 0xFu) | (((hw >> 8) & 0xFu) << 8) | (((hw >> 13) & 0x7u) << 16) | (((hw >> 12) & 1u) << 24);
+}
+extern "C" int azg_debug_placement(int n_workgroups, uint32_t* out_dev, void* stream) {
+    if (n_workgroups <= 0) return 0;
+    k_debug_placement<<<dim3(n_workgroups), dim3(64), 0, (hipStream_t)stream>>>(out_dev, 20000);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ---- forest ---------------------------------------------------------------------------------------------------------
 struct azg_forest {
     azg_forest_cfg cfg;

@@ -468,6 +468,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     constexpr int NPL = SPLIT ? SPLIT : 3;                  // planes per tile: 3 = bf16 x 3, 2 = f16 x 2
     constexpr int NS = 8, ROWS = NS * 25, CS = 68, CP2 = 2, AS = (A + 3) / 4 * 4 + 4, PLANE_B = (ROWS + 1) * 128, TILE_B = NPL * PLANE_B;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (NPL == 2) h2_fp16_saturate_mode();
     float* X = smem;                        // [ROWS][CS]   (SPLIT: three bf16 planes, TILE_B bytes)
     float* Y = SPLIT ? (float*)((uint8_t*)smem + TILE_B) : X + ROWS * CS;               // [ROWS][CS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -808,6 +809,7 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     constexpr int PLANE_B = (ROWS + 1) * 128, TILE_B = NPL * PLANE_B, HREG_B = 3 * PLANE_B;
     constexpr size_t G64_U4 = (size_t)4 * 2 * NPL * 64;        // uint4 per 64 x 64 matrix
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (NPL == 2) h2_fp16_saturate_mode();
     uint8_t* XP = (uint8_t*)smem;                               // X: three bf16 planes [ROWS + 1][64]
     uint8_t* HP = XP + TILE_B;                                  // one third of the expanded tile, same layout
     float* META = (float*)(HP + HREG_B);                        // [NS][32]

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int L = CF::L, C = CF::C, NS = CF::NS, NW = CF::NW, RT = CF::RT, XS = CF::XS, OS = CF::OS, HS = CF::HS, A = CF::A,
                   P = CF::P, AS = CF::AS, CP = CF::CP;
+    if (H2) h2_fp16_saturate_mode();        // out-of-range activations saturate instead of becoming inf (inf * zero padding = NaN)
     float* XA = smem;                       // first-layer output, later the head blocks' output O (row stride OS)
     float* X2 = XA + CF::XA_SZ;             // trunk output
     float* H = X2 + CF::X2_SZ;              // expanded activations; board tile before, head temporaries after

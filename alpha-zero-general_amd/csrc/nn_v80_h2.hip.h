@@ -45,6 +45,15 @@ struct H2NetW {
 // lane groups of an MFMA operand fetch -- 16 rows x 4 adjacent chunks -- hit 16 distinct 16-byte bank columns)
 __device__ __forceinline__ int h2_off(int row, int q, int RS) { return row * RS + ((q ^ (row & 7)) << 4); }
 
+// Activation range of the f16 x 2 kernels.  The planes hold 64 * x as f16, so |x| >= 1023.5 does not fit.  Every h2 kernel sets the
+// FP16_OVFL bit of its waves' MODE register (bit 23): an f16 result that overflows is CLAMPED to +-65504 instead of becoming inf, at no
+// instruction cost, so an out-of-range activation saturates (hi = 65504, lo = the clamped remainder: up to ~2047 is still carried) and
+// can never turn into inf - inf = NaN in the lo part or inf * 0 = NaN against a zero-padded weight.  The f32-operand kernels
+// (h2 = False) have the full f32 range; include/azg.h states the contract next to the 1e-5 one.
+__device__ __forceinline__ void h2_fp16_saturate_mode() {
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);      // hwreg(HW_REG_MODE, 23, 1) = 1
+}
+
 __device__ __forceinline__ void h2_split2(float a, float b, uint32_t& h, uint32_t& l) {
     const f16x2_t hh = __builtin_convertvector(f32x2{a, b}, f16x2_t);            // v_cvt_pk_f16_f32 (round to nearest even)
     const f32x2 back = __builtin_convertvector(hh, f32x2);
@@ -391,6 +400,7 @@ __global__ __launch_bounds__(768) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2
                                                     float* __restrict__ v_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int NS = 16, C = 56;
+    h2_fp16_saturate_mode();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
     const int b0 = blockIdx.x * NS;

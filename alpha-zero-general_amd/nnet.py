@@ -269,7 +269,7 @@ class SplendorV80Hip(SplendorV80):
 
     def _h2_ptrs(self):
         """pointer table + descale factors of azg_nn_v80_forward_h2 (include/azg.h): every matrix zero padded to K % 32 == 0,
-        N % 16 == 0, scaled by 2^k (max |w| * 2^k in [2^12, 2^13)) and split into f16 hi / lo fragments"""
+        N % 16 == 0, scaled by 2^k (max |w| * 2^k in (2^11, 2^12]) and split into f16 hi / lo fragments"""
         import ctypes as C
         import math
         d, f = self.device, torch.float32
@@ -281,7 +281,7 @@ class SplendorV80Hip(SplendorV80):
 
         def frag(W, K, N):
             m = pad(W.to(f), (K, N))
-            k = 12 - int(math.ceil(math.log2(float(m.abs().max()))))
+            k = 12 - int(math.ceil(math.log2(max(float(m.abs().max()), 1e-30))))      # (an all-zero matrix: any scale)
             m = m * (2.0 ** k)
             hi = m.to(torch.float16)
             lo = (m - hi.float()).to(torch.float16)
@@ -763,7 +763,7 @@ class SantoriniV89Hip:
             return frag(m.reshape(9 * cin_pad, co).contiguous())
         convs = [c for blk in base.blocks for c in blk]
         wmax = max(float(w.abs().max()) for w, _ in convs)
-        k2 = 12 - int(math.ceil(math.log2(wmax)))               # one power-of-two scale for the whole trunk: max |w| * 2^k in [2^11, 2^12]
+        k2 = 12 - int(math.ceil(math.log2(max(wmax, 1e-30))))               # one power-of-two scale for the whole trunk: max |w| * 2^k in [2^11, 2^12]
         self.descale = (2.0 ** -k2) / 64.0
 
         def conv_h2(w):                    # [co][ci][3][3] -> [4 ct][18 chunks][2 planes hi, lo][64 lanes][8] f16 of W * 2^k
@@ -893,8 +893,8 @@ class SantoriniV78Hip(SantoriniV89Hip):
         self._lib, self.base, self.device, self.split, self.h2 = _lib, base, base.device, bool(split) or bool(h2), bool(h2)
         self.P, self.A = base.P, base.A
         assert base.dtype == torch.float32 and self.device.type == 'cuda' and len(base.blocks) == 10 and self.A == 1782 and self.P == 2
-        ke = 12 - int(math.ceil(math.log2(max(float(we.abs().max()) for (we, _), _, _ in base.blocks))))
-        kp = 12 - int(math.ceil(math.log2(max(float(wp.abs().max()) for _, _, (wp, _) in base.blocks))))
+        ke = 12 - int(math.ceil(math.log2(max(1e-30, max(float(we.abs().max()) for (we, _), _, _ in base.blocks)))))
+        kp = 12 - int(math.ceil(math.log2(max(1e-30, max(float(wp.abs().max()) for _, _, (wp, _) in base.blocks)))))
         self.ds_e, self.ds_p = (2.0 ** -ke) / 64.0, (2.0 ** -kp) / 64.0
 
         def h2_64(m, k):                   # [64 K][64 N] f32 -> [4 ct][2 chunks of 32][2 planes hi, lo][64 lanes][8] f16 of W * 2^k

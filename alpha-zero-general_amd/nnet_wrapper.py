@@ -154,14 +154,25 @@ class NNetWrapper:
             self.requestKnowledgeTransfer = True
             return ck
         try:
-            if not self._custom and (self.nnet is None or getattr(self.nnet, 'version', None) != ver):
-                self.nnet = _module_for(self.game, ver, float(self._arg('dropout', 0.0) or 0.0))
+            # the replacement module is built and filled in a local: self.nnet changes only when the whole load succeeded (the
+            # reference's load_network keeps its existing net when the state dict does not fit, GenericNNetWrapper.py:262-267)
+            target = self.nnet
+            if not self._custom and (target is None or getattr(target, 'version', None) != ver):
+                target = _module_for(self.game, ver, float(self._arg('dropout', 0.0) or 0.0))
             sd = {k: torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v for k, v in ck['state_dict'].items()}
-            self.nnet.load_state_dict(sd, strict=True)
+            if target is self.nnet and target is not None:
+                # load_state_dict copies tensor by tensor: check the fit first, so that a mismatch cannot leave a half-loaded net
+                own = target.state_dict()
+                bad = [k for k in own if k not in sd or tuple(sd[k].shape) != tuple(own[k].shape)] + [k for k in sd if k not in own]
+                if bad:
+                    raise RuntimeError('state dict does not fit: %s' % ', '.join(bad[:4]))
+            target.load_state_dict(sd, strict=True)
         except (RuntimeError, ValueError) as ex:                         # another architecture: GenericNNetWrapper.py:262-267
             print('Could not load state dict (%s), initiate knowledge transfer' % str(ex).splitlines()[0])
             self.requestKnowledgeTransfer = True
+            self._eval = None                                            # (nothing cached may outlive a failed load)
             return ck
+        self.nnet = target
         self._eval = None
         return ck
 

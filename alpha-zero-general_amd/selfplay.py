@@ -1,7 +1,7 @@
 """Coach.executeEpisodes on the engine (Coach.py:86-148): T games per GPU, device-resident episode state machines, one
 batched NeuralNet.predict per lock-step round.  The reference time-slices N game threads on one core around a lock ring
 to build inference batches of N (Coach.py:117-144); here every round is
-    select (HIP) -> predict_batch (MFMA net kernels) -> expand_backup (HIP) -> selfplay_advance (HIP)
+    select (HIP; the expansion + backup of the previous round's leaves rides in its prologue) -> predict_batch (MFMA net kernel)
 with no host decision in the loop, so it is captured once in a HIP graph and replayed.  selfplay_advance only has work
 for a tree once per search (numMCTSSims rounds), so it is launched every `advance_every` rounds: a tree whose search is
 finished (or whose fresh root waits for its Dirichlet noise) sits out up to advance_every-1 rounds -- (advance_every-1) /
@@ -12,9 +12,17 @@ Whole-game sweep at 4096 x 800 sims (env-steps/s), round 1: budget 0 -> 21.3 k, 
 advance every 4 / 8 / 16 / 32 rounds -> 32.5 / 33.8 / 34.4 / 34.7 k.  Round 3 (tools/sweep_budget_games.sh): Splendor 10 / 48 -> 68.1 k
 against 63.0 k for 20 / 16; Azul and Santorini keep 20 / 16 -- the defaults below are per game family.
 
-The descent kernel is a latency chain (few waves, each waiting on dependent loads) while the net is throughput bound, so
-the games are split into `groups` independent forests whose rounds are skewed by one stage and run on separate HIP
-streams inside the same graph: while group 0 descends its trees, group 1's leaves are in the net, and vice versa."""
+PIPELINES (round 4).  Both kernels of a round are latency chains -- a select launch lasts as long as the slowest of its trees
+(median wave 20 us, last wave 33 us at 4096 trees), a net launch as long as one workgroup's 16 leaves -- and neither can share a CU
+with the other (a net workgroup takes 504 of a SIMD's 512 VGPRs and 156 of the CU's 160 KB of LDS).  So the games are split into
+`groups` independent forests, each with its own stream, its own leaf / pi / v buffers and its own captured graph of K fused rounds,
+and each stream's hardware queue is masked to the CUs of ONE XCD (azg_stream_create_xcd; 8 groups = 8 XCDs x 32 CUs = 512 trees =
+16 per CU, the same per-CU load as one big launch).  Nothing synchronises the groups: a group's launch boundary waits for the
+slowest of ITS trees only, the groups drift out of phase so that the memory system sees descents and net forwards mixed instead of
+4096 descents at once, and a group's leaf batch, pi / v and net weights stay in its XCD's L2.  Per-tree results do not depend on
+the grouping (global game streams stream0 + index; tested)."""
+import ctypes as C
+
 import torch
 
 from .forest import Forest
@@ -27,6 +35,8 @@ class _Group:
         static = torch.is_tensor(st) and tuple(st.shape) == (forest.T, forest.A) and st.dtype == torch.float32
         self.pi = st if static else torch.zeros((forest.T, forest.A), dtype=torch.float32, device=forest.device)
         self.v = net.v if static else torch.zeros((forest.T, forest.P), dtype=torch.float32, device=forest.device)
+        self.stream = None          # torch stream of this group's pipeline (None: the caller's current stream)
+        self.graph = None
 
     def select(self):
         self.f.select(device_noise=self.device_noise)
@@ -46,14 +56,24 @@ class _Group:
         if pi.data_ptr() != self.pi.data_ptr():          # nets without static output buffers: keep the addresses stable
             self.pi.copy_(pi); self.v.copy_(v)
 
-    def predict_expand_advance(self):
-        self.predict_expand()
-        self.f.selfplay_advance()
+    def round(self, fused, advance=True):
+        """one lock-step round of this group's trees on the current stream"""
+        if fused:
+            self.select_fused()                       # expansion of the previous round's leaves + this round's descent
+            if advance:
+                self.f.selfplay_advance()
+            self.predict_into_buffers()
+        else:
+            self.select()
+            self.predict_expand()
+            if advance:
+                self.f.selfplay_advance()
 
 
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
-                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=None, fused=True):
+                 use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=None, fused=True,
+                 pin_xcd=None):
         self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
@@ -61,7 +81,7 @@ class SelfPlayEngine:
         cap = node_capacity or max(1024, 16 * sims + 512)
         assert n_games % groups == 0
         self.T, self.G = n_games, groups
-        self.fused = bool(fused) and groups == 1
+        self.fused = bool(fused)
         # defaults per game family, from whole-game sweeps at 4096 games x 800 sims (tools/sweep_budget_games.sh; the timings repeat to
         # 0.1 % since k_select stopped reading the dispatch packet): Splendor 2p / 4p prefer short launches and a rarer advance (work
         # budget 10, every 48 rounds: +8 % / +3 % over 20 / 16), Azul and Santorini the opposite (20 / 16: 42.5 k vs 35.5 k, 21.6 k vs 20.9 k)
@@ -71,7 +91,6 @@ class SelfPlayEngine:
             work_budget = 10 if splendor else 20
         # cadence of the advance launch: idle share (K-1)/numMCTSSims kept to a few per cent
         self.K = max(1, min(48, sims // 16) if splendor else min(16, sims // 50)) if advance_every is None else int(advance_every)
-        assert self.K == 1 or groups == 1
         self.work_budget = int(work_budget)
         Tg = n_games // groups
         alpha = float(get('dirichletAlpha', 0.0)) if dirichlet is None else float(dirichlet)
@@ -87,9 +106,46 @@ class SelfPlayEngine:
         self.forest = self.groups[0].f
         self.nnet = nets[0]
         self.use_graph = use_graph
-        self.graph = None
         self.rounds = 0
-        self._streams = [torch.cuda.Stream() for _ in range(groups)] if groups > 1 else None
+        # one stream per pipeline; pinned to an XCD (or an equal share of the 8 XCDs) unless pin_xcd=False
+        self.pin_xcd = (groups > 1) if pin_xcd is None else bool(pin_xcd)
+        self._raw_streams = []
+        if groups > 1:
+            n_xcd = 8
+            for g, grp in enumerate(self.groups):
+                if self.pin_xcd:
+                    per = max(1, n_xcd // groups)
+                    first = (g * per) % n_xcd
+                    h = C.c_void_p()
+                    _lib.check(_lib.lib().azg_stream_create_xcd(first, per, C.byref(h)))
+                    self._raw_streams.append(h)
+                    grp.stream = torch.cuda.ExternalStream(h.value, device=game.device)
+                    grp.xcds = (first, per)
+                else:
+                    grp.stream = torch.cuda.Stream(device=game.device)
+
+    @property
+    def graph(self):
+        """the captured rounds of the first group (None = nothing captured / stale)"""
+        return self.groups[0].graph
+
+    @graph.setter
+    def graph(self, value):
+        assert value is None
+        for grp in self.groups:
+            grp.graph = None
+
+    def close(self):
+        for grp in self.groups:
+            grp.graph = None
+            grp.f.close()
+        torch.cuda.synchronize()
+        from . import _lib
+        for grp in self.groups:
+            grp.stream = None
+        for h in self._raw_streams:
+            _lib.lib().azg_stream_destroy(h)
+        self._raw_streams = []
 
     def start(self, init_boards=None, epoch=0, episode_quota=0):
         """epoch: re-keys every random stream (Coach passes the iteration number, so that successive iterations do not
@@ -100,17 +156,17 @@ class SelfPlayEngine:
             # a group without episodes cannot be expressed to the forest (its quota 0 means "restart forever"): refuse before
             # anything is launched
             raise ValueError('episode_quota %d is smaller than the number of groups %d' % (episode_quota, self.G))
+        # the kernel deals a quota out as quota / T (+1 for the first quota % T trees); global stream t of the whole engine must play what
+        # it would play in ONE forest of T trees, whatever the grouping: group g gets the sum over its streams
+        a, b = divmod(int(episode_quota), self.T)
         for g, grp in enumerate(self.groups):
-            q = episode_quota // self.G + (1 if g < episode_quota % self.G else 0)
+            q = a * Tg + max(0, min(Tg, b - g * Tg)) if episode_quota else 0
+            if episode_quota and q == 0:
+                raise ValueError('episode_quota %d leaves group %d of %d without a game' % (episode_quota, g, self.G))
             grp.f.selfplay_start(None if init_boards is None else init_boards[g * Tg:(g + 1) * Tg], epoch=epoch, episode_quota=q)
         if (epoch, episode_quota) != getattr(self, '_epoch_quota', (0, 0)):
             self.graph = None                # seed and quota are kernel arguments: the captured rounds are stale
         self._epoch_quota = (epoch, episode_quota)
-        torch.cuda.synchronize()
-        # pipeline prologue: odd groups enter the steady state one stage ahead (their leaves are already selected)
-        for g, grp in enumerate(self.groups):
-            if g % 2 == 1:
-                grp.select()
         torch.cuda.synchronize()
 
     def set_search_params(self, numMCTSSims, prob_fullMCTS):
@@ -121,48 +177,35 @@ class SelfPlayEngine:
         self.graph = None
 
     def _round(self, advance=True):
-        """one round of every group; group g's stage order is rotated by g (software-pipeline skew)"""
+        """one eager round of every group (each on its own stream when there are several)"""
         if self.G == 1:
-            grp = self.groups[0]
-            if self.fused:
-                grp.select_fused()                   # expansion of the previous round's leaves + this round's descent
-                if advance:
-                    grp.f.selfplay_advance()
-                grp.predict_into_buffers()
-                return
-            grp.select()
-            grp.predict_expand()
-            if advance:
-                grp.f.selfplay_advance()
+            self.groups[0].round(self.fused, advance)
             return
         cur = torch.cuda.current_stream()
-        for g, grp in enumerate(self.groups):
-            s = self._streams[g]
-            s.wait_stream(cur)
-            with torch.cuda.stream(s):
-                if g % 2 == 0:
-                    grp.select()
-                    grp.predict_expand_advance()
-                else:
-                    grp.predict_expand_advance()
-                    grp.select()
-        for s in self._streams:
-            cur.wait_stream(s)
+        for grp in self.groups:
+            grp.stream.wait_stream(cur)
+            with torch.cuda.stream(grp.stream):
+                grp.round(self.fused, advance)
+        for grp in self.groups:
+            cur.wait_stream(grp.stream)
 
     def capture(self):
-        """Capture one round in a HIP graph (after a few eager warm-up rounds on a side stream)."""
+        """Capture K rounds of every group in a HIP graph of its own (after a few eager warm-up rounds on a side stream)."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(3):
-                self._round()
+                for grp in self.groups:
+                    grp.round(self.fused)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for k in range(self.K):
-                self._round(advance=(k == self.K - 1))
-        self.graph = g
+        for grp in self.groups:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for k in range(self.K):
+                    grp.round(self.fused, advance=(k == self.K - 1))
+            grp.graph = g
+        torch.cuda.synchronize()
         self.rounds += 3 + self.K
 
     def run(self, rounds):
@@ -170,8 +213,21 @@ class SelfPlayEngine:
             self.capture()
         done = 0
         if self.graph is not None:
-            for _ in range(rounds // self.K):
-                self.graph.replay()
+            n = rounds // self.K
+            if self.G == 1:
+                for _ in range(n):
+                    self.groups[0].graph.replay()
+            elif n:
+                # every group's replays go to its own (XCD-pinned) stream: independent pipelines, joined at the end of the call
+                cur = torch.cuda.current_stream()
+                for grp in self.groups:
+                    grp.stream.wait_stream(cur)
+                for _ in range(n):
+                    for grp in self.groups:
+                        with torch.cuda.stream(grp.stream):
+                            grp.graph.replay()
+                for grp in self.groups:
+                    cur.wait_stream(grp.stream)
             done = rounds - rounds % self.K
         for _ in range(rounds - done):               # remainder (or no graph): eager rounds, advance every round
             self._round()

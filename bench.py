@@ -212,7 +212,8 @@ def build_engine(a, game_key, T, rank, dev):
         try:
             eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
                                  stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups,
-                                 work_budget=None if a.work_budget < 0 else a.work_budget, advance_every=a.advance_every or None)
+                                 work_budget=None if a.work_budget < 0 else a.work_budget, advance_every=a.advance_every or None,
+                                 pin_xcd=None if not a.no_pin_xcd else False)
             break
         except Exception as ex:        # azg_amd.AzgError: hipMalloc failed
             if a.node_capacity or attempt == 2:
@@ -368,8 +369,7 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
     res['roofline'] = measure_roofline(a, eng, T) if roofline and a.roofline_rounds > 0 else None
     res['roofline_net'] = measure_net(a, eng, T, game_key, net_kind) if roofline and a.roofline_rounds > 0 else None
     del ex
-    for grp in eng.groups:
-        grp.f.close()
+    eng.close()
     del eng
     torch.cuda.empty_cache()
     return res
@@ -388,7 +388,10 @@ def main():
     ap.add_argument('--sims', type=int, default=800)
     ap.add_argument('--node-capacity', type=int, default=0)
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--groups', type=int, default=1, help='independent forests with skewed rounds on separate streams')
+    ap.add_argument('--groups', type=int, default=1,
+                    help='independent pipelines: the games are split into this many forests, each with its own stream (pinned to one XCD, or '
+                         'to 8 / groups XCDs), leaf batch and captured graph; nothing synchronises them')
+    ap.add_argument('--no-pin-xcd', action='store_true', help='groups > 1 on ordinary streams (no CU mask): A/B of the XCD pinning')
     ap.add_argument('--level-budget', type=int, default=0, help='max descent levels per tree per select launch (0 = unlimited)')
     ap.add_argument('--advance-every', type=int, default=0, help='rounds per selfplay_advance launch / HIP graph (0 = engine default)')
     ap.add_argument('--work-budget', type=int, default=-1, help='per-launch work cap per tree (level units), 0 = off, -1 = the engine default for the game')

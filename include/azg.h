@@ -170,6 +170,15 @@ int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8_t* states,
 /* debug: fill the LDS of every CU and the queue's scratch memory with `pattern` (a kernel that reads on-chip memory it never wrote then
    depends on the pattern, not on what ran before) */
 int azg_debug_poison_onchip(uint32_t pattern, void* stream);
+/* XCD-pinned streams (no reference counterpart: the reference time-slices N game threads on one core, Coach.py:117-144; here groups
+   of games run as independent select -> predict pipelines, one per XCD, selfplay.py): a HIP stream whose queue may only use the CUs of
+   XCDs [xcd_first, xcd_first + xcd_count) of the current device (hipExtStreamCreateWithCUMask).  Pass the handle as `stream` to
+   any call of this header. */
+int azg_stream_create_xcd(int xcd_first, int xcd_count, void** out_stream);
+int azg_stream_destroy(void* stream);
+/* debug / tests: launch n_workgroups one-wave workgroups on `stream`; out_dev[i] = XCC_ID | cu_id << 8 | se_id << 16 | sh_id << 24 of
+   the CU that ran workgroup i */
+int azg_debug_placement(int n_workgroups, uint32_t* out_dev, void* stream);
 /* debug / tests: check the structural invariants of every tree on the host; returns the number of violations */
 int azg_forest_validate(azg_forest* f, int verbose);
 
@@ -273,6 +282,13 @@ int azg_nn_v80_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev,
    The token-mix matrices Wd[7][7] of the two Hardswish blocks (policy, value head) are passed DIVIDED BY 6: the kernel computes
    6 * Hardswish and leaves the 1/6 to the next linear step.
    descale (HOST array of 16 floats) = 2^-k / 64 for W0, {We, W1, W2, Wp} x (trunk, policy, value), Wpi1, Wpi2, Wv1. */
+/* Activation range of the f16 x 2 ("h2") forwards -- azg_nn_v80_forward_h2, azg_nn_mb1d_forward_h2, azg_nn_conv5_forward_h2,
+   azg_nn_s78_forward_h2: their LDS planes hold 64 * x as f16 (hi) + f16 (lo), so the 1e-5 contract holds for activations and
+   residual-stream values |x| < 1023 (the reference's trained nets stay below ~50).  Beyond that the value SATURATES: the kernels run
+   with the FP16_OVFL bit of the wave MODE register set, so an f16 conversion that overflows gives +-65504 instead of inf -- pi / v stay
+   finite, never NaN (tests/test_nnet.py::test_h2_kernels_saturate_out_of_range_activations_gpu).  A net that may leave the range (e.g.
+   a diverging training run) is evaluated with the f32-operand kernels (azg_nn_v80_forward / _mb1d_forward / _conv5_forward /
+   _s78_forward; Python: h2=False), which have the full f32 range at 1/3 .. 1/2 of the speed. */
 int azg_nn_v80_forward_h2(const int8_t* boards_dev, const uint8_t* valid_dev, const void* const* w, const float* descale_host,
                           int B, int P, float* pi_dev, float* v_dev, void* stream);
 /* The whole MobileNetV3-1d forward (first layer, trunk block, policy block + head, value block + head) in one launch for

@@ -323,3 +323,43 @@ def test_net_kernels_do_not_depend_on_stale_onchip_memory(tag):
         outs.append((pi.clone(), v.clone()))
     for pi, v in outs[1:]:
         assert torch.equal(pi, outs[0][0]) and torch.equal(v, outs[0][1])
+
+
+@pytest.mark.gpu
+def test_h2_kernels_saturate_out_of_range_activations_gpu():
+    """Activation range of the f16 x 2 kernels (include/azg.h, 'Activation range'): their LDS planes hold 64 * x as f16, so |x| >= 1023.5
+    does not fit.  The kernels run with the FP16_OVFL mode bit set: such a value saturates -- pi / v stay finite, never NaN -- and the
+    f32-operand kernel of the same net (h2=False, split=False) has the full range and stays on the fp32 model.  A net whose first layer
+    is scaled up 2000 x drives the residual stream to ~1e4 (GenericNNetWrapper.train can diverge like this)."""
+    from azg_amd import nnet
+    z = np.load(os.path.join(root, 'weights_splendor2_v80.npz'))
+    sd = {k[3:]: torch.as_tensor(z[k]).clone() for k in z.files if k.startswith('sd/')}
+    sd['first_layer.linear.weight'] *= 2000.0
+    torch.manual_seed(5)
+    B = 64
+    boards = torch.randint(0, 6, (B, 56, 7), dtype=torch.int8, device='cuda:0')
+    valids = (torch.rand((B, 81), device='cuda:0') < 0.5).to(torch.uint8)
+    valids[:, 80] = 1
+    ref = nnet.SplendorV80(sd, device='cuda:0', dtype=torch.float64)
+    x0 = torch.matmul(boards.reshape(B, 56, 7).double().transpose(1, 2), ref.W0) + ref.b0
+    assert float(x0.abs().max()) > 2000.0                      # the tile really leaves the planes' range
+    p64, v64 = ref.predict_batch(boards, valids.bool())
+    h2 = nnet.SplendorV80Hip(sd, device='cuda:0', max_batch=B, h2=True)
+    pi, v = h2.predict_batch(boards, valids)
+    assert bool(torch.isfinite(pi).all()) and bool(torch.isfinite(v).all()), 'out-of-range activations must saturate, not turn into inf / NaN'
+    assert torch.allclose(pi.sum(dim=1), torch.ones(B, device='cuda:0'), atol=1e-4)
+    f32 = nnet.SplendorV80Hip(sd, device='cuda:0', max_batch=B, h2=False, split=False)
+    pf, vf = f32.predict_batch(boards, valids)
+    assert float((pf.double() - p64).abs().max()) < 1e-3 and float((vf.double() - v64).abs().max()) < 1e-3     # f32 arithmetic at 1e4 magnitudes
+    # the generic kernel splits its f32 tiles as they are read; a saturated operand may not meet zero padding as inf * 0 = NaN
+    sd4 = {k[3:]: torch.as_tensor(np.load(os.path.join(root, 'weights_azul_v84.npz'))[k]).clone()
+           for k in np.load(os.path.join(root, 'weights_azul_v84.npz')).files if k.startswith('sd/')}
+    key = [k for k in sd4 if k.startswith('first_layer') and k.endswith('linear.weight')][0]
+    sd4[key] *= 5000.0
+    base = nnet.AzulV84(sd4, device='cuda:0')
+    mb = nnet.MobileNet1dHip(base, max_batch=B, h2=True)
+    ab = torch.randint(0, 5, (B, 23, 6), dtype=torch.int8, device='cuda:0')
+    av = (torch.rand((B, base.A), device='cuda:0') < 0.5).to(torch.uint8)
+    av[:, 0] = 1
+    pa, va = mb.predict_batch(ab, av)
+    assert bool(torch.isfinite(pa).all()) and bool(torch.isfinite(va).all())
