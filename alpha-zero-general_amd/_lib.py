@@ -37,7 +37,7 @@ EXPORTS = [
     'azg_last_error', 'azg_version', 'azg_device_count', 'azg_set_device', 'azg_game_info', 'azg_env_valid_moves',
     'azg_env_next_state', 'azg_env_game_ended', 'azg_env_canonical', 'azg_env_init_boards', 'azg_env_symmetries', 'azg_env_symmetries_ex', 'azg_debug_poison_onchip', 'azg_stream_create_xcd', 'azg_stream_destroy', 'azg_debug_placement', 'azg_forest_create',
     'azg_forest_destroy', 'azg_forest_device_bytes', 'azg_forest_reset', 'azg_forest_begin_search',
-    'azg_forest_select', 'azg_forest_select_fused', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
+    'azg_forest_select', 'azg_forest_select_fused', 'azg_forest_rounds_v80_h2', 'azg_forest_rounds_profile', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
     'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_forest_validate', 'azg_selfplay_start', 'azg_selfplay_start_ex', 'azg_selfplay_advance', 'azg_selfplay_active',
     'azg_selfplay_stats_get', 'azg_selfplay_drain_examples', 'azg_forest_last_kernel_ms', 'azg_forest_enable_timing', 'azg_forest_set_search_params', 'azg_nn_linear', 'azg_nn_linear_ws', 'azg_nn_dw_pool', 'azg_nn_v80_block', 'azg_nn_v80_forward', 'azg_nn_v80_forward_split', 'azg_nn_v80_forward_h2',
     'azg_nn_board_to_x', 'azg_nn_heads_out', 'azg_nn_dw_pool_l', 'azg_nn_board_to_x_ld', 'azg_nn_mb1d_forward', 'azg_nn_mb1d_forward_h2', 'azg_nn_conv5_forward', 'azg_nn_conv5_forward_split', 'azg_nn_conv5_forward_h2', 'azg_nn_s78_forward', 'azg_nn_s78_forward_split', 'azg_nn_s78_forward_h2',
@@ -86,6 +86,8 @@ def lib():
     L.azg_selfplay_drain_examples.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, ip, vp]
     L.azg_forest_last_kernel_ms.argtypes = [vp, i, C.POINTER(dbl), C.POINTER(u64)]
     L.azg_forest_enable_timing.argtypes = [vp, i]
+    L.azg_forest_rounds_v80_h2.argtypes = [vp, vp, vp, vp, vp, vp, i, vp, vp, i, vp]
+    L.azg_forest_rounds_profile.argtypes = [vp, C.POINTER(C.c_double), i]
     L.azg_stream_create_xcd.argtypes = [i, i, C.POINTER(vp)]
     L.azg_stream_destroy.argtypes = [vp]
     L.azg_debug_placement.argtypes = [i, vp, vp]

@@ -16,6 +16,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fP
 # -- a scalar load from the queue ring in HOST memory at the top of k_select's descent: 10-30 k cycles per launch, and the whole of the
 # kernel's "slow / fast mode" (47-50 vs 57-62 us; 41.7 us without the load).  With the pass off those 32 bytes are scratch.
 UNITS = [('azg.hip', ['-mllvm', '-disable-promote-alloca-to-lds']), ('azg_nn.hip', ['-mllvm', '-disable-promote-alloca-to-lds'])]
+# (azg_nn.hip also holds the per-CU round kernel, azg_fused.hip.h: 16 tree descents + their net forward in one workgroup)
 # debugging builds: AZG_DEFINES="AZG_CYC_COUNTERS AZG_NN_PHASE_TIMES" python alpha-zero-general_amd/build.py
 FLAGS += ['-D' + d for d in os.environ.get('AZG_DEFINES', '').split()]
 FLAGS += os.environ.get('AZG_EXTRA_FLAGS', '').split()            # e.g. -ftrivial-auto-var-init=pattern when hunting an uninitialised local
@@ -33,20 +34,46 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in sources())
 
 
+def _unit_stale(obj, dep):
+    """an object is up to date when it is newer than every file its compile read (the -MD dependency file next to it)"""
+    if not (os.path.exists(obj) and os.path.exists(dep)):
+        return True
+    t = os.path.getmtime(obj)
+    try:
+        words = open(dep).read().replace('\\\n', ' ').split()
+    except OSError:
+        return True
+    files = [w for w in words[1:] if not w.endswith(':')]
+    return any((not os.path.exists(f)) or os.path.getmtime(f) > t for f in files)
+
+
 def build(force=False, verbose=False):
+    """force=True (the driver's build check): compile every unit from scratch.  Otherwise units whose sources did not change are
+    taken from the object cache (AZG_OBJ_DIR, default build_ab/obj/<flags hash>): a change to the net kernels recompiles azg_nn.hip only."""
     if not force and not needs_build():
         return LIB
+    import hashlib
     import shutil
     import tempfile
-    tmp = tempfile.mkdtemp(prefix='azg_build_')
+    cache = None
+    if not force:
+        key = hashlib.sha1(' '.join(FLAGS + [str(u) for u in UNITS]).encode()).hexdigest()[:12]
+        cache = os.path.join(os.environ.get('AZG_OBJ_DIR') or os.path.join(HERE, '..', 'build_ab', 'obj'), key)
+        os.makedirs(cache, exist_ok=True)
+    tmp = cache or tempfile.mkdtemp(prefix='azg_build_')
     objs, procs = [], []
     for src, extra in UNITS:                       # the units compile concurrently
         obj = os.path.join(tmp, src.replace('.hip', '.o'))
-        cmd = [HIPCC] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
+        dep = obj + '.d'
+        objs.append(obj)
+        if cache and not _unit_stale(obj, dep):
+            if verbose:
+                print('up to date:', obj)
+            continue
+        cmd = [HIPCC] + FLAGS + extra + ['-MD', '-MF', dep, '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
@@ -54,9 +81,11 @@ def build(force=False, verbose=False):
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
-    shutil.rmtree(tmp, ignore_errors=True)
+    if not cache:
+        shutil.rmtree(tmp, ignore_errors=True)
     return LIB
 
 
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force='--incremental' not in sys.argv, verbose=True))

@@ -382,6 +382,13 @@ extern "C" size_t azg_forest_device_bytes(const azg_forest* f) { return f ? f->b
 
 #define FDISPATCH(f, ...) AZG_DISPATCH((f)->cfg.game, (f)->cfg.variant, __VA_ARGS__)
 
+const azg::ForestDev* azg_forest_dev_internal(azg_forest* f, int* game, int* variant, double* dirichlet_alpha) {
+    if (game) *game = f->cfg.game;
+    if (variant) *variant = f->cfg.variant;
+    if (dirichlet_alpha) *dirichlet_alpha = f->cfg.dirichletAlpha;
+    return &f->dev;
+}
+
 extern "C" int azg_forest_reset(azg_forest* f, void* stream) {
     if (!f) return fail("null forest");
     FDISPATCH(f, k_forest_reset<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev));

@@ -11,10 +11,27 @@
 
 namespace azg {
 
+#ifdef AZG_WAVE_LOCAL_SYNC
+// (the translation unit of the per-CU round kernel: the lane id is laundered through an empty volatile asm, so that the compiler cannot
+// hoist the descent's lane-derived address arithmetic out of the kernel's round loop -- and keep it alive, spilled, across the net phase)
+__device__ __forceinline__ int lane_id() { int l = threadIdx.x & 63; asm volatile("" : "+v"(l)); return l; }
+#else
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+#endif
 
-// LDS ordering inside a single-wave workgroup: s_barrier is a no-op for one wave, the waitcnt it carries is what matters.
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// LDS ordering inside ONE wavefront.  In a single-wave workgroup __syncthreads() does it (s_barrier is a no-op for one wave, the waitcnt
+// it carries is what matters).  A translation unit whose workgroups hold several tree waves (azg_nn.hip with azg_fused.hip.h) defines
+// AZG_WAVE_LOCAL_SYNC: a wavefront-scope fence (the LDS and the vector-memory path serve one wave's requests in order, so only the
+// compiler must be kept from reordering) + the wave barrier intrinsic; a workgroup barrier there would deadlock divergent waves.
+__device__ __forceinline__ void wave_sync() {
+#ifdef AZG_WAVE_LOCAL_SYNC
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#else
+    __syncthreads();
+#endif
+}
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
@@ -141,7 +158,7 @@ __device__ __forceinline__ int lane0_make_move(int8_t* st, int move, int player,
     np = __builtin_amdgcn_readfirstlane(np);
     rng.counter = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rng.counter >> 32)) << 32) |
                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rng.counter);
-    __syncthreads();
+    wave_sync();
     return np;
 }
 

@@ -6,3 +6,9 @@
 int azg_fail(const std::string& m);               // records the message for azg_last_error(), returns -1
 static inline int fail(const std::string& m) { return azg_fail(m); }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
+
+
+// internal (not part of include/azg.h): what azg_fused.hip needs from a forest handle owned by azg.hip
+struct azg_forest;
+namespace azg { struct ForestDev; }
+const azg::ForestDev* azg_forest_dev_internal(azg_forest* f, int* game, int* variant, double* dirichlet_alpha);

@@ -7,6 +7,9 @@
 #include <string.h>
 #include <string>
 
+// this unit also holds the per-CU round kernel (azg_fused.hip.h, included at the end): its workgroups run 16 independent tree waves, so
+// wave_sync() must be a wavefront fence here (the net kernels synchronise with __syncthreads() directly and are not affected)
+#define AZG_WAVE_LOCAL_SYNC 1
 #include "../../include/azg.h"
 #include "azg_host.h"
 #include "azg_common.hip.h"
@@ -223,23 +226,18 @@ extern "C" int azg_nn_v80_forward_h2(const int8_t* boards, const uint8_t* valid,
                                      const float* descale /* 16, host */, int B, int P, float* pi, float* v, void* stream) {
     if (!boards || !valid || !w || !descale || !pi || !v || B <= 0) return fail("azg_nn_v80_forward_h2: null/empty argument");
     if (P < 2 || P > 4) return fail("azg_nn_v80_forward_h2: 2 <= P <= 4");
-    auto blk = [&](int o, int d) {
-        return H2BlockW{(const uint4*)w[o], (const uint4*)w[o + 5], (const uint4*)w[o + 7], (const uint4*)w[o + 9],
-                        (const float*)w[o + 1], (const float*)w[o + 2], (const float*)w[o + 3], (const float*)w[o + 4],
-                        (const float*)w[o + 6], (const float*)w[o + 8], (const float*)w[o + 10],
-                        descale[d], descale[d + 1], descale[d + 2], descale[d + 3]};
-    };
-    const H2BlockW Wt = blk(2, 1), Wp = blk(13, 5), Wv = blk(24, 9);
-    const H2NetW N{(const uint4*)w[0], (const uint4*)w[35], (const uint4*)w[37], (const uint4*)w[39],
-                   (const float*)w[1], (const float*)w[36], (const float*)w[38], (const float*)w[40], (const float*)w[41],
-                   (const float*)w[42], descale[0], descale[13], descale[14], descale[15]};
+    const H2Weights HW = h2_weights(w, descale);
+    const H2BlockW &Wt = HW.Wt, &Wp = HW.Wp, &Wv = HW.Wv;
+    const H2NetW& N = HW.N;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_h2 = false;
-    if (!attr_h2) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_v80_net_h2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_h2 = true;
+    static int waves_h2 = 0;          // AZG_V80_WAVES=16: the 16-wave / 128-VGPR variant (the form the fused round kernel uses); default 12
+    if (!waves_h2) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_v80_net_h2<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_v80_net_h2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        waves_h2 = (getenv("AZG_V80_WAVES") && atoi(getenv("AZG_V80_WAVES")) == 16) ? 16 : 12;
     }
-    k_v80_net_h2<<<dim3((B + 15) / 16), dim3(768), H2_LDS, s>>>(Wt, Wp, Wv, N, boards, valid, B, P, pi, v);
+    if (waves_h2 == 16) k_v80_net_h2<16><<<dim3((B + 15) / 16), dim3(1024), H2_LDS, s>>>(Wt, Wp, Wv, N, boards, valid, B, P, pi, v);
+    else k_v80_net_h2<12><<<dim3((B + 15) / 16), dim3(768), H2_LDS, s>>>(Wt, Wp, Wv, N, boards, valid, B, P, pi, v);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -449,3 +447,5 @@ extern "C" int azg_nn_heads_out(const float* logits, int ldl, const uint8_t* val
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+#include "azg_fused.hip.h"

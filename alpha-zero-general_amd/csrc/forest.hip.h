@@ -179,7 +179,7 @@ __device__ __forceinline__ T load_uniform(const T* p) {
 template <class T>
 __device__ __forceinline__ T load_uniform_hot(const T* p) { return load_uniform<T, true>(p); }
 
-__device__ __constant__ long long AZG_MAGIC_SEEDS[8] = {31416, 1, 14142, 42, 27183, 2, 16180, 7};   // MCTS.py:14
+static __device__ __constant__ long long AZG_MAGIC_SEEDS[8] = {31416, 1, 14142, 42, 27183, 2, 16180, 7};   // MCTS.py:14
 
 __host__ __device__ __forceinline__ uint32_t align16u(uint32_t x) { return (x + 15u) & ~15u; }
 
@@ -263,6 +263,43 @@ __device__ inline float np_sum_f32(const float* a, int n) {
         }
     }
     return ret;
+}
+
+// The same sums on a policy held in REGISTERS (element i in lane i & 63 of pv[i >> 6], the layout the expansion loads it in): NumPy's
+// order -- 8 strided accumulators r[j] = a[j] + a[8 + j] + ..., the fixed tree ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), then the
+// n % 8 tail -- with the strided terms fetched by ds_bpermute (all of them in flight together) instead of eight lanes walking an LDS
+// array term by term (2.5 k cycles of the expansion's 11 k for Splendor's 81 actions).  Every lane returns the sum.
+template <int OFF, int LEN, int NA>
+__device__ __forceinline__ float np_sum_block_regs(const float (&pv)[NA]) {
+    static_assert(LEN >= 8 && LEN <= 128 && OFF % 8 == 0 && OFF + LEN <= 64 * NA, "one pairwise leaf block");
+    constexpr int LIM = LEN - LEN % 8, K = LIM / 8;
+    const int l = lane_id(), j = l & 7;
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const float v = __shfl(pv[(OFF + 8 * k) >> 6], ((OFF + 8 * k) & 63) + j, 64);      // a[OFF + 8k + j]: every lane gets its j's term
+        r = k == 0 ? v : r + v;
+    }
+    const float r1 = __shfl_xor(r, 1, 64);
+    const float s2 = (l & 1) ? (r1 + r) : (r + r1);
+    const float s2o = __shfl_xor(s2, 2, 64);
+    const float s4 = (l & 2) ? (s2o + s2) : (s2 + s2o);
+    const float s4o = __shfl_xor(s4, 4, 64);
+    float res = (l & 4) ? (s4o + s4) : (s4 + s4o);          // every group of 8 lanes holds the same r[0..7]: all lanes end with the full sum
+#pragma unroll
+    for (int i = LIM; i < LEN; i++)
+        res += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[(OFF + i) >> 6]), (OFF + i) & 63));
+    return res;
+}
+template <int N, int NA>
+__device__ __forceinline__ float np_sum_regs(const float (&pv)[NA]) {
+    static_assert(N >= 8 && N <= 256, "np_sum_regs: one or two leaf blocks");
+    if constexpr (N <= 128) return np_sum_block_regs<0, N, NA>(pv);
+    else {
+        constexpr int N2 = N / 2 - (N / 2) % 8;
+        const float lo = np_sum_block_regs<0, N2, NA>(pv);
+        return lo + np_sum_block_regs<N2, N - N2, NA>(pv);
+    }
 }
 
 // Gamma(alpha, 1) variate from a counter-based uniform stream (Marsaglia-Tsang squeeze; alpha < 1 via the
@@ -479,6 +516,9 @@ struct Forest {
     }
 
     // Lane-parallel value backup along the recorded path (MCTS.py:176-183 unwound): level d belongs to lane d.
+    // (Round 4, measured and dropped: carrying the four statistics the descent read at each level (Nsa, Qsa, Ns, Qs) along with the
+    // path, so that the backup only stores -- the round trip it saves is hidden behind the expansion's own work, while the extra bytes
+    // ride on the bandwidth-bound first round trip of every launch and the descent pays two more readlanes per level: -2 % env-steps/s.)
     __device__ static __forceinline__ void backup(const ForestDev& F, int t, const PathEnt* path, int depth, const float* v) {
         if (depth == 0) return;
         int tot = 0;
@@ -507,11 +547,11 @@ struct Forest {
                 uint8_t* rec = hp + (size_t)e.rec * 16u;
                 RecHdr* rh = (RecHdr*)rec;
                 uint8_t* ent = rec + RG.hot(e.j);
-                uint32_t n = *(uint32_t*)(ent + AZG_H_N);
-                double q = *(double*)(ent + AZG_H_Q);
+                const uint32_t n = *(uint32_t*)(ent + AZG_H_N), ns = rh->Ns;
+                const double q = *(double*)(ent + AZG_H_Q);
+                const float qs = rh->Qs;
                 *(double*)(ent + AZG_H_Q) = ((double)n * q + (double)v0) / (double)(n + 1u);
-                uint32_t ns = rh->Ns;
-                float tq = (float)(ns + 1u) * rh->Qs;
+                float tq = (float)(ns + 1u) * qs;
                 tq = tq + v0;
                 rh->Qs = tq / (float)(ns + 2u);
                 *(uint32_t*)(ent + AZG_H_N) = n + 1u;

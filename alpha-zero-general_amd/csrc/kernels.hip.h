@@ -355,7 +355,7 @@ __device__ __forceinline__ void stat_add(uint64_t* p, uint64_t v) {
 
 #ifdef AZG_CYC_COUNTERS
 // debug: ordered clock stamps through the prologue (asm volatile + memory clobber: memory operations cannot move across)
-__device__ unsigned long long g_prolog[16];
+static __device__ unsigned long long g_prolog[16];
 #define AZG_STAMP(k) do { long long c_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_)::"memory"); azg_stamp[k] = c_; } while (0)
 #else
 #define AZG_STAMP(k)
@@ -365,6 +365,9 @@ __device__ unsigned long long g_prolog[16];
 // Split in a load half (everything whose address does not depend on loaded data: header words, pi, v, the valid mask the
 // descent wrote for this leaf, the first 64 path entries -- ONE memory round trip) and an apply half, so that k_select can
 // run it in its own prologue (self-play: the expansion of round r rides on the descent launch of round r+1).
+#ifndef AZG_PATH_PF
+#define AZG_PATH_PF 16       /* path entries that ride on the first round trip of a launch */
+#endif
 template <class G>
 struct ExpandIn {
     static constexpr int NA = (G::A + 63) / 64;
@@ -422,7 +425,9 @@ __device__ __forceinline__ void expand_load(const ForestDev& F, int t, const flo
 #pragma unroll
     for (int p = 0; p < G::P; p++)     // (the net's output of the previous launch: never through the scalar cache)
         in.v[p] = __uint_as_float(__hip_atomic_load((const uint32_t*)vin + (size_t)t * G::P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    in.pe0 = (F.path + (size_t)t * AZG_MAXD)[l];
+    // (the first round trip of a launch is requested by all T waves at once and is bandwidth-bound: only the path entries almost every
+    // descent has ride on it -- 16 of them, a descent has 4.8 levels on average; a deeper path is completed in expand_apply)
+    in.pe0 = l < AZG_PATH_PF ? (F.path + (size_t)t * AZG_MAXD)[l] : PathEnt{0u, 0, 0, 0};
 }
 
 template <class G>
@@ -447,16 +452,22 @@ __device__ __forceinline__ bool expand_apply(const ForestDev& F, int t, const Ex
     RecHdr* rhp = (RecHdr*)rec;
     const RecGeom RG = FR::geom(F);
     const PathEnt* gp = F.path + (size_t)t * AZG_MAXD;
-    path[l] = in.pe0;
-    for (int d = l + 64; d < depth; d += 64) path[d] = gp[d];
+    if (l < AZG_PATH_PF) path[l] = in.pe0;
+    for (int d = l + AZG_PATH_PF; d < depth; d += 64) path[d] = gp[d];            // (a path deeper than the prefetched entries: one more round trip)
+    constexpr bool SUM_IN_REGS = G::A >= 8 && G::A <= 256;      // NumPy's pairwise order on the registers the policy was loaded into
+    if (!SUM_IN_REGS) {
 #pragma unroll
-    for (int k = 0; k < NA; k++) if (l + 64 * k < G::A) dense[l + 64 * k] = in.pv[k];
+        for (int k = 0; k < NA; k++) if (l + 64 * k < G::A) dense[l + 64 * k] = in.pv[k];
+    }
     wave_sync();
     // a root expanded by simulation 0 of a full search gets root noise (MCTS.py:147-149): keep the RAW net output in the
     // entries and let the noise step do softmax -> noise -> normalise; every other leaf is normalised here (:150,250-253)
     const bool dir_now = (noise_enabled && uni_u32(in.leaf_is_root) && sim == 0 && uni_u32(in.is_full) && F.dirichletAlpha != 0.0);
     float s = 1.f;
-    if (!dir_now) s = np_sum_f32(dense, G::A);
+    if (!dir_now) {
+        if constexpr (SUM_IN_REGS) s = np_sum_regs<G::A>(in.pv);
+        else s = np_sum_f32(dense, G::A);
+    }
     AZG_STAMP(2);
     // entry j belongs to the j-th valid action (the rank of its bit in the leaf's valid mask): no read of the record needed
     int base_rank = 0;
@@ -520,21 +531,18 @@ struct SelState {
     uint32_t rng_lo, rng_hi;        // the tree's RNG counter (STOCHASTIC games draw the env randomness of every simulated step)
 };
 
-// One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175).
+// One lock-step round, part 1 (MCTS.search descent, MCTS.py:105-175) for tree t, run by ONE wavefront: the body of k_select (one
+// single-wave workgroup per tree) and of the select phase of k_rounds_v80 (azg_fused.hip.h: sixteen trees per workgroup, each wave with
+// its own Smem / dense block in the workgroup's LDS; wave_sync() is then wave-local).  pi != nullptr: the expansion + backup of the
+// previous round's leaf first (its loads ride on the header's round trip).
 template <class G>
-__global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
-                                                  uint8_t* needs_eval, int wait_noise, const float* pi, const float* vin,
-                                                  int noise_enabled) {
+__device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typename Forest<G>::Smem& sm, float* dense /* LDS [A]: fused expansion only */,
+                                            int8_t* leaf_states, uint8_t* leaf_valid, uint8_t* needs_eval, int wait_noise, const float* pi,
+                                            const float* vin, int noise_enabled) {
     using FR = Forest<G>;
-    __shared__ typename FR::Smem sm;
-    __shared__ __attribute__((aligned(16))) float dense[G::A];          // fused expansion only
-    static_assert(sizeof(ForestDev) + 52 <= 448 && sizeof(ForestDev) + 52 > 0x180 + 4,
-                  "warm_kernarg_448 touches exactly the seven 64-byte lines of this kernel's explicit arguments");
-    warm_kernarg_448();
     long long azg_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     AZG_STAMP(0);
     const long long t_first = AZG_CLK();
-    const int t = blockIdx.x;
     const int l = lane_id();
     TreeHdr* Hp = &F.hdr[t];
 #ifdef AZG_WALL_CAL
@@ -862,6 +870,18 @@ __global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #endif
         needs_eval[t] = need_nn ? 1 : 0;
     }
+}
+
+template <class G>
+__global__ __launch_bounds__(64, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_select(ForestDev F, int8_t* leaf_states, uint8_t* leaf_valid,
+                                                  uint8_t* needs_eval, int wait_noise, const float* pi, const float* vin,
+                                                  int noise_enabled) {
+    __shared__ typename Forest<G>::Smem sm;
+    __shared__ __attribute__((aligned(16))) float dense[G::A];          // fused expansion only
+    static_assert(sizeof(ForestDev) + 52 <= 448 && sizeof(ForestDev) + 52 > 0x180 + 4,
+                  "warm_kernarg_448 touches exactly the seven 64-byte lines of this kernel's explicit arguments");
+    warm_kernarg_448();
+    select_tree<G>(F, (int)blockIdx.x, sm, dense, leaf_states, leaf_valid, needs_eval, wait_noise, pi, vin, noise_enabled);
 }
 
 // MCTS.getActionProb epilogue (MCTS.py:67-103) into dense LDS buffers; returns false if the root has no policy.

@@ -241,7 +241,7 @@ __device__ __forceinline__ void heads1x1_h2(const float* __restrict__ Wp, const 
 }
 
 #ifdef AZG_NN_PHASE_TIMES
-__device__ long long g_c5_phase[32];
+static __device__ long long g_c5_phase[32];
 #define C5_PH(k) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_c5_phase[k] = clock64(); } while (0)
 #else
 #define C5_PH(k) do { } while (0)

@@ -378,7 +378,7 @@ struct V80NetW {
 #define FRAG(ptr, NCH, nt, c) (*(const float4*)((ptr) + ((((size_t)(nt) * (NCH) + (c)) * 64 + lane) << 2)))
 
 #ifdef AZG_NN_PHASE_TIMES
-__device__ long long g_v80_phase[4][16];
+static __device__ long long g_v80_phase[4][16];
 #define AZG_PH(k) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_v80_phase[MODE][k] = clock64(); } while (0)
 #else
 #define AZG_PH(k)

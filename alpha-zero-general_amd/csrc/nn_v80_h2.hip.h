@@ -19,7 +19,7 @@
 #pragma once
 #include "nn_kernels.hip.h"
 
-#pragma clang fp contract(fast)
+#pragma clang fp contract(on)
 
 namespace azg {
 
@@ -40,6 +40,21 @@ struct H2NetW {
     const float *b0, *bpi1, *bpi2, *bv1, *Wv2, *bv2;      // [64], [96], [96], [16], [P][P] plain, [P]
     float s0, spi1, spi2, sv1;
 };
+
+// the 43 pointer slots + 16 descale factors of azg_nn_v80_forward_h2 (include/azg.h) -> the kernel's argument structs (host side)
+struct H2Weights { H2BlockW Wt, Wp, Wv; H2NetW N; };
+static inline H2Weights h2_weights(const void* const* w, const float* descale) {
+    auto blk = [&](int o, int d) {
+        return H2BlockW{(const uint4*)w[o], (const uint4*)w[o + 5], (const uint4*)w[o + 7], (const uint4*)w[o + 9],
+                        (const float*)w[o + 1], (const float*)w[o + 2], (const float*)w[o + 3], (const float*)w[o + 4],
+                        (const float*)w[o + 6], (const float*)w[o + 8], (const float*)w[o + 10],
+                        descale[d], descale[d + 1], descale[d + 2], descale[d + 3]};
+    };
+    return H2Weights{blk(2, 1), blk(13, 5), blk(24, 9),
+                     H2NetW{(const uint4*)w[0], (const uint4*)w[35], (const uint4*)w[37], (const uint4*)w[39],
+                            (const float*)w[1], (const float*)w[36], (const float*)w[38], (const float*)w[40], (const float*)w[41],
+                            (const float*)w[42], descale[0], descale[13], descale[14], descale[15]}};
+}
 
 // byte offset of (row, 16-byte chunk q = 8 halves) in a plane of row stride RS (RS = 128 mod 256: with the XOR the ds_read_b128
 // lane groups of an MFMA operand fetch -- 16 rows x 4 adjacent chunks -- hit 16 distinct 16-byte bank columns)
@@ -122,7 +137,7 @@ constexpr int H2_PDX = H2_XL - H2_XH, H2_PDH = H2_HL - H2_HH, H2_PDP = H2_PLL - 
 constexpr int H2_RED = H2_HH, H2_HIDH = H2_HH + 12288, H2_HIDL = H2_HIDH + 6144, H2_LG = H2_HIDL + 6144, H2_LS = 100;
 
 #ifdef AZG_NN_PHASE_TIMES
-__device__ long long g_h2_phase[4][16];
+static __device__ long long g_h2_phase[4][16];
 #define H2_PH(k) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_h2_phase[MODE][k] = clock64(); } while (0)
 #else
 #define H2_PH(k)
@@ -130,15 +145,19 @@ __device__ long long g_h2_phase[4][16];
 
 // One InvertedResidual1d block (SplendorNNet.py:189-202) on the tile in the X planes.  MODE 1: trunk (output replaces X);
 // MODE 2 / 3: policy / value head block (output -> O planes, X stays for the other head) followed by the head's tail.
-template <int ACT, int POOLMAX, int MODE>
+// NW = waves of the workgroup: 12 (the stand-alone kernel, 168 VGPRs, 3 waves per SIMD) or 16 (128 VGPRs, 4 waves per SIMD -- the budget
+// of a workgroup that also runs 16 tree descents, kernels.hip.h k_rounds): with 16 waves the weights of a later phase are requested
+// later (LEAN: fewer fragment registers in flight), the project GEMM and the first layer run over four row-tile groups instead of three.
+template <int ACT, int POOLMAX, int MODE, int NW>
 __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const H2NetW& N, int B, int P,
                                          const uint8_t* __restrict__ valid, float* __restrict__ pi_out, float* __restrict__ v_out,
                                          H2EW& ew /* in: this block's phase-E operands; out: the next block's */,
-                                         const H2BlockW& Wnext) {
+                                         const H2BlockW& Wnext, int wg, const int tid) {
     constexpr int NS = 16, A = 81;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr bool LEAN = NW > 12;
+    const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
-    const int b0 = blockIdx.x * NS;
+    const int b0 = wg * NS;
     uint8_t* const XH = lds + H2_XH;
     uint8_t* const OH = lds + H2_OH;
     uint8_t* const HH = lds + H2_HH;
@@ -153,10 +172,11 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
     const uint4 weh0 = ew.weh[0], weh1 = ew.weh[1], wel0 = ew.wel[0], wel1 = ew.wel[1];
     const f32x4 be4 = ew.be4, sd4 = ew.sd4, bd4 = ew.bd4;
     const float wdv = ew.wdv;
-    // SE fc1 (K = 192 = 6 chunks, 3 column tiles): 9 waves, wave w takes column tile w % 3 and the chunk pair w / 3; the three
-    // K groups of a tile are added up through LDS (a 3-wave fc1 would hold 48 registers of fragments per wave through phase E)
-    uint4 w1h[2], w1l[2];
-    const int nt1 = wave % 3, kg1 = wave < 9 ? wave / 3 : 0;
+    // SE fc1 (K = 192 = 6 chunks, 3 column tiles) = 9 units (column tile u % 3, chunk pair u / 3) whose partial sums are added up through
+    // LDS.  12-wave workgroup: waves 0..8 take one unit each (a 3-wave fc1 would hold 48 registers of fragments per wave through phase
+    // E).  16-wave workgroup (128 VGPRs): the five waves that sit out phase E (11..15) take units w - 11 and w - 6 -- the waves that
+    // carry the token-mix results through the SE phases then never hold fc1 fragments (the two roles are separate code paths with the
+    // same number of barriers, so the register allocator never sees their fragments live together).
     const int cs1 = tid / 12, cc1 = 4 * (tid - cs1 * 12);     // the fc1 combine step: (sample, 4 hidden units) of thread tid < 192
     f32x4 b24, b14;
     // the H planes' pad columns 176..191 (chunks 22, 23) must read as zeros; a head tail may have left its buffers there
@@ -164,10 +184,16 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         const int row = tid >> 2, q = 22 + (tid & 1), pl = (tid >> 1) & 1;
         *(uint4*)(HH + pl * H2_PDH + h2_off(row, q, H2_RSH)) = make_uint4(0u, 0u, 0u, 0u);
     }
-
-    // ---- E: expand GEMM (+BN+act) -> depthwise token mix (+BN+act) -> squeeze, all in this wave's registers ----
+    float* const RED1 = (float*)(lds + H2_OH);                // [3 K groups][16][48] f32: the O planes are free until phase P
+    constexpr int PG = NW / 4;                                // row-tile groups of the project GEMM: 4 column tiles x PG waves (1: every weight
+                                                              // fragment enters the CU once; the four waves sit on the four SIMDs)
+    const int ntp = wave & 3, rt0 = wave >> 2;
+    uint4 wph[6], wpl[6];
+    f32x4 bp4;
     f32x4 dw[7];
-    if (wave < 11) {
+
+    // ---- E: expand GEMM (+BN+act) -> depthwise token mix (+BN+act) -> squeeze, all in this wave's registers (waves 0..10) ----
+    auto phase_e = [&](uint4 (&w1h)[2], uint4 (&w1l)[2], int nt1, int kg1) {
         f32x4 in[7];
 #pragma unroll
         for (int t = 0; t < 7; t++) {
@@ -184,12 +210,14 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         H2_PH(11);
         // the SE weights: requested behind the expand GEMM's operands (the vector-memory pipe of the CU takes ~30 cycles per 1 KiB
         // wave request when every wave is asking), they land during the token mix
+        if (!LEAN) {
 #pragma unroll
-        for (int c = 0; c < 2; c++) { w1h[c] = H2FRAG(W.W1, 6, nt1, 2 * kg1 + c, 0); w1l[c] = H2FRAG(W.W1, 6, nt1, 2 * kg1 + c, 1); }
+            for (int c = 0; c < 2; c++) { w1h[c] = H2FRAG(W.W1, 6, nt1, 2 * kg1 + c, 0); w1l[c] = H2FRAG(W.W1, 6, nt1, 2 * kg1 + c, 1); }
 #pragma unroll
-        for (int c = 0; c < 2; c++) { w2h[c] = H2FRAG(W.W2, 2, nt, c, 0); w2l[c] = H2FRAG(W.W2, 2, nt, c, 1); }
-        b24 = *(const f32x4*)(W.b2 + ch0);
-        b14 = *(const f32x4*)(W.b1 + (tid < 192 ? cc1 : 0));
+            for (int c = 0; c < 2; c++) { w2h[c] = H2FRAG(W.W2, 2, nt, c, 0); w2l[c] = H2FRAG(W.W2, 2, nt, c, 1); }
+            b24 = *(const f32x4*)(W.b2 + ch0);
+            b14 = *(const f32x4*)(W.b1 + (tid < 192 ? cc1 : 0));
+        }
         f32x4 pool = POOLMAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 7; m++) {
@@ -205,45 +233,34 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
             else pool += a;
         }
         H2_PH(12);
+        if (LEAN) {          // 128-VGPR budget: the fc2 weights only once the token mix has released its 28 input registers
+#pragma unroll
+            for (int c = 0; c < 2; c++) { w2h[c] = H2FRAG(W.W2, 2, nt, c, 0); w2l[c] = H2FRAG(W.W2, 2, nt, c, 1); }
+            b24 = *(const f32x4*)(W.b2 + ch0);
+        }
         constexpr float ACT_DIV = ACT == ACT_HSWISH ? 6.f : 1.f;                 // dw holds 6 * Hardswish(.)
         h2_store4(PLH, H2_PDP, H2_RSH, r, ch0, pool, H2_AS / ACT_DIV / (POOLMAX ? 1.f : 7.f));
-    }
-    // project weights: requested when the phase-E arithmetic is done, they land during the SE phases
-    constexpr int PG = 3;                                     // row-tile groups of the project GEMM: 4 column tiles x PG waves (1: every weight
-                                                              // fragment enters the CU once; the four waves sit on the four SIMDs)
-    const int ntp = wave & 3, rt0 = wave >> 2;
-    uint4 wph[6], wpl[6];
-    if (wave < 4 * PG) {
+    };
+    auto load_wp = [&]() {
 #pragma unroll
         for (int c = 0; c < 6; c++) { wph[c] = H2FRAG(W.Wp, 6, ntp, c, 0); wpl[c] = H2FRAG(W.Wp, 6, ntp, c, 1); }
-    }
-    const f32x4 bp4 = *(const f32x4*)(W.bp + ntp * 16 + 4 * g);
-    __syncthreads();
-    H2_PH(1);
-
-    // ---- S1: SE fc1 partial sums (9 waves) -> RED1, then bias + ReLU -> SH ----
-    float* const RED1 = (float*)(lds + H2_OH);                // [3 K groups][16][48] f32: the O planes are free until phase P
-    if (wave < 9) {
+        bp4 = *(const f32x4*)(W.bp + ntp * 16 + 4 * g);
+    };
+    // one fc1 unit (column tile nt1, chunk pair kg1): partial sums -> RED1
+    auto s1_unit = [&](const uint4 (&w1h)[2], const uint4 (&w1l)[2], int nt1, int kg1) {
         f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
         const int o0 = h2_off(r, 8 * kg1 + g, H2_RSH), o1 = h2_off(r, 8 * kg1 + 4 + g, H2_RSH);
         a0 = h2_mma(w1h[0], w1l[0], *(const uint4*)(PLH + o0), *(const uint4*)(PLH + H2_PDP + o0), a0);
         a1 = h2_mma(w1h[1], w1l[1], *(const uint4*)(PLH + o1), *(const uint4*)(PLH + H2_PDP + o1), a1);
         *(f32x4*)(RED1 + (kg1 * 16 + r) * 48 + nt1 * 16 + 4 * g) = a0 + a1;
-    }
-    H2_PH(13);
-    H2_PH(14);
-    __syncthreads();
-    H2_PH(15);
-    if (tid < 192) {
+    };
+    auto s1_combine = [&]() {                                 // bias + ReLU -> SH (threads 0..191)
         const int s = cs1, col = cc1;
         const f32x4 hv = (*(const f32x4*)(RED1 + s * 48 + col) + *(const f32x4*)(RED1 + (16 + s) * 48 + col) + *(const f32x4*)(RED1 + (32 + s) * 48 + col)) * W.s1 + b14;
         h2_store4(SHH, H2_PDS, H2_RSX, s, col, f32x4{fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f)});
-    }
-    __syncthreads();
-    H2_PH(2);
-
-    // ---- S2: SE fc2 + Hardsigmoid: the scale of (sample r, this lane's 4 channels) lands in this lane -> H = 64 * dw * scale ----
-    if (wave < 11) {
+    };
+    // S2: SE fc2 + Hardsigmoid: the scale of (sample r, this lane's 4 channels) lands in this lane -> H = 64 * dw * scale
+    auto phase_s2 = [&]() {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -254,9 +271,62 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         const f32x4 sc = f32x4{hardsigmoid(y[0]), hardsigmoid(y[1]), hardsigmoid(y[2]), hardsigmoid(y[3])};
 #pragma unroll
         for (int t = 0; t < 7; t++) h2_store4(HH, H2_PDH, H2_RSH, t * 16 + r, ch0, dw[t] * sc, H2_AS / (ACT == ACT_HSWISH ? 6.f : 1.f));
+    };
+
+    if (!LEAN) {
+        uint4 w1h[2], w1l[2];
+        const int nt1 = wave % 3, kg1 = wave < 9 ? wave / 3 : 0;
+        if (wave < 11) phase_e(w1h, w1l, nt1, kg1);
+        // project weights: requested when the phase-E arithmetic is done, they land during the SE phases
+        if (wave < 4 * PG) load_wp();
+        else bp4 = *(const f32x4*)(W.bp + ntp * 16 + 4 * g);
+        __syncthreads();
+        H2_PH(1);
+        if (wave < 9) s1_unit(w1h, w1l, nt1, kg1);           // ---- S1: SE fc1 partial sums (9 waves) -> RED1, then bias + ReLU -> SH ----
+        H2_PH(13);
+        H2_PH(14);
+        __syncthreads();
+        H2_PH(15);
+        if (tid < 192) s1_combine();
+        __syncthreads();
+        H2_PH(2);
+        if (wave < 11) phase_s2();
+        __syncthreads();
+        H2_PH(3);
+    } else if (wave < 11) {
+        // role A (16-wave workgroup): the eleven column-tile waves -- E, [S1 runs elsewhere], combine (waves 0..2), S2
+        uint4 none_h[2], none_l[2];
+        if (tid < 192) b14 = *(const f32x4*)(W.b1 + cc1);
+        phase_e(none_h, none_l, 0, 0);
+        __syncthreads();
+        H2_PH(1);
+        __syncthreads();
+        H2_PH(15);
+        if (tid < 192) s1_combine();
+        __syncthreads();
+        H2_PH(2);
+        load_wp();                                            // lands during S2 (the fc2 MFMAs and the seven split-and-store steps)
+        phase_s2();
+        __syncthreads();
+        H2_PH(3);
+    } else {
+        // role B: the five waves that sit out phase E hold the fc1 fragments (units w - 11 and w - 6 of the nine) and run S1
+        uint4 w1h[2][2], w1l[2][2];
+        const int u0 = wave - 11, u1 = wave - 6;              // u1 < 9 for waves 11..14
+#pragma unroll
+        for (int c = 0; c < 2; c++) { w1h[0][c] = H2FRAG(W.W1, 6, u0 % 3, 2 * (u0 / 3) + c, 0); w1l[0][c] = H2FRAG(W.W1, 6, u0 % 3, 2 * (u0 / 3) + c, 1); }
+        if (u1 < 9) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) { w1h[1][c] = H2FRAG(W.W1, 6, u1 % 3, 2 * (u1 / 3) + c, 0); w1l[1][c] = H2FRAG(W.W1, 6, u1 % 3, 2 * (u1 / 3) + c, 1); }
+        }
+        __syncthreads();
+        s1_unit(w1h[0], w1l[0], u0 % 3, u0 / 3);
+        if (u1 < 9) s1_unit(w1h[1], w1l[1], u1 % 3, u1 / 3);
+        __syncthreads();
+        __syncthreads();
+        load_wp();
+        __syncthreads();
     }
-    __syncthreads();
-    H2_PH(3);
 
     // the next block's phase-E operands and the head tail's first fragments stream in while the project GEMM runs
     if (MODE != 2) h2_load_ew(ew, Wnext, nt, g, lane);        // (policy block: after the tail's first GEMM, whose 56 fragment registers come first)
@@ -264,13 +334,17 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
     const int ht_nt = wave % 6, ht_half = wave / 6;
     f32x4 bt1 = f32x4{0.f, 0.f, 0.f, 0.f}, bt2 = bt1;         // the tails' biases: requested with the fragments
     const int ts = tid / 24, tcol = 4 * (tid - ts * 24);      // policy tail combine step: (sample, 4 hidden units) of thread tid < 384
+    constexpr int PRE = LEAN ? 2 : 4;                         // fragments of the first policy Linear requested before the project GEMM
+    const bool tailw = wave < 12;                             // the policy tail's first GEMM: 6 column tiles x 2 K halves = 12 waves
     if (MODE == 2) {
         bt1 = *(const f32x4*)(N.bpi1 + (tid < 384 ? tcol : 0));
         bt2 = *(const f32x4*)(N.bpi2 + (wave < 6 ? wave : 0) * 16 + 4 * g);
+        if (tailw) {
 #pragma unroll
-        for (int cc = 0; cc < 4; cc++) { wfh[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 0); wfl[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 1); }
+            for (int cc = 0; cc < PRE; cc++) { wfh[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 0); wfl[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 1); }
+        }
     }
-    if (MODE == 3) {
+    if (MODE == 3 && tailw) {                                 // (twelve K groups whatever NW is: the summation order is part of the result)
 #pragma unroll
         for (int cc = 0; cc < 2; cc++) {
             const int c = wave + 12 * cc;
@@ -296,9 +370,9 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
             h2_store4(MODE == 1 ? XH : OH, H2_PDX, H2_RSX, row, col0, o4);       // (columns 56..63: zero weights + zero bias + zero x)
         }
     }
-    if (MODE == 2) {                                          // the rest of the first policy Linear's fragments (the project fragments are dead)
+    if (MODE == 2 && tailw) {                                 // the rest of the first policy Linear's fragments (the project fragments are dead)
 #pragma unroll
-        for (int cc = 4; cc < 7; cc++) { wfh[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 0); wfl[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 1); }
+        for (int cc = PRE; cc < 7; cc++) { wfh[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 0); wfl[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 1); }
     }
     if (MODE == 2 && wave < 6) {                              // second policy Linear
 #pragma unroll
@@ -312,7 +386,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         float* RED = (float*)(lds + H2_RED);                  // [2 K halves][16][96]
         float* LG = (float*)(lds + H2_LG);                    // [16][H2_LS]
         uint8_t* const HIDH = lds + H2_HIDH;
-        {
+        if (tailw) {
             f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
             for (int cc = 0; cc < 7; cc++) {
@@ -343,7 +417,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         __syncthreads();
         H2_PH(5);
         // masked softmax == exp(log_softmax(where(valid, logits, -1e8))) (GenericNNetWrapper.py:105-107), one wave per sample
-        for (int s = wave; s < NS; s += 12) {
+        for (int s = wave; s < NS; s += NW) {
             const int b = b0 + s;
             if (b >= B) continue;
             const int a1i = lane + 64;
@@ -363,7 +437,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
     if (MODE == 3) {
         // ---- value tail: Flatten -> Linear(392, P) + ReLU -> Linear(P, P) -> tanh ----
         float* RED = (float*)(lds + H2_RED);                  // [12 waves][16][16]
-        {
+        if (tailw) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int cc = 0; cc < 2; cc++) {
@@ -392,27 +466,28 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
     }
 }
 
-#ifdef AZG_NET_W4          /* experiment: cap the kernel at 128 VGPRs (4 waves per SIMD), the budget of a 16-wave workgroup */
-__attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
-__global__ __launch_bounds__(768) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2BlockW Wv, H2NetW N, const int8_t* __restrict__ boards,
-                                                    const uint8_t* __restrict__ valid, int B, int P, float* __restrict__ pi_out,
-                                                    float* __restrict__ v_out) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int NS = 16, C = 56;
+// the whole forward of workgroup `wg` (samples 16 * wg ..); the caller's workgroup has NW waves and H2_LDS bytes of LDS at `lds`
+template <int NW>
+__device__ __forceinline__ void h2_net_body(uint8_t* lds, const H2BlockW& Wt, const H2BlockW& Wp, const H2BlockW& Wv, const H2NetW& N,
+                                            const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid, int B, int P,
+                                            float* __restrict__ pi_out, float* __restrict__ v_out, int wg) {
+    constexpr int NS = 16, C = 56, NT = NW * 64, KB = (NS * (7 * C / 4) + NT - 1) / NT;
     h2_fp16_saturate_mode();
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));      // (opaque: inside the round loop of k_rounds_v80 nothing derived from the thread id may be hoisted out of the loop)
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
-    const int b0 = blockIdx.x * NS;
+    const int b0 = wg * NS;
     const int nb = min(NS, B - b0);
     uint8_t* const XH = lds + H2_XH;
     uint8_t* const X0 = lds + H2_OH;                          // the board tile as ONE f16 plane (64 * int8 is exact): O is free until the heads
 
     // ---- board tile int8 [s][c][l] -> X0[l*16 + s][c] = 64 * board, requested before any weight ----
     const uint32_t* bsrc = (const uint32_t*)(boards + (size_t)b0 * (7 * C));
-    uint32_t bv[3];
+    uint32_t bv[KB];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { const int i = tid + 768 * k; bv[k] = (i < NS * (7 * C / 4) && i / (7 * C / 4) < nb) ? bsrc[i] : 0u; }
+    for (int k = 0; k < KB; k++) { const int i = tid + NT * k; bv[k] = (i < NS * (7 * C / 4) && i / (7 * C / 4) < nb) ? bsrc[i] : 0u; }
+    constexpr int RG0 = NW / 4;                               // row-tile groups of the first layer
     const int ntp = wave & 3, rt0 = wave >> 2;
     uint4 w0h[2], w0l[2];
 #pragma unroll
@@ -421,13 +496,13 @@ __global__ __launch_bounds__(768) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2
     H2EW ew;
     h2_load_ew(ew, Wt, wave < 11 ? wave : 0, g, lane);       // the trunk block's first operands, behind the board tile and W0
     // zero what is read but never written: the pooled / SE-hidden planes (pad columns) and X0's columns 56..63
-    *(uint4*)(lds + H2_PLH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);                      // 768 x 16 B = both PL planes
+    if (tid < 768) *(uint4*)(lds + H2_PLH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);       // 768 x 16 B = both PL planes
     if (tid < 256) *(uint4*)(lds + H2_SHH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);       // both SH planes
     if (tid < 112) *(uint4*)(X0 + h2_off(tid, 7, H2_RSX)) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();                                           // (the zeroing of X0's last chunk precedes the scatter below: none overlap, but PL/SH need it anyway)
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int i = tid + 768 * k;
+    for (int k = 0; k < KB; k++) {
+        const int i = tid + NT * k;
         if (i < NS * (7 * C / 4)) {
             const int s = i / (7 * C / 4), d = i - s * (7 * C / 4);
 #pragma unroll
@@ -441,7 +516,7 @@ __global__ __launch_bounds__(768) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2
     __syncthreads();
     // ---- first layer Linear(56, 56) + BN (SplendorNNet.py:397-401) -> X planes; the operand has no lo part ----
 #pragma unroll 1
-    for (int rt = rt0; rt < 7; rt += 3) {
+    for (int rt = rt0; rt < 7; rt += RG0) {
         const int row = rt * 16 + r;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -454,9 +529,17 @@ __global__ __launch_bounds__(768) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2
     }
     __syncthreads();
     // V80 geometry (SplendorNNet.py:262-283): trunk ReLU + mean squeeze, both heads Hardswish + max squeeze
-    h2_block<1, 0, 1>(lds, Wt, N, B, P, valid, pi_out, v_out, ew, Wp);
-    h2_block<2, 1, 2>(lds, Wp, N, B, P, valid, pi_out, v_out, ew, Wv);
-    h2_block<2, 1, 3>(lds, Wv, N, B, P, valid, pi_out, v_out, ew, Wv);       // (the last prefetch is unused)
+    h2_block<1, 0, 1, NW>(lds, Wt, N, B, P, valid, pi_out, v_out, ew, Wp, wg, tid);
+    h2_block<2, 1, 2, NW>(lds, Wp, N, B, P, valid, pi_out, v_out, ew, Wv, wg, tid);
+    h2_block<2, 1, 3, NW>(lds, Wv, N, B, P, valid, pi_out, v_out, ew, Wv, wg, tid);       // (the last prefetch is unused)
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2BlockW Wv, H2NetW N, const int8_t* __restrict__ boards,
+                                                        const uint8_t* __restrict__ valid, int B, int P, float* __restrict__ pi_out,
+                                                        float* __restrict__ v_out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    h2_net_body<NW>(lds, Wt, Wp, Wv, N, boards, valid, B, P, pi_out, v_out, (int)blockIdx.x);
 }
 
 }  // namespace azg

@@ -110,6 +110,21 @@ class Forest:
         check(lib().azg_forest_select_fused(self.h, _ptr(self.leaf_states), _ptr(self.leaf_valid), _ptr(self.needs_eval),
                                             _ptr(pi), _ptr(v), -2 if device_noise else 0, _stream()))
 
+    def rounds_v80(self, net, pi, v, rounds, device_noise=False):
+        """`rounds` x (select_fused -> V80 forward of the leaf batch) in ONE launch of the per-CU round kernel (azg_forest_rounds_v80_h2):
+        Splendor 2 players with a SplendorV80Hip(h2=True) evaluator `net`; pi / v are the buffers the forward writes and the next
+        expansion reads"""
+        assert pi.dtype == torch.float32 and v.dtype == torch.float32 and pi.is_contiguous() and v.is_contiguous()
+        assert pi.shape == (self.T, self.A) and v.shape == (self.T, self.P)
+        check(lib().azg_forest_rounds_v80_h2(self.h, _ptr(self.leaf_states), _ptr(self.leaf_valid), _ptr(self.needs_eval), _ptr(pi), _ptr(v),
+                                             -2 if device_noise else 0, net.net_ptrs_h2, net.descale_h2, int(rounds), _stream()))
+
+    def rounds_profile(self, reset=True):
+        """(select phase us, net phase us, a wave's own descent us, rounds) per round of the per-CU round kernel since the last reset"""
+        out = (C.c_double * 4)()
+        check(lib().azg_forest_rounds_profile(self.h, out, int(reset)))
+        return tuple(out)
+
     def expand_backup(self, pi, v, noise=None, normalised=False, device_noise=False):
         assert pi.dtype == torch.float32 and v.dtype == torch.float32 and pi.is_contiguous() and v.is_contiguous()
         assert pi.shape == (self.T, self.A) and v.shape == (self.T, self.P)

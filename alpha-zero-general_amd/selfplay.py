@@ -56,6 +56,17 @@ class _Group:
         if pi.data_ptr() != self.pi.data_ptr():          # nets without static output buffers: keep the addresses stable
             self.pi.copy_(pi); self.v.copy_(v)
 
+    def rounds(self, n, fused, percu, advance=True):
+        """n lock-step rounds of this group's trees on the current stream, then (advance) one selfplay_advance.  percu: ONE launch of
+        the per-CU round kernel (azg_forest_rounds_v80_h2: 16 trees + their 16 leaves per workgroup, no launch boundary between rounds)"""
+        if percu:
+            self.f.rounds_v80(self.net, self.pi, self.v, n, device_noise=bool(self.device_noise))
+            if advance:
+                self.f.selfplay_advance()
+            return
+        for k in range(n):
+            self.round(fused, advance and k == n - 1)
+
     def round(self, fused, advance=True):
         """one lock-step round of this group's trees on the current stream"""
         if fused:
@@ -73,7 +84,7 @@ class _Group:
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
                  use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=None, fused=True,
-                 pin_xcd=None):
+                 pin_xcd=None, percu=None):
         self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
@@ -107,6 +118,19 @@ class SelfPlayEngine:
         self.nnet = nets[0]
         self.use_graph = use_graph
         self.rounds = 0
+        # the per-CU round kernel exists for Splendor 2 players + the V80 net on its f16 x 2 kernel with static output buffers
+        import os
+        can = (splendor and int(getattr(game, 'variant', 0) or 2) == 2 and self.fused and
+               all(getattr(n, 'h2', False) and getattr(n, 'fused_net', False) and hasattr(n, 'net_ptrs_h2') and
+                   torch.is_tensor(getattr(n, 'pi', None)) and tuple(n.pi.shape) == (Tg, self.forest.A) for n in nets))
+        if percu is None:
+            # opt-in (AZG_PERCU=1 / percu=True): measured on one MI355X at 4096 x 800 it is the slower form of the round (65.1 k against
+            # 72.5 k env-steps/s, DESIGN.md 3.6: the 16-wave / 128-VGPR net phase costs 40 us against 32 for the 12-wave kernel and the
+            # launch ends with its slowest workgroup, which eats what the per-CU boundary gains on the descents)
+            percu = can and os.environ.get('AZG_PERCU', '0') == '1'
+        elif percu and not can:
+            raise ValueError('percu=True needs Splendor 2 players and SplendorV80Hip(h2=True) evaluators with max_batch == games per group')
+        self.percu = bool(percu)
         # one stream per pipeline; pinned to an XCD (or an equal share of the 8 XCDs) unless pin_xcd=False
         self.pin_xcd = (groups > 1) if pin_xcd is None else bool(pin_xcd)
         self._raw_streams = []
@@ -179,13 +203,13 @@ class SelfPlayEngine:
     def _round(self, advance=True):
         """one eager round of every group (each on its own stream when there are several)"""
         if self.G == 1:
-            self.groups[0].round(self.fused, advance)
+            self.groups[0].rounds(1, self.fused, self.percu, advance)
             return
         cur = torch.cuda.current_stream()
         for grp in self.groups:
             grp.stream.wait_stream(cur)
             with torch.cuda.stream(grp.stream):
-                grp.round(self.fused, advance)
+                grp.rounds(1, self.fused, self.percu, advance)
         for grp in self.groups:
             cur.wait_stream(grp.stream)
 
@@ -196,14 +220,13 @@ class SelfPlayEngine:
         with torch.cuda.stream(s):
             for _ in range(3):
                 for grp in self.groups:
-                    grp.round(self.fused)
+                    grp.rounds(1, self.fused, self.percu)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for grp in self.groups:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for k in range(self.K):
-                    grp.round(self.fused, advance=(k == self.K - 1))
+                grp.rounds(self.K, self.fused, self.percu, advance=True)
             grp.graph = g
         torch.cuda.synchronize()
         self.rounds += 3 + self.K

@@ -228,17 +228,31 @@ def measure_roofline(a, eng, T):
     """eager rounds with HIP events around the select (+ fused expand/backup) launches, on the stream they are launched on"""
     import torch
     f = eng.forest
-    r0 = eng.stats()
-    f.enable_timing(True)
-    for _ in range(a.roofline_rounds):
-        eng._round()
-    torch.cuda.synchronize()
-    ms_sel, n_sel = f.kernel_ms(0)
-    ms_exp, n_exp = f.kernel_ms(1)
-    if not n_exp:                 # fused engine: the expansion + backup runs in the prologue of k_select, no launch of its own
-        ms_exp = 0.0
-    f.enable_timing(False)
-    r1 = eng.stats()
+    kprof = None
+    if getattr(eng, 'percu', False):
+        # the per-CU round kernel: there is no launch of the descent alone to put HIP events around -- its select phase is timed INSIDE
+        # the kernel on the 100 MHz wall clock (azg_forest_rounds_profile): per round, how long a workgroup's select phase lasts (it waits
+        # for the slowest of its 16 trees), averaged over the workgroups and the rounds of the same graph replays the timed region uses
+        n = max(eng.K, a.roofline_rounds // eng.K * eng.K)
+        f.rounds_profile(reset=True)
+        r0 = eng.stats()
+        eng.run(n)
+        torch.cuda.synchronize()
+        r1 = eng.stats()
+        kprof = f.rounds_profile(reset=True)
+        ms_sel, n_sel, ms_exp, n_exp = kprof[0] * 1e-3, int(kprof[3]), 0.0, 0
+    else:
+        r0 = eng.stats()
+        f.enable_timing(True)
+        for _ in range(a.roofline_rounds):
+            eng._round()
+        torch.cuda.synchronize()
+        ms_sel, n_sel = f.kernel_ms(0)
+        ms_exp, n_exp = f.kernel_ms(1)
+        if not n_exp:                 # fused engine: the expansion + backup runs in the prologue of k_select, no launch of its own
+            ms_exp = 0.0
+        f.enable_timing(False)
+        r1 = eng.stats()
     rs = r1['sims'] - r0['sims']
     if rs <= 0 or n_sel <= 0:
         return None
@@ -261,7 +275,13 @@ def measure_roofline(a, eng, T):
                                  'gfx950 corrections); NOT measured in this run')
         except Exception:
             prof = None
-    return dict(bound='hbm', kernels=['k_select', 'k_expand_backup'] if n_exp else ['k_select (expand+backup fused into its prologue)'],
+    extra = {}
+    if kprof is not None:
+        extra = dict(net_phase_ms=kprof[1] * 1e-3, select_wave_ms=kprof[2] * 1e-3,
+                     timing='inside k_rounds_v80 on the 100 MHz wall clock (s_memrealtime), per round, averaged over the workgroups: select_ms = '
+                            'the select phase of a workgroup (its slowest of 16 trees), select_wave_ms = a wave\'s own descent, net_phase_ms = the net phase')
+    return dict(bound='hbm', kernels=(['k_rounds_v80: select phase (expansion + backup + descent of 16 trees per workgroup)'] if kprof is not None else
+                                      ['k_select', 'k_expand_backup'] if n_exp else ['k_select (expand+backup fused into its prologue)']), **extra,
                 achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                 traffic=None, traffic_from_profile=prof,
                 bytes_per_sim=b_sim, sims_per_launch=sims_per_launch, bytes_per_launch=bytes_per_launch,
@@ -288,6 +308,10 @@ def measure_net(a, eng, T, game_key, net_kind):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
+    standalone_ms = ms
+    rl = getattr(eng, '_last_roofline', None)
+    if getattr(eng, 'percu', False) and rl and rl.get('net_phase_ms'):
+        ms = rl['net_phase_ms']           # the net phase of the round kernel (16 waves, timed inside the kernel); the stand-alone launch is kept beside it
     Tg = T // a.groups
     flops = NET_MFLOP_PER_LEAF[game_key] * 1e6 * Tg
     h2 = net_kind == 'hip' and getattr(grp.net, 'h2', False)
@@ -300,7 +324,7 @@ def measure_net(a, eng, T, game_key, net_kind):
                 mfma_input_dtype=dt, frac_of_f32_mfma_peak=ach / MFMA_PEAK_TFLOPS['f32'],
                 note='fp32-accurate (<= 1e-5 of the reference outputs): every f32 operand is a hi + lo pair of 16-bit numbers, one '
                      'algorithmic product = 3 (f16 pair) or 6 (bf16 triple) MFMAs; achieved counts ALGORITHMIC flops only',
-                flops_per_launch=flops, leaves_per_launch=Tg, net_ms=ms, launches=n)
+                flops_per_launch=flops, leaves_per_launch=Tg, net_ms=ms, launches=n, standalone_launch_ms=standalone_ms)
 
 
 def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roofline=True):
@@ -367,6 +391,8 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
                    gather_ms=ginfo.get('ms'), gather_bytes_received_rank0=ginfo.get('bytes_received'), gather_mode=ginfo.get('mode'),
                    gather_row_bytes=ginfo.get('row_bytes'))
     res['roofline'] = measure_roofline(a, eng, T) if roofline and a.roofline_rounds > 0 else None
+    eng._last_roofline = res['roofline']
+    res['percu'] = bool(getattr(eng, 'percu', False))
     res['roofline_net'] = measure_net(a, eng, T, game_key, net_kind) if roofline and a.roofline_rounds > 0 else None
     del ex
     eng.close()
@@ -459,7 +485,7 @@ def main():
                groups=a.groups)
     for k in ('value_from_sims', 'sims_per_sec', 'plies_completed', 'games_finished', 'examples_gathered', 'examples_dropped',
               'engine_errors', 'forest_bytes_per_gpu', 'node_capacity', 'max_live_after_gc', 'max_live_frac', 'max_nodes_per_tree', 'gc_runs',
-              'rounds_timed', 'ms_per_round', 'preroll_plies', 'work_budget', 'advance_every'):
+              'rounds_timed', 'ms_per_round', 'preroll_plies', 'work_budget', 'advance_every', 'percu'):
         out[k] = r[k]
     for k in ('rccl_world', 'rccl_backend', 'examples_per_rank', 'gather_ms', 'gather_bytes_received_rank0', 'gather_mode', 'gather_row_bytes'):
         if k in r:

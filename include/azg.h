@@ -146,6 +146,22 @@ int azg_forest_select(azg_forest* f, int8_t* leaf_states_dev, uint8_t* leaf_vali
    noise_stride: 0 = no root noise, -2 = device sampler run by azg_selfplay_advance (see azg_forest_select). */
 int azg_forest_select_fused(azg_forest* f, int8_t* leaf_states_dev, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev,
                             const float* pi_dev, const float* v_dev, int noise_stride, void* stream);
+/* The per-CU form of the self-play round for Splendor 2 players + the V80 net (csrc/azg_fused.hip.h): ONE launch runs `rounds` rounds of
+       azg_forest_select_fused  ->  azg_nn_v80_forward_h2 on the leaf batch
+   with one 16-wave workgroup per 16 trees doing both -- every wave descends one tree, then the same waves evaluate the workgroup's 16
+   leaves -- so that a round of a CU waits for the slowest of ITS 16 trees instead of the slowest of all T, and nothing is launched
+   between the rounds (what the reference does with a lock ring of N game threads around one inference batch, Coach.py:117-144).
+   Arguments as for those two calls (same buffers, same 43-pointer weight table + 16 descale factors); per-tree results are identical
+   bit for bit to `rounds` times the two calls (tests/test_gpu_selfplay.py).  azg_selfplay_advance is launched by the caller between
+   launches, as between rounds of the two-kernel form. */
+int azg_forest_rounds_v80_h2(azg_forest* f, int8_t* leaf_states_dev, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev,
+                             float* v_dev, int noise_stride, const void* const* w, const float* descale_host, int rounds, void* stream);
+/* measurement: phase times of that kernel since the last reset, from the 100 MHz wall clock read inside the kernel, averaged over the
+   workgroups -- out[0] = select phase of a round (a workgroup waits for the slowest of its 16 trees), out[1] = net phase, out[2] = a
+   wave's own descent, all in microseconds per round; out[3] = rounds measured.  (bench.py's roofline uses out[0]: there is no launch
+   of the descent alone to put HIP events around.) */
+int azg_forest_rounds_profile(azg_forest* f, double* out4, int reset);
+
 /* part 2: store (Ps, v) on the pending leaves and back the values up (MCTS.py:147-154,176-183).
    pi f32[T][A] are PROBABILITIES (exp of the net's log-softmax, GenericNNetWrapper.py:107,119), v f32[T][P].
    The leaf_valid buffer handed to the preceding azg_forest_select must still hold what that call wrote (the kernel maps

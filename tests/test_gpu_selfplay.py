@@ -464,3 +464,46 @@ def test_set_search_params_between_moves():
     eng.run(120 * (sims + eng.K))                          # games end: the plies played with full searches were recorded
     s2 = eng.stats()
     assert s2['errors'] == 0 and s2['games'] > 0 and s2['examples'] > 0
+
+
+@pytest.mark.parametrize('T,sims,use_graph', [(40, 24, False), (64, 40, True)])
+def test_percu_round_kernel_equals_two_kernel_rounds(T, sims, use_graph):
+    """The per-CU round kernel (azg_forest_rounds_v80_h2: 16 trees + their 16 leaves per workgroup, `advance_every` rounds per launch)
+    against the two-kernel rounds (azg_forest_select_fused + azg_nn_v80_forward_h2) it replaces: the same games move for move -- every
+    drained example record (board, pi, z, valids, q, meta), the statistics counters and the root statistics are EQUAL, not close.
+    T = 40 leaves the last workgroup half empty."""
+    import os
+    import torch
+    from azg_amd import games
+    from azg_amd.nnet import SplendorV80Hip
+    from azg_amd.selfplay import SelfPlayEngine
+    g = games.SplendorGame(2)
+    w = os.path.join(os.path.dirname(__file__), 'golden', 'weights_splendor2_v80.npz')
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0],
+                tempThreshold=6, **MCTS_ARGS['splendor2'])
+    out = []
+    for percu in (False, True):
+        net = SplendorV80Hip.from_npz(w, max_batch=T)
+        e = SelfPlayEngine(g, net, args, T, node_capacity=2048, max_examples=T * 400, rng_seed=9, use_graph=use_graph, advance_every=8,
+                           percu=percu)
+        assert e.percu == percu
+        e.start()
+        e.run(8 * 60 * (sims + 8) // 8)               # ~60 plies: most games end and restart
+        st = e.stats()
+        assert st['errors'] == 0 and st['games'] > 0
+        ex = [x.cpu() for x in e.drain_examples()]
+        m = ex[5].to(torch.int64)                       # the ring's order is the order in which games happened to end: sort by (stream, game, ply)
+        order = torch.argsort((m[:, 0] * 100000 + m[:, 1]) * 1000 + m[:, 2])
+        ex = [x[order] for x in ex]
+        rs = {k: v.cpu() for k, v in e.forest.root_stats().items()}
+        out.append((st, ex, rs))
+        assert e.forest.validate(verbose=False) == 0
+        e.close()
+    (s0, e0, r0), (s1, e1, r1) = out
+    for k in ('plies', 'games', 'sims', 'levels', 'expansions', 'terminal_hits', 'examples', 'sum_valid_visited', 'sum_depth_at_expand'):
+        assert s0[k] == s1[k], (k, s0[k], s1[k])
+    assert len(e0[0]) == len(e1[0]) > 0
+    for a, b in zip(e0, e1):
+        assert torch.equal(a, b)
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k

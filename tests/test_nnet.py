@@ -332,6 +332,7 @@ def test_h2_kernels_saturate_out_of_range_activations_gpu():
     f32-operand kernel of the same net (h2=False, split=False) has the full range and stays on the fp32 model.  A net whose first layer
     is scaled up 2000 x drives the residual stream to ~1e4 (GenericNNetWrapper.train can diverge like this)."""
     from azg_amd import nnet
+    root = os.path.join(os.path.dirname(__file__), 'golden')
     z = np.load(os.path.join(root, 'weights_splendor2_v80.npz'))
     sd = {k[3:]: torch.as_tensor(z[k]).clone() for k in z.files if k.startswith('sd/')}
     sd['first_layer.linear.weight'] *= 2000.0
