@@ -19,17 +19,20 @@ __device__ __forceinline__ int lane_id() { int l = threadIdx.x & 63; asm volatil
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 #endif
 
-// LDS ordering inside ONE wavefront.  In a single-wave workgroup __syncthreads() does it (s_barrier is a no-op for one wave, the waitcnt
-// it carries is what matters).  A translation unit whose workgroups hold several tree waves (azg_nn.hip with azg_fused.hip.h) defines
-// AZG_WAVE_LOCAL_SYNC: a wavefront-scope fence (the LDS and the vector-memory path serve one wave's requests in order, so only the
-// compiler must be kept from reordering) + the wave barrier intrinsic; a workgroup barrier there would deadlock divergent waves.
+// LDS ordering inside ONE wavefront (every forest / env kernel gives a tree or a state to one wave): a wavefront-scope fence -- the LDS and
+// the vector-memory path serve one wave's requests in order, so only the COMPILER must be kept from reordering -- plus the wave barrier
+// intrinsic.  Rounds 1-3 used __syncthreads() here (the s_barrier is dropped for a single-wave workgroup, its waitcnt is what mattered):
+// that waitcnt is `vmcnt(0) lgkmcnt(0)`, i.e. every LDS hand-over between lanes also DRAINED every global load and store the wave had
+// in flight -- 46 full drains in k_select, which serialised each memory round trip with the LDS work that could have run under it.
+// AZG_SYNC_DRAINS restores the old behaviour (A/B runs).  In a workgroup of several tree waves (azg_fused.hip.h) a workgroup barrier
+// would be wrong anyway.
 __device__ __forceinline__ void wave_sync() {
-#ifdef AZG_WAVE_LOCAL_SYNC
+#ifdef AZG_SYNC_DRAINS
+    __syncthreads();
+#else
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#else
-    __syncthreads();
 #endif
 }
 

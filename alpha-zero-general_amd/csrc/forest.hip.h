@@ -517,8 +517,8 @@ struct Forest {
 
     // Lane-parallel value backup along the recorded path (MCTS.py:176-183 unwound): level d belongs to lane d.
     // (Round 4, measured and dropped: carrying the four statistics the descent read at each level (Nsa, Qsa, Ns, Qs) along with the
-    // path, so that the backup only stores -- the round trip it saves is hidden behind the expansion's own work, while the extra bytes
-    // ride on the bandwidth-bound first round trip of every launch and the descent pays two more readlanes per level: -2 % env-steps/s.)
+    // path, so that the backup only stores -- the extra bytes ride on the bandwidth-bound first round trip of every launch and the descent
+    // pays two more readlanes per level: -2 % env-steps/s.)
     __device__ static __forceinline__ void backup(const ForestDev& F, int t, const PathEnt* path, int depth, const float* v) {
         if (depth == 0) return;
         int tot = 0;

@@ -334,6 +334,9 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
     c1 = AZG_CLK(); AZG_SEG(2, c1 - c0);
     uint32_t free_slot;
     uint32_t found_rec = AZG_NONE;
+    // (Round 4, measured and dropped: requesting the table's first round trip ahead and computing the new node's terminal test and valid
+    // mask under it, and requesting the backup's statistics before the expansion's arithmetic -- both bit-identical, both -0.5 %: with
+    // four waves per SIMD the waits they remove were already covered by the other waves' work.)
     const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
     c0 = AZG_CLK(); AZG_SEG(3, c0 - c1);
     uint32_t crec;
@@ -568,6 +571,9 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
     H.cur_depth = AZG_HW(hw, cur_depth); H.cur_pre = AZG_HW(hw, cur_pre);
     H.rng_lo = hw[offsetof(TreeHdr, rng_counter) / 4]; H.rng_hi = hw[offsetof(TreeHdr, rng_counter) / 4 + 1];
     bool fresh_noise = false;
+    // (Round 4, measured and dropped: touching the lines of the previous simulation's path records -- one load instruction, ten lanes per
+    // level, issued here -- so that the descent finds them in the L2: the first round trip of a launch is requested by all T waves at
+    // the same moment and is bandwidth-bound, the extra lines cost more than the hits give back: -1.6 % env-steps/s.)
     if (pi && uni_u32(status0) == ST_WAIT_NN) {
         fresh_noise = expand_apply<G>(F, t, ein, dense, sm.path, noise_enabled, azg_stamp);
 #ifdef AZG_STAMP_DRAIN
