@@ -281,6 +281,9 @@ __global__ __launch_bounds__(64) void k_selfplay_advance(ForestDev F) {
     }
     const double T = temp_for_selfplay(F, (int)H.step + 1);
     const double u_pick = rng.u01();
+    // temperature == 0 (Coach.py:278-292): np.random.choice(bests) takes u_pick (the k-th of the nb maxima, k = floor(u * nb)), and
+    // random_pick then still calls np.random.choice(len(p), p = the one-hot result) -- a second uniform is consumed, whatever its value
+    if (T == 0.0) (void)rng.u01();
     for (int a = l; a < G::A; a += 64) {
         double p = tot > 0 ? (double)cnt[a] / (double)tot : 0.0;
         w[a] = (T == 0.0) ? p : pow(p, 1.0 / T);

@@ -19,7 +19,10 @@
  *     raw(seed, stream, counter) = mix64(mix64(mix64(seed ^ 0x9E3779B97F4A7C15) + stream) + counter)
  *     u01 = (raw >> 11) * 2^-53;   stream = global game index, counter = per-game draw count.
  *   Per ply a self-play game draws: u_full (MCTS.py:58), u_pick (Coach.py:289-292), then whatever
- *   make_move(random_seed=0) consumes (SplendorLogicNumba.py:311-315).
+ *   make_move(random_seed=0) consumes (SplendorLogicNumba.py:311-315).  u_pick drives np.random.choice(len(p), p=p) as NumPy does it
+ *   (searchsorted of the normalised cumulative sum).  With temperature == 0 (Coach.py:278-283) the reference calls np.random.choice
+ *   twice -- the unweighted choice among the maxima, k = floor(u_pick * n_maxima), then the weighted choice on the one-hot result --
+ *   so a SECOND uniform is consumed after u_pick (fixture tests/golden/episode_splendor2_temp0.npz, played by the reference).
  */
 #ifndef AZG_H
 #define AZG_H

@@ -70,7 +70,12 @@ int azo_episode_run(const azo_game* g, const azo_episode_cfg* cfg, const int8_t*
         int is_full = azo_mcts_get_action_prob(m, canon, 1.0, 0, u_full, NULL, predict, ctx, pi, q);   /* :62 */
         if (is_full < 0) { plies = -1; break; }
         double u_pick = azo_rng_u01(&rng);
-        int action = random_pick(pi, A, temp_for_selfplay(cfg, step), u_pick);      /* :63 */
+        const double temp = temp_for_selfplay(cfg, step);
+        int action = random_pick(pi, A, temp, u_pick);                              /* :63 */
+        /* temperature == 0 (Coach.py:278-292): applyTemperatureAndNormalize draws np.random.choice(bests) -- u_pick above, the k-th of
+           the nb maxima with k = floor(u * nb), the contract's unweighted choice -- and random_pick then still calls
+           np.random.choice(len(p), p = the one-hot result): a second uniform is consumed, its outcome is the one-hot index */
+        if (temp == 0) (void)azo_rng_u01(&rng);
         memcpy(out_canonical + (size_t)plies * S, canon, (size_t)S);
         out_action[plies] = action; out_player[plies] = cur; out_full[plies] = is_full;
         plies++;

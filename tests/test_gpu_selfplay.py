@@ -507,3 +507,38 @@ def test_percu_round_kernel_equals_two_kernel_rounds(T, sims, use_graph):
         assert torch.equal(a, b)
     for k in r0:
         assert torch.equal(r0[k], r1[k]), k
+
+
+@pytest.mark.parametrize('game_key', ['santorini11', 'splendor4', 'azul', 'santorini1'])
+def test_full_size_properties_other_configs(game_key):
+    """BASELINE.json configs 3 / 4 / 5 (and the north star's second target) at FULL size -- 4096 concurrent games, 800 simulations per
+    move, the pretrained net of the game on the engine's kernels, the engine exactly as bench.py builds it: size-independent invariants
+    after three plies -- no error flag, the structural validator passes on all 4096 trees, every root's visit counts add up
+    (MCTS.py:180-181), every tree keeps moving.  (Splendor 2p: test_full_size_properties.)"""
+    import importlib.util
+    import os
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('azg_bench', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    T, sims = 4096, 800
+    a = bench.argparse.Namespace(net_dtype='fp32', net='hip', groups=1, sims=sims, prob_full=1.0, node_capacity=0, no_graph=False, level_budget=0,
+                                 work_budget=-1, advance_every=0, no_pin_xcd=False)
+    eng, margs, label, weights, net_kind = bench.build_engine(a, game_key, T, 0, 'cuda:0')
+    assert net_kind == 'hip'
+    eng.start()
+    eng.run(3 * sims + 64)
+    st = eng.stats()
+    assert st['errors'] == 0
+    assert 2 * T <= st['plies'] <= 4 * T                 # every tree is in its 3rd or 4th search
+    assert st['sims'] >= st['expansions'] > 0
+    assert eng.forest.validate(verbose=False) == 0
+    rs = eng.forest.root_stats()
+    Ns, Nsa = rs['Ns'].cpu().numpy().astype(np.int64), rs['Nsa'].cpu().numpy().astype(np.int64)
+    has_root = Ns > 0
+    assert has_root.mean() > 0.9
+    assert np.array_equal(Nsa.sum(axis=1)[has_root], Ns[has_root])
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()

@@ -42,6 +42,9 @@ CASES = [
     ('santorini11', 'capstep', 4242, 1003, 40, 0.5, [1.0, 0.3, 1.0], -4),      # tempThreshold < 0: the step schedule (:268-269)
     ('azul', 'full', 4242, 1000, 40, 1.0, [1.25, 0.8, 1.0], 10),
     ('azul', 'cap', 4242, 1002, 40, 0.5, [1.0, 0.1, 1.1], 10),                 # main.py's default temperatures
+    # temperature == 0 after the third ply (step schedule with t_end = 0): applyTemperatureAndNormalize's np.random.choice(bests) and the
+    # second np.random.choice(len(p), p=one-hot) of random_pick (Coach.py:278-292) -- two uniforms per pick
+    ('splendor2', 'temp0', 4242, 1004, 40, 1.0, [1.0, 0.0, 1.0], -3),
 ]
 
 _checked = [0]
@@ -170,7 +173,7 @@ def main():
     ap.add_argument('--only', default=None)
     a = ap.parse_args()
     for c in CASES:
-        if a.only and c[0] != a.only:
+        if a.only and a.only not in (c[0], c[0] + '_' + c[1]):
             continue
         out = gen_case(*c)
         fn = os.path.join(GOLDEN, 'episode_%s_%s.npz' % (c[0], c[1]))
