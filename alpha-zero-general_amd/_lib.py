@@ -17,7 +17,7 @@ class ForestCfg(C.Structure):
                 ('universes', C.c_int), ('prob_fullMCTS', C.c_double), ('ratio_fullMCTS', C.c_int),
                 ('forced_playouts', C.c_int), ('dirichletAlpha', C.c_double), ('temperature', C.c_double * 3),
                 ('tempThreshold', C.c_double), ('rng_seed', C.c_uint64), ('stream0', C.c_uint64),
-                ('max_examples', C.c_int), ('level_budget', C.c_int), ('work_budget', C.c_int)]
+                ('max_examples', C.c_int), ('level_budget', C.c_int), ('work_budget', C.c_int), ('gc_high_water_pct', C.c_int)]
 
 
 class SelfplayStats(C.Structure):

@@ -59,6 +59,10 @@ extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
     } while (0)
 
 // games whose expanded nodes carry many more entries than the default heap sizing assumes name their typical count (REC_NV_HINT)
+// ... or the AVERAGE record size in bytes over the nodes of a tree (REC_BYTES_HINT, measured), when the default -- room for 64 entries in
+// every record, plus a quarter -- would make the heap twice what the records take (Azul: three nodes in four fit one 32-entry page)
+template <class G, class = void> struct RecBytesHint { static constexpr int value = 0; };
+template <class G> struct RecBytesHint<G, std::void_t<decltype(G::REC_BYTES_HINT)>> { static constexpr int value = G::REC_BYTES_HINT; };
 template <class G, class = void> struct RecNvHint { static constexpr int value = 0; };
 template <class G> struct RecNvHint<G, std::void_t<decltype(G::REC_NV_HINT)>> { static constexpr int value = G::REC_NV_HINT; };
 
@@ -279,7 +283,8 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     f->launches[0] = f->launches[1] = 0;
     int game = f->cfg.game, variant = f->cfg.variant;
     int nv_hint = 0;                     // typical valid actions per expanded node (sizes the record heap of large action spaces)
-    AZG_DISPATCH(game, variant, { f->S = G::S; f->SP = G::SP; f->A = G::A; f->P = G::P; nv_hint = RecNvHint<G>::value; });
+    int rec_bytes_hint = 0;              // average record bytes per node (overrides the nv_hint sizing)
+    AZG_DISPATCH(game, variant, { f->S = G::S; f->SP = G::SP; f->A = G::A; f->P = G::P; nv_hint = RecNvHint<G>::value; rec_bytes_hint = RecBytesHint<G>::value; });
     if (cfg->n_trees <= 0 || cfg->node_capacity < 16) { delete f; return fail("bad n_trees / node_capacity"); }
     if (cfg->node_capacity > (1 << AZG_IDX_BITS) - 2) { delete f; return fail("node_capacity too large"); }
     if (cfg->universes < 0 || cfg->universes > AZG_MAX_UNIVERSES) { delete f; return fail("universes out of range"); }
@@ -298,6 +303,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
                             : (D.cls_q == f->A ? (size_t)D.cap * RecGeom(D.cls_q, D.U).total(f->A) + 4096
+                                               : rec_bytes_hint ? (size_t)D.cap * (size_t)rec_bytes_hint
                                                : (size_t)D.cap * RecGeom(D.cls_q, D.U).total(nv_hint ? nv_hint : (f->A <= 256 ? 64 : 160)) * 5 / 4) + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     if (heap_bytes / 16 > (size_t)AZG_CHILD_IDX_MASK) { delete f; return fail("record heap per tree exceeds the 29-bit record offset (8 GiB)"); }
@@ -315,6 +321,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     D.forced_playouts = cfg->forced_playouts;
     D.level_budget = cfg->level_budget;
     D.work_budget = cfg->work_budget;
+    D.gc_high_water = cfg->gc_high_water_pct > 0 ? (uint32_t)((long long)cfg->node_capacity * cfg->gc_high_water_pct / 100) : 0u;
     { const char* e = getenv("AZG_SPEC_STATE"); D.spec_state = e ? atoi(e) : 8; }
     D.cpuct = cfg->cpuct; D.fpu = cfg->fpu; D.prob_fullMCTS = cfg->prob_fullMCTS;
     D.dirichletAlpha = cfg->dirichletAlpha;

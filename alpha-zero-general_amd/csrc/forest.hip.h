@@ -124,6 +124,8 @@ struct ForestDev {
     int spec_state;                    // one-class forests: fetch the node's state with its entries (the frontier edge then finds its parent
                                        // state in registers): 1 = at every level, N >= 2 = at nodes reached over an edge with < N visits
                                        // (default 8), 0 = never, i.e. when an edge is resolved (AZG_SPEC_STATE, A/B runs)
+    uint32_t gc_high_water;            // self-play: clean a tree up before its next search once its arena holds more nodes than this (0 = only
+                                       // when the arena could not take another search)
     uint32_t episode_quota;            // self-play: total games this forest plays (azg_selfplay_start_ex), 0 = restart forever
     double cpuct, fpu, prob_fullMCTS, dirichletAlpha, temp_begin, temp_end, temp_root, tempThreshold;
     uint64_t rng_seed, stream0;

@@ -13,6 +13,9 @@ struct AzulDev {
     static constexpr bool RANDOM_SYM = false;   // get_symmetries draws no randomness
     static constexpr int P = 2;
     static constexpr int ROWS = 23, COLS = 6;
+    // record heap sizing: a visited node has 21-26 valid moves (one 32-entry page = 736 B; a third of the nodes need two pages); the
+    // clean-up runs at 70 % of the node capacity, so 1100 B per capacity node leaves the live records 45 % of slack
+    static constexpr int REC_BYTES_HINT = 1100;
     static constexpr int S = 138;
     static constexpr int SP = 144;
     static constexpr int A = 180;                 // action_size :55-57
@@ -239,12 +242,16 @@ struct AzulDev {
     // any move can end the round, whose refill draws tiles with random_seed (setup_new_round :237-255)
     __device__ static __forceinline__ bool move_uses_seed(int) { return true; }
 
+    // Board.make_move :125-159.  The ply's tile moves are a dozen byte updates and the "table empty?" scan reads 35 consecutive bytes
+    // (a few wide LDS reads once the compiler merges them): lane 0 runs the step.  (Round 4, measured and dropped: lane 0 moves the
+    // tiles, all lanes read one table byte each and a ballot answers "empty?", lane 0 alone runs the rare end of round -- two more LDS
+    // hand-overs than the serial form, -2.7 % env-steps/s at 4096 games.)
     __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
         return lane0_make_move<AzulDev>(st, move, player, seed, rng);
     }
 
-    // Board.make_move :125-159 -- lane 0 only
-    __device__ static int make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
+    // the tiles of one move: factory / centre -> pattern line, floor, discard (:125-147)
+    __device__ static void take_tiles(int8_t* st, int move, int player) {
         int8_t* fac = move < 30 ? row(st, R_CENTRE) : row(st, R_FACT + (move - 30) / 30);
         const int colour = (move % 30) / 6, line = move % 6;
         int8_t* pr = row(st, R_PROW + player);
@@ -268,15 +275,22 @@ struct AzulDev {
             int8_t* centre = row(st, R_CENTRE);
             for (int c = 0; c < 6; c++) { centre[c] = (int8_t)(centre[c] + fac[c]); fac[c] = 0; }
         }
+    }
+    // the table is empty: score the round, refill, bonuses at the end of the game (:149-158); returns the next player
+    __device__ static int end_round(int8_t* st, long long seed, Rng& rng) {
+        score_round(st);
+        const int next = setup_new_round(st, seed, rng);
+        if (game_over(st)) score_bonuses(st);
+        return next;
+    }
+
+    // Board.make_move :125-159 -- one thread (host-style entry)
+    __device__ static int make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
+        take_tiles(st, move, player);
         bool empty = true;
         for (int i = 0; i < 5 * COLS; i++) empty = empty && row(st, R_FACT)[i] == 0;
         for (int c = 0; c < 5; c++) empty = empty && row(st, R_CENTRE)[c] == 0;
-        if (empty) {
-            score_round(st);
-            const int next = setup_new_round(st, seed, rng);
-            if (game_over(st)) score_bonuses(st);
-            return next;
-        }
+        if (empty) return end_round(st, seed, rng);
         return (player + 1) % 2;
     }
 

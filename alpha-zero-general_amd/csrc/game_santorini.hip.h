@@ -37,6 +37,28 @@ struct SantoriniDev {
         for (int i = 24; i >= 0; i--) f = (W(st, i) == id) ? i : f;
         return Pos{f / 5, f % 5};
     }
+    // The same for all four workers at once, wave-parallel: lane i < 25 reads cell i, one ballot per worker id, lowest set bit = the
+    // first cell holding it (0 when there is none, as the reference's scan).  wp[0..1] = player 0's workers 1, 2; wp[2..3] = player 1's.
+    struct Workers { int cell[4]; };
+    __device__ static __forceinline__ Workers find_workers(const int8_t* st) {
+        const int l = lane_id();
+        const int w = l < 25 ? W(st, l) : 0;
+        Workers k;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int id = (i & 1) + 1, sgn = i < 2 ? 1 : -1;
+            const uint64_t m = __ballot(w == id * sgn);
+            k.cell[i] = m ? first_lane(m) : 0;
+        }
+        return k;
+    }
+    __device__ static __forceinline__ Pos worker_of(const Workers& k, int player, int worker) {
+        // (a select chain, not k.cell[2 * player + worker]: a dynamically indexed private array lives in scratch memory, and every
+        // byte of scratch a wave touches is written back to HBM once 4096 waves' worth no longer fits the L2)
+        const int a = player ? k.cell[2] : k.cell[0], b = player ? k.cell[3] : k.cell[1];
+        const int c = worker ? b : a;
+        return Pos{c / 5, c - 5 * (c / 5)};
+    }
 
     __device__ static bool able_to_move(const int8_t* st, Pos old, Pos np, int player, bool no_climb, bool swap,
                                         bool push) {                                               // :675-716
@@ -74,7 +96,7 @@ struct SantoriniDev {
     }
 
     // Board.valid_moves (:125-432) as a predicate of one action
-    __device__ static bool valid_action(const int8_t* st, int a, int player, int god, bool opp_athena) {
+    __device__ static bool valid_action(const int8_t* st, int a, int player, int god, bool opp_athena, const Workers& wk) {
         const int worker = a / (NB * 81);
         int rem = a - worker * NB * 81;
         const int power = rem / 81; rem -= power * 81;
@@ -82,7 +104,7 @@ struct SantoriniDev {
         if (god < 0) return false;
         if (power != NO_GOD && power != god) return false;
         const int wid = (worker + 1) * (player == 0 ? 1 : -1);
-        const Pos old = worker_pos(st, wid);
+        const Pos old = worker_of(wk, player, worker);
         const Pos np = dir(old, md);
         const Pos bp = dir(np, bd);
         switch (god) {
@@ -164,9 +186,10 @@ struct SantoriniDev {
         const int l = lane_id();
         const int god = owned_god(st, player);
         const bool opp_athena = GP(st, ATHENA + NB * ((player + 1) % 2)) > 64;                      // :133
+        const Workers wk = find_workers(st);
         for (int k = 0; k < AW; k++) {
             const int a = k * 64 + l;
-            const uint64_t m = __ballot(a < A && valid_action(st, a < A ? a : 0, player, god, opp_athena));
+            const uint64_t m = __ballot(a < A && valid_action(st, a < A ? a : 0, player, god, opp_athena, wk));
             if (l == 0) mask_lds[k] = m;
         }
     }
@@ -232,19 +255,33 @@ struct SantoriniDev {
     // no chance events in Santorini: random_seed is never read by make_move (:434-550)
     __device__ static __forceinline__ bool move_uses_seed(int) { return false; }
 
+    // Board.make_move :434-550 for the whole wave: the moving worker is located by one ballot over the 25 cells (every lane then holds
+    // the same positions in scalar registers), the handful of byte updates of the move are lane 0's stores
     __device__ static __forceinline__ int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
-        return lane0_make_move<SantoriniDev<NB>>(st, move, player, seed, rng);
+        (void)seed; (void)rng;
+        const int worker = move / (NB * 81);
+        const Workers wk = find_workers(st);
+        const Pos old = worker_of(wk, player, worker);
+        int np_ = 0;
+        if (lane_id() == 0) np_ = make_move_at(st, move, player, old);
+        np_ = __builtin_amdgcn_readfirstlane(np_);
+        wave_sync();
+        return np_;
     }
 
-    // Board.make_move :434-550 -- lane 0 only
+    // Board.make_move :434-550 -- host-style entry (one thread): locates the worker by the reference's scan
     __device__ static int make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {
         (void)seed; (void)rng;
+        const int worker = move / (NB * 81);
+        const int wid = (worker + 1) * (player == 0 ? 1 : -1);
+        return make_move_at(st, move, player, worker_pos(st, wid));
+    }
+    __device__ static int make_move_at(int8_t* st, int move, int player, const Pos old) {
         const int worker = move / (NB * 81);
         int rem = move - worker * NB * 81;
         const int power = rem / 81; rem -= power * 81;
         const int md = rem / 9, bd = rem - md * 9;
         const int wid = (worker + 1) * (player == 0 ? 1 : -1);
-        const Pos old = worker_pos(st, wid);
         const Pos np = dir(old, md);
         const int io = idx(old) * 3, in = idx(np) * 3;
         bool opp_next = true;
@@ -324,15 +361,19 @@ struct SantoriniDev {
     __device__ static bool game_ended(const int8_t* st, int next_player, float* out, uint64_t* mask_scratch) {
         (void)mask_scratch;
         out[0] = out[1] = 0.f;
-        if (get_score(st, 0) == 3 || GP(st, PAN + NB * 0) > 64) { out[0] = 1.f; out[1] = -1.f; return true; }
-        if (get_score(st, 1) == 3 || GP(st, PAN + NB * 1) > 64) { out[0] = -1.f; out[1] = 1.f; return true; }
         const int l = lane_id();
+        // get_score(p) == 3 <=> one of p's workers stands on level 3 (levels under a worker are 0..3): one read per cell, two ballots
+        const int w = l < 25 ? W(st, l) : 0, lv = l < 25 ? LV(st, l) : 0;
+        const bool top0 = __ballot(w > 0 && lv == 3) != 0ull, top1 = __ballot(w < 0 && lv == 3) != 0ull;
+        if (top0 || GP(st, PAN + NB * 0) > 64) { out[0] = 1.f; out[1] = -1.f; return true; }
+        if (top1 || GP(st, PAN + NB * 1) > 64) { out[0] = -1.f; out[1] = 1.f; return true; }
         const int god = owned_god(st, next_player);
         const bool opp_athena = GP(st, ATHENA + NB * ((next_player + 1) % 2)) > 64;
+        const Workers wk = find_workers(st);
         bool any = false;
         for (int k = 0; k < AW && !any; k++) {
             const int a = k * 64 + l;
-            any = __ballot(a < A && valid_action(st, a < A ? a : 0, next_player, god, opp_athena)) != 0ull;
+            any = __ballot(a < A && valid_action(st, a < A ? a : 0, next_player, god, opp_athena, wk)) != 0ull;
         }
         if (!any) {
             if (next_player == 0) { out[0] = -1.f; out[1] = 1.f; }

@@ -162,6 +162,8 @@ __device__ __forceinline__ bool arena_is_short(const ForestDev& F, const TreeHdr
     const uint32_t need_units = need_nodes * FR::cls_units(F, FR::cls_of(F, G::A < 96 ? G::A : 96)) + 256u;
     // ids in use (dead ones included until the next clean-up) / record space left on the bump pointer and the free lists
     if ((H.id_top - H.n_free_ids) + need_nodes > (uint32_t)F.cap) return true;
+    // high-water mark (cfg.gc_high_water_pct): clean up early enough that the arena never fills beyond it + one search
+    if (F.gc_high_water && (H.id_top - H.n_free_ids) > F.gc_high_water) return true;
     return F.cls_q != G::A && (F.heap_units - H.heap_top) + H.free_units < need_units;   // one-class forests: slot == node id
 }
 

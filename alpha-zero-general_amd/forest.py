@@ -22,7 +22,7 @@ class Forest:
     tempThreshold (main.py:120-156, pit.py:49-57)."""
 
     def __init__(self, game_id, variant, n_trees, args, node_capacity=4096, max_examples=0, rng_seed=0, stream0=0,
-                 device='cuda:0', row_capacity_bytes=0, level_budget=0, work_budget=0):
+                 device='cuda:0', row_capacity_bytes=0, level_budget=0, work_budget=0, gc_high_water_pct=0):
         if not torch.cuda.is_available():
             raise _lib.AzgError('no GPU visible: the engine has no CPU fallback')
         self.device = torch.device(device)
@@ -47,6 +47,7 @@ class Forest:
         cfg.rng_seed, cfg.stream0, cfg.max_examples = rng_seed, stream0, max_examples
         cfg.level_budget = level_budget
         cfg.work_budget = work_budget
+        cfg.gc_high_water_pct = int(gc_high_water_pct)
         self.cfg = cfg
         self.T = n_trees
         h = C.c_void_p()

@@ -84,7 +84,7 @@ class _Group:
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
                  use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=None, fused=True,
-                 pin_xcd=None, percu=None):
+                 pin_xcd=None, percu=None, gc_high_water_pct=None):
         self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
@@ -112,7 +112,8 @@ class SelfPlayEngine:
         for g in range(groups):
             f = Forest(game.GAME_ID, game.variant, Tg, args, node_capacity=cap,
                        max_examples=(max_examples or n_games * 64) // groups, rng_seed=rng_seed,
-                       stream0=stream0 + g * Tg, device=str(game.device), level_budget=level_budget, work_budget=work_budget)
+                       stream0=stream0 + g * Tg, device=str(game.device), level_budget=level_budget, work_budget=work_budget,
+                       gc_high_water_pct=70 if gc_high_water_pct is None else gc_high_water_pct)
             self.groups.append(_Group(f, nets[g], (Tg,) + tuple(f.board_shape()), 'deferred' if alpha != 0.0 else False))
         self.forest = self.groups[0].f
         self.nnet = nets[0]

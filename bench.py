@@ -206,7 +206,10 @@ def build_engine(a, game_key, T, rank, dev):
     margs['prob_fullMCTS'] = a.prob_full
     # nodes live until the root's age passes theirs: ~12 plies' worth of simulations in Splendor, more in the narrow, deep
     # searches of Azul / Santorini (with gods: A = 1782 makes a node ~5 KB; 14 x sims keeps 4096 trees within the 288 GB)
-    cap = a.node_capacity or max(2048, {'splendor2': 16, 'santorini11': 14}.get(game_key, 32) * a.sims + 512)
+    # Round 4: the engine cleans a tree up once its arena is 70 % full (cfg.gc_high_water_pct), not only when another search would not
+    # fit, so the arena is sized for the largest LIVE tree + one search with >= 20 % headroom (Splendor 2p: 7.5 k live nodes measured over
+    # whole games -> 13 x sims; it was 16 x sims with the clean-up at exhaustion: 158.9 -> 130.5 GB for 4096 trees)
+    cap = a.node_capacity or max(2048, {'splendor2': 13, 'santorini11': 14}.get(game_key, 32) * a.sims + 512)
     eng = None
     for attempt in range(3):           # the forest wants a large share of the 288 GB HBM: shrink the arena if the device has less to give
         try:

@@ -113,6 +113,11 @@ typedef struct azg_forest_cfg {
                                     level = 1, one frontier-edge resolution = 5; 0 = unlimited): a launch lasts as long as
                                     its slowest tree, so the few trees with a very deep or transposition-heavy simulation
                                     are parked at a level boundary and resume in the next launch.  Pure scheduling. */
+    int gc_high_water_pct;       /* self-play clean-up (the reference's MCTS.py:86-91, every > 20 rounds): a tree whose arena holds more
+                                    than this share of node_capacity when its next search begins is cleaned up first -- not only when
+                                    the arena could not take another search -- so the arena keeps headroom and can be sized for the
+                                    LIVE tree instead of live + many plies of dead nodes.  0 = only at exhaustion (rounds 1-3).  Which
+                                    nodes survive does not depend on when the clean-up runs: results identical. */
 } azg_forest_cfg;
 
 typedef struct azg_forest azg_forest;
