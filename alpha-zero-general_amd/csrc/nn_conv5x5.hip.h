@@ -26,6 +26,66 @@ struct Conv5NetW {
     const float *Wf2, *bf2;           // value fc2 [64][P], bias [P]
 };
 
+// Row order of an activation tile.  Sample-major (CM = false, rounds 1-3): row = sample * 25 + cell -- a 16-row MFMA tile mixes up to 16
+// different cells, so every tile needs all nine taps and a tap that leaves the board is an MFMA on the zero row.  CELL-major (CM = true,
+// the f16 x 2 ResNet kernel since round 4): row = cell * NS + sample; with NS = 8 a tile is exactly two neighbouring cells, the taps that
+// leave the board for BOTH of them are skipped for the whole tile (wave-uniform): 99 (tile, tap) pairs per convolution instead of 117,
+// i.e. 15 % fewer MFMAs and LDS operand reads.  A neighbour cell is NS * (dy * 5 + dx) rows away.
+template <int NS, bool CM> __device__ __forceinline__ int c5_cell(int r) { return CM ? r / NS : r % 25; }
+template <int NS, bool CM> __device__ __forceinline__ int c5_sample(int r) { return CM ? r % NS : r / 25; }
+template <int NS, bool CM> __device__ __forceinline__ int c5_step(int dcell) { return CM ? NS * dcell : dcell; }
+__host__ __device__ constexpr uint32_t c5_cell_taps(int cell) {        // bit t = tap t (ky * 3 + kx) stays on the 5 x 5 board
+    const int y = cell / 5, x = cell - 5 * y;
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < 5 && xx >= 0 && xx < 5) m |= 1u << t;
+    }
+    return m;
+}
+
+// Row tile of slot i of row group rg (12 waves = 4 output-channel tiles x 3 row groups).  Sample-major: rt = rg + 3 i (group 0 takes the odd
+// 13th tile).  Cell-major: the 13 tiles need 6 6 8 9 9 9 9 9 9 9 6 6 4 taps (99), dealt out so that every group walks 33 (tile, tap) pairs
+// -- {3 4 5 0}, {6 7 8 1}, {9 2 10 11 12} -- instead of 37 / 30 / 32 with the strided deal (the convolution ends with its slowest group).
+template <bool CM> __host__ __device__ constexpr int c5_tile_of(int rg, int i) {
+    if (!CM) return rg + 3 * i;
+    constexpr int T[3][5] = {{3, 4, 5, 0, 99}, {6, 7, 8, 1, 99}, {9, 2, 10, 11, 12}};
+    return T[rg][i];
+}
+template <bool CM> __host__ __device__ constexpr int c5_last_group() { return CM ? 2 : 0; }     // the group with five tiles
+
+// The (kernel row ky, fragment k6 = kx * 2 + K chunk, tile slot i) steps of one convolution for the waves of row group RGV (row tiles
+// rt = RGV + 3 i, i < NT), kernel row by kernel row, fragment by fragment, in the order the software pipeline walks them.  CM: a step is
+// kept only if its tap stays on the board for at least one of the tile's two cells; last[s] marks a fragment's final step of its kernel row.
+template <int NT, int RGV, bool CM>
+struct C5Steps {
+    int n = 0;
+    int8_t ky[18 * NT] = {}, k6[18 * NT] = {}, ti[18 * NT] = {};
+    bool last[18 * NT] = {};
+    constexpr C5Steps() {
+        for (int y = 0; y < 3; y++)
+            for (int k = 0; k < 6; k++) {
+                int first = n;
+                for (int i = 0; i < NT; i++) {
+                    const int rt = c5_tile_of<CM>(RGV, i), c0 = 2 * rt, c1 = 2 * rt + 1;
+                    const uint32_t tm = CM ? ((c0 < 25 ? c5_cell_taps(c0) : 0u) | (c1 < 25 ? c5_cell_taps(c1) : 0u)) : 0x1FFu;
+                    if ((tm >> (y * 3 + (k >> 1))) & 1u) { ky[n] = (int8_t)y; k6[n] = (int8_t)k; ti[n] = (int8_t)i; last[n] = false; n++; }
+                }
+                if (n > first) last[n - 1] = true;
+                // (every fragment keeps at least one tile in every row group: the board has five rows and columns, a row group of at
+                // least four tiles always holds a cell that is neither on the top / bottom nor on the left / right edge)
+            }
+    }
+};
+
+template <int NT, int RGV, bool CM> struct C5StepList { static constexpr C5Steps<NT, RGV, CM> value{}; };
+// compile-time loop: f(integral_constant<int, I>) for I = LO .. HI - 1 (indices into register arrays stay constants whatever the body's size)
+template <int LO, int HI, class F>
+__device__ __forceinline__ void c5_static_for(F&& f) {
+    if constexpr (LO < HI) { f(std::integral_constant<int, LO>{}); c5_static_for<LO + 1, HI>(f); }
+}
+
 // one 3x3 convolution over the workgroup's tile.  KC = input-channel chunks of 16 per tap.
 //   IN [ROWS][CS] -> OUT [ROWS][CS] = relu(conv(IN) + bias (+ RES)); OUT may alias RES (same lane reads and writes an element)
 template <int KC, int NS, bool RELU = true>
@@ -152,7 +212,7 @@ __device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wf
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 // `prefetch` is called once this convolution's own weights are requested: whatever it asks for travels behind them and lands during
 // the tile loop (which only touches LDS) instead of delaying the first MFMAs
-template <int NS, bool RELU = true, class Prefetch = NoPrefetch>
+template <int NS, bool RELU = true, class Prefetch = NoPrefetch, bool CM = false>
 __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag, const float* __restrict__ bias,
                                                  const float* IN, uint8_t* OUT, Prefetch prefetch = Prefetch()) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
@@ -179,13 +239,13 @@ __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag
     for (int i = 0; i < MAXT; i++) {
         const int rt = rg + RG * i, r = rt * 16 + r16;
         if (rt >= RT) continue;
-        const int cell = r % 25, y = cell / 5, x = cell - 5 * y;
+        const int cell = r < ROWS ? c5_cell<NS, CM>(r) : 0, y = cell / 5, x = cell - 5 * y;
         uint32_t bv[4];
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             const int tap = 4 * g + jj, dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
             const bool on = r < ROWS && tap < 9 && y + dy >= 0 && y + dy < 5 && x + dx >= 0 && x + dx < 5;
-            const float2 v = *(const float2*)(IN + (on ? r + dy * 5 + dx : 0) * CS);
+            const float2 v = *(const float2*)(IN + (on ? r + c5_step<NS, CM>(dy * 5 + dx) : 0) * CS);
             bv[jj] = on ? __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{v.x, v.y}, f16x2_t)) : 0u;
         }
         const f16x8 bh = __builtin_bit_cast(f16x8, make_uint4(bv[0], bv[1], bv[2], bv[3]));
@@ -203,7 +263,7 @@ __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag
 // The two 1x1-convolution heads of the SimpleHead pair (policy: 64 -> 2 channels, value: 64 -> 1; + folded BN + ReLU) on the trunk's
 // f16 x 2 planes: one MFMA column tile (channels 0, 1 = policy, 2 = value, the rest zero), weights split on the fly from the f32
 // matrices Wp [64][2] / Wv [64][1]; wave w owns row tile w (wave 0 the 13th as well).  HP [NS][2 * 25] (channel-major), HV [NS][25].
-template <int NS>
+template <int NS, bool CM = false>
 __device__ __forceinline__ void heads1x1_h2(const float* __restrict__ Wp, const float* __restrict__ bp, const float* __restrict__ Wv,
                                             const float* __restrict__ bv, const uint8_t* IN, float* HP, float* HV) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, PB = (ROWS + 1) * 128;
@@ -232,7 +292,7 @@ __device__ __forceinline__ void heads1x1_h2(const float* __restrict__ Wp, const 
         }
         if (g == 0 && r < ROWS) {                           // lanes of g = 0 hold output channels 0..3 of row r
             const float ds = 1.f / (WS * H2_AS);
-            const int smp = r / 25, cell = r - 25 * smp;
+            const int smp = c5_sample<NS, CM>(r), cell = c5_cell<NS, CM>(r);
             HP[smp * 50 + cell] = fmaxf(acc[0] * ds + b0, 0.f);
             HP[smp * 50 + 25 + cell] = fmaxf(acc[1] * ds + b1, 0.f);
             HV[smp * 25 + cell] = fmaxf(acc[2] * ds + b2, 0.f);
@@ -253,7 +313,7 @@ struct SplitFrag { uint4 h, m, l; };                        // operand fragments
 // NPL = 3: bf16 x 3 (hi + mid + lo, six MFMAs per product).  NPL = 2: f16 x 2 (hi + lo: 22 significant bits, three
 // v_mfma_f32_16x16x32_f16 per product -- lo*hi, hi*lo, hi*hi; nn_v80_h2.hip.h): two planes per tile, the activation planes hold
 // 64 * x, the weight fragments W * 2^k, `descale` = 2^-k / 64 brings the accumulator back
-template <int NS, int NPL = 3, bool PRELOADED = false>
+template <int NS, int NPL = 3, bool PRELOADED = false, bool CM = false>
 __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, const float* __restrict__ bias, const uint8_t* IN,
                                               uint8_t* OUT, const uint8_t* RES, float descale = 1.f,
                                               const uint4* __restrict__ WNEXT = nullptr, uint4 (*wio)[6][3] = nullptr) {
@@ -262,30 +322,26 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
     C5_PH(24);
+    static_assert(!CM || NS == 8, "cell-major tiles: two cells of eight samples per 16-row tile");
     int row[MAXT];
     uint32_t tapmask[MAXT];
+    int r16v = r16;
+    if (CM) asm volatile("" : "+v"(r16v));      // opaque per call: with every step a compile-time constant the ~90 operand addresses of a
+                                                // convolution are loop-invariant in the caller's block loop, and hoisted out of it they
+                                                // cost 118 spilled registers
 #pragma unroll
     for (int i = 0; i < MAXT; i++) {
-        const int rt = rg + RG * i, r = rt * 16 + r16;
+        const int rt = c5_tile_of<CM>(rg, i), r = rt * 16 + r16v;
         row[i] = r;
-        uint32_t m = 0;
-        if (rt < RT && r < ROWS) {
-            const int cell = r % 25, y = cell / 5, x = cell - 5 * y;
-#pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                if (yy >= 0 && yy < 5 && xx >= 0 && xx < 5) m |= 1u << t;
-            }
-        }
-        tapmask[i] = m;
+        tapmask[i] = (rt < RT && r < ROWS) ? c5_cell_taps(c5_cell<NS, CM>(r)) : 0u;
     }
     f32x4 acc[MAXT];
 #pragma unroll
     for (int i = 0; i < MAXT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool last_slot = rg == 0;                         // wave-uniform: this wave has a tile in slot MAXT - 1
+    const bool last_slot = rg == c5_last_group<CM>();       // wave-uniform: this wave has a tile in slot MAXT - 1
     auto load = [&](int i, int t, int c) {
         const bool on = (tapmask[i] >> t) & 1u;
-        const int r = on ? row[i] + (t / 3 - 1) * 5 + (t % 3 - 1) : ROWS;          // off the board: the zero row
+        const int r = on ? row[i] + c5_step<NS, CM>((t / 3 - 1) * 5 + (t % 3 - 1)) : ROWS;          // off the board: the zero row
         const uint8_t* src = IN + pl_off(r, 4 * c + g);
         return SplitFrag{*(const uint4*)src, *(const uint4*)(src + PB), NPL == 3 ? *(const uint4*)(src + 2 * PB) : make_uint4(0u, 0u, 0u, 0u)};
     };
@@ -328,12 +384,18 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
         // ds_read pair -> s_waitcnt -> three MFMAs per step otherwise, i.e. every step waits out an LDS round trip), across the
         // kernel rows as well; a step = (fragment k6 = s / NT: tap ky * 3 + k6 / 2, K chunk k6 & 1; tile s % NT).  The waves with
         // the odd 13th row tile run the NT = MAXT instance, the others NT = MAXT - 1 (wave-uniform branch)
-        auto run = [&](auto nt_tag) {
-            constexpr int NT = decltype(nt_tag)::value, S = 6 * NT;
-            auto ld = [&](int ky, int sidx) {
-                const int k6 = sidx / NT, i = sidx % NT, kx = k6 >> 1, c = k6 & 1;
+        // CM (cell-major tiles): the steps whose tap leaves the board for both cells of the tile are dropped AT COMPILE TIME -- the row
+        // group rg of the wave is a template argument of the loop body (three instances), every kernel row is unrolled, and the list of
+        // the remaining steps (C5Steps) drives the same software pipeline; the code stays straight-line (a first version skipped the
+        // steps with wave-uniform branches: the branches broke the pipelining, 226 -> 265 us per 4096 leaves).
+        auto run = [&](auto nt_tag, auto rg_tag) {
+            constexpr int NT = decltype(nt_tag)::value, RGV = decltype(rg_tag)::value;
+            using SL = C5StepList<NT, RGV, CM>;
+            constexpr int NSTEP = SL::value.n;
+            auto ld = [&](int ky, int k6, int i) {
+                const int kx = k6 >> 1, c = k6 & 1;
                 const bool on = (tapmask[i] >> (ky * 3 + kx)) & 1u;
-                const int r = on ? row[i] + (ky - 1) * 5 + (kx - 1) : ROWS;
+                const int r = on ? row[i] + c5_step<NS, CM>((ky - 1) * 5 + (kx - 1)) : ROWS;
                 const uint8_t* src = IN + pl_off(r, 4 * c + g);
                 return SplitFrag{*(const uint4*)src, *(const uint4*)(src + PB), make_uint4(0u, 0u, 0u, 0u)};
             };
@@ -341,29 +403,27 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 #define AZG_C5_AHEAD 1
 #endif
             constexpr int AH = AZG_C5_AHEAD;
-            SplitFrag f[AH];
-#pragma unroll
-            for (int k = 0; k < AH; k++) f[k] = ld(0, k);
-#pragma unroll 1
-            for (int ky = 0; ky < 3; ky++) {
-                const uint4* __restrict__ Wn = ky < 2 ? Wfrag : (WNEXT ? WNEXT : Wfrag);
-                const int kyn = ky < 2 ? ky + 1 : 0;
-                const int kyl = ky < 2 ? ky + 1 : 2;            // (the look-ahead reads past the last row are not used)
-#pragma unroll
-                for (int sidx = 0; sidx < S; sidx++) {
-                    const int k6 = sidx / NT, i = sidx % NT;
-                    const SplitFrag fn = sidx + AH < S ? ld(ky, sidx + AH) : ld(kyl, sidx + AH - S);
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[i] = h2_mma(w[k6][0], w[k6][1], f[0].h, f[0].m, acc[i]);
-                    if (i == NT - 1) { w[k6][0] = wfrag(Wn, kyn, k6, 0); w[k6][1] = wfrag(Wn, kyn, k6, 1); }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int k = 0; k + 1 < AH; k++) f[k] = f[k + 1];
-                    f[AH - 1] = fn;
+            static_assert(AH == 1, "the compile-time step loop carries one look-ahead operand");
+            SplitFrag f0 = ld(SL::value.ky[0], SL::value.k6[0], SL::value.ti[0]);
+            c5_static_for<0, NSTEP>([&](auto I) {
+                constexpr int sidx = decltype(I)::value;
+                constexpr int ky = SL::value.ky[sidx], k6 = SL::value.k6[sidx], i = SL::value.ti[sidx];
+                SplitFrag fn = f0;
+                if constexpr (sidx + 1 < NSTEP) fn = ld(SL::value.ky[sidx + 1], SL::value.k6[sidx + 1], SL::value.ti[sidx + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i] = h2_mma(w[k6][0], w[k6][1], f0.h, f0.m, acc[i]);
+                if constexpr (SL::value.last[sidx]) {          // the fragment's last step of this kernel row: refill with the next row's
+                    const uint4* __restrict__ Wn = ky < 2 ? Wfrag : (WNEXT ? WNEXT : Wfrag);
+                    constexpr int kyn = ky < 2 ? ky + 1 : 0;
+                    w[k6][0] = wfrag(Wn, kyn, k6, 0); w[k6][1] = wfrag(Wn, kyn, k6, 1);
                 }
-            }
+                __builtin_amdgcn_sched_barrier(0);
+                f0 = fn;
+            });
         };
-        if (last_slot) run(std::integral_constant<int, MAXT>{}); else run(std::integral_constant<int, MAXT - 1>{});
+        if (rg == 0) run(std::integral_constant<int, CM ? MAXT - 1 : MAXT>{}, std::integral_constant<int, 0>{});
+        else if (rg == 1) run(std::integral_constant<int, MAXT - 1>{}, std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, CM ? MAXT : MAXT - 1>{}, std::integral_constant<int, 2>{});
     } else
 #pragma unroll 1
     for (int ky = 0; ky < 3; ky++) {
@@ -400,7 +460,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
     const float4 b = *(const float4*)(bias + ct * 16 + 4 * g);
 #pragma unroll
     for (int i = 0; i < MAXT; i++) {
-        if (rg + RG * i >= RT || row[i] >= ROWS) continue;
+        if (c5_tile_of<CM>(rg, i) >= RT || row[i] >= ROWS) continue;
         if (NPL == 2) {
             f32x4 o = acc[i] * descale + f32x4{b.x, b.y, b.z, b.w};
             if (RES) o += h2_load4(RES, PB, 128, row[i], ct * 16 + 4 * g);
@@ -481,9 +541,10 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     // ---- board int8 [s][y][x][3] -> Y[s*25 + cell][plane 0..1], channels 2..15 zero (the first conv reads 16) ----
     for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(Y + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    constexpr bool CM = NPL == 2 && SPLIT == 2;                // cell-major tiles (row = cell * NS + sample) in the f16 x 2 kernel
     for (int i = tid; i < nb * 25 * 2; i += 768) {
-        const int r = i >> 1, pl = i & 1;
-        Y[r * CS + pl] = (float)boards[(size_t)b0 * 75 + r * 3 + pl];
+        const int sc = i >> 1, pl = i & 1, smp = sc / 25, cell = sc - 25 * smp;        // (sample, cell) of the board byte
+        Y[(CM ? cell * NS + smp : sc) * CS + pl] = (float)boards[(size_t)b0 * 75 + sc * 3 + pl];
     }
     __syncthreads();
     C5_PH(1);
@@ -497,7 +558,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
             // requested behind the first convolution's own weights, landing during its tile loop: the first kernel row of the trunk's
             // weights, and the matrices of the heads and FCs (39 KB, kept in LDS behind the tiles: the phases at the end of the kernel
             // then never wait for a first touch of global memory)
-            conv3x3_first_h2<NS, true>(N.W0, N.b0, Y, XP, [&]() {
+            auto pf_lambda = [&]() {
                 const int ct = wave & 3;
 #pragma unroll
                 for (int c6 = 0; c6 < 6; c6++) {
@@ -517,7 +578,8 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
                 };
                 dma(N.Wfp, 0, WST_FP * 4); dma(N.Wf1, WST_FP, (WST_F1 - WST_FP) * 4); dma(N.Wp, WST_F1, (WST_P - WST_F1) * 4);
                 dma(N.Wv, WST_P, (WST_N - WST_P) * 4);
-            });
+            };
+            conv3x3_first_h2<NS, true, decltype(pf_lambda), CM>(N.W0, N.b0, Y, XP, pf_lambda);
         } else conv3x3_first_split<NS, true, NPL>(N.W0, N.b0, Y, XP);   // (Y still holds the f32 board staging tile)
         __syncthreads();
         C5_PH(2);
@@ -526,9 +588,9 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         for (int blk = 0; blk < NB; blk++) {
             const uint4* W1 = (const uint4*)N.Wc + (size_t)(2 * blk) * CONV_U4;
             if (NPL == 2) {
-                conv3x3_split<NS, NPL, true>(W1, N.bc + (2 * blk) * 64, XP, YP, nullptr, descale, W1 + CONV_U4, &wreg);
+                conv3x3_split<NS, NPL, true, CM>(W1, N.bc + (2 * blk) * 64, XP, YP, nullptr, descale, W1 + CONV_U4, &wreg);
                 __syncthreads();
-                conv3x3_split<NS, NPL, true>(W1 + CONV_U4, N.bc + (2 * blk + 1) * 64, YP, XP, XP, descale,
+                conv3x3_split<NS, NPL, true, CM>(W1 + CONV_U4, N.bc + (2 * blk + 1) * 64, YP, XP, XP, descale,
                                              blk + 1 < NB ? W1 + 2 * CONV_U4 : nullptr, &wreg);
                 __syncthreads();
                 C5_PH(3 + blk);
@@ -545,7 +607,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
             C5_PH(20);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the LDS copies of the head / FC matrices (DMA issued at the start)
             __syncthreads();
-            heads1x1_h2<NS>(WST + WST_F1, N.bp, WST + WST_P, N.bv, XP, Y, Y + NS * CP2 * 25);
+            heads1x1_h2<NS, CM>(WST + WST_F1, N.bp, WST + WST_P, N.bv, XP, Y, Y + NS * CP2 * 25);
             __syncthreads();
             heads_done = true;
         } else {
