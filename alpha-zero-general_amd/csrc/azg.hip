@@ -303,7 +303,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
                             : (D.cls_q == f->A ? (size_t)D.cap * RecGeom(D.cls_q, D.U).total(f->A) + 4096
-                                               : rec_bytes_hint ? (size_t)D.cap * (size_t)rec_bytes_hint
+                                               : (rec_bytes_hint && D.cap >= 8192) ? (size_t)D.cap * (size_t)rec_bytes_hint   // (an average: large arenas only)
                                                : (size_t)D.cap * RecGeom(D.cls_q, D.U).total(nv_hint ? nv_hint : (f->A <= 256 ? 64 : 160)) * 5 / 4) + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     if (heap_bytes / 16 > (size_t)AZG_CHILD_IDX_MASK) { delete f; return fail("record heap per tree exceeds the 29-bit record offset (8 GiB)"); }

@@ -105,15 +105,22 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #undef AZG_OP_ADD
     return readlane_u64(v, 0) + readlane_u64(v, 16) + readlane_u64(v, 32) + readlane_u64(v, 48);
 }
-// maximum of an f64 over the wave (no NaNs expected; -inf for idle lanes), wave-uniform result
+// maximum of an f64 over the wave (no NaNs: -inf for idle lanes), wave-uniform result.  One v_max_f64 per combine, written as asm:
+// fmax() lowers to llvm.maxnum, which quiets a possible signalling NaN in EACH operand first -- two extra v_max_f64 x, x per step, 45
+// instructions per reduction instead of 23 -- and the inputs here are PUCT scores and -inf.
+__device__ __forceinline__ double max_f64_nonan(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ double wave_max_f64(double x) {
     uint64_t v = (uint64_t)__double_as_longlong(x);
-#define AZG_OP_FMAX(a, b) ((uint64_t)__double_as_longlong(fmax(__longlong_as_double((long long)(a)), __longlong_as_double((long long)(b)))))
+#define AZG_OP_FMAX(a, b) ((uint64_t)__double_as_longlong(max_f64_nonan(__longlong_as_double((long long)(a)), __longlong_as_double((long long)(b)))))
     AZG_DPP_REDUCE_U64(v, AZG_OP_FMAX);
 #undef AZG_OP_FMAX
     const double a = __longlong_as_double((long long)readlane_u64(v, 0)), b = __longlong_as_double((long long)readlane_u64(v, 16));
     const double c = __longlong_as_double((long long)readlane_u64(v, 32)), d = __longlong_as_double((long long)readlane_u64(v, 48));
-    return fmax(fmax(a, b), fmax(c, d));
+    return max_f64_nonan(max_f64_nonan(a, b), max_f64_nonan(c, d));
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll

@@ -329,6 +329,11 @@ template <class G>
 struct Forest {
     static constexpr int S = G::S, SP = G::SP, A = G::A, P = G::P, AW = G::AW;
     static constexpr int SPW = SP / 4;
+    // record size classes are a property of the game (the host sets ForestDev::cls_q by the same rule, azg.hip): entries per page = A for a
+    // small action space (one class, one page), 32 otherwise.  As a compile-time constant every j / PC, j % PC of the record geometry is a
+    // shift or a multiply-shift instead of a dozen instructions of integer-division emulation (expansion: per valid entry; backup: per level).
+    static constexpr int CLS_Q = A <= 96 ? A : AZG_CLS_Q_MULTI;
+    static constexpr bool ONE_CLASS = CLS_Q == A;
 
     struct Smem {
         __attribute__((aligned(16))) int8_t st[SP];
@@ -424,7 +429,7 @@ struct Forest {
     __device__ static __forceinline__ LeafPf leaf_pf_begin(const ForestDev& F, int t, const HS& H) {
         LeafPf pf;
         pf.id_v = H.n_free_ids > 0 ? (F.free_ids + (size_t)t * F.s_free)[H.n_free_ids - 1] : 0u;
-        pf.lists = F.cls_q != A && n_classes(F) <= 64;
+        pf.lists = !ONE_CLASS && n_classes(F) <= 64;
         pf.head_v = (pf.lists && lane_id() < n_classes(F)) ? rec_free(F, t)[lane_id()] : AZG_NONE;
         pf.next_v = AZG_NONE;
         return pf;
@@ -456,12 +461,12 @@ struct Forest {
     }
 
     // ---- record size classes ----
-    __device__ static __forceinline__ int cls_of(const ForestDev& F, int nv) { return nv == 0 ? 0 : 1 + (nv - 1) / F.cls_q; }
-    __device__ static __forceinline__ RecGeom geom(const ForestDev& F) { return RecGeom(F.cls_q, F.U); }
+    __device__ static __forceinline__ int cls_of(const ForestDev& F, int nv) { (void)F; return nv == 0 ? 0 : 1 + (nv - 1) / CLS_Q; }
+    __device__ static __forceinline__ RecGeom geom(const ForestDev& F) { return RecGeom(CLS_Q, F.U); }
     __device__ static __forceinline__ uint32_t cls_units(const ForestDev& F, int c) {      // class c = c pages
         return (AZG_REC_HDR + (uint32_t)c * geom(F).PAGE) / 16u;
     }
-    __device__ static __forceinline__ int n_classes(const ForestDev& F) { return 2 + (A - 1) / F.cls_q; }
+    __device__ static __forceinline__ int n_classes(const ForestDev& F) { (void)F; return 2 + (A - 1) / CLS_Q; }
 
     // Record for a node with nv valid actions.  Records never move; a dropped node's record sits on the free list of its
     // size class.  The wave reads the heads of classes c .. c+63 in one request and takes the first non-empty one (closest
@@ -470,7 +475,7 @@ struct Forest {
     template <class HS>
     __device__ static __forceinline__ uint32_t alloc_record(const ForestDev& F, int t, HS& H, int nv, uint32_t node_id,
                                                             int* cls_out, const LeafPf* pf = nullptr) {
-        if (F.cls_q == A) {
+        if (ONE_CLASS) {
             // one class for every expanded node: the record slot IS the node id (no list, no load); heap = cap slots
             *cls_out = cls_of(F, nv);
             return node_id * cls_units(F, 1);

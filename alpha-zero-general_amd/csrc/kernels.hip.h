@@ -614,7 +614,7 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
     // this lane's byte offsets inside a record (entry l of the first 64): constant over the launch.  One-class forests have a single
     // page of A entries, the others pages of AZG_CLS_Q_MULTI = 32 entries (forest.hip.h RecGeom)
     const RecGeom RG = FR::geom(F);
-    const bool one_page = F.cls_q == G::A;
+    constexpr bool one_page = FR::ONE_CLASS;
     auto hot_off = [&](uint32_t j) { return one_page ? AZG_REC_HDR + j * 16u : AZG_REC_HDR + (j >> 5) * RG.PAGE + (j & 31u) * 16u; };
     auto child_off = [&](uint32_t j, uint32_t u) {
         return one_page ? AZG_REC_HDR + RG.PC * (16u + 4u * u) + j * 4u : AZG_REC_HDR + (j >> 5) * RG.PAGE + 32u * (16u + 4u * u) + (j & 31u) * 4u;
@@ -627,7 +627,7 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
     // F.spec_state: 0 = never, 1 = at every level, N >= 2 = only at nodes reached over an edge with fewer than N visits (a node
     // with few visits is where the descent meets the frontier; the much-visited top of the tree almost never is, and its 3 x 128-B
     // state lines per level were a quarter of the kernel's fetches)
-    const bool spec_state = F.spec_state && F.cls_q == G::A && FR::SPW <= 192;
+    const bool spec_state = F.spec_state && FR::ONE_CLASS && FR::SPW <= 192;
     const uint32_t spec_below = F.spec_state >= 2 ? (uint32_t)F.spec_state : 0xFFFFFFFFu;
     const float inv_units1 = 1.0f / (float)FR::cls_units(F, 1);
     bool need_nn = false;

@@ -54,14 +54,14 @@ __device__ __forceinline__ void gc_scan(const ForestDev& F, int t, TreeHdr& H, i
         const bool dead = in_use && (int)nh.round < min_round && i != H.root;
         const bool alive = in_use && !dead;
         if (dead) {
-            if (F.cls_q != G::A) {                                                       // (one-class forests: slot == node id)
+            if (!FR::ONE_CLASS) {                                                       // (one-class forests: slot == node id)
                 const uint32_t old = atomicExch(&lds_head[nh.nv], nh.rec_off);           // LDS: lanes of one size chain up
                 *(uint32_t*)(hp + (size_t)nh.rec_off * 16u) = old;
             }
             FR::nhdr(F, t, i)->flags = NF_FREE;
         }
         const uint64_t bd = __ballot(dead), ba = __ballot(alive);
-        const int units = F.cls_q != G::A ? wave_sum_i32(dead ? (int)FR::cls_units(F, nh.nv) : 0) : 0;
+        const int units = !FR::ONE_CLASS ? wave_sum_i32(dead ? (int)FR::cls_units(F, nh.nv) : 0) : 0;
         uint32_t pos = 0;
         if (l == 0) {
             if (bd) { pos = atomicAdd(&lds_ctr[0], (uint32_t)__popcll(bd)); atomicAdd(&lds_ctr[2], (uint32_t)units); }
@@ -164,7 +164,7 @@ __device__ __forceinline__ bool arena_is_short(const ForestDev& F, const TreeHdr
     if ((H.id_top - H.n_free_ids) + need_nodes > (uint32_t)F.cap) return true;
     // high-water mark (cfg.gc_high_water_pct): clean up early enough that the arena never fills beyond it + one search
     if (F.gc_high_water && (H.id_top - H.n_free_ids) > F.gc_high_water) return true;
-    return F.cls_q != G::A && (F.heap_units - H.heap_top) + H.free_units < need_units;   // one-class forests: slot == node id
+    return !FR::ONE_CLASS && (F.heap_units - H.heap_top) + H.free_units < need_units;   // one-class forests: slot == node id
 }
 
 // locate the new root (canonical state in sm.st) so that the clean-up keeps it
