@@ -12,14 +12,15 @@ Whole-game sweep at 4096 x 800 sims (env-steps/s), round 1: budget 0 -> 21.3 k, 
 advance every 4 / 8 / 16 / 32 rounds -> 32.5 / 33.8 / 34.4 / 34.7 k.  Round 3 (tools/sweep_budget_games.sh): Splendor 10 / 48 -> 68.1 k
 against 63.0 k for 20 / 16; Azul and Santorini keep 20 / 16 -- the defaults below are per game family.
 
-PIPELINES (round 4).  Both kernels of a round are latency chains -- a select launch lasts as long as the slowest of its trees
-(median wave 20 us, last wave 33 us at 4096 trees), a net launch as long as one workgroup's 16 leaves -- and neither can share a CU
-with the other (a net workgroup takes 504 of a SIMD's 512 VGPRs and 156 of the CU's 160 KB of LDS).  So the games are split into
-`groups` independent forests, each with its own stream, its own leaf / pi / v buffers and its own captured graph of K fused rounds,
-and each stream's hardware queue is masked to the CUs of ONE XCD (azg_stream_create_xcd; 8 groups = 8 XCDs x 32 CUs = 512 trees =
-16 per CU, the same per-CU load as one big launch).  Nothing synchronises the groups: a group's launch boundary waits for the
-slowest of ITS trees only, the groups drift out of phase so that the memory system sees descents and net forwards mixed instead of
-4096 descents at once, and a group's leaf batch, pi / v and net weights stay in its XCD's L2.  Per-tree results do not depend on
+GROUPS (round 4, measured, NOT the default).  Both kernels of a round are latency chains -- a select launch lasts as long as the
+slowest of its trees (median wave 20 us, last wave 33 us at 4096 trees), a net launch as long as one workgroup's 16 leaves -- and
+neither can share a CU with the other (a net workgroup takes 504 of a SIMD's 512 VGPRs and 156 of the CU's 160 KB of LDS).  `groups`
+> 1 splits the games into independent forests, each with its own stream, leaf / pi / v buffers and captured graph of K fused rounds;
+nothing synchronises the groups.  The streams ask for a CU mask of one XCD each (azg_stream_create_xcd) -- but on this MI355X (one
+partition over 8 XCDs) the hardware deals a queue's workgroups round-robin over ALL XCDs and the mask is not honoured
+(tools/dbg_placement.py: every masked stream ran on the 256 CUs of all 8 XCDs), so the groups share every CU: a net workgroup then
+waits for a whole CU to drain while the other groups' descents keep landing on it.  Driver flags, one MI355X: 1 group 72.6 k
+env-steps/s, 2 groups 72.3 k, 4 groups 40.5 k, 8 groups 27.4 k (profiles/r04_round_structure.md).  Per-tree results do not depend on
 the grouping (global game streams stream0 + index; tested)."""
 import ctypes as C
 

@@ -195,9 +195,11 @@ int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8_t* states,
    depends on the pattern, not on what ran before) */
 int azg_debug_poison_onchip(uint32_t pattern, void* stream);
 /* XCD-pinned streams (no reference counterpart: the reference time-slices N game threads on one core, Coach.py:117-144; here groups
-   of games run as independent select -> predict pipelines, one per XCD, selfplay.py): a HIP stream whose queue may only use the CUs of
-   XCDs [xcd_first, xcd_first + xcd_count) of the current device (hipExtStreamCreateWithCUMask).  Pass the handle as `stream` to
-   any call of this header. */
+   of games can run as independent select -> predict pipelines, selfplay.py): a HIP stream whose queue ASKS for the CUs of XCDs
+   [xcd_first, xcd_first + xcd_count) of the current device only (hipExtStreamCreateWithCUMask; bit b of the mask = CU b / 8 of XCD
+   b % 8).  Whether the mask is honoured is up to the platform: on the round-4 MI355X box (one partition over 8 XCDs) it was NOT -- the
+   hardware deals a queue's workgroups round-robin over all XCDs; azg_debug_placement shows where a launch really ran.  Pass the
+   handle as `stream` to any call of this header. */
 int azg_stream_create_xcd(int xcd_first, int xcd_count, void** out_stream);
 int azg_stream_destroy(void* stream);
 /* debug / tests: launch n_workgroups one-wave workgroups on `stream`; out_dev[i] = XCC_ID | cu_id << 8 | se_id << 16 | sh_id << 24 of
