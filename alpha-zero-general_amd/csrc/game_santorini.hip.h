@@ -13,6 +13,7 @@ template <int NB>
 struct SantoriniDev {
     static constexpr bool STOCHASTIC = false;   // the env step is a function of (state, action, random_seed): edges are memoised
     static constexpr bool RANDOM_SYM = false;   // get_symmetries draws no randomness
+    static constexpr bool ENDED_FILLS_MASK = true;   // game_ended(st, p, ., mask) leaves valid_mask(st, p) in `mask` when the game goes on
     static constexpr int P = 2;
     static constexpr int ROWS = 25, COLS = 3;
     static constexpr int S = 75;
@@ -107,6 +108,10 @@ struct SantoriniDev {
         const Pos old = worker_of(wk, player, worker);
         const Pos np = dir(old, md);
         const Pos bp = dir(np, bd);
+        if (NB == 1) {          // no gods: power 0 is the only one (the switch below would keep ten gods' rules and registers alive)
+            if (md == NO_MOVE || bd == NO_BUILD) return false;
+            return able_to_move(st, old, np, player, opp_athena, false, false) && able_to_build(st, bp, wid, false, false);
+        }
         switch (god) {
         case NO_GOD: case PAN: case ATHENA: {
             if (power != NO_GOD || md == NO_MOVE || bd == NO_BUILD) return false;
@@ -359,7 +364,6 @@ struct SantoriniDev {
 
     // Board.check_end_game(next_player) :552-565 -- wave-cooperative (needs the valid-move scan)
     __device__ static bool game_ended(const int8_t* st, int next_player, float* out, uint64_t* mask_scratch) {
-        (void)mask_scratch;
         out[0] = out[1] = 0.f;
         const int l = lane_id();
         // get_score(p) == 3 <=> one of p's workers stands on level 3 (levels under a worker are 0..3): one read per cell, two ballots
@@ -370,10 +374,15 @@ struct SantoriniDev {
         const int god = owned_god(st, next_player);
         const bool opp_athena = GP(st, ATHENA + NB * ((next_player + 1) % 2)) > 64;
         const Workers wk = find_workers(st);
+        // "no valid move for next_player" needs the valid-move scan: all AW passes are run and their ballots kept in mask_scratch, so that
+        // the caller that asks for the valid mask of the same (state, player) right afterwards (create_leaf: MCTS.py:131 then :142) finds
+        // it there instead of evaluating every action a second time (ENDED_FILLS_MASK)
         bool any = false;
-        for (int k = 0; k < AW && !any; k++) {
+        for (int k = 0; k < AW; k++) {
             const int a = k * 64 + l;
-            any = __ballot(a < A && valid_action(st, a < A ? a : 0, next_player, god, opp_athena, wk)) != 0ull;
+            const uint64_t m = __ballot(a < A && valid_action(st, a < A ? a : 0, next_player, god, opp_athena, wk));
+            if (mask_scratch && l == 0) mask_scratch[k] = m;
+            any = any || m != 0ull;
         }
         if (!any) {
             if (next_player == 0) { out[0] = -1.f; out[1] = 1.f; }

@@ -1,6 +1,7 @@
 // kernels.hip.h -- __global__ kernels of the engine, templated on the device game (SplendorDev<n>, SantoriniDev<g>).
 // One workgroup = one wavefront (64 threads) = one state (env kernels) or one tree (forest kernels).
 #pragma once
+#include <type_traits>
 #include "forest.hip.h"
 
 namespace azg {
@@ -259,6 +260,10 @@ __device__ __forceinline__ double ucb_score(float p, uint32_t n, double q, doubl
     return fpu_init + cpuct * (double)p * sqrtNsEps;
 }
 
+// games whose terminal test has to scan the valid moves anyway leave the mask behind (G::ENDED_FILLS_MASK)
+template <class G, class = void> struct EndedFillsMask { static constexpr bool value = false; };
+template <class G> struct EndedFillsMask<G, std::void_t<decltype(G::ENDED_FILLS_MASK)>> { static constexpr bool value = G::ENDED_FILLS_MASK; };
+
 // Frontier edge / new root: the state of a node that is not in the tree yet is in sm.st.  Creates the node and its record,
 // runs the terminal test and the valid-move scan (MCTS.py:127-142).  Returns the record offset (AZG_NONE on overflow);
 // *terminal tells whether the new node ended the game (then es[] holds Es).  For a non-terminal leaf the canonical state and
@@ -274,7 +279,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
     const bool ended = G::game_ended(sm.st, 0, es, sm.mask);                                     // MCTS.py:131
     int nv = 0;
     if (!ended) {
-        G::valid_mask(sm.st, 0, sm.mask);                                                        // MCTS.py:142
+        if (!EndedFillsMask<G>::value) G::valid_mask(sm.st, 0, sm.mask);                         // MCTS.py:142
         wave_sync();
 #pragma unroll
         for (int k = 0; k < G::AW; k++) nv += __popcll(sm.mask[k]);
