@@ -284,7 +284,8 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     int game = f->cfg.game, variant = f->cfg.variant;
     int nv_hint = 0;                     // typical valid actions per expanded node (sizes the record heap of large action spaces)
     int rec_bytes_hint = 0;              // average record bytes per node (overrides the nv_hint sizing)
-    AZG_DISPATCH(game, variant, { f->S = G::S; f->SP = G::SP; f->A = G::A; f->P = G::P; nv_hint = RecNvHint<G>::value; rec_bytes_hint = RecBytesHint<G>::value; });
+    int seed_actions = 1 << 30;          // RecGeom SE: leading action ids whose env step can read random_seed (forest.hip.h SeedActions)
+    AZG_DISPATCH(game, variant, { f->S = G::S; f->SP = G::SP; f->A = G::A; f->P = G::P; nv_hint = RecNvHint<G>::value; rec_bytes_hint = RecBytesHint<G>::value; seed_actions = SeedActions<G>::value; });
     if (cfg->n_trees <= 0 || cfg->node_capacity < 16) { delete f; return fail("bad n_trees / node_capacity"); }
     if (cfg->node_capacity > (1 << AZG_IDX_BITS) - 2) { delete f; return fail("node_capacity too large"); }
     if (cfg->universes < 0 || cfg->universes > AZG_MAX_UNIVERSES) { delete f; return fail("universes out of range"); }
@@ -300,11 +301,14 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     // expanded nodes -- the heap is sized for cap records of the maximum size (+ cap entry-less records) and can never
     // fragment; larger action spaces use classes of 32 entries and a heap sized for the typical record
     D.cls_q = f->A <= 96 ? f->A : AZG_CLS_Q_MULTI;
+    D.seed_entries = seed_actions < D.cls_q ? seed_actions : D.cls_q;
+    D.id_bytes = f->A <= 256 ? 1 : 2;
+    const RecGeom RG0(D.cls_q, D.U, D.seed_entries, D.id_bytes);
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
-                            : (D.cls_q == f->A ? (size_t)D.cap * RecGeom(D.cls_q, D.U).total(f->A) + 4096
+                            : (D.cls_q == f->A ? (size_t)D.cap * RG0.total(f->A) + 4096
                                                : (rec_bytes_hint && D.cap >= 8192) ? (size_t)D.cap * (size_t)rec_bytes_hint   // (an average: large arenas only)
-                                               : (size_t)D.cap * RecGeom(D.cls_q, D.U).total(nv_hint ? nv_hint : (f->A <= 256 ? 64 : 160)) * 5 / 4) + 8192;
+                                               : (size_t)D.cap * RG0.total(nv_hint ? nv_hint : (f->A <= 256 ? 64 : 160)) * 5 / 4) + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     if (heap_bytes / 16 > (size_t)AZG_CHILD_IDX_MASK) { delete f; return fail("record heap per tree exceeds the 29-bit record offset (8 GiB)"); }
     D.heap_units = (uint32_t)(heap_bytes / 16);
@@ -506,7 +510,7 @@ extern "C" int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8
     if (n > max_nodes) return n;
     std::vector<NodeHdr> nh(top);
     std::vector<int8_t> st((size_t)top * f->SP);
-    const RecGeom RG(D.cls_q, D.U);
+    const RecGeom RG(D.cls_q, D.U, D.seed_entries, D.id_bytes);
     const size_t heap_used = D.cls_q == f->A ? (size_t)top * (RG.total(f->A) / 16u) : (size_t)H.heap_top;
     std::vector<uint8_t> hp(heap_used * 16);
     if (top) {
@@ -560,7 +564,7 @@ extern "C" int azg_forest_validate(azg_forest* f, int verbose) {
         if (top > (uint32_t)D.cap || n > top || H.heap_top > D.heap_units) { VBAD("[validate] t=%d n=%u id_top=%u heap_top=%u\n", t, n, top, H.heap_top); continue; }
         if (H.root != AZG_NONE && H.root >= top) VBAD("[validate] t=%d root=%u id_top=%u\n", t, H.root, top);
         HIPCHK(hipMemcpy(nh.data(), D.node_hdr + (size_t)t * D.s_nhdr, sizeof(NodeHdr) * top, hipMemcpyDeviceToHost));
-        const RecGeom RG(D.cls_q, D.U);
+        const RecGeom RG(D.cls_q, D.U, D.seed_entries, D.id_bytes);
         const uint32_t heap_used = D.cls_q == f->A ? (uint32_t)(top * (RG.total(f->A) / 16u)) : H.heap_top;
         HIPCHK(hipMemcpy(hp.data(), D.heap + (size_t)t * D.s_heap, (size_t)heap_used * 16, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(tab.data(), D.htab + (size_t)t * D.s_htab, sizeof(uint32_t) * D.HT, hipMemcpyDeviceToHost));

@@ -29,6 +29,7 @@
 // Numerics follow the shipped (Numba-typed) reference: UCB in f64 with f32 operands widened (MCTS.py:210-230),
 // Qsa running mean in f64, Qs in f32 scalar arithmetic (MCTS.py:178-181), no FMA contraction (-ffp-contract=off).
 #pragma once
+#include <type_traits>
 #include "azg_common.hip.h"
 
 namespace azg {
@@ -116,6 +117,7 @@ struct ForestDev {
     size_t s_nhdr, s_htab;             // elements (NodeHdr, u32)
     size_t s_free, s_recfree;          // elements (u32): free-id stack [cap], record free-list heads [A + 1]
     int universes, numMCTSSims, ratio_fullMCTS, forced_playouts;
+    int seed_entries, id_bytes;        // record geometry (RecGeom SE, IDB): set by the host from the game's traits, like cls_q
     int cls_q;                         // record size classes: class 0 = no entries (terminal nodes), class c >= 1 = room for
                                        // min(A, c * cls_q) entries; cls_q == A (small action spaces) makes every expanded
                                        // node's record the same size, so a freed record fits any later node
@@ -185,29 +187,45 @@ static __device__ __constant__ long long AZG_MAGIC_SEEDS[8] = {31416, 1, 14142, 
 
 __host__ __device__ __forceinline__ uint32_t align16u(uint32_t x) { return (x + 15u) & ~15u; }
 
-// record geometry: RecHdr | page[pages(nv)], page = hot[PC] (16 B: P f32, N u32, Q f64) | child[U][PC] (u32) | id[PC] (u16),
-// PC = cls_q entries per page (one-class forests: PC = A, a single page)
+// record geometry: RecHdr | page[pages(nv)], page = hot[PC] (16 B: P f32, N u32, Q f64) | child0[PC] (u32) | childX[U - 1][SE] (u32) | id[PC]
+// (IDB bytes each), PC = cls_q entries per page (one-class forests: PC = A, a single page).
+// Child slots: universe 0's for every entry, the other universes' only for the first SE entries of a page (round 4).  An entry needs one
+// slot per universe only if its env step can read random_seed; a game whose seed-dependent actions have the LOWEST action ids (Splendor:
+// the 27 buy / reserve actions that draw a replacement card, of 81) names their count as SEED_ACTIONS -- entries are valid-action-compacted
+// in ascending id order, so such an entry always sits at an index below that count.  Entries at or beyond SE use slot 0 in every universe.
+// IDB: one byte per action id when A <= 256.  Splendor record: 2464 -> 1952 B.
 #define AZG_REC_HDR 32u
 #define AZG_CLS_Q_MULTI 32      /* entries per page / size class of multi-class forests (one-class forests: A) */
 #define AZG_H_P 0u
 #define AZG_H_N 4u
 #define AZG_H_Q 8u
 struct RecGeom {
-    uint32_t PC, U, PAGE;                 // entries per page, universes, bytes per page
-    __host__ __device__ RecGeom(int pc, int u) : PC((uint32_t)pc), U((uint32_t)u), PAGE(align16u((uint32_t)pc * (18u + 4u * (uint32_t)u))) {}
+    uint32_t PC, U, SE, IDB, PAGE;        // entries per page, universes, entries with per-universe slots, bytes per action id, bytes per page
+    __host__ __device__ RecGeom(int pc, int u, int se, int idb)
+        : PC((uint32_t)pc), U((uint32_t)u), SE((uint32_t)(se < pc ? se : pc)), IDB((uint32_t)idb),
+          PAGE(align16u((uint32_t)pc * (20u + (uint32_t)idb) + ((uint32_t)u - 1u) * (uint32_t)(se < pc ? se : pc) * 4u)) {}
     __host__ __device__ __forceinline__ uint32_t pages(int nv) const { return nv == 0 ? 0u : 1u + ((uint32_t)nv - 1u) / PC; }
     __host__ __device__ __forceinline__ uint32_t total(int nv) const { return AZG_REC_HDR + pages(nv) * PAGE; }      // bytes
     __host__ __device__ __forceinline__ uint32_t page_of(uint32_t j) const { return AZG_REC_HDR + (j / PC) * PAGE; }
     __host__ __device__ __forceinline__ uint32_t hot(uint32_t j) const { return page_of(j) + (j % PC) * 16u; }
-    __host__ __device__ __forceinline__ uint32_t child(uint32_t j, uint32_t u) const { return page_of(j) + PC * (16u + 4u * u) + (j % PC) * 4u; }
-    __host__ __device__ __forceinline__ uint32_t id(uint32_t j) const { return page_of(j) + PC * (16u + 4u * U) + (j % PC) * 2u; }
+    __host__ __device__ __forceinline__ uint32_t child(uint32_t j, uint32_t u) const {
+        const uint32_t jj = j % PC;
+        return (u == 0u || jj >= SE) ? page_of(j) + PC * 16u + jj * 4u : page_of(j) + PC * 20u + ((u - 1u) * SE + jj) * 4u;
+    }
+    __host__ __device__ __forceinline__ uint32_t id(uint32_t j) const { return page_of(j) + PC * 20u + (U - 1u) * SE * 4u + (j % PC) * IDB; }
 };
 // read-only view of a record's action ids (ids[j] = action of valid-action-compacted entry j)
 struct RecIds {
     const uint8_t* rec; RecGeom G;
     __host__ __device__ RecIds(const uint8_t* r, const RecGeom& g) : rec(r), G(g) {}
-    __host__ __device__ __forceinline__ uint16_t operator[](int j) const { return *(const uint16_t*)(rec + G.id((uint32_t)j)); }
+    __host__ __device__ __forceinline__ uint16_t operator[](int j) const {
+        const uint8_t* p = rec + G.id((uint32_t)j);
+        return G.IDB == 1u ? (uint16_t)*p : *(const uint16_t*)p;
+    }
 };
+// per-game layout parameters (device: Forest<G>; host: the same rule in azg.hip)
+template <class G, class = void> struct SeedActions { static constexpr int value = 1 << 30; };
+template <class G> struct SeedActions<G, std::void_t<decltype(G::SEED_ACTIONS)>> { static constexpr int value = G::SEED_ACTIONS; };
 
 // NumPy's pairwise float32 summation order (np.sum called by `normalise`, MCTS.py:250-253) for n <= 128 elements,
 // executed by lanes 0..7 over an LDS array; every lane returns the sum.
@@ -462,7 +480,9 @@ struct Forest {
 
     // ---- record size classes ----
     __device__ static __forceinline__ int cls_of(const ForestDev& F, int nv) { (void)F; return nv == 0 ? 0 : 1 + (nv - 1) / CLS_Q; }
-    __device__ static __forceinline__ RecGeom geom(const ForestDev& F) { return RecGeom(CLS_Q, F.U); }
+    static constexpr int SEED_E = SeedActions<G>::value < CLS_Q ? SeedActions<G>::value : CLS_Q;      // entries of a page with per-universe slots
+    static constexpr int IDB = A <= 256 ? 1 : 2;
+    __device__ static __forceinline__ RecGeom geom(const ForestDev& F) { return RecGeom(CLS_Q, F.U, SEED_E, IDB); }
     __device__ static __forceinline__ uint32_t cls_units(const ForestDev& F, int c) {      // class c = c pages
         return (AZG_REC_HDR + (uint32_t)c * geom(F).PAGE) / 16u;
     }

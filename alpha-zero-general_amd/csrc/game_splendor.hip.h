@@ -345,6 +345,7 @@ struct SplendorDev {
     // true when the env step of `move` may read random_seed: buying / reserving a visible or deck card draws a replacement
     // (_get_deck_card :306-336); buying a reserved card and the gem moves never do
     __device__ static __forceinline__ bool move_uses_seed(int move) { return move < 27; }
+    static constexpr int SEED_ACTIONS = 27;     // == the bound above: only these entries get one child slot per universe (forest.hip.h RecGeom)
 
     // ALL lanes call with wave-uniform arguments; returns the next player; the LDS state is updated and synchronised.
     __device__ static int wave_make_move(int8_t* st, int move, int player, long long seed, Rng& rng) {

@@ -488,8 +488,10 @@ __device__ __forceinline__ bool expand_apply(const ForestDev& F, int t, const Ex
             e0.x = __float_as_uint(dir_now ? in.pv[k] : in.pv[k] / s); e0.y = 0u;                 // P, N = 0
             e0.z = (uint32_t)__double_as_longlong(AZG_NANQ); e0.w = (uint32_t)((uint64_t)__double_as_longlong(AZG_NANQ) >> 32);
             *(uint4*)(rec + RG.hot(j)) = e0;
-            for (int u = 0; u < F.U; u++) *(uint32_t*)(rec + RG.child(j, (uint32_t)u)) = AZG_NONE;
-            *(uint16_t*)(rec + RG.id(j)) = (uint16_t)(l + 64 * k);                                // the entry's action id
+            const int nu = (j % RG.PC) < RG.SE ? F.U : 1;                                         // (entries beyond SE share slot 0)
+            for (int u = 0; u < nu; u++) *(uint32_t*)(rec + RG.child(j, (uint32_t)u)) = AZG_NONE;
+            if (FR::IDB == 1) *(uint8_t*)(rec + RG.id(j)) = (uint8_t)(l + 64 * k);               // the entry's action id
+            else *(uint16_t*)(rec + RG.id(j)) = (uint16_t)(l + 64 * k);
         }
         base_rank += __popcll(m);
     }
@@ -621,14 +623,19 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
     const RecGeom RG = FR::geom(F);
     constexpr bool one_page = FR::ONE_CLASS;
     auto hot_off = [&](uint32_t j) { return one_page ? AZG_REC_HDR + j * 16u : AZG_REC_HDR + (j >> 5) * RG.PAGE + (j & 31u) * 16u; };
-    auto child_off = [&](uint32_t j, uint32_t u) {
-        return one_page ? AZG_REC_HDR + RG.PC * (16u + 4u * u) + j * 4u : AZG_REC_HDR + (j >> 5) * RG.PAGE + 32u * (16u + 4u * u) + (j & 31u) * 4u;
+    auto child_off = [&](uint32_t j, uint32_t u) {                                      // == RG.child(j, u) with the page split spelled out
+        const uint32_t pg = one_page ? AZG_REC_HDR : AZG_REC_HDR + (j >> 5) * RG.PAGE, jj = one_page ? j : (j & 31u);
+        return (u == 0u || jj >= RG.SE) ? pg + RG.PC * 16u + jj * 4u : pg + RG.PC * 20u + ((u - 1u) * RG.SE + jj) * 4u;
     };
     auto id_off = [&](uint32_t j) {
-        return one_page ? AZG_REC_HDR + RG.PC * (16u + 4u * RG.U) + j * 2u : AZG_REC_HDR + (j >> 5) * RG.PAGE + 32u * (16u + 4u * RG.U) + (j & 31u) * 2u;
+        const uint32_t pg = one_page ? AZG_REC_HDR : AZG_REC_HDR + (j >> 5) * RG.PAGE, jj = one_page ? j : (j & 31u);
+        return pg + RG.PC * 20u + (RG.U - 1u) * RG.SE * 4u + jj * RG.IDB;
     };
-    const uint32_t l_hot = hot_off((uint32_t)l), l_child0 = child_off((uint32_t)l, 0u), l_id = id_off((uint32_t)l);
-    const uint32_t child_ustride = (one_page ? RG.PC : 32u) * 4u;
+    const uint32_t l_hot = hot_off((uint32_t)l), l_id = id_off((uint32_t)l);
+    // this lane's child slot of entry l: universe 0's, and -- for the entries that have per-universe slots -- where universe u's is
+    const uint32_t l_child0 = child_off((uint32_t)l, 0u);
+    const bool l_seeded = (one_page ? (uint32_t)l : ((uint32_t)l & 31u)) < RG.SE;
+    const uint32_t l_childx = child_off((uint32_t)l, 1u), childx_ustride = RG.SE * 4u;      // (u >= 1: l_childx + (u - 1) * stride)
     // F.spec_state: 0 = never, 1 = at every level, N >= 2 = only at nodes reached over an edge with fewer than N visits (a node
     // with few visits is where the descent meets the frontier; the much-visited top of the tree almost never is, and its 3 x 128-B
     // state lines per level were a quarter of the kernel's fetches)
@@ -700,8 +707,8 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
             // ---- one level: header + this lane's entry requested together (entry position is independent of nv) ----
             const uint8_t* rp = hp + (size_t)rec * 16u;
             const uint4 hot0 = *(const uint4*)(rp + l_hot);                                     // { P, N, Q } of entry l
-            const uint32_t ch0 = *(const uint32_t*)(rp + l_child0 + child_ustride * (uint32_t)uidx);
-            const uint32_t id0 = *(const uint16_t*)(rp + l_id);
+            const uint32_t ch0 = *(const uint32_t*)(rp + ((uidx > 0 && l_seeded) ? l_childx + childx_ustride * (uint32_t)(uidx - 1) : l_child0));
+            const uint32_t id0 = FR::IDB == 1 ? (uint32_t)*(const uint8_t*)(rp + l_id) : (uint32_t)*(const uint16_t*)(rp + l_id);
             const uint2 pn = make_uint2(hot0.x, hot0.y);
             const double q0 = __longlong_as_double((long long)(((uint64_t)hot0.w << 32) | hot0.z));
             // one-class forests: record slot == node id, so the node's state is addressable before its header arrives --
@@ -752,7 +759,7 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
                         n = h2.y;
                         q = __longlong_as_double((long long)(((uint64_t)h2.w << 32) | h2.z));
                         chv = *(const uint32_t*)(rp + child_off(j2, (uint32_t)uidx));
-                        idv = *(const uint16_t*)(rp + id_off(j2));
+                        idv = FR::IDB == 1 ? (uint32_t)*(const uint8_t*)(rp + id_off(j2)) : (uint32_t)*(const uint16_t*)(rp + id_off(j2));
                     }
                     if (forced) {                                                 // :218-220 first deficient action wins
                         const double thr = sqrt(0.5 * (double)p * (double)H.sim_idx);
