@@ -323,10 +323,10 @@ static int conv5_launch(const int8_t* boards, const uint8_t* valid, const float*
     Conv5NetW N{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13]};
     static bool attr[3] = {false, false, false};
     if (split == 2) {
-        // two activation tiles of two f16 planes (+ a zero row each); the second tile also holds the f32 board staging tile at the
+        // two activation tiles of two f16 planes (+ two zero rows each); the second tile also holds the f32 board staging tile at the
         // start and the f32 trunk output + head buffers at the end of the kernel (54.4 KB + 9.8 KB)
         // + the LDS copies of the head / FC matrices (k_conv5_net: WST_N floats)
-        constexpr size_t lds = (size_t)2 * 201 * 128 + 65536 + (size_t)(2 * 25 * 162 + 25 * 64 + 64 * 2 + 64) * sizeof(float);
+        constexpr size_t lds = (size_t)C5_LDS_LEAD + (size_t)2 * 202 * 128 + 65536 + (size_t)(2 * 25 * 162 + 25 * 64 + 64 * 2 + 64) * sizeof(float);
         static_assert(lds <= 160 * 1024, "k_conv5_net<.., 2>: LDS");
         if (!attr[2]) {
             HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -334,7 +334,7 @@ static int conv5_launch(const int8_t* boards, const uint8_t* valid, const float*
         }
         k_conv5_net<5, 162, 2, 2><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v, descale);
     } else if (split) {
-        constexpr size_t lds = (size_t)2 * 3 * 201 * 128;              // two activation tiles of three bf16 planes (+ a zero row each)
+        constexpr size_t lds = (size_t)2 * 3 * 202 * 128;              // two activation tiles of three bf16 planes (+ two zero rows each)
         if (!attr[1]) {
             HIPCHK(hipFuncSetAttribute((const void*)k_conv5_net<5, 162, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr[1] = true;
@@ -374,7 +374,7 @@ static int s78_launch(const int8_t* boards, const uint8_t* valid, const float* c
     if (n_blocks != 10 || A != 1782 || P != 2) return fail("azg_nn_s78_forward: built for 10 blocks, A = 1782, P = 2");
     S78NetW N{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15], w[16], w[17], w[18]};
     if (split == 2) {
-        constexpr size_t lds = (size_t)(2 + 3) * 201 * 128 + 8 * 32 * sizeof(float);      // X: two f16 planes; the H region keeps three planes' room
+        constexpr size_t lds = (size_t)(2 + 3) * 202 * 128 + 8 * 32 * sizeof(float);      // X: two f16 planes; the H region keeps three planes' room
         static bool attr = false;
         if (!attr) {
             HIPCHK(hipFuncSetAttribute((const void*)k_s78_net_split<10, 1782, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -382,7 +382,7 @@ static int s78_launch(const int8_t* boards, const uint8_t* valid, const float* c
         }
         k_s78_net_split<10, 1782, 2, 2><<<dim3((B + 7) / 8), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v, ds_e, ds_p);
     } else if (split) {
-        constexpr size_t lds = (size_t)2 * 3 * 201 * 128 + 8 * 32 * sizeof(float);
+        constexpr size_t lds = (size_t)2 * 3 * 202 * 128 + 8 * 32 * sizeof(float);
         static bool attr = false;
         if (!attr) {
             HIPCHK(hipFuncSetAttribute((const void*)k_s78_net_split<10, 1782, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

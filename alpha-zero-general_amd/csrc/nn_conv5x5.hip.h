@@ -62,6 +62,7 @@ template <int NT, int RGV, bool CM>
 struct C5Steps {
     int n = 0;
     int8_t ky[18 * NT] = {}, k6[18 * NT] = {}, ti[18 * NT] = {};
+    int8_t kind[18 * NT] = {};          // CM: which of the tile's two cells the tap stays on the board for -- 0 both, 1 the first only, 2 the second only
     bool last[18 * NT] = {};
     constexpr C5Steps() {
         for (int y = 0; y < 3; y++)
@@ -69,8 +70,11 @@ struct C5Steps {
                 int first = n;
                 for (int i = 0; i < NT; i++) {
                     const int rt = c5_tile_of<CM>(RGV, i), c0 = 2 * rt, c1 = 2 * rt + 1;
-                    const uint32_t tm = CM ? ((c0 < 25 ? c5_cell_taps(c0) : 0u) | (c1 < 25 ? c5_cell_taps(c1) : 0u)) : 0x1FFu;
-                    if ((tm >> (y * 3 + (k >> 1))) & 1u) { ky[n] = (int8_t)y; k6[n] = (int8_t)k; ti[n] = (int8_t)i; last[n] = false; n++; }
+                    const uint32_t ta = CM ? (c0 < 25 ? c5_cell_taps(c0) : 0u) : 0x1FFu, tb = CM ? (c1 < 25 ? c5_cell_taps(c1) : 0u) : 0x1FFu;
+                    const bool on_a = (ta >> (y * 3 + (k >> 1))) & 1u, on_b = (tb >> (y * 3 + (k >> 1))) & 1u;
+                    if (on_a || on_b) {
+                        ky[n] = (int8_t)y; k6[n] = (int8_t)k; ti[n] = (int8_t)i; kind[n] = (int8_t)(on_a && on_b ? 0 : on_a ? 1 : 2); last[n] = false; n++;
+                    }
                 }
                 if (n > first) last[n - 1] = true;
                 // (every fragment keeps at least one tile in every row group: the board has five rows and columns, a row group of at
@@ -163,17 +167,27 @@ __device__ __forceinline__ void conv3x3_tile(const float* __restrict__ Wfrag, co
 // so the result differs from the f32 MFMA's only by the dropped 2^-24 terms and the accumulation order (checked <= 1e-5 on the
 // net's outputs against the reference model like the f32 path).  Six v_mfma_f32_16x16x32_bf16 cover K = 32 in ~100 cycles where
 // eight v_mfma_f32_16x16x4_f32 need 256.
-//   activations in LDS: three planes [ROWS + 1][64] bf16 per tile (row = 128 B; the 16-byte chunk q of a row sits at
-//   q ^ (row & 7), which makes the ds_read_b128 of 16 consecutive rows conflict-free; row ROWS stays zero: it is what a tap that
-//   leaves the 5x5 board reads, so no select is needed on the operand registers); written split by the producing epilogue;
+//   activations in LDS: three planes [ROWS + 2][64] bf16 per tile (row = 128 B; the 16-byte chunk q of a row sits at
+//   q ^ (row & 7), which makes the ds_read_b128 of 16 consecutive rows conflict-free; rows ROWS, ROWS + 1 stay zero: they are what a
+//   tap that leaves the 5x5 board reads, so no select is needed on the operand registers -- pl_off_z: the lane reads the zeros from
+//   the 16-byte bank column ITS on-board address would have used, so the other lanes of its ds_read_b128 group never meet it on a bank;
+//   rounds 2-3 had ONE zero row and every lane off the board read its chunk q: a second address on the bank column of the group's
+//   (row & 7) == 0 lane -- SQ_LDS_BANK_CONFLICT 64 % of the kernel's LDS cycles); written split by the producing epilogue;
 //   weights: frag[ct 4][chunk 18][plane 3][lane 64][8] bf16 = W_plane[32*chunk + 8*(lane>>4) + j][16*ct + (lane&15)], K = tap*64 + ci.
 // (bf16x8, split3x2, pl_off, store_split4, load_split4: nn_kernels.hip.h)
+constexpr int C5_LDS_LEAD = 6 * 1024;                    // cell-major f16 x 2 kernel: the tiles start six cells (of 8 rows x 128 B) into the LDS
+constexpr uint32_t C5_LDS_NOWHERE = 0x40000000u;         // an LDS address outside every allocation: reads return zeros
+template <int ROWS> __device__ __forceinline__ int pl_off_z(int r, int q, bool on) {
+    static_assert(ROWS % 2 == 0, "the zero rows start on a 256-byte bank row");
+    const int o = pl_off(r, q);
+    return on ? o : ROWS * 128 + (o & 255);
+}
 
 // the first convolution (2 board planes, K = 9 x 16): f32 MFMA from the f32 staging tile, output written split
 template <int NS, bool RELU = true, int NPL = 3>
 __device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wfrag, const float* __restrict__ bias,
                                                     const float* IN, uint8_t* OUT) {
-    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 2) * 128;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
     float4 w[9];
@@ -215,7 +229,7 @@ struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 template <int NS, bool RELU = true, class Prefetch = NoPrefetch, bool CM = false>
 __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag, const float* __restrict__ bias,
                                                  const float* IN, uint8_t* OUT, Prefetch prefetch = Prefetch()) {
-    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 2) * 128;
     constexpr float WS = 256.f;                             // weight scale (|w| < 255 keeps the hi half finite)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
@@ -266,7 +280,7 @@ __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag
 template <int NS, bool CM = false>
 __device__ __forceinline__ void heads1x1_h2(const float* __restrict__ Wp, const float* __restrict__ bp, const float* __restrict__ Wv,
                                             const float* __restrict__ bv, const uint8_t* IN, float* HP, float* HV) {
-    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, PB = (ROWS + 1) * 128;
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, PB = (ROWS + 2) * 128;
     constexpr float WS = 256.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     uint4 wh[2], wl[2];
@@ -283,11 +297,11 @@ __device__ __forceinline__ void heads1x1_h2(const float* __restrict__ Wp, const 
     }
     const float b0 = bp[0], b1 = bp[1], b2 = bv[0];
     for (int rt = wave; rt < RT; rt += 12) {
-        const int r = rt * 16 + r16, rr = r < ROWS ? r : ROWS;
+        const int r = rt * 16 + r16;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const uint8_t* src = IN + pl_off(rr, 4 * c + g);
+            const uint8_t* src = IN + pl_off_z<ROWS>(r, 4 * c + g, r < ROWS);
             acc = h2_mma(wh[c], wl[c], *(const uint4*)src, *(const uint4*)(src + PB), acc);
         }
         if (g == 0 && r < ROWS) {                           // lanes of g = 0 hold output channels 0..3 of row r
@@ -317,7 +331,7 @@ template <int NS, int NPL = 3, bool PRELOADED = false, bool CM = false>
 __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, const float* __restrict__ bias, const uint8_t* IN,
                                               uint8_t* OUT, const uint8_t* RES, float descale = 1.f,
                                               const uint4* __restrict__ WNEXT = nullptr, uint4 (*wio)[6][3] = nullptr) {
-    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128, KCH = 18;
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 2) * 128, KCH = 18;
     static_assert(MAXT == 5 && RT - RG * (MAXT - 1) == 1, "step schedule: two tile pairs per wave + one odd tile in the first row group");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
@@ -341,8 +355,8 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
     const bool last_slot = rg == c5_last_group<CM>();       // wave-uniform: this wave has a tile in slot MAXT - 1
     auto load = [&](int i, int t, int c) {
         const bool on = (tapmask[i] >> t) & 1u;
-        const int r = on ? row[i] + c5_step<NS, CM>((t / 3 - 1) * 5 + (t % 3 - 1)) : ROWS;          // off the board: the zero row
-        const uint8_t* src = IN + pl_off(r, 4 * c + g);
+        const int r = row[i] + c5_step<NS, CM>((t / 3 - 1) * 5 + (t % 3 - 1));
+        const uint8_t* src = IN + pl_off_z<ROWS>(r, 4 * c + g, on);                                   // off the board: the zero rows
         return SplitFrag{*(const uint4*)src, *(const uint4*)(src + PB), NPL == 3 ? *(const uint4*)(src + 2 * PB) : make_uint4(0u, 0u, 0u, 0u)};
     };
     // one (tile, tap, K chunk of 32): three 16-byte operand reads, six MFMAs into the tile's accumulator
@@ -388,28 +402,51 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
         // group rg of the wave is a template argument of the loop body (three instances), every kernel row is unrolled, and the list of
         // the remaining steps (C5Steps) drives the same software pipeline; the code stays straight-line (a first version skipped the
         // steps with wave-uniform branches: the branches broke the pipelining, 226 -> 265 us per 4096 leaves).
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        typedef u32x4_t __attribute__((address_space(3))) lds_u4;
+        const uint32_t in0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)IN;
+        uint32_t abase[MAXT];
+#pragma unroll
+        for (int i = 0; i < MAXT; i++) abase[i] = in0 + (uint32_t)pl_off(row[i], g) - 6u * 1024u;
+        const bool in_a = (r16v & 8) == 0;                   // this lane's row belongs to the first of its tile's two cells
         auto run = [&](auto nt_tag, auto rg_tag) {
             constexpr int NT = decltype(nt_tag)::value, RGV = decltype(rg_tag)::value;
             using SL = C5StepList<NT, RGV, CM>;
             constexpr int NSTEP = SL::value.n;
-            auto ld = [&](int ky, int k6, int i) {
-                const int kx = k6 >> 1, c = k6 & 1;
-                const bool on = (tapmask[i] >> (ky * 3 + kx)) & 1u;
-                const int r = on ? row[i] + c5_step<NS, CM>((ky - 1) * 5 + (kx - 1)) : ROWS;
-                const uint8_t* src = IN + pl_off(r, 4 * c + g);
-                return SplitFrag{*(const uint4*)src, *(const uint4*)(src + PB), make_uint4(0u, 0u, 0u, 0u)};
+            // Operand addresses without arithmetic (round 4, later).  Cell-major rows put a neighbour cell 8 * (dy * 5 + dx) rows = a multiple
+            // of 1 KiB away, which leaves the row's chunk swizzle (row & 7) alone: the address of (tile i, tap) is abase[i] + a COMPILE-TIME
+            // constant that goes into the ds_read's offset field (abase is taken 6 cells back so that the constant is never negative -- the
+            // tiles start C5_LDS_LEAD bytes into the workgroup's LDS).  A lane whose tap leaves the board gets an address far outside the
+            // allocation instead: an out-of-range LDS read returns zeros (the architected behaviour of the DS unit), touches no bank and
+            // needs no zero row; which half of the tile's lanes that is (first cell, second cell) is a compile-time property of the step,
+            // so the select is one v_cndmask on a wave mask computed once per convolution, and only on the ~40 % of the steps with a mixed
+            // tile.  Before: bit test + compare + select + swizzle, 7.5 VALU instructions per step beside its three MFMAs (the VALU issue
+            // slots of a SIMD were 60 % taken, the MFMA pipe 47 % busy).
+            auto ld = [&](auto S) {
+                constexpr int sx = decltype(S)::value;
+                constexpr int ky = SL::value.ky[sx], k6 = SL::value.k6[sx], i = SL::value.ti[sx], kind = SL::value.kind[sx];
+                constexpr int kx = k6 >> 1, c = k6 & 1;
+                constexpr uint32_t IMM = 1024u * (uint32_t)((ky - 1) * 5 + (kx - 1) + 6);
+                uint32_t a = abase[i];
+                if constexpr (kind == 1) a = in_a ? a : C5_LDS_NOWHERE;
+                if constexpr (kind == 2) a = in_a ? C5_LDS_NOWHERE : a;
+                if constexpr (c == 1) a ^= 64u;                                  // chunk 4 + g: bit 2 of the swizzled chunk index
+                const lds_u4* src = (const lds_u4*)(uintptr_t)(a + IMM);
+                const lds_u4* src1 = (const lds_u4*)(uintptr_t)(a + IMM + (uint32_t)PB);
+                const u32x4_t v0 = *src, v1 = *src1;
+                return SplitFrag{__builtin_bit_cast(uint4, v0), __builtin_bit_cast(uint4, v1), make_uint4(0u, 0u, 0u, 0u)};
             };
 #ifndef AZG_C5_AHEAD
 #define AZG_C5_AHEAD 1
 #endif
             constexpr int AH = AZG_C5_AHEAD;
             static_assert(AH == 1, "the compile-time step loop carries one look-ahead operand");
-            SplitFrag f0 = ld(SL::value.ky[0], SL::value.k6[0], SL::value.ti[0]);
+            SplitFrag f0 = ld(std::integral_constant<int, 0>{});
             c5_static_for<0, NSTEP>([&](auto I) {
                 constexpr int sidx = decltype(I)::value;
                 constexpr int ky = SL::value.ky[sidx], k6 = SL::value.k6[sidx], i = SL::value.ti[sidx];
                 SplitFrag fn = f0;
-                if constexpr (sidx + 1 < NSTEP) fn = ld(SL::value.ky[sidx + 1], SL::value.k6[sidx + 1], SL::value.ti[sidx + 1]);
+                if constexpr (sidx + 1 < NSTEP) fn = ld(std::integral_constant<int, sidx + 1 < NSTEP ? sidx + 1 : 0>{});
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i] = h2_mma(w[k6][0], w[k6][1], f0.h, f0.m, acc[i]);
                 if constexpr (SL::value.last[sidx]) {          // the fragment's last step of this kernel row: refill with the next row's
@@ -492,17 +529,17 @@ __device__ __forceinline__ void gemm64_wload(const uint4* __restrict__ Wfrag, ui
 }
 template <int NS, int NPL = 3>
 __device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t* IN, f32x4 (&acc)[(NS * 25 + 15) / 16 / 3 + 1]) {
-    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 1) * 128;
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 2) * 128;
     static_assert(MAXT == RT / 3 + 1 && RT - RG * (MAXT - 1) == 1, "tile schedule: MAXT - 1 tiles per wave + one odd tile in the first row group");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     const int rg = wave >> 2;
 #pragma unroll
     for (int i = 0; i < MAXT; i++) {
         if (i == MAXT - 1 && rg != 0) continue;             // (wave-uniform)
-        const int r = (rg + RG * i) * 16 + r16, rr = r < ROWS ? r : ROWS;
+        const int r = (rg + RG * i) * 16 + r16;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const uint8_t* src = IN + pl_off(rr, 4 * c + g);
+            const uint8_t* src = IN + pl_off_z<ROWS>(r, 4 * c + g, r < ROWS);
             if (NPL == 2) {
                 acc[i] = h2_mma(w[c * 3], w[c * 3 + 1], *(const uint4*)src, *(const uint4*)(src + PB), acc[i]);
                 continue;
@@ -526,17 +563,18 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
                                                    const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
                                                    float* __restrict__ v_out, float descale) {
     constexpr int NPL = SPLIT ? SPLIT : 3;                  // planes per tile: 3 = bf16 x 3, 2 = f16 x 2
-    constexpr int NS = 8, ROWS = NS * 25, CS = 68, CP2 = 2, AS = (A + 3) / 4 * 4 + 4, PLANE_B = (ROWS + 1) * 128, TILE_B = NPL * PLANE_B;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NS = 8, ROWS = NS * 25, CS = 68, CP2 = 2, AS = (A + 3) / 4 * 4 + 4, PLANE_B = (ROWS + 2) * 128, TILE_B = NPL * PLANE_B;
+    extern __shared__ __attribute__((aligned(256))) float smem[];
     if (NPL == 2) h2_fp16_saturate_mode();
-    float* X = smem;                        // [ROWS][CS]   (SPLIT: three bf16 planes, TILE_B bytes)
-    float* Y = SPLIT ? (float*)((uint8_t*)smem + TILE_B) : X + ROWS * CS;               // [ROWS][CS]
+    constexpr int LEAD = (NPL == 2 && SPLIT == 2) ? C5_LDS_LEAD : 0;      // (conv3x3_split: operand addresses reach six cells back)
+    float* X = smem + LEAD / 4;             // [ROWS][CS]   (SPLIT: three bf16 planes, TILE_B bytes)
+    float* Y = SPLIT ? (float*)((uint8_t*)X + TILE_B) : X + ROWS * CS;               // [ROWS][CS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
     bool heads_done = false;
     // f16 x 2 kernel: LDS copies of Wfp [50][A], Wf1 [25][64], Wp [64][2], Wv [64] behind the two tiles (the second is 64 KB)
     constexpr int WST_FP = CP2 * 25 * A, WST_F1 = WST_FP + 25 * 64, WST_P = WST_F1 + 64 * CP2, WST_N = WST_P + 64;
-    float* const WST = (float*)((uint8_t*)smem + TILE_B + 65536);
+    float* const WST = (float*)((uint8_t*)X + TILE_B + 65536);
     C5_PH(0);
     // ---- board int8 [s][y][x][3] -> Y[s*25 + cell][plane 0..1], channels 2..15 zero (the first conv reads 16) ----
     for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(Y + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -551,7 +589,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     if (SPLIT) {
         uint8_t* XP = (uint8_t*)X;
         uint8_t* YP = (uint8_t*)Y;
-        if (tid < NPL * 32) ((uint32_t*)(XP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // X's zero rows
+        if (tid < NPL * 64) ((uint32_t*)(XP + (tid >> 6) * PLANE_B + ROWS * 128))[tid & 63] = 0u;    // X's zero rows
         constexpr size_t CONV_U4 = (size_t)4 * 18 * NPL * 64;   // uint4 per convolution
         uint4 wreg[6][3];                                        // NPL == 2: the trunk's weight fragments travel from one convolution
         if (NPL == 2) {                                          // to the next in registers (conv3x3_split, rolling prefetch)
@@ -583,7 +621,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         } else conv3x3_first_split<NS, true, NPL>(N.W0, N.b0, Y, XP);   // (Y still holds the f32 board staging tile)
         __syncthreads();
         C5_PH(2);
-        if (tid < NPL * 32) ((uint32_t*)(YP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;    // Y's (the staging tile is dead)
+        if (tid < NPL * 64) ((uint32_t*)(YP + (tid >> 6) * PLANE_B + ROWS * 128))[tid & 63] = 0u;    // Y's (the staging tile is dead)
 #pragma unroll 1
         for (int blk = 0; blk < NB; blk++) {
             const uint4* W1 = (const uint4*)N.Wc + (size_t)(2 * blk) * CONV_U4;
@@ -868,9 +906,9 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
                                                        int B, float* __restrict__ pi_out, float* __restrict__ v_out, float ds_e, float ds_p) {
     constexpr int NS = 8, ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, CS = 68, E = 192;
     // (the f32 staging / head tile [ROWS][CS] + head buffers live in the H region: it keeps the size of three planes)
-    constexpr int PLANE_B = (ROWS + 1) * 128, TILE_B = NPL * PLANE_B, HREG_B = 3 * PLANE_B;
+    constexpr int PLANE_B = (ROWS + 2) * 128, TILE_B = NPL * PLANE_B, HREG_B = 3 * PLANE_B;
     constexpr size_t G64_U4 = (size_t)4 * 2 * NPL * 64;        // uint4 per 64 x 64 matrix
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(256))) float smem[];
     if (NPL == 2) h2_fp16_saturate_mode();
     uint8_t* XP = (uint8_t*)smem;                               // X: three bf16 planes [ROWS + 1][64]
     uint8_t* HP = XP + TILE_B;                                  // one third of the expanded tile, same layout
@@ -880,7 +918,7 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     const int ct = wave & 3, rg = wave >> 2;
     const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
     for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(STG + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < NPL * 32) ((uint32_t*)(XP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;      // X's zero row
+    if (tid < NPL * 64) ((uint32_t*)(XP + (tid >> 6) * PLANE_B + ROWS * 128))[tid & 63] = 0u;      // X's zero row
     __syncthreads();
     for (int i = tid; i < nb * 25 * 2; i += 768) {
         const int r = i >> 1, pl = i & 1;
@@ -899,7 +937,7 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     if (NPL == 2) conv3x3_first_h2<NS, false>(N.W0, zero_bias, STG, XP);
     else conv3x3_first_split<NS, false, NPL>(N.W0, zero_bias, STG, XP);
     __syncthreads();
-    if (tid < NPL * 32) ((uint32_t*)(HP + (tid >> 5) * PLANE_B + ROWS * 128))[tid & 31] = 0u;      // H's zero row (the staging tile is dead)
+    if (tid < NPL * 64) ((uint32_t*)(HP + (tid >> 6) * PLANE_B + ROWS * 128))[tid & 63] = 0u;      // H's zero row (the staging tile is dead)
 #pragma unroll 1
     for (int blk = 0; blk < NB; blk++) {
         f32x4 pacc[MAXT];
