@@ -353,6 +353,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 #pragma unroll
     for (int i = 0; i < MAXT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool last_slot = rg == c5_last_group<CM>();       // wave-uniform: this wave has a tile in slot MAXT - 1
+    float4 b;                                               // the bias of this lane's four output channels (CM: from LDS, requested a few steps before the end)
     auto load = [&](int i, int t, int c) {
         const bool on = (tapmask[i] >> t) & 1u;
         const int r = row[i] + c5_step<NS, CM>((t / 3 - 1) * 5 + (t % 3 - 1));
@@ -431,6 +432,9 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
                 if constexpr (kind == 1) a = in_a ? a : C5_LDS_NOWHERE;
                 if constexpr (kind == 2) a = in_a ? C5_LDS_NOWHERE : a;
                 if constexpr (c == 1) a ^= 64u;                                  // chunk 4 + g: bit 2 of the swizzled chunk index
+                if constexpr (kind != 0 || c == 1) asm volatile("" : "+v"(a));   // (recomputed per step: kept as common subexpressions the
+                                                                                 // up to six variants per tile are 30 live registers -> spills,
+                                                                                 // and a spill reload waits with vmcnt(0) for the weight prefetch)
                 const lds_u4* src = (const lds_u4*)(uintptr_t)(a + IMM);
                 const lds_u4* src1 = (const lds_u4*)(uintptr_t)(a + IMM + (uint32_t)PB);
                 const u32x4_t v0 = *src, v1 = *src1;
@@ -447,6 +451,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
                 constexpr int ky = SL::value.ky[sidx], k6 = SL::value.k6[sidx], i = SL::value.ti[sidx];
                 SplitFrag fn = f0;
                 if constexpr (sidx + 1 < NSTEP) fn = ld(std::integral_constant<int, sidx + 1 < NSTEP ? sidx + 1 : 0>{});
+                if constexpr (sidx == (NSTEP > 6 ? NSTEP - 6 : 0)) b = *(const float4*)(bias + ct * 16 + 4 * g);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i] = h2_mma(w[k6][0], w[k6][1], f0.h, f0.m, acc[i]);
                 if constexpr (SL::value.last[sidx]) {          // the fragment's last step of this kernel row: refill with the next row's
@@ -494,7 +499,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 #pragma unroll
             for (int p = 0; p < 3; p++) (*wio)[c6][p] = w[c6][p];
     }
-    const float4 b = *(const float4*)(bias + ct * 16 + 4 * g);
+    if (!(NPL == 2 && CM)) b = *(const float4*)(bias + ct * 16 + 4 * g);
 #pragma unroll
     for (int i = 0; i < MAXT; i++) {
         if (c5_tile_of<CM>(rg, i) >= RT || row[i] >= ROWS) continue;
@@ -578,6 +583,12 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     C5_PH(0);
     // ---- board int8 [s][y][x][3] -> Y[s*25 + cell][plane 0..1], channels 2..15 zero (the first conv reads 16) ----
     for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(Y + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // f16 x 2 kernel: the trunk's 2 NB bias vectors live in the lead bytes of the LDS (no operand address ever points there): a
+    // convolution's epilogue reads its bias from LDS instead of waiting out an L2 round trip behind its last MFMA (the compiler kept the
+    // global load below the main loop's scheduling barriers: 1-2 k cycles of every convolution)
+    float* const BL = smem;
+    static_assert(LEAD == 0 || 2 * NB * 64 * 4 <= LEAD, "bias vectors in the LDS lead");
+    if (LEAD && tid < 2 * NB * 64) BL[tid] = N.bc[tid];
     __syncthreads();
     constexpr bool CM = NPL == 2 && SPLIT == 2;                // cell-major tiles (row = cell * NS + sample) in the f16 x 2 kernel
     for (int i = tid; i < nb * 25 * 2; i += 768) {
@@ -626,9 +637,9 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         for (int blk = 0; blk < NB; blk++) {
             const uint4* W1 = (const uint4*)N.Wc + (size_t)(2 * blk) * CONV_U4;
             if (NPL == 2) {
-                conv3x3_split<NS, NPL, true, CM>(W1, N.bc + (2 * blk) * 64, XP, YP, nullptr, descale, W1 + CONV_U4, &wreg);
+                conv3x3_split<NS, NPL, true, CM>(W1, BL + (2 * blk) * 64, XP, YP, nullptr, descale, W1 + CONV_U4, &wreg);
                 __syncthreads();
-                conv3x3_split<NS, NPL, true, CM>(W1 + CONV_U4, N.bc + (2 * blk + 1) * 64, YP, XP, XP, descale,
+                conv3x3_split<NS, NPL, true, CM>(W1 + CONV_U4, BL + (2 * blk + 1) * 64, YP, XP, XP, descale,
                                              blk + 1 < NB ? W1 + 2 * CONV_U4 : nullptr, &wreg);
                 __syncthreads();
                 C5_PH(3 + blk);
