@@ -64,22 +64,67 @@ struct C5Steps {
     int8_t ky[18 * NT] = {}, k6[18 * NT] = {}, ti[18 * NT] = {};
     int8_t kind[18 * NT] = {};          // CM: which of the tile's two cells the tap stays on the board for -- 0 both, 1 the first only, 2 the second only
     bool last[18 * NT] = {};
+    // The epilogue of a tile (bias, residual, ReLU, split, store) is straight-line code inside the step loop's instance, issued EPI_DELAY
+    // steps after the tile's final MFMA: epi[s] = bit i: tile slot i's epilogue goes after step s; tail_order = the tiles left for after
+    // the loop, in completion order.  bias_at = the step before which the bias is requested.  AZG_C5_TILE_MAJOR 1 walks the LAST kernel
+    // row tile by tile, so that the accumulators complete one after the other and the epilogues sit between the MFMAs of the tiles that
+    // follow.  Measured (round 4): no gain over all epilogues after the loop (179 us either way) -- what a convolution loses is not the
+    // epilogue but its tail, the last wave of a SIMD finishing alone (AZG_C5_PRIO below); the default keeps the fragment-major order.
+#ifndef AZG_C5_EPI_DELAY
+#define AZG_C5_EPI_DELAY 100   /* 2 with AZG_C5_TILE_MAJOR 1: measured the same 179 us as the epilogues after the loop, which is the default */
+#endif
+#ifndef AZG_C5_TILE_MAJOR
+#define AZG_C5_TILE_MAJOR 0
+#endif
+    static constexpr int EPI_DELAY = AZG_C5_EPI_DELAY;
+    uint8_t epi[18 * NT] = {};
+    int8_t fin[NT] = {};                // final step of tile slot i
+    int8_t tail_order[NT] = {};
+    int n_tail = 0, bias_at = 0;
+    constexpr void add(int y, int k, int i) {
+        const int rt = c5_tile_of<CM>(RGV, i), c0 = 2 * rt, c1 = 2 * rt + 1;
+        const uint32_t ta = CM ? (c0 < 25 ? c5_cell_taps(c0) : 0u) : 0x1FFu, tb = CM ? (c1 < 25 ? c5_cell_taps(c1) : 0u) : 0x1FFu;
+        const bool on_a = (ta >> (y * 3 + (k >> 1))) & 1u, on_b = (tb >> (y * 3 + (k >> 1))) & 1u;
+        if (on_a || on_b) {
+            ky[n] = (int8_t)y; k6[n] = (int8_t)k; ti[n] = (int8_t)i; kind[n] = (int8_t)(on_a && on_b ? 0 : on_a ? 1 : 2); last[n] = false; n++;
+        }
+    }
     constexpr C5Steps() {
-        for (int y = 0; y < 3; y++)
-            for (int k = 0; k < 6; k++) {
-                int first = n;
-                for (int i = 0; i < NT; i++) {
-                    const int rt = c5_tile_of<CM>(RGV, i), c0 = 2 * rt, c1 = 2 * rt + 1;
-                    const uint32_t ta = CM ? (c0 < 25 ? c5_cell_taps(c0) : 0u) : 0x1FFu, tb = CM ? (c1 < 25 ? c5_cell_taps(c1) : 0u) : 0x1FFu;
-                    const bool on_a = (ta >> (y * 3 + (k >> 1))) & 1u, on_b = (tb >> (y * 3 + (k >> 1))) & 1u;
-                    if (on_a || on_b) {
-                        ky[n] = (int8_t)y; k6[n] = (int8_t)k; ti[n] = (int8_t)i; kind[n] = (int8_t)(on_a && on_b ? 0 : on_a ? 1 : 2); last[n] = false; n++;
-                    }
-                }
-                if (n > first) last[n - 1] = true;
-                // (every fragment keeps at least one tile in every row group: the board has five rows and columns, a row group of at
-                // least four tiles always holds a cell that is neither on the top / bottom nor on the left / right edge)
+        for (int y = 0; y < 3; y++) {
+            const int row0 = n;
+            if (CM && y == 2 && AZG_C5_TILE_MAJOR) {
+                for (int i = 0; i < NT; i++)
+                    for (int k = 0; k < 6; k++) add(y, k, i);
+            } else {
+                for (int k = 0; k < 6; k++)
+                    for (int i = 0; i < NT; i++) add(y, k, i);
             }
+            // a fragment's final step of this kernel row (where its registers are refilled with the next row's fragment)
+            // (every fragment keeps at least one tile in every row group: the board has five rows and columns, a row group of at
+            // least four tiles always holds a cell that is neither on the top / bottom nor on the left / right edge)
+            for (int k = 0; k < 6; k++) {
+                int l = -1;
+                for (int s = row0; s < n; s++) if (k6[s] == k) l = s;
+                if (l >= 0) last[l] = true;
+            }
+        }
+        int first_fin = n;
+        for (int i = 0; i < NT; i++) {
+            int f = 0;
+            for (int s = 0; s < n; s++) if (ti[s] == i) f = s;
+            fin[i] = (int8_t)f;
+            if (f < first_fin) first_fin = f;
+        }
+        bias_at = first_fin > 4 ? first_fin - 4 : 0;
+        // tiles in completion order
+        bool done[NT] = {};
+        for (int r = 0; r < NT; r++) {
+            int best = -1;
+            for (int i = 0; i < NT; i++) if (!done[i] && (best < 0 || fin[i] < fin[best])) best = i;
+            done[best] = true;
+            if (fin[best] + EPI_DELAY < n) epi[fin[best] + EPI_DELAY] |= (uint8_t)(1u << best);
+            else tail_order[n_tail++] = (int8_t)best;
+        }
     }
 };
 
@@ -410,6 +455,53 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 #pragma unroll
         for (int i = 0; i < MAXT; i++) abase[i] = in0 + (uint32_t)pl_off(row[i], g) - 6u * 1024u;
         const bool in_a = (r16v & 8) == 0;                   // this lane's row belongs to the first of its tile's two cells
+        // the epilogue of tile slot i of row group RGV: straight-line but for the one tile that carries the eight pad rows (a compile-time fact)
+        const uint32_t out0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)OUT;
+        const uint32_t res0 = RES ? (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)RES : 0u;
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        typedef u32x2_t __attribute__((address_space(3))) lds_u2;
+        auto epilogue_cm = [&](auto I, auto rg_tag) {
+            constexpr int i = decltype(I)::value, rt = c5_tile_of<CM>(decltype(rg_tag)::value, i);
+#ifdef AZG_C5_EPI_GENERIC
+            if (row[i] < ROWS) {
+                f32x4 o = acc[i] * descale + f32x4{b.x, b.y, b.z, b.w};
+                if (RES) o += h2_load4(RES, PB, 128, row[i], ct * 16 + 4 * g);
+                h2_store4(OUT, PB, 128, row[i], ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});
+            }
+            return;
+#endif
+            const uint32_t off = (uint32_t)pl_off(row[i], 2 * ct + (g >> 1)) + (uint32_t)((g & 1) << 3);
+            f32x4 o = acc[i] * descale + f32x4{b.x, b.y, b.z, b.w};
+#ifdef AZG_C5_EPI_GRES
+            if (RES) o += h2_load4(RES, PB, 128, row[i], ct * 16 + 4 * g);
+            else
+#endif
+            if (RES) {
+                typedef uint64_t __attribute__((address_space(3))) lds_u64;
+                const uint64_t hv = *(const lds_u64*)(uintptr_t)(res0 + off), lv = *(const lds_u64*)(uintptr_t)(res0 + off + (uint32_t)PB);
+                const f32x2 h0 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, (uint32_t)hv), f32x2), h1 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, (uint32_t)(hv >> 32)), f32x2);
+                const f32x2 l0 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, (uint32_t)lv), f32x2), l1 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, (uint32_t)(lv >> 32)), f32x2);
+                o += f32x4{h0.x + l0.x, h0.y + l0.y, h1.x + l1.x, h1.y + l1.y} * H2_IAS;          // == h2_load4
+            }
+#ifdef AZG_C5_EPI_GSTORE
+            if (row[i] < ROWS) h2_store4(OUT, PB, 128, row[i], ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});
+            return;
+#endif
+            o = f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)} * H2_AS;
+            uint32_t h0, l0, h1, l1;
+            h2_split2(o[0], o[1], h0, l0);
+            h2_split2(o[2], o[3], h1, l1);
+            const uint32_t dst = out0 + off;
+            if (2 * rt + 1 < 25 || in_a) {                                                         // (rows >= ROWS of the 13th tile: no store)
+#ifdef AZG_C5_EPI_PTR
+                *(uint2*)(OUT + off) = make_uint2(h0, h1);
+                *(uint2*)(OUT + off + PB) = make_uint2(l0, l1);
+#else
+                *(lds_u2*)(uintptr_t)dst = u32x2_t{h0, h1};
+                *(lds_u2*)(uintptr_t)(dst + (uint32_t)PB) = u32x2_t{l0, l1};
+#endif
+            }
+        };
         auto run = [&](auto nt_tag, auto rg_tag) {
             constexpr int NT = decltype(nt_tag)::value, RGV = decltype(rg_tag)::value;
             using SL = C5StepList<NT, RGV, CM>;
@@ -444,14 +536,27 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 #define AZG_C5_AHEAD 1
 #endif
             constexpr int AH = AZG_C5_AHEAD;
-            static_assert(AH == 1, "the compile-time step loop carries one look-ahead operand");
+            static_assert(AH == 1 || AH == 2, "the compile-time step loop carries one or two look-ahead operands");
             SplitFrag f0 = ld(std::integral_constant<int, 0>{});
+            SplitFrag f1 = f0;                               // AH == 2: the operands of the step after the next
+            if constexpr (AH == 2 && NSTEP > 1) f1 = ld(std::integral_constant<int, (NSTEP > 1 ? 1 : 0)>{});
             c5_static_for<0, NSTEP>([&](auto I) {
                 constexpr int sidx = decltype(I)::value;
                 constexpr int ky = SL::value.ky[sidx], k6 = SL::value.k6[sidx], i = SL::value.ti[sidx];
-                SplitFrag fn = f0;
-                if constexpr (sidx + 1 < NSTEP) fn = ld(std::integral_constant<int, sidx + 1 < NSTEP ? sidx + 1 : 0>{});
-                if constexpr (sidx == (NSTEP > 6 ? NSTEP - 6 : 0)) b = *(const float4*)(bias + ct * 16 + 4 * g);
+                SplitFrag fn = AH == 2 ? f1 : f0;
+                if constexpr (AH == 1 && sidx + 1 < NSTEP) fn = ld(std::integral_constant<int, sidx + 1 < NSTEP ? sidx + 1 : 0>{});
+                if constexpr (AH == 2 && sidx + 2 < NSTEP) f1 = ld(std::integral_constant<int, sidx + 2 < NSTEP ? sidx + 2 : 0>{});
+#ifndef AZG_C5_PRIO
+#define AZG_C5_PRIO 4
+#endif
+#if AZG_C5_PRIO
+                // the three waves of a SIMD share its MFMA pipe: a wave's issue priority falls as it advances through the convolution, so
+                // that none runs ahead and leaves the last one to finish alone (a lone wave waits out every LDS round trip): 4 levels over
+                // the steps of a convolution, 319.7 k -> 307.7 k cycles per launch; two look-ahead operands (AZG_C5_AHEAD 2) change nothing
+                if constexpr (sidx == 0 || (sidx * AZG_C5_PRIO) / NSTEP != ((sidx - 1) * AZG_C5_PRIO) / NSTEP)
+                    __builtin_amdgcn_s_setprio(3 - (sidx * AZG_C5_PRIO) / NSTEP * 3 / (AZG_C5_PRIO - 1 > 0 ? AZG_C5_PRIO - 1 : 1));
+#endif
+                if constexpr (sidx == SL::value.bias_at) b = *(const float4*)(bias + ct * 16 + 4 * g);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i] = h2_mma(w[k6][0], w[k6][1], f0.h, f0.m, acc[i]);
                 if constexpr (SL::value.last[sidx]) {          // the fragment's last step of this kernel row: refill with the next row's
@@ -461,7 +566,11 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f0 = fn;
+                if constexpr (CM && SL::value.epi[sidx] != 0)
+                    c5_static_for<0, NT>([&](auto J) { if constexpr ((SL::value.epi[sidx] >> decltype(J)::value) & 1) epilogue_cm(J, rg_tag); });
             });
+            if constexpr (CM)
+                c5_static_for<0, SL::value.n_tail>([&](auto J) { epilogue_cm(std::integral_constant<int, SL::value.tail_order[decltype(J)::value]>{}, rg_tag); });
         };
         if (rg == 0) run(std::integral_constant<int, CM ? MAXT - 1 : MAXT>{}, std::integral_constant<int, 0>{});
         else if (rg == 1) run(std::integral_constant<int, MAXT - 1>{}, std::integral_constant<int, 1>{});
@@ -502,6 +611,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
     if (!(NPL == 2 && CM)) b = *(const float4*)(bias + ct * 16 + 4 * g);
 #pragma unroll
     for (int i = 0; i < MAXT; i++) {
+        if (NPL == 2 && CM) continue;                         // (done inside the step loop)
         if (c5_tile_of<CM>(rg, i) >= RT || row[i] >= ROWS) continue;
         if (NPL == 2) {
             f32x4 o = acc[i] * descale + f32x4{b.x, b.y, b.z, b.w};

@@ -1,6 +1,6 @@
 # A/B of the conflict-free zero rows in the conv5 / s78 kernels + LDS conflict counters
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r04p
-python -m pytest tests/test_nnet.py -q -m gpu -k "santorini" 2>&1 | tail -3
+python -m pytest tests/test_nnet.py -q -m gpu -k "santorini" 2>&1 | grep -E "^FAILED|^E  |passed|failed" | head -12
 for r in 1 2; do for lib in "$@"; do
   echo "== $lib"; AZG_LIB=$PWD/$lib python tools/time_v89.py 2>&1 | grep "h2 us"; AZG_LIB=$PWD/$lib python tools/time_v78.py 2>&1 | grep -i "us per" | tail -2
 done; done
