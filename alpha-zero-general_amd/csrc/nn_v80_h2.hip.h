@@ -222,8 +222,17 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
 #pragma unroll
         for (int m = 0; m < 7; m++) {
             float wd[7];
+#ifndef AZG_H2_WD_HOIST
+            // (opaque per output token: hoisted above the expand GEMM, the 49 v_readlane results of a block do not fit the scalar registers
+            // beside the kernel's 116 dwords of arguments -- the compiler then spilled them and 36 argument registers to VGPR lanes and
+            // read everything back: 205 lane instructions per block and wave instead of 49)
+            float wdm = wdv;
+            asm volatile("" : "+v"(wdm));
+#else
+            const float wdm = wdv;
+#endif
 #pragma unroll
-            for (int l = 0; l < 7; l++) wd[l] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wdv), m * 7 + l));
+            for (int l = 0; l < 7; l++) wd[l] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wdm), m * 7 + l));
             f32x4 a = wd[0] * in[0];
 #pragma unroll
             for (int l = 1; l < 7; l++) a += wd[l] * in[l];
