@@ -699,6 +699,8 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     float* const BL = smem;
     static_assert(LEAD == 0 || 2 * NB * 64 * 4 <= LEAD, "bias vectors in the LDS lead");
     if (LEAD && tid < 2 * NB * 64) BL[tid] = N.bc[tid];
+    // (the small operands of the last phases -- head / FC biases, the value head's second matrix, the valid masks -- copied here as well:
+    // 307.9 k -> 312.3 k cycles per launch, dropped: their global loads are not what the 1x1 heads / FC / softmax phases wait for)
     __syncthreads();
     constexpr bool CM = NPL == 2 && SPLIT == 2;                // cell-major tiles (row = cell * NS + sample) in the f16 x 2 kernel
     for (int i = tid; i < nb * 25 * 2; i += 768) {

@@ -209,7 +209,7 @@ def build_engine(a, game_key, T, rank, dev):
     # Round 4: the engine cleans a tree up once its arena is 70 % full (cfg.gc_high_water_pct), not only when another search would not
     # fit, so the arena is sized for the largest LIVE tree + one search with >= 20 % headroom (Splendor 2p: 7.5 k live nodes measured over
     # whole games -> 13 x sims; it was 16 x sims with the clean-up at exhaustion: 158.9 -> 130.5 GB for 4096 trees)
-    cap = a.node_capacity or max(2048, {'splendor2': 13, 'santorini11': 14}.get(game_key, 32) * a.sims + 512)
+    cap = a.node_capacity or max(2048, {'splendor2': 13, 'splendor3': 24, 'splendor4': 24, 'santorini11': 14}.get(game_key, 32) * a.sims + 512)
     eng = None
     for attempt in range(3):           # the forest wants a large share of the 288 GB HBM: shrink the arena if the device has less to give
         try:
