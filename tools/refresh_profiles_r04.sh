@@ -1,9 +1,9 @@
 # round-4 evidence: run on the GPU box (gpurun), outputs under gpurun_out/r04p/ -> copied to profiles/r04_* afterwards
-# usage: bash tools/refresh_profiles_r04.sh [part ...]   parts: tests bench prof games variants nets tail f4 (default: all)
+# usage: bash tools/refresh_profiles_r04.sh [part ...]   parts: tests bench prof sant games variants nets tail f4 (default: all)
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r04p; mkdir -p $O
-PARTS=${@:-tests bench prof games variants nets tail f4}
+PARTS=${@:-tests bench prof sant games variants nets tail f4}
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 cd $R
 if has tests; then python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest.txt; fi
@@ -28,8 +28,8 @@ if has prof; then
   python tools/prof_summary.py /tmp/kt/kt_results.db 16 > $O/kernel_stats.md
   python tools/prof_summary.py /tmp/pf/pf_results.db 8 > $O/pmc_FETCH_SIZE.md
   python tools/prof_summary.py /tmp/pw/pw_results.db 8 > $O/pmc_WRITE_SIZE.md
-  python tools/prof_summary.py /tmp/pm/pm_results.db 4 | grep -E "kernel|k_v80_net_h2|k_select|^\|---" > $O/pmc_net_select_1.md
-  python tools/prof_summary.py /tmp/pn/pn_results.db 4 | grep -E "kernel|k_v80_net_h2|k_select|^\|---" > $O/pmc_net_select_2.md
+  python tools/prof_summary.py /tmp/pm/pm_results.db 4 | grep -E "^\| kernel|k_v80_net_h2|k_select|^\|---" > $O/pmc_net_select_1.md
+  python tools/prof_summary.py /tmp/pn/pn_results.db 4 | grep -E "^\| kernel|k_v80_net_h2|k_select|^\|---" > $O/pmc_net_select_2.md
   python tools/make_traffic_json.py /tmp/pf/pf_results.db /tmp/pw/pw_results.db $O/traffic.json 4096 800 $O/bench_profiled_fetch.json > /dev/null
   python tools/prof_gaps.py /tmp/kt/kt_results.db > $O/kernel_gaps.md 2>/dev/null
 fi
@@ -57,6 +57,23 @@ if has tail; then
   [ -f build_ab/libazg_cyc.so ] && AZG_LIB=$R/build_ab/libazg_cyc.so python tools/dbg_tail2.py 1500 12 > $O/tail.txt 2>&1
   [ -f build_ab/libazg_cyc.so ] && AZG_LIB=$R/build_ab/libazg_cyc.so python tools/dbg_cycles.py > $O/cycles.txt 2>&1
   python tools/dbg_placement.py > $O/placement.txt 2>&1
+fi
+if has sant; then
+  # the second north-star target: kernel trace + counters of Santorini no-gods (opening plies)
+  cd /tmp && export TMPDIR=/tmp
+  B="python $R/bench.py --game santorini1 --steps 1 --warmup 1 --preroll-plies 0 --no-cpu-baseline --roofline-rounds 100"
+  rocprofv3 --kernel-trace --stats -d /tmp/kts -o kt -- $B > $O/bench_profiled_santorini1.json 2>/dev/null
+  rocprofv3 --pmc FETCH_SIZE -d /tmp/pfs -o pf -- $B > $O/bench_profiled_fetch_santorini1.json 2>/dev/null
+  rocprofv3 --pmc WRITE_SIZE -d /tmp/pws -o pw -- $B > /dev/null 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY -d /tmp/pms -o pm -- $B > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d /tmp/pns -o pn -- $B > /dev/null 2>&1
+  cd $R
+  python tools/prof_summary.py /tmp/kts/kt_results.db 12 > $O/kernel_stats_santorini1.md
+  python tools/prof_summary.py /tmp/pfs/pf_results.db 6 > $O/pmc_FETCH_SIZE_santorini1.md
+  python tools/prof_summary.py /tmp/pws/pw_results.db 6 > $O/pmc_WRITE_SIZE_santorini1.md
+  python tools/prof_summary.py /tmp/pms/pm_results.db 4 | grep -E "^\| kernel|k_conv5_net|k_select|^\|---" > $O/pmc_net_select_1_santorini1.md
+  python tools/prof_summary.py /tmp/pns/pn_results.db 4 | grep -E "^\| kernel|k_conv5_net|k_select|^\|---" > $O/pmc_net_select_2_santorini1.md
+  python tools/make_traffic_json.py /tmp/pfs/pf_results.db /tmp/pws/pw_results.db $O/traffic_santorini1.json 4096 800 $O/bench_profiled_fetch_santorini1.json > /dev/null
 fi
 if has f4; then
   {
