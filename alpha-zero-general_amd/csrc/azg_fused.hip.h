@@ -92,10 +92,9 @@ __global__ __launch_bounds__(1024) void k_rounds_v80(const RoundArgs* args, int 
             const RoundArgs* a = args;
             asm volatile("" : "+s"(a));
             const RoundArgsC A = (RoundArgsC)(uintptr_t)a;
-            const H2Weights W = load_const(&A->W);
             int wg = (int)blockIdx.x;
             asm volatile("" : "+s"(wg));
-            h2_net_body<16>(lds, W.Wt, W.Wp, W.Wv, W.N, A->leaf_states, A->leaf_valid, A->F.T, G::P, A->pi, A->v, wg);
+            h2_net_body<16>(lds, &A->W, A->leaf_states, A->leaf_valid, A->F.T, G::P, A->pi, A->v, wg);
         }
         __syncthreads();               // pi / v of the 16 leaves are written; the H planes are free for the descents again
         const unsigned long long c2 = wall_clock64();

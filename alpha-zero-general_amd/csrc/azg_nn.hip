@@ -227,8 +227,6 @@ extern "C" int azg_nn_v80_forward_h2(const int8_t* boards, const uint8_t* valid,
     if (!boards || !valid || !w || !descale || !pi || !v || B <= 0) return fail("azg_nn_v80_forward_h2: null/empty argument");
     if (P < 2 || P > 4) return fail("azg_nn_v80_forward_h2: 2 <= P <= 4");
     const H2Weights HW = h2_weights(w, descale);
-    const H2BlockW &Wt = HW.Wt, &Wp = HW.Wp, &Wv = HW.Wv;
-    const H2NetW& N = HW.N;
     hipStream_t s = (hipStream_t)stream;
     static int waves_h2 = 0;          // AZG_V80_WAVES=16: the 16-wave / 128-VGPR variant (the form the fused round kernel uses); default 12
     if (!waves_h2) {
@@ -236,8 +234,8 @@ extern "C" int azg_nn_v80_forward_h2(const int8_t* boards, const uint8_t* valid,
         HIPCHK(hipFuncSetAttribute((const void*)k_v80_net_h2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         waves_h2 = (getenv("AZG_V80_WAVES") && atoi(getenv("AZG_V80_WAVES")) == 16) ? 16 : 12;
     }
-    if (waves_h2 == 16) k_v80_net_h2<16><<<dim3((B + 15) / 16), dim3(1024), H2_LDS, s>>>(Wt, Wp, Wv, N, boards, valid, B, P, pi, v);
-    else k_v80_net_h2<12><<<dim3((B + 15) / 16), dim3(768), H2_LDS, s>>>(Wt, Wp, Wv, N, boards, valid, B, P, pi, v);
+    if (waves_h2 == 16) k_v80_net_h2<16><<<dim3((B + 15) / 16), dim3(1024), H2_LDS, s>>>(HW, boards, valid, B, P, pi, v);
+    else k_v80_net_h2<12><<<dim3((B + 15) / 16), dim3(768), H2_LDS, s>>>(HW, boards, valid, B, P, pi, v);
     HIPCHK(hipGetLastError());
     return 0;
 }

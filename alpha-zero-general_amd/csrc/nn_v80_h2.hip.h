@@ -56,6 +56,29 @@ static inline H2Weights h2_weights(const void* const* w, const float* descale) {
                             (const float*)w[42], descale[0], descale[13], descale[14], descale[15]}};
 }
 
+// The kernel's ~116 dwords of pointers and scales do not fit the scalar registers beside what a block needs, and the compiler spilled
+// them to VGPR lanes (v_writelane / v_readlane are VALU instructions, in phases that are VALU-bound).  The forward therefore takes ONE
+// pointer to the H2Weights in the constant address space (the kernel's own argument segment, or the round arguments of the per-CU
+// kernel) and every block loads what it uses with scalar loads where it uses it, through a pointer the compiler cannot see through
+// (so that nothing is kept live from one block to the next).
+typedef const H2Weights __attribute__((address_space(4))) * H2WeightsC;
+template <class T>
+__device__ __forceinline__ T h2_load_const(const T __attribute__((address_space(4))) * p) {
+    static_assert(sizeof(T) % 4 == 0, "word-sized struct");
+    const uint32_t __attribute__((address_space(4))) * s = (const uint32_t __attribute__((address_space(4))) *)p;
+    uint32_t w[sizeof(T) / 4];
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); k++) w[k] = s[k];      // scalar loads; the words a block does not use are dropped
+    T out;
+    __builtin_memcpy(&out, w, sizeof(T));
+    return out;
+}
+__device__ __forceinline__ H2WeightsC h2_opaque(H2WeightsC p) {
+    uint64_t v = (uint64_t)(uintptr_t)p;
+    asm volatile("" : "+s"(v));
+    return (H2WeightsC)(uintptr_t)v;
+}
+
 // byte offset of (row, 16-byte chunk q = 8 halves) in a plane of row stride RS (RS = 128 mod 256: with the XOR the ds_read_b128
 // lane groups of an MFMA operand fetch -- 16 rows x 4 adjacent chunks -- hit 16 distinct 16-byte bank columns)
 __device__ __forceinline__ int h2_off(int row, int q, int RS) { return row * RS + ((q ^ (row & 7)) << 4); }
@@ -219,9 +242,34 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
             b14 = *(const f32x4*)(W.b1 + (tid < 192 ? cc1 : 0));
         }
         f32x4 pool = POOLMAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef AZG_H2_WD_READLANE
+        // the 7 x 7 token-mix matrix through the scalar data cache: row m + 1 is requested (7 dwords, constant address space) before
+        // row m's 28 packed FMAs are issued; no v_readlane (AZG_H2_WD_READLANE: the matrix in a VGPR, element m * 7 + l read with
+        // v_readlane -- 147 more VALU instructions per wave, the same time within 0.3 %)
+        typedef const float __attribute__((address_space(4))) * cfp;
+        float wdn[7];
+        {
+            const float* p0 = W.Wd;
+            asm volatile("" : "+s"(p0));
+            const cfp q0 = (cfp)(uintptr_t)p0;
+#pragma unroll
+            for (int l = 0; l < 7; l++) wdn[l] = q0[l];
+        }
+#endif
 #pragma unroll
         for (int m = 0; m < 7; m++) {
             float wd[7];
+#ifndef AZG_H2_WD_READLANE
+#pragma unroll
+            for (int l = 0; l < 7; l++) wd[l] = wdn[l];
+            if (m < 6) {
+                const float* p1 = W.Wd + 7 * (m + 1);
+                asm volatile("" : "+s"(p1));
+                const cfp q1 = (cfp)(uintptr_t)p1;
+#pragma unroll
+                for (int l = 0; l < 7; l++) wdn[l] = q1[l];
+            }
+#else
 #ifndef AZG_H2_WD_HOIST
             // (opaque per output token: hoisted above the expand GEMM, the 49 v_readlane results of a block do not fit the scalar registers
             // beside the kernel's 116 dwords of arguments -- the compiler then spilled them and 36 argument registers to VGPR lanes and
@@ -233,6 +281,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
 #endif
 #pragma unroll
             for (int l = 0; l < 7; l++) wd[l] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wdm), m * 7 + l));
+#endif
             f32x4 a = wd[0] * in[0];
 #pragma unroll
             for (int l = 1; l < 7; l++) a += wd[l] * in[l];
@@ -478,9 +527,8 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
 
 // the whole forward of workgroup `wg` (samples 16 * wg ..); the caller's workgroup has NW waves and H2_LDS bytes of LDS at `lds`
 template <int NW>
-__device__ __forceinline__ void h2_net_body(uint8_t* lds, const H2BlockW& Wt, const H2BlockW& Wp, const H2BlockW& Wv, const H2NetW& N,
-                                            const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid, int B, int P,
-                                            float* __restrict__ pi_out, float* __restrict__ v_out, int wg) {
+__device__ __forceinline__ void h2_net_body(uint8_t* lds, H2WeightsC Wc, const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid,
+                                            int B, int P, float* __restrict__ pi_out, float* __restrict__ v_out, int wg) {
     constexpr int NS = 16, C = 56, NT = NW * 64, KB = (NS * (7 * C / 4) + NT - 1) / NT;
     h2_fp16_saturate_mode();
     int tid_ = threadIdx.x;
@@ -500,11 +548,19 @@ __device__ __forceinline__ void h2_net_body(uint8_t* lds, const H2BlockW& Wt, co
     constexpr int RG0 = NW / 4;                               // row-tile groups of the first layer
     const int ntp = wave & 3, rt0 = wave >> 2;
     uint4 w0h[2], w0l[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++) { w0h[c] = H2FRAG(N.W0, 2, ntp, c, 0); w0l[c] = H2FRAG(N.W0, 2, ntp, c, 1); }
-    const f32x4 b04 = *(const f32x4*)(N.b0 + ntp * 16 + 4 * g);
+    float s0;
+    f32x4 b04;
     H2EW ew;
-    h2_load_ew(ew, Wt, wave < 11 ? wave : 0, g, lane);       // the trunk block's first operands, behind the board tile and W0
+    {
+        const H2WeightsC c0 = h2_opaque(Wc);
+        const H2NetW N = h2_load_const(&c0->N);
+        const H2BlockW Wt = h2_load_const(&c0->Wt);
+#pragma unroll
+        for (int c = 0; c < 2; c++) { w0h[c] = H2FRAG(N.W0, 2, ntp, c, 0); w0l[c] = H2FRAG(N.W0, 2, ntp, c, 1); }
+        b04 = *(const f32x4*)(N.b0 + ntp * 16 + 4 * g);
+        s0 = N.s0;
+        h2_load_ew(ew, Wt, wave < 11 ? wave : 0, g, lane);   // the trunk block's first operands, behind the board tile and W0
+    }
     // zero what is read but never written: the pooled / SE-hidden planes (pad columns) and X0's columns 56..63
     if (tid < 768) *(uint4*)(lds + H2_PLH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);       // 768 x 16 B = both PL planes
     if (tid < 256) *(uint4*)(lds + H2_SHH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);       // both SH planes
@@ -535,21 +591,38 @@ __device__ __forceinline__ void h2_net_body(uint8_t* lds, const H2BlockW& Wt, co
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0l[c]), a, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0h[c]), a, acc, 0, 0, 0);
         }
-        h2_store4(XH, H2_PDX, H2_RSX, row, ntp * 16 + 4 * g, acc * N.s0 + b04);
+        h2_store4(XH, H2_PDX, H2_RSX, row, ntp * 16 + 4 * g, acc * s0 + b04);
     }
     __syncthreads();
     // V80 geometry (SplendorNNet.py:262-283): trunk ReLU + mean squeeze, both heads Hardswish + max squeeze
-    h2_block<1, 0, 1, NW>(lds, Wt, N, B, P, valid, pi_out, v_out, ew, Wp, wg, tid);
-    h2_block<2, 1, 2, NW>(lds, Wp, N, B, P, valid, pi_out, v_out, ew, Wv, wg, tid);
-    h2_block<2, 1, 3, NW>(lds, Wv, N, B, P, valid, pi_out, v_out, ew, Wv, wg, tid);       // (the last prefetch is unused)
+    {
+        const H2WeightsC c1 = h2_opaque(Wc);
+        const H2BlockW Wt = h2_load_const(&c1->Wt), Wp = h2_load_const(&c1->Wp);
+        const H2NetW N = h2_load_const(&c1->N);
+        h2_block<1, 0, 1, NW>(lds, Wt, N, B, P, valid, pi_out, v_out, ew, Wp, wg, tid);
+    }
+    {
+        const H2WeightsC c2 = h2_opaque(Wc);
+        const H2BlockW Wp = h2_load_const(&c2->Wp), Wv = h2_load_const(&c2->Wv);
+        const H2NetW N = h2_load_const(&c2->N);
+        h2_block<2, 1, 2, NW>(lds, Wp, N, B, P, valid, pi_out, v_out, ew, Wv, wg, tid);
+    }
+    {
+        const H2WeightsC c3 = h2_opaque(Wc);
+        const H2BlockW Wv = h2_load_const(&c3->Wv);
+        const H2NetW N = h2_load_const(&c3->N);
+        h2_block<2, 1, 3, NW>(lds, Wv, N, B, P, valid, pi_out, v_out, ew, Wv, wg, tid);   // (the last prefetch is unused)
+    }
 }
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_v80_net_h2(H2BlockW Wt, H2BlockW Wp, H2BlockW Wv, H2NetW N, const int8_t* __restrict__ boards,
-                                                        const uint8_t* __restrict__ valid, int B, int P, float* __restrict__ pi_out,
-                                                        float* __restrict__ v_out) {
+__global__ __launch_bounds__(NW * 64) void k_v80_net_h2(H2Weights W /* first argument: offset 0 of the kernel argument segment; never read
+                                                                        by name (see H2WeightsC) */,
+                                                        const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid, int B, int P,
+                                                        float* __restrict__ pi_out, float* __restrict__ v_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    h2_net_body<NW>(lds, Wt, Wp, Wv, N, boards, valid, B, P, pi_out, v_out, (int)blockIdx.x);
+    const H2WeightsC Wc = (H2WeightsC)__builtin_amdgcn_kernarg_segment_ptr();
+    h2_net_body<NW>(lds, Wc, boards, valid, B, P, pi_out, v_out, (int)blockIdx.x);
 }
 
 }  // namespace azg
