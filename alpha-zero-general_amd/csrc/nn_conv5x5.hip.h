@@ -322,7 +322,9 @@ __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag
 // The two 1x1-convolution heads of the SimpleHead pair (policy: 64 -> 2 channels, value: 64 -> 1; + folded BN + ReLU) on the trunk's
 // f16 x 2 planes: one MFMA column tile (channels 0, 1 = policy, 2 = value, the rest zero), weights split on the fly from the f32
 // matrices Wp [64][2] / Wv [64][1]; wave w owns row tile w (wave 0 the 13th as well).  HP [NS][2 * 25] (channel-major), HV [NS][25].
-template <int NS, bool CM = false>
+// HPT: the policy features feature-major, HP[(c * 25 + cell) * NS + sample] (the policy FC then reads the NS samples of a feature as two
+// float4), instead of HP[sample][c * 25 + cell]
+template <int NS, bool CM = false, bool HPT = false>
 __device__ __forceinline__ void heads1x1_h2(const float* __restrict__ Wp, const float* __restrict__ bp, const float* __restrict__ Wv,
                                             const float* __restrict__ bv, const uint8_t* IN, float* HP, float* HV) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, PB = (ROWS + 2) * 128;
@@ -352,8 +354,8 @@ __device__ __forceinline__ void heads1x1_h2(const float* __restrict__ Wp, const 
         if (g == 0 && r < ROWS) {                           // lanes of g = 0 hold output channels 0..3 of row r
             const float ds = 1.f / (WS * H2_AS);
             const int smp = c5_sample<NS, CM>(r), cell = c5_cell<NS, CM>(r);
-            HP[smp * 50 + cell] = fmaxf(acc[0] * ds + b0, 0.f);
-            HP[smp * 50 + 25 + cell] = fmaxf(acc[1] * ds + b1, 0.f);
+            HP[HPT ? cell * NS + smp : smp * 50 + cell] = fmaxf(acc[0] * ds + b0, 0.f);
+            HP[HPT ? (25 + cell) * NS + smp : smp * 50 + 25 + cell] = fmaxf(acc[1] * ds + b1, 0.f);
             HV[smp * 25 + cell] = fmaxf(acc[2] * ds + b2, 0.f);
         }
     }
@@ -560,9 +562,9 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i] = h2_mma(w[k6][0], w[k6][1], f0.h, f0.m, acc[i]);
                 if constexpr (SL::value.last[sidx]) {          // the fragment's last step of this kernel row: refill with the next row's
-                    const uint4* __restrict__ Wn = ky < 2 ? Wfrag : (WNEXT ? WNEXT : Wfrag);
-                    constexpr int kyn = ky < 2 ? ky + 1 : 0;
-                    w[k6][0] = wfrag(Wn, kyn, k6, 0); w[k6][1] = wfrag(Wn, kyn, k6, 1);
+                    const uint4* __restrict__ Wn = ky < 2 ? Wfrag : (WNEXT ? WNEXT : Wfrag);      // (the trunk's last convolution re-requests its
+                    constexpr int kyn = ky < 2 ? ky + 1 : 0;                                      // own first row: skipping that with a uniform
+                    w[k6][0] = wfrag(Wn, kyn, k6, 0); w[k6][1] = wfrag(Wn, kyn, k6, 1);           // branch measured 307.9 k -> 310.8 k cycles)
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f0 = fn;
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
             C5_PH(20);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the LDS copies of the head / FC matrices (DMA issued at the start)
             __syncthreads();
-            heads1x1_h2<NS, CM>(WST + WST_F1, N.bp, WST + WST_P, N.bv, XP, Y, Y + NS * CP2 * 25);
+            heads1x1_h2<NS, CM, true>(WST + WST_F1, N.bp, WST + WST_P, N.bv, XP, Y, Y + NS * CP2 * 25);
             __syncthreads();
             heads_done = true;
         } else {
@@ -826,7 +828,37 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
             H1[s * 64 + j] = fmaxf(acc, 0.f);
         }
     };
-    if constexpr (NPL == 2 && SPLIT == 2) fcs(WST, WST + WST_FP); else fcs(N.Wfp, N.Wf1);
+    if constexpr (NPL == 2 && SPLIT == 2) {
+        // f16 x 2 kernel: the policy FC with the 50 features split over four thread groups (thread = (K quarter, action), all NS samples of
+        // a feature from two float4 reads of the feature-major HP): 39 LDS reads per thread instead of 200, partial sums combined after a barrier
+        static_assert(NS == 8, "two float4 of samples per feature");
+        constexpr int KF = CP2 * 25, KQ = (KF + 3) / 4;
+        float* const RED = H1 + NS * 64;                     // [4][NS][AS]
+        const float* const Wfp = WST;
+        if (tid < 4 * A) {
+            const int q = tid / A, a = tid - q * A, k1 = min(KF, (q + 1) * KQ);
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            for (int k = q * KQ; k < k1; k++) {
+                const float w = Wfp[k * A + a];
+                a0 += *(const f32x4*)(HP + k * NS) * w;
+                a1 += *(const f32x4*)(HP + k * NS + 4) * w;
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) { RED[(q * NS + s4) * AS + a] = a0[s4]; RED[(q * NS + 4 + s4) * AS + a] = a1[s4]; }
+        }
+        const float* const Wf1 = WST + WST_FP;
+        for (int i = tid; i < NS * 64; i += 768) {
+            const int s = i >> 6, j = i & 63;
+            float acc = N.bf1[j];
+            for (int k = 0; k < 25; k++) acc += HV[s * 25 + k] * Wf1[k * 64 + j];
+            H1[s * 64 + j] = fmaxf(acc, 0.f);
+        }
+        __syncthreads();
+        for (int i = tid; i < NS * A; i += 768) {
+            const int s = i / A, a = i - s * A;
+            LG[s * AS + a] = N.bfp[a] + ((RED[s * AS + a] + RED[(NS + s) * AS + a]) + (RED[(2 * NS + s) * AS + a] + RED[(3 * NS + s) * AS + a]));
+        }
+    } else fcs(N.Wfp, N.Wf1);
     __syncthreads();
     C5_PH(22);
     // masked softmax == exp(log_softmax(where(valid, logits, -1e8))), one wave per sample
