@@ -35,7 +35,7 @@ _lib = None
 
 EXPORTS = [
     'azg_last_error', 'azg_version', 'azg_device_count', 'azg_set_device', 'azg_game_info', 'azg_env_valid_moves',
-    'azg_env_next_state', 'azg_env_game_ended', 'azg_env_canonical', 'azg_env_init_boards', 'azg_env_symmetries', 'azg_env_symmetries_ex', 'azg_debug_poison_onchip', 'azg_stream_create_xcd', 'azg_stream_destroy', 'azg_debug_placement', 'azg_forest_create',
+    'azg_env_next_state', 'azg_env_game_ended', 'azg_env_canonical', 'azg_env_init_boards', 'azg_env_symmetries', 'azg_env_symmetries_ex', 'azg_debug_poison_onchip', 'azg_stream_create_xcd', 'azg_stream_destroy', 'azg_debug_placement', 'azg_eval_hashnet', 'azg_forest_create',
     'azg_forest_destroy', 'azg_forest_device_bytes', 'azg_forest_reset', 'azg_forest_begin_search',
     'azg_forest_select', 'azg_forest_select_fused', 'azg_forest_rounds_v80_h2', 'azg_forest_rounds_profile', 'azg_forest_expand_backup', 'azg_forest_active', 'azg_forest_action_probs',
     'azg_forest_root_stats', 'azg_forest_dump_tree', 'azg_forest_validate', 'azg_selfplay_start', 'azg_selfplay_start_ex', 'azg_selfplay_advance', 'azg_selfplay_active',
@@ -91,6 +91,8 @@ def lib():
     L.azg_stream_create_xcd.argtypes = [i, i, C.POINTER(vp)]
     L.azg_stream_destroy.argtypes = [vp]
     L.azg_debug_placement.argtypes = [i, vp, vp]
+    if hasattr(L, 'azg_eval_hashnet'):
+        L.azg_eval_hashnet.argtypes = [vp, vp, i, i, i, i, vp, vp, vp]
     if hasattr(L, 'azg_forest_set_search_params'):          # (absent from older builds loaded through AZG_LIB for A/B runs)
         L.azg_forest_set_search_params.argtypes = [vp, i, dbl]
     L.azg_nn_linear.argtypes = [vp, i, vp, i, i, vp, vp, i, vp, i, vp, i, i, i, i, i, i, vp]

@@ -234,6 +234,38 @@ extern "C" int azg_debug_placement(int n_workgroups, uint32_t* out_dev, void* st
     return 0;
 }
 
+// The integer hash-net of SURVEY.md Appendix C.3 on the device: the deterministic stand-in for NeuralNet.predict that the parity tests use
+// on both sides (tests/hashnet.py is the same function as torch ops / numpy).  One wave per sample.  Not a product net: it lets the plugin
+// benches time the tree + env side of a game without ~35 tiny torch kernels per round.
+__global__ __launch_bounds__(64) void k_eval_hashnet(const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid, int T, int S, int A, int P,
+                                                     float* __restrict__ pi, float* __restrict__ v) {
+    const int t = blockIdx.x, l = lane_id();
+    if (t >= T) return;
+    const int8_t* b = boards + (size_t)t * S;
+    long long acc = 0;
+    for (int i = l; i < S; i += 64) acc += (long long)b[i] * (long long)(i + 1);
+    const uint64_t s = wave_sum_u64((uint64_t)acc);                               // (two's complement: the low 32 bits of the product are
+    const uint32_t h = (uint32_t)(s * 2654435761ull);                              // torch.remainder(s * 2654435761, 2^32) for negative s too)
+    const uint8_t* va = valid + (size_t)t * A;
+    int wsum = 0;
+    for (int a = l; a < A; a += 64) wsum += va[a] ? 1 + (int)(((h >> 8) + 2654435761u * (uint32_t)a) % 13u) : 0;
+    wsum = wave_sum_i32(wsum);
+    for (int a = l; a < A; a += 64) {
+        const int w = va[a] ? 1 + (int)(((h >> 8) + 2654435761u * (uint32_t)a) % 13u) : 0;
+        pi[(size_t)t * A + a] = (float)((double)w / (double)wsum);
+    }
+    if (l < P) {
+        const float v0 = (float)((double)h / 2147483648.0 - 1.0);
+        v[(size_t)t * P + l] = l == 0 ? v0 : (float)(-(double)v0 / (double)(P - 1));
+    }
+}
+extern "C" int azg_eval_hashnet(const int8_t* boards, const uint8_t* valid, int T, int S, int A, int P, float* pi, float* v, void* stream) {
+    if (!boards || !valid || !pi || !v || T <= 0 || S <= 0 || A <= 0 || P < 2) return fail("azg_eval_hashnet: bad argument");
+    k_eval_hashnet<<<dim3(T), dim3(64), 0, (hipStream_t)stream>>>(boards, valid, T, S, A, P, pi, v);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ---- forest ---------------------------------------------------------------------------------------------------------
 struct azg_forest {
     azg_forest_cfg cfg;

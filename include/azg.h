@@ -205,6 +205,10 @@ int azg_stream_destroy(void* stream);
 /* debug / tests: launch n_workgroups one-wave workgroups on `stream`; out_dev[i] = XCC_ID | cu_id << 8 | se_id << 16 | sh_id << 24 of
    the CU that ran workgroup i */
 int azg_debug_placement(int n_workgroups, uint32_t* out_dev, void* stream);
+/* debug / tests / plugin benches: the integer hash-net of SURVEY.md Appendix C.3 as a leaf evaluator on the device (the deterministic stand-in
+   for NeuralNet.predict, NeuralNet.py:32-43, that the MCTS parity tests run on both sides): boards int8[T][S], valid u8[T][A] ->
+   pi f32[T][A], v f32[T][P], bit-identical to tests/hashnet.py.  Not a product net. */
+int azg_eval_hashnet(const int8_t* boards, const uint8_t* valid, int T, int S, int A, int P, float* pi, float* v, void* stream);
 /* debug / tests: check the structural invariants of every tree on the host; returns the number of violations */
 int azg_forest_validate(azg_forest* f, int verbose);
 

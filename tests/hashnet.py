@@ -42,3 +42,27 @@ class HashNetNumpy:
         a = np.arange(len(valids), dtype=np.int64)
         w = np.asarray(valids).astype(np.int64) * (1 + (((h >> 8) + 2654435761 * a) % (1 << 32)) % 13)
         return (w / w.sum()).astype(np.float32), v
+
+
+class HashNetHip:
+    """the same hash-net evaluated by the engine library (azg_eval_hashnet, one wave per sample): bit-identical to HashNetTorch, one
+    launch instead of ~35 torch kernels -- the evaluator of tools/bench_f4.py --net hashhip"""
+
+    def __init__(self, P):
+        self.P = P
+        self._out = {}
+
+    def predict_batch(self, boards, valids):
+        import ctypes as C
+        from azg_amd import _lib
+        T, A = valids.shape
+        S = boards[0].numel()
+        key = (T, A, boards.device)
+        if key not in self._out:
+            self._out[key] = (torch.empty((T, A), dtype=torch.float32, device=boards.device), torch.empty((T, self.P), dtype=torch.float32, device=boards.device))
+        pi, v = self._out[key]
+        b = boards if boards.is_contiguous() else boards.contiguous()
+        va = valids if valids.dtype == torch.uint8 and valids.is_contiguous() else valids.to(torch.uint8).contiguous()
+        _lib.check(_lib.lib().azg_eval_hashnet(C.c_void_p(b.data_ptr()), C.c_void_p(va.data_ptr()), T, S, A, self.P, C.c_void_p(pi.data_ptr()),
+                                               C.c_void_p(v.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return pi, v

@@ -350,3 +350,21 @@ def test_c3_known_answers_on_the_forest(case):
     qq = q[0].cpu().numpy()
     assert qq[0] == np.float32(Qs) and qq[1] == -np.float32(Qs)
     m.forest.close()
+
+
+@pytest.mark.gpu
+def test_device_hashnet_equals_torch_hashnet():
+    """azg_eval_hashnet (the stand-in evaluator as one engine kernel) == tests/hashnet.py HashNetTorch bit for bit, on random boards of
+    three plugins incl. negative board bytes and a 3-player value vector"""
+    import torch
+    from hashnet import HashNetHip, HashNetTorch
+    gen = torch.Generator().manual_seed(5)
+    for S, A, P, T in ((320, 131, 2, 257), (825, 9, 3, 64), (2310, 428, 2, 33)):
+        boards = torch.randint(-128, 128, (T, S), dtype=torch.int8, generator=gen).cuda()
+        valids = (torch.rand((T, A), generator=gen) < 0.4).to(torch.uint8)
+        valids[:, 0] = 1
+        valids = valids.cuda()
+        pi0, v0 = HashNetTorch(P).predict_batch(boards, valids)
+        pi1, v1 = HashNetHip(P).predict_batch(boards, valids)
+        torch.cuda.synchronize()
+        assert torch.equal(pi0, pi1) and torch.equal(v0, v1)

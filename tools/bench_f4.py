@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from azg_amd import games  # noqa: E402
 from azg_amd.selfplay import SelfPlayEngine  # noqa: E402
-from hashnet import HashNetTorch  # noqa: E402
+from hashnet import HashNetHip, HashNetTorch  # noqa: E402
 
 
 class Args(dict):
@@ -52,7 +52,8 @@ class MlpNet(torch.nn.Module):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--net', default='hash', choices=['hash', 'mlp'], help='leaf evaluator: integer hash-net (torch ops) or MlpNet through TorchModuleEvaluator')
+    ap.add_argument('--net', default='hash', choices=['hash', 'hashhip', 'mlp'],
+                    help='leaf evaluator: integer hash-net as torch ops, the same as one engine kernel (azg_eval_hashnet), or MlpNet through TorchModuleEvaluator')
     ap.add_argument('--md', action='store_true', help='markdown table row instead of JSON')
     ap.add_argument('--games', type=int, default=1024)
     ap.add_argument('--sims', type=int, default=200)
@@ -71,6 +72,8 @@ def main():
             from azg_amd.nnet import TorchModuleEvaluator
             torch.manual_seed(0)
             net = TorchModuleEvaluator(MlpNet(int(g.S), g.A, g.P), g)
+        elif a.net == 'hashhip':
+            net = HashNetHip(g.P)
         else:
             net = HashNetTorch(g.P)
         eng = SelfPlayEngine(g, net, args, n_games=T, node_capacity=max(2048, capf * a.sims), max_examples=T * 256)

@@ -76,13 +76,7 @@ if has sant; then
   python tools/make_traffic_json.py /tmp/pfs/pf_results.db /tmp/pws/pw_results.db $O/traffic_santorini1.json 4096 800 $O/bench_profiled_fetch_santorini1.json > /dev/null
 fi
 if has f4; then
-  {
-  echo '# f4 game plugins on one MI355X (`tools/bench_f4.py --md [--net mlp]`: batched self-play, 200 simulations per move, 20 timed ply waves after 2 of warm-up, HIP-graph rounds)'
-  echo
-  echo '| game | players | state B | actions | games | evaluator | plies/s | M sims/s | ms / round | levels / sim | valid / level | errors | validate | forest GB |'
-  echo '|---|---|---|---|---|---|---|---|---|---|---|---|---|---|'
-  python tools/bench_f4.py --md --plies 20 2>/dev/null
-  python tools/bench_f4.py --md --plies 20 --net mlp 2>/dev/null
-  } > $O/f4_bench.md
+  bash tools/r04_f4ab.sh > /dev/null 2>&1          # -> $O/f4_bench.md: hash (torch ops) / hashhip (one engine kernel) / mlp (TorchModuleEvaluator)
+  for g in smallworld botanik; do python tools/bench_f4.py --md --plies 12 --net hashhip --games 4096 --only $g 2>/dev/null; done >> $O/f4_bench.md
 fi
 ls -la $O | tail -40
