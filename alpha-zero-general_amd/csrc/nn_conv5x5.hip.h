@@ -1124,6 +1124,10 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
             }
             __syncthreads();
             // ---- depthwise 3x3 + BN + ReLU in place: one thread = the 5x5 plane of one (sample, channel) ----
+            // (round 4, f16 x 2 kernel, measured and dropped: one thread per channel PAIR -- dword accesses to the planes, packed f32
+            // multiply-adds, 256 threads instead of 512 -- 415 -> 419 us per 4096 leaves; the GEMM phases' weight fragments and biases
+            // requested one phase ahead -- 411-419 -> 408-415 us, 48 B of spills: neither the 16-bit LDS accesses nor the 60 weight
+            // round trips are what this kernel waits for)
             if (tid < NS * 64) {
                 const int s = tid >> 6, c = tid & 63, ec = blk * E + t * 64 + c;
                 float in[25], w[9];
