@@ -124,7 +124,11 @@ __device__ __forceinline__ f32x4 h2_mma(uint4 wh, uint4 wl, uint4 ah, uint4 al, 
     return acc;
 }
 // weight fragment (tile nt, chunk c, plane p) of a matrix with NCH chunks
-#define H2FRAG(ptr, NCH, nt, c, p) ((ptr)[((((size_t)(nt) * (NCH) + (c)) * 2 + (p)) << 6) + lane])
+// (every weight / bias request goes through an explicitly GLOBAL pointer: the pointers come out of a word-wise copy from the constant
+// address space and are generic to the compiler, which made every request a flat_load -- counted against the LDS counter too)
+typedef uint32_t h2_u32x4 __attribute__((ext_vector_type(4)));
+#define H2G(T, p) ((const __attribute__((address_space(1))) T*)(p))
+#define H2FRAG(ptr, NCH, nt, c, p) __builtin_bit_cast(uint4, H2G(h2_u32x4, ptr)[((((size_t)(nt) * (NCH) + (c)) * 2 + (p)) << 6) + lane])
 
 // ReLU, or 6 * Hardswish = x * clamp(x + 3, 0, 6): the 1/6 is folded into the next linear step (the token-mix weights the host
 // passes for a Hardswish block are Wd / 6; the pooled value and the project operand take it with their plane scale)
@@ -133,6 +137,29 @@ __device__ __forceinline__ f32x4 h2_act6(f32x4 x, int act) {
     const f32x4 t = x + 3.f;
     return x * f32x4{__builtin_amdgcn_fmed3f(t[0], 0.f, 6.f), __builtin_amdgcn_fmed3f(t[1], 0.f, 6.f), __builtin_amdgcn_fmed3f(t[2], 0.f, 6.f),
                      __builtin_amdgcn_fmed3f(t[3], 0.f, 6.f)};
+}
+
+// 6 * Hardswish(x) from x6 = 6 x on the packed-f32 pipe: 6 x * clamp(x / 6 + 1 / 2, 0, 1) = x6 * clamp(x6 / 36 + 1 / 2): one v_pk_fma_f32 with
+// the CLAMP output modifier + one v_pk_mul_f32 per two values, where x * med3(x + 3, 0, 6) takes a packed add, two v_med3_f32 and a packed
+// multiply (the compiler does not fold a clamp into a packed FMA: inline asm).  The factor 6 on the input is free: it goes into the
+// scale and bias of the FMA that produces x.  (Rounding differs from the med3 form in the last bit of the clamp argument.)
+__device__ __forceinline__ f32x2 h2_hswish6_pk(f32x2 x6) {
+    f32x2 t;
+    const f32x2 k = f32x2{1.f / 36.f, 1.f / 36.f};
+    asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,0,0] clamp" : "=v"(t) : "v"(x6), "s"(k));
+    return x6 * t;
+}
+// act(acc * scale + bias) for the block's activation; Hardswish blocks return 6 * Hardswish (see h2_act6)
+template <int ACT>
+__device__ __forceinline__ f32x4 h2_scale_bias_act6(f32x4 acc, f32x4 scale, f32x4 bias) {
+#ifndef AZG_H2_MED3_HSWISH
+    if (ACT == ACT_HSWISH) {
+        const f32x4 x6 = acc * (scale * 6.f) + bias * 6.f;           // (the two constant products are hoisted out of the token loops)
+        const f32x2 a = h2_hswish6_pk(f32x2{x6[0], x6[1]}), b = h2_hswish6_pk(f32x2{x6[2], x6[3]});
+        return f32x4{a[0], a[1], b[0], b[1]};
+    }
+#endif
+    return h2_act6(acc * scale + bias, ACT);
 }
 
 // phase-E operands of one block for this lane (column tile nt of the expand GEMM): requested one phase ahead -- during the
@@ -146,8 +173,8 @@ __device__ __forceinline__ void h2_load_ew(H2EW& e, const H2BlockW& W, int nt, i
 #pragma unroll
     for (int c = 0; c < 2; c++) { e.weh[c] = H2FRAG(W.We, 2, nt, c, 0); e.wel[c] = H2FRAG(W.We, 2, nt, c, 1); }
     const int ch0 = nt * 16 + 4 * g;
-    e.be4 = *(const f32x4*)(W.be + ch0); e.sd4 = *(const f32x4*)(W.sd + ch0); e.bd4 = *(const f32x4*)(W.bd + ch0);
-    e.wdv = W.Wd[lane < 49 ? lane : 0];
+    e.be4 = *H2G(f32x4, W.be + ch0); e.sd4 = *H2G(f32x4, W.sd + ch0); e.bd4 = *H2G(f32x4, W.bd + ch0);
+    e.wdv = H2G(float, W.Wd)[lane < 49 ? lane : 0];
 }
 
 // LDS map (bytes).  X: the tile the three blocks read; O: a head block's output (and the int8 board tile before the first layer);
@@ -227,7 +254,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
                 acc = h2_mma(weh0, wel0, *(const uint4*)(XH + o0), *(const uint4*)(XH + H2_PDX + o0), acc);
                 acc = h2_mma(weh1, wel1, *(const uint4*)(XH + o1), *(const uint4*)(XH + H2_PDX + o1), acc);
             }
-            in[t] = h2_act6(acc * W.se + be4, ACT);
+            in[t] = h2_scale_bias_act6<ACT>(acc, f32x4{W.se, W.se, W.se, W.se}, be4);
             if (t == 0) H2_PH(10);
         }
         H2_PH(11);
@@ -238,8 +265,8 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
             for (int c = 0; c < 2; c++) { w1h[c] = H2FRAG(W.W1, 6, nt1, 2 * kg1 + c, 0); w1l[c] = H2FRAG(W.W1, 6, nt1, 2 * kg1 + c, 1); }
 #pragma unroll
             for (int c = 0; c < 2; c++) { w2h[c] = H2FRAG(W.W2, 2, nt, c, 0); w2l[c] = H2FRAG(W.W2, 2, nt, c, 1); }
-            b24 = *(const f32x4*)(W.b2 + ch0);
-            b14 = *(const f32x4*)(W.b1 + (tid < 192 ? cc1 : 0));
+            b24 = *H2G(f32x4, W.b2 + ch0);
+            b14 = *H2G(f32x4, W.b1 + (tid < 192 ? cc1 : 0));
         }
         f32x4 pool = POOLMAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef AZG_H2_WD_READLANE
@@ -285,7 +312,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
             f32x4 a = wd[0] * in[0];
 #pragma unroll
             for (int l = 1; l < 7; l++) a += wd[l] * in[l];
-            a = h2_act6(a * sd4 + bd4, ACT);
+            a = h2_scale_bias_act6<ACT>(a, sd4, bd4);
             dw[m] = a;
             if (POOLMAX) pool = f32x4{fmaxf(pool[0], a[0]), fmaxf(pool[1], a[1]), fmaxf(pool[2], a[2]), fmaxf(pool[3], a[3])};
             else pool += a;
@@ -294,7 +321,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         if (LEAN) {          // 128-VGPR budget: the fc2 weights only once the token mix has released its 28 input registers
 #pragma unroll
             for (int c = 0; c < 2; c++) { w2h[c] = H2FRAG(W.W2, 2, nt, c, 0); w2l[c] = H2FRAG(W.W2, 2, nt, c, 1); }
-            b24 = *(const f32x4*)(W.b2 + ch0);
+            b24 = *H2G(f32x4, W.b2 + ch0);
         }
         constexpr float ACT_DIV = ACT == ACT_HSWISH ? 6.f : 1.f;                 // dw holds 6 * Hardswish(.)
         h2_store4(PLH, H2_PDP, H2_RSH, r, ch0, pool, H2_AS / ACT_DIV / (POOLMAX ? 1.f : 7.f));
@@ -302,7 +329,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
     auto load_wp = [&]() {
 #pragma unroll
         for (int c = 0; c < 6; c++) { wph[c] = H2FRAG(W.Wp, 6, ntp, c, 0); wpl[c] = H2FRAG(W.Wp, 6, ntp, c, 1); }
-        bp4 = *(const f32x4*)(W.bp + ntp * 16 + 4 * g);
+        bp4 = *H2G(f32x4, W.bp + ntp * 16 + 4 * g);
     };
     // one fc1 unit (column tile nt1, chunk pair kg1): partial sums -> RED1
     auto s1_unit = [&](const uint4 (&w1h)[2], const uint4 (&w1l)[2], int nt1, int kg1) {
@@ -337,7 +364,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         if (wave < 11) phase_e(w1h, w1l, nt1, kg1);
         // project weights: requested when the phase-E arithmetic is done, they land during the SE phases
         if (wave < 4 * PG) load_wp();
-        else bp4 = *(const f32x4*)(W.bp + ntp * 16 + 4 * g);
+        else bp4 = *H2G(f32x4, W.bp + ntp * 16 + 4 * g);
         __syncthreads();
         H2_PH(1);
         if (wave < 9) s1_unit(w1h, w1l, nt1, kg1);           // ---- S1: SE fc1 partial sums (9 waves) -> RED1, then bias + ReLU -> SH ----
@@ -354,7 +381,7 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
     } else if (wave < 11) {
         // role A (16-wave workgroup): the eleven column-tile waves -- E, [S1 runs elsewhere], combine (waves 0..2), S2
         uint4 none_h[2], none_l[2];
-        if (tid < 192) b14 = *(const f32x4*)(W.b1 + cc1);
+        if (tid < 192) b14 = *H2G(f32x4, W.b1 + cc1);
         phase_e(none_h, none_l, 0, 0);
         __syncthreads();
         H2_PH(1);
@@ -395,8 +422,8 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
     constexpr int PRE = LEAN ? 2 : 4;                         // fragments of the first policy Linear requested before the project GEMM
     const bool tailw = wave < 12;                             // the policy tail's first GEMM: 6 column tiles x 2 K halves = 12 waves
     if (MODE == 2) {
-        bt1 = *(const f32x4*)(N.bpi1 + (tid < 384 ? tcol : 0));
-        bt2 = *(const f32x4*)(N.bpi2 + (wave < 6 ? wave : 0) * 16 + 4 * g);
+        bt1 = *H2G(f32x4, N.bpi1 + (tid < 384 ? tcol : 0));
+        bt2 = *H2G(f32x4, N.bpi2 + (wave < 6 ? wave : 0) * 16 + 4 * g);
         if (tailw) {
 #pragma unroll
             for (int cc = 0; cc < PRE; cc++) { wfh[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 0); wfl[cc] = H2FRAG(N.Wpi1, 14, ht_nt, ht_half * 7 + cc, 1); }
@@ -512,11 +539,11 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         if (tid < NS * P) {
             const int s = tid / P, p = tid - s * P, b = b0 + s;
             if (b < B) {
-                float a = N.bv2[p];
+                float a = H2G(float, N.bv2)[p];
                 for (int j = 0; j < P; j++) {
                     float h = 0.f;
                     for (int w = 0; w < 12; w++) h += RED[(w * 16 + s) * 16 + j];
-                    a += fmaxf(h * N.sv1 + N.bv1[j], 0.f) * N.Wv2[j * P + p];
+                    a += fmaxf(h * N.sv1 + H2G(float, N.bv1)[j], 0.f) * H2G(float, N.Wv2)[j * P + p];
                 }
                 v_out[(size_t)b * P + p] = tanhf(a);
             }
@@ -557,7 +584,7 @@ __device__ __forceinline__ void h2_net_body(uint8_t* lds, H2WeightsC Wc, const i
         const H2BlockW Wt = h2_load_const(&c0->Wt);
 #pragma unroll
         for (int c = 0; c < 2; c++) { w0h[c] = H2FRAG(N.W0, 2, ntp, c, 0); w0l[c] = H2FRAG(N.W0, 2, ntp, c, 1); }
-        b04 = *(const f32x4*)(N.b0 + ntp * 16 + 4 * g);
+        b04 = *H2G(f32x4, N.b0 + ntp * 16 + 4 * g);
         s0 = N.s0;
         h2_load_ew(ew, Wt, wave < 11 ? wave : 0, g, lane);   // the trunk block's first operands, behind the board tile and W0
     }
