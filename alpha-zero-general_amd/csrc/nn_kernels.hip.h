@@ -96,14 +96,16 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     if (act == ACT_HSIGMOID) return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
     return x;
 }
-// activation of two packed values: the clamp is one v_med3_f32 per component, the rest packed (v_pk_add / v_pk_mul)
+// activation of two packed values
 __device__ __forceinline__ f32x2 act_apply2(f32x2 x, int act) {
     if (act == ACT_RELU) return f32x2{fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
     if (act == ACT_HSWISH || act == ACT_HSIGMOID) {
-        f32x2 t = x + 3.f;
-        t.x = __builtin_amdgcn_fmed3f(t.x, 0.f, 6.f);
-        t.y = __builtin_amdgcn_fmed3f(t.y, 0.f, 6.f);
-        return act == ACT_HSWISH ? x * t * (1.f / 6.f) : t * (1.f / 6.f);
+        // relu6(x + 3) / 6 == clamp(x / 6 + 1 / 2, 0, 1): ONE packed FMA with the CLAMP output modifier (round 4; was a packed add, a
+        // v_med3_f32 per component and a packed multiply by 1 / 6).  The compiler does not fold a clamp into v_pk_fma_f32: inline asm.
+        f32x2 t;
+        const f32x2 k = f32x2{1.f / 6.f, 1.f / 6.f};
+        asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,0,0] clamp" : "=v"(t) : "v"(x), "s"(k));
+        return act == ACT_HSWISH ? x * t : t;
     }
     return x;
 }
