@@ -94,10 +94,18 @@ __device__ __forceinline__ void h2_fp16_saturate_mode() {
 
 __device__ __forceinline__ void h2_split2(float a, float b, uint32_t& h, uint32_t& l) {
     const f16x2_t hh = __builtin_convertvector(f32x2{a, b}, f16x2_t);            // v_cvt_pk_f16_f32 (round to nearest even)
+    h = __builtin_bit_cast(uint32_t, hh);
+#ifndef AZG_H2_SPLIT_CVT
+    // lo = rn16(x - hi) as ONE mixed-precision FMA per value (f16 source widened on the fly, f16 result written to one half of the
+    // destination): three instructions per pair instead of five (two v_cvt_f32_f16, a packed subtract, a v_cvt_pk_f16_f32); x - hi is
+    // exact in f32 either way, so the bits are the same.  (The compiler turns the C expression back into the five-instruction form.)
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+#else
     const f32x2 back = __builtin_convertvector(hh, f32x2);
     const f16x2_t ll = __builtin_convertvector(f32x2{a - back.x, b - back.y}, f16x2_t);
-    h = __builtin_bit_cast(uint32_t, hh);
     l = __builtin_bit_cast(uint32_t, ll);
+#endif
 }
 // four consecutive channels (ch0 % 4 == 0) of one row -> both planes (PD = byte distance hi plane -> lo plane); o is UNSCALED
 __device__ __forceinline__ void h2_store4(uint8_t* hi, int PD, int RS, int row, int ch0, f32x4 o, float mul = H2_AS) {
