@@ -481,9 +481,8 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
             if (RES) {
                 typedef uint64_t __attribute__((address_space(3))) lds_u64;
                 const uint64_t hv = *(const lds_u64*)(uintptr_t)(res0 + off), lv = *(const lds_u64*)(uintptr_t)(res0 + off + (uint32_t)PB);
-                const f32x2 h0 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, (uint32_t)hv), f32x2), h1 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, (uint32_t)(hv >> 32)), f32x2);
-                const f32x2 l0 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, (uint32_t)lv), f32x2), l1 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, (uint32_t)(lv >> 32)), f32x2);
-                o += f32x4{h0.x + l0.x, h0.y + l0.y, h1.x + l1.x, h1.y + l1.y} * H2_IAS;          // == h2_load4
+                const f32x2 ra = h2_join2((uint32_t)hv, (uint32_t)lv), rb = h2_join2((uint32_t)(hv >> 32), (uint32_t)(lv >> 32));
+                o += f32x4{ra.x, ra.y, rb.x, rb.y} * H2_IAS;                                         // == h2_load4
             }
 #ifdef AZG_C5_EPI_GSTORE
             if (row[i] < ROWS) h2_store4(OUT, PB, 128, row[i], ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});

@@ -117,12 +117,23 @@ __device__ __forceinline__ void h2_store4(uint8_t* hi, int PD, int RS, int row, 
     *(uint2*)dst = make_uint2(h0, h1);
     *(uint2*)(dst + PD) = make_uint2(l0, l1);
 }
+// hi + lo of a packed pair of f16 x 2 values as f32: one mixed-precision FMA per value (f32(hi) * 1 + f32(lo); was two conversions and
+// half a packed add per value; hi + lo is exact in f32 either way)
+__device__ __forceinline__ f32x2 h2_join2(uint32_t h, uint32_t l) {
+#ifndef AZG_H2_SPLIT_CVT
+    f32x2 r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r.x) : "v"(h), "v"(l));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r.y) : "v"(h), "v"(l));
+    return r;
+#else
+    return __builtin_convertvector(__builtin_bit_cast(f16x2_t, h), f32x2) + __builtin_convertvector(__builtin_bit_cast(f16x2_t, l), f32x2);
+#endif
+}
 __device__ __forceinline__ f32x4 h2_load4(const uint8_t* hi, int PD, int RS, int row, int ch0) {
     const uint8_t* src = hi + h2_off(row, ch0 >> 3, RS) + ((ch0 & 4) << 1);
     const uint2 h = *(const uint2*)src, l = *(const uint2*)(src + PD);
-    const f32x2 h0 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, h.x), f32x2), h1 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, h.y), f32x2);
-    const f32x2 l0 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, l.x), f32x2), l1 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, l.y), f32x2);
-    return f32x4{h0.x + l0.x, h0.y + l0.y, h1.x + l1.x, h1.y + l1.y} * H2_IAS;
+    const f32x2 a = h2_join2(h.x, l.x), b = h2_join2(h.y, l.y);
+    return f32x4{a.x, a.y, b.x, b.y} * H2_IAS;
 }
 // acc += W * A for one K chunk of 32: the three products of relative weight >= 2^-11, smallest first
 __device__ __forceinline__ f32x4 h2_mma(uint4 wh, uint4 wl, uint4 ah, uint4 al, f32x4 acc) {
