@@ -464,43 +464,24 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
         typedef u32x2_t __attribute__((address_space(3))) lds_u2;
         auto epilogue_cm = [&](auto I, auto rg_tag) {
             constexpr int i = decltype(I)::value, rt = c5_tile_of<CM>(decltype(rg_tag)::value, i);
-#ifdef AZG_C5_EPI_GENERIC
-            if (row[i] < ROWS) {
-                f32x4 o = acc[i] * descale + f32x4{b.x, b.y, b.z, b.w};
-                if (RES) o += h2_load4(RES, PB, 128, row[i], ct * 16 + 4 * g);
-                h2_store4(OUT, PB, 128, row[i], ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});
-            }
-            return;
-#endif
             const uint32_t off = (uint32_t)pl_off(row[i], 2 * ct + (g >> 1)) + (uint32_t)((g & 1) << 3);
-            f32x4 o = acc[i] * descale + f32x4{b.x, b.y, b.z, b.w};
-#ifdef AZG_C5_EPI_GRES
-            if (RES) o += h2_load4(RES, PB, 128, row[i], ct * 16 + 4 * g);
-            else
-#endif
+            // (everything in units of the planes' scale: `bias` holds 64 b, the accumulator is brought back by 64 * descale, the residual
+            // is taken as stored -- scaling by 2^6 commutes with every rounding here, the bits are those of relu(acc * descale + b + res) * 64)
+            f32x4 o = acc[i] * (descale * H2_AS) + f32x4{b.x, b.y, b.z, b.w};
             if (RES) {
                 typedef uint64_t __attribute__((address_space(3))) lds_u64;
                 const uint64_t hv = *(const lds_u64*)(uintptr_t)(res0 + off), lv = *(const lds_u64*)(uintptr_t)(res0 + off + (uint32_t)PB);
                 const f32x2 ra = h2_join2((uint32_t)hv, (uint32_t)lv), rb = h2_join2((uint32_t)(hv >> 32), (uint32_t)(lv >> 32));
-                o += f32x4{ra.x, ra.y, rb.x, rb.y} * H2_IAS;                                         // == h2_load4
+                o += f32x4{ra.x, ra.y, rb.x, rb.y};                                                  // == 64 * h2_load4
             }
-#ifdef AZG_C5_EPI_GSTORE
-            if (row[i] < ROWS) h2_store4(OUT, PB, 128, row[i], ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});
-            return;
-#endif
-            o = f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)} * H2_AS;
+            o = f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
             uint32_t h0, l0, h1, l1;
             h2_split2(o[0], o[1], h0, l0);
             h2_split2(o[2], o[3], h1, l1);
             const uint32_t dst = out0 + off;
             if (2 * rt + 1 < 25 || in_a) {                                                         // (rows >= ROWS of the 13th tile: no store)
-#ifdef AZG_C5_EPI_PTR
-                *(uint2*)(OUT + off) = make_uint2(h0, h1);
-                *(uint2*)(OUT + off + PB) = make_uint2(l0, l1);
-#else
                 *(lds_u2*)(uintptr_t)dst = u32x2_t{h0, h1};
                 *(lds_u2*)(uintptr_t)(dst + (uint32_t)PB) = u32x2_t{l0, l1};
-#endif
             }
         };
         auto run = [&](auto nt_tag, auto rg_tag) {
@@ -699,7 +680,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     // global load below the main loop's scheduling barriers: 1-2 k cycles of every convolution)
     float* const BL = smem;
     static_assert(LEAD == 0 || 2 * NB * 64 * 4 <= LEAD, "bias vectors in the LDS lead");
-    if (LEAD && tid < 2 * NB * 64) BL[tid] = N.bc[tid];
+    if (LEAD && tid < 2 * NB * 64) BL[tid] = N.bc[tid] * H2_AS;          // (64 b: the epilogue works in the planes' units)
     // (the small operands of the last phases -- head / FC biases, the value head's second matrix, the valid masks -- copied here as well:
     // 307.9 k -> 312.3 k cycles per launch, dropped: their global loads are not what the 1x1 heads / FC / softmax phases wait for)
     __syncthreads();
