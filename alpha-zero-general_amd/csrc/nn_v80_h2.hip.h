@@ -129,11 +129,11 @@ __device__ __forceinline__ f32x2 h2_join2(uint32_t h, uint32_t l) {
     return __builtin_convertvector(__builtin_bit_cast(f16x2_t, h), f32x2) + __builtin_convertvector(__builtin_bit_cast(f16x2_t, l), f32x2);
 #endif
 }
-__device__ __forceinline__ f32x4 h2_load4(const uint8_t* hi, int PD, int RS, int row, int ch0) {
+__device__ __forceinline__ f32x4 h2_load4(const uint8_t* hi, int PD, int RS, int row, int ch0, float mul = H2_IAS) {
     const uint8_t* src = hi + h2_off(row, ch0 >> 3, RS) + ((ch0 & 4) << 1);
     const uint2 h = *(const uint2*)src, l = *(const uint2*)(src + PD);
     const f32x2 a = h2_join2(h.x, l.x), b = h2_join2(h.y, l.y);
-    return f32x4{a.x, a.y, b.x, b.y} * H2_IAS;
+    return f32x4{a.x, a.y, b.x, b.y} * mul;
 }
 // acc += W * A for one K chunk of 32: the three products of relative weight >= 2^-11, smallest first
 __device__ __forceinline__ f32x4 h2_mma(uint4 wh, uint4 wl, uint4 ah, uint4 al, f32x4 acc) {
@@ -373,8 +373,9 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         }
         const f32x4 y = acc * W.s2 + b24;
         const f32x4 sc = f32x4{hardsigmoid(y[0]), hardsigmoid(y[1]), hardsigmoid(y[2]), hardsigmoid(y[3])};
+        const f32x4 scm = sc * (H2_AS / (ACT == ACT_HSWISH ? 6.f : 1.f));                   // (the plane scale goes into the SE scale once)
 #pragma unroll
-        for (int t = 0; t < 7; t++) h2_store4(HH, H2_PDH, H2_RSH, t * 16 + r, ch0, dw[t] * sc, H2_AS / (ACT == ACT_HSWISH ? 6.f : 1.f));
+        for (int t = 0; t < 7; t++) h2_store4(HH, H2_PDH, H2_RSH, t * 16 + r, ch0, dw[t] * scm, 1.f);
     };
 
     if (!LEAN) {
@@ -471,8 +472,9 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
                 a1 = h2_mma(wph[c + 1], wpl[c + 1], *(const uint4*)(HH + o1), *(const uint4*)(HH + H2_PDH + o1), a1);
             }
             const int col0 = ntp * 16 + 4 * g;
-            const f32x4 o4 = (a0 + a1) * W.sp + bp4 + h2_load4(XH, H2_PDX, H2_RSX, row, col0);
-            h2_store4(MODE == 1 ? XH : OH, H2_PDX, H2_RSX, row, col0, o4);       // (columns 56..63: zero weights + zero bias + zero x)
+            // (in the planes' units: 64 * sp, 64 * bias, the residual as stored -- the bits of ((a0 + a1) * sp + bias + x) * 64)
+            const f32x4 o4 = (a0 + a1) * (W.sp * H2_AS) + bp4 * H2_AS + h2_load4(XH, H2_PDX, H2_RSX, row, col0, 1.f);
+            h2_store4(MODE == 1 ? XH : OH, H2_PDX, H2_RSX, row, col0, o4, 1.f);  // (columns 56..63: zero weights + zero bias + zero x)
         }
     }
     if (MODE == 2 && tailw) {                                 // the rest of the first policy Linear's fragments (the project fragments are dead)
