@@ -249,6 +249,7 @@ extern "C" int azg_nn_debug_phase_times(long long* out /* [4][16] */) {
 extern "C" int azg_nn_debug_phase_times_c5(long long* out /* [32] */) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c5_phase), sizeof(long long) * 32));
+    HIPCHK(hipMemcpyFromSymbol(out + 28, HIP_SYMBOL(g_c5_first), sizeof(long long) * 3));      // stamps inside the first convolution
     return 0;
 }
 extern "C" int azg_nn_debug_phase_times_h2(long long* out /* [4][16] */) {

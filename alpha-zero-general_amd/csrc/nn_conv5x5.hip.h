@@ -268,10 +268,20 @@ __device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wf
 // The first convolution on one f16 MFMA chunk: K = 9 taps x 2 board planes = 18 of the 32 (k = 2 * tap + plane).  The board values are
 // small integers (exact in f16, no lo half), the weights split hi + lo on the fly from the f32 fragments: two v_mfma_f32_16x16x32_f16 per
 // row tile instead of eighteen v_mfma_f32_16x16x4_f32 (a sixteenth of the rate each).  Output written as f16 x 2 planes.
+#ifdef AZG_NN_PHASE_TIMES
+static __device__ long long g_c5_first[8];
+#define C5F_PH(k) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_c5_first[k] = clock64(); } while (0)
+#else
+#define C5F_PH(k) do { } while (0)
+#endif
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 // `prefetch` is called once this convolution's own weights are requested: whatever it asks for travels behind them and lands during
 // the tile loop (which only touches LDS) instead of delaying the first MFMAs
-template <int NS, bool RELU = true, class Prefetch = NoPrefetch, bool CM = false>
+// WLDS: Wfrag points to the compact LDS copy [4 ct][9 taps][16 output channels][2 board planes] made at kernel start (and `bias` to LDS
+// as well): the gather from the padded f32 fragment array in global memory (8 dword loads per lane, 128 cache lines per wave) and the bias
+// behind the prefetch made this convolution as long as a trunk convolution (4.2 k cycles until the weights had arrived, 4.9 k in the tile
+// loop waiting for 16 bytes of bias)
+template <int NS, bool RELU = true, class Prefetch = NoPrefetch, bool CM = false, bool WLDS = false>
 __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag, const float* __restrict__ bias,
                                                  const float* IN, uint8_t* OUT, Prefetch prefetch = Prefetch()) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 2) * 128;
@@ -279,12 +289,14 @@ __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
     uint4 wh, wl;
+    C5F_PH(0);
     {
         float wv[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int tap = 4 * g + (j >> 1);
-            wv[j] = tap < 9 ? Wfrag[((((size_t)ct * 9 + tap) * 64 + r16) << 2) + (j & 1)] : 0.f;
+            if (WLDS) wv[j] = tap < 9 ? Wfrag[(((ct * 9 + tap) * 16 + r16) << 1) + (j & 1)] : 0.f;
+            else wv[j] = tap < 9 ? Wfrag[((((size_t)ct * 9 + tap) * 64 + r16) << 2) + (j & 1)] : 0.f;
         }
         prefetch();
 #pragma unroll
@@ -292,6 +304,7 @@ __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag
         h2_split2(wv[0], wv[1], wh.x, wl.x); h2_split2(wv[2], wv[3], wh.y, wl.y);
         h2_split2(wv[4], wv[5], wh.z, wl.z); h2_split2(wv[6], wv[7], wh.w, wl.w);
     }
+    C5F_PH(1);
     const float4 b = *(const float4*)(bias + ct * 16 + 4 * g);
     __builtin_amdgcn_sched_barrier(0);                      // (keeps the prefetch requests behind this convolution's own)
 #pragma unroll
@@ -317,6 +330,7 @@ __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag
             h2_store4(OUT, PB, 128, r, ct * 16 + 4 * g, o);
         }
     }
+    C5F_PH(2);
 }
 
 // The two 1x1-convolution heads of the SimpleHead pair (policy: 64 -> 2 channels, value: 64 -> 1; + folded BN + ReLU) on the trunk's
@@ -679,8 +693,14 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     // convolution's epilogue reads its bias from LDS instead of waiting out an L2 round trip behind its last MFMA (the compiler kept the
     // global load below the main loop's scheduling barriers: 1-2 k cycles of every convolution)
     float* const BL = smem;
-    static_assert(LEAD == 0 || 2 * NB * 64 * 4 <= LEAD, "bias vectors in the LDS lead");
+    static_assert(LEAD == 0 || (2 * NB + 1) * 64 * 4 <= LEAD, "bias vectors in the LDS lead");
     if (LEAD && tid < 2 * NB * 64) BL[tid] = N.bc[tid] * H2_AS;          // (64 b: the epilogue works in the planes' units)
+    // ... and the first convolution's operands: its bias behind the trunk's, the 1152 weights that are not zero padding (of the 9216 of
+    // the f32 fragment array) compactly behind the f32 staging tile -- requested here, they arrive while the boards are staged
+    float* const W0L = Y + ROWS * CS;                        // [4 ct][9 taps][16][2]
+    static_assert(!LEAD || (ROWS * CS + 4 * 9 * 16 * 2) * 4 <= 65536, "compact first-convolution weights behind the staging tile");
+    if (LEAD && tid < 4 * 9 * 16) *(float2*)(W0L + 2 * tid) = *(const float2*)(N.W0 + (((size_t)(tid >> 4) * 64 + (tid & 15)) << 2));
+    if (LEAD && tid >= 704 && tid < 768) BL[2 * NB * 64 + tid - 704] = N.b0[tid - 704];
     // (the small operands of the last phases -- head / FC biases, the value head's second matrix, the valid masks -- copied here as well:
     // 307.9 k -> 312.3 k cycles per launch, dropped: their global loads are not what the 1x1 heads / FC / softmax phases wait for)
     __syncthreads();
@@ -722,7 +742,7 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
                 dma(N.Wfp, 0, WST_FP * 4); dma(N.Wf1, WST_FP, (WST_F1 - WST_FP) * 4); dma(N.Wp, WST_F1, (WST_P - WST_F1) * 4);
                 dma(N.Wv, WST_P, (WST_N - WST_P) * 4);
             };
-            conv3x3_first_h2<NS, true, decltype(pf_lambda), CM>(N.W0, N.b0, Y, XP, pf_lambda);
+            conv3x3_first_h2<NS, true, decltype(pf_lambda), CM, true>(W0L, BL + 2 * NB * 64, Y, XP, pf_lambda);
         } else conv3x3_first_split<NS, true, NPL>(N.W0, N.b0, Y, XP);   // (Y still holds the f32 board staging tile)
         __syncthreads();
         C5_PH(2);

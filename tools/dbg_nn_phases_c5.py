@@ -24,3 +24,4 @@ for k in sorted(names):
     prev = t[k]
 print('total', t[23] - t[0])
 print('last convolution, wave 0 (5 row tiles): prologue (tap masks, weights) %d  main loop %d  epilogue %d  barrier %d' % (t[25] - t[24], t[26] - t[25], t[27] - t[26], t[7] - t[27]))
+print('first convolution, wave 0: from the phase start to its own start %d  weights arrive + split %d  tile loop %d  to the barrier %d' % (t[28] - t[1], t[29] - t[28], t[30] - t[29], t[2] - t[30]))
