@@ -386,7 +386,14 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         const f32x4 sc = f32x4{hardsigmoid(y[0]), hardsigmoid(y[1]), hardsigmoid(y[2]), hardsigmoid(y[3])};
         const f32x4 scm = sc * (H2_AS / (ACT == ACT_HSWISH ? 6.f : 1.f));                   // (the plane scale goes into the SE scale once)
 #pragma unroll
-        for (int t = 0; t < 7; t++) h2_store4(HH, H2_PDH, H2_RSH, t * 16 + r, ch0, dw[t] * scm, 1.f);
+        for (int t = 0; t < 7; t++) {
+#ifndef AZG_H2_NO_EPRIO          /* (the same ladder through the seven split-and-store steps: +0.2 %) */
+            if (t == 0) __builtin_amdgcn_s_setprio(2);
+            if (t == 3) __builtin_amdgcn_s_setprio(1);
+            if (t == 6) __builtin_amdgcn_s_setprio(0);
+#endif
+            h2_store4(HH, H2_PDH, H2_RSH, t * 16 + r, ch0, dw[t] * scm, 1.f);
+        }
     };
 
     if (!LEAN) {
@@ -471,7 +478,8 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
 
     // ---- P: project GEMM + BN + residual -> X (trunk, in place: a lane rewrites the cells it read) or O (heads) ----
     if (wave < 4 * PG) {
-        // (seven row tiles over PG = 3 waves of a SIMD; raising the issue priority of the wave that has three of them: 74.5 -> 74.3 k, dropped)
+        // (seven row tiles over PG = 3 waves of a SIMD; raising the issue priority of the wave that has three of them: 74.5 -> 74.3 k,
+        // a priority that falls tile by tile: 76.3 -> 75.6 k -- both dropped)
 #pragma unroll 1
         for (int rt = rt0; rt < 7; rt += PG) {
             const int row = rt * 16 + r;
