@@ -274,6 +274,8 @@ struct azg_forest {
     size_t bytes;
     std::vector<void*> allocs;
     const uint8_t* last_leaf_valid = nullptr;   // valid masks written by the last azg_forest_select (read by expand_backup)
+    struct Attached { std::string key; void* obj; void (*deleter)(void*); };
+    std::vector<Attached> attached;             // azg_forest_attach (azg_host.h): round-kernel state owned by this forest
     // timing
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
@@ -412,8 +414,16 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     return azg_forest_reset(f, nullptr);
 }
 
+void azg_forest_attach(azg_forest* f, const char* key, void* obj, void (*deleter)(void*)) { f->attached.push_back({key, obj, deleter}); }
+void* azg_forest_attached(azg_forest* f, const char* key) {
+    for (auto& a : f->attached) if (a.key == key) return a.obj;
+    return nullptr;
+}
+
 extern "C" int azg_forest_destroy(azg_forest* f) {
     if (!f) return 0;
+    if (!f->attached.empty()) (void)hipDeviceSynchronize();      // (a round kernel may still be reading its argument block)
+    for (auto& a : f->attached) if (a.deleter) a.deleter(a.obj);
     for (void* p : f->allocs) (void)hipFree(p);
     for (int k = 0; k < 2; k++)
         for (auto& pr : f->ev[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

@@ -1,0 +1,509 @@
+// azg_async.hip.h -- (included at the end of azg_nn.hip) the ASYNCHRONOUS TREE PIPELINE: games search while other games sit in the net.
+//
+// What the reference does (Coach.py:117-144, GenericNNetWrapper.py:122-157): N game threads share one inference server through a lock ring --
+// a game that has reached a leaf waits for the batch, the others keep searching.  The two-kernel round of this engine (k_select ->
+// k_v80_net_h2) has a LAUNCH-WIDE boundary instead: all T trees descend, the grid drains (the median descent wave is done
+// after 19 us, the launch after 32-36), all T leaves go through the net, the grid drains.  Round 4 measured every barriered form of overlap
+// (stream groups, XCD pinning, the per-CU round kernel) and none won.  Here there is no boundary wider than one tree:
+//
+//   * k_async_select: `n_sel` persistent 16-wave workgroups.  Workgroup g OWNS trees g, g + n_sel, g + 2 n_sel, ... for the whole launch
+//     (so everything a tree keeps in HBM is only ever touched from ONE CU: plain loads / stores stay coherent through that CU's L1 and its
+//     XCD's L2 -- no fence per hand-over, which would cost a whole-L1 invalidate / a whole-L2 write-back each, MI355X_MICROARCH.md).  A free
+//     wave claims one of the workgroup's READY trees (ready word per tree in HBM, claim bit in LDS), runs select_tree -- the expansion +
+//     backup of the tree's evaluated leaf, then the next descent: the same device function as k_select -- and pushes the new leaf on the
+//     LEAF RING.
+//   * k_async_net: `n_net` persistent 12-wave workgroups, each the V80 forward of k_v80_net_h2<12> (168 VGPRs, 156 KB LDS: one per CU).
+//     A workgroup claims up to 16 leaves from the ring (16 when there are 16; what is there after `batch_wait` of waiting), evaluates
+//     them, writes pi / v at the TREES' rows and marks the 16 trees ready.
+//   Both kernels are resident at the same time on two streams; a select workgroup (16 waves x <= 128 VGPRs = every VGPR of its CU) and a
+//   net workgroup (504 of a SIMD's 512 VGPRs) can never share a CU, so n_sel + n_net <= CUs makes every workgroup resident whatever the
+//   order of dispatch -- the CU partition round 4 could not get from CU masks falls out of occupancy.
+//   Every tree runs `rounds` (descent, forward) pairs per launch, then waits for the launch to end (k_selfplay_advance runs between
+//   launches, at the cadence the two-kernel rounds have).  Per tree the sequence of select_tree calls and the pi / v each one sees are
+//   those of the two-kernel rounds, so results are identical bit for bit (tests/test_gpu_selfplay.py); nothing depends on which leaves
+//   share a forward (rows of the MFMA tiles are independent).
+//
+// Hand-over protocol (MI355X: 8 XCDs with private L2s, per-CU L1s that other CUs' stores never refresh; cdna_hip_programming.md G16):
+//   payload that crosses CUs -- the leaf record (state + valid bit mask), pi, v -- is stored WRITE-THROUGH (relaxed agent-scope atomic
+//   stores = `global_store ... sc1`) by the producer, every storing wave drains (`s_waitcnt vmcnt(0)`), then ONE lane publishes the
+//   queue word (agent-scope atomic); the consumer polls that word relaxed and reads the payload with agent-scope loads (past its L1).
+//   No fence anywhere.  Queue words: ring entries carry a lap tag (never reset), ready words are owned by one select workgroup.
+//   Every spin loop is bounded: past `timeout_ticks` of the 100 MHz wall clock a wave sets ctl->abort (everyone leaves) and error bit
+//   ERR_ASYNC_TIMEOUT on tree 0 -- a pipeline that cannot make progress (a workgroup not resident) fails loudly instead of hanging.
+#pragma once
+#include "azg_fused.hip.h"
+
+namespace azg {
+
+constexpr uint32_t ERR_ASYNC_TIMEOUT = 128;
+constexpr int ASYNC_RS = 128;                 // ready words per select workgroup (trees per workgroup <= 128: two ballots)
+constexpr int ASYNC_NPROF = 96;
+
+struct AsyncCtl {                              // zeroed by the host before every launch; hot words on lines of their own
+    uint32_t leaf_tail; uint32_t pad0[31];     // leaf tickets issued (producers: descent waves)
+    uint32_t leaf_head; uint32_t pad1[31];     // leaf tickets claimed (consumers: net workgroups)
+    uint32_t retired; uint32_t abort; uint32_t pad2[30];   // trees that are done with this launch; != 0: leave now (1 select, 2 net, 3 ring)
+};
+
+// profile counters (accumulated over launches, wall-clock ticks of 10 ns):
+//  0 select_tree calls   1 ticks inside them        2 ticks a descent wave spent looking for a ready tree
+//  3 net batches         4 leaves in them           5 ticks inside the forward    6 ticks a net workgroup spent waiting for leaves
+//  7 sum of (leaf claimed - leaf pushed)            8 sum of (tree claimed - tree marked ready)
+//  9 launches           10 select workgroup-ticks resident   11 net workgroup-ticks resident
+// 12 n_sel  13 n_net (filled by the host)   14 shader-clock cycles inside the forwards   15 inside the descents
+// 32..63 histogram of the leaf wait in us (last bucket: >= 31)    64..95 histogram of the ready wait
+struct AsyncArgs {
+    ForestDev F;
+    H2Weights W;
+    int8_t* aleaf; uint8_t* leaf_valid; uint8_t* needs_eval; float* pi; float* v;
+    AsyncCtl* ctl; uint32_t* ring; uint32_t* ready; uint32_t* ts_leaf; uint32_t* ts_ready;
+    unsigned long long* prof;
+    unsigned long long* wginfo;                // [n_sel + n_net][4]: where the workgroup ran (XCC | cu << 8 | se << 16 | sh << 24), role, calls, busy shader cycles
+    int noise, rounds, n_sel, ring_bits, batch_wait, timeout_ticks;
+};
+__device__ __forceinline__ uint32_t where_am_i() {
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));              // HW_REG_XCC_ID
+    asm volatile("s_getreg_b32 %0, hwreg(4, 0, 32)" : "=s"(hw));               // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+    return (xcc & 0xFu) | (((hw >> 8) & 0xFu) << 8) | (((hw >> 13) & 0x7u) << 16) | (((hw >> 12) & 1u) << 24);
+}
+typedef const AsyncArgs __attribute__((address_space(4))) * AsyncArgsC;
+
+__device__ __forceinline__ uint32_t aload(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void astore(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t wall32() { return (uint32_t)wall_clock64(); }
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// LDS control block of a select workgroup
+struct AsyncSelLds {
+    unsigned long long claimed[2];             // bit i: tree i of this workgroup is being handled by one of its waves
+    unsigned long long seen[2];                // bit i: the last poll of the ready words (by the scout wave) found tree i ready
+    uint32_t retired;                          // trees of this workgroup that are done with the launch
+    uint32_t cursor;                           // rotating start of the scan (fairness)
+    uint32_t scout;                            // 1: a wave is polling the ready words in HBM (ONE poller per CU; the other idle waves watch `seen`)
+    uint32_t pad;
+    unsigned long long prof[5];                // calls, busy ticks, idle ticks, ready-wait sum, shader cycles inside the descents
+    uint32_t hist[32];
+};
+
+template <class G>
+__global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    using RL = RoundLds<G>;
+    AsyncSelLds* const C = (AsyncSelLds*)(lds + 16 * RL::STRIDE);
+    const int g = (int)blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t t_begin = wall32();
+    int n_g, n_sel, rounds, timeout;
+    uint32_t* my_ready;
+    {
+        const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+        n_sel = A->n_sel; rounds = A->rounds; timeout = A->timeout_ticks;
+        const int T = A->F.T;
+        n_g = g < T ? (T - g + n_sel - 1) / n_sel : 0;
+        my_ready = A->ready + (size_t)g * ASYNC_RS;
+        // every tree of this workgroup starts the launch ready, with `rounds` pairs to go (ready word = pairs left + 1)
+        const int i = (int)threadIdx.x;
+        if (i < ASYNC_RS) astore(my_ready + i, i < n_g ? (uint32_t)rounds + 1u : 0u);
+        if (i < n_g) astore(A->ts_ready + (g + i * n_sel), t_begin);
+        if (i == 0) {
+            C->claimed[0] = C->claimed[1] = 0ull; C->retired = 0u; C->cursor = 0u; C->scout = 0u; C->prof[0] = C->prof[1] = C->prof[2] = C->prof[3] = C->prof[4] = 0ull;
+            C->seen[0] = n_g >= 64 ? ~0ull : (1ull << n_g) - 1ull;             // every tree starts ready
+            C->seen[1] = n_g >= 128 ? ~0ull : n_g > 64 ? (1ull << (n_g - 64)) - 1ull : 0ull;
+        }
+        if (i < 32) C->hist[i] = 0u;
+        drain_vmem();
+    }
+    __syncthreads();
+    uint8_t* const mine = lds + wave * RL::STRIDE;
+    typename RL::Smem& sm = *(typename RL::Smem*)mine;
+    float* const dense = (float*)(mine + RL::DENSE_OFF);
+    uint32_t idle_since = wall32();                 // (profile sums live in the LDS block: nothing but this word is carried around the loop)
+#pragma unroll 1
+    for (;;) {
+        const int l = lane_id();
+        if (__hip_atomic_load(&C->retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)n_g) break;
+        // ---- look for a ready tree of this workgroup that no wave is handling: in the LDS copy of the ready words first ----
+#define AZG_LDS_LD64(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+        unsigned long long c0 = AZG_LDS_LD64(&C->seen[0]) & ~AZG_LDS_LD64(&C->claimed[0]);
+        unsigned long long c1 = AZG_LDS_LD64(&C->seen[1]) & ~AZG_LDS_LD64(&C->claimed[1]);
+        if (!(c0 | c1)) {
+            // nothing known to be ready: ONE wave of the workgroup (the scout) polls the ready words in HBM, the others sleep on the LDS copy
+            uint32_t got = 0u;
+            if (l == 0) got = __hip_atomic_exchange(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u ? 1u : 0u;
+            if (!uni_u32(got)) { __builtin_amdgcn_s_sleep(16); continue; }
+            const uint32_t v0 = l < n_g ? aload(my_ready + l) : 0u;
+            const uint32_t v1 = l + 64 < n_g ? aload(my_ready + 64 + l) : 0u;
+            const unsigned long long r0 = __ballot(v0 != 0u), r1 = __ballot(v1 != 0u);
+            if (l == 0) {
+                __hip_atomic_store(&C->seen[0], r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&C->seen[1], r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            c0 = r0 & ~AZG_LDS_LD64(&C->claimed[0]);
+            c1 = r1 & ~AZG_LDS_LD64(&C->claimed[1]);
+            bool leave = false;
+            if (!(c0 | c1)) {
+                const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+                const uint32_t now = wall32();
+                if (uni_u32(aload(&A->ctl->abort))) leave = true;
+                else if ((int)(now - t_begin) > timeout) {
+                    if (l == 0) { astore(&A->ctl->abort, 1u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT); }
+                    leave = true;
+                }
+                if (leave && l == 0) __hip_atomic_store(&C->retired, 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // everyone out
+                if (!leave) __builtin_amdgcn_s_sleep(8);
+            }
+            if (l == 0) __hip_atomic_store(&C->scout, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (leave) break;
+            if (!(c0 | c1)) continue;
+        }
+        // the first candidate at or after the rotating cursor
+        const uint32_t cur = __hip_atomic_load(&C->cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 127u;
+        const unsigned long long m0 = cur < 64u ? c0 & (~0ull << cur) : 0ull, m1 = cur < 64u ? c1 : c1 & (~0ull << (cur - 64u));
+        int i;
+        if (m0) i = __builtin_ctzll(m0);
+        else if (m1) i = 64 + __builtin_ctzll(m1);
+        else if (c0) i = __builtin_ctzll(c0);
+        else i = 64 + __builtin_ctzll(c1);
+        const unsigned long long bit = 1ull << (i & 63);
+        unsigned long long old = 0ull;
+        if (l == 0) {
+            old = __hip_atomic_fetch_or(&C->claimed[i >> 6], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&C->cursor, (uint32_t)i + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (uni_u32((uint32_t)((old & bit) != 0ull))) continue;            // another wave of this workgroup was faster
+        // the claim is ours: read the word again (a wave that handled the tree since our poll cleared it BEFORE it released the claim)
+        const uint32_t word = uni_u32(aload(my_ready + i));
+        if (word == 0u) {                                                  // (a stale bit of the LDS copy)
+            if (l == 0) {
+                __hip_atomic_fetch_and(&C->seen[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            continue;
+        }
+        if (l == 0) __hip_atomic_fetch_and(&C->seen[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // taken: ready again only by a later poll
+        const uint32_t pairs_left = word - 1u;
+        int t;
+        {
+            const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+            t = g + i * A->n_sel;
+            const uint32_t now = wall32();
+            const uint32_t w = now - uni_u32(aload(A->ts_ready + t));
+            if (l == 0) {
+                atomicAdd(&C->prof[2], (unsigned long long)(now - idle_since));
+                atomicAdd(&C->prof[3], (unsigned long long)w);
+                atomicAdd(&C->hist[(w / 100u) < 31u ? (w / 100u) : 31u], 1u);
+            }
+        }
+        bool need = false;
+        uint32_t left = pairs_left;                                         // calls of this tree still to run in this launch
+        while (left > 0u) {
+            const AsyncArgs* a = args;
+            asm volatile("" : "+s"(a));                                     // (opaque per tree: nothing of a descent is kept live across the loop)
+            const AsyncArgsC A = (AsyncArgsC)(uintptr_t)a;
+            const ForestDev F = load_const(&A->F);
+            const uint32_t c0t = wall32();
+            const uint32_t y0t = (uint32_t)clock64();
+            const int r = select_tree<G, true>(F, t, sm, dense, A->aleaf, A->leaf_valid, A->needs_eval, A->noise, A->pi, A->v, A->noise);
+            if (l == 0) {
+                atomicAdd(&C->prof[0], 1ull); atomicAdd(&C->prof[1], (unsigned long long)(wall32() - c0t));
+                atomicAdd(&C->prof[4], (unsigned long long)((uint32_t)clock64() - y0t));
+            }
+            left--;
+            need = r == 1;
+            // r == 2: the work budget parked the descent (what a round of the two-kernel form does with such a tree: no leaf this round,
+            // the descent goes on in the next one) -- the next call follows at once, on this wave; a tree is never left mid-call, so a
+            // launch can end with parked descents
+            if (r != 2) { if (r == 0) left = 0u; break; }
+        }
+        // ---- hand the tree on: clear its ready word, drain EVERY store of this wave (the tree's records, its leaf), release the claim ----
+        if (l == 0) astore(my_ready + i, 0u);
+        drain_vmem();
+        if (l == 0) __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        {
+            const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+            if (l == 0) {
+                if (need) {
+                    astore(A->ts_leaf + t, wall32());
+                    drain_vmem();
+                    const uint32_t tk = atomicAdd(&A->ctl->leaf_tail, 1u);
+                    const uint32_t rb = (uint32_t)A->ring_bits;
+                    astore(A->ring + (tk & ((1u << rb) - 1u)), (uint32_t)t | (left << 20) | ((((tk >> rb) & 7u) + 1u) << 28));
+                } else {
+                    __hip_atomic_fetch_add(&C->retired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    atomicAdd(&A->ctl->retired, 1u);
+                }
+            }
+        }
+        idle_since = wall32();
+    }
+    if (lane_id() == 0) atomicAdd(&C->prof[2], (unsigned long long)(wall32() - idle_since));
+    __syncthreads();
+    {
+        const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+        unsigned long long* prof = A->prof;
+        const int i = (int)threadIdx.x;
+        if (i == 0) {
+            atomicAdd(prof + 0, C->prof[0]); atomicAdd(prof + 1, C->prof[1]); atomicAdd(prof + 2, C->prof[2]); atomicAdd(prof + 8, C->prof[3]);
+            atomicAdd(prof + 15, C->prof[4]);
+            unsigned long long* wi = A->wginfo + (size_t)g * 4;
+            wi[0] = where_am_i(); wi[1] = 1ull; wi[2] += C->prof[0]; wi[3] += C->prof[4];
+            atomicAdd(prof + 10, (unsigned long long)(wall32() - t_begin));
+            if (g == 0) atomicAdd(prof + 9, 1ull);
+        }
+        if (i < 32 && C->hist[i]) atomicAdd(prof + 64 + i, (unsigned long long)C->hist[i]);
+    }
+}
+
+constexpr int ASYNC_NET_LDS = H2_LDS + 256;   // the forward's LDS map + the batch descriptor: tree of sample s [16], pairs left [16], count
+
+__global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    int* const sidx = (int*)(lds + H2_LDS);
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t t_begin = wall32();
+    unsigned long long* const P = (unsigned long long*)(lds + H2_LDS + 160);   // batches, leaves, busy, idle, leaf wait (LDS: nothing live across the forward)
+    if (tid < 6) P[tid] = 0ull;
+    // the workgroup's TICKET RANGE: sixteen consecutive leaf tickets taken with one returning atomic add (a claim that has to look at
+    // head and tail and compare-and-swap costs several memory round trips and serialises the 150 workgroups: measured 285 us of leaf
+    // wait).  The range is consumed in one batch when its sixteen leaves are there, in several when the producers are slow; sidx[34] =
+    // first ticket, sidx[35] = bit mask of the tickets already consumed, sidx[36] = 1 when the range is valid.
+    if (tid == 0) sidx[36] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (;;) {
+        if (wave == 0) {
+            const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+            AsyncCtl* const ctl = A->ctl;
+            const int T = A->F.T, wait_ticks = A->batch_wait, timeout = A->timeout_ticks;
+            const uint32_t rb = (uint32_t)A->ring_bits, rmask = (1u << rb) - 1u;
+            const uint32_t idle0 = wall32();
+            uint32_t base = (uint32_t)sidx[34], taken = (uint32_t)sidx[35];
+            if (!sidx[36]) {
+                uint32_t b = 0u;
+                if (lane == 0) b = atomicAdd(&ctl->leaf_head, 16u);
+                base = uni_u32(b); taken = 0u;
+            }
+            const uint32_t tk = base + (uint32_t)(lane & 15);
+            const uint32_t tag = ((tk >> rb) & 7u) + 1u;
+            uint32_t first_seen = 0u, e = 0u;
+            bool seen = false;
+            int n = 0;
+            uint32_t take = 0u;
+            unsigned spins = 0u;
+            for (;;) {
+                e = lane < 16 ? aload(A->ring + (tk & rmask)) : 0u;
+                const uint32_t filled = (uint32_t)__ballot(lane < 16 && (e >> 28) == tag) & ~taken;
+                const uint32_t now = wall32();
+                if (filled && !seen) { seen = true; first_seen = now; }
+                if (filled && ((filled | taken) == 0xFFFFu || (int)(now - first_seen) >= wait_ticks)) { take = filled; n = __popc(filled); break; }
+                if (!filled && (++spins & 7u) == 0u) {
+                    if (uni_u32(aload(&ctl->retired)) >= (uint32_t)T || uni_u32(aload(&ctl->abort))) { n = -1; break; }
+                    if ((int)(now - t_begin) > timeout) {
+                        if (lane == 0) { astore(&ctl->abort, 2u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT); }
+                        n = -1;
+                        break;
+                    }
+                }
+                if (filled) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
+            }
+            if (n > 0) {
+                const uint32_t now = wall32();
+                taken |= take;
+                if (lane < 16) { sidx[lane] = -1; sidx[16 + lane] = 0; }
+                const bool mine = lane < 16 && ((take >> lane) & 1u);
+                uint32_t w = 0u;
+                if (mine) {
+                    const int slot = __popc(take & ((1u << lane) - 1u));           // the batch is the taken tickets, compacted
+                    const int t = (int)(e & 0xFFFFFu);
+                    sidx[slot] = t;
+                    sidx[16 + slot] = (int)((e >> 20) & 0xFFu);
+                    w = now - aload(A->ts_leaf + t);
+                    atomicAdd(A->prof + 32 + ((w / 100u) < 31u ? (w / 100u) : 31u), 1ull);
+                }
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) w += __shfl_xor(w, m, 16);
+                if (lane == 0) {
+                    P[4] += (unsigned long long)w; P[3] += (unsigned long long)(now - idle0);
+                    sidx[34] = (int)base; sidx[35] = (int)taken; sidx[36] = taken != 0xFFFFu ? 1 : 0;
+                }
+            }
+            if (lane == 0) sidx[32] = n;
+        }
+        __syncthreads();
+        if (sidx[32] < 0) break;
+        if (tid == 0) { sidx[33] = (int)wall32(); sidx[37] = (int)(uint32_t)clock64(); }
+        {
+            const AsyncArgs* a = args;
+            asm volatile("" : "+s"(a));
+            const AsyncArgsC A = (AsyncArgsC)(uintptr_t)a;
+            h2_net_body<12, true>(lds, &A->W, A->aleaf, (const uint8_t*)A->aleaf, A->F.T, SplendorDev<2>::P, A->pi, A->v, 0, sidx);
+        }
+        drain_vmem();                                   // EVERY wave: its write-through pi / v rows have left
+        __syncthreads();
+        {
+            const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+            if (tid < 16 && sidx[tid] >= 0) {
+                const int t = sidx[tid], ns = A->n_sel;
+                const int gi = t % ns, ii = t / ns;
+                astore(A->ts_ready + t, wall32());
+                drain_vmem();
+                astore(A->ready + (size_t)gi * ASYNC_RS + ii, (uint32_t)sidx[16 + tid] + 1u);
+            }
+        }
+        if (tid == 0) {
+            P[0] += 1ull; P[1] += (unsigned long long)sidx[32]; P[2] += (unsigned long long)(wall32() - (uint32_t)sidx[33]);
+            P[5] += (unsigned long long)((uint32_t)clock64() - (uint32_t)sidx[37]);
+        }
+        __syncthreads();                                // the batch descriptor is free for the next claim
+    }
+    if (tid == 0) {
+        const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+        unsigned long long* prof = A->prof;
+        atomicAdd(prof + 3, P[0]); atomicAdd(prof + 4, P[1]); atomicAdd(prof + 5, P[2]); atomicAdd(prof + 6, P[3]);
+        atomicAdd(prof + 7, P[4]); atomicAdd(prof + 11, (unsigned long long)(wall32() - t_begin)); atomicAdd(prof + 14, P[5]);
+        unsigned long long* wi = A->wginfo + (size_t)(A->n_sel + (int)blockIdx.x) * 4;
+        wi[0] = where_am_i(); wi[1] = 2ull; wi[2] += P[0]; wi[3] += P[5];
+    }
+}
+
+}  // namespace azg
+
+// ---- host side ----
+struct AsyncSlot {
+    AsyncArgs host; AsyncArgs* devbuf;
+    int8_t* aleaf; AsyncCtl* ctl; uint32_t* ring; uint32_t* ready; uint32_t* ts; unsigned long long* prof; unsigned long long* wginfo;
+    hipStream_t side; hipEvent_t fork, join;
+    int n_sel, n_net, ring_bits;
+};
+static void async_slot_free(void* p) {
+    AsyncSlot* s = (AsyncSlot*)p;
+    (void)hipFree(s->devbuf); (void)hipFree(s->aleaf); (void)hipFree(s->ctl); (void)hipFree(s->ring); (void)hipFree(s->ready);
+    (void)hipFree(s->ts); (void)hipFree(s->prof); (void)hipFree(s->wginfo);
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->fork) (void)hipEventDestroy(s->fork);
+    if (s->join) (void)hipEventDestroy(s->join);
+    delete s;
+}
+
+// include/azg.h: profile counters of the asynchronous pipeline since the last reset
+extern "C" int azg_forest_async_profile(azg_forest* f, double* out /* [ASYNC_NPROF] */, int reset) {
+    if (!f || !out) return fail("azg_forest_async_profile: null argument");
+    for (int i = 0; i < ASYNC_NPROF; i++) out[i] = 0.0;
+    AsyncSlot* sl = (AsyncSlot*)azg_forest_attached(f, "async_v80");
+    if (!sl) return 0;
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long h[ASYNC_NPROF];
+    HIPCHK(hipMemcpy(h, sl->prof, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < ASYNC_NPROF; i++) out[i] = (double)h[i];
+    out[12] = (double)sl->n_sel; out[13] = (double)sl->n_net;
+    if (reset) HIPCHK(hipMemset(sl->prof, 0, sizeof(h)));
+    return 0;
+}
+
+// include/azg.h: per-workgroup placement and load of the pipeline's kernels (debugging / placement studies)
+extern "C" int azg_forest_async_wginfo(azg_forest* f, unsigned long long* out /* host [max_wg][4] */, int max_wg, int reset) {
+    if (!f || !out) return fail("azg_forest_async_wginfo: null argument");
+    AsyncSlot* sl = (AsyncSlot*)azg_forest_attached(f, "async_v80");
+    if (!sl) return 0;
+    const int n = sl->n_sel + sl->n_net < max_wg ? sl->n_sel + sl->n_net : max_wg;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, sl->wginfo, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(sl->wginfo, 0, sizeof(unsigned long long) * 4 * (sl->n_sel + sl->n_net)));
+    return n;
+}
+
+// include/azg.h: `rounds` (descent, forward) pairs per tree of a Splendor-2p forest with the V80 net, as ONE pair of concurrent
+// persistent kernels
+extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v, int noise_stride,
+                                              const void* const* w, const float* descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
+                                              void* stream) {
+    if (!f || !leaf_valid || !needs_eval || !pi || !v || !w || !descale) return fail("azg_forest_async_rounds_v80_h2: null argument");
+    if (rounds <= 0) return 0;
+    if (rounds > 255) return fail("azg_forest_async_rounds_v80_h2: at most 255 rounds per launch");
+    if (noise_stride != 0 && noise_stride != -2) return fail("azg_forest_async_rounds_v80_h2: noise_stride must be 0 or -2");
+    int game = 0, variant = 0;
+    double alpha = 0.0;
+    const ForestDev* dev = azg_forest_dev_internal(f, &game, &variant, &alpha);
+    if (game != AZG_SPLENDOR || variant != 2) return fail("azg_forest_async_rounds_v80_h2: Splendor 2 players only (the V80 geometry of nn_v80_h2.hip.h)");
+    using G = SplendorDev<2>;
+    static_assert(AsyncLeaf<G>::STRIDE == H2_AL_STRIDE && AsyncLeaf<G>::MASK_OFF == H2_AL_MASK, "leaf record layout shared with the net kernel");
+    static int n_cu = 0;
+    if (!n_cu) {
+        int d = 0;
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDevice(&d));
+        HIPCHK(hipGetDeviceProperties(&prop, d));
+        n_cu = prop.multiProcessorCount;
+        HIPCHK(hipFuncSetAttribute((const void*)k_async_net, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_async_select<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    const int T = dev->T;
+    if (n_net <= 0 || n_sel <= 0) {                   // default split of the CUs: 9 / 16 for the net (a forward is 30 us, a descent 19)
+        n_net = n_cu * 9 / 16;
+        n_sel = n_cu - n_net;
+    }
+    if (n_sel > T) n_sel = T;
+    if (n_net > (T + 15) / 16) n_net = (T + 15) / 16;
+    if (n_net + n_sel > n_cu)
+        return fail("azg_forest_async_rounds_v80_h2: n_net + n_sel exceeds the CUs of the device (every workgroup of the pipeline must be resident)");
+    if ((long long)n_sel * ASYNC_RS < T) return fail("azg_forest_async_rounds_v80_h2: more than 128 trees per select workgroup");
+    if (T >= (1 << 20)) return fail("azg_forest_async_rounds_v80_h2: at most 2^20 - 1 trees");
+    AsyncSlot* sl = (AsyncSlot*)azg_forest_attached(f, "async_v80");
+    if (sl && (sl->n_sel != n_sel || sl->n_net != n_net)) return fail("azg_forest_async_rounds_v80_h2: the CU split of a forest cannot change");
+    if (!sl) {
+        sl = new AsyncSlot();
+        memset(sl, 0, sizeof(*sl));
+        memset(&sl->host, 0xFF, sizeof(sl->host));
+        azg_forest_attach(f, "async_v80", sl, async_slot_free);
+        sl->n_sel = n_sel; sl->n_net = n_net;
+        int rb = 6;
+        while ((1 << rb) < 2 * T) rb++;
+        sl->ring_bits = rb;
+        HIPCHK(hipMalloc(&sl->devbuf, sizeof(AsyncArgs)));
+        HIPCHK(hipMalloc(&sl->aleaf, (size_t)T * AsyncLeaf<G>::STRIDE));
+        HIPCHK(hipMalloc(&sl->ctl, sizeof(AsyncCtl)));
+        HIPCHK(hipMalloc(&sl->ring, sizeof(uint32_t) << rb));
+        HIPCHK(hipMalloc(&sl->ready, sizeof(uint32_t) * ASYNC_RS * n_sel));
+        HIPCHK(hipMalloc(&sl->ts, sizeof(uint32_t) * 2 * T));
+        HIPCHK(hipMalloc(&sl->prof, sizeof(unsigned long long) * ASYNC_NPROF));
+        HIPCHK(hipMemset(sl->prof, 0, sizeof(unsigned long long) * ASYNC_NPROF));
+        HIPCHK(hipMalloc(&sl->wginfo, sizeof(unsigned long long) * 4 * (n_sel + n_net)));
+        HIPCHK(hipMemset(sl->wginfo, 0, sizeof(unsigned long long) * 4 * (n_sel + n_net)));
+        HIPCHK(hipMemset(sl->aleaf, 0, (size_t)T * AsyncLeaf<G>::STRIDE));
+        HIPCHK(hipMemset(sl->ts, 0, sizeof(uint32_t) * 2 * T));
+        HIPCHK(hipStreamCreateWithFlags(&sl->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl->join, hipEventDisableTiming));
+    }
+    AsyncArgs want;
+    memset(&want, 0, sizeof(want));
+    want.F = *dev;
+    // (the forest's work / level budget stays: a call that runs into it is followed by the next one at once, so no tree waits for another
+    // inside a launch -- but a launch ends only when every tree has had its calls, and a tree whose simulations all end on terminal nodes
+    // would otherwise run its whole search inside ONE call: measured 4.1 ms launches of 48 rounds where the mean tree needs 3.4 ms)
+    want.W = h2_weights(w, descale);
+    want.aleaf = sl->aleaf; want.leaf_valid = leaf_valid; want.needs_eval = needs_eval; want.pi = pi; want.v = v;
+    want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_leaf = sl->ts; want.ts_ready = sl->ts + T; want.prof = sl->prof; want.wginfo = sl->wginfo;
+    want.noise = (alpha != 0.0 && noise_stride == -2) ? 1 : 0;
+    want.rounds = rounds; want.n_sel = n_sel; want.ring_bits = sl->ring_bits;
+    want.batch_wait = batch_wait_ticks >= 0 ? batch_wait_ticks : 150;
+    { const char* e = getenv("AZG_ASYNC_TIMEOUT_MS"); want.timeout_ticks = (e ? atoi(e) : 2000) * 100000; }
+    hipStream_t s = (hipStream_t)stream;
+    if (memcmp(&sl->host, &want, sizeof(want)) != 0) {
+        sl->host = want;
+        HIPCHK(hipMemcpyAsync(sl->devbuf, &sl->host, sizeof(AsyncArgs), hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipMemsetAsync(sl->ctl, 0, sizeof(AsyncCtl), s));
+    HIPCHK(hipMemsetAsync(sl->ring, 0, sizeof(uint32_t) << sl->ring_bits, s));
+    // fork: the net workgroups on the caller's stream, the descent workgroups on the side stream; join before returning
+    HIPCHK(hipEventRecord(sl->fork, s));
+    HIPCHK(hipStreamWaitEvent(sl->side, sl->fork, 0));
+    k_async_net<<<dim3(n_net), dim3(768), ASYNC_NET_LDS, s>>>(sl->devbuf);
+    HIPCHK(hipGetLastError());
+    k_async_select<G><<<dim3(n_sel), dim3(1024), 16 * RoundLds<G>::STRIDE + (int)sizeof(AsyncSelLds), sl->side>>>(sl->devbuf);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(sl->join, sl->side));
+    HIPCHK(hipStreamWaitEvent(s, sl->join, 0));
+    return 0;
+}

@@ -114,16 +114,19 @@ __global__ __launch_bounds__(1024) void k_rounds_v80(const RoundArgs* args, int 
 
 }  // namespace azg
 
-struct RoundSlot { const ForestDev* dev; RoundArgs host; RoundArgs* devbuf; unsigned long long* prof; int n_wg; };
-static std::vector<RoundSlot*>& round_slots() { static std::vector<RoundSlot*> s; return s; }
+// the round kernel's argument block + profile counters: owned by the forest they belong to (azg_forest_attach), freed with it
+struct RoundSlot { RoundArgs host; RoundArgs* devbuf; unsigned long long* prof; int n_wg; };
+static void round_slot_free(void* p) {
+    RoundSlot* sl = (RoundSlot*)p;
+    (void)hipFree(sl->devbuf); (void)hipFree(sl->prof);
+    delete sl;
+}
 
 // include/azg.h: phase times of the round kernel since the last reset, averaged per round (microseconds)
 extern "C" int azg_forest_rounds_profile(azg_forest* f, double* out /* [4] */, int reset) {
     if (!f || !out) return fail("azg_forest_rounds_profile: null argument");
-    const ForestDev* dev = azg_forest_dev_internal(f, nullptr, nullptr, nullptr);
     out[0] = out[1] = out[2] = out[3] = 0.0;
-    for (RoundSlot* sl : round_slots()) {
-        if (sl->dev != dev) continue;
+    if (RoundSlot* sl = (RoundSlot*)azg_forest_attached(f, "rounds_v80")) {
         HIPCHK(hipDeviceSynchronize());
         std::vector<unsigned long long> h((size_t)4 * sl->n_wg);
         HIPCHK(hipMemcpy(h.data(), sl->prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
@@ -160,22 +163,20 @@ extern "C" int azg_forest_rounds_v80_h2(azg_forest* f, int8_t* leaf_states, uint
     // the argument block lives in device memory, one per (forest, buffers, weights) combination; it is (re)written -- ordered on the
     // launch stream, from a host copy that stays alive -- whenever the combination changes (also under stream capture: the copy becomes a
     // graph node in front of the kernel node)
-    std::vector<RoundSlot*>& slots = round_slots();
     RoundArgs want;
     memset(&want, 0, sizeof(want));
     want.F = *dev; want.W = h2_weights(w, descale);
     want.leaf_states = leaf_states; want.leaf_valid = leaf_valid; want.needs_eval = needs_eval; want.pi = pi; want.v = v; want.noise = noise;
-    RoundSlot* sl = nullptr;
-    for (RoundSlot* x : slots) if (x->dev == dev) sl = x;
+    RoundSlot* sl = (RoundSlot*)azg_forest_attached(f, "rounds_v80");
     if (!sl) {
         sl = new RoundSlot();
-        sl->dev = dev;
         sl->n_wg = (dev->T + 15) / 16;
+        sl->devbuf = nullptr; sl->prof = nullptr;
         memset(&sl->host, 0xFF, sizeof(sl->host));
+        azg_forest_attach(f, "rounds_v80", sl, round_slot_free);
         HIPCHK(hipMalloc(&sl->devbuf, sizeof(RoundArgs)));
         HIPCHK(hipMalloc(&sl->prof, sizeof(unsigned long long) * 4 * sl->n_wg));
         HIPCHK(hipMemset(sl->prof, 0, sizeof(unsigned long long) * 4 * sl->n_wg));
-        slots.push_back(sl);
     }
     want.prof = sl->prof;
     if (memcmp(&sl->host, &want, sizeof(want)) != 0) {

@@ -12,3 +12,8 @@ static inline int fail(const std::string& m) { return azg_fail(m); }
 struct azg_forest;
 namespace azg { struct ForestDev; }
 const azg::ForestDev* azg_forest_dev_internal(azg_forest* f, int* game, int* variant, double* dirichlet_alpha);
+
+// objects another translation unit hangs on a forest handle (the argument blocks / queues of the round kernels in azg_nn.hip): owned by
+// the forest, released by azg_forest_destroy through `deleter` -- nothing is keyed by a forest's address, which a later forest can inherit
+void azg_forest_attach(azg_forest* f, const char* key, void* obj, void (*deleter)(void*));
+void* azg_forest_attached(azg_forest* f, const char* key);

@@ -268,7 +268,15 @@ template <class G> struct EndedFillsMask<G, std::void_t<decltype(G::ENDED_FILLS_
 // runs the terminal test and the valid-move scan (MCTS.py:127-142).  Returns the record offset (AZG_NONE on overflow);
 // *terminal tells whether the new node ended the game (then es[] holds Es).  For a non-terminal leaf the canonical state and
 // valid mask are written to the net's leaf batch.
-template <class G, class HS>
+// ASYNC (azg_async.hip.h, the asynchronous tree pipeline): `leaf_states` is the pipeline's leaf-record array (AsyncLeaf<G>: padded state +
+// valid bit mask, one record per tree) and the record is written WRITE-THROUGH (agent-scope stores), because the net workgroup that reads it
+// runs on another CU, possibly another XCD, inside the same launch; the byte mask in leaf_valid is still written for this CU's own expansion.
+template <class G>
+struct AsyncLeaf {
+    static constexpr int MASK_OFF = G::SP;                                   // state int8[SP] (zero tail), then the valid mask u64[AW]
+    static constexpr int STRIDE = (G::SP + G::AW * 8 + 15) / 16 * 16;
+};
+template <class G, class HS, bool ASYNC = false>
 __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H, typename Forest<G>::Smem& sm,
                                              uint64_t h, uint32_t free_slot, int8_t* leaf_states, uint8_t* leaf_valid,
                                              bool* terminal, float* es, const typename Forest<G>::LeafPf* pf = nullptr) {
@@ -305,7 +313,15 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
     if (!ended) {
         // the entries themselves (action id included) are written by the expansion, in one pass, when the policy arrives
         for (int a = l; a < G::A; a += 64) leaf_valid[(size_t)t * G::A + a] = (uint8_t)((sm.mask[a >> 6] >> (a & 63)) & 1);
-        FR::store_state_unpadded(leaf_states + (size_t)t * G::S, sm.st);
+        if constexpr (ASYNC) {
+            using AL = AsyncLeaf<G>;
+            static_assert(G::SP % 8 == 0, "8-byte granules");
+            unsigned long long* dst = (unsigned long long*)(leaf_states + (size_t)t * AL::STRIDE);
+            const unsigned long long* src = (const unsigned long long*)sm.st;
+            for (int i = l; i < G::SP / 8 + G::AW; i += 64)
+                __hip_atomic_store(dst + i, i < G::SP / 8 ? src[i] : (unsigned long long)sm.mask[i - G::SP / 8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else
+            FR::store_state_unpadded(leaf_states + (size_t)t * G::S, sm.st);
     }
     return rec_off;
 }
@@ -313,7 +329,7 @@ __device__ __forceinline__ uint32_t create_leaf(const ForestDev& F, int t, HS& H
 // Resolve the child of (parent record, entry j, universe): replay the env step from the parent's state
 // (get_next_best_action_and_canonical_state, MCTS.py:233-248), look the state up, create it if new.
 // Returns child slot value (record offset | next_player << AZG_CHILD_NP_SHIFT) or AZG_NONE on overflow.
-template <class G, class HS>
+template <class G, class HS, bool ASYNC = false>
 __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& H, typename Forest<G>::Smem& sm,
                                               uint32_t parent_node, int a, long long seed, int8_t* leaf_states,
                                               uint8_t* leaf_valid, bool* is_new, bool* terminal, float* es, Rng& rng,
@@ -349,7 +365,7 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
     if (found != AZG_NONE) crec = found_rec;
     else {
         const long long t_l = AZG_CLK();
-        crec = create_leaf<G, HS>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, terminal, es, &pf);
+        crec = create_leaf<G, HS, ASYNC>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, terminal, es, &pf);
         H.cyc_leaf += (uint32_t)(AZG_CLK() - t_l);
         if (crec == AZG_NONE) return AZG_NONE;
         *is_new = true;
@@ -419,7 +435,8 @@ __device__ __forceinline__ void warm_kernarg_448() {
                  : "memory");
 }
 
-template <class G>
+// ASYNC: the policy was written by a net workgroup on another CU inside this launch (write-through) -- read it past this CU's L1
+template <class G, bool ASYNC = false>
 __device__ __forceinline__ void expand_load(const ForestDev& F, int t, const float* pi, const float* vin,
                                             const uint8_t* leaf_valid, ExpandIn<G>& in, const uint32_t (&hw)[AZG_HOT_WORDS]) {
     const int l = lane_id();
@@ -427,6 +444,9 @@ __device__ __forceinline__ void expand_load(const ForestDev& F, int t, const flo
 #pragma unroll
     for (int k = 0; k < ExpandIn<G>::NA; k++) {
         const int a = l + 64 * k;
+        if constexpr (ASYNC)
+            in.pv[k] = a < G::A ? __uint_as_float(__hip_atomic_load((const uint32_t*)pi + (size_t)t * G::A + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
+        else
         in.pv[k] = a < G::A ? pi[(size_t)t * G::A + a] : 0.f;
         in.va[k] = a < G::A ? leaf_valid[(size_t)t * G::A + a] : (uint8_t)0;
     }
@@ -545,8 +565,11 @@ struct SelState {
 // single-wave workgroup per tree) and of the select phase of k_rounds_v80 (azg_fused.hip.h: sixteen trees per workgroup, each wave with
 // its own Smem / dense block in the workgroup's LDS; wave_sync() is then wave-local).  pi != nullptr: the expansion + backup of the
 // previous round's leaf first (its loads ride on the header's round trip).
-template <class G>
-__device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typename Forest<G>::Smem& sm, float* dense /* LDS [A]: fused expansion only */,
+// Returns 1 when the tree handed a leaf to the net (status ST_WAIT_NN), 2 when the level / work budget parked its descent (it goes on at the
+// next call), 0 otherwise (search finished, idle, waiting for its root noise).  ASYNC: the asynchronous pipeline's hand-over forms
+// (create_leaf, expand_load).
+template <class G, bool ASYNC = false>
+__device__ __forceinline__ int select_tree(const ForestDev& F, const int t, typename Forest<G>::Smem& sm, float* dense /* LDS [A]: fused expansion only */,
                                             int8_t* leaf_states, uint8_t* leaf_valid, uint8_t* needs_eval, int wait_noise, const float* pi,
                                             const float* vin, int noise_enabled) {
     using FR = Forest<G>;
@@ -563,7 +586,7 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
     ExpandIn<G> ein;
     uint32_t hw[AZG_HOT_WORDS];
     load_hot_header<true>(Hp, hw);
-    if (pi) expand_load<G>(F, t, pi, vin, leaf_valid, ein, hw);         // pi != nullptr: the previous round's expansion first
+    if (pi) expand_load<G, ASYNC>(F, t, pi, vin, leaf_valid, ein, hw);  // pi != nullptr: the previous round's expansion first
 #ifdef AZG_PIN_HEADER
     pin_hot_header(hw);
 #endif
@@ -593,7 +616,7 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
     // wait_noise: the root noise is applied by the periodic k_selfplay_advance launch; until then the tree sits out
     if (uni_u32(status0) != ST_SEARCHING || (wait_noise && (uni_u32(pending0) || fresh_noise))) {
         if (l == 0) needs_eval[t] = 0;
-        return;
+        return 0;
     }
     AZG_STAMP(7);
 #ifdef AZG_PAD_CODE
@@ -678,7 +701,7 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
                 uint32_t found_rec = AZG_NONE;
                 const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
                 if (found == AZG_NONE) {
-                    rec = uni_u32(create_leaf<G, SelState>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, &leaf_terminal, es));
+                    rec = uni_u32(create_leaf<G, SelState, ASYNC>(F, t, H, sm, h, free_slot, leaf_states, leaf_valid, &leaf_terminal, es));
                     if (rec == AZG_NONE) continue;
                     H.root = uni_u32(((const RecHdr*)(hp + (size_t)rec * 16u))->node_id);
                     H.root_rec = rec;
@@ -817,7 +840,7 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
                 const int a = a_sel;
                 bool is_new = false;
                 const long long t_e = AZG_CLK();
-                child = uni_u32(resolve_edge<G, SelState>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es,
+                child = uni_u32(resolve_edge<G, SelState, ASYNC>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es,
                                                           srng, spec_now, ps0, ps1, ps2));
                 cyc_edge += AZG_CLK() - t_e;
                 if (child == AZG_NONE) { H.sim_idx = H.n_sims; break; }
@@ -888,6 +911,7 @@ __device__ __forceinline__ void select_tree(const ForestDev& F, const int t, typ
 #endif
         needs_eval[t] = need_nn ? 1 : 0;
     }
+    return need_nn ? 1 : (uni_u32(H.mid_sim) ? 2 : 0);
 }
 
 template <class G>

@@ -217,11 +217,15 @@ static __device__ long long g_h2_phase[4][16];
 // NW = waves of the workgroup: 12 (the stand-alone kernel, 168 VGPRs, 3 waves per SIMD) or 16 (128 VGPRs, 4 waves per SIMD -- the budget
 // of a workgroup that also runs 16 tree descents, kernels.hip.h k_rounds): with 16 waves the weights of a later phase are requested
 // later (LEAN: fewer fragment registers in flight), the project GEMM and the first layer run over four row-tile groups instead of three.
-template <int ACT, int POOLMAX, int MODE, int NW>
+// IND (the asynchronous pipeline, azg_async.hip.h): sample s of the workgroup is tree sidx[s] (LDS; < 0 = no sample) -- `valid` is then the
+// pipeline's leaf-record array (its valid BIT mask, kernels.hip.h AsyncLeaf<SplendorDev<2>>: stride 416, mask at byte 400), read past the L1,
+// and pi / v rows are written WRITE-THROUGH at the tree's index: the reader is a descent wave on another CU, inside the same launch.
+constexpr int H2_AL_STRIDE = 416, H2_AL_MASK = 400;
+template <int ACT, int POOLMAX, int MODE, int NW, bool IND = false>
 __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const H2NetW& N, int B, int P,
                                          const uint8_t* __restrict__ valid, float* __restrict__ pi_out, float* __restrict__ v_out,
                                          H2EW& ew /* in: this block's phase-E operands; out: the next block's */,
-                                         const H2BlockW& Wnext, int wg, const int tid) {
+                                         const H2BlockW& Wnext, int wg, const int tid, const int* sidx = nullptr) {
     constexpr int NS = 16, A = 81;
     constexpr bool LEAN = NW > 12;
     const int lane = tid & 63, wave = tid >> 6;
@@ -544,17 +548,31 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         H2_PH(5);
         // masked softmax == exp(log_softmax(where(valid, logits, -1e8))) (GenericNNetWrapper.py:105-107), one wave per sample
         for (int s = wave; s < NS; s += NW) {
-            const int b = b0 + s;
-            if (b >= B) continue;
+            const int b = IND ? sidx[s] : b0 + s;
+            if (IND ? b < 0 : b >= B) continue;
             const int a1i = lane + 64;
-            float x0 = valid[(size_t)b * A + lane] ? LG[s * H2_LS + lane] : -1e8f;
-            float x1 = a1i < A ? (valid[(size_t)b * A + a1i] ? LG[s * H2_LS + a1i] : -1e8f) : -INFINITY;
+            bool ok0, ok1;
+            if constexpr (IND) {
+                const unsigned long long* mp = (const unsigned long long*)(valid + (size_t)b * H2_AL_STRIDE + H2_AL_MASK);
+                const unsigned long long m0 = __hip_atomic_load(mp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long m1 = __hip_atomic_load(mp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok0 = (m0 >> lane) & 1ull; ok1 = (m1 >> lane) & 1ull;
+            } else {
+                ok0 = valid[(size_t)b * A + lane] != 0; ok1 = a1i < A && valid[(size_t)b * A + a1i] != 0;
+            }
+            float x0 = ok0 ? LG[s * H2_LS + lane] : -1e8f;
+            float x1 = a1i < A ? (ok1 ? LG[s * H2_LS + a1i] : -1e8f) : -INFINITY;
             const float mx = nn_wave_max(fmaxf(x0, x1));
             x0 = expf(x0 - mx);
             x1 = a1i < A ? expf(x1 - mx) : 0.f;
             const float sum = nn_wave_sum(x0 + x1);
-            pi_out[(size_t)b * A + lane] = x0 / sum;
-            if (a1i < A) pi_out[(size_t)b * A + a1i] = x1 / sum;
+            if constexpr (IND) {
+                __hip_atomic_store((uint32_t*)pi_out + (size_t)b * A + lane, __float_as_uint(x0 / sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a1i < A) __hip_atomic_store((uint32_t*)pi_out + (size_t)b * A + a1i, __float_as_uint(x1 / sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                pi_out[(size_t)b * A + lane] = x0 / sum;
+                if (a1i < A) pi_out[(size_t)b * A + a1i] = x1 / sum;
+            }
         }
         __syncthreads();                                      // the value block re-zeroes H's pad columns under LG / HID
         H2_PH(6);
@@ -577,15 +595,16 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
         }
         __syncthreads();
         if (tid < NS * P) {
-            const int s = tid / P, p = tid - s * P, b = b0 + s;
-            if (b < B) {
+            const int s = tid / P, p = tid - s * P, b = IND ? sidx[s] : b0 + s;
+            if (IND ? b >= 0 : b < B) {
                 float a = H2G(float, N.bv2)[p];
                 for (int j = 0; j < P; j++) {
                     float h = 0.f;
                     for (int w = 0; w < 12; w++) h += RED[(w * 16 + s) * 16 + j];
                     a += fmaxf(h * N.sv1 + H2G(float, N.bv1)[j], 0.f) * H2G(float, N.Wv2)[j * P + p];
                 }
-                v_out[(size_t)b * P + p] = tanhf(a);
+                if constexpr (IND) __hip_atomic_store((uint32_t*)v_out + (size_t)b * P + p, __float_as_uint(tanhf(a)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else v_out[(size_t)b * P + p] = tanhf(a);
             }
         }
         H2_PH(5);
@@ -593,9 +612,10 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
 }
 
 // the whole forward of workgroup `wg` (samples 16 * wg ..); the caller's workgroup has NW waves and H2_LDS bytes of LDS at `lds`
-template <int NW>
+// IND: see h2_block -- `boards` and `valid` are both the pipeline's leaf-record array, sidx[16] (LDS) names the workgroup's trees
+template <int NW, bool IND = false>
 __device__ __forceinline__ void h2_net_body(uint8_t* lds, H2WeightsC Wc, const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid,
-                                            int B, int P, float* __restrict__ pi_out, float* __restrict__ v_out, int wg) {
+                                            int B, int P, float* __restrict__ pi_out, float* __restrict__ v_out, int wg, const int* sidx = nullptr) {
     constexpr int NS = 16, C = 56, NT = NW * 64, KB = (NS * (7 * C / 4) + NT - 1) / NT;
     h2_fp16_saturate_mode();
     int tid_ = threadIdx.x;
@@ -611,7 +631,15 @@ __device__ __forceinline__ void h2_net_body(uint8_t* lds, H2WeightsC Wc, const i
     const uint32_t* bsrc = (const uint32_t*)(boards + (size_t)b0 * (7 * C));
     uint32_t bv[KB];
 #pragma unroll
-    for (int k = 0; k < KB; k++) { const int i = tid + NT * k; bv[k] = (i < NS * (7 * C / 4) && i / (7 * C / 4) < nb) ? bsrc[i] : 0u; }
+    for (int k = 0; k < KB; k++) {
+        const int i = tid + NT * k;
+        if constexpr (IND) {
+            const int s = i / (7 * C / 4), d = i - s * (7 * C / 4);
+            const int b = i < NS * (7 * C / 4) ? sidx[s] : -1;
+            bv[k] = b >= 0 ? __hip_atomic_load((const uint32_t*)(boards + (size_t)b * H2_AL_STRIDE) + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        } else
+            bv[k] = (i < NS * (7 * C / 4) && i / (7 * C / 4) < nb) ? bsrc[i] : 0u;
+    }
     constexpr int RG0 = NW / 4;                               // row-tile groups of the first layer
     const int ntp = wave & 3, rt0 = wave >> 2;
     uint4 w0h[2], w0l[2];
@@ -666,19 +694,19 @@ __device__ __forceinline__ void h2_net_body(uint8_t* lds, H2WeightsC Wc, const i
         const H2WeightsC c1 = h2_opaque(Wc);
         const H2BlockW Wt = h2_load_const(&c1->Wt), Wp = h2_load_const(&c1->Wp);
         const H2NetW N = h2_load_const(&c1->N);
-        h2_block<1, 0, 1, NW>(lds, Wt, N, B, P, valid, pi_out, v_out, ew, Wp, wg, tid);
+        h2_block<1, 0, 1, NW, IND>(lds, Wt, N, B, P, valid, pi_out, v_out, ew, Wp, wg, tid, sidx);
     }
     {
         const H2WeightsC c2 = h2_opaque(Wc);
         const H2BlockW Wp = h2_load_const(&c2->Wp), Wv = h2_load_const(&c2->Wv);
         const H2NetW N = h2_load_const(&c2->N);
-        h2_block<2, 1, 2, NW>(lds, Wp, N, B, P, valid, pi_out, v_out, ew, Wv, wg, tid);
+        h2_block<2, 1, 2, NW, IND>(lds, Wp, N, B, P, valid, pi_out, v_out, ew, Wv, wg, tid, sidx);
     }
     {
         const H2WeightsC c3 = h2_opaque(Wc);
         const H2BlockW Wv = h2_load_const(&c3->Wv);
         const H2NetW N = h2_load_const(&c3->N);
-        h2_block<2, 1, 3, NW>(lds, Wv, N, B, P, valid, pi_out, v_out, ew, Wv, wg, tid);   // (the last prefetch is unused)
+        h2_block<2, 1, 3, NW, IND>(lds, Wv, N, B, P, valid, pi_out, v_out, ew, Wv, wg, tid, sidx);   // (the last prefetch is unused)
     }
 }
 

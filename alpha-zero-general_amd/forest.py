@@ -120,6 +120,49 @@ class Forest:
         check(lib().azg_forest_rounds_v80_h2(self.h, _ptr(self.leaf_states), _ptr(self.leaf_valid), _ptr(self.needs_eval), _ptr(pi), _ptr(v),
                                              -2 if device_noise else 0, net.net_ptrs_h2, net.descale_h2, int(rounds), _stream()))
 
+    def async_rounds_v80(self, net, pi, v, rounds, device_noise=False, n_net=0, n_sel=0, batch_wait_ticks=-1):
+        """`rounds` (descent, forward) pairs per tree as ONE launch of the asynchronous pipeline (azg_forest_async_rounds_v80_h2): persistent
+        descent workgroups and persistent V80 net workgroups resident together, leaves and trees handed over through device-side queues"""
+        assert pi.dtype == torch.float32 and v.dtype == torch.float32 and pi.is_contiguous() and v.is_contiguous()
+        assert pi.shape == (self.T, self.A) and v.shape == (self.T, self.P)
+        check(lib().azg_forest_async_rounds_v80_h2(self.h, _ptr(self.leaf_valid), _ptr(self.needs_eval), _ptr(pi), _ptr(v),
+                                                   -2 if device_noise else 0, net.net_ptrs_h2, net.descale_h2, int(rounds), int(n_net), int(n_sel),
+                                                   int(batch_wait_ticks), _stream()))
+
+    def async_profile(self, reset=True):
+        """the pipeline's counters since the last reset as a dict (times in microseconds; include/azg.h azg_forest_async_profile)"""
+        out = (C.c_double * 96)()
+        check(lib().azg_forest_async_profile(self.h, out, int(reset)))
+        o = list(out)
+        d = dict(descents=o[0], batches=o[3], leaves=o[4], launches=o[9])
+        d['descent_us'] = o[1] / max(o[0], 1) / 100.0
+        d['forward_us'] = o[5] / max(o[3], 1) / 100.0
+        d['leaves_per_batch'] = o[4] / max(o[3], 1)
+        d['leaf_wait_us'] = o[7] / max(o[4], 1) / 100.0            # queued -> claimed by a net workgroup
+        d['ready_wait_us'] = o[8] / max(o[0], 1) / 100.0           # handed back by the net -> claimed by a descent wave
+        d['select_wave_busy'] = o[1] / max(o[1] + o[2], 1)          # share of a descent wave's life inside select_tree
+        d['net_wg_busy'] = o[5] / max(o[11], 1)                     # share of a net workgroup's life inside the forward
+        d['n_sel'], d['n_net'] = int(o[12]), int(o[13])
+        d['forward_cycles'] = o[14] / max(o[3], 1)                   # shader-clock cycles of a forward / a descent, and the clock they imply
+        d['descent_cycles'] = o[15] / max(o[0], 1)
+        d['net_cu_mhz'] = o[14] / max(o[5], 1) * 100.0
+        d['select_cu_mhz'] = o[15] / max(o[1], 1) * 100.0
+        d['launch_us'] = o[10] / max(o[9], 1) / max(o[12], 1) / 100.0   # a launch of the descent kernel (mean over its workgroups)
+        d['select_resident_ticks'], d['net_resident_ticks'] = o[10], o[11]
+        d['leaf_wait_hist_us'] = [int(x) for x in o[32:64]]
+        d['ready_wait_hist_us'] = [int(x) for x in o[64:96]]
+        return d
+
+    def async_wginfo(self, reset=True):
+        """per workgroup of the pipeline: (xcc, cu, se, sh, role 1 descent / 2 net, calls, shader cycles per call)"""
+        buf = (C.c_uint64 * (4 * 1024))()
+        n = check(lib().azg_forest_async_wginfo(self.h, buf, 1024, int(reset)))
+        out = []
+        for k in range(n):
+            w, role, calls, cyc = buf[4 * k], buf[4 * k + 1], buf[4 * k + 2], buf[4 * k + 3]
+            out.append((int(w & 0xF), int((w >> 8) & 0xF), int((w >> 16) & 0x7), int((w >> 24) & 1), int(role), int(calls), cyc / max(calls, 1)))
+        return out
+
     def rounds_profile(self, reset=True):
         """(select phase us, net phase us, a wave's own descent us, rounds) per round of the per-CU round kernel since the last reset"""
         out = (C.c_double * 4)()

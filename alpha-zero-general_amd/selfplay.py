@@ -38,6 +38,7 @@ class _Group:
         self.v = net.v if static else torch.zeros((forest.T, forest.P), dtype=torch.float32, device=forest.device)
         self.stream = None          # torch stream of this group's pipeline (None: the caller's current stream)
         self.graph = None
+        self.async_cfg = {}         # n_net / n_sel / batch_wait_ticks of the asynchronous pipeline (defaults of the C-ABI when empty)
 
     def select(self):
         self.f.select(device_noise=self.device_noise)
@@ -59,7 +60,17 @@ class _Group:
 
     def rounds(self, n, fused, percu, advance=True):
         """n lock-step rounds of this group's trees on the current stream, then (advance) one selfplay_advance.  percu: ONE launch of
-        the per-CU round kernel (azg_forest_rounds_v80_h2: 16 trees + their 16 leaves per workgroup, no launch boundary between rounds)"""
+        the per-CU round kernel (azg_forest_rounds_v80_h2: 16 trees + their 16 leaves per workgroup, no launch boundary between rounds);
+        percu == 'async': ONE launch of the asynchronous pipeline (azg_forest_async_rounds_v80_h2: n descent / forward pairs per tree)"""
+        if percu == 'async':
+            done = 0
+            while done < n:                       # (a launch carries at most 255 pairs per tree)
+                k = min(255, n - done)
+                self.f.async_rounds_v80(self.net, self.pi, self.v, k, device_noise=bool(self.device_noise), **self.async_cfg)
+                done += k
+            if advance:
+                self.f.selfplay_advance()
+            return
         if percu:
             self.f.rounds_v80(self.net, self.pi, self.v, n, device_noise=bool(self.device_noise))
             if advance:
@@ -85,7 +96,7 @@ class _Group:
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
                  use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=None, fused=True,
-                 pin_xcd=None, percu=None, gc_high_water_pct=None):
+                 pin_xcd=None, percu=None, gc_high_water_pct=None, async_pipe=None, async_cfg=None):
         self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
@@ -133,6 +144,22 @@ class SelfPlayEngine:
         elif percu and not can:
             raise ValueError('percu=True needs Splendor 2 players and SplendorV80Hip(h2=True) evaluators with max_batch == games per group')
         self.percu = bool(percu)
+        # the asynchronous tree pipeline (csrc/azg_async.hip.h): persistent descent + net workgroups, no launch-wide boundary between the
+        # descents and the forwards.  Same preconditions as the per-CU kernel (Splendor 2 players, V80 on its f16 x 2 kernel with static
+        # output buffers), one group.  AZG_ASYNC=0 / async_pipe=False: the two-kernel rounds.
+        if async_pipe is None:
+            async_pipe = can and groups == 1 and not self.percu and os.environ.get('AZG_ASYNC', '0') == '1'
+        elif async_pipe and not (can and groups == 1):
+            raise ValueError('async_pipe=True needs Splendor 2 players, SplendorV80Hip(h2=True) evaluators with max_batch == n_games, groups == 1')
+        self.async_pipe = bool(async_pipe)
+        if self.async_pipe:
+            self.percu = 'async'
+            cfg = dict(async_cfg or {})
+            for k, e in (('n_net', 'AZG_ASYNC_NNET'), ('n_sel', 'AZG_ASYNC_NSEL'), ('batch_wait_ticks', 'AZG_ASYNC_WAIT')):
+                if k not in cfg and os.environ.get(e):
+                    cfg[k] = int(os.environ[e])
+            self.groups[0].async_cfg = cfg
+            self.use_graph = False          # two launches per K rounds: nothing to amortise
         # one stream per pipeline; pinned to an XCD (or an equal share of the 8 XCDs) unless pin_xcd=False
         self.pin_xcd = (groups > 1) if pin_xcd is None else bool(pin_xcd)
         self._raw_streams = []
@@ -234,6 +261,15 @@ class SelfPlayEngine:
         self.rounds += 3 + self.K
 
     def run(self, rounds):
+        if self.async_pipe:
+            # K descent / forward pairs per tree per launch of the pipeline, then the advance -- the cadence of the two-kernel rounds
+            grp, done = self.groups[0], 0
+            while done < rounds:
+                k = min(self.K, rounds - done)
+                grp.rounds(k, self.fused, self.percu, advance=True)
+                done += k
+            self.rounds += rounds
+            return
         if self.use_graph and self.graph is None:
             self.capture()
         done = 0

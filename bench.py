@@ -216,7 +216,8 @@ def build_engine(a, game_key, T, rank, dev):
             eng = SelfPlayEngine(game, net, margs, T, node_capacity=cap, max_examples=T * 160, rng_seed=2026,
                                  stream0=rank * T, use_graph=not a.no_graph, level_budget=a.level_budget, groups=a.groups,
                                  work_budget=None if a.work_budget < 0 else a.work_budget, advance_every=a.advance_every or None,
-                                 pin_xcd=None if not a.no_pin_xcd else False)
+                                 pin_xcd=None if not a.no_pin_xcd else False,
+                                 async_pipe=None if getattr(a, 'async_pipe', -1) < 0 else bool(a.async_pipe))
             break
         except Exception as ex:        # azg_amd.AzgError: hipMalloc failed
             if a.node_capacity or attempt == 2:
@@ -232,7 +233,20 @@ def measure_roofline(a, eng, T):
     import torch
     f = eng.forest
     kprof = None
-    if getattr(eng, 'percu', False):
+    aprof = None
+    if getattr(eng, 'async_pipe', False):
+        # the asynchronous pipeline: the descents run in ONE persistent kernel per `advance_every` rounds, next to the net workgroups.
+        # Its launch duration (mean over its workgroups, 100 MHz wall clock inside the kernel) is the roofline's denominator; the
+        # per-descent latency, the forward's latency, the queue waits and their distributions come from the same counters
+        n = max(eng.K, a.roofline_rounds // eng.K * eng.K)
+        f.async_profile(reset=True)
+        r0 = eng.stats()
+        eng.run(n)
+        torch.cuda.synchronize()
+        r1 = eng.stats()
+        aprof = f.async_profile(reset=True)
+        ms_sel, n_sel, ms_exp, n_exp = aprof['launch_us'] * 1e-3, int(aprof['launches']), 0.0, 0
+    elif getattr(eng, 'percu', False):
         # the per-CU round kernel: there is no launch of the descent alone to put HIP events around -- its select phase is timed INSIDE
         # the kernel on the 100 MHz wall clock (azg_forest_rounds_profile): per round, how long a workgroup's select phase lasts (it waits
         # for the slowest of its 16 trees), averaged over the workgroups and the rounds of the same graph replays the timed region uses
@@ -279,11 +293,20 @@ def measure_roofline(a, eng, T):
         except Exception:
             prof = None
     extra = {}
+    if aprof is not None:
+        extra = dict(async_pipeline=dict((k, aprof[k]) for k in ('n_sel', 'n_net', 'descent_us', 'forward_us', 'leaves_per_batch', 'leaf_wait_us',
+                                                                 'ready_wait_us', 'select_wave_busy', 'net_wg_busy', 'launch_us', 'forward_cycles', 'descent_cycles', 'net_cu_mhz', 'select_cu_mhz',
+                                                                 'leaf_wait_hist_us', 'ready_wait_hist_us')),
+                     rounds_per_launch=eng.K,
+                     timing='inside the persistent kernels on the 100 MHz wall clock (s_memrealtime): select_ms = one launch of k_async_select '
+                            '(rounds_per_launch descents per tree, the waves wait for the net in between); achieved = the launch\'s algorithmic '
+                            'bytes / that; descent_us = one select_tree call (expansion + backup + descent of one tree)')
     if kprof is not None:
         extra = dict(net_phase_ms=kprof[1] * 1e-3, select_wave_ms=kprof[2] * 1e-3,
                      timing='inside k_rounds_v80 on the 100 MHz wall clock (s_memrealtime), per round, averaged over the workgroups: select_ms = '
                             'the select phase of a workgroup (its slowest of 16 trees), select_wave_ms = a wave\'s own descent, net_phase_ms = the net phase')
-    return dict(bound='hbm', kernels=(['k_rounds_v80: select phase (expansion + backup + descent of 16 trees per workgroup)'] if kprof is not None else
+    return dict(bound='hbm', kernels=(['k_async_select (persistent: expansion + backup + descent of the trees a workgroup owns)'] if aprof is not None else
+                                      ['k_rounds_v80: select phase (expansion + backup + descent of 16 trees per workgroup)'] if kprof is not None else
                                       ['k_select', 'k_expand_backup'] if n_exp else ['k_select (expand+backup fused into its prologue)']), **extra,
                 achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                 traffic=None, traffic_from_profile=prof,
@@ -416,7 +439,8 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
                    gather_row_bytes=ginfo.get('row_bytes'))
     res['roofline'] = measure_roofline(a, eng, T) if roofline and a.roofline_rounds > 0 else None
     eng._last_roofline = res['roofline']
-    res['percu'] = bool(getattr(eng, 'percu', False))
+    res['percu'] = bool(getattr(eng, 'percu', False)) and not getattr(eng, 'async_pipe', False)
+    res['async_pipe'] = bool(getattr(eng, 'async_pipe', False))
     res['roofline_net'] = measure_net(a, eng, T, game_key, net_kind) if roofline and a.roofline_rounds > 0 else None
     del ex
     eng.close()
@@ -442,6 +466,8 @@ def main():
                     help='independent pipelines: the games are split into this many forests, each with its own stream (pinned to one XCD, or '
                          'to 8 / groups XCDs), leaf batch and captured graph; nothing synchronises them')
     ap.add_argument('--no-pin-xcd', action='store_true', help='groups > 1 on ordinary streams (no CU mask): A/B of the XCD pinning')
+    ap.add_argument('--async-pipe', type=int, default=-1,
+                    help='1 / 0: the asynchronous tree pipeline (persistent descent + net workgroups, csrc/azg_async.hip.h) on / off; -1 = engine default')
     ap.add_argument('--level-budget', type=int, default=0, help='max descent levels per tree per select launch (0 = unlimited)')
     ap.add_argument('--advance-every', type=int, default=0, help='rounds per selfplay_advance launch / HIP graph (0 = engine default)')
     ap.add_argument('--work-budget', type=int, default=-1, help='per-launch work cap per tree (level units), 0 = off, -1 = the engine default for the game')
@@ -509,7 +535,7 @@ def main():
                groups=a.groups)
     for k in ('value_from_sims', 'sims_per_sec', 'plies_completed', 'games_finished', 'examples_gathered', 'examples_dropped',
               'engine_errors', 'forest_bytes_per_gpu', 'node_capacity', 'max_live_after_gc', 'max_live_frac', 'max_nodes_per_tree', 'gc_runs',
-              'rounds_timed', 'ms_per_round', 'preroll_plies', 'work_budget', 'advance_every', 'percu'):
+              'rounds_timed', 'ms_per_round', 'preroll_plies', 'work_budget', 'advance_every', 'percu', 'async_pipe'):
         out[k] = r[k]
     for k in ('rccl_world', 'rccl_backend', 'examples_per_rank', 'gather_ms', 'gather_bytes_received_rank0', 'gather_mode', 'gather_row_bytes'):
         if k in r:

@@ -170,6 +170,34 @@ int azg_forest_rounds_v80_h2(azg_forest* f, int8_t* leaf_states_dev, uint8_t* le
    of the descent alone to put HIP events around.) */
 int azg_forest_rounds_profile(azg_forest* f, double* out4, int reset);
 
+/* The ASYNCHRONOUS TREE PIPELINE form of the self-play round for Splendor 2 players + the V80 net (csrc/azg_async.hip.h): games search
+   while other games sit in the net -- what the reference's lock ring of N game threads around one inference server does
+   (Coach.py:117-144, GenericNNetWrapper.py:122-157).  ONE call launches two persistent kernels that run concurrently: `n_sel` descent
+   workgroups (16 waves; each owns a fixed share of the trees, a free wave takes whichever of them has its pi / v, runs the expansion +
+   backup + next descent of azg_forest_select_fused and queues the leaf) and `n_net` net workgroups (each takes up to 16 queued leaves --
+   fewer after `batch_wait_ticks` x 10 ns of waiting --, runs the forward of azg_nn_v80_forward_h2 on them and hands the trees back).
+   Every tree runs `rounds` (<= 255) descent / forward pairs, then the call's kernels end; azg_selfplay_advance is launched by the caller
+   between calls, as between rounds of the two-kernel form.  n_net + n_sel must not exceed the CUs of the device (every workgroup has to
+   be resident; <= 0: a default split); the first call fixes the split of a forest.  Per-tree results are identical bit for bit to
+   `rounds` x (azg_forest_select_fused -> azg_nn_v80_forward_h2) on a forest without work / level budget (tests/test_gpu_selfplay.py).
+   leaf_valid_dev u8[T][A], needs_eval_dev u8[T], pi_dev f32[T][A], v_dev f32[T][P]: as for azg_forest_select_fused (the leaf states
+   travel through a buffer the forest owns).  A pipeline that stops making progress for AZG_ASYNC_TIMEOUT_MS (2000) sets error bit 128
+   (azg_selfplay_stats.errors) and ends the kernels. */
+int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev,
+                                   int noise_stride, const void* const* w, const float* descale_host, int rounds, int n_net, int n_sel,
+                                   int batch_wait_ticks, void* stream);
+/* measurement: counters of the pipeline since the last reset (ticks = 10 ns of the 100 MHz wall clock read inside the kernels):
+   out[0] descents (select_tree calls), [1] ticks inside them, [2] ticks descent waves spent looking for a ready tree, [3] net batches,
+   [4] leaves in them, [5] ticks inside the forward, [6] ticks net workgroups waited for leaves, [7] sum over leaves of (claimed by a net
+   workgroup - queued), [8] sum over descents of (tree claimed - tree handed back by the net), [9] launches, [10] / [11] resident ticks
+   summed over the select / net workgroups, [12] n_sel, [13] n_net, [32..63] histogram of [7]'s waits in microseconds (last bucket: >= 31), [64..95] of [8]'s. */
+#define AZG_ASYNC_NPROF 96
+int azg_forest_async_profile(azg_forest* f, double* out96, int reset);
+/* placement study: one row of four u64 per workgroup of the pipeline (the n_sel descent workgroups first): where it ran (XCC id | cu_id
+   << 8 | se_id << 16 | sh_id << 24), role (1 descent, 2 net), calls (descents / forwards) and the shader cycles spent in them since
+   the last reset.  Returns the number of rows written (<= max_wg). */
+int azg_forest_async_wginfo(azg_forest* f, unsigned long long* out_host, int max_wg, int reset);
+
 /* part 2: store (Ps, v) on the pending leaves and back the values up (MCTS.py:147-154,176-183).
    pi f32[T][A] are PROBABILITIES (exp of the net's log-softmax, GenericNNetWrapper.py:107,119), v f32[T][P].
    The leaf_valid buffer handed to the preceding azg_forest_select must still hold what that call wrote (the kernel maps

@@ -509,6 +509,57 @@ def test_percu_round_kernel_equals_two_kernel_rounds(T, sims, use_graph):
         assert torch.equal(r0[k], r1[k]), k
 
 
+@pytest.mark.parametrize('T,sims,K,budget,cfg', [(40, 24, 8, 0, dict(n_net=3, n_sel=5)), (64, 40, 8, 10, dict(n_net=2, n_sel=64)),
+                                                 (300, 32, 16, 4, dict(n_net=8, n_sel=3, batch_wait_ticks=0)), (256, 48, 48, 0, {})])
+def test_async_pipeline_equals_two_kernel_rounds(T, sims, K, budget, cfg):
+    """The asynchronous tree pipeline (azg_forest_async_rounds_v80_h2: persistent descent workgroups + persistent net workgroups, leaves and
+    trees handed over through device-side queues, no boundary wider than one tree) against the two-kernel rounds it replaces
+    (azg_forest_select_fused + azg_nn_v80_forward_h2): the same games move for move -- every drained example record
+    (board, pi, z, valids, q, meta), the statistics counters and the root statistics are EQUAL, not close, whatever the CU split, the
+    trees per workgroup (1 .. 100), the batch wait, the work budget (a call that parks its descent is followed by the next call, as
+    a round is by the next round) and the number of calls per launch."""
+    import os
+    import torch
+    from azg_amd import games
+    from azg_amd.nnet import SplendorV80Hip
+    from azg_amd.selfplay import SelfPlayEngine
+    g = games.SplendorGame(2)
+    w = os.path.join(os.path.dirname(__file__), 'golden', 'weights_splendor2_v80.npz')
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0],
+                tempThreshold=6, **MCTS_ARGS['splendor2'])
+    out = []
+    for pipe in (False, True):
+        net = SplendorV80Hip.from_npz(w, max_batch=T)
+        e = SelfPlayEngine(g, net, args, T, node_capacity=2048, max_examples=T * 400, rng_seed=9, use_graph=False, advance_every=K,
+                           work_budget=budget, percu=False, async_pipe=pipe, async_cfg=cfg)
+        assert e.async_pipe == pipe
+        e.start()
+        for _ in range(60 * (sims + K) // K):           # ~60 plies: most games end and restart.  The same cadence for both forms: K rounds
+            e.groups[0].rounds(K, e.fused, e.percu)     # (descent / forward pairs per tree), then the advance
+        torch.cuda.synchronize()
+        st = e.stats()
+        assert st['errors'] == 0 and st['games'] > 0
+        ex = [x.cpu() for x in e.drain_examples()]
+        m = ex[5].to(torch.int64)                       # the ring's order is the order in which games happened to end: sort by (stream, game, ply)
+        order = torch.argsort((m[:, 0] * 100000 + m[:, 1]) * 1000 + m[:, 2])
+        ex = [x[order] for x in ex]
+        rs = {k: v.cpu() for k, v in e.forest.root_stats().items()}
+        if pipe:
+            prof = e.forest.async_profile()
+            assert prof['descents'] > 0 and prof['leaves'] > 0 and prof['batches'] > 0
+        out.append((st, ex, rs))
+        assert e.forest.validate(verbose=False) == 0
+        e.close()
+    (s0, e0, r0), (s1, e1, r1) = out
+    for k in ('plies', 'games', 'sims', 'levels', 'expansions', 'terminal_hits', 'examples', 'sum_valid_visited', 'sum_depth_at_expand'):
+        assert s0[k] == s1[k], (k, s0[k], s1[k])
+    assert len(e0[0]) == len(e1[0]) > 0
+    for a, b in zip(e0, e1):
+        assert torch.equal(a, b)
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+
+
 @pytest.mark.parametrize('game_key', ['santorini11', 'splendor4', 'azul', 'santorini1'])
 def test_full_size_properties_other_configs(game_key):
     """BASELINE.json configs 3 / 4 / 5 (and the north star's second target) at FULL size -- 4096 concurrent games, 800 simulations per

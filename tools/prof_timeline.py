@@ -35,5 +35,20 @@ def main():
         sum(r[1] - r[0] for r in rows) / 1e3, busy / 1e3, sum(r[1] - r[0] for r in rows) / max(busy, 1)))
 
 
+def launches(path, pattern):
+    """one line per dispatch whose name contains `pattern`: start offset, duration, gap since the previous matching dispatch ended"""
+    db = sqlite3.connect(path)
+    rows = db.execute("select start, end, name from kernels order by start").fetchall()
+    rows = [r for r in rows if pattern in r[2]]
+    t0 = rows[0][0]
+    prev = t0
+    for i, (s_, e_, name) in enumerate(rows):
+        print('%4d  start %10.1f us  dur %8.1f  since previous end %+8.1f  %s' % (i, (s_ - t0) / 1e3, (e_ - s_) / 1e3, (s_ - prev) / 1e3, name[:40]))
+        prev = e_
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 2 and sys.argv[2] == '--launches':
+        launches(sys.argv[1], sys.argv[3])
+        sys.exit(0)
     main()
