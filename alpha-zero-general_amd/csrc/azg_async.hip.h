@@ -28,10 +28,12 @@
 //   stores = `global_store ... sc1`) by the producer, every storing wave drains (`s_waitcnt vmcnt(0)`), then ONE lane publishes the
 //   queue word (agent-scope atomic); the consumer polls that word relaxed and reads the payload with agent-scope loads (past its L1).
 //   No fence anywhere.  Queue words: ring entries carry a lap tag (never reset), ready words are owned by one select workgroup.
-//   Every spin loop is bounded: past `timeout_ticks` of the 100 MHz wall clock a wave sets ctl->abort (everyone leaves) and error bit
-//   ERR_ASYNC_TIMEOUT on tree 0 -- a pipeline that cannot make progress (a workgroup not resident) fails loudly instead of hanging.
+//   Every spin loop is bounded: a wave that finds nothing to do for `timeout_ticks` of the 100 MHz wall clock sets ctl->abort (everyone
+//   leaves) and error bit ERR_ASYNC_TIMEOUT on tree 0 -- a pipeline that cannot make progress (a workgroup not resident) fails loudly
+//   instead of hanging.
 #pragma once
 #include "azg_fused.hip.h"
+#include "selfplay.hip.h"
 
 namespace azg {
 
@@ -43,24 +45,26 @@ struct AsyncCtl {                              // zeroed by the host before ever
     uint32_t leaf_tail; uint32_t pad0[31];     // leaf tickets issued (producers: descent waves)
     uint32_t leaf_head; uint32_t pad1[31];     // leaf tickets claimed (consumers: net workgroups)
     uint32_t retired; uint32_t abort; uint32_t pad2[30];   // trees that are done with this launch; != 0: leave now (1 select, 2 net, 3 ring)
-};
+    unsigned long long calls; uint32_t stop; uint32_t pad3[29];   // work-sharing budget: select_tree calls so far (flushed per workgroup in
+};                                                                 // blocks of 32); 1 once they reach AsyncArgs.total_calls: trees retire
 
 // profile counters (accumulated over launches, wall-clock ticks of 10 ns):
 //  0 select_tree calls   1 ticks inside them        2 ticks a descent wave spent looking for a ready tree
 //  3 net batches         4 leaves in them           5 ticks inside the forward    6 ticks a net workgroup spent waiting for leaves
 //  7 sum of (leaf claimed - leaf pushed)            8 sum of (tree claimed - tree marked ready)
 //  9 launches           10 select workgroup-ticks resident   11 net workgroup-ticks resident
-// 12 n_sel  13 n_net (filled by the host)   14 shader-clock cycles inside the forwards   15 inside the descents
+// 12 n_sel  13 n_net (filled by the host)   14 shader-clock cycles inside the forwards   15 inside the descents   16 plies advanced in-kernel
 // 32..63 histogram of the leaf wait in us (last bucket: >= 31)    64..95 histogram of the ready wait
 struct AsyncArgs {
     ForestDev F;
     H2Weights W;
     int8_t* aleaf; uint8_t* leaf_valid; uint8_t* needs_eval; float* pi; float* v;
-    AsyncCtl* ctl; uint32_t* ring; uint32_t* ready; uint32_t* ts_leaf; uint32_t* ts_ready;
+    AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts_leaf; uint32_t* ts_ready;
     unsigned long long* prof;
     unsigned long long* wginfo;                // [n_sel + n_net][4]: where the workgroup ran (XCC | cu << 8 | se << 16 | sh << 24), role, calls, busy shader cycles
     int noise, rounds, n_sel, ring_bits, batch_wait, timeout_ticks;
-};
+    unsigned long long total_calls;            // != 0: the launch ends when the trees TOGETHER have had this many calls (whichever tree is fast
+};                                             // gets more of them: no tree waits for the slowest at the end of a launch); 0: `rounds` calls per tree
 __device__ __forceinline__ uint32_t where_am_i() {
     uint32_t xcc, hw;
     asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));              // HW_REG_XCC_ID
@@ -81,10 +85,59 @@ struct AsyncSelLds {
     uint32_t retired;                          // trees of this workgroup that are done with the launch
     uint32_t cursor;                           // rotating start of the scan (fairness)
     uint32_t scout;                            // 1: a wave is polling the ready words in HBM (ONE poller per CU; the other idle waves watch `seen`)
-    uint32_t pad;
-    unsigned long long prof[5];                // calls, busy ticks, idle ticks, ready-wait sum, shader cycles inside the descents
+    uint32_t calls;                            // select_tree calls of this workgroup (every 32nd one adds 32 to ctl->calls)
+    uint32_t stop;                             // the scout's copy of ctl->stop
+    uint32_t pad[3];
+    unsigned long long prof[6];                // calls, busy ticks, idle ticks, ready-wait sum, shader cycles inside the descents, plies advanced
     uint32_t hist[32];
-};
+    uint32_t rw[ASYNC_RS];                     // the scout's snapshot of the ready words (calls left + 1; 0 = not ready)
+    uint32_t last[ASYNC_RS];                   // the ready word this workgroup consumed last for tree i: a tree's words DECREASE over a launch,
+};                                             // so a snapshot is current iff it is smaller -- no second look at HBM before a claim
+
+// What the two-kernel rounds do BETWEEN rounds (azg_selfplay_advance: k_selfplay_advance -> k_gc -> k_after_gc -> k_root_noise), for one
+// tree, on the descent wave that found the search finished or the fresh root waiting for its noise: the tree goes on at once instead of
+// sitting out the rest of a launch.  Out of line: ~once per 800 calls of a tree, and the f64 pow / log / cos of the temperature and of the
+// Gamma sampler must not weigh on the descent loop's registers.  Returns true when the tree is searching again.
+template <class G>
+__device__ __noinline__ bool async_between_calls(const AsyncArgs* args, int t, uint8_t* mine /* this wave's LDS block */) {
+    using FR = Forest<G>;
+    using RL = RoundLds<G>;
+    const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+    const ForestDev F = load_const(&A->F);
+    typename FR::Smem& sm = *(typename FR::Smem*)mine;
+    float* const dense = (float*)(mine + RL::DENSE_OFF);
+    static_assert(sizeof(sm.path) >= sizeof(double) * G::A && sizeof(sm.path) >= sizeof(uint32_t) * (G::A + 8), "the path block doubles as scratch here");
+    const int l = lane_id();
+    uint32_t status = ld_agent_u32(&F.hdr[t].status);
+    if (status == ST_DONE && !ld_agent_u32(&F.hdr[t].err)) {
+        advance_tree<G>(F, t, sm, (int*)dense, (double*)sm.path, dense);
+        wave_sync();
+        status = ld_agent_u32(&F.hdr[t].status);
+        if (status == ST_GC) {
+            // the clean-up on this one wave (k_gc gives it sixteen; here the other fifteen are descending other trees)
+            TreeHdr H = load_uniform(&F.hdr[t]);
+            uint32_t* head = (uint32_t*)sm.path;
+            gc_scan<G, true>(F, t, H, (int)H.cur_pre, head, head + G::A + 1, 0, 1);
+            if (l == 0) {
+                TreeHdr* Hp = &F.hdr[t];
+                Hp->n_free_ids = H.n_free_ids; Hp->n_nodes = H.n_nodes; Hp->max_live = H.max_live; Hp->free_units = H.free_units;
+                Hp->gc_runs = H.gc_runs; Hp->status = ST_GC_DONE;
+            }
+            drain_vmem();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the table was re-filled with L2 atomics: drop this CU's L1 copy of it
+            after_gc_tree<G>(F, t, sm, dense);
+            wave_sync();
+        }
+    }
+    if (A->noise && F.dirichletAlpha != 0.0 && ld_agent_u32(&F.hdr[t].noise_pending)) {
+        const uint32_t root_rec = ld_agent_u32(&F.hdr[t].root_rec);
+        const uint64_t c_sims = ld_agent_u64(&F.hdr[t].c_sims);
+        if (root_noise_tree<G>(F, t, root_rec, c_sims, nullptr, -1, dense, sm.mask) && l == 0) F.hdr[t].noise_pending = 0u;
+        wave_sync();
+    }
+    drain_vmem();
+    return ld_agent_u32(&F.hdr[t].status) == ST_SEARCHING && !ld_agent_u32(&F.hdr[t].err);
+}
 
 template <class G>
 __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
@@ -94,20 +147,25 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
     const int g = (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t t_begin = wall32();
-    int n_g, n_sel, rounds, timeout;
+    int n_g, n_sel, timeout;
     uint32_t* my_ready;
     {
         const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
-        n_sel = A->n_sel; rounds = A->rounds; timeout = A->timeout_ticks;
-        const int T = A->F.T;
+        n_sel = A->n_sel; timeout = A->timeout_ticks;
+        const int T = A->F.T, rounds = A->rounds;
         n_g = g < T ? (T - g + n_sel - 1) / n_sel : 0;
         my_ready = A->ready + (size_t)g * ASYNC_RS;
-        // every tree of this workgroup starts the launch ready, with `rounds` pairs to go (ready word = pairs left + 1)
+        // every tree of this workgroup starts the launch ready, with `rounds` calls to go (ready word = calls left + 1)
         const int i = (int)threadIdx.x;
-        if (i < ASYNC_RS) astore(my_ready + i, i < n_g ? (uint32_t)rounds + 1u : 0u);
+        if (i < ASYNC_RS) {
+            const uint32_t w0 = i < n_g ? (uint32_t)rounds + 1u : 0u;
+            astore(my_ready + i, w0);
+            C->rw[i] = w0; C->last[i] = 0xFFFFFFFFu;
+        }
         if (i < n_g) astore(A->ts_ready + (g + i * n_sel), t_begin);
         if (i == 0) {
-            C->claimed[0] = C->claimed[1] = 0ull; C->retired = 0u; C->cursor = 0u; C->scout = 0u; C->prof[0] = C->prof[1] = C->prof[2] = C->prof[3] = C->prof[4] = 0ull;
+            C->claimed[0] = C->claimed[1] = 0ull; C->retired = 0u; C->cursor = 0u; C->scout = 0u; C->calls = 0u; C->stop = 0u;
+            for (int k = 0; k < 6; k++) C->prof[k] = 0ull;
             C->seen[0] = n_g >= 64 ? ~0ull : (1ull << n_g) - 1ull;             // every tree starts ready
             C->seen[1] = n_g >= 128 ? ~0ull : n_g > 64 ? (1ull << (n_g - 64)) - 1ull : 0ull;
         }
@@ -119,12 +177,13 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
     typename RL::Smem& sm = *(typename RL::Smem*)mine;
     float* const dense = (float*)(mine + RL::DENSE_OFF);
     uint32_t idle_since = wall32();                 // (profile sums live in the LDS block: nothing but this word is carried around the loop)
+#define AZG_LDS_LD64(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define AZG_LDS_LD32(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #pragma unroll 1
     for (;;) {
         const int l = lane_id();
-        if (__hip_atomic_load(&C->retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)n_g) break;
+        if (AZG_LDS_LD32(&C->retired) >= (uint32_t)n_g) break;
         // ---- look for a ready tree of this workgroup that no wave is handling: in the LDS copy of the ready words first ----
-#define AZG_LDS_LD64(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
         unsigned long long c0 = AZG_LDS_LD64(&C->seen[0]) & ~AZG_LDS_LD64(&C->claimed[0]);
         unsigned long long c1 = AZG_LDS_LD64(&C->seen[1]) & ~AZG_LDS_LD64(&C->claimed[1]);
         if (!(c0 | c1)) {
@@ -134,7 +193,19 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
             if (!uni_u32(got)) { __builtin_amdgcn_s_sleep(16); continue; }
             const uint32_t v0 = l < n_g ? aload(my_ready + l) : 0u;
             const uint32_t v1 = l + 64 < n_g ? aload(my_ready + 64 + l) : 0u;
-            const unsigned long long r0 = __ballot(v0 != 0u), r1 = __ballot(v1 != 0u);
+            {
+                const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+                if (A->total_calls) {
+                    const uint32_t st = uni_u32(aload(&A->ctl->stop));
+                    if (st && l == 0) __hip_atomic_store(&C->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            // current = smaller than the word this workgroup consumed last for the tree (a tree's ready words decrease over a launch)
+            const unsigned long long r0 = __ballot(v0 != 0u && v0 < AZG_LDS_LD32(&C->last[l]));
+            const unsigned long long r1 = __ballot(v1 != 0u && v1 < AZG_LDS_LD32(&C->last[64 + l]));
+            __hip_atomic_store(&C->rw[l], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&C->rw[64 + l], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            wave_sync();
             if (l == 0) {
                 __hip_atomic_store(&C->seen[0], r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_store(&C->seen[1], r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -146,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
                 const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
                 const uint32_t now = wall32();
                 if (uni_u32(aload(&A->ctl->abort))) leave = true;
-                else if ((int)(now - t_begin) > timeout) {
+                else if ((int)(now - idle_since) > timeout) {                  // (this wave has found nothing to do for that long)
                     if (l == 0) { astore(&A->ctl->abort, 1u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT); }
                     leave = true;
                 }
@@ -158,7 +229,7 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
             if (!(c0 | c1)) continue;
         }
         // the first candidate at or after the rotating cursor
-        const uint32_t cur = __hip_atomic_load(&C->cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 127u;
+        const uint32_t cur = AZG_LDS_LD32(&C->cursor) & 127u;
         const unsigned long long m0 = cur < 64u ? c0 & (~0ull << cur) : 0ull, m1 = cur < 64u ? c1 : c1 & (~0ull << (cur - 64u));
         int i;
         if (m0) i = __builtin_ctzll(m0);
@@ -172,17 +243,14 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
             __hip_atomic_store(&C->cursor, (uint32_t)i + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (uni_u32((uint32_t)((old & bit) != 0ull))) continue;            // another wave of this workgroup was faster
-        // the claim is ours: read the word again (a wave that handled the tree since our poll cleared it BEFORE it released the claim)
-        const uint32_t word = uni_u32(aload(my_ready + i));
-        if (word == 0u) {                                                  // (a stale bit of the LDS copy)
-            if (l == 0) {
-                __hip_atomic_fetch_and(&C->seen[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+        // the claim is ours.  Is the snapshot current?  (A wave that handled the tree since the poll recorded the word it consumed BEFORE it
+        // released the claim.)
+        const uint32_t word = uni_u32(AZG_LDS_LD32(&C->rw[i]));
+        if (l == 0) __hip_atomic_fetch_and(&C->seen[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // taken: ready again only by a later poll
+        if (word == 0u || word >= uni_u32(AZG_LDS_LD32(&C->last[i]))) {
+            if (l == 0) __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             continue;
         }
-        if (l == 0) __hip_atomic_fetch_and(&C->seen[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // taken: ready again only by a later poll
-        const uint32_t pairs_left = word - 1u;
         int t;
         {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
@@ -196,39 +264,67 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
             }
         }
         bool need = false;
-        uint32_t left = pairs_left;                                         // calls of this tree still to run in this launch
+        uint32_t left = word - 1u;                                          // calls of this tree still to run in this launch
+        if (AZG_LDS_LD32(&C->stop)) left = 0u;                              // the launch's shared budget is spent: the tree retires as it is
         while (left > 0u) {
-            const AsyncArgs* a = args;
-            asm volatile("" : "+s"(a));                                     // (opaque per tree: nothing of a descent is kept live across the loop)
-            const AsyncArgsC A = (AsyncArgsC)(uintptr_t)a;
-            const ForestDev F = load_const(&A->F);
-            const uint32_t c0t = wall32();
-            const uint32_t y0t = (uint32_t)clock64();
-            const int r = select_tree<G, true>(F, t, sm, dense, A->aleaf, A->leaf_valid, A->needs_eval, A->noise, A->pi, A->v, A->noise);
-            if (l == 0) {
-                atomicAdd(&C->prof[0], 1ull); atomicAdd(&C->prof[1], (unsigned long long)(wall32() - c0t));
-                atomicAdd(&C->prof[4], (unsigned long long)((uint32_t)clock64() - y0t));
+            int r;
+            {
+                const AsyncArgs* a = args;
+                asm volatile("" : "+s"(a));                                 // (opaque per call: nothing of a descent is kept live across the loop)
+                const AsyncArgsC A = (AsyncArgsC)(uintptr_t)a;
+                const ForestDev F = load_const(&A->F);
+                const uint32_t c0t = wall32();
+                const uint32_t y0t = (uint32_t)clock64();
+                r = select_tree<G, true>(F, t, sm, dense, A->aleaf, A->leaf_valid, A->needs_eval, A->noise, A->pi, A->v, A->noise);
+                if (l == 0) {
+                    atomicAdd(&C->prof[0], 1ull); atomicAdd(&C->prof[1], (unsigned long long)(wall32() - c0t));
+                    atomicAdd(&C->prof[4], (unsigned long long)((uint32_t)clock64() - y0t));
+                }
             }
             left--;
             need = r == 1;
-            // r == 2: the work budget parked the descent (what a round of the two-kernel form does with such a tree: no leaf this round,
-            // the descent goes on in the next one) -- the next call follows at once, on this wave; a tree is never left mid-call, so a
-            // launch can end with parked descents
-            if (r != 2) { if (r == 0) left = 0u; break; }
+            {
+                const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+                const unsigned long long total = A->total_calls;
+                if (total) {
+                    uint32_t stop = 0u;
+                    if (l == 0) {
+                        const uint32_t c = __hip_atomic_fetch_add(&C->calls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+                        if ((c & 31u) == 0u) {
+                            const unsigned long long g0 = atomicAdd(&A->ctl->calls, 32ull) + 32ull;
+                            if (g0 >= total) { astore(&A->ctl->stop, 1u); __hip_atomic_store(&C->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                        }
+                        stop = AZG_LDS_LD32(&C->stop);
+                    }
+                    if (uni_u32(stop) && r != 1) { left = 0u; }              // (a tree that has just queued a leaf carries on until the net hands it back)
+                }
+            }
+            if (r == 1) break;
+            // r == 2: the work budget parked the descent (what a round of the two-kernel form does with such a tree: no leaf this round, the
+            // descent goes on in the next one) -- the next call follows at once, on this wave.
+            // r == 0: the search is finished, or its fresh root waits for the noise: what azg_selfplay_advance does between rounds happens
+            // here and now (the move, the example record, the next search, the clean-up, the noise), then the next call follows
+            if (r == 0) {
+                drain_vmem();
+                const bool on = async_between_calls<G>(args, t, mine);
+                if (l == 0) atomicAdd(&C->prof[5], 1ull);
+                if (!on) { left = 0u; break; }                              // idle (episode quota), parked with an error: done with this launch
+            }
         }
-        // ---- hand the tree on: clear its ready word, drain EVERY store of this wave (the tree's records, its leaf), release the claim ----
-        if (l == 0) astore(my_ready + i, 0u);
+        // ---- hand the tree on: record the word consumed, drain EVERY store of this wave (the tree's records, its leaf), release the claim ----
+        if (l == 0) __hip_atomic_store(&C->last[i], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         drain_vmem();
         if (l == 0) __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
             if (l == 0) {
                 if (need) {
-                    astore(A->ts_leaf + t, wall32());
-                    drain_vmem();
+                    astore(A->ts_leaf + t, wall32());                        // (profile only: not ordered against the ticket)
                     const uint32_t tk = atomicAdd(&A->ctl->leaf_tail, 1u);
                     const uint32_t rb = (uint32_t)A->ring_bits;
-                    astore(A->ring + (tk & ((1u << rb) - 1u)), (uint32_t)t | (left << 20) | ((((tk >> rb) & 7u) + 1u) << 28));
+                    __hip_atomic_store(A->ring + (tk & ((1u << rb) - 1u)),
+                                       (unsigned long long)(uint32_t)t | ((unsigned long long)left << 32) | ((unsigned long long)(((tk >> rb) & 7u) + 1u) << 60),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     __hip_atomic_fetch_add(&C->retired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     atomicAdd(&A->ctl->retired, 1u);
@@ -245,7 +341,7 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
         const int i = (int)threadIdx.x;
         if (i == 0) {
             atomicAdd(prof + 0, C->prof[0]); atomicAdd(prof + 1, C->prof[1]); atomicAdd(prof + 2, C->prof[2]); atomicAdd(prof + 8, C->prof[3]);
-            atomicAdd(prof + 15, C->prof[4]);
+            atomicAdd(prof + 15, C->prof[4]); atomicAdd(prof + 16, C->prof[5]);
             unsigned long long* wi = A->wginfo + (size_t)g * 4;
             wi[0] = where_am_i(); wi[1] = 1ull; wi[2] += C->prof[0]; wi[3] += C->prof[4];
             atomicAdd(prof + 10, (unsigned long long)(wall32() - t_begin));
@@ -286,20 +382,21 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
             }
             const uint32_t tk = base + (uint32_t)(lane & 15);
             const uint32_t tag = ((tk >> rb) & 7u) + 1u;
-            uint32_t first_seen = 0u, e = 0u;
+            uint32_t first_seen = 0u;
+            unsigned long long e = 0ull;
             bool seen = false;
             int n = 0;
             uint32_t take = 0u;
             unsigned spins = 0u;
             for (;;) {
-                e = lane < 16 ? aload(A->ring + (tk & rmask)) : 0u;
-                const uint32_t filled = (uint32_t)__ballot(lane < 16 && (e >> 28) == tag) & ~taken;
+                e = lane < 16 ? __hip_atomic_load(A->ring + (tk & rmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                const uint32_t filled = (uint32_t)__ballot(lane < 16 && (uint32_t)(e >> 60) == tag) & ~taken;
                 const uint32_t now = wall32();
                 if (filled && !seen) { seen = true; first_seen = now; }
                 if (filled && ((filled | taken) == 0xFFFFu || (int)(now - first_seen) >= wait_ticks)) { take = filled; n = __popc(filled); break; }
                 if (!filled && (++spins & 7u) == 0u) {
                     if (uni_u32(aload(&ctl->retired)) >= (uint32_t)T || uni_u32(aload(&ctl->abort))) { n = -1; break; }
-                    if ((int)(now - t_begin) > timeout) {
+                    if ((int)(now - idle0) > timeout) {                              // (no leaf for that long)
                         if (lane == 0) { astore(&ctl->abort, 2u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT); }
                         n = -1;
                         break;
@@ -315,9 +412,9 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
                 uint32_t w = 0u;
                 if (mine) {
                     const int slot = __popc(take & ((1u << lane) - 1u));           // the batch is the taken tickets, compacted
-                    const int t = (int)(e & 0xFFFFFu);
+                    const int t = (int)(uint32_t)e;
                     sidx[slot] = t;
-                    sidx[16 + slot] = (int)((e >> 20) & 0xFFu);
+                    sidx[16 + slot] = (int)((e >> 32) & 0xFFFFFFu);
                     w = now - aload(A->ts_leaf + t);
                     atomicAdd(A->prof + 32 + ((w / 100u) < 31u ? (w / 100u) : 31u), 1ull);
                 }
@@ -346,8 +443,7 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
             if (tid < 16 && sidx[tid] >= 0) {
                 const int t = sidx[tid], ns = A->n_sel;
                 const int gi = t % ns, ii = t / ns;
-                astore(A->ts_ready + t, wall32());
-                drain_vmem();
+                astore(A->ts_ready + t, wall32());                       // (profile only: not ordered against the ready word)
                 astore(A->ready + (size_t)gi * ASYNC_RS + ii, (uint32_t)sidx[16 + tid] + 1u);
             }
         }
@@ -372,17 +468,17 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
 // ---- host side ----
 struct AsyncSlot {
     AsyncArgs host; AsyncArgs* devbuf;
-    int8_t* aleaf; AsyncCtl* ctl; uint32_t* ring; uint32_t* ready; uint32_t* ts; unsigned long long* prof; unsigned long long* wginfo;
-    hipStream_t side; hipEvent_t fork, join;
+    int8_t* aleaf; AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts; unsigned long long* prof; unsigned long long* wginfo;
+    hipEvent_t fork, join, join_net;
     int n_sel, n_net, ring_bits;
 };
 static void async_slot_free(void* p) {
     AsyncSlot* s = (AsyncSlot*)p;
     (void)hipFree(s->devbuf); (void)hipFree(s->aleaf); (void)hipFree(s->ctl); (void)hipFree(s->ring); (void)hipFree(s->ready);
     (void)hipFree(s->ts); (void)hipFree(s->prof); (void)hipFree(s->wginfo);
-    if (s->side) (void)hipStreamDestroy(s->side);
     if (s->fork) (void)hipEventDestroy(s->fork);
     if (s->join) (void)hipEventDestroy(s->join);
+    if (s->join_net) (void)hipEventDestroy(s->join_net);
     delete s;
 }
 
@@ -397,6 +493,12 @@ extern "C" int azg_forest_async_profile(azg_forest* f, double* out /* [ASYNC_NPR
     HIPCHK(hipMemcpy(h, sl->prof, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < ASYNC_NPROF; i++) out[i] = (double)h[i];
     out[12] = (double)sl->n_sel; out[13] = (double)sl->n_net;
+    {   // the control block as the last launch left it: tickets issued / claimed, trees retired, abort code, shared-budget state
+        AsyncCtl c;
+        HIPCHK(hipMemcpy(&c, sl->ctl, sizeof(c), hipMemcpyDeviceToHost));
+        out[20] = (double)c.leaf_tail; out[21] = (double)c.leaf_head; out[22] = (double)c.retired; out[23] = (double)c.abort;
+        out[24] = (double)c.calls; out[25] = (double)c.stop;
+    }
     if (reset) HIPCHK(hipMemset(sl->prof, 0, sizeof(h)));
     return 0;
 }
@@ -417,10 +519,10 @@ extern "C" int azg_forest_async_wginfo(azg_forest* f, unsigned long long* out /*
 // persistent kernels
 extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v, int noise_stride,
                                               const void* const* w, const float* descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
-                                              void* stream) {
+                                              int shared_budget, void* stream) {
     if (!f || !leaf_valid || !needs_eval || !pi || !v || !w || !descale) return fail("azg_forest_async_rounds_v80_h2: null argument");
     if (rounds <= 0) return 0;
-    if (rounds > 255) return fail("azg_forest_async_rounds_v80_h2: at most 255 rounds per launch");
+    if (rounds >= (1 << 24)) return fail("azg_forest_async_rounds_v80_h2: at most 2^24 - 1 rounds per launch");
     if (noise_stride != 0 && noise_stride != -2) return fail("azg_forest_async_rounds_v80_h2: noise_stride must be 0 or -2");
     int game = 0, variant = 0;
     double alpha = 0.0;
@@ -429,7 +531,19 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
     using G = SplendorDev<2>;
     static_assert(AsyncLeaf<G>::STRIDE == H2_AL_STRIDE && AsyncLeaf<G>::MASK_OFF == H2_AL_MASK, "leaf record layout shared with the net kernel");
     static int n_cu = 0;
+    // The two kernels MUST run side by side, so their streams must not share a hardware queue (HIP multiplexes streams onto a few queues
+    // -- 4 per priority level by default -- and kernels of one queue run one after the other: the net kernel would wait for leaves that
+    // the descent kernel, queued behind it, can never deliver; seen as the 2 s time-out in a process that had created many streams
+    // before) and must not synchronise implicitly with the legacy default stream (a BLOCKING stream's kernel waits for the default
+    // stream's earlier work: the same dead end when the caller is on the default stream).  Both kernels therefore run on two private
+    // NON-BLOCKING streams of the HIGH priority level, created once per process -- the first streams of that level own a hardware queue
+    // each --, and the caller's stream only forks into them and joins them.
+    static hipStream_t net_stream = nullptr, sel_stream = nullptr;
     if (!n_cu) {
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&net_stream, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&sel_stream, hipStreamNonBlocking, hi));
         int d = 0;
         hipDeviceProp_t prop;
         HIPCHK(hipGetDevice(&d));
@@ -439,8 +553,8 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         HIPCHK(hipFuncSetAttribute((const void*)k_async_select<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int T = dev->T;
-    if (n_net <= 0 || n_sel <= 0) {                   // default split of the CUs: 9 / 16 for the net (a forward is 30 us, a descent 19)
-        n_net = n_cu * 9 / 16;
+    if (n_net <= 0 || n_sel <= 0) {                   // default split of the CUs: 17 / 32 for the net (measured at 4096 x 800: 136 + 120 of 256)
+        n_net = n_cu * 17 / 32;
         n_sel = n_cu - n_net;
     }
     if (n_sel > T) n_sel = T;
@@ -448,7 +562,6 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
     if (n_net + n_sel > n_cu)
         return fail("azg_forest_async_rounds_v80_h2: n_net + n_sel exceeds the CUs of the device (every workgroup of the pipeline must be resident)");
     if ((long long)n_sel * ASYNC_RS < T) return fail("azg_forest_async_rounds_v80_h2: more than 128 trees per select workgroup");
-    if (T >= (1 << 20)) return fail("azg_forest_async_rounds_v80_h2: at most 2^20 - 1 trees");
     AsyncSlot* sl = (AsyncSlot*)azg_forest_attached(f, "async_v80");
     if (sl && (sl->n_sel != n_sel || sl->n_net != n_net)) return fail("azg_forest_async_rounds_v80_h2: the CU split of a forest cannot change");
     if (!sl) {
@@ -463,7 +576,7 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         HIPCHK(hipMalloc(&sl->devbuf, sizeof(AsyncArgs)));
         HIPCHK(hipMalloc(&sl->aleaf, (size_t)T * AsyncLeaf<G>::STRIDE));
         HIPCHK(hipMalloc(&sl->ctl, sizeof(AsyncCtl)));
-        HIPCHK(hipMalloc(&sl->ring, sizeof(uint32_t) << rb));
+        HIPCHK(hipMalloc(&sl->ring, sizeof(unsigned long long) << rb));
         HIPCHK(hipMalloc(&sl->ready, sizeof(uint32_t) * ASYNC_RS * n_sel));
         HIPCHK(hipMalloc(&sl->ts, sizeof(uint32_t) * 2 * T));
         HIPCHK(hipMalloc(&sl->prof, sizeof(unsigned long long) * ASYNC_NPROF));
@@ -472,9 +585,9 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         HIPCHK(hipMemset(sl->wginfo, 0, sizeof(unsigned long long) * 4 * (n_sel + n_net)));
         HIPCHK(hipMemset(sl->aleaf, 0, (size_t)T * AsyncLeaf<G>::STRIDE));
         HIPCHK(hipMemset(sl->ts, 0, sizeof(uint32_t) * 2 * T));
-        HIPCHK(hipStreamCreateWithFlags(&sl->side, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl->join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl->join_net, hipEventDisableTiming));
     }
     AsyncArgs want;
     memset(&want, 0, sizeof(want));
@@ -487,6 +600,10 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
     want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_leaf = sl->ts; want.ts_ready = sl->ts + T; want.prof = sl->prof; want.wginfo = sl->wginfo;
     want.noise = (alpha != 0.0 && noise_stride == -2) ? 1 : 0;
     want.rounds = rounds; want.n_sel = n_sel; want.ring_bits = sl->ring_bits;
+    if (shared_budget) {                              // `rounds` x T calls for the trees together; no tree is held back by a share of its own
+        want.total_calls = (unsigned long long)rounds * (unsigned long long)T;
+        want.rounds = (1 << 24) - 2;
+    }
     want.batch_wait = batch_wait_ticks >= 0 ? batch_wait_ticks : 150;
     { const char* e = getenv("AZG_ASYNC_TIMEOUT_MS"); want.timeout_ticks = (e ? atoi(e) : 2000) * 100000; }
     hipStream_t s = (hipStream_t)stream;
@@ -495,15 +612,18 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         HIPCHK(hipMemcpyAsync(sl->devbuf, &sl->host, sizeof(AsyncArgs), hipMemcpyHostToDevice, s));
     }
     HIPCHK(hipMemsetAsync(sl->ctl, 0, sizeof(AsyncCtl), s));
-    HIPCHK(hipMemsetAsync(sl->ring, 0, sizeof(uint32_t) << sl->ring_bits, s));
-    // fork: the net workgroups on the caller's stream, the descent workgroups on the side stream; join before returning
+    HIPCHK(hipMemsetAsync(sl->ring, 0, sizeof(unsigned long long) << sl->ring_bits, s));
+    // fork from the caller's stream into the two private streams, join both before returning
     HIPCHK(hipEventRecord(sl->fork, s));
-    HIPCHK(hipStreamWaitEvent(sl->side, sl->fork, 0));
-    k_async_net<<<dim3(n_net), dim3(768), ASYNC_NET_LDS, s>>>(sl->devbuf);
+    HIPCHK(hipStreamWaitEvent(net_stream, sl->fork, 0));
+    HIPCHK(hipStreamWaitEvent(sel_stream, sl->fork, 0));
+    k_async_net<<<dim3(n_net), dim3(768), ASYNC_NET_LDS, net_stream>>>(sl->devbuf);
     HIPCHK(hipGetLastError());
-    k_async_select<G><<<dim3(n_sel), dim3(1024), 16 * RoundLds<G>::STRIDE + (int)sizeof(AsyncSelLds), sl->side>>>(sl->devbuf);
+    k_async_select<G><<<dim3(n_sel), dim3(1024), 16 * RoundLds<G>::STRIDE + (int)sizeof(AsyncSelLds), sel_stream>>>(sl->devbuf);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(sl->join, sl->side));
+    HIPCHK(hipEventRecord(sl->join_net, net_stream));
+    HIPCHK(hipEventRecord(sl->join, sel_stream));
+    HIPCHK(hipStreamWaitEvent(s, sl->join_net, 0));
     HIPCHK(hipStreamWaitEvent(s, sl->join, 0));
     return 0;
 }

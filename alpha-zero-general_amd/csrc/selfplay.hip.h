@@ -28,9 +28,14 @@ __device__ __forceinline__ double temp_for_selfplay(const ForestDev& F, int n) {
 // throttled sustained self-play to a tenth of its fresh-start rate).
 // `n_waves` wavefronts of one workgroup share the scan (wave w takes the 64-id groups w, w + n_waves, ...); the list heads
 // and the three running counters live in LDS.  With n_waves == 1 the barriers compile away.
-template <class G>
+// WAVE_ONLY: the caller is ONE wave of a workgroup whose other waves do something else (the asynchronous pipeline, azg_async.hip.h): the
+// hand-overs between the lanes are wavefront fences, not workgroup barriers; the caller drops its CU's L1 afterwards (the table is
+// re-filled with L2 atomics, which the L1 does not see).
+template <class G, bool WAVE_ONLY = false>
 __device__ __forceinline__ void gc_scan(const ForestDev& F, int t, TreeHdr& H, int min_round, uint32_t* lds_head /*[A + 1]*/,
                                         uint32_t* lds_ctr /*[4]*/, int wave, int n_waves) {
+#define AZG_GC_SYNC() do { if (WAVE_ONLY) wave_sync(); else __syncthreads(); } while (0)
+#define AZG_GC_FENCE() do { if (!WAVE_ONLY) __threadfence(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
     using FR = Forest<G>;
     const int l = lane_id(), tid = wave * 64 + l, nthr = n_waves * 64;
     uint8_t* hp = FR::heap(F, t);
@@ -43,8 +48,8 @@ __device__ __forceinline__ void gc_scan(const ForestDev& F, int t, TreeHdr& H, i
     for (int i = tid; i < nc; i += nthr) lds_head[i] = gfree[i];
     for (int i = tid; i < F.HT; i += nthr) tab[i] = AZG_NONE;
     if (tid == 0) { lds_ctr[0] = H.n_free_ids; lds_ctr[1] = 0u; lds_ctr[2] = 0u; }
-    __threadfence();
-    __syncthreads();
+    AZG_GC_FENCE();
+    AZG_GC_SYNC();
     for (uint32_t base = (uint32_t)wave * 64u; base < n; base += (uint32_t)nthr) {
         const uint32_t i = base + (uint32_t)l;
         NodeHdr nh;
@@ -75,15 +80,17 @@ __device__ __forceinline__ void gc_scan(const ForestDev& F, int t, TreeHdr& H, i
             while (atomicCAS(&tab[s], AZG_NONE, entry) != AZG_NONE) s = (s + 1u) & maskHT;
         }
     }
-    __syncthreads();
+    AZG_GC_SYNC();
     for (int i = tid; i < nc; i += nthr) gfree[i] = lds_head[i];
-    __threadfence();
+    AZG_GC_FENCE();
     H.n_free_ids = uni_u32(lds_ctr[0]);
     H.n_nodes = uni_u32(lds_ctr[1]);
     if (H.n_nodes > H.max_live) H.max_live = H.n_nodes;
     H.free_units += uni_u32(lds_ctr[2]);
     H.gc_runs++;
-    __syncthreads();
+    AZG_GC_SYNC();
+#undef AZG_GC_SYNC
+#undef AZG_GC_FENCE
 }
 
 // single-wave form (host-driven searches)
@@ -217,6 +224,17 @@ __global__ __launch_bounds__(1024) void k_gc(ForestDev F) {
     }
 }
 
+// the search of a cleaned-up tree (status ST_GC_DONE) begins: one wave, the caller supplies the LDS blocks
+template <class G>
+__device__ __forceinline__ void after_gc_tree(const ForestDev& F, int t, typename Forest<G>::Smem& sm, float* dense /*LDS [A]*/) {
+    using FR = Forest<G>;
+    TreeHdr H = load_uniform(&F.hdr[t]);
+    Rng rng{forest_seed(F), F.stream0 + (uint64_t)t, H.rng_counter};
+    FR::load_state(sm.st, F.root_state + (size_t)t * G::SP);
+    begin_next_search<G>(F, t, H, sm, rng, dense);
+    if (lane_id() == 0) F.hdr[t] = H;
+}
+
 template <class G>
 __global__ __launch_bounds__(64) void k_after_gc(ForestDev F) {
     using FR = Forest<G>;
@@ -224,11 +242,7 @@ __global__ __launch_bounds__(64) void k_after_gc(ForestDev F) {
     __shared__ __attribute__((aligned(16))) float dense[G::A];
     const int t = blockIdx.x;
     if (ld_agent_u32(&F.hdr[t].status) != ST_GC_DONE) return;
-    TreeHdr H = load_uniform(&F.hdr[t]);
-    Rng rng{forest_seed(F), F.stream0 + (uint64_t)t, H.rng_counter};
-    FR::load_state(sm.st, F.root_state + (size_t)t * G::SP);
-    begin_next_search<G>(F, t, H, sm, rng, dense);
-    if (lane_id() == 0) F.hdr[t] = H;
+    after_gc_tree<G>(F, t, sm, dense);
 }
 
 // MCTS.getActionProb prologue for host-driven searches (azg_forest_begin_search)
@@ -250,21 +264,15 @@ __global__ __launch_bounds__(64) void k_begin_search(ForestDev F, const int8_t* 
     if (lane_id() == 0) F.hdr[t] = H;
 }
 
+// The per-ply work of Coach.executeEpisode for ONE tree whose search is finished (status ST_DONE), run by one wave; the caller supplies the
+// LDS blocks (k_selfplay_advance: one single-wave workgroup per tree; the asynchronous pipeline: the descent wave that found the search
+// finished, azg_async.hip.h).  Leaves the tree searching again, waiting for the clean-up (ST_GC), idle (episode quota) or parked with an
+// error flag.
 template <class G>
-__global__ __launch_bounds__(64) void k_selfplay_advance(ForestDev F) {
+__device__ __forceinline__ void advance_tree(const ForestDev& F, const int t, typename Forest<G>::Smem& sm, int* cnt /*LDS [A]*/,
+                                             double* w /*LDS [A]*/, float* dense /*LDS [A]*/) {
     using FR = Forest<G>;
-    __shared__ typename FR::Smem sm;
-    __shared__ int cnt[G::A];
-    __shared__ double w[G::A];
-    __shared__ __attribute__((aligned(16))) float dense[G::A];
-    const int t = blockIdx.x;
     const int l = lane_id();
-    const uint32_t status0 = ld_agent_u32(&F.hdr[t].status);
-    if (status0 != ST_DONE) {
-        // nothing to advance; a root expanded by simulation 0 may still be waiting for its Dirichlet noise (MCTS.py:147-149)
-        // (k_root_noise, launched right after, serves it)
-        return;
-    }
     TreeHdr H = load_uniform(&F.hdr[t]);
     if (H.err) return;                         // tree is parked; the host reads the error flag
     Rng rng{forest_seed(F), F.stream0 + (uint64_t)t, H.rng_counter};
@@ -412,6 +420,20 @@ __global__ __launch_bounds__(64) void k_selfplay_advance(ForestDev F) {
     }
     begin_next_search<G>(F, t, H, sm, rng, dense);
     if (l == 0) F.hdr[t] = H;
+}
+
+template <class G>
+__global__ __launch_bounds__(64) void k_selfplay_advance(ForestDev F) {
+    using FR = Forest<G>;
+    __shared__ typename FR::Smem sm;
+    __shared__ int cnt[G::A];
+    __shared__ double w[G::A];
+    __shared__ __attribute__((aligned(16))) float dense[G::A];
+    const int t = blockIdx.x;
+    // nothing to advance unless the search is finished; a root expanded by simulation 0 may still be waiting for its Dirichlet noise
+    // (MCTS.py:147-149): k_root_noise, launched right after, serves it
+    if (ld_agent_u32(&F.hdr[t].status) != ST_DONE) return;
+    advance_tree<G>(F, t, sm, cnt, w, dense);
 }
 
 }  // namespace azg

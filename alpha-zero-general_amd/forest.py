@@ -120,21 +120,21 @@ class Forest:
         check(lib().azg_forest_rounds_v80_h2(self.h, _ptr(self.leaf_states), _ptr(self.leaf_valid), _ptr(self.needs_eval), _ptr(pi), _ptr(v),
                                              -2 if device_noise else 0, net.net_ptrs_h2, net.descale_h2, int(rounds), _stream()))
 
-    def async_rounds_v80(self, net, pi, v, rounds, device_noise=False, n_net=0, n_sel=0, batch_wait_ticks=-1):
+    def async_rounds_v80(self, net, pi, v, rounds, device_noise=False, n_net=0, n_sel=0, batch_wait_ticks=-1, shared_budget=False):
         """`rounds` (descent, forward) pairs per tree as ONE launch of the asynchronous pipeline (azg_forest_async_rounds_v80_h2): persistent
         descent workgroups and persistent V80 net workgroups resident together, leaves and trees handed over through device-side queues"""
         assert pi.dtype == torch.float32 and v.dtype == torch.float32 and pi.is_contiguous() and v.is_contiguous()
         assert pi.shape == (self.T, self.A) and v.shape == (self.T, self.P)
         check(lib().azg_forest_async_rounds_v80_h2(self.h, _ptr(self.leaf_valid), _ptr(self.needs_eval), _ptr(pi), _ptr(v),
                                                    -2 if device_noise else 0, net.net_ptrs_h2, net.descale_h2, int(rounds), int(n_net), int(n_sel),
-                                                   int(batch_wait_ticks), _stream()))
+                                                   int(batch_wait_ticks), int(bool(shared_budget)), _stream()))
 
     def async_profile(self, reset=True):
         """the pipeline's counters since the last reset as a dict (times in microseconds; include/azg.h azg_forest_async_profile)"""
         out = (C.c_double * 96)()
         check(lib().azg_forest_async_profile(self.h, out, int(reset)))
         o = list(out)
-        d = dict(descents=o[0], batches=o[3], leaves=o[4], launches=o[9])
+        d = dict(descents=o[0], batches=o[3], leaves=o[4], launches=o[9], plies_in_kernel=o[16])
         d['descent_us'] = o[1] / max(o[0], 1) / 100.0
         d['forward_us'] = o[5] / max(o[3], 1) / 100.0
         d['leaves_per_batch'] = o[4] / max(o[3], 1)
@@ -143,6 +143,7 @@ class Forest:
         d['select_wave_busy'] = o[1] / max(o[1] + o[2], 1)          # share of a descent wave's life inside select_tree
         d['net_wg_busy'] = o[5] / max(o[11], 1)                     # share of a net workgroup's life inside the forward
         d['n_sel'], d['n_net'] = int(o[12]), int(o[13])
+        d['ctl'] = dict(leaf_tail=int(o[20]), leaf_head=int(o[21]), retired=int(o[22]), abort=int(o[23]), calls=int(o[24]), stop=int(o[25]))
         d['forward_cycles'] = o[14] / max(o[3], 1)                   # shader-clock cycles of a forward / a descent, and the clock they imply
         d['descent_cycles'] = o[15] / max(o[0], 1)
         d['net_cu_mhz'] = o[14] / max(o[5], 1) * 100.0

@@ -63,13 +63,8 @@ class _Group:
         the per-CU round kernel (azg_forest_rounds_v80_h2: 16 trees + their 16 leaves per workgroup, no launch boundary between rounds);
         percu == 'async': ONE launch of the asynchronous pipeline (azg_forest_async_rounds_v80_h2: n descent / forward pairs per tree)"""
         if percu == 'async':
-            done = 0
-            while done < n:                       # (a launch carries at most 255 pairs per tree)
-                k = min(255, n - done)
-                self.f.async_rounds_v80(self.net, self.pi, self.v, k, device_noise=bool(self.device_noise), **self.async_cfg)
-                done += k
-            if advance:
-                self.f.selfplay_advance()
+            # (no selfplay_advance: in the pipeline a tree whose search is finished advances at once, on the wave that found it finished)
+            self.f.async_rounds_v80(self.net, self.pi, self.v, n, device_noise=bool(self.device_noise), **self.async_cfg)
             return
         if percu:
             self.f.rounds_v80(self.net, self.pi, self.v, n, device_noise=bool(self.device_noise))
@@ -109,17 +104,41 @@ class SelfPlayEngine:
         # 0.1 % since k_select stopped reading the dispatch packet): Splendor 2p / 4p prefer short launches and a rarer advance (work
         # budget 10, every 48 rounds: +8 % / +3 % over 20 / 16), Azul and Santorini the opposite (20 / 16: 42.5 k vs 35.5 k, 21.6 k vs 20.9 k)
         from . import _lib
+        import os
         splendor = getattr(game, 'GAME_ID', None) == _lib.SPLENDOR
+        Tg = n_games // groups
+        nets = nnet if isinstance(nnet, (list, tuple)) else [nnet] + [nnet.clone_buffers() for _ in range(groups - 1)]
+        # the per-CU round kernel and the asynchronous pipeline exist for Splendor 2 players + the V80 net on its f16 x 2 kernel with static
+        # output buffers
+        A_game = _lib.game_info(game.GAME_ID, game.variant)[1]
+        can = (splendor and int(getattr(game, 'variant', 0) or 2) == 2 and self.fused and
+               all(getattr(n, 'h2', False) and getattr(n, 'fused_net', False) and hasattr(n, 'net_ptrs_h2') and
+                   torch.is_tensor(getattr(n, 'pi', None)) and tuple(n.pi.shape) == (Tg, A_game) for n in nets))
+        if percu is None:
+            # opt-in (AZG_PERCU=1 / percu=True): measured on one MI355X at 4096 x 800 it is the slower form of the round (65.1 k against
+            # 72.5 k env-steps/s, DESIGN.md 3.6: the 16-wave / 128-VGPR net phase costs 40 us against 32 for the 12-wave kernel and the
+            # launch ends with its slowest workgroup, which eats what the per-CU boundary gains on the descents)
+            percu = can and os.environ.get('AZG_PERCU', '0') == '1'
+        elif percu and not can:
+            raise ValueError('percu=True needs Splendor 2 players and SplendorV80Hip(h2=True) evaluators with max_batch == games per group')
+        # the asynchronous tree pipeline (csrc/azg_async.hip.h): persistent descent + net workgroups, no launch-wide boundary between the
+        # descents and the forwards; round 5: 100 k env-steps/s against 79 k for the two-kernel rounds at 4096 x 800.  Same preconditions
+        # as the per-CU kernel, one group.  AZG_ASYNC=0 / async_pipe=False: the two-kernel rounds.
+        if async_pipe is None:
+            async_pipe = can and groups == 1 and not percu and os.environ.get('AZG_ASYNC', '1') == '1'
+        elif async_pipe and not (can and groups == 1):
+            raise ValueError('async_pipe=True needs Splendor 2 players, SplendorV80Hip(h2=True) evaluators with max_batch == n_games, groups == 1')
+        self.async_pipe = bool(async_pipe)
         if work_budget is None:
-            work_budget = 10 if splendor else 20
+            # (the pipeline: a call that runs into the budget is followed by the next at once, the budget only bounds how long the trees
+            # take to notice the end of a launch: 20 measured best of 0 / 10 / 20 / 40)
+            work_budget = (20 if self.async_pipe else 10) if splendor else 20
         # cadence of the advance launch: idle share (K-1)/numMCTSSims kept to a few per cent
         self.K = max(1, min(48, sims // 16) if splendor else min(16, sims // 50)) if advance_every is None else int(advance_every)
         self.work_budget = int(work_budget)
-        Tg = n_games // groups
         alpha = float(get('dirichletAlpha', 0.0)) if dirichlet is None else float(dirichlet)
         # Coach passes dirichlet_noise=(dirichletAlpha != 0) (Coach.py:31,96).  The Gamma variates of
         # rng.dirichlet([alpha]*n_valid) (MCTS.py:187-192) are drawn on device by the engine's own sampler.
-        nets = nnet if isinstance(nnet, (list, tuple)) else [nnet] + [nnet.clone_buffers() for _ in range(groups - 1)]
         self.groups = []
         for g in range(groups):
             f = Forest(game.GAME_ID, game.variant, Tg, args, node_capacity=cap,
@@ -131,33 +150,16 @@ class SelfPlayEngine:
         self.nnet = nets[0]
         self.use_graph = use_graph
         self.rounds = 0
-        # the per-CU round kernel exists for Splendor 2 players + the V80 net on its f16 x 2 kernel with static output buffers
-        import os
-        can = (splendor and int(getattr(game, 'variant', 0) or 2) == 2 and self.fused and
-               all(getattr(n, 'h2', False) and getattr(n, 'fused_net', False) and hasattr(n, 'net_ptrs_h2') and
-                   torch.is_tensor(getattr(n, 'pi', None)) and tuple(n.pi.shape) == (Tg, self.forest.A) for n in nets))
-        if percu is None:
-            # opt-in (AZG_PERCU=1 / percu=True): measured on one MI355X at 4096 x 800 it is the slower form of the round (65.1 k against
-            # 72.5 k env-steps/s, DESIGN.md 3.6: the 16-wave / 128-VGPR net phase costs 40 us against 32 for the 12-wave kernel and the
-            # launch ends with its slowest workgroup, which eats what the per-CU boundary gains on the descents)
-            percu = can and os.environ.get('AZG_PERCU', '0') == '1'
-        elif percu and not can:
-            raise ValueError('percu=True needs Splendor 2 players and SplendorV80Hip(h2=True) evaluators with max_batch == games per group')
         self.percu = bool(percu)
-        # the asynchronous tree pipeline (csrc/azg_async.hip.h): persistent descent + net workgroups, no launch-wide boundary between the
-        # descents and the forwards.  Same preconditions as the per-CU kernel (Splendor 2 players, V80 on its f16 x 2 kernel with static
-        # output buffers), one group.  AZG_ASYNC=0 / async_pipe=False: the two-kernel rounds.
-        if async_pipe is None:
-            async_pipe = can and groups == 1 and not self.percu and os.environ.get('AZG_ASYNC', '0') == '1'
-        elif async_pipe and not (can and groups == 1):
-            raise ValueError('async_pipe=True needs Splendor 2 players, SplendorV80Hip(h2=True) evaluators with max_batch == n_games, groups == 1')
-        self.async_pipe = bool(async_pipe)
         if self.async_pipe:
             self.percu = 'async'
             cfg = dict(async_cfg or {})
-            for k, e in (('n_net', 'AZG_ASYNC_NNET'), ('n_sel', 'AZG_ASYNC_NSEL'), ('batch_wait_ticks', 'AZG_ASYNC_WAIT')):
+            for k, e in (('n_net', 'AZG_ASYNC_NNET'), ('n_sel', 'AZG_ASYNC_NSEL'), ('batch_wait_ticks', 'AZG_ASYNC_WAIT'), ('shared_budget', 'AZG_ASYNC_SHARED')):
                 if k not in cfg and os.environ.get(e):
                     cfg[k] = int(os.environ[e])
+            # run(rounds) = rounds x n_games calls for the trees TOGETHER (no tree waits for the slowest at the end of a launch);
+            # async_cfg=dict(shared_budget=False): exactly `rounds` calls per tree (results a function of `rounds` alone: the parity tests)
+            cfg.setdefault('shared_budget', True)
             self.groups[0].async_cfg = cfg
             self.use_graph = False          # two launches per K rounds: nothing to amortise
         # one stream per pipeline; pinned to an XCD (or an equal share of the 8 XCDs) unless pin_xcd=False
@@ -262,12 +264,9 @@ class SelfPlayEngine:
 
     def run(self, rounds):
         if self.async_pipe:
-            # K descent / forward pairs per tree per launch of the pipeline, then the advance -- the cadence of the two-kernel rounds
-            grp, done = self.groups[0], 0
-            while done < rounds:
-                k = min(self.K, rounds - done)
-                grp.rounds(k, self.fused, self.percu, advance=True)
-                done += k
+            # ONE launch of the pipeline: `rounds` calls per tree (a call = what a round of the two-kernel form does for the tree); moves,
+            # example records, clean-ups and root noise happen inside, tree by tree
+            self.groups[0].rounds(rounds, self.fused, self.percu)
             self.rounds += rounds
             return
         if self.use_graph and self.graph is None:

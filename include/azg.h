@@ -176,16 +176,21 @@ int azg_forest_rounds_profile(azg_forest* f, double* out4, int reset);
    workgroups (16 waves; each owns a fixed share of the trees, a free wave takes whichever of them has its pi / v, runs the expansion +
    backup + next descent of azg_forest_select_fused and queues the leaf) and `n_net` net workgroups (each takes up to 16 queued leaves --
    fewer after `batch_wait_ticks` x 10 ns of waiting --, runs the forward of azg_nn_v80_forward_h2 on them and hands the trees back).
-   Every tree runs `rounds` (<= 255) descent / forward pairs, then the call's kernels end; azg_selfplay_advance is launched by the caller
-   between calls, as between rounds of the two-kernel form.  n_net + n_sel must not exceed the CUs of the device (every workgroup has to
+   A "call" of a tree is what one round of the two-kernel form does for it (expansion + backup of its evaluated leaf, then descents until a
+   leaf needs the net, the search ends or the work budget parks it).  shared_budget == 0: every tree has exactly `rounds` calls, then the
+   kernels end -- results are a function of `rounds` alone.  shared_budget != 0: the kernels end when the trees TOGETHER have had rounds x T
+   calls; a fast tree gets more of them, no tree waits for the slowest at the end of the launch (per-game results are the same, how far
+   each game gets is not fixed).  What azg_selfplay_advance does between rounds -- the move, the example record, the restart, the
+   clean-up, the next search, the root noise -- happens inside, per tree, the moment its search is finished: no call of
+   azg_selfplay_advance is needed (or harmful) between launches.  n_net + n_sel must not exceed the CUs of the device (every workgroup has to
    be resident; <= 0: a default split); the first call fixes the split of a forest.  Per-tree results are identical bit for bit to
-   `rounds` x (azg_forest_select_fused -> azg_nn_v80_forward_h2) on a forest without work / level budget (tests/test_gpu_selfplay.py).
+   `rounds` x (azg_forest_select_fused -> azg_selfplay_advance -> azg_nn_v80_forward_h2) with shared_budget == 0 (tests/test_gpu_selfplay.py).
    leaf_valid_dev u8[T][A], needs_eval_dev u8[T], pi_dev f32[T][A], v_dev f32[T][P]: as for azg_forest_select_fused (the leaf states
    travel through a buffer the forest owns).  A pipeline that stops making progress for AZG_ASYNC_TIMEOUT_MS (2000) sets error bit 128
    (azg_selfplay_stats.errors) and ends the kernels. */
 int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev,
                                    int noise_stride, const void* const* w, const float* descale_host, int rounds, int n_net, int n_sel,
-                                   int batch_wait_ticks, void* stream);
+                                   int batch_wait_ticks, int shared_budget, void* stream);
 /* measurement: counters of the pipeline since the last reset (ticks = 10 ns of the 100 MHz wall clock read inside the kernels):
    out[0] descents (select_tree calls), [1] ticks inside them, [2] ticks descent waves spent looking for a ready tree, [3] net batches,
    [4] leaves in them, [5] ticks inside the forward, [6] ticks net workgroups waited for leaves, [7] sum over leaves of (claimed by a net

@@ -485,7 +485,7 @@ def test_percu_round_kernel_equals_two_kernel_rounds(T, sims, use_graph):
     for percu in (False, True):
         net = SplendorV80Hip.from_npz(w, max_batch=T)
         e = SelfPlayEngine(g, net, args, T, node_capacity=2048, max_examples=T * 400, rng_seed=9, use_graph=use_graph, advance_every=8,
-                           percu=percu)
+                           percu=percu, async_pipe=False)
         assert e.percu == percu
         e.start()
         e.run(8 * 60 * (sims + 8) // 8)               # ~60 plies: most games end and restart
@@ -530,15 +530,23 @@ def test_async_pipeline_equals_two_kernel_rounds(T, sims, K, budget, cfg):
     out = []
     for pipe in (False, True):
         net = SplendorV80Hip.from_npz(w, max_batch=T)
-        e = SelfPlayEngine(g, net, args, T, node_capacity=2048, max_examples=T * 400, rng_seed=9, use_graph=False, advance_every=K,
-                           work_budget=budget, percu=False, async_pipe=pipe, async_cfg=cfg)
+        e = SelfPlayEngine(g, net, args, T, node_capacity=2048, max_examples=T * 400, rng_seed=9, use_graph=False, advance_every=1,
+                           work_budget=budget, percu=False, async_pipe=pipe, async_cfg=dict(cfg, shared_budget=False))
         assert e.async_pipe == pipe
         e.start()
-        for _ in range(60 * (sims + K) // K):           # ~60 plies: most games end and restart.  The same cadence for both forms: K rounds
-            e.groups[0].rounds(K, e.fused, e.percu)     # (descent / forward pairs per tree), then the advance
+        # ~60 plies: most games end and restart.  A tree of the pipeline advances the moment its search is finished (on the wave that
+        # found it finished), the two-kernel form therefore advances after every round; the pipeline runs K calls per tree per launch
+        n = 60 * (sims + 2)
+        if pipe:
+            for _ in range(n // K):
+                e.run(K)
+            e.run(n % K)
+        else:
+            for _ in range(n):
+                e.groups[0].round(e.fused, advance=True)
         torch.cuda.synchronize()
         st = e.stats()
-        assert st['errors'] == 0 and st['games'] > 0
+        assert st['errors'] == 0 and st['games'] > 0, (st['errors'], e.forest.async_profile()['ctl'] if pipe else None)
         ex = [x.cpu() for x in e.drain_examples()]
         m = ex[5].to(torch.int64)                       # the ring's order is the order in which games happened to end: sort by (stream, game, ply)
         order = torch.argsort((m[:, 0] * 100000 + m[:, 1]) * 1000 + m[:, 2])
@@ -558,6 +566,43 @@ def test_async_pipeline_equals_two_kernel_rounds(T, sims, K, budget, cfg):
         assert torch.equal(a, b)
     for k in r0:
         assert torch.equal(r0[k], r1[k]), k
+
+
+@pytest.mark.parametrize('on_side_stream', [False, True])
+def test_async_pipeline_in_a_process_with_many_streams(on_side_stream):
+    """The pipeline's two kernels must run side by side whatever streams the process has: HIP multiplexes streams onto a few hardware
+    queues (kernels of one queue run one after the other) and a blocking stream waits for the legacy default stream -- either would leave
+    the net kernel waiting for leaves the descent kernel can never deliver (the engine reports that as error bit 128 after its
+    time-out).  The kernels run on two private non-blocking high-priority streams; here the caller is on the default stream or on the
+    fourth of a dozen streams the process created first."""
+    import os
+    import torch
+    from azg_amd import games
+    from azg_amd.nnet import SplendorV80Hip
+    from azg_amd.selfplay import SelfPlayEngine
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    x = torch.zeros(1024, device='cuda')
+    for s in streams:
+        with torch.cuda.stream(s):
+            x = x + 1
+    torch.cuda.synchronize()
+    g = games.SplendorGame(2)
+    w = os.path.join(os.path.dirname(__file__), 'golden', 'weights_splendor2_v80.npz')
+    args = Args(numMCTSSims=24, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0], tempThreshold=6,
+                **MCTS_ARGS['splendor2'])
+    T = 40
+    e = SelfPlayEngine(g, SplendorV80Hip.from_npz(w, max_batch=T), args, T, node_capacity=2048, max_examples=T * 400, rng_seed=9,
+                       async_pipe=True, async_cfg=dict(n_net=3, n_sel=5))
+    e.start()
+    if on_side_stream:
+        with torch.cuda.stream(streams[3]):
+            e.run(200)
+    else:
+        e.run(200)
+    torch.cuda.synchronize()
+    st = e.stats()
+    assert st['errors'] == 0 and st['plies'] > 4 * T, (st['errors'], st['plies'], e.forest.async_profile()['ctl'])
+    e.close()
 
 
 @pytest.mark.parametrize('game_key', ['santorini11', 'splendor4', 'azul', 'santorini1'])
