@@ -15,7 +15,15 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fP
 # block, ...) into LDS, one slot per work-item, and computes the work-item's linear id from the work-group sizes in the AQL DISPATCH PACKET
 # -- a scalar load from the queue ring in HOST memory at the top of k_select's descent: 10-30 k cycles per launch, and the whole of the
 # kernel's "slow / fast mode" (47-50 vs 57-62 us; 41.7 us without the load).  With the pass off those 32 bytes are scratch.
-UNITS = [('azg.hip', ['-mllvm', '-disable-promote-alloca-to-lds']), ('azg_nn.hip', ['-mllvm', '-disable-promote-alloca-to-lds'])]
+UNITS = [('azg.hip', ['-mllvm', '-disable-promote-alloca-to-lds']),
+         ('azg_nn.hip', ['-mllvm', '-disable-promote-alloca-to-lds'] + os.environ.get('AZG_NN_FLAGS', '').split()),
+         ('azg_async.hip', ['-mllvm', '-disable-promote-alloca-to-lds', '-mllvm', '-disable-machine-licm'] + os.environ.get('AZG_ASYNC_FLAGS', '').split()),
+         ('azg_async_sel.hip', ['-mllvm', '-disable-promote-alloca-to-lds'] + os.environ.get('AZG_ASYNC_SEL_FLAGS', '').split())]
+# (azg_async.hip / azg_async_sel.hip: the asynchronous tree pipeline, azg_async.hip.h -- the persistent net kernel + the C-ABI / the
+# persistent descent kernel.  -disable-machine-licm for the NET kernel only: it is ONE long loop around a body that fills the register
+# file; with machine LICM the compiler hoists address constants and zero vectors out of that loop and then spills them -- 34 spilled
+# VGPRs / 140 B scratch with it, 4 / 20 B without, the forward 32.3 -> 26.6 us; the descent kernel LOSES with the flag (23.2 -> 30.6 us
+# per descent), hence the two units.  AZG_ASYNC_FLAGS / AZG_ASYNC_SEL_FLAGS: further code-generation experiments.)
 # (azg_nn.hip also holds the per-CU round kernel, azg_fused.hip.h: 16 tree descents + their net forward in one workgroup)
 # debugging builds: AZG_DEFINES="AZG_CYC_COUNTERS AZG_NN_PHASE_TIMES" python alpha-zero-general_amd/build.py
 FLAGS += ['-D' + d for d in os.environ.get('AZG_DEFINES', '').split()]

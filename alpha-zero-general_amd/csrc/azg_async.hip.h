@@ -59,7 +59,7 @@ struct AsyncArgs {
     ForestDev F;
     H2Weights W;
     int8_t* aleaf; uint8_t* leaf_valid; uint8_t* needs_eval; float* pi; float* v;
-    AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts_leaf; uint32_t* ts_ready;
+    AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts_ready;
     unsigned long long* prof;
     unsigned long long* wginfo;                // [n_sel + n_net][4]: where the workgroup ran (XCC | cu << 8 | se << 16 | sh << 24), role, calls, busy shader cycles
     int noise, rounds, n_sel, ring_bits, batch_wait, timeout_ticks;
@@ -78,6 +78,7 @@ __device__ __forceinline__ void astore(uint32_t* p, uint32_t v) { __hip_atomic_s
 __device__ __forceinline__ uint32_t wall32() { return (uint32_t)wall_clock64(); }
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+#ifdef AZG_ASYNC_PART_SELECT     /* the descent kernel: azg_async_sel.hip */
 // LDS control block of a select workgroup
 struct AsyncSelLds {
     unsigned long long claimed[2];             // bit i: tree i of this workgroup is being handled by one of its waves
@@ -91,6 +92,7 @@ struct AsyncSelLds {
     unsigned long long prof[6];                // calls, busy ticks, idle ticks, ready-wait sum, shader cycles inside the descents, plies advanced
     uint32_t hist[32];
     uint32_t rw[ASYNC_RS];                     // the scout's snapshot of the ready words (calls left + 1; 0 = not ready)
+    uint32_t rts[ASYNC_RS];                    // ... and of the time stamps the net wrote beside them (profile: how long a ready tree waits)
     uint32_t last[ASYNC_RS];                   // the ready word this workgroup consumed last for tree i: a tree's words DECREASE over a launch,
 };                                             // so a snapshot is current iff it is smaller -- no second look at HBM before a claim
 
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
             astore(my_ready + i, w0);
             C->rw[i] = w0; C->last[i] = 0xFFFFFFFFu;
         }
-        if (i < n_g) astore(A->ts_ready + (g + i * n_sel), t_begin);
+        if (i < ASYNC_RS) { astore(A->ts_ready + (size_t)g * ASYNC_RS + i, t_begin); C->rts[i] = t_begin; }
         if (i == 0) {
             C->claimed[0] = C->claimed[1] = 0ull; C->retired = 0u; C->cursor = 0u; C->scout = 0u; C->calls = 0u; C->stop = 0u;
             for (int k = 0; k < 6; k++) C->prof[k] = 0ull;
@@ -195,6 +197,10 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
             const uint32_t v1 = l + 64 < n_g ? aload(my_ready + 64 + l) : 0u;
             {
                 const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+                const uint32_t* my_ts = A->ts_ready + (size_t)g * ASYNC_RS;
+                const uint32_t s0 = l < n_g ? aload(my_ts + l) : 0u, s1 = l + 64 < n_g ? aload(my_ts + 64 + l) : 0u;
+                __hip_atomic_store(&C->rts[l], s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&C->rts[64 + l], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (A->total_calls) {
                     const uint32_t st = uni_u32(aload(&A->ctl->stop));
                     if (st && l == 0) __hip_atomic_store(&C->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
             t = g + i * A->n_sel;
             const uint32_t now = wall32();
-            const uint32_t w = now - uni_u32(aload(A->ts_ready + t));
+            const uint32_t w = now - uni_u32(AZG_LDS_LD32(&C->rts[i]));
             if (l == 0) {
                 atomicAdd(&C->prof[2], (unsigned long long)(now - idle_since));
                 atomicAdd(&C->prof[3], (unsigned long long)w);
@@ -311,7 +317,14 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
                 if (!on) { left = 0u; break; }                              // idle (episode quota), parked with an error: done with this launch
             }
         }
-        // ---- hand the tree on: record the word consumed, drain EVERY store of this wave (the tree's records, its leaf), release the claim ----
+        // ---- hand the tree on: the leaf's ticket is taken FIRST (a returning atomic: its round trip runs under the drain), then EVERY store
+        // of this wave drains (the tree's records, its leaf record), then the word consumed is recorded, the claim released, the ring entry
+        // published ----
+        uint32_t tk = 0u;
+        {
+            const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+            if (need && l == 0) tk = atomicAdd(&A->ctl->leaf_tail, 1u);
+        }
         if (l == 0) __hip_atomic_store(&C->last[i], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         drain_vmem();
         if (l == 0) __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -319,11 +332,11 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
             if (l == 0) {
                 if (need) {
-                    astore(A->ts_leaf + t, wall32());                        // (profile only: not ordered against the ticket)
-                    const uint32_t tk = atomicAdd(&A->ctl->leaf_tail, 1u);
                     const uint32_t rb = (uint32_t)A->ring_bits;
+                    // ring entry: tree [19:0] | time stamp (100 MHz clock >> 4, 12 bits: profile only) [31:20] | calls left [55:32] | lap tag [63:60]
                     __hip_atomic_store(A->ring + (tk & ((1u << rb) - 1u)),
-                                       (unsigned long long)(uint32_t)t | ((unsigned long long)left << 32) | ((unsigned long long)(((tk >> rb) & 7u) + 1u) << 60),
+                                       (unsigned long long)((uint32_t)t | (((wall32() >> 4) & 0xFFFu) << 20)) | ((unsigned long long)left << 32) |
+                                           ((unsigned long long)(((tk >> rb) & 7u) + 1u) << 60),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     __hip_atomic_fetch_add(&C->retired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -351,7 +364,11 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
     }
 }
 
-constexpr int ASYNC_NET_LDS = H2_LDS + 256;   // the forward's LDS map + the batch descriptor: tree of sample s [16], pairs left [16], count
+#endif  // AZG_ASYNC_PART_SELECT
+
+#ifdef AZG_ASYNC_PART_NET        /* the net kernel and the host side: azg_async.hip */
+constexpr int ASYNC_NET_LDS = H2_LDS + 512;   // the forward's LDS map + the batch descriptor: tree of sample s [16], calls left [16], count, the
+                                              // profile sums and (nn_v80_h2.hip.h H2_IND_MASK) the samples' valid bit masks
 
 __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -412,10 +429,10 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
                 uint32_t w = 0u;
                 if (mine) {
                     const int slot = __popc(take & ((1u << lane) - 1u));           // the batch is the taken tickets, compacted
-                    const int t = (int)(uint32_t)e;
+                    const int t = (int)((uint32_t)e & 0xFFFFFu);
                     sidx[slot] = t;
                     sidx[16 + slot] = (int)((e >> 32) & 0xFFFFFFu);
-                    w = now - aload(A->ts_leaf + t);
+                    w = ((((now >> 4) & 0xFFFu) - (((uint32_t)e >> 20) & 0xFFFu)) & 0xFFFu) << 4;       // (ticks; wraps at 655 us)
                     atomicAdd(A->prof + 32 + ((w / 100u) < 31u ? (w / 100u) : 31u), 1ull);
                 }
 #pragma unroll
@@ -436,14 +453,21 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)a;
             h2_net_body<12, true>(lds, &A->W, A->aleaf, (const uint8_t*)A->aleaf, A->F.T, SplendorDev<2>::P, A->pi, A->v, 0, sidx);
         }
+        // the next ticket range, when this one is used up: the returning atomic is issued HERE, so that its round trip runs under the drain
+        // and the hand-back below instead of in front of the next claim (measured: 4.6 us per batch outside the forward, 12 % of a
+        // net-bound pipeline's time)
+        uint32_t next_base = 0u;
+        const bool need_range = wave == 0 && !sidx[36];
+        if (need_range && lane == 0) next_base = atomicAdd(&((AsyncArgsC)(uintptr_t)args)->ctl->leaf_head, 16u);
         drain_vmem();                                   // EVERY wave: its write-through pi / v rows have left
         __syncthreads();
         {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+            if (need_range && lane == 0) { sidx[34] = (int)next_base; sidx[35] = 0; sidx[36] = 1; }
             if (tid < 16 && sidx[tid] >= 0) {
                 const int t = sidx[tid], ns = A->n_sel;
                 const int gi = t % ns, ii = t / ns;
-                astore(A->ts_ready + t, wall32());                       // (profile only: not ordered against the ready word)
+                astore(A->ts_ready + (size_t)gi * ASYNC_RS + ii, wall32());     // (profile only: not ordered against the ready word)
                 astore(A->ready + (size_t)gi * ASYNC_RS + ii, (uint32_t)sidx[16 + tid] + 1u);
             }
         }
@@ -451,7 +475,7 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
             P[0] += 1ull; P[1] += (unsigned long long)sidx[32]; P[2] += (unsigned long long)(wall32() - (uint32_t)sidx[33]);
             P[5] += (unsigned long long)((uint32_t)clock64() - (uint32_t)sidx[37]);
         }
-        __syncthreads();                                // the batch descriptor is free for the next claim
+        // (no barrier here: between the barrier above and the next claim only wave 0 touches the batch descriptor, in program order)
     }
     if (tid == 0) {
         const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
@@ -463,8 +487,27 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
     }
 }
 
+#endif  // AZG_ASYNC_PART_NET
 }  // namespace azg
 
+#ifdef AZG_ASYNC_PART_SELECT
+// the descent kernel's launcher, called by azg_forest_async_rounds_v80_h2 (azg_async.hip): the two kernels live in two translation units
+// because they want different code generation (build.py)
+int azg_async_launch_select_splendor2(const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s) {
+    using G = azg::SplendorDev<2>;
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void*)azg::k_async_select<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    azg::k_async_select<G><<<dim3(n_sel), dim3(1024), 16 * azg::RoundLds<G>::STRIDE + (int)sizeof(azg::AsyncSelLds), s>>>(devbuf);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+#endif  // AZG_ASYNC_PART_SELECT
+
+#ifdef AZG_ASYNC_PART_NET
+int azg_async_launch_select_splendor2(const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s);
 // ---- host side ----
 struct AsyncSlot {
     AsyncArgs host; AsyncArgs* devbuf;
@@ -511,7 +554,7 @@ extern "C" int azg_forest_async_wginfo(azg_forest* f, unsigned long long* out /*
     const int n = sl->n_sel + sl->n_net < max_wg ? sl->n_sel + sl->n_net : max_wg;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, sl->wginfo, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost));
-    if (reset) HIPCHK(hipMemset(sl->wginfo, 0, sizeof(unsigned long long) * 4 * (sl->n_sel + sl->n_net)));
+    if (reset) HIPCHK(hipMemset(sl->wginfo, 0, sizeof(unsigned long long) * 4 * n));
     return n;
 }
 
@@ -550,7 +593,6 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         HIPCHK(hipGetDeviceProperties(&prop, d));
         n_cu = prop.multiProcessorCount;
         HIPCHK(hipFuncSetAttribute((const void*)k_async_net, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_async_select<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int T = dev->T;
     if (n_net <= 0 || n_sel <= 0) {                   // default split of the CUs: 17 / 32 for the net (measured at 4096 x 800: 136 + 120 of 256)
@@ -563,13 +605,11 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         return fail("azg_forest_async_rounds_v80_h2: n_net + n_sel exceeds the CUs of the device (every workgroup of the pipeline must be resident)");
     if ((long long)n_sel * ASYNC_RS < T) return fail("azg_forest_async_rounds_v80_h2: more than 128 trees per select workgroup");
     AsyncSlot* sl = (AsyncSlot*)azg_forest_attached(f, "async_v80");
-    if (sl && (sl->n_sel != n_sel || sl->n_net != n_net)) return fail("azg_forest_async_rounds_v80_h2: the CU split of a forest cannot change");
     if (!sl) {
         sl = new AsyncSlot();
         memset(sl, 0, sizeof(*sl));
         memset(&sl->host, 0xFF, sizeof(sl->host));
         azg_forest_attach(f, "async_v80", sl, async_slot_free);
-        sl->n_sel = n_sel; sl->n_net = n_net;
         int rb = 6;
         while ((1 << rb) < 2 * T) rb++;
         sl->ring_bits = rb;
@@ -577,18 +617,19 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         HIPCHK(hipMalloc(&sl->aleaf, (size_t)T * AsyncLeaf<G>::STRIDE));
         HIPCHK(hipMalloc(&sl->ctl, sizeof(AsyncCtl)));
         HIPCHK(hipMalloc(&sl->ring, sizeof(unsigned long long) << rb));
-        HIPCHK(hipMalloc(&sl->ready, sizeof(uint32_t) * ASYNC_RS * n_sel));
-        HIPCHK(hipMalloc(&sl->ts, sizeof(uint32_t) * 2 * T));
+        HIPCHK(hipMalloc(&sl->ready, sizeof(uint32_t) * ASYNC_RS * n_cu));          // (sized for any split: it may change from launch to launch)
+        HIPCHK(hipMalloc(&sl->ts, sizeof(uint32_t) * ASYNC_RS * n_cu));
         HIPCHK(hipMalloc(&sl->prof, sizeof(unsigned long long) * ASYNC_NPROF));
         HIPCHK(hipMemset(sl->prof, 0, sizeof(unsigned long long) * ASYNC_NPROF));
-        HIPCHK(hipMalloc(&sl->wginfo, sizeof(unsigned long long) * 4 * (n_sel + n_net)));
-        HIPCHK(hipMemset(sl->wginfo, 0, sizeof(unsigned long long) * 4 * (n_sel + n_net)));
+        HIPCHK(hipMalloc(&sl->wginfo, sizeof(unsigned long long) * 4 * n_cu));
+        HIPCHK(hipMemset(sl->wginfo, 0, sizeof(unsigned long long) * 4 * n_cu));
         HIPCHK(hipMemset(sl->aleaf, 0, (size_t)T * AsyncLeaf<G>::STRIDE));
-        HIPCHK(hipMemset(sl->ts, 0, sizeof(uint32_t) * 2 * T));
+        HIPCHK(hipMemset(sl->ts, 0, sizeof(uint32_t) * ASYNC_RS * n_cu));
         HIPCHK(hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl->join, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl->join_net, hipEventDisableTiming));
     }
+    sl->n_sel = n_sel; sl->n_net = n_net;
     AsyncArgs want;
     memset(&want, 0, sizeof(want));
     want.F = *dev;
@@ -597,7 +638,7 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
     // would otherwise run its whole search inside ONE call: measured 4.1 ms launches of 48 rounds where the mean tree needs 3.4 ms)
     want.W = h2_weights(w, descale);
     want.aleaf = sl->aleaf; want.leaf_valid = leaf_valid; want.needs_eval = needs_eval; want.pi = pi; want.v = v;
-    want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_leaf = sl->ts; want.ts_ready = sl->ts + T; want.prof = sl->prof; want.wginfo = sl->wginfo;
+    want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_ready = sl->ts; want.prof = sl->prof; want.wginfo = sl->wginfo;
     want.noise = (alpha != 0.0 && noise_stride == -2) ? 1 : 0;
     want.rounds = rounds; want.n_sel = n_sel; want.ring_bits = sl->ring_bits;
     if (shared_budget) {                              // `rounds` x T calls for the trees together; no tree is held back by a share of its own
@@ -619,11 +660,12 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
     HIPCHK(hipStreamWaitEvent(sel_stream, sl->fork, 0));
     k_async_net<<<dim3(n_net), dim3(768), ASYNC_NET_LDS, net_stream>>>(sl->devbuf);
     HIPCHK(hipGetLastError());
-    k_async_select<G><<<dim3(n_sel), dim3(1024), 16 * RoundLds<G>::STRIDE + (int)sizeof(AsyncSelLds), sel_stream>>>(sl->devbuf);
-    HIPCHK(hipGetLastError());
+    if (azg_async_launch_select_splendor2(sl->devbuf, n_sel, sel_stream)) return -1;
     HIPCHK(hipEventRecord(sl->join_net, net_stream));
     HIPCHK(hipEventRecord(sl->join, sel_stream));
     HIPCHK(hipStreamWaitEvent(s, sl->join_net, 0));
     HIPCHK(hipStreamWaitEvent(s, sl->join, 0));
     return 0;
 }
+
+#endif  // AZG_ASYNC_PART_NET

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(1024) void k_rounds_v80(const RoundArgs* args, int 
 }  // namespace azg
 
 // the round kernel's argument block + profile counters: owned by the forest they belong to (azg_forest_attach), freed with it
+#ifndef AZG_FUSED_DEVICE_ONLY      /* (azg_async.hip includes this file for RoundLds / load_const only) */
 struct RoundSlot { RoundArgs host; RoundArgs* devbuf; unsigned long long* prof; int n_wg; };
 static void round_slot_free(void* p) {
     RoundSlot* sl = (RoundSlot*)p;
@@ -187,3 +188,4 @@ extern "C" int azg_forest_rounds_v80_h2(azg_forest* f, int8_t* leaf_states, uint
     HIPCHK(hipGetLastError());
     return 0;
 }
+#endif  // AZG_FUSED_DEVICE_ONLY

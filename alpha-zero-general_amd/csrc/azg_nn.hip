@@ -448,4 +448,3 @@ extern "C" int azg_nn_heads_out(const float* logits, int ldl, const uint8_t* val
 }
 
 #include "azg_fused.hip.h"
-#include "azg_async.hip.h"      // the asynchronous tree pipeline: persistent descent + net workgroups

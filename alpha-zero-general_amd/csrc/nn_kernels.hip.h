@@ -13,6 +13,10 @@
 //                 (the two SE fully-connected layers E -> Q -> E are two more k_linear launches, hardsigmoid epilogue)
 //   k_heads_out   masked softmax of the policy logits (exp(log_softmax), GenericNNetWrapper.py:107) and the value tail
 #pragma once
+// the non-template kernels of this header get internal linkage in a translation unit that only wants its device helpers (azg_async.hip)
+#ifndef AZG_NN_KERNEL
+#define AZG_NN_KERNEL
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -813,7 +817,7 @@ __device__ __forceinline__ void v80_block_body(float* X, float* H, float* xsave,
 }
 
 template <int ACT, int POOLMAX, int MODE>
-__global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin, float* __restrict__ xout, V80BlockW W,
+AZG_NN_KERNEL __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin, float* __restrict__ xout, V80BlockW W,
                                                    int B, const int8_t* __restrict__ boards, V80NetW N,
                                                    const uint8_t* __restrict__ valid, float* __restrict__ pi_out,
                                                    float* __restrict__ v_out, int P) {
@@ -825,7 +829,7 @@ __global__ __launch_bounds__(768) void k_v80_block(const float* __restrict__ xin
 // The whole V80 forward of one 16-sample tile in ONE workgroup pass: first layer + trunk block (its output stays in LDS and
 // is copied to a second tile buffer), policy head block + tail on the first copy, value head block + tail on the second.
 // Nothing but the int8 boards, the valid masks and pi / v crosses HBM; LDS = 2 x [112][60] + the block's 129.5 KB = 156.4 KB.
-__global__ __launch_bounds__(768) void k_v80_net(V80BlockW Wt, V80BlockW Wp, V80BlockW Wv, V80NetW N0, V80NetW Np, V80NetW Nv,
+AZG_NN_KERNEL __global__ __launch_bounds__(768) void k_v80_net(V80BlockW Wt, V80BlockW Wp, V80BlockW Wv, V80NetW N0, V80NetW Np, V80NetW Nv,
                                                  const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid, int B,
                                                  int P, float* __restrict__ pi_out, float* __restrict__ v_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -841,7 +845,7 @@ __global__ __launch_bounds__(768) void k_v80_net(V80BlockW Wt, V80BlockW Wp, V80
 
 // The same forward with the tile the three blocks read kept as bf16 planes and the expand GEMMs on bf16 x 3 operands (SPX above):
 // LDS = 3 x [112][64] bf16 + the block's buffers + 12 KB = 154.3 KB; one copy of the trunk output serves both heads.
-__global__ __launch_bounds__(768) void k_v80_net_spx(V80BlockW Wt, V80BlockW Wp, V80BlockW Wv, V80NetW N0, V80NetW Np, V80NetW Nv,
+AZG_NN_KERNEL __global__ __launch_bounds__(768) void k_v80_net_spx(V80BlockW Wt, V80BlockW Wp, V80BlockW Wv, V80NetW N0, V80NetW Np, V80NetW Nv,
                                                      const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid, int B,
                                                      int P, float* __restrict__ pi_out, float* __restrict__ v_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -855,7 +859,7 @@ __global__ __launch_bounds__(768) void k_v80_net_spx(V80BlockW Wt, V80BlockW Wp,
 }
 
 // boards int8 [B][C][L] (reference layout) -> x f32 [B][L][ldx] (channels-last; columns C..ldx-1 zeroed)
-__global__ __launch_bounds__(256) void k_board_to_x(const int8_t* __restrict__ boards, float* __restrict__ x, int B, int C,
+AZG_NN_KERNEL __global__ __launch_bounds__(256) void k_board_to_x(const int8_t* __restrict__ boards, float* __restrict__ x, int B, int C,
                                                     int L, int ldx) {
     const long long total = (long long)B * L * ldx;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -865,7 +869,7 @@ __global__ __launch_bounds__(256) void k_board_to_x(const int8_t* __restrict__ b
 }
 
 // pi[b] = softmax(where(valid, logits, -1e8)) ; v[b] = tanh(relu(vhid[b]) @ Wv2 + bv2)      one wave per sample
-__global__ __launch_bounds__(64) void k_heads_out(const float* __restrict__ logits, int ldl,
+AZG_NN_KERNEL __global__ __launch_bounds__(64) void k_heads_out(const float* __restrict__ logits, int ldl,
                                                   const uint8_t* __restrict__ valid, const float* __restrict__ vhid,
                                                   int ldv, const float* __restrict__ Wv2, const float* __restrict__ bv2,
                                                   float* __restrict__ pi, float* __restrict__ v, int B, int A, int P) {

@@ -221,6 +221,8 @@ static __device__ long long g_h2_phase[4][16];
 // pipeline's leaf-record array (its valid BIT mask, kernels.hip.h AsyncLeaf<SplendorDev<2>>: stride 416, mask at byte 400), read past the L1,
 // and pi / v rows are written WRITE-THROUGH at the tree's index: the reader is a descent wave on another CU, inside the same launch.
 constexpr int H2_AL_STRIDE = 416, H2_AL_MASK = 400;
+constexpr int H2_IND_MASK = 52;               // IND: the samples' valid bit masks (u64 [16][2]) sit 52 ints behind sidx in LDS -- fetched with the
+                                              // board tile at the start of the forward, so that the softmax does not wait for HBM
 template <int ACT, int POOLMAX, int MODE, int NW, bool IND = false>
 __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const H2NetW& N, int B, int P,
                                          const uint8_t* __restrict__ valid, float* __restrict__ pi_out, float* __restrict__ v_out,
@@ -553,9 +555,8 @@ __device__ __forceinline__ void h2_block(uint8_t* lds, const H2BlockW& W, const 
             const int a1i = lane + 64;
             bool ok0, ok1;
             if constexpr (IND) {
-                const unsigned long long* mp = (const unsigned long long*)(valid + (size_t)b * H2_AL_STRIDE + H2_AL_MASK);
-                const unsigned long long m0 = __hip_atomic_load(mp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long m1 = __hip_atomic_load(mp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long* mp = (const unsigned long long*)(sidx + H2_IND_MASK) + 2 * s;
+                const unsigned long long m0 = mp[0], m1 = mp[1];
                 ok0 = (m0 >> lane) & 1ull; ok1 = (m1 >> lane) & 1ull;
             } else {
                 ok0 = valid[(size_t)b * A + lane] != 0; ok1 = a1i < A && valid[(size_t)b * A + a1i] != 0;
@@ -630,6 +631,14 @@ __device__ __forceinline__ void h2_net_body(uint8_t* lds, H2WeightsC Wc, const i
     // ---- board tile int8 [s][c][l] -> X0[l*16 + s][c] = 64 * board, requested before any weight ----
     const uint32_t* bsrc = (const uint32_t*)(boards + (size_t)b0 * (7 * C));
     uint32_t bv[KB];
+    unsigned long long ind_mask = 0ull;
+    if constexpr (IND) {
+        if (tid < 32) {
+            const int b = sidx[tid >> 1];
+            if (b >= 0) ind_mask = __hip_atomic_load((const unsigned long long*)(valid + (size_t)b * H2_AL_STRIDE + H2_AL_MASK) + (tid & 1), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < KB; k++) {
         const int i = tid + NT * k;
@@ -660,6 +669,7 @@ __device__ __forceinline__ void h2_net_body(uint8_t* lds, H2WeightsC Wc, const i
     if (tid < 768) *(uint4*)(lds + H2_PLH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);       // 768 x 16 B = both PL planes
     if (tid < 256) *(uint4*)(lds + H2_SHH + tid * 16) = make_uint4(0u, 0u, 0u, 0u);       // both SH planes
     if (tid < 112) *(uint4*)(X0 + h2_off(tid, 7, H2_RSX)) = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (IND) { if (tid < 32) ((unsigned long long*)(sidx + H2_IND_MASK))[tid] = ind_mask; }
     __syncthreads();                                           // (the zeroing of X0's last chunk precedes the scatter below: none overlap, but PL/SH need it anyway)
 #pragma unroll
     for (int k = 0; k < KB; k++) {

@@ -129,11 +129,17 @@ class Forest:
                                                    -2 if device_noise else 0, net.net_ptrs_h2, net.descale_h2, int(rounds), int(n_net), int(n_sel),
                                                    int(batch_wait_ticks), int(bool(shared_budget)), _stream()))
 
-    def async_profile(self, reset=True):
-        """the pipeline's counters since the last reset as a dict (times in microseconds; include/azg.h azg_forest_async_profile)"""
+    def async_counters(self, reset=False):
+        """the pipeline's raw counters (include/azg.h azg_forest_async_profile: 96 numbers, accumulated since the last reset)"""
         out = (C.c_double * 96)()
         check(lib().azg_forest_async_profile(self.h, out, int(reset)))
-        o = list(out)
+        return list(out)
+
+    def async_profile(self, reset=True, since=None):
+        """the pipeline's counters since the last reset (or since the raw counters `since`) as a dict (times in microseconds)"""
+        o = self.async_counters(reset)
+        if since is not None:
+            o = [a - b if k not in (12, 13) and not 20 <= k < 32 else a for k, (a, b) in enumerate(zip(o, since))]
         d = dict(descents=o[0], batches=o[3], leaves=o[4], launches=o[9], plies_in_kernel=o[16])
         d['descent_us'] = o[1] / max(o[0], 1) / 100.0
         d['forward_us'] = o[5] / max(o[3], 1) / 100.0

@@ -129,6 +129,7 @@ class SelfPlayEngine:
         elif async_pipe and not (can and groups == 1):
             raise ValueError('async_pipe=True needs Splendor 2 players, SplendorV80Hip(h2=True) evaluators with max_batch == n_games, groups == 1')
         self.async_pipe = bool(async_pipe)
+        self.adaptive = False
         if work_budget is None:
             # (the pipeline: a call that runs into the budget is followed by the next at once, the budget only bounds how long the trees
             # take to notice the end of a launch: 20 measured best of 0 / 10 / 20 / 40)
@@ -161,6 +162,11 @@ class SelfPlayEngine:
             # async_cfg=dict(shared_budget=False): exactly `rounds` calls per tree (results a function of `rounds` alone: the parity tests)
             cfg.setdefault('shared_budget', True)
             self.groups[0].async_cfg = cfg
+            # adaptive split only with the work-sharing budget (with per-tree budgets the results must not depend on anything measured)
+            self.adaptive = bool(cfg['shared_budget']) and 'n_net' not in cfg and os.environ.get('AZG_ASYNC_ADAPT', '1') == '1'
+            self.adapt_chunk = int(os.environ.get('AZG_ASYNC_CHUNK', '200'))
+            self._adapt_last = None
+            self.split_log = []
             self.use_graph = False          # two launches per K rounds: nothing to amortise
         # one stream per pipeline; pinned to an XCD (or an equal share of the 8 XCDs) unless pin_xcd=False
         self.pin_xcd = (groups > 1) if pin_xcd is None else bool(pin_xcd)
@@ -264,9 +270,23 @@ class SelfPlayEngine:
 
     def run(self, rounds):
         if self.async_pipe:
-            # ONE launch of the pipeline: `rounds` calls per tree (a call = what a round of the two-kernel form does for the tree); moves,
+            # launches of the pipeline: `rounds` calls per tree (a call = what a round of the two-kernel form does for the tree); moves,
             # example records, clean-ups and root noise happen inside, tree by tree
-            self.groups[0].rounds(rounds, self.fused, self.percu)
+            grp = self.groups[0]
+            if not self.adaptive:
+                grp.rounds(rounds, self.fused, self.percu)
+            else:
+                # ADAPTIVE CU SPLIT: which side is the bottleneck changes with the phase of the games (late game: many simulations end on
+                # terminal nodes and need no forward -> the descents are; opening / middle game: every simulation needs one -> the net is,
+                # measured 107 k vs 73 k plies/s with a fixed split).  The launch is cut into chunks; after each one the busy shares of the
+                # two kinds of workgroup (counters of the kernels) move 8 CUs to the busier side.
+                done = 0
+                while done < rounds:
+                    k = min(self.adapt_chunk, rounds - done)
+                    grp.rounds(k, self.fused, self.percu)
+                    done += k
+                    if done < rounds or k == self.adapt_chunk:
+                        self._adapt_split()
             self.rounds += rounds
             return
         if self.use_graph and self.graph is None:
@@ -292,6 +312,28 @@ class SelfPlayEngine:
         for _ in range(rounds - done):               # remainder (or no graph): eager rounds, advance every round
             self._round()
         self.rounds += rounds
+
+    def _adapt_split(self):
+        """move 8 CUs to the busier kind of workgroup (asynchronous pipeline, see run)"""
+        f, cfg = self.forest, self.groups[0].async_cfg
+        o = f.async_counters()
+        last, self._adapt_last = self._adapt_last, o
+        if last is None or o[9] < last[9]:               # (first chunk, or the counters were reset in between)
+            return
+        d = [a - b for a, b in zip(o, last)]
+        n_sel, n_net = int(o[12]), int(o[13])
+        if d[11] <= 0 or d[1] + d[2] <= 0:
+            return
+        net_busy, sel_busy = d[5] / d[11], d[1] / (d[1] + d[2])
+        n_cu, step = n_sel + n_net, 8
+        lo_sel = max(16, -(-self.T // 128))
+        if net_busy - sel_busy > 0.06 and n_sel - step >= lo_sel:
+            n_net, n_sel = n_net + step, n_sel - step
+        elif sel_busy - net_busy > 0.06 and n_net - step >= 32:
+            n_net, n_sel = n_net - step, n_sel + step
+        cfg['n_net'], cfg['n_sel'] = n_net, n_sel
+        self.split_log.append((n_net, round(net_busy, 3), round(sel_busy, 3)))
+        assert n_net + n_sel == n_cu
 
     def stats(self):
         tot = None

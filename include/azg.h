@@ -183,7 +183,7 @@ int azg_forest_rounds_profile(azg_forest* f, double* out4, int reset);
    each game gets is not fixed).  What azg_selfplay_advance does between rounds -- the move, the example record, the restart, the
    clean-up, the next search, the root noise -- happens inside, per tree, the moment its search is finished: no call of
    azg_selfplay_advance is needed (or harmful) between launches.  n_net + n_sel must not exceed the CUs of the device (every workgroup has to
-   be resident; <= 0: a default split); the first call fixes the split of a forest.  Per-tree results are identical bit for bit to
+   be resident; <= 0: a default split); the split may change from call to call.  Per-tree results are identical bit for bit to
    `rounds` x (azg_forest_select_fused -> azg_selfplay_advance -> azg_nn_v80_forward_h2) with shared_budget == 0 (tests/test_gpu_selfplay.py).
    leaf_valid_dev u8[T][A], needs_eval_dev u8[T], pi_dev f32[T][A], v_dev f32[T][P]: as for azg_forest_select_fused (the leaf states
    travel through a buffer the forest owns).  A pipeline that stops making progress for AZG_ASYNC_TIMEOUT_MS (2000) sets error bit 128
