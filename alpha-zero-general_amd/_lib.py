@@ -56,6 +56,11 @@ def lib():
     ip = C.POINTER(C.c_int)
     L.azg_last_error.restype = C.c_char_p
     L.azg_version.restype = C.c_char_p
+    # ABI check: azg_forest_cfg grew over the rounds; a library whose struct differs from this binding's would read garbage past the end
+    # (an older build loaded through AZG_LIB for an A/B run has no azg_forest_cfg_size at all: it must then be a build of this tree's layout)
+    if hasattr(L, 'azg_forest_cfg_size') and L.azg_forest_cfg_size() != C.sizeof(ForestCfg):
+        raise AzgError('%s (%s) has a %d-byte azg_forest_cfg, this binding a %d-byte one: rebuild the library'
+                       % (LIB_PATH, L.azg_version().decode(), L.azg_forest_cfg_size(), C.sizeof(ForestCfg)))
     L.azg_game_info.argtypes = [i, i, ip, ip, ip, ip, ip]
     L.azg_env_valid_moves.argtypes = [i, i, vp, vp, i, vp, vp]
     L.azg_env_next_state.argtypes = [i, i, vp, vp, vp, vp, i, vp, vp, u64, u64, vp, vp]

@@ -28,7 +28,8 @@ static thread_local std::string g_err;
 int azg_fail(const std::string& m) { g_err = m; return -1; }
 
 extern "C" const char* azg_last_error(void) { return g_err.c_str(); }
-extern "C" const char* azg_version(void) { return "azg-hip r2 (gfx950)"; }
+extern "C" const char* azg_version(void) { return "azg-hip r5 (gfx950)"; }
+extern "C" int azg_forest_cfg_size(void) { return (int)sizeof(azg_forest_cfg); }      // ABI check of a binding against this build
 extern "C" int azg_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
 
@@ -341,7 +342,8 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     size_t heap_bytes = cfg->row_capacity_bytes > 0
                             ? (size_t)cfg->row_capacity_bytes
                             : (D.cls_q == f->A ? (size_t)D.cap * RG0.total(f->A) + 4096
-                                               : (rec_bytes_hint && D.cap >= 8192) ? (size_t)D.cap * (size_t)rec_bytes_hint   // (an average: large arenas only)
+                                               : (rec_bytes_hint && D.cap >= 8192 && cfg->gc_high_water_pct > 0)
+                                                     ? (size_t)D.cap * (size_t)rec_bytes_hint   // (an average: large arenas that are cleaned at a high-water mark only)
                                                : (size_t)D.cap * RG0.total(nv_hint ? nv_hint : (f->A <= 256 ? 64 : 160)) * 5 / 4) + 8192;
     heap_bytes = (heap_bytes + 15) / 16 * 16;
     if (heap_bytes / 16 > (size_t)AZG_CHILD_IDX_MASK) { delete f; return fail("record heap per tree exceeds the 29-bit record offset (8 GiB)"); }
@@ -658,13 +660,13 @@ extern "C" int azg_selfplay_start_ex(azg_forest* f, const int8_t* init_boards, u
                                      void* stream) {
     if (!f) return fail("null forest");
     if (f->dev.max_examples <= 0) return fail("forest created with max_examples == 0");
-    if (episode_quota < 0) return fail("azg_selfplay_start_ex: episode_quota < 0");
+    if (episode_quota < -1) return fail("azg_selfplay_start_ex: episode_quota < -1");
     // epoch 0 keeps the streams of the RNG contract; any other epoch re-keys every stream of this forest (boards, playout-cap
     // draws, root noise, move picks), so that successive self-play / arena waves of one run do not replay the same games
     // (seed and quota are kernel arguments: HIP graphs captured under other values must be captured again)
     f->dev.rng_seed = epoch ? f->cfg.rng_seed ^ (0x9E3779B97F4A7C15ULL * (epoch + 0x632BE59BD9B4E019ULL)) : f->cfg.rng_seed;
-    if (episode_quota > 0xFFFFFFFFll) return fail("azg_selfplay_start_ex: episode_quota too large");
-    f->dev.episode_quota = (uint32_t)episode_quota;
+    if (episode_quota > 0xFFFFFFFEll) return fail("azg_selfplay_start_ex: episode_quota too large");
+    f->dev.episode_quota = episode_quota < 0 ? 0xFFFFFFFFu : (uint32_t)episode_quota;      // -1: this forest plays no game at all (every tree idle)
     HIPCHK(hipMemsetAsync(f->dev.ex_count, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));
     FDISPATCH(f, k_selfplay_start<G><<<dim3(f->dev.T), dim3(64), 0, (hipStream_t)stream>>>(f->dev,
                                      init_boards));

@@ -595,8 +595,8 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         HIPCHK(hipFuncSetAttribute((const void*)k_async_net, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int T = dev->T;
-    if (n_net <= 0 || n_sel <= 0) {                   // default split of the CUs: 17 / 32 for the net (measured at 4096 x 800: 136 + 120 of 256)
-        n_net = n_cu * 17 / 32;
+    if (n_net <= 0 || n_sel <= 0) {                   // default split of the CUs: half and half (measured at 4096 x 800, whole games and the
+        n_net = n_cu / 2;                             // driver's window: 128 + 128 of 256 beats 120 / 124 / 132 / 136 for the net)
         n_sel = n_cu - n_net;
     }
     if (n_sel > T) n_sel = T;

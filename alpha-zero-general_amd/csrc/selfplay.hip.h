@@ -132,6 +132,7 @@ __device__ void start_game(const ForestDev& F, int t, TreeHdr& H, typename Fores
 // restarting, so every started game finishes and is kept -- no bias towards short games.  0 = restart forever.
 __device__ __forceinline__ uint32_t tree_quota(const ForestDev& F, int t) {
     const uint32_t q = F.episode_quota;
+    if (q == 0xFFFFFFFFu) return 0u;                  // (azg_selfplay_start_ex with episode_quota -1: no game on this forest)
     return q / (uint32_t)F.T + ((uint32_t)t < q % (uint32_t)F.T ? 1u : 0u);
 }
 

@@ -162,14 +162,18 @@ class SelfPlayEngine:
             # async_cfg=dict(shared_budget=False): exactly `rounds` calls per tree (results a function of `rounds` alone: the parity tests)
             cfg.setdefault('shared_budget', True)
             self.groups[0].async_cfg = cfg
-            # adaptive split only with the work-sharing budget (with per-tree budgets the results must not depend on anything measured)
-            self.adaptive = bool(cfg['shared_budget']) and 'n_net' not in cfg and os.environ.get('AZG_ASYNC_ADAPT', '1') == '1'
+            # adaptive split (opt-in, AZG_ASYNC_ADAPT=1; only with the work-sharing budget -- with per-tree budgets the results must not
+            # depend on anything measured): round 5 measured it and it LOSES to the fixed half-and-half split -- every chunk boundary is a
+            # launch tail + a counter read-back (chunks of 100 / 200 / 800 rounds: 84.6 / 88.9 / 92.1 k env-steps/s against 93.1 k fixed)
+            self.adaptive = bool(cfg['shared_budget']) and 'n_net' not in cfg and os.environ.get('AZG_ASYNC_ADAPT', '0') == '1'
             self.adapt_chunk = int(os.environ.get('AZG_ASYNC_CHUNK', '200'))
             self._adapt_last = None
             self.split_log = []
             self.use_graph = False          # two launches per K rounds: nothing to amortise
         # one stream per pipeline; pinned to an XCD (or an equal share of the 8 XCDs) unless pin_xcd=False
-        self.pin_xcd = (groups > 1) if pin_xcd is None else bool(pin_xcd)
+        # (default off: on this MI355X a stream's CU mask is not honoured, profiles/r04_placement.txt, and azg_stream_create_xcd refuses
+        # devices whose CU count is not a multiple of 8)
+        self.pin_xcd = False if pin_xcd is None else bool(pin_xcd)
         self._raw_streams = []
         if groups > 1:
             n_xcd = 8
@@ -213,17 +217,13 @@ class SelfPlayEngine:
         replay the same games); episode_quota = numEps of Coach.executeEpisodes: exactly that many games are played, each to
         its end (0 = trees restart forever; the caller decides when to stop)"""
         Tg = self.T // self.G
-        if episode_quota and episode_quota < self.G:
-            # a group without episodes cannot be expressed to the forest (its quota 0 means "restart forever"): refuse before
-            # anything is launched
-            raise ValueError('episode_quota %d is smaller than the number of groups %d' % (episode_quota, self.G))
         # the kernel deals a quota out as quota / T (+1 for the first quota % T trees); global stream t of the whole engine must play what
-        # it would play in ONE forest of T trees, whatever the grouping: group g gets the sum over its streams
+        # it would play in ONE forest of T trees, whatever the grouping: group g gets the sum over its streams.  Every share is computed
+        # before anything is launched; a group whose share is empty plays nothing (quota -1 of the C-ABI: every tree idle).
         a, b = divmod(int(episode_quota), self.T)
+        shares = [(a * Tg + max(0, min(Tg, b - g * Tg))) if episode_quota else 0 for g in range(self.G)]
         for g, grp in enumerate(self.groups):
-            q = a * Tg + max(0, min(Tg, b - g * Tg)) if episode_quota else 0
-            if episode_quota and q == 0:
-                raise ValueError('episode_quota %d leaves group %d of %d without a game' % (episode_quota, g, self.G))
+            q = shares[g] if episode_quota == 0 or shares[g] > 0 else -1
             grp.f.selfplay_start(None if init_boards is None else init_boards[g * Tg:(g + 1) * Tg], epoch=epoch, episode_quota=q)
         if (epoch, episode_quota) != getattr(self, '_epoch_quota', (0, 0)):
             self.graph = None                # seed and quota are kernel arguments: the captured rounds are stale

@@ -166,7 +166,10 @@ def respawn_ranks(n):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
            '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    return subprocess.call(cmd, env=env)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:            # a rank died (torch.distributed.run has already torn the others down): say so, with a non-zero exit code
+        sys.stderr.write('bench.py: the %d-rank run failed (torch.distributed.run exit code %d): no result line\n' % (n, rc))
+    return rc
 
 
 def build_engine(a, game_key, T, rank, dev):
@@ -374,7 +377,7 @@ def measure_net(a, eng, T, game_key, net_kind):
                 flops_per_launch=flops, leaves_per_launch=Tg, net_ms=ms, launches=n, standalone_launch_ms=standalone_ms)
 
 
-def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roofline=True):
+def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roofline=True, preroll_override=None):
     """warm-up ply waves, then exactly `steps` timed ply waves bracketed by barrier + synchronize; -> result dict (rank-reduced)"""
     import torch
     import torch.distributed as dist
@@ -384,6 +387,8 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
     sims = a.sims
     eng.start()
     preroll = PREROLL_PLIES.get(game_key, 0) if a.preroll_plies < 0 else a.preroll_plies
+    if preroll_override is not None:
+        preroll = preroll_override
     if preroll > 0:
         fast = max(1, sims // int(margs.get('ratio_fullMCTS', 5)))
         eng.set_search_params(sims, 0.0)                     # every ply a fast search: no examples, no forced playouts
@@ -409,15 +414,16 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
     t1 = time.perf_counter()
     s1 = eng.stats()
     dt = t1 - t0
+    rdev = dev if (not use_dist or dist.get_backend() == 'nccl') else 'cpu'          # (gloo: the small reductions on host tensors)
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loc = torch.tensor([s1['sims'] - s0['sims'], s1['plies'] - s0['plies'], s1['errors'], s1['games'] - s0['games'],
-                        n_local_examples, s1['examples_dropped']], dtype=torch.int64, device=dev)
+                        n_local_examples, s1['examples_dropped']], dtype=torch.int64, device=rdev)
     if use_dist:
         # error flags are a bit mask: OR them over the ranks as a MAX per bit (RCCL has no BOR; a SUM would garble the bits)
-        bits = torch.tensor([(int(loc[2]) >> b) & 1 for b in range(8)], dtype=torch.int64, device=dev)
+        bits = torch.tensor([(int(loc[2]) >> b) & 1 for b in range(8)], dtype=torch.int64, device=rdev)
         dist.all_reduce(loc, op=dist.ReduceOp.SUM)
         dist.all_reduce(bits, op=dist.ReduceOp.MAX)
         loc[2] = sum(int(x) << b for b, x in enumerate(bits.tolist()))
@@ -488,6 +494,8 @@ def main():
                     help='plies played with fast searches before the warm-up (-1 = per-game default, about 3/4 of a game; 0 = start from '
                          'the opening): moves the games to where they end inside a short timed window, so the example gather is not empty')
     ap.add_argument('--no-secondary', action='store_true', help='skip the Santorini no-gods leg (north star\'s second target)')
+    ap.add_argument('--no-sustained', action='store_true', help='skip the whole-games leg (value_whole_games)')
+    ap.add_argument('--sustained-steps', type=int, default=70, help='timed ply waves of the whole-games leg')
     ap.add_argument('--secondary-steps', type=int, default=0, help='timed ply waves of the secondary leg (0 = max(3, steps // 5))')
     a = ap.parse_args()
     if a.traffic_json is None:
@@ -507,14 +515,23 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     use_dist = world > 1 or bool(os.environ.get('AZG_FORCE_DIST'))      # AZG_FORCE_DIST: exercise the RCCL path on one GPU
     assert world == a.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, a.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = 'cuda:%d' % local_rank
+    # AZG_BENCH_BACKEND=gloo: the whole multi-rank flow (spawn -> shard -> gather -> rank-reduced line) on however many GPUs there are --
+    # the ranks share the devices round-robin (tests/test_gpu_bench_ranks.py runs world 2 on one GPU); default: one GPU per rank over RCCL
+    backend = os.environ.get('AZG_BENCH_BACKEND', 'nccl')
+    local_dev = local_rank % max(1, torch.cuda.device_count()) if backend != 'nccl' else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = 'cuda:%d' % local_dev
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     T = a.games
+    if os.environ.get('AZG_BENCH_FAIL_RANK') and int(os.environ['AZG_BENCH_FAIL_RANK']) == rank:
+        raise SystemExit('AZG_BENCH_FAIL_RANK: rank %d dies on purpose (tests/test_gpu_bench_ranks.py)' % rank)
     r = run_workload(a, a.game, T, a.steps, a.warmup, rank, world, dev, use_dist)
     search_mix = ('every ply a full search' if a.prob_full >= 1.0 else
                   'prob_fullMCTS=%g: full searches mixed with numMCTSSims//5 fast ones (reference default mix, secondary figure)' % a.prob_full)
@@ -529,7 +546,9 @@ def main():
                value=r['value'], unit='env-steps/sec', n_gpus=world, steps=a.steps, warmup=a.warmup,
                ms_per_step=r['dt'] / a.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64',
                data='synthetic (Board.init_game boards from the counter RNG; net weights: reference checkpoint converted (%s))' % r['weights'],
-               config=dict(workload=workload, games_per_gpu=T, step='one ply wave = %d lock-step rounds' % a.sims,
+               config=dict(workload=workload, games_per_gpu=T,
+                           step=('one ply wave = %d calls per tree on average (asynchronous pipeline: the trees share the launch\'s %d x %d calls; a call = '
+                                 'what one lock-step round does for a tree)' % (a.sims, a.sims, T)) if r.get('async_pipe') else 'one ply wave = %d lock-step rounds' % a.sims,
                            parallelism='games sharded x%d by game index, no data-path collective; 1 RCCL example gather to rank 0 at episode end' % world if world > 1 else 'single GPU',
                            hip_graph=r['hip_graph']),
                groups=a.groups)
@@ -549,6 +568,18 @@ def main():
         out['roofline_net'] = r['roofline_net']
     if use_dist:
         dist.barrier()
+    # ---- sustained: the same workload over WHOLE games (no pre-roll: opening, middle game, endgame, restart), no roofline legs -- the
+    # window above times the phase the pre-roll moved the games to; this is the rate a training run sees ----
+    if a.game == 'splendor2' and not a.no_sustained and (a.preroll_plies != 0 or a.steps < 60):
+        try:
+            r3 = run_workload(a, a.game, T, a.sustained_steps, 10, rank, world, dev, use_dist, roofline=False, preroll_override=0)
+            out['value_whole_games'] = r3['value']
+            out['sustained'] = dict(value=r3['value'], unit='env-steps/sec', steps=a.sustained_steps, warmup=10, preroll_plies=0,
+                                    plies_completed=r3['plies_completed'], games_finished=r3['games_finished'], engine_errors=r3['engine_errors'],
+                                    ms_per_step=r3['dt'] / a.sustained_steps * 1e3,
+                                    note='same engine and flags from the opening position over ~one whole game per tree')
+        except Exception as ex:
+            out['sustained'] = dict(error=repr(ex))
     # ---- secondary: the north star's second target (Santorini no-gods), same engine, shorter window, own roofline ----
     if a.game == 'splendor2' and not a.no_secondary:
         try:

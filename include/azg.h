@@ -251,11 +251,14 @@ int azg_selfplay_start(azg_forest* f, const int8_t* init_boards_dev /* or NULL *
 /* the same with (a) an RNG epoch: epoch 0 == azg_selfplay_start; another epoch re-keys every random stream of the forest, so
    the next wave of episodes of one Coach.learn run (Coach.py:150-215 draws fresh randomness every iteration) does not replay
    the previous one; (b) an episode quota = Coach.executeEpisodes' numEps (Coach.py:86-148): tree t plays quota / T (+1 for
-   t < quota % T) games to their end and then idles -- every started game is finished and kept; 0 = restart forever.
+   t < quota % T) games to their end and then idles -- every started game is finished and kept; 0 = restart forever; -1 = this
+   forest plays no game (every tree idle: a group of a larger engine whose share of numEps is empty).
    Seed and quota are kernel arguments: HIP graphs that captured this forest's launches under another epoch / quota must be
    captured again. */
 int azg_selfplay_start_ex(azg_forest* f, const int8_t* init_boards_dev /* or NULL */, uint64_t epoch, int64_t episode_quota,
                           void* stream);
+/* sizeof(azg_forest_cfg) of this build: a binding compares it with its own declaration before it hands a cfg over */
+int azg_forest_cfg_size(void);
 /* to be called after expand_backup, every round or every few rounds: trees whose search finished sample the move
    (Coach.py:63,278-292), record the example (Coach.py:65-69), play it (Coach.py:71), detect the end (Coach.py:73-82),
    restart finished games, re-root and begin the next search -- all on device. */
