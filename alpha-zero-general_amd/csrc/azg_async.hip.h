@@ -57,7 +57,8 @@ struct AsyncCtl {                              // zeroed by the host before ever
 // 32..63 histogram of the leaf wait in us (last bucket: >= 31)    64..95 histogram of the ready wait
 struct AsyncArgs {
     ForestDev F;
-    H2Weights W;
+    H2Weights W;                               // net V80 (Splendor 2 players): nn_v80_h2.hip.h
+    Conv5NetW C5; float c5_descale; int c5_pad; // net V89 (Santorini no-gods): nn_conv5x5.hip.h
     int8_t* aleaf; uint8_t* leaf_valid; uint8_t* needs_eval; float* pi; float* v;
     AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts_ready;
     unsigned long long* prof;
@@ -367,15 +368,39 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
 #endif  // AZG_ASYNC_PART_SELECT
 
 #ifdef AZG_ASYNC_PART_NET        /* the net kernel and the host side: azg_async.hip */
-constexpr int ASYNC_NET_LDS = H2_LDS + 512;   // the forward's LDS map + the batch descriptor: tree of sample s [16], calls left [16], count, the
-                                              // profile sums and (nn_v80_h2.hip.h H2_IND_MASK) the samples' valid bit masks
+// The net side of the pipeline is the same for every net: NET names the forward (a 12-wave workgroup body that takes its samples from a batch
+// descriptor in LDS), its batch size BS (samples per forward = tickets per range) and its LDS bytes; behind the forward's LDS map sit 512
+// bytes: the batch descriptor (tree of sample s [16 ints], calls left [16], count, ...), the profile sums and the samples' valid bit masks.
+constexpr int ASYNC_DESC_BYTES = 512;
+struct NetV80 {                                // Splendor 2 players: k_v80_net_h2<12>'s body, 16 leaves per forward
+    using G = SplendorDev<2>;
+    static constexpr int BS = 16, LDS = H2_LDS;
+    static __device__ __forceinline__ void run(uint8_t* lds, AsyncArgsC A, const int* sidx, unsigned long long* smask) {
+        (void)smask;                           // (h2_net_body finds the masks H2_IND_MASK ints behind sidx)
+        h2_net_body<12, true>(lds, &A->W, A->aleaf, (const uint8_t*)A->aleaf, A->F.T, G::P, A->pi, A->v, 0, sidx);
+    }
+};
+constexpr int C5_NET_LDS = C5_LDS_LEAD + 2 * 202 * 128 + 65536 + (2 * 25 * 162 + 25 * 64 + 64 * 2 + 64) * 4;      // (azg_nn.hip conv5_launch)
+struct NetC5 {                                 // Santorini no-gods: k_conv5_net<5, 162, 2, 2>'s body, 8 leaves per forward
+    using G = SantoriniDev<1>;
+    static constexpr int BS = 8, LDS = (C5_NET_LDS + 255) / 256 * 256;
+    static __device__ __forceinline__ void run(uint8_t* lds, AsyncArgsC A, const int* sidx, unsigned long long* smask) {
+        const Conv5NetW N = load_const(&A->C5);
+        conv5_net_body<5, 162, 2, 2, true>((float*)lds, N, A->aleaf, (const uint8_t*)A->aleaf, A->F.T, A->pi, A->v, A->c5_descale, 0, sidx, smask);
+    }
+};
+static_assert(NetV80::LDS + ASYNC_DESC_BYTES <= 160 * 1024 && NetC5::LDS + ASYNC_DESC_BYTES <= 160 * 1024, "net LDS + batch descriptor");
 
+template <class NET>
 __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    int* const sidx = (int*)(lds + H2_LDS);
+    extern __shared__ __attribute__((aligned(256))) uint8_t lds[];
+    constexpr int BS = NET::BS;
+    constexpr uint32_t FULL = (1u << BS) - 1u;
+    int* const sidx = (int*)(lds + NET::LDS);
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t t_begin = wall32();
-    unsigned long long* const P = (unsigned long long*)(lds + H2_LDS + 160);   // batches, leaves, busy, idle, leaf wait (LDS: nothing live across the forward)
+    unsigned long long* const P = (unsigned long long*)(lds + NET::LDS + 160);   // batches, leaves, busy, idle, leaf wait (LDS: nothing live across the forward)
+    unsigned long long* const smask = (unsigned long long*)(sidx + H2_IND_MASK);
     if (tid < 6) P[tid] = 0ull;
     // the workgroup's TICKET RANGE: sixteen consecutive leaf tickets taken with one returning atomic add (a claim that has to look at
     // head and tail and compare-and-swap costs several memory round trips and serialises the 150 workgroups: measured 285 us of leaf
@@ -394,10 +419,10 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
             uint32_t base = (uint32_t)sidx[34], taken = (uint32_t)sidx[35];
             if (!sidx[36]) {
                 uint32_t b = 0u;
-                if (lane == 0) b = atomicAdd(&ctl->leaf_head, 16u);
+                if (lane == 0) b = atomicAdd(&ctl->leaf_head, (uint32_t)BS);
                 base = uni_u32(b); taken = 0u;
             }
-            const uint32_t tk = base + (uint32_t)(lane & 15);
+            const uint32_t tk = base + (uint32_t)(lane % BS);
             const uint32_t tag = ((tk >> rb) & 7u) + 1u;
             uint32_t first_seen = 0u;
             unsigned long long e = 0ull;
@@ -406,11 +431,11 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
             uint32_t take = 0u;
             unsigned spins = 0u;
             for (;;) {
-                e = lane < 16 ? __hip_atomic_load(A->ring + (tk & rmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                const uint32_t filled = (uint32_t)__ballot(lane < 16 && (uint32_t)(e >> 60) == tag) & ~taken;
+                e = lane < BS ? __hip_atomic_load(A->ring + (tk & rmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                const uint32_t filled = (uint32_t)__ballot(lane < BS && (uint32_t)(e >> 60) == tag) & ~taken;
                 const uint32_t now = wall32();
                 if (filled && !seen) { seen = true; first_seen = now; }
-                if (filled && ((filled | taken) == 0xFFFFu || (int)(now - first_seen) >= wait_ticks)) { take = filled; n = __popc(filled); break; }
+                if (filled && ((filled | taken) == FULL || (int)(now - first_seen) >= wait_ticks)) { take = filled; n = __popc(filled); break; }
                 if (!filled && (++spins & 7u) == 0u) {
                     if (uni_u32(aload(&ctl->retired)) >= (uint32_t)T || uni_u32(aload(&ctl->abort))) { n = -1; break; }
                     if ((int)(now - idle0) > timeout) {                              // (no leaf for that long)
@@ -425,7 +450,7 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
                 const uint32_t now = wall32();
                 taken |= take;
                 if (lane < 16) { sidx[lane] = -1; sidx[16 + lane] = 0; }
-                const bool mine = lane < 16 && ((take >> lane) & 1u);
+                const bool mine = lane < BS && ((take >> lane) & 1u);
                 uint32_t w = 0u;
                 if (mine) {
                     const int slot = __popc(take & ((1u << lane) - 1u));           // the batch is the taken tickets, compacted
@@ -439,7 +464,7 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
                 for (int m = 8; m >= 1; m >>= 1) w += __shfl_xor(w, m, 16);
                 if (lane == 0) {
                     P[4] += (unsigned long long)w; P[3] += (unsigned long long)(now - idle0);
-                    sidx[34] = (int)base; sidx[35] = (int)taken; sidx[36] = taken != 0xFFFFu ? 1 : 0;
+                    sidx[34] = (int)base; sidx[35] = (int)taken; sidx[36] = taken != FULL ? 1 : 0;
                 }
             }
             if (lane == 0) sidx[32] = n;
@@ -451,14 +476,14 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
             const AsyncArgs* a = args;
             asm volatile("" : "+s"(a));
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)a;
-            h2_net_body<12, true>(lds, &A->W, A->aleaf, (const uint8_t*)A->aleaf, A->F.T, SplendorDev<2>::P, A->pi, A->v, 0, sidx);
+            NET::run(lds, A, sidx, smask);
         }
         // the next ticket range, when this one is used up: the returning atomic is issued HERE, so that its round trip runs under the drain
         // and the hand-back below instead of in front of the next claim (measured: 4.6 us per batch outside the forward, 12 % of a
         // net-bound pipeline's time)
         uint32_t next_base = 0u;
         const bool need_range = wave == 0 && !sidx[36];
-        if (need_range && lane == 0) next_base = atomicAdd(&((AsyncArgsC)(uintptr_t)args)->ctl->leaf_head, 16u);
+        if (need_range && lane == 0) next_base = atomicAdd(&((AsyncArgsC)(uintptr_t)args)->ctl->leaf_head, (uint32_t)BS);
         drain_vmem();                                   // EVERY wave: its write-through pi / v rows have left
         __syncthreads();
         {
@@ -493,8 +518,8 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
 #ifdef AZG_ASYNC_PART_SELECT
 // the descent kernel's launcher, called by azg_forest_async_rounds_v80_h2 (azg_async.hip): the two kernels live in two translation units
 // because they want different code generation (build.py)
-int azg_async_launch_select_splendor2(const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s) {
-    using G = azg::SplendorDev<2>;
+template <class G>
+static int async_launch_select(const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         HIPCHK(hipFuncSetAttribute((const void*)azg::k_async_select<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -504,10 +529,14 @@ int azg_async_launch_select_splendor2(const azg::AsyncArgs* devbuf, int n_sel, h
     HIPCHK(hipGetLastError());
     return 0;
 }
+// net_kind: 0 = Splendor 2 players (V80), 1 = Santorini no-gods (V89)
+int azg_async_launch_select(int net_kind, const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s) {
+    return net_kind == 0 ? async_launch_select<azg::SplendorDev<2>>(devbuf, n_sel, s) : async_launch_select<azg::SantoriniDev<1>>(devbuf, n_sel, s);
+}
 #endif  // AZG_ASYNC_PART_SELECT
 
 #ifdef AZG_ASYNC_PART_NET
-int azg_async_launch_select_splendor2(const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s);
+int azg_async_launch_select(int net_kind, const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s);
 // ---- host side ----
 struct AsyncSlot {
     AsyncArgs host; AsyncArgs* devbuf;
@@ -558,21 +587,24 @@ extern "C" int azg_forest_async_wginfo(azg_forest* f, unsigned long long* out /*
     return n;
 }
 
-// include/azg.h: `rounds` (descent, forward) pairs per tree of a Splendor-2p forest with the V80 net, as ONE pair of concurrent
-// persistent kernels
-extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v, int noise_stride,
-                                              const void* const* w, const float* descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
-                                              int shared_budget, void* stream) {
-    if (!f || !leaf_valid || !needs_eval || !pi || !v || !w || !descale) return fail("azg_forest_async_rounds_v80_h2: null argument");
+// One launch of the pipeline.  net_kind 0: Splendor 2 players + V80 (w = 43 pointers, descale = 16 host floats); 1: Santorini no-gods + V89
+// (w = 14 pointers, descale = 1 host float).
+static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v,
+                             int noise_stride, const void* const* w, const float* descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
+                             int shared_budget, void* stream) {
+    const std::string me(who);
+    if (!f || !leaf_valid || !needs_eval || !pi || !v || !w || !descale) return fail(me + ": null argument");
     if (rounds <= 0) return 0;
-    if (rounds >= (1 << 24)) return fail("azg_forest_async_rounds_v80_h2: at most 2^24 - 1 rounds per launch");
-    if (noise_stride != 0 && noise_stride != -2) return fail("azg_forest_async_rounds_v80_h2: noise_stride must be 0 or -2");
+    if (rounds >= (1 << 24)) return fail(me + ": at most 2^24 - 1 rounds per launch");
+    if (noise_stride != 0 && noise_stride != -2) return fail(me + ": noise_stride must be 0 or -2");
     int game = 0, variant = 0;
     double alpha = 0.0;
     const ForestDev* dev = azg_forest_dev_internal(f, &game, &variant, &alpha);
-    if (game != AZG_SPLENDOR || variant != 2) return fail("azg_forest_async_rounds_v80_h2: Splendor 2 players only (the V80 geometry of nn_v80_h2.hip.h)");
-    using G = SplendorDev<2>;
-    static_assert(AsyncLeaf<G>::STRIDE == H2_AL_STRIDE && AsyncLeaf<G>::MASK_OFF == H2_AL_MASK, "leaf record layout shared with the net kernel");
+    if (net_kind == 0 && (game != AZG_SPLENDOR || variant != 2)) return fail(me + ": Splendor 2 players only (the V80 geometry of nn_v80_h2.hip.h)");
+    if (net_kind == 1 && (game != AZG_SANTORINI || variant != 1)) return fail(me + ": Santorini without gods only (the V89 geometry of nn_conv5x5.hip.h)");
+    static_assert(AsyncLeaf<SplendorDev<2>>::STRIDE == H2_AL_STRIDE && AsyncLeaf<SplendorDev<2>>::MASK_OFF == H2_AL_MASK, "leaf record layout shared with the net kernel");
+    static_assert(AsyncLeaf<SantoriniDev<1>>::STRIDE == C5_AL_STRIDE && AsyncLeaf<SantoriniDev<1>>::MASK_OFF == C5_AL_MASK, "leaf record layout shared with the net kernel");
+    const int leaf_stride = net_kind == 0 ? H2_AL_STRIDE : C5_AL_STRIDE, bs = net_kind == 0 ? NetV80::BS : NetC5::BS;
     static int n_cu = 0;
     // The two kernels MUST run side by side, so their streams must not share a hardware queue (HIP multiplexes streams onto a few queues
     // -- 4 per priority level by default -- and kernels of one queue run one after the other: the net kernel would wait for leaves that
@@ -592,18 +624,23 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         HIPCHK(hipGetDevice(&d));
         HIPCHK(hipGetDeviceProperties(&prop, d));
         n_cu = prop.multiProcessorCount;
-        HIPCHK(hipFuncSetAttribute((const void*)k_async_net, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetV80>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetC5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int T = dev->T;
-    if (n_net <= 0 || n_sel <= 0) {                   // default split of the CUs: half and half (measured at 4096 x 800, whole games and the
-        n_net = n_cu / 2;                             // driver's window: 128 + 128 of 256 beats 120 / 124 / 132 / 136 for the net)
+    if (n_net <= 0 || n_sel <= 0) {
+        // default split of the CUs.  V80: half and half (measured at 4096 x 800, whole games and the driver's window: 128 + 128 of 256
+        // beats 120 / 124 / 132 / 136 for the net); V89: a forward of 8 leaves costs ~80 us of a CU, a descent ~33 us of a sixteenth of one:
+        // 13 / 16 for the net (measured: 208 + 48 -> 28.8 k env-steps/s, 216 + 40 24.5 k, 204 + 52 28.7 k, 200 + 56 28.3 k; two kernels 26.5 k)
+        n_net = net_kind == 0 ? n_cu / 2 : n_cu * 13 / 16;
         n_sel = n_cu - n_net;
     }
     if (n_sel > T) n_sel = T;
-    if (n_net > (T + 15) / 16) n_net = (T + 15) / 16;
+    if (n_net > (T + bs - 1) / bs) n_net = (T + bs - 1) / bs;
     if (n_net + n_sel > n_cu)
-        return fail("azg_forest_async_rounds_v80_h2: n_net + n_sel exceeds the CUs of the device (every workgroup of the pipeline must be resident)");
-    if ((long long)n_sel * ASYNC_RS < T) return fail("azg_forest_async_rounds_v80_h2: more than 128 trees per select workgroup");
+        return fail(me + ": n_net + n_sel exceeds the CUs of the device (every workgroup of the pipeline must be resident)");
+    if ((long long)n_sel * ASYNC_RS < T) return fail(me + ": more than 128 trees per select workgroup");
+    if (T >= (1 << 20)) return fail(me + ": at most 2^20 - 1 trees");
     AsyncSlot* sl = (AsyncSlot*)azg_forest_attached(f, "async_v80");
     if (!sl) {
         sl = new AsyncSlot();
@@ -614,7 +651,7 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         while ((1 << rb) < 2 * T) rb++;
         sl->ring_bits = rb;
         HIPCHK(hipMalloc(&sl->devbuf, sizeof(AsyncArgs)));
-        HIPCHK(hipMalloc(&sl->aleaf, (size_t)T * AsyncLeaf<G>::STRIDE));
+        HIPCHK(hipMalloc(&sl->aleaf, (size_t)T * leaf_stride));
         HIPCHK(hipMalloc(&sl->ctl, sizeof(AsyncCtl)));
         HIPCHK(hipMalloc(&sl->ring, sizeof(unsigned long long) << rb));
         HIPCHK(hipMalloc(&sl->ready, sizeof(uint32_t) * ASYNC_RS * n_cu));          // (sized for any split: it may change from launch to launch)
@@ -623,7 +660,7 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
         HIPCHK(hipMemset(sl->prof, 0, sizeof(unsigned long long) * ASYNC_NPROF));
         HIPCHK(hipMalloc(&sl->wginfo, sizeof(unsigned long long) * 4 * n_cu));
         HIPCHK(hipMemset(sl->wginfo, 0, sizeof(unsigned long long) * 4 * n_cu));
-        HIPCHK(hipMemset(sl->aleaf, 0, (size_t)T * AsyncLeaf<G>::STRIDE));
+        HIPCHK(hipMemset(sl->aleaf, 0, (size_t)T * leaf_stride));
         HIPCHK(hipMemset(sl->ts, 0, sizeof(uint32_t) * ASYNC_RS * n_cu));
         HIPCHK(hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl->join, hipEventDisableTiming));
@@ -636,7 +673,12 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
     // (the forest's work / level budget stays: a call that runs into it is followed by the next one at once, so no tree waits for another
     // inside a launch -- but a launch ends only when every tree has had its calls, and a tree whose simulations all end on terminal nodes
     // would otherwise run its whole search inside ONE call: measured 4.1 ms launches of 48 rounds where the mean tree needs 3.4 ms)
-    want.W = h2_weights(w, descale);
+    if (net_kind == 0) want.W = h2_weights(w, descale);
+    else {
+        const float* const* wf = (const float* const*)w;
+        want.C5 = Conv5NetW{wf[0], wf[1], wf[2], wf[3], wf[4], wf[5], wf[6], wf[7], wf[8], wf[9], wf[10], wf[11], wf[12], wf[13]};
+        want.c5_descale = descale[0];
+    }
     want.aleaf = sl->aleaf; want.leaf_valid = leaf_valid; want.needs_eval = needs_eval; want.pi = pi; want.v = v;
     want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_ready = sl->ts; want.prof = sl->prof; want.wginfo = sl->wginfo;
     want.noise = (alpha != 0.0 && noise_stride == -2) ? 1 : 0;
@@ -658,14 +700,30 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
     HIPCHK(hipEventRecord(sl->fork, s));
     HIPCHK(hipStreamWaitEvent(net_stream, sl->fork, 0));
     HIPCHK(hipStreamWaitEvent(sel_stream, sl->fork, 0));
-    k_async_net<<<dim3(n_net), dim3(768), ASYNC_NET_LDS, net_stream>>>(sl->devbuf);
+    if (net_kind == 0) k_async_net<NetV80><<<dim3(n_net), dim3(768), NetV80::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf);
+    else k_async_net<NetC5><<<dim3(n_net), dim3(768), NetC5::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf);
     HIPCHK(hipGetLastError());
-    if (azg_async_launch_select_splendor2(sl->devbuf, n_sel, sel_stream)) return -1;
+    if (azg_async_launch_select(net_kind, sl->devbuf, n_sel, sel_stream)) return -1;
     HIPCHK(hipEventRecord(sl->join_net, net_stream));
     HIPCHK(hipEventRecord(sl->join, sel_stream));
     HIPCHK(hipStreamWaitEvent(s, sl->join_net, 0));
     HIPCHK(hipStreamWaitEvent(s, sl->join, 0));
     return 0;
+}
+
+// include/azg.h: the pipeline for a Splendor-2p forest with the V80 net
+extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v, int noise_stride,
+                                              const void* const* w, const float* descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
+                                              int shared_budget, void* stream) {
+    return async_rounds_impl("azg_forest_async_rounds_v80_h2", 0, f, leaf_valid, needs_eval, pi, v, noise_stride, w, descale, rounds, n_net, n_sel,
+                             batch_wait_ticks, shared_budget, stream);
+}
+// include/azg.h: the pipeline for a Santorini no-gods forest with the V89 net (14 pointers of azg_nn_conv5_forward_h2, its descale)
+extern "C" int azg_forest_async_rounds_conv5_h2(azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v, int noise_stride,
+                                                const float* const* w, float descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
+                                                int shared_budget, void* stream) {
+    return async_rounds_impl("azg_forest_async_rounds_conv5_h2", 1, f, leaf_valid, needs_eval, pi, v, noise_stride, (const void* const*)w, &descale, rounds,
+                             n_net, n_sel, batch_wait_ticks, shared_budget, stream);
 }
 
 #endif  // AZG_ASYNC_PART_NET

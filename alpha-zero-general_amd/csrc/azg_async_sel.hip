@@ -19,6 +19,8 @@
 #include "azg_common.hip.h"
 #include "nn_kernels.hip.h"
 #include "nn_v80_h2.hip.h"
+#include "nn_conv5x5.hip.h"
+#include "game_santorini.hip.h"
 
 using namespace azg;
 

@@ -668,21 +668,36 @@ __device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t*
 }
 #undef AZG_BF
 
-// SPLIT: the trunk on bf16 x 3 operands (above; N.Wc then points to the split fragments); LDS = 2 tiles x 3 planes x (ROWS + 1) x 128 B
-template <int NB, int A, int P, int SPLIT = 0>
-__global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __restrict__ boards,
-                                                   const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
-                                                   float* __restrict__ v_out, float descale) {
+// IND (the asynchronous pipeline, azg_async.hip.h): sample s of the workgroup is tree sidx[s] (LDS; < 0 = no sample); `boards` and `valid`
+// are then both the pipeline's leaf-record array (kernels.hip.h AsyncLeaf<SantoriniDev<1>>: int8 state [80] + valid bit mask u64[3], stride
+// 112), read past the L1; the samples' masks are fetched with the boards into `smask` (LDS u64 [8][3]); pi / v rows are written
+// WRITE-THROUGH at the tree's index -- the reader is a descent wave on another CU, inside the same launch.
+constexpr int C5_AL_STRIDE = 112, C5_AL_MASK = 80;
+template <int NB, int A, int P, int SPLIT, bool IND>
+__device__ __forceinline__ void conv5_net_body(float* smem, const Conv5NetW& N, const int8_t* __restrict__ boards,
+                                               const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
+                                               float* __restrict__ v_out, float descale, const int wg, const int* sidx = nullptr,
+                                               unsigned long long* smask = nullptr) {
     constexpr int NPL = SPLIT ? SPLIT : 3;                  // planes per tile: 3 = bf16 x 3, 2 = f16 x 2
     constexpr int NS = 8, ROWS = NS * 25, CS = 68, CP2 = 2, AS = (A + 3) / 4 * 4 + 4, PLANE_B = (ROWS + 2) * 128, TILE_B = NPL * PLANE_B;
-    extern __shared__ __attribute__((aligned(256))) float smem[];
+    constexpr int AWI = (A + 63) / 64;
     if (NPL == 2) h2_fp16_saturate_mode();
     constexpr int LEAD = (NPL == 2 && SPLIT == 2) ? C5_LDS_LEAD : 0;      // (conv3x3_split: operand addresses reach six cells back)
     float* X = smem + LEAD / 4;             // [ROWS][CS]   (SPLIT: three bf16 planes, TILE_B bytes)
     float* Y = SPLIT ? (float*)((uint8_t*)X + TILE_B) : X + ROWS * CS;               // [ROWS][CS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
+    int tid_ = threadIdx.x;
+    if (IND) asm volatile("" : "+v"(tid_));            // (opaque inside the pipeline's persistent loop)
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
+    const int b0 = wg * NS, nb = IND ? NS : min(NS, B - b0);
     bool heads_done = false;
+    unsigned long long ind_mask = 0ull;
+    if constexpr (IND) {
+        if (tid < NS * AWI) {
+            const int b = sidx[tid / AWI];
+            if (b >= 0) ind_mask = __hip_atomic_load((const unsigned long long*)(valid + (size_t)b * C5_AL_STRIDE + C5_AL_MASK) + tid % AWI, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // f16 x 2 kernel: LDS copies of Wfp [50][A], Wf1 [25][64], Wp [64][2], Wv [64] behind the two tiles (the second is 64 KB)
     constexpr int WST_FP = CP2 * 25 * A, WST_F1 = WST_FP + 25 * 64, WST_P = WST_F1 + 64 * CP2, WST_N = WST_P + 64;
     float* const WST = (float*)((uint8_t*)X + TILE_B + 65536);
@@ -703,10 +718,16 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     if (LEAD && tid >= 704 && tid < 768) BL[2 * NB * 64 + tid - 704] = N.b0[tid - 704];
     // (the small operands of the last phases -- head / FC biases, the value head's second matrix, the valid masks -- copied here as well:
     // 307.9 k -> 312.3 k cycles per launch, dropped: their global loads are not what the 1x1 heads / FC / softmax phases wait for)
+    if constexpr (IND) { if (tid < NS * AWI) smask[tid] = ind_mask; }
     __syncthreads();
     constexpr bool CM = NPL == 2 && SPLIT == 2;                // cell-major tiles (row = cell * NS + sample) in the f16 x 2 kernel
     for (int i = tid; i < nb * 25 * 2; i += 768) {
         const int sc = i >> 1, pl = i & 1, smp = sc / 25, cell = sc - 25 * smp;        // (sample, cell) of the board byte
+        if constexpr (IND) {
+            const int b = sidx[smp];
+            Y[(CM ? cell * NS + smp : sc) * CS + pl] =
+                b >= 0 ? (float)(int8_t)__hip_atomic_load((const uint8_t*)boards + (size_t)b * C5_AL_STRIDE + cell * 3 + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        } else
         Y[(CM ? cell * NS + smp : sc) * CS + pl] = (float)boards[(size_t)b0 * 75 + sc * 3 + pl];
     }
     __syncthreads();
@@ -863,14 +884,16 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
     C5_PH(22);
     // masked softmax == exp(log_softmax(where(valid, logits, -1e8))), one wave per sample
     for (int s = wave; s < nb; s += 12) {
-        const int b = b0 + s;
+        const int b = IND ? sidx[s] : b0 + s;
+        if (IND && b < 0) continue;
         float x[(A + 63) / 64];
         float mx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < (A + 63) / 64; k++) {
             const int a = lane + 64 * k;
             x[k] = -INFINITY;
-            if (a < A) x[k] = valid[(size_t)b * A + a] ? LG[s * AS + a] : -1e8f;
+            if constexpr (IND) { if (a < A) x[k] = ((smask[s * AWI + k] >> lane) & 1ull) ? LG[s * AS + a] : -1e8f; }
+            else if (a < A) x[k] = valid[(size_t)b * A + a] ? LG[s * AS + a] : -1e8f;
             mx = fmaxf(mx, x[k]);
         }
         mx = nn_wave_max(mx);
@@ -880,15 +903,31 @@ __global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __
         sum = nn_wave_sum(sum);
 #pragma unroll
         for (int k = 0; k < (A + 63) / 64; k++)
-            if (lane + 64 * k < A) pi_out[(size_t)b * A + lane + 64 * k] = x[k] / sum;
+            if (lane + 64 * k < A) {
+                if constexpr (IND) __hip_atomic_store((uint32_t*)pi_out + (size_t)b * A + lane + 64 * k, __float_as_uint(x[k] / sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else pi_out[(size_t)b * A + lane + 64 * k] = x[k] / sum;
+            }
     }
     if (tid < nb * P) {
         const int s = tid / P, p = tid - s * P;
-        float acc = N.bf2[p];
-        for (int j = 0; j < 64; j++) acc += H1[s * 64 + j] * N.Wf2[j * P + p];
-        v_out[(size_t)(b0 + s) * P + p] = tanhf(acc);
+        const int b = IND ? sidx[s] : b0 + s;
+        if (!IND || b >= 0) {
+            float acc = N.bf2[p];
+            for (int j = 0; j < 64; j++) acc += H1[s * 64 + j] * N.Wf2[j * P + p];
+            if constexpr (IND) __hip_atomic_store((uint32_t*)v_out + (size_t)b * P + p, __float_as_uint(tanhf(acc)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else v_out[(size_t)b * P + p] = tanhf(acc);
+        }
     }
     C5_PH(23);
+}
+
+// SPLIT: the trunk on bf16 x 3 operands (above; N.Wc then points to the split fragments); LDS = 2 tiles x 3 planes x (ROWS + 1) x 128 B
+template <int NB, int A, int P, int SPLIT = 0>
+__global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __restrict__ boards,
+                                                   const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
+                                                   float* __restrict__ v_out, float descale) {
+    extern __shared__ __attribute__((aligned(256))) float smem[];
+    conv5_net_body<NB, A, P, SPLIT, false>(smem, N, boards, valid, B, pi_out, v_out, descale, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -124,10 +124,16 @@ class SelfPlayEngine:
         # the asynchronous tree pipeline (csrc/azg_async.hip.h): persistent descent + net workgroups, no launch-wide boundary between the
         # descents and the forwards; round 5: 100 k env-steps/s against 79 k for the two-kernel rounds at 4096 x 800.  Same preconditions
         # as the per-CU kernel, one group.  AZG_ASYNC=0 / async_pipe=False: the two-kernel rounds.
+        # ... and for Santorini without gods + the V89 net on its f16 x 2 kernel (SantoriniV89Hip(h2=True)) with static output buffers
+        can_c5 = (getattr(game, 'GAME_ID', None) == _lib.SANTORINI and int(getattr(game, 'variant', 0) or 0) == 1 and self.fused and
+                  hasattr(_lib.lib(), 'azg_forest_async_rounds_conv5_h2') and
+                  all(type(n).__name__ == 'SantoriniV89Hip' and getattr(n, 'h2', False) and torch.is_tensor(getattr(n, 'pi', None)) and
+                      tuple(n.pi.shape) == (Tg, A_game) for n in nets))
         if async_pipe is None:
-            async_pipe = can and groups == 1 and not percu and os.environ.get('AZG_ASYNC', '1') == '1'
-        elif async_pipe and not (can and groups == 1):
-            raise ValueError('async_pipe=True needs Splendor 2 players, SplendorV80Hip(h2=True) evaluators with max_batch == n_games, groups == 1')
+            async_pipe = (can or can_c5) and groups == 1 and not percu and os.environ.get('AZG_ASYNC', '1') == '1'
+        elif async_pipe and not ((can or can_c5) and groups == 1):
+            raise ValueError('async_pipe=True needs Splendor 2 players + SplendorV80Hip(h2=True) or Santorini no-gods + SantoriniV89Hip(h2=True) '
+                             'evaluators with max_batch == n_games, groups == 1')
         self.async_pipe = bool(async_pipe)
         self.adaptive = False
         if work_budget is None:

@@ -568,6 +568,56 @@ def test_async_pipeline_equals_two_kernel_rounds(T, sims, K, budget, cfg):
         assert torch.equal(r0[k], r1[k]), k
 
 
+@pytest.mark.parametrize('T,sims,K,budget,cfg', [(24, 24, 8, 0, dict(n_net=3, n_sel=5)), (200, 32, 16, 6, dict(n_net=25, n_sel=2)), (128, 40, 40, 20, {})])
+def test_async_pipeline_santorini_equals_two_kernel_rounds(T, sims, K, budget, cfg):
+    """The asynchronous tree pipeline for the second hot-path game -- Santorini without gods with the V89 ResNet, 8 leaves per forward
+    (azg_forest_async_rounds_conv5_h2) -- against the two-kernel rounds (azg_forest_select_fused + azg_selfplay_advance +
+    azg_nn_conv5_forward_h2): the same games move for move, every example record, statistics counter and root statistic EQUAL."""
+    import os
+    import torch
+    from azg_amd import games
+    from azg_amd.nnet import SantoriniV89, SantoriniV89Hip
+    from azg_amd.selfplay import SelfPlayEngine
+    g = games.SantoriniGame(1)
+    w = os.path.join(os.path.dirname(__file__), 'golden', 'weights_santorini1_v89.npz')
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.2, temperature=[1.25, 0.8, 1.0],
+                tempThreshold=6, **MCTS_ARGS['santorini1'])
+    out = []
+    for pipe in (False, True):
+        net = SantoriniV89Hip(SantoriniV89.from_npz(w, device='cuda:0'), max_batch=T)
+        e = SelfPlayEngine(g, net, args, T, node_capacity=4096, max_examples=T * 400, rng_seed=11, use_graph=False, advance_every=1,
+                           work_budget=budget, async_pipe=pipe, async_cfg=dict(cfg, shared_budget=False))
+        assert e.async_pipe == pipe
+        e.start()
+        n = 40 * (sims + 2)                             # ~40 plies: most games end and restart
+        if pipe:
+            for _ in range(n // K):
+                e.run(K)
+            e.run(n % K)
+        else:
+            for _ in range(n):
+                e.groups[0].round(e.fused, advance=True)
+        torch.cuda.synchronize()
+        st = e.stats()
+        assert st['errors'] == 0 and st['games'] > 0, (st['errors'], e.forest.async_profile()['ctl'] if pipe else None)
+        ex = [x.cpu() for x in e.drain_examples()]
+        m = ex[5].to(torch.int64)
+        order = torch.argsort((m[:, 0] * 100000 + m[:, 1]) * 1000 + m[:, 2])
+        ex = [x[order] for x in ex]
+        rs = {k: v.cpu() for k, v in e.forest.root_stats().items()}
+        out.append((st, ex, rs))
+        assert e.forest.validate(verbose=False) == 0
+        e.close()
+    (s0, e0, r0), (s1, e1, r1) = out
+    for k in ('plies', 'games', 'sims', 'levels', 'expansions', 'terminal_hits', 'examples', 'sum_valid_visited', 'sum_depth_at_expand'):
+        assert s0[k] == s1[k], (k, s0[k], s1[k])
+    assert len(e0[0]) == len(e1[0]) > 0
+    for a, b in zip(e0, e1):
+        assert torch.equal(a, b)
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+
+
 @pytest.mark.parametrize('on_side_stream', [False, True])
 def test_async_pipeline_in_a_process_with_many_streams(on_side_stream):
     """The pipeline's two kernels must run side by side whatever streams the process has: HIP multiplexes streams onto a few hardware
