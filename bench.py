@@ -297,7 +297,7 @@ def measure_roofline(a, eng, T):
             prof = None
     extra = {}
     if aprof is not None:
-        extra = dict(async_pipeline=dict((k, aprof[k]) for k in ('n_sel', 'n_net', 'descent_us', 'forward_us', 'leaves_per_batch', 'leaf_wait_us',
+        extra = dict(async_pipeline=dict((k, aprof[k]) for k in ('n_sel', 'n_net', 'leaves', 'launches', 'descents', 'plies_in_kernel', 'descent_us', 'forward_us', 'leaves_per_batch', 'leaf_wait_us',
                                                                  'ready_wait_us', 'select_wave_busy', 'net_wg_busy', 'launch_us', 'forward_cycles', 'descent_cycles', 'net_cu_mhz', 'select_cu_mhz',
                                                                  'leaf_wait_hist_us', 'ready_wait_hist_us')),
                      rounds_per_launch=eng.K,
@@ -360,8 +360,23 @@ def measure_net(a, eng, T, game_key, net_kind):
         ms = e0.elapsed_time(e1) / n
     standalone_ms = ms
     rl = getattr(eng, '_last_roofline', None)
-    if getattr(eng, 'percu', False) and rl and rl.get('net_phase_ms'):
+    if getattr(eng, 'percu', False) and not getattr(eng, 'async_pipe', False) and rl and rl.get('net_phase_ms'):
         ms = rl['net_phase_ms']           # the net phase of the round kernel (16 waves, timed inside the kernel); the stand-alone launch is kept beside it
+    ap = (rl or {}).get('async_pipeline') if getattr(eng, 'async_pipe', False) else None
+    if ap:
+        # the pipeline: the forward runs inside the persistent net kernel, one batch per workgroup at a time; the kernel's rate over its
+        # launch = leaves evaluated x algorithmic FLOPs per leaf / launch duration (its n_net workgroups hold n_net of the CUs)
+        h2 = net_kind == 'hip' and getattr(grp.net, 'h2', False)
+        dt = 'f16' if h2 else 'f32'
+        flops_leaf = NET_MFLOP_PER_LEAF[game_key] * 1e6
+        ach = flops_leaf * ap['leaves'] / max(ap['launch_us'] * ap['launches'], 1e-9) / 1e6
+        return dict(bound='mfma', kernel='k_async_net (persistent: the forward of %s on batches of queued leaves)' % ('k_v80_net_h2<12>' if game_key == 'splendor2' else 'k_conv5_net<5, 162, 2, 2>'),
+                    achieved=ach, peak=MFMA_PEAK_TFLOPS[dt], unit='TFLOP/s', frac=ach / MFMA_PEAK_TFLOPS[dt], traffic=None, mfma_input_dtype=dt,
+                    frac_of_peak_of_its_cus=ach / (MFMA_PEAK_TFLOPS[dt] * ap['n_net'] / max(1, ap['n_net'] + ap['n_sel'])),
+                    note='fp32-accurate (<= 1e-5 of the reference outputs): every f32 operand is a hi + lo pair of f16 numbers, one algorithmic product = 3 '
+                         'MFMAs; achieved counts ALGORITHMIC flops only, over the whole launch of the persistent kernel (its workgroups also wait for leaves)',
+                    forward_us=ap['forward_us'], leaves_per_forward=ap['leaves_per_batch'], net_workgroups=ap['n_net'], net_wg_busy=ap['net_wg_busy'],
+                    forward_cycles=ap.get('forward_cycles'), flops_per_leaf=flops_leaf, standalone_launch_ms=standalone_ms, standalone_leaves=T // a.groups)
     Tg = T // a.groups
     flops = NET_MFLOP_PER_LEAF[game_key] * 1e6 * Tg
     h2 = net_kind == 'hip' and getattr(grp.net, 'h2', False)
