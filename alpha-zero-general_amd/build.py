@@ -32,7 +32,7 @@ FLAGS += os.environ.get('AZG_EXTRA_FLAGS', '').split()            # e.g. -ftrivi
 
 def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
-        [os.path.join(HERE, '..', 'include', 'azg.h')]
+        [os.path.join(HERE, '..', 'include', 'azg.h'), os.path.join(HERE, '..', 'include', 'azg_testaids.h')]
 
 
 def needs_build():

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/azg.h"
+#include "../../include/azg_testaids.h"
 #include "game_splendor.hip.h"
 #include "game_santorini.hip.h"
 #include "game_azul.hip.h"

@@ -385,8 +385,7 @@ struct NetC5 {                                 // Santorini no-gods: k_conv5_net
     using G = SantoriniDev<1>;
     static constexpr int BS = 8, LDS = (C5_NET_LDS + 255) / 256 * 256;
     static __device__ __forceinline__ void run(uint8_t* lds, AsyncArgsC A, const int* sidx, unsigned long long* smask) {
-        const Conv5NetW N = load_const(&A->C5);
-        conv5_net_body<5, 162, 2, 2, true>((float*)lds, N, A->aleaf, (const uint8_t*)A->aleaf, A->F.T, A->pi, A->v, A->c5_descale, 0, sidx, smask);
+        conv5_net_body<5, 162, 2, 2, true>((float*)lds, &A->C5, A->aleaf, (const uint8_t*)A->aleaf, A->F.T, A->pi, A->v, A->c5_descale, 0, sidx, smask);
     }
 };
 static_assert(NetV80::LDS + ASYNC_DESC_BYTES <= 160 * 1024 && NetC5::LDS + ASYNC_DESC_BYTES <= 160 * 1024, "net LDS + batch descriptor");

@@ -15,6 +15,7 @@
 #define AZG_FUSED_DEVICE_ONLY 1
 #define AZG_NN_KERNEL static
 #include "../../include/azg.h"
+#include "../../include/azg_testaids.h"
 #include "azg_host.h"
 #include "azg_common.hip.h"
 #include "nn_kernels.hip.h"

@@ -673,8 +673,13 @@ __device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t*
 // 112), read past the L1; the samples' masks are fetched with the boards into `smask` (LDS u64 [8][3]); pi / v rows are written
 // WRITE-THROUGH at the tree's index -- the reader is a descent wave on another CU, inside the same launch.
 constexpr int C5_AL_STRIDE = 112, C5_AL_MASK = 80;
+// The weight pointers are read through the CONSTANT address space wherever they are used (the stand-alone kernel: its own argument segment;
+// the pipeline: its argument block in device memory) -- as a by-value struct inside the pipeline's persistent loop the 14 pointers stayed
+// live in 28 scalar registers through the whole forward, and the scalar spills they caused became 48 spilled vector registers.
+typedef const Conv5NetW __attribute__((address_space(4))) * Conv5NetWC;
+#define N (*Np)
 template <int NB, int A, int P, int SPLIT, bool IND>
-__device__ __forceinline__ void conv5_net_body(float* smem, const Conv5NetW& N, const int8_t* __restrict__ boards,
+__device__ __forceinline__ void conv5_net_body(float* smem, const Conv5NetWC Np, const int8_t* __restrict__ boards,
                                                const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
                                                float* __restrict__ v_out, float descale, const int wg, const int* sidx = nullptr,
                                                unsigned long long* smask = nullptr) {
@@ -920,14 +925,17 @@ __device__ __forceinline__ void conv5_net_body(float* smem, const Conv5NetW& N, 
     }
     C5_PH(23);
 }
+#undef N
 
 // SPLIT: the trunk on bf16 x 3 operands (above; N.Wc then points to the split fragments); LDS = 2 tiles x 3 planes x (ROWS + 1) x 128 B
 template <int NB, int A, int P, int SPLIT = 0>
-__global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N, const int8_t* __restrict__ boards,
+__global__ __launch_bounds__(768) void k_conv5_net(Conv5NetW N /* first argument: offset 0 of the kernel argument segment, read through it */,
+                                                   const int8_t* __restrict__ boards,
                                                    const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
                                                    float* __restrict__ v_out, float descale) {
     extern __shared__ __attribute__((aligned(256))) float smem[];
-    conv5_net_body<NB, A, P, SPLIT, false>(smem, N, boards, valid, B, pi_out, v_out, descale, (int)blockIdx.x);
+    (void)N;
+    conv5_net_body<NB, A, P, SPLIT, false>(smem, (Conv5NetWC)__builtin_amdgcn_kernarg_segment_ptr(), boards, valid, B, pi_out, v_out, descale, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -203,10 +203,6 @@ int azg_forest_async_rounds_conv5_h2(azg_forest* f, uint8_t* leaf_valid_dev, uin
    summed over the select / net workgroups, [12] n_sel, [13] n_net, [32..63] histogram of [7]'s waits in microseconds (last bucket: >= 31), [64..95] of [8]'s. */
 #define AZG_ASYNC_NPROF 96
 int azg_forest_async_profile(azg_forest* f, double* out96, int reset);
-/* placement study: one row of four u64 per workgroup of the pipeline (the n_sel descent workgroups first): where it ran (XCC id | cu_id
-   << 8 | se_id << 16 | sh_id << 24), role (1 descent, 2 net), calls (descents / forwards) and the shader cycles spent in them since
-   the last reset.  Returns the number of rows written (<= max_wg). */
-int azg_forest_async_wginfo(azg_forest* f, unsigned long long* out_host, int max_wg, int reset);
 
 /* part 2: store (Ps, v) on the pending leaves and back the values up (MCTS.py:147-154,176-183).
    pi f32[T][A] are PROBABILITIES (exp of the net's log-softmax, GenericNNetWrapper.py:107,119), v f32[T][P].
@@ -229,24 +225,14 @@ int azg_forest_root_stats(azg_forest* f, int32_t* Ns_dev, float* Qs_dev, int32_t
 int azg_forest_dump_tree(azg_forest* f, int tree, int max_nodes, int8_t* states, int32_t* Ns, float* Qs, float* Es,
                          int32_t* Nsa, double* Qsa, float* Ps, uint8_t* has_policy);
 
-/* debug: fill the LDS of every CU and the queue's scratch memory with `pattern` (a kernel that reads on-chip memory it never wrote then
-   depends on the pattern, not on what ran before) */
-int azg_debug_poison_onchip(uint32_t pattern, void* stream);
 /* XCD-pinned streams (no reference counterpart: the reference time-slices N game threads on one core, Coach.py:117-144; here groups
    of games can run as independent select -> predict pipelines, selfplay.py): a HIP stream whose queue ASKS for the CUs of XCDs
    [xcd_first, xcd_first + xcd_count) of the current device only (hipExtStreamCreateWithCUMask; bit b of the mask = CU b / 8 of XCD
    b % 8).  Whether the mask is honoured is up to the platform: on the round-4 MI355X box (one partition over 8 XCDs) it was NOT -- the
-   hardware deals a queue's workgroups round-robin over all XCDs; azg_debug_placement shows where a launch really ran.  Pass the
+   hardware deals a queue's workgroups round-robin over all XCDs; azg_testaids.h has a probe that shows where a launch really ran.  Pass the
    handle as `stream` to any call of this header. */
 int azg_stream_create_xcd(int xcd_first, int xcd_count, void** out_stream);
 int azg_stream_destroy(void* stream);
-/* debug / tests: launch n_workgroups one-wave workgroups on `stream`; out_dev[i] = XCC_ID | cu_id << 8 | se_id << 16 | sh_id << 24 of
-   the CU that ran workgroup i */
-int azg_debug_placement(int n_workgroups, uint32_t* out_dev, void* stream);
-/* debug / tests / plugin benches: the integer hash-net of SURVEY.md Appendix C.3 as a leaf evaluator on the device (the deterministic stand-in
-   for NeuralNet.predict, NeuralNet.py:32-43, that the MCTS parity tests run on both sides): boards int8[T][S], valid u8[T][A] ->
-   pi f32[T][A], v f32[T][P], bit-identical to tests/hashnet.py.  Not a product net. */
-int azg_eval_hashnet(const int8_t* boards, const uint8_t* valid, int T, int S, int A, int P, float* pi, float* v, void* stream);
 /* debug / tests: check the structural invariants of every tree on the host; returns the number of violations */
 int azg_forest_validate(azg_forest* f, int verbose);
 

@@ -1,0 +1,32 @@
+/* azg_testaids.h -- TEST AND DEBUGGING AIDS exported by libazg_hip.so that have NO counterpart in the reference and are NOT part of the
+   drop-in surface (include/azg.h is that surface: every entry point there replaces a call of the reference).  Used by tests/, tools/ and
+   the plugin benches only; nothing under alpha-zero-general_amd/ needs them to play, search or train. */
+#ifndef AZG_TESTAIDS_H
+#define AZG_TESTAIDS_H
+#include "azg.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* debug: fill the LDS of every CU and the queue's scratch memory with `pattern` (a kernel that reads on-chip memory it never wrote then
+   depends on the pattern, not on what ran before) */
+int azg_debug_poison_onchip(uint32_t pattern, void* stream);
+
+/* debug / tests: launch n_workgroups one-wave workgroups on `stream`; out_dev[i] = XCC_ID | cu_id << 8 | se_id << 16 | sh_id << 24 of
+   the CU that ran workgroup i */
+int azg_debug_placement(int n_workgroups, uint32_t* out_dev, void* stream);
+
+/* debug / tests / plugin benches: the integer hash-net of SURVEY.md Appendix C.3 as a leaf evaluator on the device (the deterministic stand-in
+   for NeuralNet.predict, NeuralNet.py:32-43, that the MCTS parity tests run on both sides): boards int8[T][S], valid u8[T][A] ->
+   pi f32[T][A], v f32[T][P], bit-identical to tests/hashnet.py.  Not a product net. */
+int azg_eval_hashnet(const int8_t* boards, const uint8_t* valid, int T, int S, int A, int P, float* pi, float* v, void* stream);
+
+/* placement study: one row of four u64 per workgroup of the pipeline (the n_sel descent workgroups first): where it ran (XCC id | cu_id
+   << 8 | se_id << 16 | sh_id << 24), role (1 descent, 2 net), calls (descents / forwards) and the shader cycles spent in them since
+   the last reset.  Returns the number of rows written (<= max_wg). */
+int azg_forest_async_wginfo(azg_forest* f, unsigned long long* out_host, int max_wg, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

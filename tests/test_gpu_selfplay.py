@@ -655,12 +655,14 @@ def test_async_pipeline_in_a_process_with_many_streams(on_side_stream):
     e.close()
 
 
-@pytest.mark.parametrize('game_key', ['santorini11', 'splendor4', 'azul', 'santorini1'])
-def test_full_size_properties_other_configs(game_key):
+@pytest.mark.parametrize('game_key,sims,cap', [('santorini11', 800, 0), ('splendor4', 800, 0), ('azul', 800, 0), ('santorini1', 800, 0),
+                                               ('azul', 1600, 44000)])
+def test_full_size_properties_other_configs(game_key, sims, cap):
     """BASELINE.json configs 3 / 4 / 5 (and the north star's second target) at FULL size -- 4096 concurrent games, 800 simulations per
-    move, the pretrained net of the game on the engine's kernels, the engine exactly as bench.py builds it: size-independent invariants
-    after three plies -- no error flag, the structural validator passes on all 4096 trees, every root's visit counts add up
-    (MCTS.py:180-181), every tree keeps moving.  (Splendor 2p: test_full_size_properties.)"""
+    move (config 5: Azul at its 1600 simulations with the automatic root Dirichlet noise of azul/pretrained.pt, alpha = 10 / n_valid,
+    MCTS.py:188-192, in 232 of the 288 GB), the pretrained net of the game on the engine's kernels, the engine exactly as bench.py builds
+    it: size-independent invariants after three plies -- no error flag, the structural validator passes on all 4096 trees, every root's
+    visit counts add up (MCTS.py:180-181), every tree keeps moving.  (Splendor 2p: test_full_size_properties.)"""
     import importlib.util
     import os
     import torch
@@ -668,11 +670,13 @@ def test_full_size_properties_other_configs(game_key):
     spec = importlib.util.spec_from_file_location('azg_bench', os.path.join(root, 'bench.py'))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    T, sims = 4096, 800
-    a = bench.argparse.Namespace(net_dtype='fp32', net='hip', groups=1, sims=sims, prob_full=1.0, node_capacity=0, no_graph=False, level_budget=0,
+    T = 4096
+    a = bench.argparse.Namespace(net_dtype='fp32', net='hip', groups=1, sims=sims, prob_full=1.0, node_capacity=cap, no_graph=False, level_budget=0,
                                  work_budget=-1, advance_every=0, no_pin_xcd=False)
     eng, margs, label, weights, net_kind = bench.build_engine(a, game_key, T, 0, 'cuda:0')
-    assert net_kind == 'hip'
+    assert net_kind == 'hip' and int(margs['numMCTSSims']) == sims
+    if game_key == 'azul':
+        assert float(margs['dirichletAlpha']) < 0          # the automatic alpha: root noise is on
     eng.start()
     eng.run(3 * sims + 64)
     st = eng.stats()
