@@ -322,12 +322,34 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
         // of this wave drains (the tree's records, its leaf record), then the word consumed is recorded, the claim released, the ring entry
         // published ----
         uint32_t tk = 0u;
+        // ... and the workgroup's ready words are polled HERE as well, under the same drain: a wave that has just finished a tree is the one
+        // that needs a new one, and without this it found the LDS copy empty more often than not and paid a poll's round trip (1.5 us of a
+        // 25 us cycle) before it could go on
+        uint32_t pv0, pv1, ps0, ps1;
         {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
             if (need && l == 0) tk = atomicAdd(&A->ctl->leaf_tail, 1u);
+            const uint32_t* my_ts = A->ts_ready + (size_t)g * ASYNC_RS;
+            pv0 = l < n_g ? aload(my_ready + l) : 0u; pv1 = l + 64 < n_g ? aload(my_ready + 64 + l) : 0u;
+            ps0 = l < n_g ? aload(my_ts + l) : 0u; ps1 = l + 64 < n_g ? aload(my_ts + 64 + l) : 0u;
         }
         if (l == 0) __hip_atomic_store(&C->last[i], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         drain_vmem();
+        {
+            // publish the snapshot (as a scout would; several waves may do so at once: every value is checked against `last` when it is claimed)
+            wave_sync();
+            const unsigned long long r0 = __ballot(pv0 != 0u && pv0 < AZG_LDS_LD32(&C->last[l]));
+            const unsigned long long r1 = __ballot(pv1 != 0u && pv1 < AZG_LDS_LD32(&C->last[64 + l]));
+            __hip_atomic_store(&C->rw[l], pv0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&C->rw[64 + l], pv1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&C->rts[l], ps0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&C->rts[64 + l], ps1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            wave_sync();
+            if (l == 0) {
+                __hip_atomic_store(&C->seen[0], r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&C->seen[1], r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         if (l == 0) __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
