@@ -95,6 +95,8 @@ def lib():
     L.azg_forest_rounds_profile.argtypes = [vp, C.POINTER(C.c_double), i]
     if hasattr(L, 'azg_forest_async_rounds_v80_h2'):        # (absent from older builds loaded through AZG_LIB for A/B runs)
         L.azg_forest_async_rounds_v80_h2.argtypes = [vp, vp, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp]
+        if hasattr(L, 'azg_forest_async_rounds_mb1d_h2'):
+            L.azg_forest_async_rounds_mb1d_h2.argtypes = [vp, i, vp, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp]
         if hasattr(L, 'azg_forest_async_rounds_conv5_h2'):
             L.azg_forest_async_rounds_conv5_h2.argtypes = [vp, vp, vp, vp, vp, i, vp, C.c_float, i, i, i, i, i, vp]
         L.azg_forest_async_profile.argtypes = [vp, C.POINTER(C.c_double), i]

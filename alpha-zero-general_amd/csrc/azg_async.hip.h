@@ -59,6 +59,7 @@ struct AsyncArgs {
     ForestDev F;
     H2Weights W;                               // net V80 (Splendor 2 players): nn_v80_h2.hip.h
     Conv5NetW C5; float c5_descale; int c5_pad; // net V89 (Santorini no-gods): nn_conv5x5.hip.h
+    Mb1dNetW MB;                               // the MobileNet-1d family (Splendor 3 / 4 players, Azul): nn_mb1d.hip.h
     int8_t* aleaf; uint8_t* leaf_valid; uint8_t* needs_eval; float* pi; float* v;
     AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts_ready;
     unsigned long long* prof;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
 // The net side of the pipeline is the same for every net: NET names the forward (a 12-wave workgroup body that takes its samples from a batch
 // descriptor in LDS), its batch size BS (samples per forward = tickets per range) and its LDS bytes; behind the forward's LDS map sit 512
 // bytes: the batch descriptor (tree of sample s [16 ints], calls left [16], count, ...), the profile sums and the samples' valid bit masks.
-constexpr int ASYNC_DESC_BYTES = 512;
+constexpr int ASYNC_DESC_BYTES = 640;
 struct NetV80 {                                // Splendor 2 players: k_v80_net_h2<12>'s body, 16 leaves per forward
     using G = SplendorDev<2>;
     static constexpr int BS = 16, LDS = H2_LDS;
@@ -410,7 +411,21 @@ struct NetC5 {                                 // Santorini no-gods: k_conv5_net
         conv5_net_body<5, 162, 2, 2, true>((float*)lds, &A->C5, A->aleaf, (const uint8_t*)A->aleaf, A->F.T, A->pi, A->v, A->c5_descale, 0, sidx, smask);
     }
 };
-static_assert(NetV80::LDS + ASYNC_DESC_BYTES <= 160 * 1024 && NetC5::LDS + ASYNC_DESC_BYTES <= 160 * 1024, "net LDS + batch descriptor");
+template <class CF, class GAME>
+struct NetMb1d {                               // Splendor 3 / 4 players (8 leaves per forward), Azul (16): k_mb1d_net<CF, true>'s body
+    using G = GAME;
+    static constexpr int BS = CF::NS, LDS = (CF::LDS_FLOATS * 4 + 255) / 256 * 256;
+    static __device__ __forceinline__ void run(uint8_t* lds, AsyncArgsC A, const int* sidx, unsigned long long* smask) {
+        mb1d_net_body<CF, true, true, AsyncLeaf<G>::STRIDE, AsyncLeaf<G>::MASK_OFF>((float*)lds, &A->MB, A->aleaf, (const uint8_t*)A->aleaf, A->F.T, A->pi, A->v, 0,
+                                                                                    sidx, smask);
+    }
+};
+using NetSpl3 = NetMb1d<CfgSplendor3, SplendorDev<3>>;
+using NetSpl4 = NetMb1d<CfgSplendor4, SplendorDev<4>>;
+using NetAzul = NetMb1d<CfgAzul, AzulDev>;
+static_assert(NetV80::LDS + ASYNC_DESC_BYTES <= 160 * 1024 && NetC5::LDS + ASYNC_DESC_BYTES <= 160 * 1024 && NetSpl4::LDS + ASYNC_DESC_BYTES <= 160 * 1024 &&
+              NetSpl3::LDS + ASYNC_DESC_BYTES <= 160 * 1024 && NetAzul::LDS + ASYNC_DESC_BYTES <= 160 * 1024, "net LDS + batch descriptor");
+static_assert(16 * 3 * 8 + H2_IND_MASK * 4 <= ASYNC_DESC_BYTES, "sixteen samples' three mask words behind the descriptor");
 
 template <class NET>
 __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
@@ -550,9 +565,15 @@ static int async_launch_select(const azg::AsyncArgs* devbuf, int n_sel, hipStrea
     HIPCHK(hipGetLastError());
     return 0;
 }
-// net_kind: 0 = Splendor 2 players (V80), 1 = Santorini no-gods (V89)
+// net_kind: 0 = Splendor 2 players (V80), 1 = Santorini no-gods (V89), 2 / 3 = Splendor 3 / 4 players, 4 = Azul (MobileNet-1d)
 int azg_async_launch_select(int net_kind, const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s) {
-    return net_kind == 0 ? async_launch_select<azg::SplendorDev<2>>(devbuf, n_sel, s) : async_launch_select<azg::SantoriniDev<1>>(devbuf, n_sel, s);
+    switch (net_kind) {
+        case 0: return async_launch_select<azg::SplendorDev<2>>(devbuf, n_sel, s);
+        case 1: return async_launch_select<azg::SantoriniDev<1>>(devbuf, n_sel, s);
+        case 2: return async_launch_select<azg::SplendorDev<3>>(devbuf, n_sel, s);
+        case 3: return async_launch_select<azg::SplendorDev<4>>(devbuf, n_sel, s);
+        default: return async_launch_select<azg::AzulDev>(devbuf, n_sel, s);
+    }
 }
 #endif  // AZG_ASYNC_PART_SELECT
 
@@ -623,9 +644,13 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
     const ForestDev* dev = azg_forest_dev_internal(f, &game, &variant, &alpha);
     if (net_kind == 0 && (game != AZG_SPLENDOR || variant != 2)) return fail(me + ": Splendor 2 players only (the V80 geometry of nn_v80_h2.hip.h)");
     if (net_kind == 1 && (game != AZG_SANTORINI || variant != 1)) return fail(me + ": Santorini without gods only (the V89 geometry of nn_conv5x5.hip.h)");
+    if ((net_kind == 2 || net_kind == 3) && (game != AZG_SPLENDOR || variant != net_kind + 1)) return fail(me + ": the geometry does not match the forest's game");
+    if (net_kind == 4 && game != AZG_AZUL) return fail(me + ": the geometry does not match the forest's game");
     static_assert(AsyncLeaf<SplendorDev<2>>::STRIDE == H2_AL_STRIDE && AsyncLeaf<SplendorDev<2>>::MASK_OFF == H2_AL_MASK, "leaf record layout shared with the net kernel");
     static_assert(AsyncLeaf<SantoriniDev<1>>::STRIDE == C5_AL_STRIDE && AsyncLeaf<SantoriniDev<1>>::MASK_OFF == C5_AL_MASK, "leaf record layout shared with the net kernel");
-    const int leaf_stride = net_kind == 0 ? H2_AL_STRIDE : C5_AL_STRIDE, bs = net_kind == 0 ? NetV80::BS : NetC5::BS;
+    const int leaf_strides[5] = {H2_AL_STRIDE, C5_AL_STRIDE, AsyncLeaf<SplendorDev<3>>::STRIDE, AsyncLeaf<SplendorDev<4>>::STRIDE, AsyncLeaf<AzulDev>::STRIDE};
+    const int batch[5] = {NetV80::BS, NetC5::BS, NetSpl3::BS, NetSpl4::BS, NetAzul::BS};
+    const int leaf_stride = leaf_strides[net_kind], bs = batch[net_kind];
     static int n_cu = 0;
     // The two kernels MUST run side by side, so their streams must not share a hardware queue (HIP multiplexes streams onto a few queues
     // -- 4 per priority level by default -- and kernels of one queue run one after the other: the net kernel would wait for leaves that
@@ -647,13 +672,17 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
         n_cu = prop.multiProcessorCount;
         HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetV80>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetC5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetSpl3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetSpl4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetAzul>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int T = dev->T;
     if (n_net <= 0 || n_sel <= 0) {
         // default split of the CUs.  V80: half and half (measured at 4096 x 800, whole games and the driver's window: 128 + 128 of 256
         // beats 120 / 124 / 132 / 136 for the net); V89: a forward of 8 leaves costs ~80 us of a CU, a descent ~33 us of a sixteenth of one:
         // 13 / 16 for the net (measured: 208 + 48 -> 28.8 k env-steps/s, 216 + 40 24.5 k, 204 + 52 28.7 k, 200 + 56 28.3 k; two kernels 26.5 k)
-        n_net = net_kind == 0 ? n_cu / 2 : n_cu * 13 / 16;
+        // Splendor 3 / 4 players (forward ~120 us per 8 leaves): as V89; Azul (descent-heavy: lane-0 env step, forward 30 us per 16): 3 / 8
+        n_net = net_kind == 0 ? n_cu / 2 : net_kind == 4 ? n_cu * 3 / 8 : n_cu * 13 / 16;
         n_sel = n_cu - n_net;
     }
     if (n_sel > T) n_sel = T;
@@ -695,7 +724,18 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
     // inside a launch -- but a launch ends only when every tree has had its calls, and a tree whose simulations all end on terminal nodes
     // would otherwise run its whole search inside ONE call: measured 4.1 ms launches of 48 rounds where the mean tree needs 3.4 ms)
     if (net_kind == 0) want.W = h2_weights(w, descale);
-    else {
+    else if (net_kind >= 2) {                         // the 43-pointer table + 16 descale factors of azg_nn_mb1d_forward_h2
+        const float* const* wf = (const float* const*)w;
+        Mb1dNetW& N = want.MB;
+        for (int i = 0; i < 16; i++) N.ds[i] = descale[i];
+        N.W0 = wf[0]; N.b0 = wf[1];
+        for (int b = 0; b < 3; b++) {
+            const float* const* q = wf + 2 + 11 * b;
+            N.blk[b] = Mb1dBlockW{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10]};
+        }
+        const float* const* h = wf + 35;
+        N.Wpi1 = h[0]; N.bpi1 = h[1]; N.Wpi2 = h[2]; N.bpi2 = h[3]; N.Wv1 = h[4]; N.bv1 = h[5]; N.Wv2 = h[6]; N.bv2 = h[7];
+    } else {
         const float* const* wf = (const float* const*)w;
         want.C5 = Conv5NetW{wf[0], wf[1], wf[2], wf[3], wf[4], wf[5], wf[6], wf[7], wf[8], wf[9], wf[10], wf[11], wf[12], wf[13]};
         want.c5_descale = descale[0];
@@ -721,8 +761,13 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
     HIPCHK(hipEventRecord(sl->fork, s));
     HIPCHK(hipStreamWaitEvent(net_stream, sl->fork, 0));
     HIPCHK(hipStreamWaitEvent(sel_stream, sl->fork, 0));
-    if (net_kind == 0) k_async_net<NetV80><<<dim3(n_net), dim3(768), NetV80::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf);
-    else k_async_net<NetC5><<<dim3(n_net), dim3(768), NetC5::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf);
+    switch (net_kind) {
+        case 0: k_async_net<NetV80><<<dim3(n_net), dim3(768), NetV80::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf); break;
+        case 1: k_async_net<NetC5><<<dim3(n_net), dim3(768), NetC5::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf); break;
+        case 2: k_async_net<NetSpl3><<<dim3(n_net), dim3(768), NetSpl3::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf); break;
+        case 3: k_async_net<NetSpl4><<<dim3(n_net), dim3(768), NetSpl4::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf); break;
+        default: k_async_net<NetAzul><<<dim3(n_net), dim3(768), NetAzul::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf); break;
+    }
     HIPCHK(hipGetLastError());
     if (azg_async_launch_select(net_kind, sl->devbuf, n_sel, sel_stream)) return -1;
     HIPCHK(hipEventRecord(sl->join_net, net_stream));
@@ -737,6 +782,15 @@ extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid
                                               const void* const* w, const float* descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
                                               int shared_budget, void* stream) {
     return async_rounds_impl("azg_forest_async_rounds_v80_h2", 0, f, leaf_valid, needs_eval, pi, v, noise_stride, w, descale, rounds, n_net, n_sel,
+                             batch_wait_ticks, shared_budget, stream);
+}
+// include/azg.h: the pipeline for Splendor 3 / 4 players and Azul with their MobileNet-1d nets (geometry = AZG_NET_* of azg_nn_mb1d_forward_h2)
+extern "C" int azg_forest_async_rounds_mb1d_h2(azg_forest* f, int geometry, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v, int noise_stride,
+                                               const void* const* w, const float* descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
+                                               int shared_budget, void* stream) {
+    const int kind = geometry == AZG_NET_SPLENDOR3 ? 2 : geometry == AZG_NET_SPLENDOR4 ? 3 : geometry == AZG_NET_AZUL ? 4 : -1;
+    if (kind < 0) return fail("azg_forest_async_rounds_mb1d_h2: geometry must be AZG_NET_SPLENDOR3, AZG_NET_SPLENDOR4 or AZG_NET_AZUL");
+    return async_rounds_impl("azg_forest_async_rounds_mb1d_h2", kind, f, leaf_valid, needs_eval, pi, v, noise_stride, w, descale, rounds, n_net, n_sel,
                              batch_wait_ticks, shared_budget, stream);
 }
 // include/azg.h: the pipeline for a Santorini no-gods forest with the V89 net (14 pointers of azg_nn_conv5_forward_h2, its descale)

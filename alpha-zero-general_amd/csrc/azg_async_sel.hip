@@ -21,7 +21,9 @@
 #include "nn_kernels.hip.h"
 #include "nn_v80_h2.hip.h"
 #include "nn_conv5x5.hip.h"
+#include "nn_mb1d.hip.h"
 #include "game_santorini.hip.h"
+#include "game_azul.hip.h"
 
 using namespace azg;
 

@@ -260,11 +260,7 @@ extern "C" int azg_nn_debug_phase_times_h2(long long* out /* [4][16] */) {
 #endif
 
 // ---- whole MobileNet-1d forward, any supported geometry, one launch (nn_mb1d.hip.h) ----
-//                        L   C  NS    A  P   E0   E1   E2  Q0  Q1  Q2 CO1 A0 A12 PMAX
-typedef Mb1dCfg<7, 56, 8, 81, 2, 168, 168, 168, 40, 40, 40, 56, 1, 2, 1> CfgSplendor2;
-typedef Mb1dCfg<7, 71, 8, 81, 3, 213, 213, 213, 56, 56, 56, 71, 1, 2, 1> CfgSplendor3;
-typedef Mb1dCfg<7, 88, 8, 81, 4, 264, 264, 264, 64, 64, 64, 88, 1, 2, 1> CfgSplendor4;
-typedef Mb1dCfg<6, 23, 16, 180, 2, 115, 115, 46, 32, 32, 16, 46, 1, 2, 0> CfgAzul;
+// (the geometries CfgSplendor2 / 3 / 4, CfgAzul: nn_mb1d.hip.h)
 
 template <class CF, bool H2>
 static int launch_mb1d(const Mb1dNetW& N, const int8_t* boards, const uint8_t* valid, int B, float* pi, float* v, hipStream_t s) {

@@ -270,11 +270,31 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
     __syncthreads();
 }
 
-template <class CF, bool H2 = false>
-__global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __restrict__ boards,
-                                                  const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
-                                                  float* __restrict__ v_out) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// The forward of one workgroup (samples NS * wg ..) as a device function: the body of k_mb1d_net and -- IND -- of the asynchronous pipeline's
+// net kernel (azg_async.hip.h): sample s of the workgroup is then tree sidx[s] (LDS; < 0 = no sample), `boards` / `valid` are both the
+// pipeline's leaf-record array (kernels.hip.h AsyncLeaf<G>: int8 state [SP] + valid bit mask u64[AW], stride AL_STRIDE, mask at AL_MASK),
+// read past the L1; the samples' masks are fetched with the boards into `smask` (LDS u64 [NS][AW]); pi / v rows are written WRITE-THROUGH
+// at the tree's index.  The weight table is read through the CONSTANT address space wherever it is used (the kernel's own argument
+// segment / the pipeline's argument block).
+typedef const Mb1dNetW __attribute__((address_space(4))) * Mb1dNetWC;
+template <class T>
+__device__ __forceinline__ T mb_ldc(const T __attribute__((address_space(4))) * p) {          // word-wise copy out of the constant address space
+    static_assert(sizeof(T) % 4 == 0, "word-sized struct");
+    const uint32_t __attribute__((address_space(4))) * w = (const uint32_t __attribute__((address_space(4))) *)p;
+    uint32_t a[sizeof(T) / 4];
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 4); k++) a[k] = w[k];
+    T out;
+    __builtin_memcpy(&out, a, sizeof(T));
+    return out;
+}
+struct Mb1dDs4 { float v[4]; };
+#define N (*Np)
+template <class CF, bool H2, bool IND, int AL_STRIDE = 0, int AL_MASK = 0>
+__device__ __forceinline__ void mb1d_net_body(float* smem, const Mb1dNetWC Np, const int8_t* __restrict__ boards,
+                                              const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
+                                              float* __restrict__ v_out, const int wg, const int* sidx = nullptr,
+                                              unsigned long long* smask = nullptr) {
     constexpr int L = CF::L, C = CF::C, NS = CF::NS, NW = CF::NW, RT = CF::RT, XS = CF::XS, OS = CF::OS, HS = CF::HS, A = CF::A,
                   P = CF::P, AS = CF::AS, CP = CF::CP;
     if (H2) h2_fp16_saturate_mode();        // out-of-range activations saturate instead of becoming inf (inf * zero padding = NaN)
@@ -285,10 +305,22 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
     float* SC = PL + CF::PL_SZ;
     float* SH = SC + CF::SC_SZ;
     float* WD = SH + CF::SH_SZ;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
-    const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
+    int tid_ = threadIdx.x;
+    if (IND) asm volatile("" : "+v"(tid_));            // (opaque inside the pipeline's persistent loop)
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const int b0 = wg * NS, nb = IND ? NS : min(NS, B - b0);
+    constexpr int AWI = (A + 63) / 64;
+    unsigned long long ind_mask = 0ull;
+    if constexpr (IND) {
+        if (tid < NS * AWI) {
+            const int b = sidx[tid / AWI];
+            if (b >= 0) ind_mask = __hip_atomic_load((const unsigned long long*)(valid + (size_t)b * AL_STRIDE + AL_MASK) + tid % AWI, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     for (int i = tid; i < CF::LDS_FLOATS / 4; i += NW * 64) ((float4*)smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (IND) { if (tid < NS * AWI) smask[tid] = ind_mask; }
     __syncthreads();
     // ---- board tile int8 [s][c][l] -> X0[s*L + l][c] f32 (in H), first layer (+BN) -> XA ----
     float* X0 = H;
@@ -296,6 +328,11 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
         const int8_t* src = boards + (size_t)b0 * (C * L);
         for (int i = tid; i < nb * C * L; i += NW * 64) {
             const int s = i / (C * L), rem = i - s * (C * L), c = rem / L, l = rem - c * L;
+            if constexpr (IND) {
+                const int b = sidx[s];
+                X0[(s * L + l) * XS + c] =
+                    b >= 0 ? (float)(int8_t)__hip_atomic_load((const uint8_t*)boards + (size_t)b * AL_STRIDE + rem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            } else
             X0[(s * L + l) * XS + c] = (float)src[i];
         }
     }
@@ -308,10 +345,18 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
             *(float4*)(XA + (rt * 16 + r16) * XS + ct * 16 + 4 * g) = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
         });
     __syncthreads();
-    mb_block<CF, 0, CP, XS, H2>(N.blk[0], XA, X2, H, PL, SC, SH, WD, true, N.ds + 1);
+    {
+        const Mb1dBlockW Wb = mb_ldc(&Np->blk[0]);
+        const Mb1dDs4 d4 = mb_ldc((const Mb1dDs4 __attribute__((address_space(4))) *)(Np->ds + 1));
+        mb_block<CF, 0, CP, XS, H2>(Wb, XA, X2, H, PL, SC, SH, WD, true, d4.v);
+    }
 
     // ================= policy head =================
-    mb_block<CF, 1, CP, OS, H2>(N.blk[1], X2, XA, H, PL, SC, SH, WD, CF::CO[1] == C, N.ds + 5);
+    {
+        const Mb1dBlockW Wb = mb_ldc(&Np->blk[1]);
+        const Mb1dDs4 d4 = mb_ldc((const Mb1dDs4 __attribute__((address_space(4))) *)(Np->ds + 5));
+        mb_block<CF, 1, CP, OS, H2>(Wb, X2, XA, H, PL, SC, SH, WD, CF::CO[1] == C, d4.v);
+    }
     {
         constexpr int KCH1 = (L * OS + 15) / 16, NT1 = CF::AP / 16;
         float* RED = H;
@@ -334,7 +379,8 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
         __syncthreads();
         // masked softmax == exp(log_softmax(where(valid, logits, -1e8))) (GenericNNetWrapper.py:105-107), one wave per sample
         for (int s = wave; s < nb; s += NW) {
-            const int b = b0 + s;
+            const int b = IND ? sidx[s] : b0 + s;
+            if (IND && b < 0) continue;
             float x[(A + 63) / 64];
             float mx = -INFINITY;
 #pragma unroll
@@ -344,7 +390,8 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
                 if (a < A) {
                     float lg = N.bpi2[a];
                     for (int q = 0; q < ks2; q++) lg += RED[(q * 16 + s) * AS + a];
-                    x[k] = valid[(size_t)b * A + a] ? lg : -1e8f;
+                    if constexpr (IND) x[k] = ((smask[s * AWI + k] >> lane) & 1ull) ? lg : -1e8f;
+                    else x[k] = valid[(size_t)b * A + a] ? lg : -1e8f;
                 }
                 mx = fmaxf(mx, x[k]);
             }
@@ -355,13 +402,20 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
             sum = nn_wave_sum(sum);
 #pragma unroll
             for (int k = 0; k < (A + 63) / 64; k++)
-                if (lane + 64 * k < A) pi_out[(size_t)b * A + lane + 64 * k] = x[k] / sum;
+                if (lane + 64 * k < A) {
+                    if constexpr (IND) __hip_atomic_store((uint32_t*)pi_out + (size_t)b * A + lane + 64 * k, __float_as_uint(x[k] / sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else pi_out[(size_t)b * A + lane + 64 * k] = x[k] / sum;
+                }
         }
         __syncthreads();
     }
 
     // ================= value head =================
-    mb_block<CF, 2, CP, OS, H2>(N.blk[2], X2, XA, H, PL, SC, SH, WD, true, N.ds + 9);
+    {
+        const Mb1dBlockW Wb = mb_ldc(&Np->blk[2]);
+        const Mb1dDs4 d4 = mb_ldc((const Mb1dDs4 __attribute__((address_space(4))) *)(Np->ds + 9));
+        mb_block<CF, 2, CP, OS, H2>(Wb, X2, XA, H, PL, SC, SH, WD, true, d4.v);
+    }
     {
         constexpr int KCH1 = (L * OS + 15) / 16;
         float* RED = H;                      // [NW][16][20]
@@ -370,17 +424,39 @@ __global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N, const int8_t* __re
         __syncthreads();
         if (tid < nb * P) {
             const int s = tid / P, p = tid - s * P;
-            float a = N.bv2[p];
-            for (int j = 0; j < P; j++) {
-                float h = N.bv1[j];
-                for (int w = 0; w < ks; w++) h += RED[(w * 16 + s) * 20 + j];
-                a += fmaxf(h, 0.f) * N.Wv2[j * P + p];
+            const int b = IND ? sidx[s] : b0 + s;
+            if (!IND || b >= 0) {
+                float a = N.bv2[p];
+                for (int j = 0; j < P; j++) {
+                    float h = N.bv1[j];
+                    for (int w = 0; w < ks; w++) h += RED[(w * 16 + s) * 20 + j];
+                    a += fmaxf(h, 0.f) * N.Wv2[j * P + p];
+                }
+                if constexpr (IND) __hip_atomic_store((uint32_t*)v_out + (size_t)b * P + p, __float_as_uint(tanhf(a)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else v_out[(size_t)b * P + p] = tanhf(a);
             }
-            v_out[(size_t)(b0 + s) * P + p] = tanhf(a);
         }
     }
 }
+#undef N
+
+template <class CF, bool H2 = false>
+__global__ __launch_bounds__(768) void k_mb1d_net(Mb1dNetW N /* first argument: offset 0 of the kernel argument segment, read through it */,
+                                                  const int8_t* __restrict__ boards,
+                                                  const uint8_t* __restrict__ valid, int B, float* __restrict__ pi_out,
+                                                  float* __restrict__ v_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    (void)N;
+    mb1d_net_body<CF, H2, false>(smem, (Mb1dNetWC)__builtin_amdgcn_kernarg_segment_ptr(), boards, valid, B, pi_out, v_out, (int)blockIdx.x);
+}
 
 #pragma clang fp contract(off)
+
+// the supported geometries (azg.h AZG_NET_*)
+//                        L   C  NS    A  P   E0   E1   E2  Q0  Q1  Q2 CO1 A0 A12 PMAX
+typedef Mb1dCfg<7, 56, 8, 81, 2, 168, 168, 168, 40, 40, 40, 56, 1, 2, 1> CfgSplendor2;
+typedef Mb1dCfg<7, 71, 8, 81, 3, 213, 213, 213, 56, 56, 56, 71, 1, 2, 1> CfgSplendor3;
+typedef Mb1dCfg<7, 88, 8, 81, 4, 264, 264, 264, 64, 64, 64, 88, 1, 2, 1> CfgSplendor4;
+typedef Mb1dCfg<6, 23, 16, 180, 2, 115, 115, 46, 32, 32, 16, 46, 1, 2, 0> CfgAzul;
 
 }  // namespace azg

@@ -129,11 +129,19 @@ class SelfPlayEngine:
                   hasattr(_lib.lib(), 'azg_forest_async_rounds_conv5_h2') and
                   all(type(n).__name__ == 'SantoriniV89Hip' and getattr(n, 'h2', False) and torch.is_tensor(getattr(n, 'pi', None)) and
                       tuple(n.pi.shape) == (Tg, A_game) for n in nets))
+        # ... and for Splendor 3 / 4 players and Azul + their MobileNet-1d nets on the f16 x 2 one-launch kernel (MobileNet1dHip(h2=True, fused))
+        gid, var = getattr(game, 'GAME_ID', None), int(getattr(game, 'variant', 0) or 0)
+        can_mb = (self.fused and hasattr(_lib.lib(), 'azg_forest_async_rounds_mb1d_h2') and
+                  ((gid == _lib.SPLENDOR and var in (3, 4)) or gid == _lib.AZUL) and
+                  all(type(n).__name__ == 'MobileNet1dHip' and getattr(n, 'h2', False) and getattr(n, 'fused', False) and
+                      getattr(n, 'geometry', None) == ({3: 1, 4: 2}.get(var) if gid == _lib.SPLENDOR else 3) and
+                      torch.is_tensor(getattr(n, 'pi', None)) and tuple(n.pi.shape) == (Tg, A_game) for n in nets))
+        any_pipe = can or can_c5 or can_mb
         if async_pipe is None:
-            async_pipe = (can or can_c5) and groups == 1 and not percu and os.environ.get('AZG_ASYNC', '1') == '1'
-        elif async_pipe and not ((can or can_c5) and groups == 1):
-            raise ValueError('async_pipe=True needs Splendor 2 players + SplendorV80Hip(h2=True) or Santorini no-gods + SantoriniV89Hip(h2=True) '
-                             'evaluators with max_batch == n_games, groups == 1')
+            async_pipe = any_pipe and groups == 1 and not percu and os.environ.get('AZG_ASYNC', '1') == '1'
+        elif async_pipe and not (any_pipe and groups == 1):
+            raise ValueError('async_pipe=True needs Splendor 2 players + SplendorV80Hip(h2=True), Santorini no-gods + SantoriniV89Hip(h2=True) or Splendor 3 / 4 '
+                             'players / Azul + MobileNet1dHip(h2=True) evaluators with max_batch == n_games, groups == 1')
         self.async_pipe = bool(async_pipe)
         self.adaptive = False
         if work_budget is None:

@@ -196,6 +196,11 @@ int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid_dev, uint8
 int azg_forest_async_rounds_conv5_h2(azg_forest* f, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev,
                                      int noise_stride, const float* const* w, float descale, int rounds, int n_net, int n_sel,
                                      int batch_wait_ticks, int shared_budget, void* stream);
+/* ... and for Splendor 3 / 4 players and Azul with their MobileNet-1d nets: geometry, w (43 device pointers) and descale (16 host floats) as
+   for azg_nn_mb1d_forward_h2; 8 (Splendor) / 16 (Azul) leaves per forward. */
+int azg_forest_async_rounds_mb1d_h2(azg_forest* f, int geometry, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev,
+                                    int noise_stride, const void* const* w, const float* descale_host, int rounds, int n_net, int n_sel,
+                                    int batch_wait_ticks, int shared_budget, void* stream);
 /* measurement: counters of the pipeline since the last reset (ticks = 10 ns of the 100 MHz wall clock read inside the kernels):
    out[0] descents (select_tree calls), [1] ticks inside them, [2] ticks descent waves spent looking for a ready tree, [3] net batches,
    [4] leaves in them, [5] ticks inside the forward, [6] ticks net workgroups waited for leaves, [7] sum over leaves of (claimed by a net

@@ -618,6 +618,68 @@ def test_async_pipeline_santorini_equals_two_kernel_rounds(T, sims, K, budget, c
         assert torch.equal(r0[k], r1[k]), k
 
 
+@pytest.mark.parametrize('variant,T,sims,K,budget,cfg', [('splendor4', 40, 24, 8, 0, dict(n_net=4, n_sel=3)), ('splendor3', 64, 32, 16, 10, {}),
+                                                         ('azul', 48, 24, 8, 0, dict(n_net=2, n_sel=7)), ('azul', 96, 40, 40, 20, {})])
+def test_async_pipeline_mobilenet1d_equals_two_kernel_rounds(variant, T, sims, K, budget, cfg):
+    """The asynchronous tree pipeline for the MobileNet-1d games -- Splendor 3 / 4 players (8 leaves per forward) and Azul (16; root noise with
+    the automatic alpha) -- (azg_forest_async_rounds_mb1d_h2) against the two-kernel rounds (azg_forest_select_fused + azg_selfplay_advance +
+    azg_nn_mb1d_forward_h2): the same games move for move, every example record, statistics counter and root statistic EQUAL."""
+    import os
+    import torch
+    from azg_amd import games, nnet
+    from azg_amd.selfplay import SelfPlayEngine
+    root = os.path.join(os.path.dirname(__file__), 'golden')
+    if variant == 'azul':
+        g = games.AzulGame()
+        mk = lambda: nnet.MobileNet1dHip(nnet.AzulV84.from_npz(os.path.join(root, 'weights_azul_v84.npz'), device='cuda:0'), max_batch=T)  # noqa: E731
+        alpha = -1
+    else:
+        npl = int(variant[-1])
+        g = games.SplendorGame(npl)
+        wfile = 'weights_splendor4_v80.npz' if npl == 4 else None
+        if wfile is None:                                # (no 3-player checkpoint in the fixtures: random weights of the 3-player geometry)
+            base3 = nnet.SplendorV80.random_init(num_players=3, seed=5, device='cuda:0')
+            mk = lambda: nnet.MobileNet1dHip(base3, max_batch=T)  # noqa: E731
+        else:
+            mk = lambda: nnet.MobileNet1dHip(nnet.SplendorV80.from_npz(os.path.join(root, wfile), num_players=npl, device='cuda:0'), max_batch=T)  # noqa: E731
+        alpha = 0.3
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=alpha, temperature=[1.25, 0.8, 1.0],
+                tempThreshold=6, **MCTS_ARGS[variant])
+    out = []
+    for pipe in (False, True):
+        e = SelfPlayEngine(g, mk(), args, T, node_capacity=4096, max_examples=T * 400, rng_seed=13, use_graph=False, advance_every=1,
+                           work_budget=budget, async_pipe=pipe, async_cfg=dict(cfg, shared_budget=False))
+        assert e.async_pipe == pipe
+        e.start()
+        n_rounds = 50 * (sims + 2)
+        if pipe:
+            for _ in range(n_rounds // K):
+                e.run(K)
+            e.run(n_rounds % K)
+        else:
+            for _ in range(n_rounds):
+                e.groups[0].round(e.fused, advance=True)
+        torch.cuda.synchronize()
+        st = e.stats()
+        assert st['errors'] == 0 and st['plies'] > 10 * T, (st['errors'], e.forest.async_profile()['ctl'] if pipe else None)
+        ex = [x.cpu() for x in e.drain_examples()]
+        m = ex[5].to(torch.int64)
+        order = torch.argsort((m[:, 0] * 100000 + m[:, 1]) * 1000 + m[:, 2])
+        ex = [x[order] for x in ex]
+        rs = {k: v.cpu() for k, v in e.forest.root_stats().items()}
+        out.append((st, ex, rs))
+        assert e.forest.validate(verbose=False) == 0
+        e.close()
+    (s0, e0, r0), (s1, e1, r1) = out
+    for k in ('plies', 'games', 'sims', 'levels', 'expansions', 'terminal_hits', 'examples', 'sum_valid_visited', 'sum_depth_at_expand'):
+        assert s0[k] == s1[k], (k, s0[k], s1[k])
+    assert len(e0[0]) == len(e1[0])
+    for a, b in zip(e0, e1):
+        assert torch.equal(a, b)
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+
+
 @pytest.mark.parametrize('on_side_stream', [False, True])
 def test_async_pipeline_in_a_process_with_many_streams(on_side_stream):
     """The pipeline's two kernels must run side by side whatever streams the process has: HIP multiplexes streams onto a few hardware
