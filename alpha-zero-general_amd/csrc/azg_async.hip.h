@@ -38,6 +38,10 @@
 namespace azg {
 
 constexpr uint32_t ERR_ASYNC_TIMEOUT = 128;
+#ifndef AZG_ASYNC_SEL_WAVES
+#define AZG_ASYNC_SEL_WAVES 16                /* waves of a descent workgroup: 16 (<= 128 VGPRs each) fills a CU; 12 (<= 168 VGPRs) measured in round 5 */
+#endif
+constexpr int ASYNC_SEL_WAVES = AZG_ASYNC_SEL_WAVES;
 constexpr int ASYNC_RS = 128;                 // ready words per select workgroup (trees per workgroup <= 128: two ballots)
 constexpr int ASYNC_NPROF = 96;
 
@@ -144,10 +148,10 @@ __device__ __noinline__ bool async_between_calls(const AsyncArgs* args, int t, u
 }
 
 template <class G>
-__global__ __launch_bounds__(1024) void k_async_select(const AsyncArgs* args) {
+__global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const AsyncArgs* args) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using RL = RoundLds<G>;
-    AsyncSelLds* const C = (AsyncSelLds*)(lds + 16 * RL::STRIDE);
+    AsyncSelLds* const C = (AsyncSelLds*)(lds + ASYNC_SEL_WAVES * RL::STRIDE);
     const int g = (int)blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t t_begin = wall32();
@@ -561,7 +565,7 @@ static int async_launch_select(const azg::AsyncArgs* devbuf, int n_sel, hipStrea
         HIPCHK(hipFuncSetAttribute((const void*)azg::k_async_select<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    azg::k_async_select<G><<<dim3(n_sel), dim3(1024), 16 * azg::RoundLds<G>::STRIDE + (int)sizeof(azg::AsyncSelLds), s>>>(devbuf);
+    azg::k_async_select<G><<<dim3(n_sel), dim3(azg::ASYNC_SEL_WAVES * 64), azg::ASYNC_SEL_WAVES * azg::RoundLds<G>::STRIDE + (int)sizeof(azg::AsyncSelLds), s>>>(devbuf);
     HIPCHK(hipGetLastError());
     return 0;
 }
