@@ -131,7 +131,9 @@ extern "C" int azg_nn_dw_pool_l(float* H, int ldh, const float* Wd, const float*
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (L == 7) k_dw_pool<7><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(H, ldh, Wd, sd, bd, pooled, B, E, act, pool_max);
     else if (L == 6) k_dw_pool<6><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(H, ldh, Wd, sd, bd, pooled, B, E, act, pool_max);
-    else return fail("azg_nn_dw_pool: token count must be 6 or 7");
+    else if (L == 2) k_dw_pool<2><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(H, ldh, Wd, sd, bd, pooled, B, E, act, pool_max);
+    else if (L == 15) k_dw_pool<15><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(H, ldh, Wd, sd, bd, pooled, B, E, act, pool_max);
+    else return fail("azg_nn_dw_pool: token count must be 2, 6, 7 or 15 (Minivilles, Azul, Splendor, The Little Prince)");
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -260,7 +262,7 @@ extern "C" int azg_nn_debug_phase_times_h2(long long* out /* [4][16] */) {
 #endif
 
 // ---- whole MobileNet-1d forward, any supported geometry, one launch (nn_mb1d.hip.h) ----
-// (the geometries CfgSplendor2 / 3 / 4, CfgAzul: nn_mb1d.hip.h)
+// (the geometries CfgSplendor2 / 3 / 4, CfgAzul, CfgMinivilles2, CfgTLP3: nn_mb1d.hip.h)
 
 template <class CF, bool H2>
 static int launch_mb1d(const Mb1dNetW& N, const int8_t* boards, const uint8_t* valid, int B, float* pi, float* v, hipStream_t s) {
@@ -295,6 +297,8 @@ static int mb1d_forward(int geometry, const int8_t* boards, const uint8_t* valid
         case AZG_NET_SPLENDOR3: return launch_mb1d<CfgSplendor3, H2>(N, boards, valid, B, pi, v, s);
         case AZG_NET_SPLENDOR4: return launch_mb1d<CfgSplendor4, H2>(N, boards, valid, B, pi, v, s);
         case AZG_NET_AZUL: return launch_mb1d<CfgAzul, H2>(N, boards, valid, B, pi, v, s);
+        case AZG_NET_MINIVILLES2: return launch_mb1d<CfgMinivilles2, H2>(N, boards, valid, B, pi, v, s);
+        case AZG_NET_TLP3: return launch_mb1d<CfgTLP3, H2>(N, boards, valid, B, pi, v, s);
         default: return fail("azg_nn_mb1d_forward: unknown geometry");
     }
 }

@@ -376,16 +376,57 @@ struct Forest {
         return heap(F, t) + (size_t)rec_off * 16u;
     }
 
+    // States of more than 768 bytes (Botanik 2310, Akropolis 1352, The Little Prince 825) move as 16-byte vectors, every request of a copy
+    // issued before the first use: 3 wide requests instead of 10 dependent dword round trips for a Botanik state.
+    static constexpr bool BIG_STATE = SPW > 192;
+    static constexpr int SPV = SP / 16, NV4 = (SPV + 63) / 64;
     __device__ static __forceinline__ void load_state(int8_t* lds, const int8_t* g_padded) {
+        if constexpr (BIG_STATE) {
+            const uint4* src = (const uint4*)g_padded;
+            uint4* dst = (uint4*)lds;
+            uint4 r[NV4];
+#pragma unroll
+            for (int k = 0; k < NV4; k++) r[k] = lane_id() + 64 * k < SPV ? src[lane_id() + 64 * k] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < NV4; k++)
+                if (lane_id() + 64 * k < SPV) dst[lane_id() + 64 * k] = r[k];
+        } else {
         const uint32_t* src = (const uint32_t*)g_padded;
         uint32_t* dst = (uint32_t*)lds;
         for (int i = lane_id(); i < SPW; i += 64) dst[i] = src[i];
+        }
         wave_sync();
     }
     __device__ static __forceinline__ void store_state(int8_t* g_padded, const int8_t* lds) {
+        if constexpr (BIG_STATE) {
+            const uint4* src = (const uint4*)lds;
+            uint4* dst = (uint4*)g_padded;
+#pragma unroll
+            for (int k = 0; k < NV4; k++)
+                if (lane_id() + 64 * k < SPV) dst[lane_id() + 64 * k] = src[lane_id() + 64 * k];
+        } else {
         const uint32_t* src = (const uint32_t*)lds;
         uint32_t* dst = (uint32_t*)g_padded;
         for (int i = lane_id(); i < SPW; i += 64) dst[i] = src[i];
+        }
+    }
+    // wave_hash_state (azg_common.hip.h) of the state in LDS: the same sum, read as 16-byte vectors for the big states
+    __device__ static __forceinline__ uint64_t hash_state(const int8_t* lds) {
+        if constexpr (BIG_STATE) {
+            const uint4* src = (const uint4*)lds;
+            uint64_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < NV4; k++) {
+                const int i = lane_id() + 64 * k;
+                if (i < SPV) {
+                    const uint4 x = src[i];
+                    acc += (uint64_t)x.x * (uint64_t)(((uint32_t)(4 * i + 1) * 0x9E3779B1u) | 1u) + (uint64_t)x.y * (uint64_t)(((uint32_t)(4 * i + 2) * 0x9E3779B1u) | 1u) +
+                           (uint64_t)x.z * (uint64_t)(((uint32_t)(4 * i + 3) * 0x9E3779B1u) | 1u) + (uint64_t)x.w * (uint64_t)(((uint32_t)(4 * i + 4) * 0x9E3779B1u) | 1u);
+                }
+            }
+            return mix64(wave_sum_u64(acc) ^ 0xD6E8FEB86659FD93ULL);
+        } else
+            return wave_hash_state((const uint32_t*)lds, SPW);
     }
     // unpadded S-byte state (API buffers) -> LDS with zero tail
     __device__ static __forceinline__ void load_state_unpadded(int8_t* lds, const int8_t* g) {
@@ -421,6 +462,14 @@ struct Forest {
                 // hash check and full-key compare requested together (one round trip; tag collisions are rare)
                 const uint32_t* other = (const uint32_t*)nstate(F, t, id);
                 bool eq = true;
+                if constexpr (BIG_STATE) {
+#pragma unroll
+                    for (int k = 0; k < NV4; k++)
+                        if (lane_id() + 64 * k < SPV) {
+                            const uint4 a = ((const uint4*)other)[lane_id() + 64 * k], b = ((const uint4*)my)[lane_id() + 64 * k];
+                            eq = eq && a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+                        }
+                } else
                 for (int i = lane_id(); i < SPW; i += 64) eq = eq && (other[i] == my[i]);
                 const NodeHdr nh = load_uniform(nhdr(F, t, id));
                 if (nh.hash != h) continue;

@@ -134,6 +134,21 @@ struct BotanikDev {
             }
         return n;
     }
+    // the same count with one of the 5 x 5 cells per lane (wave-uniform result)
+    __device__ static int wave_open_pipes(const int8_t* mach) {
+        const int l = lane_id(), y = l / 5, x = l - 5 * y;
+        int n = 0;
+        if (l < 25) {
+            const int8_t* c = cell(mach, y, x);
+            if (!is_empty(c)) {
+                n += (y > 0 && is_empty(cell(mach, y - 1, x)) && c[NORTH] > 0) ? 1 : 0;
+                n += (is_empty(cell(mach, y, x + 1)) && c[EAST] > 0) ? 1 : 0;
+                n += (is_empty(cell(mach, y + 1, x)) && c[SOUTH] > 0) ? 1 : 0;
+                n += (x > 0 && is_empty(cell(mach, y, x - 1)) && c[WEST] > 0) ? 1 : 0;
+            }
+        }
+        return __popcll(__ballot(n & 1)) + 2 * __popcll(__ballot(n & 2)) + 4 * __popcll(__ballot(n & 4));
+    }
     // _check_card_on_machine :688-713 for one orientation
     __device__ static bool check_card(const int8_t* card, int y, int x, const int8_t* need, const int8_t* nei, int initial_open, int orient) {
         if (card[2] == PIPE2_STRAIGHT && orient >= 2) return false;
@@ -286,7 +301,7 @@ struct BotanikDev {
         const int l = lane_id();
         const int status = st[1];
         const bool expand = status == MAINPL_EXPAND || status == OTHERP_EXPAND;
-        const int nb_open = expand ? open_pipes(st + B_MACH + 350 * player) : 0;
+        const int nb_open = expand ? wave_open_pipes(st + B_MACH + 350 * player) : 0;
         uint64_t any = 0;
 #pragma unroll 1
         for (int k = 0; k < AW; k++) {
@@ -372,24 +387,34 @@ struct BotanikDev {
 
     // Board.swap_players :254-284 (k == 1): registers, freed cards, scores and the three machine arrays trade places (343 of the
     // 350 bytes of every slab), the status maps 1 <-> 3, 2 <-> 4 and the main player flips
+    // In place, one exchange per lane and step: the two players' bytes are disjoint pairs -- registers 35, freed cards 14, three pairs of
+    // slabs (both start on even offsets: 171 two-byte words + 1 byte each), the scores -- 566 exchanges = 9 steps of the wave, no copy.
     __device__ static void swap_players(int8_t* st, int8_t* tmp, int k) {
+        (void)tmp;
         if (k != 1) return;
-        for (int i = lane_id(); i < S; i += 64) tmp[i] = st[i];
-        wave_sync();
-        for (int i = lane_id(); i < S; i += 64) {
-            int src = i;
-            if (i >= B_REG && i < B_REG + 70) src = i < B_REG + 35 ? i + 35 : i - 35;
-            else if (i >= B_FREED && i < B_FREED + 28) src = i < B_FREED + 14 ? i + 14 : i - 14;
-            else if (i >= B_MACH) {
-                const int slab = (i - B_MACH) / 350, off = (i - B_MACH) - slab * 350;
-                if (off < 343) src = B_MACH + (slab ^ 1) * 350 + off;
+        constexpr int NPAIR = 35 + 14 + 1 + 3 * 172;
+        for (int i = lane_id(); i < NPAIR; i += 64) {
+            int a, b;
+            bool wide = false;
+            if (i < 35) { a = B_REG + i; b = a + 35; }
+            else if (i < 49) { a = B_FREED + (i - 35); b = a + 14; }
+            else if (i == 49) { a = 7; b = 8; }
+            else {
+                const int j = i - 50, pair = j / 172, w = j - pair * 172;
+                a = B_MACH + 700 * pair + 2 * w; b = a + 350;
+                wide = w < 171;
             }
-            int8_t v = tmp[src];
-            if (i == 1 && tmp[1] > TO_REGISTER) v = (int8_t)((tmp[1] + 1) % 4 + 1);
-            if (i == 2) v = (int8_t)(1 - tmp[2]);
-            if (i == 7) v = tmp[8];
-            if (i == 8) v = tmp[7];
-            st[i] = v;
+            if (wide) {
+                const uint16_t x = *(const uint16_t*)(st + a), y = *(const uint16_t*)(st + b);
+                *(uint16_t*)(st + a) = y; *(uint16_t*)(st + b) = x;
+            } else {
+                const int8_t x = st[a], y = st[b];
+                st[a] = y; st[b] = x;
+            }
+        }
+        if (lane_id() == 0) {
+            if (st[1] > TO_REGISTER) st[1] = (int8_t)((st[1] + 1) % 4 + 1);
+            st[2] = (int8_t)(1 - st[2]);
         }
         wave_sync();
     }

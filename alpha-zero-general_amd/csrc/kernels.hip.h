@@ -190,7 +190,7 @@ template <class G>
 __device__ void begin_search_from_lds(const ForestDev& F, int t, TreeHdr& H, typename Forest<G>::Smem& sm, bool full) {
     using FR = Forest<G>;
     FR::store_state(F.root_state + (size_t)t * G::SP, sm.st);
-    uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
+    uint64_t h = FR::hash_state(sm.st);
     uint32_t free_slot;
     uint32_t found_rec = AZG_NONE;
     H.root = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);
@@ -351,7 +351,7 @@ __device__ __forceinline__ uint32_t resolve_edge(const ForestDev& F, int t, HS& 
     c0 = AZG_CLK(); AZG_SEG(1, c0 - c1);
     FR::leaf_pf_links(F, t, pf);
     if (np != 0) G::swap_players(sm.st, sm.tmp, np);
-    const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
+    const uint64_t h = FR::hash_state(sm.st);
     c1 = AZG_CLK(); AZG_SEG(2, c1 - c0);
     uint32_t free_slot;
     uint32_t found_rec = AZG_NONE;
@@ -696,7 +696,7 @@ __device__ __forceinline__ int select_tree(const ForestDev& F, const int t, type
             if (rec == AZG_NONE) {
                 // the root itself is not a node yet: it is the leaf of this simulation (MCTS.py:140-154)
                 FR::load_state(sm.st, F.root_state + (size_t)t * G::SP);
-                const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
+                const uint64_t h = FR::hash_state(sm.st);
                 uint32_t free_slot;
                 uint32_t found_rec = AZG_NONE;
                 const uint32_t found = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);

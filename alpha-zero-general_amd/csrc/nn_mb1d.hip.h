@@ -50,7 +50,11 @@ struct Mb1dCfg {
     static constexpr int HEAD_PI = (KS_PI + 1) * 16 * AS, HEAD_V = NW * 16 * 20;     // RED[KS][16][AS] + HID; value RED[NW][16][20]
     static constexpr int HEAD_SZ = HEAD_PI > HEAD_V ? HEAD_PI : HEAD_V;              // aliases H
     static constexpr int H_ALLOC = H_SZ > HEAD_SZ ? H_SZ : HEAD_SZ;
-    static constexpr int LDS_FLOATS = XA_SZ + X2_SZ + H_ALLOC + PL_SZ + SC_SZ + SH_SZ + 64;
+    // the token-mix matrix Wd[L][L]: up to 8 tokens it is pinned in scalar registers (row stride L); beyond that it stays in LDS (rows padded to
+    // a multiple of 4 floats) and is read by broadcast
+    static constexpr bool WD_REGS = L_ * L_ <= 64;
+    static constexpr int WD_LD = WD_REGS ? L_ : (L_ + 3) / 4 * 4, WD_SZ = WD_REGS ? 64 : L_ * WD_LD;
+    static constexpr int LDS_FLOATS = XA_SZ + X2_SZ + H_ALLOC + PL_SZ + SC_SZ + SH_SZ + WD_SZ;
 };
 
 // One GEMM phase over the workgroup:  out(row, 16*ct + 4g .. +3) = epi( sum_k in[row][k] * W[k][col] )
@@ -190,7 +194,7 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
     constexpr int EP = mb_r16(CF::E[BI]), QP = mb_r16(CF::Q[BI]), COP = mb_r16(CF::CO[BI]);
     constexpr int ACT = CF::ACT[BI], PMAX = CF::PMAX[BI];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
-    if (tid < L * L) WD[tid] = W.Wd[tid];
+    for (int i = tid; i < L * L; i += NW * 64) WD[(i / L) * CF::WD_LD + i % L] = W.Wd[i];
     // ---- expand + BN + act -> H ----
     (void)g;
     mb_gemm_any<H2, CIN_P / 16, EP / 16, RT, NW>(
@@ -203,9 +207,11 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
     __syncthreads();
     // ---- depthwise Linear(L->L) over the tokens + BN + act (in place) + SE squeeze ----
     {
-        float wd[L * L];
+        float wd[CF::WD_REGS ? L * L : 1];
+        if constexpr (CF::WD_REGS) {
 #pragma unroll
-        for (int k = 0; k < L * L; k++) wd[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, WD[k])));
+            for (int k = 0; k < L * L; k++) wd[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, WD[k])));
+        }
         for (int i = tid; i < NS * (EP / 2); i += NW * 64) {
             const int s = i / (EP / 2), c = 2 * (i - s * (EP / 2));
             float* base = H + (s * L) * HS + c;
@@ -218,7 +224,10 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
             for (int m = 0; m < L; m++) {
                 f32x2 a = f32x2{0.f, 0.f};
 #pragma unroll
-                for (int l = 0; l < L; l++) a += wd[m * L + l] * in[l];
+                for (int l = 0; l < L; l++) {
+                    if constexpr (CF::WD_REGS) a += wd[m * L + l] * in[l];
+                    else a += WD[m * CF::WD_LD + l] * in[l];
+                }
                 a = act_apply2(a * scl + bb, ACT);
                 *(f32x2*)(base + m * HS) = a;
                 if (PMAX) { pool.x = fmaxf(pool.x, a.x); pool.y = fmaxf(pool.y, a.y); } else pool += a;
@@ -458,5 +467,9 @@ typedef Mb1dCfg<7, 56, 8, 81, 2, 168, 168, 168, 40, 40, 40, 56, 1, 2, 1> CfgSple
 typedef Mb1dCfg<7, 71, 8, 81, 3, 213, 213, 213, 56, 56, 56, 71, 1, 2, 1> CfgSplendor3;
 typedef Mb1dCfg<7, 88, 8, 81, 4, 264, 264, 264, 64, 64, 64, 88, 1, 2, 1> CfgSplendor4;
 typedef Mb1dCfg<6, 23, 16, 180, 2, 115, 115, 46, 32, 32, 16, 46, 1, 2, 0> CfgAzul;
+// two more games whose shipped checkpoints are nets of this family (MinivillesNNet.py:101-123 nn_version 82, 2 players: [58][2] board;
+// TLPNNet.py:175-196 nn_version 83, 3 players: [55][15] board)
+typedef Mb1dCfg<2, 58, 16, 21, 2, 174, 174, 174, 40, 40, 40, 58, 1, 2, 1> CfgMinivilles2;
+typedef Mb1dCfg<15, 55, 8, 9, 3, 82, 82, 82, 24, 24, 24, 55, 1, 2, 1> CfgTLP3;
 
 }  // namespace azg

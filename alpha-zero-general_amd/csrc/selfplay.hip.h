@@ -179,7 +179,7 @@ __device__ __forceinline__ bool arena_is_short(const ForestDev& F, const TreeHdr
 template <class G>
 __device__ __forceinline__ void locate_root(const ForestDev& F, int t, TreeHdr& H, typename Forest<G>::Smem& sm) {
     using FR = Forest<G>;
-    const uint64_t h = wave_hash_state((const uint32_t*)sm.st, FR::SPW);
+    const uint64_t h = FR::hash_state(sm.st);
     uint32_t free_slot;
     uint32_t found_rec = AZG_NONE;
     H.root = FR::probe(F, t, sm.st, h, &free_slot, &found_rec);

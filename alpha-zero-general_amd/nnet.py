@@ -453,6 +453,45 @@ class AzulV84(SplendorV80):
         return torch.softmax(logits, dim=1).contiguous(), v.contiguous()
 
 
+class MobileNet1d(AzulV84):
+    """Any net of the reference's one-trunk-block MobileNetV3-1d family, geometry read off the state_dict: first_layer, ONE trunk block
+    (ReLU, mean squeeze), one policy-head and one value-head block (Hardswish, `head_se` squeeze), Flatten + Linear + ReLU + Linear heads.
+    The shipped nets of two more games are of this shape (their checkpoints load unchanged):
+      minivilles/MinivillesNNet.py:101-123 nn_version 82 -- [B, 58, 2] board (2 players), blocks 58 -> 174 -> 58, heads Linear(116, 21) / (116, 2)
+      thelittleprince/TLPNNet.py:175-196 nn_version 83   -- [B, 55, 15] board (3 players), blocks 55 -> 82 -> 55, heads Linear(825, 9) / (825, 3)
+    (TLP nn_version 80 / 82 differ in the expansion factor only and load the same way.)"""
+
+    def __init__(self, state_dict, num_players=None, head_se='max', device='cuda:0', dtype=torch.float32):
+        sd = {k: torch.as_tensor(v).float() for k, v in state_dict.items()}
+        self.nb_vect = int(sd['first_layer.linear.weight'].shape[0])
+        self.L = L = int(sd['trunk.0.depthwise.linear.weight'].shape[0])
+        self.A = int(sd['output_layers_PI.4.weight'].shape[0])
+        self.P = int(sd['output_layers_V.4.weight'].shape[0])
+        assert num_players in (None, self.P)
+        s, b = _fold_bn(sd, 'first_layer.norm')
+        self.W0 = (sd['first_layer.linear.weight'] * s[:, None]).t().contiguous()
+        self.b0 = b
+        self.trunk = _Block(sd, 'trunk.0', False, 'avg')
+        self.head_pi = _Block(sd, 'output_layers_PI.0', True, head_se)
+        self.head_v = _Block(sd, 'output_layers_V.0', True, head_se)
+
+        def perm(w, C):   # reference flattens [B, C, L] (index c*L+l); ours is [B, L, C] (index l*C+c)
+            return w.view(w.shape[0], C, L).permute(0, 2, 1).reshape(w.shape[0], L * C).t().contiguous()
+        self.Wpi1, self.bpi1 = perm(sd['output_layers_PI.2.weight'], self.head_pi.Wp.shape[1]), sd['output_layers_PI.2.bias']
+        self.Wpi2, self.bpi2 = sd['output_layers_PI.4.weight'].t().contiguous(), sd['output_layers_PI.4.bias']
+        self.Wv1, self.bv1 = perm(sd['output_layers_V.2.weight'], self.head_v.Wp.shape[1]), sd['output_layers_V.2.bias']
+        self.Wv2, self.bv2 = sd['output_layers_V.4.weight'].t().contiguous(), sd['output_layers_V.4.bias']
+        self.to(device, dtype)
+
+
+class MinivillesV82(MobileNet1d):
+    """minivilles/MinivillesNNet.py nn_version == 82 (:101-123,166-172), the net of minivilles/pretrained_2players.pt"""
+
+
+class TLPV83(MobileNet1d):
+    """thelittleprince/TLPNNet.py nn_version == 83 (:175-196,211-217), the net of thelittleprince/pretrained_3players.pt"""
+
+
 class MobileNet1dHip:
     """The MobileNetV3-1d policy/value nets of any geometry (Splendor V80 for 2-4 players: C = 32 + 10n + n^2 channels x 7
     tokens; Azul V84: 23 channels x 6 tokens, AzulNNet.py:91-113) evaluated by the engine's gfx950 kernels instead of ~65
@@ -513,8 +552,11 @@ class MobileNet1dHip:
         self.pWv1 = flat(base.Wv1, gv['cout'], gv['coutp'])
         self.bpi1, self.bpi2, self.bv1 = base.bpi1.contiguous(), base.bpi2.contiguous(), base.bv1.contiguous()
         self.Wv2, self.bv2 = base.Wv2.contiguous(), base.bv2.contiguous()
-        self.geometry = {(7, 56): 0, (7, 71): 1, (7, 88): 2, (6, 23): 3}.get((self.L, self.C))    # AZG_NET_* of azg.h
+        self.geometry = {(7, 56): 0, (7, 71): 1, (7, 88): 2, (6, 23): 3, (2, 58): 4, (15, 55): 5}.get((self.L, self.C))    # AZG_NET_* of azg.h
         self.fused = fused and self.geometry is not None
+        if not self.fused and self.geometry not in (0, 1, 2, 3):
+            # the launch-per-layer path (azg_nn_linear's tile shapes) exists for the Splendor and Azul geometries only
+            raise ValueError('MobileNet1dHip: geometry L=%d C=%d has the one-launch kernels only (fused=True)' % (self.L, self.C))
         if self.fused:
             self._pack_fused(padw, padv, r16)
         self._alloc(max_batch)

@@ -291,10 +291,22 @@ def measure_roofline(a, eng, T):
             tj = json.load(open(a.traffic_json))
             if tj.get('games') == T and tj.get('sims') == a.sims and tj.get('game', 'splendor2') == eng.game_key:
                 prof = dict(hbm_bytes_per_launch=tj.get('hbm_bytes_per_launch'), file=os.path.relpath(a.traffic_json, ROOT),
+                            traffic_over_algorithmic=tj.get('traffic_over_algorithmic'),
+                            traffic_over_algorithmic_lower_bound=tj.get('traffic_over_algorithmic_lower_bound'),
                             note='PMC FETCH_SIZE/WRITE_SIZE of an earlier rocprofv3 run of this command (separate --pmc passes, '
                                  'gfx950 corrections); NOT measured in this run')
         except Exception:
             prof = None
+    # HBM bytes per launch: PMC counters cannot be read inside this run (rocprofv3 wraps the process), and a --pmc pass SERIALISES kernels,
+    # which the pipeline's two concurrent persistent kernels do not survive (the descents wait for a net kernel that is never started:
+    # the launch ends in its idle timeout).  The committed PMC passes therefore profile the SAME descent code as stand-alone launches
+    # (AZG_ASYNC=0, tools/pmc_traffic.sh); `traffic` = their measured bytes-moved / algorithmic-bytes ratio x this launch's algorithmic bytes
+    traffic = traffic_source = None
+    if prof and prof.get('traffic_over_algorithmic'):
+        traffic = prof['traffic_over_algorithmic'] * bytes_per_launch
+        traffic_source = ('%s: (TCC FETCH_SIZE x 2 + WRITE_SIZE, gfx950 corrections) / algorithmic bytes = %.3f (an upper bound; lower bound %.3f) measured on '
+                          'stand-alone launches of the same descent code, x the %.4g algorithmic bytes of this launch' %
+                          (prof['file'], prof['traffic_over_algorithmic'], prof.get('traffic_over_algorithmic_lower_bound') or float('nan'), bytes_per_launch))
     extra = {}
     if aprof is not None:
         extra = dict(async_pipeline=dict((k, aprof[k]) for k in ('n_sel', 'n_net', 'leaves', 'launches', 'descents', 'plies_in_kernel', 'descent_us', 'forward_us', 'leaves_per_batch', 'leaf_wait_us',
@@ -312,7 +324,7 @@ def measure_roofline(a, eng, T):
                                       ['k_rounds_v80: select phase (expansion + backup + descent of 16 trees per workgroup)'] if kprof is not None else
                                       ['k_select', 'k_expand_backup'] if n_exp else ['k_select (expand+backup fused into its prologue)']), **extra,
                 achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
-                traffic=None, traffic_from_profile=prof,
+                traffic=traffic, traffic_source=traffic_source, traffic_from_profile=prof,
                 bytes_per_sim=b_sim, sims_per_launch=sims_per_launch, bytes_per_launch=bytes_per_launch,
                 select_ms=ms_sel, expand_backup_ms=ms_exp, launches=int(n_sel),
                 d_levels_per_sim=d, v_valid_per_level=vbar, e_expansions_per_sim=e)

@@ -362,7 +362,9 @@ int azg_nn_v80_forward_h2(const int8_t* boards_dev, const uint8_t* valid_dev, co
    dimensions and stored in MFMA fragment order frag[N/16][K/16][64][4] = W[16c + 4*(lane>>4) + j][16nt + (lane&15)],
    every vector zero-padded to a multiple of 16; the rows of Wpi1 / Wv1 are indexed l*OS + c with OS = 16*ceil(max(C,
    policy-block channels)/16) + 4. */
-enum { AZG_NET_SPLENDOR2 = 0, AZG_NET_SPLENDOR3 = 1, AZG_NET_SPLENDOR4 = 2, AZG_NET_AZUL = 3 };
+enum { AZG_NET_SPLENDOR2 = 0, AZG_NET_SPLENDOR3 = 1, AZG_NET_SPLENDOR4 = 2, AZG_NET_AZUL = 3,
+       AZG_NET_MINIVILLES2 = 4,   /* minivilles/MinivillesNNet.py:101-123 nn_version 82, 2 players: C = 58, L = 2, A = 21 */
+       AZG_NET_TLP3 = 5 };        /* thelittleprince/TLPNNet.py:175-196 nn_version 83, 3 players: C = 55, L = 15, A = 9 */
 int azg_nn_mb1d_forward(int geometry, const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, int B,
                         float* pi_dev, float* v_dev, void* stream);
 /* The same forward with every GEMM phase on f16 x 2 split-precision operands (hi + lo halves, three v_mfma_f32_16x16x32_f16 per

@@ -20,7 +20,8 @@ def assert_net_close(pi, v, tag, d=None):
     assert np.abs(pi - d64['pi64']).max() <= 1e-5
     assert np.abs(v - d64['v64']).max() <= 1e-5, np.abs(v - d64['v64']).max()
     assert np.all(np.abs(v - d['v']) <= 1e-5 + np.abs(d['v'] - d64['v64']))
-    assert np.all(pi[d['masks'] == 0] == 0)
+    some = d['masks'].any(axis=1)           # (a board without a valid move -- ended games among the TLP boards: every logit is -1e8, pi uniform, as the reference's)
+    assert np.all(pi[some][d['masks'][some] == 0] == 0)
 
 
 def assert_close_on_random_boards(base, rb, rm, pi, v):
@@ -90,7 +91,10 @@ def _check_generic(cls, tag, device):
     assert_net_close(pi, v, tag, d)
 
 
-OTHER_NETS = [('AzulV84', 'azul_v84'), ('SantoriniV89', 'santorini1_v89'), ('SantoriniV78', 'santorini11_v78')]
+OTHER_NETS = [('AzulV84', 'azul_v84'), ('SantoriniV89', 'santorini1_v89'), ('SantoriniV78', 'santorini11_v78'),
+              # the shipped nets of two f4 games are of the MobileNet-1d family: minivilles/pretrained_2players.pt (MinivillesNNet.py nn_version 82)
+              # and thelittleprince/pretrained_3players.pt (TLPNNet.py nn_version 83); vectors from the reference's own modules
+              ('MinivillesV82', 'minivilles2_v82'), ('TLPV83', 'tlp3_v83')]
 
 
 @pytest.mark.parametrize('cls,tag', OTHER_NETS)
@@ -209,7 +213,7 @@ def test_v80_4p_forward_gpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('fused', [False, True, 'h2'], ids=['launches17', 'fused_f32', 'fused_h2'])
-@pytest.mark.parametrize('tag', ['splendor2_v80', 'splendor4_v80', 'azul_v84'])
+@pytest.mark.parametrize('tag', ['splendor2_v80', 'splendor4_v80', 'azul_v84', 'minivilles2_v82', 'tlp3_v83'])
 def test_mobilenet1d_engine_kernels_gpu(tag, fused):
     """MobileNet1dHip (engine GEMM / depthwise / head kernels, any geometry) vs the reference models' golden outputs, and at
     a batch that is not a multiple of the 16-row tiles vs the torch-ops evaluation of the same weights."""
@@ -217,9 +221,15 @@ def test_mobilenet1d_engine_kernels_gpu(tag, fused):
     root = os.path.join(os.path.dirname(__file__), 'golden')
     if tag == 'azul_v84':
         base = nnet.AzulV84.from_npz(os.path.join(root, 'weights_%s.npz' % tag), device='cuda:0')
+    elif tag in ('minivilles2_v82', 'tlp3_v83'):
+        base = nnet.MobileNet1d.from_npz(os.path.join(root, 'weights_%s.npz' % tag), device='cuda:0')
     else:
         npl = 4 if tag.startswith('splendor4') else 2
         base = nnet.SplendorV80.from_npz(os.path.join(root, 'weights_%s.npz' % tag), num_players=npl, device='cuda:0')
+    if not fused and tag in ('minivilles2_v82', 'tlp3_v83'):
+        with pytest.raises(ValueError):            # the launch-per-layer path exists for the Splendor / Azul geometries only
+            nnet.MobileNet1dHip(base, max_batch=64, fused=False)
+        return
     # one launch with the GEMM phases on f16 x 2 split-precision operands (default) / on f32 MFMAs / 17 launches
     net = nnet.MobileNet1dHip(base, max_batch=64, fused=bool(fused), h2=fused == 'h2')
     assert net.fused == bool(fused)
@@ -294,7 +304,7 @@ def test_santorini_v78_one_launch_gpu(split):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['splendor2_v80', 'splendor4_v80', 'azul_v84', 'santorini1_v89', 'santorini11_v78'])
+@pytest.mark.parametrize('tag', ['splendor2_v80', 'splendor4_v80', 'azul_v84', 'santorini1_v89', 'santorini11_v78', 'minivilles2_v82', 'tlp3_v83'])
 def test_net_kernels_do_not_depend_on_stale_onchip_memory(tag):
     """every one-launch net kernel gives bit-identical outputs whatever the LDS of the CUs and the scratch memory of the queue held
     before (azg_debug_poison_onchip): no read of on-chip memory the kernel did not write"""
@@ -308,6 +318,8 @@ def test_net_kernels_do_not_depend_on_stale_onchip_memory(tag):
         net = nnet.MobileNet1dHip(nnet.SplendorV80.from_npz(w, num_players=4, device='cuda:0'), max_batch=256)
     elif tag == 'azul_v84':
         net = nnet.MobileNet1dHip(nnet.AzulV84.from_npz(w, device='cuda:0'), max_batch=256)
+    elif tag in ('minivilles2_v82', 'tlp3_v83'):
+        net = nnet.MobileNet1dHip(nnet.MobileNet1d.from_npz(w, device='cuda:0'), max_batch=256)
     elif tag == 'santorini1_v89':
         net = nnet.SantoriniV89Hip(nnet.SantoriniV89.from_npz(w, device='cuda:0'), max_batch=256)
     else:

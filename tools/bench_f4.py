@@ -52,13 +52,16 @@ class MlpNet(torch.nn.Module):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--net', default='hash', choices=['hash', 'hashhip', 'mlp'],
-                    help='leaf evaluator: integer hash-net as torch ops, the same as one engine kernel (azg_eval_hashnet), or MlpNet through TorchModuleEvaluator')
+    ap.add_argument('--net', default='hash', choices=['hash', 'hashhip', 'mlp', 'engine', 'torchnet'],
+                    help='leaf evaluator: integer hash-net as torch ops, the same as one engine kernel (azg_eval_hashnet), MlpNet through TorchModuleEvaluator, '
+                         'engine = the game\'s SHIPPED net (minivilles/pretrained_2players.pt V82, thelittleprince/pretrained_3players.pt V83) as one launch of '
+                         'the engine\'s MobileNet-1d kernel (nn_mb1d.hip.h); torchnet = the same weights as PyTorch-ROCm ops (nnet.MobileNet1d)')
     ap.add_argument('--md', action='store_true', help='markdown table row instead of JSON')
     ap.add_argument('--games', type=int, default=1024)
     ap.add_argument('--sims', type=int, default=200)
     ap.add_argument('--plies', type=int, default=40, help='timed ply waves (one wave = `sims` lock-step rounds)')
     ap.add_argument('--only', default=None)
+    ap.add_argument('--cyc', action='store_true', help='cycle breakdown of k_select per tree and launch (a library built with AZG_DEFINES=AZG_CYC_COUNTERS)')
     a = ap.parse_args()
     for name, make, scale, capf in GAMES:
         if a.only and a.only != name:
@@ -68,7 +71,14 @@ def main():
         # (Akropolis offers hundreds of placements: with 200 simulations policy-target pruning leaves no count above 1, error bit 64)
         args = Args(numMCTSSims=a.sims, cpuct=1.0, fpu=0.0, universes=1, forced_playouts=name != 'akropolis', prob_fullMCTS=1.0, ratio_fullMCTS=5,
                     dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0], tempThreshold=6)
-        if a.net == 'mlp':
+        if a.net in ('engine', 'torchnet'):
+            tag = {'minivilles': 'minivilles2_v82', 'thelittleprince': 'tlp3_v83'}.get(name)
+            if tag is None:
+                continue
+            from azg_amd import nnet
+            base = nnet.MobileNet1d.from_npz(os.path.join(ROOT, 'tests', 'golden', 'weights_%s.npz' % tag), device='cuda:0')
+            net = nnet.MobileNet1dHip(base, max_batch=T) if a.net == 'engine' else base
+        elif a.net == 'mlp':
             from azg_amd.nnet import TorchModuleEvaluator
             torch.manual_seed(0)
             net = TorchModuleEvaluator(MlpNet(int(g.S), g.A, g.P), g)
@@ -99,6 +109,14 @@ def main():
                                   valid_per_level=(s1['sum_valid_visited'] - s0['sum_valid_visited']) / max(s1['levels'] - s0['levels'], 1),
                                   games_finished=s1['games'], errors=s1['errors'], validate_violations=bad,
                                   forest_gb=eng.device_bytes / 1e9, evaluator=a.net)), flush=True)
+        if a.cyc and 'cyc_seg' in s1:
+            n = a.plies * a.sims * T
+            seg = [s1['cyc_seg'][k] - s0['cyc_seg'][k] for k in range(4)]
+            d = {k: s1[k] - s0[k] for k in ('cyc_select', 'cyc_levels', 'cyc_edge', 'cyc_leaf', 'levels', 'sims', 'expansions', 'terminal_hits')}
+            print('  %s per tree-launch cycles: select %.0f = levels %.0f (%.2f levels, %.0f each) + edge %.0f (prologue+load_state %.0f make_move %.0f canon+hash %.0f probe %.0f) '
+                  '+ leaf %.0f + rest %.0f; expansions %.3f terminal %.3f' % (
+                      name, d['cyc_select'] / n, d['cyc_levels'] / n, d['levels'] / n, d['cyc_levels'] / max(1, d['levels']), d['cyc_edge'] / n, seg[0] / n, seg[1] / n, seg[2] / n,
+                      seg[3] / n, d['cyc_leaf'] / n, (d['cyc_select'] - d['cyc_levels'] - d['cyc_edge'] - d['cyc_leaf']) / n, d['expansions'] / n, d['terminal_hits'] / n), flush=True)
         for grp in eng.groups:
             grp.f.close()
         del eng

@@ -75,10 +75,17 @@ def main():
         forward_f64('santorini1_v89', 'santorini/pretrained.pt', dict(santorini_gods=1))
         forward_f64('azul_v84', 'azul/pretrained.pt', dict())
         forward_f64('santorini11_v78', 'santorini/pretrained_withgods.pt', dict(santorini_gods=11))
+        forward_f64('minivilles2_v82', 'minivilles/pretrained_2players.pt', dict(minivilles_players=2))
+        forward_f64('tlp3_v83', 'thelittleprince/pretrained_3players.pt', dict(tlp_players=3))
         return
     if len(sys.argv) > 2 and sys.argv[1] == '--only':
         return convert(*{'santorini11_v78': ('santorini11_v78', 'santorini/pretrained_withgods.pt', dict(santorini_gods=11),
-                                             'SantoriniGame', 'SantoriniGame', 128)}[sys.argv[2]])
+                                             'SantoriniGame', 'SantoriniGame', 128),
+                         # the two f4 games whose shipped checkpoints are nets of the MobileNet-1d family (MinivillesNNet.py:101-123
+                         # nn_version 82, TLPNNet.py:175-196 nn_version 83): engine nets through nn_mb1d.hip.h
+                         'minivilles2_v82': ('minivilles2_v82', 'minivilles/pretrained_2players.pt', dict(minivilles_players=2),
+                                             'MinivillesGame', 'MinivillesGame', 128),
+                         'tlp3_v83': ('tlp3_v83', 'thelittleprince/pretrained_3players.pt', dict(tlp_players=3), 'TLPGame', 'TLPGame', 128)}[sys.argv[2]])
     convert('splendor2_v80', 'splendor/pretrained_2players.pt', dict(splendor_players=2), 'SplendorGame', 'SplendorGame')
     convert('splendor4_v80', 'splendor/pretrained_4players.pt', dict(splendor_players=4), 'SplendorGame', 'SplendorGame', n_vec=128)
     convert('santorini1_v89', 'santorini/pretrained.pt', dict(santorini_gods=1), 'SantoriniGame', 'SantoriniGame', n_vec=128)
