@@ -176,4 +176,9 @@ __device__ __forceinline__ int first_lane(uint64_t ballot) { return __ffsll((uns
 
 template <int N> struct RoundUp16 { static constexpr int value = (N + 15) / 16 * 16; };
 
+// LDS scratch a game's make_move wants BEHIND the state it is given (G::MOVE_SCRATCH bytes at st + G::SP; 0 unless the game says so): the
+// forest's Smem has its `tmp` there (forest.hip.h), the env-step kernel allocates it with the state (kernels.hip.h k_env_next_state)
+template <class G, class = void> struct MoveScratch { static constexpr int value = 0; };
+template <class G> struct MoveScratch<G, std::void_t<decltype(G::MOVE_SCRATCH)>> { static constexpr int value = G::MOVE_SCRATCH; };
+
 }  // namespace azg

@@ -355,7 +355,8 @@ struct Forest {
 
     struct Smem {
         __attribute__((aligned(16))) int8_t st[SP];
-        __attribute__((aligned(16))) int8_t tmp[SP];
+        __attribute__((aligned(16))) int8_t tmp[SP];           // (directly behind st: also the scratch of a game's make_move, MoveScratch<G>)
+        static_assert(MoveScratch<G>::value <= SP, "make_move scratch lives in tmp");
         __attribute__((aligned(16))) uint64_t mask[AW];
         __attribute__((aligned(16))) PathEnt path[AZG_MAXD];
     };

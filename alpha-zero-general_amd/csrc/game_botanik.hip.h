@@ -85,13 +85,20 @@ struct BotanikDev {
             k += __popc(m[c] & 0x1FFFu);
         }
         if (k == 0) return false;
+        // my_random_choice(:112-115): the first index whose running sum of p = mask / k exceeds u.  A card that is gone adds 0.0 / k = +0.0,
+        // which leaves the sum as it is, so only the k cards still in the deck take a step; 1.0 / k is the same quotient every time
         const double u = rng.u01();
+        const double inv = 1.0 / (double)k;
         double acc = 0.0;
         int pick = 64;
-        for (int i = 0; i < 65; i++) {
-            const int c = i / 13, j = i - 13 * c;
-            acc += (((m[c] >> (12 - j)) & 1u) ? 1.0 : 0.0) / (double)k;
-            if (acc > u) { pick = i; break; }
+        for (int c = 0; c < 5 && pick == 64; c++) {
+            uint32_t left = m[c] & 0x1FFFu;
+            while (left) {
+                const int bit = 31 - __clz((int)left);                          // card j = 12 - bit: ascending j
+                left &= ~(1u << bit);
+                acc += inv;
+                if (acc > u) { pick = 13 * c + (12 - bit); break; }
+            }
         }
         const int c = pick / 13, j = pick - 13 * c;
         const uint32_t nm = m[c] & ~(1u << (12 - j));
@@ -178,11 +185,17 @@ struct BotanikDev {
         if (x > 0 && c[WEST] > 0) nbc[nn++] = cur - 1;
         return nn;
     }
-    __device__ static int compute_score(const int8_t* mach) {
-        uint64_t visited = 0, equiv[MM + 1];
-        int8_t labels[MM];
-        short ncards[MM + 1], nflow[MM + 1];
-        uint8_t fr_cell[MM], fr_next[MM];
+    // The walk's tables live in LDS behind the state (MOVE_SCRATCH): as private arrays with run-time indices they were scratch MEMORY, a
+    // global-memory round trip per label / frame access of the one lane that walks.
+    static constexpr int MOVE_SCRATCH = 768;
+    __device__ static int compute_score(const int8_t* mach, int8_t* scratch) {
+        uint64_t visited = 0;
+        uint64_t* equiv = (uint64_t*)scratch;                   // [MM + 1]
+        short* ncards = (short*)(scratch + 400);                // [MM + 1]
+        short* nflow = (short*)(scratch + 500);                 // [MM + 1]
+        int8_t* labels = scratch + 600;                         // [MM]
+        uint8_t* fr_cell = (uint8_t*)scratch + 656;             // [MM]
+        uint8_t* fr_next = (uint8_t*)scratch + 712;             // [MM]
         int n = 0, sp = 0, nbc[4];
         for (int i = 0; i < MM; i++) labels[i] = 99;
         int cur = (MS / 3) * MS + MS / 2;
@@ -349,7 +362,7 @@ struct BotanikDev {
                 copy7(freed(st, 2 * player), freed(st, 2 * player + 1));
                 zero7(freed(st, 2 * player + 1));
             }
-            st[7 + player] = (int8_t)compute_score(st + B_MACH + 350 * player);
+            st[7 + player] = (int8_t)compute_score(st + B_MACH + 350 * player, st + SP);
             next_status(st);
         } else {                                                                // _throw_cards_away :629-644
             zero7(freed(st, 2 * player)); zero7(freed(st, 2 * player + 1));

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64) void k_env_next_state(const int8_t* states, con
                                                        const int32_t* actions, const int64_t* seeds, int n,
                                                        int8_t* out_states, int32_t* out_next, uint64_t rng_seed,
                                                        uint64_t stream0, uint64_t* counters) {
-    __shared__ __attribute__((aligned(16))) int8_t st[G::SP];
+    __shared__ __attribute__((aligned(16))) int8_t st[G::SP + MoveScratch<G>::value];
     int t = blockIdx.x;
     if (t >= n) return;
     Forest<G>::load_state_unpadded(st, states + (size_t)t * G::S);
