@@ -277,7 +277,7 @@ struct AzulDev {
         }
     }
     // the table is empty: score the round, refill, bonuses at the end of the game (:149-158); returns the next player
-    __device__ static int end_round(int8_t* st, long long seed, Rng& rng) {
+    __device__ static __attribute__((noinline)) int end_round(int8_t* st, long long seed, Rng& rng) {
         score_round(st);
         const int next = setup_new_round(st, seed, rng);
         if (game_over(st)) score_bonuses(st);

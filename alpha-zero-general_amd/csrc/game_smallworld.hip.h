@@ -77,7 +77,9 @@ struct SmallworldDev {
     __device__ static int8_t* current_ppl(int8_t* s, int player) { return PPL(s, player, GS(s, player)[4]); }      /* :956-960 */
     __device__ static uint64_t occupied_by(const int8_t* s, const int8_t* ppl) {                                     /* _are_occupied_by :973-974 */
         uint64_t m = 0;
-        for (int a = 0; a < NA; a++) if (T(s, a)[1] == ppl[1]) m |= 1ull << a;
+        const int8_t t = ppl[1];
+#pragma unroll
+        for (int a = 0; a < NA; a++) if (T(s, a)[1] == t) m |= 1ull << a;
         return m;
     }
     __device__ static int8_t* ppl_owner_of(int8_t* s, int area, int* owner) {                                        /* :962-968 */
@@ -104,7 +106,8 @@ struct SmallworldDev {
     }
     __device__ static int total_number_of_ppl(const int8_t* s, const int8_t* cp, uint64_t terr) {                     /* :1047-1053 */
         int n = cp[0];
-        for (int a = 0; a < NA; a++) if ((terr >> a) & 1) n += T(s, a)[0];
+#pragma unroll
+        for (int a = 0; a < NA; a++) { const int v = T(s, a)[0]; if ((terr >> a) & 1) n += v; }
         return n;
     }
     __device__ static int limit_added_ppl(const int8_t* s, const int8_t* cp, int addition, int maximum, uint64_t terr) {   /* :1055-1057 */
@@ -113,7 +116,8 @@ struct SmallworldDev {
     }
     __device__ static int surplus_on_board(const int8_t* s, uint64_t terr) {               /* my_dot(max(territories[:,0] - 1, 0), territories_of_player) */
         int n = 0;
-        for (int a = 0; a < NA; a++) if (((terr >> a) & 1) && T(s, a)[0] > 1) n += T(s, a)[0] - 1;
+#pragma unroll
+        for (int a = 0; a < NA; a++) { const int v = T(s, a)[0]; if (((terr >> a) & 1) && v > 1) n += v - 1; }
         return n;
     }
     __device__ static int ppl_virtually_available(const int8_t* s, int player, const int8_t* cp, int next_status, uint64_t terr) {   /* :1206-1233 */
@@ -156,22 +160,32 @@ struct SmallworldDev {
         t[6] = (int8_t)pts;
         t[7] = (int8_t)player;
     }
+    // (The loops over the areas only LOAD: with a store to the state inside, every iteration had to wait for the one before -- the
+    // compiler cannot tell cp[6] / rs[5] from the territory rows -- and a move runs three of these.  The int8 wrap-around of every
+    // running sum and the saturation of the defence total are applied step by step, as written.)
     __device__ static void update_round_status(int8_t* s, int8_t* cp, int player) {                                    /* :1478-1508 */
         int8_t* rs = RS(s, player);
-        cp[6] = 0; rs[0] = 0; rs[5] = 0; rs[6] = 0;
-        for (int a = 0; a < NA; a++) if (T(s, a)[1] == cp[1]) cp[6] = (int8_t)(cp[6] + T(s, a)[6]);
-        for (int a = 0; a < NA; a++)
-            if (T(s, a)[7] == player) {
-                rs[0] = (int8_t)(rs[0] + T(s, a)[0]);
-                rs[5] = (int8_t)(rs[5] + T(s, a)[5]);
-                if (rs[5] < 0) rs[5] = 127;
+        const int8_t cp1 = cp[1];
+        int8_t c6 = 0, r0 = 0, r5 = 0;
+#pragma unroll
+        for (int a = 0; a < NA; a++) {
+            const uint64_t row = *(const uint64_t*)T(s, a);
+            const int8_t t0 = (int8_t)row, t1 = (int8_t)(row >> 8), t5 = (int8_t)(row >> 40), t6 = (int8_t)(row >> 48), t7 = (int8_t)(row >> 56);
+            if (t1 == cp1) c6 = (int8_t)(c6 + t6);
+            if (t7 == player) {
+                r0 = (int8_t)(r0 + t0);
+                r5 = (int8_t)(r5 + t5);
+                if (r5 < 0) r5 = 127;
             }
-        if (cp[1] >= 0) {
-            if (cp[1] == ORC) cp[6] = (int8_t)(cp[6] + rs[3]);
-            if (cp[2] == PILLAGING) cp[6] = (int8_t)(cp[6] + rs[3]);
-            if (cp[2] == ALCHEMIST) cp[6] = (int8_t)(cp[6] + 2);
-            if (cp[2] == WEALTHY && cp[4] > 0) cp[6] = (int8_t)(cp[6] + cp[4]);
         }
+        rs[0] = r0; rs[5] = r5;
+        if (cp1 >= 0) {
+            if (cp1 == ORC) c6 = (int8_t)(c6 + rs[3]);
+            if (cp[2] == PILLAGING) c6 = (int8_t)(c6 + rs[3]);
+            if (cp[2] == ALCHEMIST) c6 = (int8_t)(c6 + 2);
+            if (cp[2] == WEALTHY && cp[4] > 0) c6 = (int8_t)(c6 + cp[4]);
+        }
+        cp[6] = c6;
         rs[6] = (int8_t)(PPL(s, player, 0)[6] + PPL(s, player, 1)[6] + PPL(s, player, 2)[6]);
     }
     __device__ static void empty_area(int8_t* s, int area) {
@@ -206,11 +220,19 @@ struct SmallworldDev {
         if (nb_initial > 0) RS(s, player)[3] = (int8_t)(RS(s, player)[3] + 1);
     }
     __device__ static void gather_current_ppl_but_one(int8_t* s, int8_t* cp) {                                          /* :1059-1067 */
+        const int8_t t = cp[1];
+        int8_t c0 = cp[0];
+        uint64_t rows[NA];
+#pragma unroll
+        for (int a = 0; a < NA; a++) rows[a] = *(const uint64_t*)T(s, a);
+#pragma unroll
         for (int a = 0; a < NA; a++)
-            if (T(s, a)[1] == cp[1]) {
-                const int n = T(s, a)[0] - 1;
-                if (n > 0) { T(s, a)[0] = (int8_t)(T(s, a)[0] - n); T(s, a)[5] = (int8_t)(T(s, a)[5] - n); cp[0] = (int8_t)(cp[0] + n); }
+            if ((int8_t)(rows[a] >> 8) == t) {
+                const int8_t t0 = (int8_t)rows[a], t5 = (int8_t)(rows[a] >> 40);
+                const int n = t0 - 1;
+                if (n > 0) { T(s, a)[0] = (int8_t)(t0 - n); T(s, a)[5] = (int8_t)(t5 - n); c0 = (int8_t)(c0 + n); }
             }
+        cp[0] = c0;
     }
 
     __device__ static int roll_dice(Ctx& c) {                                                                           /* :417-425, 1193-1200 */
@@ -269,18 +291,21 @@ struct SmallworldDev {
         int8_t* cp = current_ppl(s, player);
         update_round_status(s, cp, player);
         int score = 0;
+        const int8_t p0 = PPL(s, player, 0)[1], p1 = PPL(s, player, 1)[1], p2 = PPL(s, player, 2)[1];
+#pragma unroll
         for (int a = 0; a < NA; a++) {
-            const int8_t* t = T(s, a);
-            if (t[1] == NOPPL || !(t[1] == PPL(s, player, 0)[1] || t[1] == PPL(s, player, 1)[1] || t[1] == PPL(s, player, 2)[1])) continue;
+            const uint64_t row = *(const uint64_t*)T(s, a);
+            const int8_t t1 = (int8_t)(row >> 8), t2 = (int8_t)(row >> 16), t4 = (int8_t)(row >> 32);
+            if (t1 == NOPPL || !(t1 == p0 || t1 == p1 || t1 == p2)) continue;
             score++;
-            if (MINE(a) && (t[1] == DWARF || t[1] == -DWARF)) score++;
-            if (TERRAIN(a) == FARMLAND && t[1] == HUMAN) score++;
-            if (MAGIC(a) && t[1] == WIZARD) score++;
-            if (TERRAIN(a) == FORESTT && t[2] == FOREST) score++;
-            if (TERRAIN(a) == HILLT && t[2] == HILL) score++;
-            if (TERRAIN(a) == SWAMPT && t[2] == SWAMP) score++;
-            if (t[2] == MERCHANT) score++;
-            if (t[4] > 0 && t[2] == FORTIFIED) score++;
+            if (MINE(a) && (t1 == DWARF || t1 == -DWARF)) score++;
+            if (TERRAIN(a) == FARMLAND && t1 == HUMAN) score++;
+            if (MAGIC(a) && t1 == WIZARD) score++;
+            if (TERRAIN(a) == FORESTT && t2 == FOREST) score++;
+            if (TERRAIN(a) == HILLT && t2 == HILL) score++;
+            if (TERRAIN(a) == SWAMPT && t2 == SWAMP) score++;
+            if (t2 == MERCHANT) score++;
+            if (t4 > 0 && t2 == FORTIFIED) score++;
         }
         int8_t* ap = PPL(s, player, ACTIVE);
         if (ap[1] == ORC) score += RS(s, player)[3];
@@ -567,23 +592,63 @@ struct SmallworldDev {
     }
 
 
-    // ---- Board.valid_moves :197-208 restricted to one action (every lane recomputes the shared quantities of its class) ----
-    __device__ static bool valid_action(const int8_t* cs, int a, int player) {
+    // ---- Board.valid_moves :197-208.  What every action of a class shares -- the current people, its territories, the people it could field
+    // for a conquest / a redeployment, the neighbourhood of its territories -- is computed ONCE by the wave (uniform code on broadcast
+    // reads); a lane then decides its own action from its own territory row.  (Round 4 had every lane recompute the shared quantities of
+    // its class, and the wave runs all seven classes one after the other.) ----
+    struct VShared {
+        const int8_t* cp;
+        int phase, avail_conq, avail_redeploy, total_ppl, nt, cavern_owned;
+        bool early, enough_amazons;
+        uint64_t terr, neigh, water_mask, mountain_mask;
+    };
+    __device__ static uint64_t terrain_mask(int terrain) {
+        uint64_t m = 0;
+#pragma unroll
+        for (int a = 0; a < NA; a++) if (TERRAIN(a) == terrain) m |= 1ull << a;
+        return m;
+    }
+    __device__ static VShared valid_shared(int8_t* s, int player) {
+        VShared u;
+        u.cp = current_ppl(s, player);
+        u.phase = RS(s, player)[4];
+        u.early = u.phase == PHASE_READY || u.phase == PHASE_CHOOSE || u.phase == PHASE_ABANDON || u.phase == PHASE_CONQUEST;
+        u.terr = occupied_by(s, u.cp);
+        u.nt = __popcll((unsigned long long)u.terr);
+        u.avail_conq = ppl_virtually_available(s, player, u.cp, PHASE_CONQUEST, u.terr);
+        u.avail_redeploy = ppl_virtually_available(s, player, u.cp, PHASE_REDEPLOY, u.terr);
+        u.enough_amazons = !(u.cp[1] == AMAZON && u.avail_redeploy < 0);                   // _enough_amazons_to_redeploy :1434-1440
+        u.total_ppl = total_number_of_ppl(s, u.cp, u.terr);
+        u.neigh = 0; u.cavern_owned = 0;
+#pragma unroll
+        for (int i = 0; i < NA; i++) if ((u.terr >> i) & 1) { u.neigh |= SW_CONN_(i); u.cavern_owned |= CAVERN(i); }
+        u.water_mask = terrain_mask(WATER); u.mountain_mask = terrain_mask(MOUNTAIN);
+        return u;
+    }
+    __device__ static int minimum_ppl_for_attack_u(const int8_t* s, int area, const VShared& u) {                      /* :982-998 */
+        const int8_t* cp = u.cp;
+        int m = T(s, area)[5] + 2;
+        if (cp[1] == TRITON && (SW_CONN_(area) & u.water_mask)) m--;
+        if (cp[1] == GIANT && (SW_CONN_(area) & u.mountain_mask)) m--;
+        if (cp[2] == COMMANDO) m--;
+        if (cp[2] == MOUNTED && (TERRAIN(area) == HILLT || TERRAIN(area) == FARMLAND)) m--;
+        if (cp[2] == UNDERWORLD && CAVERN(area)) m--;
+        return m > 1 ? m : 1;
+    }
+    __device__ static bool valid_action(const int8_t* cs, int a, int player, const VShared& u) {
         int8_t* s = (int8_t*)cs;                                             // (read-only use)
-        const int8_t* cp = current_ppl(s, player);
-        const int phase = RS(s, player)[4];
-        const bool early = phase == PHASE_READY || phase == PHASE_CHOOSE || phase == PHASE_ABANDON || phase == PHASE_CONQUEST;
+        const int8_t* cp = u.cp;
+        const int phase = u.phase;
+        const uint64_t terr = u.terr;
         if (a < NA) {                                                        // _valids_abandon :616-632
             if (!(phase == PHASE_READY || phase == PHASE_ABANDON || phase == PHASE_ABANDON_AMAZONS))
-                if (!(cp[1] == AMAZON && (phase == PHASE_CONQUEST || phase == PHASE_CONQ_WITH_DICE) &&
-                      ppl_virtually_available(s, player, cp, PHASE_REDEPLOY, occupied_by(s, cp)) < 0)) return false;
-            return cp[1] != NOPPL && T(s, a)[1] == cp[1];
+                if (!(cp[1] == AMAZON && (phase == PHASE_CONQUEST || phase == PHASE_CONQ_WITH_DICE) && u.avail_redeploy < 0)) return false;
+            return cp[1] != NOPPL && ((terr >> a) & 1);
         }
         if (a < 2 * NA) {                                                    // _valids_attack :342-391
             const int area = a - NA;
-            if (cp[1] == NOPPL || !early) return false;
-            const uint64_t terr = occupied_by(s, cp);
-            int avail = ppl_virtually_available(s, player, cp, PHASE_CONQUEST, terr);
+            if (cp[1] == NOPPL || !u.early) return false;
+            int avail = u.avail_conq;
             if (avail <= 0) return false;
             if (cp[2] == BERSERK && split_b(cp[4])) avail += split_a(cp[4]);
             if ((terr >> area) & 1) return false;
@@ -592,21 +657,23 @@ struct SmallworldDev {
             if (cp[2] != FLYING) {
                 if (terr == 0) { if (cp[1] != HALFLING && !AT_EDGE(area)) return false; }
                 else {
-                    uint64_t neigh = 0;
-                    int cavern_owned = 0;
-                    for (int i = 0; i < NA; i++) if ((terr >> i) & 1) { neigh |= SW_CONN_(i); cavern_owned |= CAVERN(i); }
-                    int nb = (neigh >> area) & 1;
-                    if (cp[2] == UNDERWORLD && cavern_owned && CAVERN(area)) nb = 1;
+                    int nb = (u.neigh >> area) & 1;
+                    if (cp[2] == UNDERWORLD && u.cavern_owned && CAVERN(area)) nb = 1;
                     if (!nb) return false;
                 }
             }
-            return valid_attack_area(s, player, area, cp, avail) != 0;
+            if (avail + (cp[2] == BERSERK ? 0 : MAX_DICE) < minimum_ppl_for_attack_u(s, area, u)) return false;      // _valid_attack_area :393-405
+            if (T(s, area)[2] == DIPLOMAT && cp[1] > 0) {
+                int loser;
+                const int8_t* lp = ppl_owner_of(s, area, &loser);
+                if (lp && lp[4] == PMOD(player - loser)) return false;
+            }
+            return true;
         }
         if (a < 3 * NA) {                                                    // _valids_special_actionppl :651-701 (sorcerer)
             const int area = a - 2 * NA;
-            if (cp[1] != SORCERER || !early) return false;
-            const uint64_t terr = occupied_by(s, cp);
-            if (total_number_of_ppl(s, cp, terr) + 1 > MAX_SORCERERS) return false;
+            if (cp[1] != SORCERER || !u.early) return false;
+            if (u.total_ppl + 1 > MAX_SORCERERS) return false;
             const int8_t* t = T(s, area);
             if (TERRAIN(area) == WATER && cp[2] != SEAFARING) return false;
             if (t[0] != 1 || t[1] <= 0 || t[1] == cp[1]) return false;
@@ -621,21 +688,30 @@ struct SmallworldDev {
             const int area = a - 3 * NA;
             const bool late = phase == PHASE_CONQUEST || phase == PHASE_CONQ_WITH_DICE || phase == PHASE_REDEPLOY;
             int n = NA;
-            if (cp[2] == BIVOUACKING || cp[2] == HEROIC) { if (!late || cp[4] <= 0 || !enough_amazons_to_redeploy(s, player, cp)) return false; }
-            else if (cp[2] == FORTIFIED) { if (!late || split_a(cp[4]) <= 0 || split_b(cp[4]) || !enough_amazons_to_redeploy(s, player, cp)) return false; }
+            if (cp[2] == BIVOUACKING || cp[2] == HEROIC) { if (!late || cp[4] <= 0 || !u.enough_amazons) return false; }
+            else if (cp[2] == FORTIFIED) { if (!late || split_a(cp[4]) <= 0 || split_b(cp[4]) || !u.enough_amazons) return false; }
             else if (cp[2] == DIPLOMAT) {
-                if (!(phase == PHASE_CONQUEST || phase == PHASE_CONQ_WITH_DICE) || !enough_amazons_to_redeploy(s, player, cp)) return false;
+                if (!(phase == PHASE_CONQUEST || phase == PHASE_CONQ_WITH_DICE) || !u.enough_amazons) return false;
                 n = NP;
-            } else if (cp[2] == DRAGONMASTER) { if (!early || cp[4] > 0 || cp[0] < 1) return false; }
+            } else if (cp[2] == DRAGONMASTER) { if (!u.early || cp[4] > 0 || cp[0] < 1) return false; }
             else return false;
-            return area < n && valid_special_pwr_area(s, player, area, cp) != 0;
+            if (area >= n) return false;
+            const int8_t* t = T(s, area);                                    // _valid_special_pwr_area :807-858
+            switch (cp[2]) {
+            case BIVOUACKING: return t[1] == cp[1];
+            case FORTIFIED: case HEROIC: return t[1] == cp[1] && !(t[4] > 0);
+            case DIPLOMAT: return !(cp[4] & (1 << PMOD(player - area)));
+            default:                                                         // DRAGONMASTER
+                if (TERRAIN(area) == WATER || ((terr >> area) & 1)) return false;
+                if (t[3] >= IMMUNITY || t[4] >= IMMUNITY) return false;
+                return (SW_CONN_(area) & terr) != 0;
+            }
         }
         if (a < 5 * NA + MAX_REDEPLOY) {                                     // _valids_redeploy :451-488
             const int i = a - 4 * NA;
             if (cp[1] == NOPPL || phase == PHASE_WAIT || phase == PHASE_ABANDON_AMAZONS) return false;
-            const uint64_t terr = occupied_by(s, cp);
-            const int nt = __popcll((unsigned long long)terr);
-            const int avail = nt == 0 ? 0 : ppl_virtually_available(s, player, cp, PHASE_REDEPLOY, terr);
+            const int nt = u.nt;
+            const int avail = nt == 0 ? 0 : u.avail_redeploy;
             if (nt == 0 || avail == 0) return i == 0 && phase != PHASE_REDEPLOY;     // nothing to deploy: only "skip", once
             if (avail < 0 || i == 0) return false;                                    // (a territory is always a valid target: no skip)
             return i < MAX_REDEPLOY ? avail >= i * nt : ((terr >> (i - MAX_REDEPLOY)) & 1) != 0;
@@ -651,14 +727,18 @@ struct SmallworldDev {
                 if (!((phase == PHASE_CONQUEST || phase == PHASE_CONQ_WITH_DICE || phase == PHASE_REDEPLOY) && PPL(s, player, ACTIVE)[2] == STOUT)) return false;
             return true;
         }
-        return valid_end_aux(s, player, cp) != 0;                            // _valid_end :925-927
+        if (phase != PHASE_REDEPLOY || cp[1] == NOPPL) return false;         // _valid_end :925-946
+        if (cp[0] > 0 && terr != 0)
+            if (!(cp[1] == AMAZON && cp[0] == cp[3])) return false;
+        return u.enough_amazons;
     }
-    __device__ static void valid_mask(const int8_t* st, int player, uint64_t* mask_lds) {
+    __device__ static __attribute__((noinline)) void valid_mask(const int8_t* st, int player, uint64_t* mask_lds) {
         const int l = lane_id();
+        const VShared u = valid_shared((int8_t*)st, player);
 #pragma unroll 1
         for (int k = 0; k < AW; k++) {
             const int a = k * 64 + l;
-            const uint64_t m = __ballot(a < A && valid_action(st, a < A ? a : 0, player));
+            const uint64_t m = __ballot(a < A && valid_action(st, a < A ? a : 0, player, u));
             if (l == 0) mask_lds[k] = m;
         }
     }
@@ -677,7 +757,7 @@ struct SmallworldDev {
         return lane0_make_move<SmallworldDev<NPL>>(st, move, player, seed, rng);
     }
     // Board.make_move :210-240 -- lane 0 only
-    __device__ static int make_move(int8_t* s, int move, int player, long long seed, Rng& rng) {
+    __device__ static __attribute__((noinline)) int make_move(int8_t* s, int move, int player, long long seed, Rng& rng) {
         Ctx c{s, seed, rng};
         if (move < NA) do_abandon(c, player, move);
         else if (move < 2 * NA) do_attack(c, player, move - NA);
