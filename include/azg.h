@@ -355,7 +355,8 @@ int azg_nn_v80_forward_h2(const int8_t* boards_dev, const uint8_t* valid_dev, co
                           int B, int P, float* pi_dev, float* v_dev, void* stream);
 /* The whole MobileNetV3-1d forward (first layer, trunk block, policy block + head, value block + head) in one launch for
    the geometries of the reference's Splendor (SplendorNNet.py:259-283, n players: C = 32 + 10n + n^2 channels x 7 tokens)
-   and Azul (AzulNNet.py:91-113: 23 channels x 6 tokens) nets -- the generic sibling of azg_nn_v80_forward.
+   and Azul (AzulNNet.py:91-113: 23 channels x 6 tokens) nets, and of the shipped nets of Minivilles (MinivillesNNet.py:101-123: 58 x 2)
+   and The Little Prince (TLPNNet.py:175-196: 55 x 15) -- the generic sibling of azg_nn_v80_forward.
    boards int8 [B][C][L], valid u8 [B][A] -> pi f32 [B][A] (probabilities), v f32 [B][P].  w = 43 device pointers:
    {W0, b0}, 3 x {We, be, Wd[L][L], bn_scale_d, bn_bias_d, W1, b1, W2, b2, Wp, bp} (trunk, policy head, value head),
    {Wpi1, bpi1, Wpi2, bpi2, Wv1, bv1, Wv2[P][P], bv2}; every matrix but Wd / Wv2 is zero-padded to multiples of 16 in both

@@ -1,0 +1,5 @@
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+pr() { python -c "import sys,json; d=json.loads(sys.stdin.read()); a=d['roofline'].get('async_pipeline',{}); print('$1', round(d['value']), 'errors', d.get('engine_errors'), 'n_sel', a.get('n_sel'), 'n_net', a.get('n_net'), 'descent_us', round(a.get('descent_us',0),2), 'forward_us', round(a.get('forward_us',0),2), 'busy', round(a.get('select_wave_busy',0),3), round(a.get('net_wg_busy',0),3))"; }
+for ns in ${NS:-168 176 184 192}; do
+  AZG_ASYNC_NSEL=$ns AZG_ASYNC_NNET=$((256-ns)) timeout 600 python bench.py --game azul --steps 50 --warmup 5 --no-cpu-baseline --roofline-rounds 100 --no-sustained 2>/dev/null | tail -1 | pr azul_$ns
+done
