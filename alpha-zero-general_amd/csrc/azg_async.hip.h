@@ -42,6 +42,12 @@ constexpr uint32_t ERR_ASYNC_TIMEOUT = 128;
 #define AZG_ASYNC_SEL_WAVES 16                /* waves of a descent workgroup: 16 (<= 128 VGPRs each) fills a CU; 12 (<= 168 VGPRs) measured in round 5 */
 #endif
 constexpr int ASYNC_SEL_WAVES = AZG_ASYNC_SEL_WAVES;
+#ifndef AZG_IDLE_SLEEP
+#define AZG_IDLE_SLEEP 16                   /* s_sleep of a wave that found nothing ready and is not the scout (units of 64 cycles) */
+#endif
+#ifndef AZG_SCOUT_SLEEP
+#define AZG_SCOUT_SLEEP 8                   /* s_sleep of the scout between two polls of the ready words that found nothing */
+#endif
 constexpr int ASYNC_RS = 128;                 // ready words per select workgroup (trees per workgroup <= 128: two ballots)
 constexpr int ASYNC_NPROF = 96;
 
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
             // nothing known to be ready: ONE wave of the workgroup (the scout) polls the ready words in HBM, the others sleep on the LDS copy
             uint32_t got = 0u;
             if (l == 0) got = __hip_atomic_exchange(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u ? 1u : 0u;
-            if (!uni_u32(got)) { __builtin_amdgcn_s_sleep(16); continue; }
+            if (!uni_u32(got)) { __builtin_amdgcn_s_sleep(AZG_IDLE_SLEEP); continue; }
             const uint32_t v0 = l < n_g ? aload(my_ready + l) : 0u;
             const uint32_t v1 = l + 64 < n_g ? aload(my_ready + 64 + l) : 0u;
             {
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                     leave = true;
                 }
                 if (leave && l == 0) __hip_atomic_store(&C->retired, 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // everyone out
-                if (!leave) __builtin_amdgcn_s_sleep(8);
+                if (!leave) __builtin_amdgcn_s_sleep(AZG_SCOUT_SLEEP);
             }
             if (l == 0) __hip_atomic_store(&C->scout, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (leave) break;

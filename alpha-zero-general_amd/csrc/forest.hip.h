@@ -285,6 +285,64 @@ __device__ inline float np_sum_f32(const float* a, int n) {
     return ret;
 }
 
+// The same recursion for a length known at compile time (G::A), laid out for the wave: the recursion tree is static, so its leaf blocks
+// (<= 128 elements each: 16 for Santorini's 1782 actions, 32 for Abalone / Akropolis) are summed EIGHT AT A TIME -- one per group of eight
+// lanes, the eight strided accumulators of a block in the group's lanes, the fixed ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) tree
+// by xor-shuffles inside the group, then the n % 8 tail -- and combined left + right along the static tree.  The run-time form above walks
+// the blocks one after the other with its stack in private arrays (scratch memory): 81 k cycles of a Santorini-with-gods expansion.
+constexpr int np_half(int len) { return len / 2 - (len / 2) % 8; }
+template <int LEN> constexpr int np_leaves() {
+    if constexpr (LEN <= 128) return 1;
+    else return np_leaves<np_half(LEN)>() + np_leaves<LEN - np_half(LEN)>();
+}
+template <int OFF, int LEN, int IDX>
+__device__ __forceinline__ void np_leaf_of(int want, int& off, int& len) {           // (offset, length) of leaf block `want`
+    if constexpr (LEN <= 128) { if (want == IDX) { off = OFF; len = LEN; } }
+    else {
+        np_leaf_of<OFF, np_half(LEN), IDX>(want, off, len);
+        np_leaf_of<OFF + np_half(LEN), LEN - np_half(LEN), IDX + np_leaves<np_half(LEN)>()>(want, off, len);
+    }
+}
+template <int OFF, int LEN, int IDX, int R>
+__device__ __forceinline__ float np_combine(const float (&leaf)[R]) {
+    if constexpr (LEN <= 128) return __shfl(leaf[IDX >> 3], 8 * (IDX & 7), 64);
+    else {
+        const float lo = np_combine<OFF, np_half(LEN), IDX, R>(leaf);
+        const float hi = np_combine<OFF + np_half(LEN), LEN - np_half(LEN), IDX + np_leaves<np_half(LEN)>(), R>(leaf);
+        return lo + hi;
+    }
+}
+template <int N>
+__device__ __forceinline__ float np_sum_f32_static(const float* a) {
+    if constexpr (N <= 256) return np_sum_f32(a, N);
+    else {
+        constexpr int NL = np_leaves<N>(), R = (NL + 7) / 8;
+        const int l = lane_id(), g = l >> 3, j = l & 7;
+        float leaf[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            int off = 0, len = 0;
+            np_leaf_of<0, N, 0>(8 * r + g, off, len);
+            const int lim = len - (len % 8);                                       // (a leaf of the recursion holds at least 8 elements)
+            float acc = 0.f;
+            if (len > 0) {
+                acc = a[off + j];
+                for (int i = 8 + j; i < lim; i += 8) acc += a[off + i];
+            }
+            const float r1 = __shfl_xor(acc, 1, 64);
+            const float s2 = (l & 1) ? (r1 + acc) : (acc + r1);
+            const float s2o = __shfl_xor(s2, 2, 64);
+            const float s4 = (l & 2) ? (s2o + s2) : (s2 + s2o);
+            const float s4o = __shfl_xor(s4, 4, 64);
+            float res = (l & 4) ? (s4o + s4) : (s4 + s4o);
+            res = __shfl(res, 8 * g, 64);                                           // the group's lane 0 holds the tree's value
+            for (int i = lim; i < len; i++) res += a[off + i];
+            leaf[r] = res;
+        }
+        return np_combine<0, N, 0, R>(leaf);
+    }
+}
+
 // The same sums on a policy held in REGISTERS (element i in lane i & 63 of pv[i >> 6], the layout the expansion loads it in): NumPy's
 // order -- 8 strided accumulators r[j] = a[j] + a[8 + j] + ..., the fixed tree ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), then the
 // n % 8 tail -- with the strided terms fetched by ds_bpermute (all of them in flight together) instead of eight lanes walking an LDS
@@ -680,7 +738,7 @@ struct Forest {
             }
         }
         wave_sync();
-        float s = np_sum_f32(dense, A);
+        float s = np_sum_f32_static<A>(dense);
         for (int i = l; i < A; i += 64) dense[i] = dense[i] / s;
         wave_sync();
     }

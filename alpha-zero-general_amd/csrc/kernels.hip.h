@@ -494,7 +494,7 @@ __device__ __forceinline__ bool expand_apply(const ForestDev& F, int t, const Ex
     float s = 1.f;
     if (!dir_now) {
         if constexpr (SUM_IN_REGS) s = np_sum_regs<G::A>(in.pv);
-        else s = np_sum_f32(dense, G::A);
+        else s = np_sum_f32_static<G::A>(dense);
     }
     AZG_STAMP(2);
     // entry j belongs to the j-th valid action (the rank of its bit in the leaf's valid mask): no read of the record needed

@@ -4,6 +4,6 @@ pr() { python -c "import sys,json; d=json.loads(sys.stdin.read()); a=d['roofline
 for i in 1 2; do
   for v in "$@"; do
     lib=$R/alpha-zero-general_amd/libazg_hip.so; [ $v != base ] && lib=$R/build_ab/libazg_$v.so
-    AZG_LIB=$lib timeout 900 python bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline 2>/dev/null | tail -1 | pr $v
+    AZG_LIB=$lib timeout 900 python bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline ${AB_FLAGS:---no-sustained} 2>/dev/null | tail -1 | pr $v
   done
 done
