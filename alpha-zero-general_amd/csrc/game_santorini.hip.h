@@ -187,16 +187,50 @@ struct SantoriniDev {
         return false;
     }
 
-    __device__ static void valid_mask(const int8_t* st, int player, uint64_t* mask_lds) {
+    // the valid-move scan for `player`: fills mask_lds (may be null) and tells whether any action is valid
+    __device__ static bool scan_valid(const int8_t* st, int player, int god, bool opp_athena, const Workers& wk, uint64_t* mask_lds) {
         const int l = lane_id();
+        bool any = false;
+        if constexpr (NB == 1) {
+            for (int k = 0; k < AW; k++) {
+                const int a = k * 64 + l;
+                const uint64_t m = __ballot(a < A && valid_action(st, a < A ? a : 0, player, god, opp_athena, wk));
+                if (mask_lds && l == 0) mask_lds[k] = m;
+                any = any || m != 0ull;
+            }
+        } else {
+            // with gods: an action is (worker, power, move, build) and only the powers "none" and the player's own god can be valid, so
+            // 2 workers x 2 powers x 81 = 324 of the 1782 actions are evaluated (8 passes of the wave instead of 28) and their bits are
+            // placed into the mask words by lane 0 (a block of 81 does not start on a word boundary)
+            if (mask_lds) {
+                if (l < AW) mask_lds[l] = 0ull;
+                wave_sync();
+            }
+            if (god >= 0) {
+                for (int worker = 0; worker < 2; worker++)
+                    for (int pi = 0; pi < (god == NO_GOD ? 1 : 2); pi++) {
+                        const int base = (worker * NB + (pi == 0 ? (int)NO_GOD : god)) * 81;
+                        for (int p = 0; p < 2; p++) {
+                            const int i = 64 * p + l;
+                            const uint64_t m = __ballot(i < 81 && valid_action(st, base + (i < 81 ? i : 0), player, god, opp_athena, wk));
+                            any = any || m != 0ull;
+                            if (mask_lds && l == 0 && m) {
+                                const int first = base + 64 * p, w = first >> 6, o = first & 63;
+                                mask_lds[w] |= m << o;
+                                if (o && (m >> (64 - o))) mask_lds[w + 1] |= m >> (64 - o);
+                            }
+                        }
+                    }
+            }
+            if (mask_lds) wave_sync();
+        }
+        return any;
+    }
+    __device__ static void valid_mask(const int8_t* st, int player, uint64_t* mask_lds) {
         const int god = owned_god(st, player);
         const bool opp_athena = GP(st, ATHENA + NB * ((player + 1) % 2)) > 64;                      // :133
         const Workers wk = find_workers(st);
-        for (int k = 0; k < AW; k++) {
-            const int a = k * 64 + l;
-            const uint64_t m = __ballot(a < A && valid_action(st, a < A ? a : 0, player, god, opp_athena, wk));
-            if (l == 0) mask_lds[k] = m;
-        }
+        scan_valid(st, player, god, opp_athena, wk, mask_lds);
     }
     // Board.get_symmetries :578-653: identity, rot90 x1..3 (np.rot90: out[i][j] = in[j][4-i]), fliplr, flipud, swap of
     // the own workers, swap of the opponent's workers.  The Artemis / Demeter memo (65 + 9*worker + direction) follows
@@ -374,16 +408,10 @@ struct SantoriniDev {
         const int god = owned_god(st, next_player);
         const bool opp_athena = GP(st, ATHENA + NB * ((next_player + 1) % 2)) > 64;
         const Workers wk = find_workers(st);
-        // "no valid move for next_player" needs the valid-move scan: all AW passes are run and their ballots kept in mask_scratch, so that
+        // "no valid move for next_player" needs the valid-move scan: it is run once and its mask kept in mask_scratch, so that
         // the caller that asks for the valid mask of the same (state, player) right afterwards (create_leaf: MCTS.py:131 then :142) finds
         // it there instead of evaluating every action a second time (ENDED_FILLS_MASK)
-        bool any = false;
-        for (int k = 0; k < AW; k++) {
-            const int a = k * 64 + l;
-            const uint64_t m = __ballot(a < A && valid_action(st, a < A ? a : 0, next_player, god, opp_athena, wk));
-            if (mask_scratch && l == 0) mask_scratch[k] = m;
-            any = any || m != 0ull;
-        }
+        const bool any = scan_valid(st, next_player, god, opp_athena, wk, mask_scratch);
         if (!any) {
             if (next_player == 0) { out[0] = -1.f; out[1] = 1.f; }
             else { out[0] = 1.f; out[1] = -1.f; }
