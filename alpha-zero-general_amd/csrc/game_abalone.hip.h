@@ -83,14 +83,35 @@ struct AbaloneDev {
         }
         return false;
     }
+    // An action starts at a cell that holds one of the player's own marbles (:271-356 skip every other cell first): at most 14 of the 81
+    // cells.  The wave compacts those cells (two ballots over the board), then evaluates 64 (own cell, plane) pairs per pass -- <= 10
+    // passes instead of the 54 over all 3402 action ids -- and every valid lane sets its action's bit in the mask.
     __device__ static void valid_mask(const int8_t* st, int player, uint64_t* mask_lds) {
         const int l = lane_id();
-#pragma unroll 1
-        for (int k = 0; k < AW; k++) {
-            const int a = k * 64 + l;
-            const uint64_t m = __ballot(a < A && valid_action(st, a < A ? a : 0, player));
-            if (l == 0) mask_lds[k] = m;
+        for (int k = l; k < AW; k += 64) mask_lds[k] = 0ull;
+        const uint64_t b0 = __ballot(st[(l << 2) + player] != 0);                          // cells 0..63 (cell c = r * 9 + q, 4 bytes each)
+        const uint64_t b1 = __ballot(l < 81 - 64 && st[((l + 64) << 2) + player] != 0);    // cells 64..80
+        const int n_own = __popcll(b0) + __popcll(b1);
+        int mycell = 0;                                                                     // lane i: the i-th own cell
+        {
+            uint64_t w0 = b0, w1 = b1;
+            for (int i = 0; i < n_own; i++) {
+                int c;
+                if (w0) { c = __builtin_ctzll(w0); w0 &= w0 - 1; } else { c = 64 + __builtin_ctzll(w1); w1 &= w1 - 1; }
+                if (l == i) mycell = c;
+            }
         }
+        wave_sync();
+        const int n_pairs = n_own * 42;
+#pragma unroll 1
+        for (int base = 0; base < n_pairs; base += 64) {
+            const int x = base + l, ci = x / 42, plane = x - ci * 42;
+            const int c = __shfl(mycell, ci < 64 ? ci : 0, 64);
+            const int a = c * 42 + plane;
+            if (x < n_pairs && valid_action(st, a, player))
+                __hip_atomic_fetch_or((unsigned long long*)&mask_lds[a >> 6], 1ull << (a & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        wave_sync();
     }
 
     __device__ static __forceinline__ bool move_uses_seed(int) { return false; }
