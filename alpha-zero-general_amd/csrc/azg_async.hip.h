@@ -42,6 +42,9 @@ constexpr uint32_t ERR_ASYNC_TIMEOUT = 128;
 #define AZG_ASYNC_SEL_WAVES 16                /* waves of a descent workgroup: 16 (<= 128 VGPRs each) fills a CU; 12 (<= 168 VGPRs) measured in round 5 */
 #endif
 constexpr int ASYNC_SEL_WAVES = AZG_ASYNC_SEL_WAVES;
+#ifndef AZG_ASYNC_SCOUTS
+#define AZG_ASYNC_SCOUTS 1                  /* waves of a descent workgroup that may poll the ready words at the same time */
+#endif
 #ifndef AZG_IDLE_SLEEP
 #define AZG_IDLE_SLEEP 16                   /* s_sleep of a wave that found nothing ready and is not the scout (units of 64 cycles) */
 #endif
@@ -203,7 +206,13 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         if (!(c0 | c1)) {
             // nothing known to be ready: ONE wave of the workgroup (the scout) polls the ready words in HBM, the others sleep on the LDS copy
             uint32_t got = 0u;
-            if (l == 0) got = __hip_atomic_exchange(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u ? 1u : 0u;
+            if (l == 0) {
+                if (AZG_ASYNC_SCOUTS == 1) got = __hip_atomic_exchange(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u ? 1u : 0u;
+                else {          // up to AZG_ASYNC_SCOUTS polls in flight: a poll's answer is ~2 us old, a second one started meanwhile halves the gap
+                    got = __hip_atomic_fetch_add(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)AZG_ASYNC_SCOUTS ? 1u : 0u;
+                    if (!got) __hip_atomic_fetch_sub(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
             if (!uni_u32(got)) { __builtin_amdgcn_s_sleep(AZG_IDLE_SLEEP); continue; }
             const uint32_t v0 = l < n_g ? aload(my_ready + l) : 0u;
             const uint32_t v1 = l + 64 < n_g ? aload(my_ready + 64 + l) : 0u;
@@ -242,7 +251,10 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                 if (leave && l == 0) __hip_atomic_store(&C->retired, 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // everyone out
                 if (!leave) __builtin_amdgcn_s_sleep(AZG_SCOUT_SLEEP);
             }
-            if (l == 0) __hip_atomic_store(&C->scout, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (l == 0) {
+                if (AZG_ASYNC_SCOUTS == 1) __hip_atomic_store(&C->scout, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_fetch_sub(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             if (leave) break;
             if (!(c0 | c1)) continue;
         }
