@@ -16,6 +16,12 @@ if GAME == 'azul':
     g = games.AzulGame()
     net = nnet.MobileNet1dHip(nnet.AzulV84.from_npz(G + '/weights_azul_v84.npz', device='cuda:0'), max_batch=T)
     cap = 32 * 800 + 512
+elif GAME == 'santorini1':
+    from azg_amd import nnet
+    a = Args(numMCTSSims=800, cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True, dirichletAlpha=0.2, temperature=[1.25,0.8,1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0)
+    g = games.SantoriniGame(1)
+    net = nnet.SantoriniV89Hip(nnet.SantoriniV89.from_npz(G + '/weights_santorini1_v89.npz', device='cuda:0'), max_batch=T)
+    cap = 32 * 800 + 512
 elif GAME == 'santorini11':
     from azg_amd import nnet
     a = Args(numMCTSSims=800, cpuct=1.1, fpu=0.03, universes=0, forced_playouts=True, dirichletAlpha=0.2, temperature=[1.25,0.8,1.0], tempThreshold=6, ratio_fullMCTS=5, prob_fullMCTS=1.0)
