@@ -135,3 +135,38 @@ def test_minivilles_whole_tree_and_selfplay_vs_oracle():
             r = o['result']
             assert np.array_equal(zs[k], np.roll(r, -int(o['player'][ply])))
     f.close()
+
+
+@pytest.mark.parametrize('game_tag', [('minivilles', 'minivilles2_v82'), ('tlp', 'tlp3_v83')], ids=['minivilles_v82', 'tlp_v83'])
+def test_selfplay_with_the_shipped_engine_net(golden_dir, game_tag):
+    """Self-play of the two f4 games whose shipped nets are engine kernels (MobileNet1dHip on the reference's own checkpoints, the MCTS
+    arguments stored with them): the engine's forest with the one-launch net and with the same weights as PyTorch ops plays the same
+    first plies (the two evaluators agree to <= 1e-5, so a search may differ later where two PUCT scores tie within that), no engine
+    errors, structurally valid trees, examples for every finished game."""
+    from azg_amd import games, nnet
+    from azg_amd.selfplay import SelfPlayEngine
+    game, tag = game_tag
+    z = np.load(os.path.join(golden_dir, 'weights_%s.npz' % tag))
+    a = Args(numMCTSSims=50, cpuct=float(z['arg/cpuct']), fpu=float(z['arg/fpu']), universes=int(z['arg/universes']), forced_playouts=True,
+             prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.0, temperature=[1.25, 0.8, 1.0], tempThreshold=4)
+    T = 64
+    out = []
+    for engine_net in (True, False):
+        g = games.MinivillesGame(2) if game == 'minivilles' else games.TLPGame(3)
+        base = nnet.MobileNet1d.from_npz(os.path.join(golden_dir, 'weights_%s.npz' % tag), device='cuda:0')
+        assert (base.nb_vect * base.L, base.A, base.P) == (g.S, g.A, g.P)
+        net = nnet.MobileNet1dHip(base, max_batch=T) if engine_net else base
+        eng = SelfPlayEngine(g, net, a, n_games=T, node_capacity=2048, max_examples=T * 256, use_graph=False)
+        eng.start()
+        eng.run(6 * 50)
+        torch.cuda.synchronize()
+        st = eng.stats()
+        assert st['errors'] == 0 and st['plies'] >= 3 * T
+        assert sum(grp.f.validate() for grp in eng.groups) == 0
+        boards, pi, zz, valids, q, meta = eng.drain_examples(symmetries=False)
+        pi, valids = torch.as_tensor(pi).cpu().numpy(), torch.as_tensor(valids).cpu().numpy()
+        assert np.all(np.isfinite(pi)) and np.all(pi[valids == 0] == 0) and np.allclose(pi.sum(axis=1), 1.0, atol=1e-5)
+        out.append((st['plies'], st['sims']))
+        for grp in eng.groups:
+            grp.f.close()
+    assert abs(out[0][0] - out[1][0]) <= T        # the same pace of play with either evaluator
