@@ -703,8 +703,9 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
         // default split of the CUs.  V80: half and half (measured at 4096 x 800, whole games and the driver's window: 128 + 128 of 256
         // beats 120 / 124 / 132 / 136 for the net); V89: a forward of 8 leaves costs ~80 us of a CU, a descent ~33 us of a sixteenth of one:
         // 13 / 16 for the net (measured: 208 + 48 -> 28.8 k env-steps/s, 216 + 40 24.5 k, 204 + 52 28.7 k, 200 + 56 28.3 k; two kernels 26.5 k)
-        // Splendor 3 / 4 players (forward ~120 us per 8 leaves): as V89; Azul (descent-heavy: lane-0 env step, forward 30 us per 16): 3 / 8
-        n_net = net_kind == 0 ? n_cu / 2 : net_kind == 4 ? n_cu * 3 / 8 : n_cu * 13 / 16;
+        // Splendor 3 / 4 players (forward 55-59 us per 8 leaves, descent 27 us): 25 / 32 for the net (4 players: 200 + 56 -> 35.8 k, 208 + 48
+        // 33.1 k, 192 + 64 34.6 k); Azul (descent-heavy, forward 29 us per 16): 3 / 8 (96 + 160 -> 70.4 k; 112 + 144 68.6 k, 88 + 168 66.3 k)
+        n_net = net_kind == 0 ? n_cu / 2 : net_kind == 4 ? n_cu * 3 / 8 : (net_kind == 2 || net_kind == 3) ? n_cu * 25 / 32 : n_cu * 13 / 16;
         n_sel = n_cu - n_net;
     }
     if (n_sel > T) n_sel = T;

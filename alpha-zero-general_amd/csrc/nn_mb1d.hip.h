@@ -96,9 +96,12 @@ __device__ __forceinline__ void mb_gemm(const float* __restrict__ Wfrag, LoadB l
 // as they are read: 8 values = 20 VALU instructions per three MFMAs, which makes the phase VALU-bound at about a third of the f32
 // MFMA time.  loadB(rt, k0) returns the float4 at K offset k0; KCH32 chunks of 32 (the weights are zero beyond the real K, the LDS
 // holds finite numbers everywhere); `ds` = 2^-k / 64 brings the accumulator back.
+// (Round 5: the H2 kernels keep 64 * x in the LDS -- every writer of an activation scales it once, H2_AS, an exact power of two, and the few
+// readers that are not GEMM operands scale back -- so the split of a GEMM operand no longer multiplies: 12 instead of 20 VALU instructions
+// per 8 values, in every (column tile, row tile, K chunk) step; the outputs keep their bits.)
 __device__ __forceinline__ void mb_split8(float4 a, float4 b, uint4& hi, uint4& lo) {
-    h2_split2(a.x * H2_AS, a.y * H2_AS, hi.x, lo.x); h2_split2(a.z * H2_AS, a.w * H2_AS, hi.y, lo.y);
-    h2_split2(b.x * H2_AS, b.y * H2_AS, hi.z, lo.z); h2_split2(b.z * H2_AS, b.w * H2_AS, hi.w, lo.w);
+    h2_split2(a.x, a.y, hi.x, lo.x); h2_split2(a.z, a.w, hi.y, lo.y);
+    h2_split2(b.x, b.y, hi.z, lo.z); h2_split2(b.z, b.w, hi.w, lo.w);
 }
 template <int KCH32, int NT, int RTN, int NW, class LoadB, class Epi>
 __device__ __forceinline__ void mb_gemm_h2(const float* __restrict__ Wfrag_, float ds, LoadB loadB, Epi epi) {
@@ -194,6 +197,7 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
     constexpr int EP = mb_r16(CF::E[BI]), QP = mb_r16(CF::Q[BI]), COP = mb_r16(CF::CO[BI]);
     constexpr int ACT = CF::ACT[BI], PMAX = CF::PMAX[BI];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
+    constexpr float SA = H2 ? H2_AS : 1.f, ISA = H2 ? H2_IAS : 1.f;       // what the LDS holds of an activation x: SA * x
     for (int i = tid; i < L * L; i += NW * 64) WD[(i / L) * CF::WD_LD + i % L] = W.Wd[i];
     // ---- expand + BN + act -> H ----
     (void)g;
@@ -201,7 +205,7 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
         W.We, H2 ? ds[0] : 1.f, [&](int rt, int k0) { return *(const float4*)(IN + (rt * 16 + r16) * XS + k0); },
         [&](int ct, int rt, f32x4 acc) {
             const float4 b = *(const float4*)(W.be + ct * 16 + 4 * g);
-            const f32x2 lo = act_apply2(f32x2{acc[0] + b.x, acc[1] + b.y}, ACT), hi = act_apply2(f32x2{acc[2] + b.z, acc[3] + b.w}, ACT);
+            const f32x2 lo = act_apply2(f32x2{acc[0] + b.x, acc[1] + b.y}, ACT) * SA, hi = act_apply2(f32x2{acc[2] + b.z, acc[3] + b.w}, ACT) * SA;
             *(float4*)(H + (rt * 16 + r16) * HS + ct * 16 + 4 * g) = make_float4(lo.x, lo.y, hi.x, hi.y);
         });
     __syncthreads();
@@ -218,7 +222,7 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
             f32x2 in[L];
 #pragma unroll
             for (int l = 0; l < L; l++) in[l] = *(const f32x2*)(base + l * HS);
-            const f32x2 scl = *(const f32x2*)(W.sd + c), bb = *(const f32x2*)(W.bd + c);
+            const f32x2 scl = *(const f32x2*)(W.sd + c), bb = *(const f32x2*)(W.bd + c) * SA;      // (the sums below are SA * the reference's)
             f32x2 pool = PMAX ? f32x2{-INFINITY, -INFINITY} : f32x2{0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < L; m++) {
@@ -228,7 +232,7 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
                     if constexpr (CF::WD_REGS) a += wd[m * L + l] * in[l];
                     else a += WD[m * CF::WD_LD + l] * in[l];
                 }
-                a = act_apply2(a * scl + bb, ACT);
+                a = H2 ? act_apply2((a * scl + bb) * ISA, ACT) * SA : act_apply2(a * scl + bb, ACT);
                 *(f32x2*)(base + m * HS) = a;
                 if (PMAX) { pool.x = fmaxf(pool.x, a.x); pool.y = fmaxf(pool.y, a.y); } else pool += a;
             }
@@ -243,7 +247,7 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
         [&](int ct, int, f32x4 acc) {
             const float4 b = *(const float4*)(W.b1 + ct * 16 + 4 * g);
             *(float4*)(SH + r16 * QS + ct * 16 + 4 * g) =
-                make_float4(fmaxf(acc[0] + b.x, 0.f), fmaxf(acc[1] + b.y, 0.f), fmaxf(acc[2] + b.z, 0.f), fmaxf(acc[3] + b.w, 0.f));
+                make_float4(fmaxf(acc[0] + b.x, 0.f) * SA, fmaxf(acc[1] + b.y, 0.f) * SA, fmaxf(acc[2] + b.z, 0.f) * SA, fmaxf(acc[3] + b.w, 0.f) * SA);
         });
     __syncthreads();
     mb_gemm_any<H2, QP / 16, EP / 16, 1, NW>(
@@ -256,14 +260,28 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
             }
         });
     __syncthreads();
+    if constexpr (H2) {
+        // the SE scale goes into H once (in place), not into every read of the project GEMM -- each value was scaled (and its scale row
+        // read) once per column tile of the output
+        for (int i = tid; i < CF::ROWSP * (EP / 4); i += NW * 64) {
+            const int row = i / (EP / 4), k0 = 4 * (i - row * (EP / 4));
+            float4 a = *(const float4*)(H + row * HS + k0);
+            const float4 s4 = *(const float4*)(SC + (row / L) * HS + k0);
+            a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
+            *(float4*)(H + row * HS + k0) = a;
+        }
+        __syncthreads();
+    }
     // ---- project (SE-scaled operand) + BN (+ residual) -> OUT ----
     mb_gemm_any<H2, EP / 16, COP / 16, RT, NW>(
         W.Wp, H2 ? ds[3] : 1.f,
         [&](int rt, int k0) {
             const int row = rt * 16 + r16;
             float4 a = *(const float4*)(H + row * HS + k0);
-            const float4 s4 = *(const float4*)(SC + (row / L) * HS + k0);
-            a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
+            if constexpr (!H2) {
+                const float4 s4 = *(const float4*)(SC + (row / L) * HS + k0);
+                a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
+            }
             return a;
         },
         [&](int ct, int rt, f32x4 acc) {
@@ -272,9 +290,9 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
             float4 o = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
             if (residual) {
                 const float4 x = *(const float4*)(IN + row * XS + col0);
-                o.x += x.x; o.y += x.y; o.z += x.z; o.w += x.w;
+                o.x += x.x * ISA; o.y += x.y * ISA; o.z += x.z * ISA; o.w += x.w * ISA;
             }
-            *(float4*)(OUT + row * OSTRIDE + col0) = o;
+            *(float4*)(OUT + row * OSTRIDE + col0) = make_float4(o.x * SA, o.y * SA, o.z * SA, o.w * SA);
         });
     __syncthreads();
 }
@@ -307,6 +325,7 @@ __device__ __forceinline__ void mb1d_net_body(float* smem, const Mb1dNetWC Np, c
     constexpr int L = CF::L, C = CF::C, NS = CF::NS, NW = CF::NW, RT = CF::RT, XS = CF::XS, OS = CF::OS, HS = CF::HS, A = CF::A,
                   P = CF::P, AS = CF::AS, CP = CF::CP;
     if (H2) h2_fp16_saturate_mode();        // out-of-range activations saturate instead of becoming inf (inf * zero padding = NaN)
+    constexpr float SA = H2 ? H2_AS : 1.f;  // what the LDS holds of an activation x: SA * x (mb_split8)
     float* XA = smem;                       // first-layer output, later the head blocks' output O (row stride OS)
     float* X2 = XA + CF::XA_SZ;             // trunk output
     float* H = X2 + CF::X2_SZ;              // expanded activations; board tile before, head temporaries after
@@ -340,9 +359,9 @@ __device__ __forceinline__ void mb1d_net_body(float* smem, const Mb1dNetWC Np, c
             if constexpr (IND) {
                 const int b = sidx[s];
                 X0[(s * L + l) * XS + c] =
-                    b >= 0 ? (float)(int8_t)__hip_atomic_load((const uint8_t*)boards + (size_t)b * AL_STRIDE + rem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                    b >= 0 ? SA * (float)(int8_t)__hip_atomic_load((const uint8_t*)boards + (size_t)b * AL_STRIDE + rem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
             } else
-            X0[(s * L + l) * XS + c] = (float)src[i];
+            X0[(s * L + l) * XS + c] = SA * (float)src[i];
         }
     }
     __syncthreads();
@@ -351,7 +370,7 @@ __device__ __forceinline__ void mb1d_net_body(float* smem, const Mb1dNetWC Np, c
         N.W0, N.ds[0], [&](int rt, int k0) { return *(const float4*)(X0 + (rt * 16 + r16) * XS + k0); },
         [&](int ct, int rt, f32x4 acc) {
             const float4 b = *(const float4*)(N.b0 + ct * 16 + 4 * g);
-            *(float4*)(XA + (rt * 16 + r16) * XS + ct * 16 + 4 * g) = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
+            *(float4*)(XA + (rt * 16 + r16) * XS + ct * 16 + 4 * g) = make_float4((acc[0] + b.x) * SA, (acc[1] + b.y) * SA, (acc[2] + b.z) * SA, (acc[3] + b.w) * SA);
         });
     __syncthreads();
     {
@@ -380,7 +399,7 @@ __device__ __forceinline__ void mb1d_net_body(float* smem, const Mb1dNetWC Np, c
                 const float4 p = *(const float4*)(RED + (k * 16 + s) * AS + col);
                 v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
             }
-            *(float4*)(HID + s * AS + col) = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            *(float4*)(HID + s * AS + col) = make_float4(fmaxf(v.x, 0.f) * SA, fmaxf(v.y, 0.f) * SA, fmaxf(v.z, 0.f) * SA, fmaxf(v.w, 0.f) * SA);
         }
         __syncthreads();
         const int ks2 = H2 ? mb_head_gemm_h2<(NT1 + 1) / 2, NT1, NW, AS, 16>(N.Wpi2, N.ds[14], HID, AS, RED)
