@@ -282,8 +282,10 @@ __device__ __forceinline__ void advance_tree(const ForestDev& F, const int t, ty
     for (int p = 0; p < G::P; p++) q[p] = 0.f;
     root_counts<G>(F, t, H, cnt, q);
     // ---- pi with temp = 1 (MCTS.py:100-103), then random_pick with the self-play temperature (Coach.py:62-63) ----
-    long long tot = 0;
-    for (int a = 0; a < G::A; a++) tot += cnt[a];
+    long long tot = 0;                          // (integer: any order; every lane ends with the total)
+    for (int a = l; a < G::A; a += 64) tot += cnt[a];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) tot += (long long)shfl_xor_u64((uint64_t)tot, m);
     if (tot == 0) {
         // policy-target pruning left no count above 1 (too few simulations for the number of valid actions): the reference computes 0 / 0 and
         // raises at MCTS.py:100-102.  Park the tree with an error flag instead of playing an arbitrary move.
@@ -300,28 +302,42 @@ __device__ __forceinline__ void advance_tree(const ForestDev& F, const int t, ty
         w[a] = (T == 0.0) ? p : pow(p, 1.0 / T);
     }
     wave_sync();
-    int action = 0;
-    if (l == 0) {
-        if (T == 0.0) {                                                    // uniform among the maxima (Coach.py:279-282)
-            double mx = -1.0; int nb = 0;
-            for (int a = 0; a < G::A; a++) mx = w[a] > mx ? w[a] : mx;
-            for (int a = 0; a < G::A; a++) nb += w[a] == mx;
-            int k = (int)(u_pick * nb); k = k >= nb ? nb - 1 : k;
-            for (int a = 0; a < G::A; a++) if (w[a] == mx) { if (k-- == 0) { action = a; break; } }
-        } else {
-            double s = 0.0;
-            for (int a = 0; a < G::A; a++) s += w[a];
-            double tot2 = 0.0;
-            for (int a = 0; a < G::A; a++) tot2 += w[a] / s;
-            double cdf = 0.0; int pick = -1, last = 0;
-            for (int a = 0; a < G::A; a++) {
-                double pa = w[a] / s;
-                cdf += pa;
-                if (pa > 0) last = a;
-                if (cdf / tot2 > u_pick) { pick = a; break; }
+    // The reference's sums run over all A entries in index order; an entry without visits is 0.0 and leaves every running f64 sum as it
+    // is, so only the actions with visits take part: per 64 actions one ballot says which have any, and the wave -- every lane the same
+    // arithmetic on broadcast reads -- steps through those in ascending order: a few dozen steps instead of three passes of one lane over
+    // 1782 / 3402 / 4056 entries with two f64 divisions each.
+    auto visited = [&](auto&& fn) {            // fn(a) for every a with w[a] != 0, ascending, until it returns false
+        for (int base = 0; base < G::A; base += 64) {
+            const int a = base + l;
+            uint64_t m = __ballot(a < G::A && w[a < G::A ? a : 0] != 0.0);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                if (!fn(base + b)) return;
             }
-            action = pick < 0 ? last : pick;
         }
+    };
+    int action = 0;
+    if (T == 0.0) {                                                        // uniform among the maxima (Coach.py:279-282)
+        double mx = -1.0; int nb = 0;
+        visited([&](int a) { mx = w[a] > mx ? w[a] : mx; return true; });
+        visited([&](int a) { nb += w[a] == mx; return true; });
+        int k = (int)(u_pick * nb); k = k >= nb ? nb - 1 : k;
+        visited([&](int a) { if (w[a] == mx) { if (k-- == 0) { action = a; return false; } } return true; });
+    } else {
+        double s = 0.0;
+        visited([&](int a) { s += w[a]; return true; });
+        double tot2 = 0.0;
+        visited([&](int a) { tot2 += w[a] / s; return true; });
+        double cdf = 0.0; int pick = -1, last = 0;
+        visited([&](int a) {
+            const double pa = w[a] / s;
+            cdf += pa;
+            if (pa > 0) last = a;
+            if (cdf / tot2 > u_pick) { pick = a; return false; }
+            return true;
+        });
+        action = pick < 0 ? last : pick;
     }
     action = __shfl(action, 0, 64);
     // ---- record the example on full searches (Coach.py:65-69; symmetries are applied by the consumer) ----
