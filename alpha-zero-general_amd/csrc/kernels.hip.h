@@ -1003,7 +1003,17 @@ __global__ __launch_bounds__(64) void k_action_probs(ForestDev F, double temp, d
     }
     double s = 0.0;                                                                              // :100-103 sequential sum
     const double e = 1.0 / temp;
-    for (int a = 0; a < G::A; a++) s += (temp == 1.0) ? (double)cnt[a] : pow((double)cnt[a], e);
+    // (in index order over the actions with a count: a zero count contributes 0.0 -- or 0.0 ** e = 0.0 -- and leaves the sum as it is;
+    // every lane steps through the same actions, one ballot per 64 of them, instead of evaluating all A powers itself)
+    for (int base = 0; base < G::A; base += 64) {
+        const int a = base + l;
+        uint64_t m = __ballot(a < G::A && cnt[a < G::A ? a : 0] != 0);
+        while (m) {
+            const int b = base + __builtin_ctzll(m);
+            m &= m - 1;
+            s += (temp == 1.0) ? (double)cnt[b] : pow((double)cnt[b], e);
+        }
+    }
     for (int a = l; a < G::A; a += 64) pr[a] = ((temp == 1.0) ? (double)cnt[a] : pow((double)cnt[a], e)) / s;
 }
 
