@@ -45,6 +45,7 @@ constexpr int ASYNC_SEL_WAVES = AZG_ASYNC_SEL_WAVES;
 #ifndef AZG_ASYNC_SCOUTS
 #define AZG_ASYNC_SCOUTS 1                  /* waves of a descent workgroup that may poll the ready words at the same time */
 #endif
+constexpr uint32_t ASYNC_IDLE_STEP_CAP = 100000u;          // 1 ms in 10-ns ticks: what one pass of a waiting loop can add to its idle time
 #ifndef AZG_IDLE_SLEEP
 #define AZG_IDLE_SLEEP 16                   /* s_sleep of a wave that found nothing ready and is not the scout (units of 64 cycles) */
 #endif
@@ -106,6 +107,7 @@ struct AsyncSelLds {
     uint32_t pad[3];
     unsigned long long prof[6];                // calls, busy ticks, idle ticks, ready-wait sum, shader cycles inside the descents, plies advanced
     uint32_t hist[32];
+    uint32_t idle_acc[16], idle_last[16];      // per wave: time spent looking for work since it last handled a tree / its last clock read
     uint32_t rw[ASYNC_RS];                     // the scout's snapshot of the ready words (calls left + 1; 0 = not ready)
     uint32_t rts[ASYNC_RS];                    // ... and of the time stamps the net wrote beside them (profile: how long a ready tree waits)
     uint32_t last[ASYNC_RS];                   // the ready word this workgroup consumed last for tree i: a tree's words DECREASE over a launch,
@@ -193,7 +195,13 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
     uint8_t* const mine = lds + wave * RL::STRIDE;
     typename RL::Smem& sm = *(typename RL::Smem*)mine;
     float* const dense = (float*)(mine + RL::DENSE_OFF);
-    uint32_t idle_since = wall32();                 // (profile sums live in the LDS block: nothing but this word is carried around the loop)
+    uint32_t idle_since = wall32();                 // (profile sums live in the LDS block: nothing but these words are carried around the loop)
+    // The idle time-out counts the time this wave has itself SPENT looking for work: the clock advance between two passes of its loop,
+    // capped at 1 ms per pass.  A wave that was not running -- the whole GPU held up for seconds by a driver operation (a 200 GB forest of
+    // the previous engine being unmapped), a clock that jumped -- has not been idle, and must not abort the launch: one full-size test in
+    // eight did, with the plain difference of two clock reads.
+    // (The two words live in the LDS, AsyncSelLds::idle_acc / idle_last: as registers carried around the loop they cost the descent 0.8 us.)
+    if (lane_id() == 0) { C->idle_acc[wave] = 0u; C->idle_last[wave] = idle_since; }
 #define AZG_LDS_LD64(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define AZG_LDS_LD32(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #pragma unroll 1
@@ -213,7 +221,15 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                     if (!got) __hip_atomic_fetch_sub(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            if (!uni_u32(got)) { __builtin_amdgcn_s_sleep(AZG_IDLE_SLEEP); continue; }
+            if (!uni_u32(got)) {                        // (the clock is read on passes that found nothing only: never in front of a claim)
+                if (l == 0) {
+                    const uint32_t now = wall32(), d = now - C->idle_last[wave];
+                    C->idle_acc[wave] += d < ASYNC_IDLE_STEP_CAP ? d : ASYNC_IDLE_STEP_CAP;
+                    C->idle_last[wave] = now;
+                }
+                __builtin_amdgcn_s_sleep(AZG_IDLE_SLEEP);
+                continue;
+            }
             const uint32_t v0 = l < n_g ? aload(my_ready + l) : 0u;
             const uint32_t v1 = l + 64 < n_g ? aload(my_ready + 64 + l) : 0u;
             {
@@ -243,8 +259,15 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
             if (!(c0 | c1)) {
                 const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
                 const uint32_t now = wall32();
+                uint32_t acc = 0u;
+                if (l == 0) {
+                    const uint32_t d = now - C->idle_last[wave];
+                    acc = C->idle_acc[wave] + (d < ASYNC_IDLE_STEP_CAP ? d : ASYNC_IDLE_STEP_CAP);
+                    C->idle_acc[wave] = acc; C->idle_last[wave] = now;
+                }
+                acc = uni_u32(acc);
                 if (uni_u32(aload(&A->ctl->abort))) leave = true;
-                else if ((int)(now - idle_since) > timeout) {                  // (this wave has found nothing to do for that long)
+                else if (acc > (uint32_t)timeout) {                        // (this wave has looked for work for that long and found none)
                     if (l == 0) { astore(&A->ctl->abort, 1u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT); }
                     leave = true;
                 }
@@ -391,6 +414,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
             }
         }
         idle_since = wall32();
+        if (lane_id() == 0) { C->idle_acc[wave] = 0u; C->idle_last[wave] = idle_since; }
     }
     if (lane_id() == 0) atomicAdd(&C->prof[2], (unsigned long long)(wall32() - idle_since));
     __syncthreads();
@@ -474,6 +498,7 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
             const int T = A->F.T, wait_ticks = A->batch_wait, timeout = A->timeout_ticks;
             const uint32_t rb = (uint32_t)A->ring_bits, rmask = (1u << rb) - 1u;
             const uint32_t idle0 = wall32();
+            uint32_t idle_acc = 0u, idle_last = idle0;                           // (time spent waiting, 1 ms per pass at most: see k_async_select)
             uint32_t base = (uint32_t)sidx[34], taken = (uint32_t)sidx[35];
             if (!sidx[36]) {
                 uint32_t b = 0u;
@@ -492,11 +517,12 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
                 e = lane < BS ? __hip_atomic_load(A->ring + (tk & rmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                 const uint32_t filled = (uint32_t)__ballot(lane < BS && (uint32_t)(e >> 60) == tag) & ~taken;
                 const uint32_t now = wall32();
+                { const uint32_t d = now - idle_last; idle_acc += d < ASYNC_IDLE_STEP_CAP ? d : ASYNC_IDLE_STEP_CAP; idle_last = now; }
                 if (filled && !seen) { seen = true; first_seen = now; }
                 if (filled && ((filled | taken) == FULL || (int)(now - first_seen) >= wait_ticks)) { take = filled; n = __popc(filled); break; }
                 if (!filled && (++spins & 7u) == 0u) {
                     if (uni_u32(aload(&ctl->retired)) >= (uint32_t)T || uni_u32(aload(&ctl->abort))) { n = -1; break; }
-                    if ((int)(now - idle0) > timeout) {                              // (no leaf for that long)
+                    if (idle_acc > (uint32_t)timeout) {                              // (no leaf for that long)
                         if (lane == 0) { astore(&ctl->abort, 2u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT); }
                         n = -1;
                         break;
@@ -772,7 +798,7 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
         want.rounds = (1 << 24) - 2;
     }
     want.batch_wait = batch_wait_ticks >= 0 ? batch_wait_ticks : 150;
-    { const char* e = getenv("AZG_ASYNC_TIMEOUT_MS"); want.timeout_ticks = (e ? atoi(e) : 2000) * 100000; }
+    { const char* e = getenv("AZG_ASYNC_TIMEOUT_MS"); int ms = e ? atoi(e) : 2000; ms = ms < 1 ? 1 : (ms > 20000 ? 20000 : ms); want.timeout_ticks = ms * 100000; }   // (32-bit ticks of 10 ns: <= 20 s)
     hipStream_t s = (hipStream_t)stream;
     if (memcmp(&sl->host, &want, sizeof(want)) != 0) {
         sl->host = want;
