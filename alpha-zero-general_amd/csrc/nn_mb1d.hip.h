@@ -40,7 +40,7 @@ struct Mb1dCfg {
     static constexpr int ROWS = NS * L, ROWSP = mb_r16(ROWS), RT = ROWSP / 16;
     static constexpr int CP = mb_r16(C), XS = CP + 4;
     static constexpr int COPmax = mb_r16(CO1 > C_ ? CO1 : C_), OS = COPmax + 4;     // head block output row stride
-    static constexpr int EPmax = mb_r16(E0 > E1 ? (E0 > E2 ? E0 : E2) : (E1 > E2 ? E1 : E2)), HS = EPmax + 4;
+    static constexpr int EPmax = mb_r16(E0 > E1 ? (E0 > E2 ? E0 : E2) : (E1 > E2 ? E1 : E2)), HS = EPmax + 28;     // (+28: = 4 mod 8 floats, and room for the project GEMM's f16 planes of its K-padded operand, mb_block)
     static constexpr int QPmax = mb_r16(Q0 > Q1 ? (Q0 > Q2 ? Q0 : Q2) : (Q1 > Q2 ? Q1 : Q2)), QS = QPmax + 4;
     static constexpr int AP = mb_r16(A), AS = AP + 4;
     // LDS map (floats)
@@ -124,6 +124,35 @@ __device__ __forceinline__ void mb_gemm_h2(const float* __restrict__ Wfrag_, flo
         for (int c = 0; c < KCH32; c++) {
             uint4 ah, al;
             mb_split8(loadB(rt, 32 * c + 8 * g), loadB(rt, 32 * c + 8 * g + 4), ah, al);
+            if (c & 1) a1 = h2_mma(wh[c], wl[c], ah, al, a1); else a0 = h2_mma(wh[c], wl[c], ah, al, a0);
+        }
+        epi(ct, rt, (a0 + a1) * ds);
+    }
+}
+// The same GEMM phase with the B operand already split: two f16 planes (hi, lo) of row stride PRS halves in LDS -- a K chunk of a row
+// tile is two 16-byte reads and no VALU work at all.  Used for the project GEMM, whose operand (the expanded tile times the SE scale) is
+// written once per block and read once per column tile of the output.
+template <int KCH32, int NT, int RTN, int NW, int PRS, class Epi>
+__device__ __forceinline__ void mb_gemm_h2p(const float* __restrict__ Wfrag_, float ds, const uint8_t* __restrict__ hi, const uint8_t* __restrict__ lo, Epi epi) {
+    const uint4* __restrict__ Wfrag = (const uint4*)Wfrag_;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    constexpr int U = NT * RTN;
+    const int u0 = wave * U / NW, u1 = (wave + 1) * U / NW;
+    uint4 wh[KCH32], wl[KCH32];
+    int cur = -1;
+#pragma unroll 1
+    for (int u = u0; u < u1; u++) {
+        const int ct = u / RTN, rt = u - ct * RTN;
+        if (ct != cur) {
+#pragma unroll
+            for (int c = 0; c < KCH32; c++) { wh[c] = H2FRAG(Wfrag, KCH32, ct, c, 0); wl[c] = H2FRAG(Wfrag, KCH32, ct, c, 1); }
+            cur = ct;
+        }
+        const int off = ((rt * 16 + r16) * PRS + 8 * g) * 2;
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int c = 0; c < KCH32; c++) {
+            const uint4 ah = *(const uint4*)(hi + off + 64 * c), al = *(const uint4*)(lo + off + 64 * c);
             if (c & 1) a1 = h2_mma(wh[c], wl[c], ah, al, a1); else a0 = h2_mma(wh[c], wl[c], ah, al, a0);
         }
         epi(ct, rt, (a0 + a1) * ds);
@@ -260,31 +289,44 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
             }
         });
     __syncthreads();
+    // the project GEMM's K extent (chunks of 32) and the row stride of its operand planes: + 8 halves = conflict-free 16-byte reads
+    constexpr int KP32 = (EP / 16 + 1) / 2, EPK = 32 * KP32, PRS = EPK + 8;
+    static_assert(!H2 || (PRS * 4 <= HS * 4 && PRS % 8 == 0), "the two f16 planes fit the expanded tile");
+    uint8_t* const PHI = (uint8_t*)H;
+    uint8_t* const PLO = PHI + CF::ROWSP * PRS * 2;
     if constexpr (H2) {
-        // the SE scale goes into H once (in place), not into every read of the project GEMM -- each value was scaled (and its scale row
-        // read) once per column tile of the output
-        for (int i = tid; i < CF::ROWSP * (EP / 4); i += NW * 64) {
-            const int row = i / (EP / 4), k0 = 4 * (i - row * (EP / 4));
-            float4 a = *(const float4*)(H + row * HS + k0);
-            const float4 s4 = *(const float4*)(SC + (row / L) * HS + k0);
-            a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
-            *(float4*)(H + row * HS + k0) = a;
+        // The operand of the project GEMM, (expanded tile) x (SE scale), is formed ONCE, split into its f16 hi / lo planes, and written
+        // over the expanded tile: every thread first loads its share of the products (registers), the workgroup meets, then the planes are
+        // stored (the same values, the same split as when the GEMM split them as it read them: the outputs keep their bits).  Columns
+        // EP .. EPK of the K padding are zeroed: the weights there are zero, but a stale bit pattern read as f16 may be a NaN.
+        constexpr int Q4 = EPK / 4, TOT = CF::ROWSP * Q4, NE = (TOT + NW * 64 - 1) / (NW * 64);
+        float4 v[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const int i = tid + e * NW * 64, row = i / Q4, k0 = 4 * (i - row * Q4);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < TOT && k0 < EP) {
+                a = *(const float4*)(H + row * HS + k0);
+                const float4 s4 = *(const float4*)(SC + (row / L) * HS + k0);
+                a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
+            }
+            v[e] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const int i = tid + e * NW * 64, row = i / Q4, k0 = 4 * (i - row * Q4);
+            if (i < TOT) {
+                uint32_t h0, l0, h1, l1;
+                h2_split2(v[e].x, v[e].y, h0, l0); h2_split2(v[e].z, v[e].w, h1, l1);
+                *(uint2*)(PHI + (row * PRS + k0) * 2) = make_uint2(h0, h1);
+                *(uint2*)(PLO + (row * PRS + k0) * 2) = make_uint2(l0, l1);
+            }
         }
         __syncthreads();
     }
     // ---- project (SE-scaled operand) + BN (+ residual) -> OUT ----
-    mb_gemm_any<H2, EP / 16, COP / 16, RT, NW>(
-        W.Wp, H2 ? ds[3] : 1.f,
-        [&](int rt, int k0) {
-            const int row = rt * 16 + r16;
-            float4 a = *(const float4*)(H + row * HS + k0);
-            if constexpr (!H2) {
-                const float4 s4 = *(const float4*)(SC + (row / L) * HS + k0);
-                a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
-            }
-            return a;
-        },
-        [&](int ct, int rt, f32x4 acc) {
+    auto project_epi = [&](int ct, int rt, f32x4 acc) {
             const int row = rt * 16 + r16, col0 = ct * 16 + 4 * g;
             const float4 b = *(const float4*)(W.bp + col0);
             float4 o = make_float4(acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w);
@@ -293,7 +335,19 @@ __device__ __forceinline__ void mb_block(const Mb1dBlockW& W, const float* IN, f
                 o.x += x.x * ISA; o.y += x.y * ISA; o.z += x.z * ISA; o.w += x.w * ISA;
             }
             *(float4*)(OUT + row * OSTRIDE + col0) = make_float4(o.x * SA, o.y * SA, o.z * SA, o.w * SA);
-        });
+        };
+    if constexpr (H2) mb_gemm_h2p<KP32, COP / 16, RT, NW, PRS>(W.Wp, ds[3], PHI, PLO, project_epi);
+    else
+        mb_gemm<EP / 16, COP / 16, RT, NW>(
+            W.Wp,
+            [&](int rt, int c) {
+                const int row = rt * 16 + r16, k0 = 16 * c + 4 * g;
+                float4 a = *(const float4*)(H + row * HS + k0);
+                const float4 s4 = *(const float4*)(SC + (row / L) * HS + k0);
+                a.x *= s4.x; a.y *= s4.y; a.z *= s4.z; a.w *= s4.w;
+                return a;
+            },
+            project_epi);
     __syncthreads();
 }
 
