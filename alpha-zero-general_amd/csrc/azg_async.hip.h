@@ -798,7 +798,7 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
         want.rounds = (1 << 24) - 2;
     }
     want.batch_wait = batch_wait_ticks >= 0 ? batch_wait_ticks : 150;
-    { const char* e = getenv("AZG_ASYNC_TIMEOUT_MS"); int ms = e ? atoi(e) : 2000; ms = ms < 1 ? 1 : (ms > 20000 ? 20000 : ms); want.timeout_ticks = ms * 100000; }   // (32-bit ticks of 10 ns: <= 20 s)
+    { const char* e = getenv("AZG_ASYNC_TIMEOUT_MS"); int ms = e ? atoi(e) : 20000; ms = ms < 1 ? 1 : (ms > 20000 ? 20000 : ms); want.timeout_ticks = ms * 100000; }   // (32-bit ticks of 10 ns: <= 20 s)
     hipStream_t s = (hipStream_t)stream;
     if (memcmp(&sl->host, &want, sizeof(want)) != 0) {
         sl->host = want;

@@ -186,7 +186,7 @@ int azg_forest_rounds_profile(azg_forest* f, double* out4, int reset);
    be resident; <= 0: a default split); the split may change from call to call.  Per-tree results are identical bit for bit to
    `rounds` x (azg_forest_select_fused -> azg_selfplay_advance -> azg_nn_v80_forward_h2) with shared_budget == 0 (tests/test_gpu_selfplay.py).
    leaf_valid_dev u8[T][A], needs_eval_dev u8[T], pi_dev f32[T][A], v_dev f32[T][P]: as for azg_forest_select_fused (the leaf states
-   travel through a buffer the forest owns).  A pipeline that stops making progress for AZG_ASYNC_TIMEOUT_MS (2000) sets error bit 128
+   travel through a buffer the forest owns).  A pipeline that stops making progress for AZG_ASYNC_TIMEOUT_MS (20000; at most 20000) sets error bit 128
    (azg_selfplay_stats.errors) and ends the kernels. */
 int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev,
                                    int noise_stride, const void* const* w, const float* descale_host, int rounds, int n_net, int n_sel,

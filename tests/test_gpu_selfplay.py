@@ -739,18 +739,20 @@ def test_full_size_properties_other_configs(game_key, sims, cap):
     assert net_kind == 'hip' and int(margs['numMCTSSims']) == sims
     if game_key == 'azul':
         assert float(margs['dirichletAlpha']) < 0          # the automatic alpha: root noise is on
-    eng.start()
-    eng.run(3 * sims + 64)
-    st = eng.stats()
-    assert st['errors'] == 0
-    assert 2 * T <= st['plies'] <= 4 * T                 # every tree is in its 3rd or 4th search
-    assert st['sims'] >= st['expansions'] > 0
-    assert eng.forest.validate(verbose=False) == 0
-    rs = eng.forest.root_stats()
-    Ns, Nsa = rs['Ns'].cpu().numpy().astype(np.int64), rs['Nsa'].cpu().numpy().astype(np.int64)
-    has_root = Ns > 0
-    assert has_root.mean() > 0.9
-    assert np.array_equal(Nsa.sum(axis=1)[has_root], Ns[has_root])
-    eng.close()
-    del eng
-    torch.cuda.empty_cache()
+    try:                                                 # (the forest is 140-230 GB: it must be gone before the next case, whatever happens)
+        eng.start()
+        eng.run(3 * sims + 64)
+        st = eng.stats()
+        assert st['errors'] == 0, (st['errors'], eng.forest.async_profile()['ctl'] if getattr(eng, 'async_pipe', False) else None)
+        assert 2 * T <= st['plies'] <= 4 * T                 # every tree is in its 3rd or 4th search
+        assert st['sims'] >= st['expansions'] > 0
+        assert eng.forest.validate(verbose=False) == 0
+        rs = eng.forest.root_stats()
+        Ns, Nsa = rs['Ns'].cpu().numpy().astype(np.int64), rs['Nsa'].cpu().numpy().astype(np.int64)
+        has_root = Ns > 0
+        assert has_root.mean() > 0.9
+        assert np.array_equal(Nsa.sum(axis=1)[has_root], Ns[has_root])
+    finally:
+        eng.close()
+        del eng
+        torch.cuda.empty_cache()

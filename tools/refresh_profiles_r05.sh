@@ -6,7 +6,7 @@ O=$R/gpurun_out/r05prof; mkdir -p $O
 PARTS=${@:-tests bench prof sant games variants phases}
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 cd $R
-if has tests; then python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest.txt; fi
+if has tests; then python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -40 > $O/pytest_tail.txt; tail -3 $O/pytest_tail.txt > $O/pytest.txt; fi
 if has bench; then
   python bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err      # the driver's flags (pipeline; whole-games leg; Santorini; CPU baseline)
   python bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline --no-sustained 2>/dev/null | tail -1 > $O/bench_driver_repeat.json
