@@ -136,6 +136,22 @@ struct SmallworldDev {
         }
         return n;
     }
+    // the same with the two sums over the people's territories already known (the valid-move scan forms them in one pass over the areas)
+    __device__ static int ppl_virtually_available_u(int old, const int8_t* cp, int next_status, int surplus, int total_ppl) {
+        int n = cp[0];
+        if (old == PHASE_READY && in3(next_status, PHASE_ABANDON, PHASE_CONQUEST, PHASE_CONQ_WITH_DICE)) n += surplus;
+        else if ((old == PHASE_READY || old == PHASE_ABANDON || old == PHASE_CONQUEST || old == PHASE_CONQ_WITH_DICE || old == PHASE_ABANDON_AMAZONS) &&
+                 next_status == PHASE_REDEPLOY) n += surplus;
+        if (cp[1] == AMAZON) {
+            if (in3(old, PHASE_CONQUEST, PHASE_CONQ_WITH_DICE, PHASE_ABANDON_AMAZONS) && next_status == PHASE_REDEPLOY) { if (cp[3] != 0) n -= cp[3]; }
+            else if (in3(old, PHASE_READY, PHASE_CHOOSE, PHASE_ABANDON) && next_status == PHASE_CONQUEST) { if (cp[3] == 0) n += 4; }
+        } else if (cp[1] == SKELETON) {
+            if ((in3(old, PHASE_READY, PHASE_CHOOSE, PHASE_ABANDON) || in3(old, PHASE_CONQUEST, PHASE_CONQ_WITH_DICE, PHASE_ABANDON_AMAZONS)) &&
+                next_status == PHASE_REDEPLOY)
+                if (cp[3] == 0) { const int add = cp[3] / 2, room = MAX_SKELETONS - total_ppl; n += add < room ? add : room; }
+        }
+        return n;
+    }
     __device__ static int enough_amazons_to_redeploy(const int8_t* s, int player, const int8_t* cp) {                  /* :1434-1440 */
         if (cp[1] == AMAZON && ppl_virtually_available(s, player, cp, PHASE_REDEPLOY, occupied_by(s, cp)) < 0) return 0;
         return 1;
@@ -613,15 +629,25 @@ struct SmallworldDev {
         u.cp = current_ppl(s, player);
         u.phase = RS(s, player)[4];
         u.early = u.phase == PHASE_READY || u.phase == PHASE_CHOOSE || u.phase == PHASE_ABANDON || u.phase == PHASE_CONQUEST;
-        u.terr = occupied_by(s, u.cp);
-        u.nt = __popcll((unsigned long long)u.terr);
-        u.avail_conq = ppl_virtually_available(s, player, u.cp, PHASE_CONQUEST, u.terr);
-        u.avail_redeploy = ppl_virtually_available(s, player, u.cp, PHASE_REDEPLOY, u.terr);
-        u.enough_amazons = !(u.cp[1] == AMAZON && u.avail_redeploy < 0);                   // _enough_amazons_to_redeploy :1434-1440
-        u.total_ppl = total_number_of_ppl(s, u.cp, u.terr);
-        u.neigh = 0; u.cavern_owned = 0;
+        // one pass over the areas (one 8-byte row each): the people's territories, their surplus and their head count, their neighbourhood
+        u.terr = 0; u.neigh = 0; u.cavern_owned = 0;
+        int surplus = 0, on_board = 0;
+        const int8_t cp1 = u.cp[1];
 #pragma unroll
-        for (int i = 0; i < NA; i++) if ((u.terr >> i) & 1) { u.neigh |= SW_CONN_(i); u.cavern_owned |= CAVERN(i); }
+        for (int a = 0; a < NA; a++) {
+            const uint64_t row = *(const uint64_t*)T(s, a);
+            const int t0 = (int8_t)row;
+            if ((int8_t)(row >> 8) == cp1) {
+                u.terr |= 1ull << a; u.neigh |= SW_CONN_(a); u.cavern_owned |= CAVERN(a);
+                on_board += t0;
+                if (t0 > 1) surplus += t0 - 1;
+            }
+        }
+        u.nt = __popcll((unsigned long long)u.terr);
+        u.total_ppl = u.cp[0] + on_board;
+        u.avail_conq = ppl_virtually_available_u(u.phase, u.cp, PHASE_CONQUEST, surplus, u.total_ppl);
+        u.avail_redeploy = ppl_virtually_available_u(u.phase, u.cp, PHASE_REDEPLOY, surplus, u.total_ppl);
+        u.enough_amazons = !(u.cp[1] == AMAZON && u.avail_redeploy < 0);                   // _enough_amazons_to_redeploy :1434-1440
         u.water_mask = terrain_mask(WATER); u.mountain_mask = terrain_mask(MOUNTAIN);
         return u;
     }
