@@ -95,6 +95,28 @@ __device__ __forceinline__ uint32_t wall32() { return (uint32_t)wall_clock64(); 
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 #ifdef AZG_ASYNC_PART_SELECT     /* the descent kernel: azg_async_sel.hip */
+// The forest descriptor reaches the persistent kernel through a device buffer (constant address space), not as a kernel argument: the
+// compiler then knows nothing about the pointers inside it and every access of the descent became a FLAT instruction (45 flat_load,
+// 59 flat_store in k_async_select<SplendorDev<2>>: 64-bit VALU address arithmetic per access, no scalar-base addressing, and a wait on
+// BOTH counters -- vmcnt and lgkmcnt -- at every use, which ties the level loop's memory round trip to its LDS traffic).  A round trip
+// through the global address space tells it what a by-value kernel argument would have: the same accesses are global_load / global_store.
+#ifndef AZG_ASYNC_NO_GLOBALIZE
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) { return (T*)(T __attribute__((address_space(1)))*)(uintptr_t)p; }
+#else
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) { return p; }
+#endif
+__device__ __forceinline__ ForestDev forest_as_global(ForestDev F) {
+    F.hdr = as_global(F.hdr); F.node_hdr = as_global(F.node_hdr); F.node_state = as_global(F.node_state); F.heap = as_global(F.heap);
+    F.htab = as_global(F.htab); F.free_ids = as_global(F.free_ids); F.rec_free = as_global(F.rec_free); F.path = as_global(F.path);
+    F.root_state = as_global(F.root_state); F.board = as_global(F.board);
+    F.rec_board = as_global(F.rec_board); F.rec_pi = as_global(F.rec_pi); F.rec_valid = as_global(F.rec_valid); F.rec_q = as_global(F.rec_q);
+    F.rec_player = as_global(F.rec_player); F.rec_ply = as_global(F.rec_ply);
+    F.ex_board = as_global(F.ex_board); F.ex_pi = as_global(F.ex_pi); F.ex_z = as_global(F.ex_z); F.ex_valid = as_global(F.ex_valid);
+    F.ex_q = as_global(F.ex_q); F.ex_meta = as_global(F.ex_meta); F.ex_count = as_global(F.ex_count);
+    return F;
+}
 // LDS control block of a select workgroup
 struct AsyncSelLds {
     unsigned long long claimed[2];             // bit i: tree i of this workgroup is being handled by one of its waves
@@ -325,10 +347,11 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                 const AsyncArgs* a = args;
                 asm volatile("" : "+s"(a));                                 // (opaque per call: nothing of a descent is kept live across the loop)
                 const AsyncArgsC A = (AsyncArgsC)(uintptr_t)a;
-                const ForestDev F = load_const(&A->F);
+                const ForestDev F = forest_as_global(load_const(&A->F));
                 const uint32_t c0t = wall32();
                 const uint32_t y0t = (uint32_t)clock64();
-                r = select_tree<G, true>(F, t, sm, dense, A->aleaf, A->leaf_valid, A->needs_eval, A->noise, A->pi, A->v, A->noise);
+                r = select_tree<G, true>(F, t, sm, dense, as_global(A->aleaf), as_global(A->leaf_valid), as_global(A->needs_eval), A->noise,
+                                         as_global(A->pi), as_global(A->v), A->noise);
                 if (l == 0) {
                     atomicAdd(&C->prof[0], 1ull); atomicAdd(&C->prof[1], (unsigned long long)(wall32() - c0t));
                     atomicAdd(&C->prof[4], (unsigned long long)((uint32_t)clock64() - y0t));
