@@ -99,6 +99,8 @@ def lib():
             L.azg_forest_async_rounds_mb1d_h2.argtypes = [vp, i, vp, vp, vp, vp, i, vp, vp, i, i, i, i, i, vp]
         if hasattr(L, 'azg_forest_async_rounds_conv5_h2'):
             L.azg_forest_async_rounds_conv5_h2.argtypes = [vp, vp, vp, vp, vp, i, vp, C.c_float, i, i, i, i, i, vp]
+        if hasattr(L, 'azg_forest_async_rounds_hashnet'):    # (test aid, include/azg_testaids.h)
+            L.azg_forest_async_rounds_hashnet.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         L.azg_forest_async_profile.argtypes = [vp, C.POINTER(C.c_double), i]
         L.azg_forest_async_wginfo.argtypes = [vp, vp, i, i]
     L.azg_stream_create_xcd.argtypes = [i, i, C.POINTER(vp)]

@@ -38,6 +38,8 @@
 namespace azg {
 
 constexpr uint32_t ERR_ASYNC_TIMEOUT = 128;
+constexpr uint32_t ERR_ASYNC_OVERRUN = 256;   // a leaf-ring entry was overwritten by a later lap before its net workgroup took it (abort code 3)
+constexpr int ASYNC_RING_LAPS = 8;            // ring slots = pow2 >= ASYNC_RING_LAPS x T: see the ring entry in k_async_select
 #ifndef AZG_ASYNC_SEL_WAVES
 #define AZG_ASYNC_SEL_WAVES 16                /* waves of a descent workgroup: 16 (<= 128 VGPRs each) fills a CU; 12 (<= 168 VGPRs) measured in round 5 */
 #endif
@@ -51,6 +53,9 @@ constexpr uint32_t ASYNC_IDLE_STEP_CAP = 100000u;          // 1 ms in 10-ns tick
 #endif
 #ifndef AZG_SCOUT_SLEEP
 #define AZG_SCOUT_SLEEP 8                   /* s_sleep of the scout between two polls of the ready words that found nothing */
+#endif
+#ifndef AZG_V80_NET_SHARE_256
+#define AZG_V80_NET_SHARE_256 136           /* default net share of the CUs for Splendor 2 players + V80, in 256ths */
 #endif
 constexpr int ASYNC_RS = 128;                 // ready words per select workgroup (trees per workgroup <= 128: two ballots)
 constexpr int ASYNC_NPROF = 96;
@@ -489,6 +494,60 @@ struct NetMb1d {                               // Splendor 3 / 4 players (8 leav
                                                                                     sidx, smask);
     }
 };
+// The integer hash-net of SURVEY.md Appendix C.3 (tests/hashnet.py; k_eval_hashnet in azg.hip is the same function as a stand-alone kernel)
+// as the pipeline's evaluator: the deterministic stand-in for NeuralNet.predict that the parity tests run on both sides.  With it the
+// PIPELINE ITSELF -- not only its two-kernel twin -- plays the oracle's episodes and the episodes the reference's Coach.executeEpisode
+// played (tests/test_gpu_selfplay.py [async] cases).  A test aid (include/azg_testaids.h), one wave per leaf, for every game that has a
+// descent kernel here.
+template <class GAME>
+struct NetHash {
+    using G = GAME;
+    static constexpr int BS = 16, LDS = 256;
+    static __device__ __forceinline__ void run(uint8_t* lds, AsyncArgsC A, const int* sidx, unsigned long long* smask) {
+        (void)lds; (void)smask;
+        using AL = AsyncLeaf<G>;
+        const int tid = (int)threadIdx.x, wave = tid >> 6, l = tid & 63;
+        float* const pi = A->pi;
+        float* const v = A->v;
+        for (int s = wave; s < BS; s += 12) {
+            const int t = sidx[s];
+            if (t < 0) continue;                                   // (wave-uniform)
+            const uint8_t* rec = (const uint8_t*)A->aleaf + (size_t)t * AL::STRIDE;       // written write-through by a descent wave on another CU
+            long long acc = 0;
+            for (int i = l; i < G::SP / 4; i += 64) {              // the zero tail beyond S adds nothing
+                const uint32_t w = __hip_atomic_load((const uint32_t*)rec + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc += (long long)(int8_t)(w >> (8 * k)) * (long long)(4 * i + k + 1);
+            }
+            const uint64_t sum = wave_sum_u64((uint64_t)acc);
+            const uint32_t h = (uint32_t)(sum * 2654435761ull);
+            unsigned long long m[G::AW];
+#pragma unroll
+            for (int k = 0; k < G::AW; k++)
+                m[k] = __hip_atomic_load((const unsigned long long*)(rec + AL::MASK_OFF) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int wsum = 0;
+            for (int a = l; a < G::A; a += 64) {
+                unsigned long long mk = m[0];
+#pragma unroll
+                for (int k = 1; k < G::AW; k++) mk = (a >> 6) == k ? m[k] : mk;
+                wsum += ((mk >> (a & 63)) & 1ull) ? 1 + (int)(((h >> 8) + 2654435761u * (uint32_t)a) % 13u) : 0;
+            }
+            wsum = wave_sum_i32(wsum);
+            for (int a = l; a < G::A; a += 64) {
+                unsigned long long mk = m[0];
+#pragma unroll
+                for (int k = 1; k < G::AW; k++) mk = (a >> 6) == k ? m[k] : mk;
+                const int w = ((mk >> (a & 63)) & 1ull) ? 1 + (int)(((h >> 8) + 2654435761u * (uint32_t)a) % 13u) : 0;
+                __hip_atomic_store((uint32_t*)pi + (size_t)t * G::A + a, __float_as_uint((float)((double)w / (double)wsum)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (l < G::P) {
+                const float v0 = (float)((double)h / 2147483648.0 - 1.0);
+                __hip_atomic_store((uint32_t*)v + (size_t)t * G::P + l, __float_as_uint(l == 0 ? v0 : (float)(-(double)v0 / (double)(G::P - 1))), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+};
 using NetSpl3 = NetMb1d<CfgSplendor3, SplendorDev<3>>;
 using NetSpl4 = NetMb1d<CfgSplendor4, SplendorDev<4>>;
 using NetAzul = NetMb1d<CfgAzul, AzulDev>;
@@ -539,6 +598,15 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
             for (;;) {
                 e = lane < BS ? __hip_atomic_load(A->ring + (tk & rmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                 const uint32_t filled = (uint32_t)__ballot(lane < BS && (uint32_t)(e >> 60) == tag) & ~taken;
+                // a slot of this range that already carries the NEXT lap's tag before its ticket was taken here: the producers lapped this
+                // workgroup (it was held up for several whole cycles of every other tree -- the ring has ASYNC_RING_LAPS x T slots and no
+                // back-pressure: a producer's check of the slot would cost every hand-over a dependent memory round trip) and the entry is
+                // lost.  Fail at once, with a code of its own, instead of waiting 20 s for a tag that cannot come.
+                if ((uint32_t)__ballot(lane < BS && (uint32_t)(e >> 60) == ((((tk >> rb) + 1u) & 7u) + 1u)) & ~taken) {
+                    if (lane == 0) { astore(&ctl->abort, 3u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_OVERRUN); }
+                    n = -1;
+                    break;
+                }
                 const uint32_t now = wall32();
                 { const uint32_t d = now - idle_last; idle_acc += d < ASYNC_IDLE_STEP_CAP ? d : ASYNC_IDLE_STEP_CAP; idle_last = now; }
                 if (filled && !seen) { seen = true; first_seen = now; }
@@ -627,23 +695,29 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
 // because they want different code generation (build.py)
 template <class G>
 static int async_launch_select(const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[64];                       // (per device: a function attribute belongs to the device that was current when it was set)
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
+    if (device >= 0 && device < 64 && !attr[device]) {
         HIPCHK(hipFuncSetAttribute((const void*)azg::k_async_select<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        attr[device] = true;
     }
     azg::k_async_select<G><<<dim3(n_sel), dim3(azg::ASYNC_SEL_WAVES * 64), azg::ASYNC_SEL_WAVES * azg::RoundLds<G>::STRIDE + (int)sizeof(azg::AsyncSelLds), s>>>(devbuf);
     HIPCHK(hipGetLastError());
     return 0;
 }
-// net_kind: 0 = Splendor 2 players (V80), 1 = Santorini no-gods (V89), 2 / 3 = Splendor 3 / 4 players, 4 = Azul (MobileNet-1d)
+// net_kind: 0 = Splendor 2 players (V80), 1 = Santorini no-gods (V89), 2 / 3 = Splendor 3 / 4 players, 4 = Azul (MobileNet-1d), 5 = Santorini with gods
 int azg_async_launch_select(int net_kind, const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s) {
     switch (net_kind) {
         case 0: return async_launch_select<azg::SplendorDev<2>>(devbuf, n_sel, s);
         case 1: return async_launch_select<azg::SantoriniDev<1>>(devbuf, n_sel, s);
         case 2: return async_launch_select<azg::SplendorDev<3>>(devbuf, n_sel, s);
         case 3: return async_launch_select<azg::SplendorDev<4>>(devbuf, n_sel, s);
-        default: return async_launch_select<azg::AzulDev>(devbuf, n_sel, s);
+        case 4: return async_launch_select<azg::AzulDev>(devbuf, n_sel, s);
+#ifdef AZG_ASYNC_SANTORINI11
+        case 5: return async_launch_select<azg::SantoriniDev<11>>(devbuf, n_sel, s);
+#endif
+        default: return -1;
     }
 }
 #endif  // AZG_ASYNC_PART_SELECT
@@ -656,6 +730,7 @@ struct AsyncSlot {
     int8_t* aleaf; AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts; unsigned long long* prof; unsigned long long* wginfo;
     hipEvent_t fork, join, join_net;
     int n_sel, n_net, ring_bits;
+    int device, n_cu, leaf_stride, T;          // what the buffers were sized for (checked on every reuse)
 };
 static void async_slot_free(void* p) {
     AsyncSlot* s = (AsyncSlot*)p;
@@ -666,6 +741,23 @@ static void async_slot_free(void* p) {
     if (s->join_net) (void)hipEventDestroy(s->join_net);
     delete s;
 }
+
+// Per-DEVICE state of the pipeline: the CU count and the two private streams its kernels run on.
+// The two kernels MUST run side by side, so their streams must not share a hardware queue (HIP multiplexes streams onto a few queues
+// -- 4 per priority level by default -- and kernels of one queue run one after the other: the net kernel would wait for leaves that
+// the descent kernel, queued behind it, can never deliver; seen as the 2 s time-out in a process that had created many streams
+// before) and must not synchronise implicitly with the legacy default stream (a BLOCKING stream's kernel waits for the default
+// stream's earlier work: the same dead end when the caller is on the default stream).  Both kernels therefore run on two private
+// NON-BLOCKING streams of the HIGH priority level, created once per device on the first launch there -- the first streams of that
+// level own a hardware queue each --, and the caller's stream only forks into them and joins them.
+// (Round 5 kept these as function-local statics made on whichever device was current at the first call: a process that moved to
+// another GPU afterwards launched on the first device's streams with the first device's CU count.)
+// The pipeline assumes that it has the GPU's CUs to itself while a launch runs: every workgroup must be resident (n_sel + n_net <= CUs)
+// because they wait for each other.  Another process or stream that occupies CUs for seconds makes the launch end in the time-out
+// (error bit 128) -- loud, never a hang; see include/azg.h.
+struct AsyncDevice { int n_cu; hipStream_t net_stream, sel_stream; bool attr_done; };
+constexpr int ASYNC_MAX_DEVICES = 64;
+static AsyncDevice g_async_dev[ASYNC_MAX_DEVICES];
 
 // include/azg.h: profile counters of the asynchronous pipeline since the last reset
 extern "C" int azg_forest_async_profile(azg_forest* f, double* out /* [ASYNC_NPROF] */, int reset) {
@@ -700,61 +792,66 @@ extern "C" int azg_forest_async_wginfo(azg_forest* f, unsigned long long* out /*
     return n;
 }
 
-// One launch of the pipeline.  net_kind 0: Splendor 2 players + V80 (w = 43 pointers, descale = 16 host floats); 1: Santorini no-gods + V89
-// (w = 14 pointers, descale = 1 host float).
-static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v,
+// One launch of the pipeline.  kind = which game's descent kernel (and, hash == 0, which net): 0 Splendor 2 players + V80 (w = 43 pointers,
+// descale = 16 host floats); 1 Santorini no-gods + V89 (w = 14 pointers, descale = 1 host float); 2 / 3 Splendor 3 / 4 players, 4 Azul
+// (MobileNet-1d: 43 pointers + 16 factors); 5 Santorini with gods (hash-net only so far).  hash != 0: the integer hash-net as the evaluator.
+template <class NET>
+static int async_launch_net(const AsyncArgs* devbuf, int n_net, hipStream_t s) {
+    k_async_net<NET><<<dim3(n_net), dim3(768), NET::LDS + ASYNC_DESC_BYTES, s>>>(devbuf);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class NET>
+static int async_net_attr() {
+    HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v,
                              int noise_stride, const void* const* w, const float* descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
                              int shared_budget, void* stream) {
     const std::string me(who);
-    if (!f || !leaf_valid || !needs_eval || !pi || !v || !w || !descale) return fail(me + ": null argument");
+    if (!f || !leaf_valid || !needs_eval || !pi || !v || (!hash && (!w || !descale))) return fail(me + ": null argument");
     if (rounds <= 0) return 0;
     if (rounds >= (1 << 24)) return fail(me + ": at most 2^24 - 1 rounds per launch");
     if (noise_stride != 0 && noise_stride != -2) return fail(me + ": noise_stride must be 0 or -2");
     int game = 0, variant = 0;
     double alpha = 0.0;
     const ForestDev* dev = azg_forest_dev_internal(f, &game, &variant, &alpha);
-    if (net_kind == 0 && (game != AZG_SPLENDOR || variant != 2)) return fail(me + ": Splendor 2 players only (the V80 geometry of nn_v80_h2.hip.h)");
-    if (net_kind == 1 && (game != AZG_SANTORINI || variant != 1)) return fail(me + ": Santorini without gods only (the V89 geometry of nn_conv5x5.hip.h)");
-    if ((net_kind == 2 || net_kind == 3) && (game != AZG_SPLENDOR || variant != net_kind + 1)) return fail(me + ": the geometry does not match the forest's game");
-    if (net_kind == 4 && game != AZG_AZUL) return fail(me + ": the geometry does not match the forest's game");
+    if (kind == 0 && (game != AZG_SPLENDOR || variant != 2)) return fail(me + ": Splendor 2 players only (the V80 geometry of nn_v80_h2.hip.h)");
+    if (kind == 1 && (game != AZG_SANTORINI || variant != 1)) return fail(me + ": Santorini without gods only (the V89 geometry of nn_conv5x5.hip.h)");
+    if ((kind == 2 || kind == 3) && (game != AZG_SPLENDOR || variant != kind + 1)) return fail(me + ": the geometry does not match the forest's game");
+    if (kind == 4 && game != AZG_AZUL) return fail(me + ": the geometry does not match the forest's game");
+    if (kind == 5 && (game != AZG_SANTORINI || variant != 11)) return fail(me + ": Santorini with gods only");
     static_assert(AsyncLeaf<SplendorDev<2>>::STRIDE == H2_AL_STRIDE && AsyncLeaf<SplendorDev<2>>::MASK_OFF == H2_AL_MASK, "leaf record layout shared with the net kernel");
     static_assert(AsyncLeaf<SantoriniDev<1>>::STRIDE == C5_AL_STRIDE && AsyncLeaf<SantoriniDev<1>>::MASK_OFF == C5_AL_MASK, "leaf record layout shared with the net kernel");
-    const int leaf_strides[5] = {H2_AL_STRIDE, C5_AL_STRIDE, AsyncLeaf<SplendorDev<3>>::STRIDE, AsyncLeaf<SplendorDev<4>>::STRIDE, AsyncLeaf<AzulDev>::STRIDE};
-    const int batch[5] = {NetV80::BS, NetC5::BS, NetSpl3::BS, NetSpl4::BS, NetAzul::BS};
-    const int leaf_stride = leaf_strides[net_kind], bs = batch[net_kind];
-    static int n_cu = 0;
-    // The two kernels MUST run side by side, so their streams must not share a hardware queue (HIP multiplexes streams onto a few queues
-    // -- 4 per priority level by default -- and kernels of one queue run one after the other: the net kernel would wait for leaves that
-    // the descent kernel, queued behind it, can never deliver; seen as the 2 s time-out in a process that had created many streams
-    // before) and must not synchronise implicitly with the legacy default stream (a BLOCKING stream's kernel waits for the default
-    // stream's earlier work: the same dead end when the caller is on the default stream).  Both kernels therefore run on two private
-    // NON-BLOCKING streams of the HIGH priority level, created once per process -- the first streams of that level own a hardware queue
-    // each --, and the caller's stream only forks into them and joins them.
-    static hipStream_t net_stream = nullptr, sel_stream = nullptr;
-    if (!n_cu) {
+    const int leaf_strides[6] = {H2_AL_STRIDE, C5_AL_STRIDE, AsyncLeaf<SplendorDev<3>>::STRIDE, AsyncLeaf<SplendorDev<4>>::STRIDE, AsyncLeaf<AzulDev>::STRIDE,
+                                 AsyncLeaf<SantoriniDev<11>>::STRIDE};
+    const int batch[6] = {NetV80::BS, NetC5::BS, NetSpl3::BS, NetSpl4::BS, NetAzul::BS, 16};
+    const int leaf_stride = leaf_strides[kind], bs = hash ? 16 : batch[kind];
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
+    if (device < 0 || device >= ASYNC_MAX_DEVICES) return fail(me + ": device index out of range");
+    AsyncDevice& D = g_async_dev[device];
+    if (!D.n_cu) {
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(hipStreamCreateWithPriority(&net_stream, hipStreamNonBlocking, hi));
-        HIPCHK(hipStreamCreateWithPriority(&sel_stream, hipStreamNonBlocking, hi));
-        int d = 0;
+        hipStream_t a = nullptr, b = nullptr;
+        HIPCHK(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&b, hipStreamNonBlocking, hi));
         hipDeviceProp_t prop;
-        HIPCHK(hipGetDevice(&d));
-        HIPCHK(hipGetDeviceProperties(&prop, d));
-        n_cu = prop.multiProcessorCount;
-        HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetV80>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetC5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetSpl3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetSpl4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_async_net<NetAzul>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        if (async_net_attr<NetV80>() || async_net_attr<NetC5>() || async_net_attr<NetSpl3>() || async_net_attr<NetSpl4>() || async_net_attr<NetAzul>()) return -1;
+        D.net_stream = a; D.sel_stream = b; D.n_cu = prop.multiProcessorCount;
     }
+    const int n_cu = D.n_cu;
     const int T = dev->T;
     if (n_net <= 0 || n_sel <= 0) {
-        // default split of the CUs.  V80: half and half (measured at 4096 x 800, whole games and the driver's window: 128 + 128 of 256
-        // beats 120 / 124 / 132 / 136 for the net); V89: a forward of 8 leaves costs ~80 us of a CU, a descent ~33 us of a sixteenth of one:
-        // 13 / 16 for the net (measured: 208 + 48 -> 28.8 k env-steps/s, 216 + 40 24.5 k, 204 + 52 28.7 k, 200 + 56 28.3 k; two kernels 26.5 k)
-        // Splendor 3 / 4 players (forward 55-59 us per 8 leaves, descent 27 us): 25 / 32 for the net (4 players: 200 + 56 -> 35.8 k, 208 + 48
-        // 33.1 k, 192 + 64 34.6 k); Azul (descent-heavy, forward 29 us per 16): 3 / 8 (96 + 160 -> 70.4 k; 112 + 144 68.6 k, 88 + 168 66.3 k)
-        n_net = net_kind == 0 ? n_cu / 2 : net_kind == 4 ? n_cu * 3 / 8 : (net_kind == 2 || net_kind == 3) ? n_cu * 25 / 32 : n_cu * 13 / 16;
+        // default split of the CUs.  V80: measured at 4096 x 800 (round 6, descent 19.9 us: see DESIGN.md 3.6); V89: a forward of 8 leaves
+        // costs ~80 us of a CU, a descent ~33 us of a sixteenth of one: 13 / 16 for the net (measured: 208 + 48 -> 28.8 k env-steps/s, 216 + 40
+        // 24.5 k, 204 + 52 28.7 k, 200 + 56 28.3 k; two kernels 26.5 k); Splendor 3 / 4 players (forward 55-59 us per 8 leaves, descent 27 us):
+        // 25 / 32 for the net (4 players: 200 + 56 -> 35.8 k, 208 + 48 33.1 k, 192 + 64 34.6 k); Azul (descent-heavy, forward 29 us per 16):
+        // 3 / 8 (96 + 160 -> 70.4 k; 112 + 144 68.6 k, 88 + 168 66.3 k).  The hash-net costs next to nothing: a sixteenth.
+        n_net = hash ? (n_cu / 16 > 0 ? n_cu / 16 : 1) : kind == 0 ? n_cu * AZG_V80_NET_SHARE_256 / 256 : kind == 4 ? n_cu * 3 / 8 : (kind == 2 || kind == 3) ? n_cu * 25 / 32 : n_cu * 13 / 16;
         n_sel = n_cu - n_net;
     }
     if (n_sel > T) n_sel = T;
@@ -764,29 +861,35 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
     if ((long long)n_sel * ASYNC_RS < T) return fail(me + ": more than 128 trees per select workgroup");
     if (T >= (1 << 20)) return fail(me + ": at most 2^20 - 1 trees");
     AsyncSlot* sl = (AsyncSlot*)azg_forest_attached(f, "async_v80");
+    if (sl && (sl->device != device || sl->n_cu != n_cu || sl->leaf_stride != leaf_stride || sl->T != T))
+        return fail(me + ": the forest's pipeline buffers were made for another device / leaf layout (one game and one GPU per forest)");
     if (!sl) {
-        sl = new AsyncSlot();
-        memset(sl, 0, sizeof(*sl));
-        memset(&sl->host, 0xFF, sizeof(sl->host));
-        azg_forest_attach(f, "async_v80", sl, async_slot_free);
+        // built in a local object and attached to the forest only when every allocation has succeeded: a half-made slot would be found by
+        // the next call and launched with null queues
+        AsyncSlot* n = new AsyncSlot();
+        memset(n, 0, sizeof(*n));
+        memset(&n->host, 0xFF, sizeof(n->host));
         int rb = 6;
-        while ((1 << rb) < 2 * T) rb++;
-        sl->ring_bits = rb;
-        HIPCHK(hipMalloc(&sl->devbuf, sizeof(AsyncArgs)));
-        HIPCHK(hipMalloc(&sl->aleaf, (size_t)T * leaf_stride));
-        HIPCHK(hipMalloc(&sl->ctl, sizeof(AsyncCtl)));
-        HIPCHK(hipMalloc(&sl->ring, sizeof(unsigned long long) << rb));
-        HIPCHK(hipMalloc(&sl->ready, sizeof(uint32_t) * ASYNC_RS * n_cu));          // (sized for any split: it may change from launch to launch)
-        HIPCHK(hipMalloc(&sl->ts, sizeof(uint32_t) * ASYNC_RS * n_cu));
-        HIPCHK(hipMalloc(&sl->prof, sizeof(unsigned long long) * ASYNC_NPROF));
-        HIPCHK(hipMemset(sl->prof, 0, sizeof(unsigned long long) * ASYNC_NPROF));
-        HIPCHK(hipMalloc(&sl->wginfo, sizeof(unsigned long long) * 4 * n_cu));
-        HIPCHK(hipMemset(sl->wginfo, 0, sizeof(unsigned long long) * 4 * n_cu));
-        HIPCHK(hipMemset(sl->aleaf, 0, (size_t)T * leaf_stride));
-        HIPCHK(hipMemset(sl->ts, 0, sizeof(uint32_t) * ASYNC_RS * n_cu));
-        HIPCHK(hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&sl->join, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&sl->join_net, hipEventDisableTiming));
+        while ((1 << rb) < ASYNC_RING_LAPS * T) rb++;
+        n->ring_bits = rb; n->device = device; n->n_cu = n_cu; n->leaf_stride = leaf_stride; n->T = T;
+        const bool ok =
+            hipMalloc(&n->devbuf, sizeof(AsyncArgs)) == hipSuccess && hipMalloc(&n->aleaf, (size_t)T * leaf_stride) == hipSuccess &&
+            hipMalloc(&n->ctl, sizeof(AsyncCtl)) == hipSuccess && hipMalloc(&n->ring, sizeof(unsigned long long) << rb) == hipSuccess &&
+            hipMalloc(&n->ready, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess &&           // (sized for any split: it may change from launch to launch)
+            hipMalloc(&n->ts, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess && hipMalloc(&n->prof, sizeof(unsigned long long) * ASYNC_NPROF) == hipSuccess &&
+            hipMalloc(&n->wginfo, sizeof(unsigned long long) * 4 * n_cu) == hipSuccess &&
+            hipMemset(n->prof, 0, sizeof(unsigned long long) * ASYNC_NPROF) == hipSuccess &&
+            hipMemset(n->wginfo, 0, sizeof(unsigned long long) * 4 * n_cu) == hipSuccess && hipMemset(n->aleaf, 0, (size_t)T * leaf_stride) == hipSuccess &&
+            hipMemset(n->ts, 0, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess &&
+            hipEventCreateWithFlags(&n->fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&n->join, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&n->join_net, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            const hipError_t e = hipGetLastError();
+            async_slot_free(n);
+            return fail(me + ": could not allocate the pipeline's queues (" + hipGetErrorString(e) + ")");
+        }
+        sl = n;
+        azg_forest_attach(f, "async_v80", sl, async_slot_free);
     }
     sl->n_sel = n_sel; sl->n_net = n_net;
     AsyncArgs want;
@@ -795,8 +898,9 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
     // (the forest's work / level budget stays: a call that runs into it is followed by the next one at once, so no tree waits for another
     // inside a launch -- but a launch ends only when every tree has had its calls, and a tree whose simulations all end on terminal nodes
     // would otherwise run its whole search inside ONE call: measured 4.1 ms launches of 48 rounds where the mean tree needs 3.4 ms)
-    if (net_kind == 0) want.W = h2_weights(w, descale);
-    else if (net_kind >= 2) {                         // the 43-pointer table + 16 descale factors of azg_nn_mb1d_forward_h2
+    if (hash) {
+    } else if (kind == 0) want.W = h2_weights(w, descale);
+    else if (kind >= 2) {                             // the 43-pointer table + 16 descale factors of azg_nn_mb1d_forward_h2
         const float* const* wf = (const float* const*)w;
         Mb1dNetW& N = want.MB;
         for (int i = 0; i < 16; i++) N.ds[i] = descale[i];
@@ -831,19 +935,35 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
     HIPCHK(hipMemsetAsync(sl->ring, 0, sizeof(unsigned long long) << sl->ring_bits, s));
     // fork from the caller's stream into the two private streams, join both before returning
     HIPCHK(hipEventRecord(sl->fork, s));
-    HIPCHK(hipStreamWaitEvent(net_stream, sl->fork, 0));
-    HIPCHK(hipStreamWaitEvent(sel_stream, sl->fork, 0));
-    switch (net_kind) {
-        case 0: k_async_net<NetV80><<<dim3(n_net), dim3(768), NetV80::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf); break;
-        case 1: k_async_net<NetC5><<<dim3(n_net), dim3(768), NetC5::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf); break;
-        case 2: k_async_net<NetSpl3><<<dim3(n_net), dim3(768), NetSpl3::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf); break;
-        case 3: k_async_net<NetSpl4><<<dim3(n_net), dim3(768), NetSpl4::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf); break;
-        default: k_async_net<NetAzul><<<dim3(n_net), dim3(768), NetAzul::LDS + ASYNC_DESC_BYTES, net_stream>>>(sl->devbuf); break;
+    HIPCHK(hipStreamWaitEvent(D.net_stream, sl->fork, 0));
+    HIPCHK(hipStreamWaitEvent(D.sel_stream, sl->fork, 0));
+    int rc;
+    if (hash) {
+        switch (kind) {
+            case 0: rc = async_launch_net<NetHash<SplendorDev<2>>>(sl->devbuf, n_net, D.net_stream); break;
+            case 1: rc = async_launch_net<NetHash<SantoriniDev<1>>>(sl->devbuf, n_net, D.net_stream); break;
+            case 2: rc = async_launch_net<NetHash<SplendorDev<3>>>(sl->devbuf, n_net, D.net_stream); break;
+            case 3: rc = async_launch_net<NetHash<SplendorDev<4>>>(sl->devbuf, n_net, D.net_stream); break;
+            case 4: rc = async_launch_net<NetHash<AzulDev>>(sl->devbuf, n_net, D.net_stream); break;
+#ifdef AZG_ASYNC_SANTORINI11
+            case 5: rc = async_launch_net<NetHash<SantoriniDev<11>>>(sl->devbuf, n_net, D.net_stream); break;
+#endif
+            default: return fail(me + ": no descent kernel for this game in the pipeline");
+        }
+    } else {
+        switch (kind) {
+            case 0: rc = async_launch_net<NetV80>(sl->devbuf, n_net, D.net_stream); break;
+            case 1: rc = async_launch_net<NetC5>(sl->devbuf, n_net, D.net_stream); break;
+            case 2: rc = async_launch_net<NetSpl3>(sl->devbuf, n_net, D.net_stream); break;
+            case 3: rc = async_launch_net<NetSpl4>(sl->devbuf, n_net, D.net_stream); break;
+            case 4: rc = async_launch_net<NetAzul>(sl->devbuf, n_net, D.net_stream); break;
+            default: return fail(me + ": no engine net for this game in the pipeline");
+        }
     }
-    HIPCHK(hipGetLastError());
-    if (azg_async_launch_select(net_kind, sl->devbuf, n_sel, sel_stream)) return -1;
-    HIPCHK(hipEventRecord(sl->join_net, net_stream));
-    HIPCHK(hipEventRecord(sl->join, sel_stream));
+    if (rc) return -1;
+    if (azg_async_launch_select(kind, sl->devbuf, n_sel, D.sel_stream)) return -1;
+    HIPCHK(hipEventRecord(sl->join_net, D.net_stream));
+    HIPCHK(hipEventRecord(sl->join, D.sel_stream));
     HIPCHK(hipStreamWaitEvent(s, sl->join_net, 0));
     HIPCHK(hipStreamWaitEvent(s, sl->join, 0));
     return 0;
@@ -853,7 +973,7 @@ static int async_rounds_impl(const char* who, int net_kind, azg_forest* f, uint8
 extern "C" int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v, int noise_stride,
                                               const void* const* w, const float* descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
                                               int shared_budget, void* stream) {
-    return async_rounds_impl("azg_forest_async_rounds_v80_h2", 0, f, leaf_valid, needs_eval, pi, v, noise_stride, w, descale, rounds, n_net, n_sel,
+    return async_rounds_impl("azg_forest_async_rounds_v80_h2", 0, 0, f, leaf_valid, needs_eval, pi, v, noise_stride, w, descale, rounds, n_net, n_sel,
                              batch_wait_ticks, shared_budget, stream);
 }
 // include/azg.h: the pipeline for Splendor 3 / 4 players and Azul with their MobileNet-1d nets (geometry = AZG_NET_* of azg_nn_mb1d_forward_h2)
@@ -862,15 +982,29 @@ extern "C" int azg_forest_async_rounds_mb1d_h2(azg_forest* f, int geometry, uint
                                                int shared_budget, void* stream) {
     const int kind = geometry == AZG_NET_SPLENDOR3 ? 2 : geometry == AZG_NET_SPLENDOR4 ? 3 : geometry == AZG_NET_AZUL ? 4 : -1;
     if (kind < 0) return fail("azg_forest_async_rounds_mb1d_h2: geometry must be AZG_NET_SPLENDOR3, AZG_NET_SPLENDOR4 or AZG_NET_AZUL");
-    return async_rounds_impl("azg_forest_async_rounds_mb1d_h2", kind, f, leaf_valid, needs_eval, pi, v, noise_stride, w, descale, rounds, n_net, n_sel,
+    return async_rounds_impl("azg_forest_async_rounds_mb1d_h2", kind, 0, f, leaf_valid, needs_eval, pi, v, noise_stride, w, descale, rounds, n_net, n_sel,
                              batch_wait_ticks, shared_budget, stream);
 }
 // include/azg.h: the pipeline for a Santorini no-gods forest with the V89 net (14 pointers of azg_nn_conv5_forward_h2, its descale)
 extern "C" int azg_forest_async_rounds_conv5_h2(azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v, int noise_stride,
                                                 const float* const* w, float descale, int rounds, int n_net, int n_sel, int batch_wait_ticks,
                                                 int shared_budget, void* stream) {
-    return async_rounds_impl("azg_forest_async_rounds_conv5_h2", 1, f, leaf_valid, needs_eval, pi, v, noise_stride, (const void* const*)w, &descale, rounds,
+    return async_rounds_impl("azg_forest_async_rounds_conv5_h2", 1, 0, f, leaf_valid, needs_eval, pi, v, noise_stride, (const void* const*)w, &descale, rounds,
                              n_net, n_sel, batch_wait_ticks, shared_budget, stream);
+}
+
+// include/azg_testaids.h: the pipeline with the integer hash-net as its evaluator, for every game that has a descent kernel here
+extern "C" int azg_forest_async_rounds_hashnet(azg_forest* f, uint8_t* leaf_valid, uint8_t* needs_eval, float* pi, float* v, int noise_stride, int rounds,
+                                               int n_net, int n_sel, int batch_wait_ticks, int shared_budget, void* stream) {
+    if (!f) return fail("azg_forest_async_rounds_hashnet: null argument");
+    int game = 0, variant = 0;
+    double alpha = 0.0;
+    (void)azg_forest_dev_internal(f, &game, &variant, &alpha);
+    const int kind = game == AZG_SPLENDOR ? (variant == 2 ? 0 : variant == 3 ? 2 : variant == 4 ? 3 : -1)
+                     : game == AZG_SANTORINI ? (variant == 1 ? 1 : -1) : game == AZG_AZUL ? 4 : -1;
+    if (kind < 0) return fail("azg_forest_async_rounds_hashnet: the pipeline has descent kernels for Splendor 2 - 4 players, Santorini without gods and Azul");
+    return async_rounds_impl("azg_forest_async_rounds_hashnet", kind, 1, f, leaf_valid, needs_eval, pi, v, noise_stride, nullptr, nullptr, rounds, n_net, n_sel,
+                             batch_wait_ticks, shared_budget, stream);
 }
 
 #endif  // AZG_ASYNC_PART_NET

@@ -125,6 +125,11 @@ class Forest:
         descent workgroups and persistent V80 net workgroups resident together, leaves and trees handed over through device-side queues"""
         assert pi.dtype == torch.float32 and v.dtype == torch.float32 and pi.is_contiguous() and v.is_contiguous()
         assert pi.shape == (self.T, self.A) and v.shape == (self.T, self.P)
+        if getattr(net, 'async_hashnet', False):        # the tests' integer hash-net as the pipeline's evaluator (include/azg_testaids.h)
+            check(lib().azg_forest_async_rounds_hashnet(self.h, _ptr(self.leaf_valid), _ptr(self.needs_eval), _ptr(pi), _ptr(v),
+                                                        -2 if device_noise else 0, int(rounds), int(n_net), int(n_sel), int(batch_wait_ticks),
+                                                        int(bool(shared_budget)), _stream()))
+            return
         if hasattr(net, 'fused_ptrs_h2'):               # the MobileNet-1d family (MobileNet1dHip: 43 pointers + 16 descale factors + geometry)
             check(lib().azg_forest_async_rounds_mb1d_h2(self.h, int(net.geometry), _ptr(self.leaf_valid), _ptr(self.needs_eval), _ptr(pi), _ptr(v),
                                                         -2 if device_noise else 0, net.fused_ptrs_h2, net.descale_h2, int(rounds), int(n_net), int(n_sel),

@@ -91,7 +91,7 @@ class _Group:
 class SelfPlayEngine:
     def __init__(self, game, nnet, args, n_games, node_capacity=None, max_examples=None, rng_seed=0, stream0=0,
                  use_graph=True, dirichlet=None, level_budget=0, groups=1, advance_every=None, work_budget=None, fused=True,
-                 pin_xcd=None, percu=None, gc_high_water_pct=None, async_pipe=None, async_cfg=None):
+                 pin_xcd=None, percu=None, gc_high_water_pct=None, async_pipe=None, async_cfg=None, deterministic=None):
         self.game, self.args = game, args
         get = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
         sims = int(get('numMCTSSims', 800))
@@ -136,12 +136,15 @@ class SelfPlayEngine:
                   all(type(n).__name__ == 'MobileNet1dHip' and getattr(n, 'h2', False) and getattr(n, 'fused', False) and
                       getattr(n, 'geometry', None) == ({3: 1, 4: 2}.get(var) if gid == _lib.SPLENDOR else 3) and
                       torch.is_tensor(getattr(n, 'pi', None)) and tuple(n.pi.shape) == (Tg, A_game) for n in nets))
-        any_pipe = can or can_c5 or can_mb
+        # ... and, for the parity tests, with the integer hash-net as the evaluator (tests/hashnet.py HashNetPipeline: async_hashnet = True)
+        can_hash = (self.fused and hasattr(_lib.lib(), 'azg_forest_async_rounds_hashnet') and all(getattr(n, 'async_hashnet', False) for n in nets) and
+                    ((gid == _lib.SPLENDOR and var in (0, 2, 3, 4)) or (gid == _lib.SANTORINI and var == 1) or gid == _lib.AZUL))
+        any_pipe = can or can_c5 or can_mb or can_hash
         if async_pipe is None:
             async_pipe = any_pipe and groups == 1 and not percu and os.environ.get('AZG_ASYNC', '1') == '1'
         elif async_pipe and not (any_pipe and groups == 1):
             raise ValueError('async_pipe=True needs Splendor 2 players + SplendorV80Hip(h2=True), Santorini no-gods + SantoriniV89Hip(h2=True) or Splendor 3 / 4 '
-                             'players / Azul + MobileNet1dHip(h2=True) evaluators with max_batch == n_games, groups == 1')
+                             'players / Azul + MobileNet1dHip(h2=True) evaluators with max_batch == n_games (or the tests\' hash-net), groups == 1')
         self.async_pipe = bool(async_pipe)
         self.adaptive = False
         if work_budget is None:
@@ -174,7 +177,14 @@ class SelfPlayEngine:
                     cfg[k] = int(os.environ[e])
             # run(rounds) = rounds x n_games calls for the trees TOGETHER (no tree waits for the slowest at the end of a launch);
             # async_cfg=dict(shared_budget=False): exactly `rounds` calls per tree (results a function of `rounds` alone: the parity tests)
-            cfg.setdefault('shared_budget', True)
+            # WHAT run(rounds) LEAVES BEHIND is then a function of (seed, rounds) only up to scheduling: every game is still played move for
+            # move as its RNG stream dictates (per-game results are identical, tests/test_gpu_selfplay.py
+            # test_async_pipeline_shared_budget_plays_the_same_games), but how far each game has got after a given number of rounds -- and
+            # therefore WHICH games have ended and delivered examples -- depends on GPU timing.  With an episode quota the set of examples
+            # is the same either way.  deterministic=True (or AZG_DETERMINISTIC=1): the per-tree budget, as in the two-kernel rounds.
+            if deterministic is None:
+                deterministic = os.environ.get('AZG_DETERMINISTIC', '0') == '1'
+            cfg.setdefault('shared_budget', not deterministic)
             self.groups[0].async_cfg = cfg
             # adaptive split (opt-in, AZG_ASYNC_ADAPT=1; only with the work-sharing budget -- with per-tree budgets the results must not
             # depend on anything measured): round 5 measured it and it LOSES to the fixed half-and-half split -- every chunk boundary is a

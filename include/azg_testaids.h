@@ -21,6 +21,14 @@ int azg_debug_placement(int n_workgroups, uint32_t* out_dev, void* stream);
    pi f32[T][A], v f32[T][P], bit-identical to tests/hashnet.py.  Not a product net. */
 int azg_eval_hashnet(const int8_t* boards, const uint8_t* valid, int T, int S, int A, int P, float* pi, float* v, void* stream);
 
+/* tests: the ASYNCHRONOUS TREE PIPELINE (include/azg.h azg_forest_async_rounds_v80_h2) with that hash-net as its evaluator instead of an
+   engine net -- the persistent descent kernel of the forest's game + a persistent evaluator kernel, same queues, same in-kernel advance --
+   so that the pipeline itself can play the oracle's episodes and the episodes the reference's Coach.executeEpisode played
+   (Coach.py:37-84,117-144).  For Splendor 2 - 4 players, Santorini without gods and Azul.  Arguments as for azg_forest_async_rounds_v80_h2
+   without the weights.  Not a product path. */
+int azg_forest_async_rounds_hashnet(azg_forest* f, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev, int noise_stride,
+                                    int rounds, int n_net, int n_sel, int batch_wait_ticks, int shared_budget, void* stream);
+
 /* placement study: one row of four u64 per workgroup of the pipeline (the n_sel descent workgroups first): where it ran (XCC id | cu_id
    << 8 | se_id << 16 | sh_id << 24), role (1 descent, 2 net), calls (descents / forwards) and the shader cycles spent in them since
    the last reset.  Returns the number of rows written (<= max_wg). */

@@ -66,3 +66,9 @@ class HashNetHip:
         _lib.check(_lib.lib().azg_eval_hashnet(C.c_void_p(b.data_ptr()), C.c_void_p(va.data_ptr()), T, S, A, self.P, C.c_void_p(pi.data_ptr()),
                                                C.c_void_p(v.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return pi, v
+
+
+class HashNetPipeline(HashNetHip):
+    """the hash-net as the evaluator of the asynchronous tree pipeline (azg_forest_async_rounds_hashnet: evaluated INSIDE the pipeline's
+    persistent evaluator kernel); as a batched evaluator it is HashNetHip, so the same object also drives the two-kernel rounds"""
+    async_hashnet = True

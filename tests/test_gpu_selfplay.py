@@ -12,9 +12,56 @@ class Args(dict):
     __getattr__ = dict.get
 
 
+def _play_until(f, T, games, mode, chunk=256, max_iter=200000):
+    """drive forest `f` with the hash-net until `games` games have ended.  mode 'rounds': the host-driven lock-step rounds (select ->
+    predict -> expand_backup -> selfplay_advance); mode 'async': the asynchronous tree pipeline ITSELF (persistent descent kernel + the
+    hash-net inside the pipeline's persistent evaluator kernel, azg_forest_async_rounds_hashnet; exactly `chunk` calls per tree per launch)"""
+    import torch
+    from hashnet import HashNetPipeline, HashNetTorch
+    shape = f.board_shape()
+    if mode == 'async':
+        net = HashNetPipeline(f.P)
+        pi = torch.zeros((T, f.A), dtype=torch.float32, device='cuda')
+        v = torch.zeros((T, f.P), dtype=torch.float32, device='cuda')
+        for _ in range(max_iter // chunk + 1):
+            f.async_rounds_v80(net, pi, v, chunk, shared_budget=False)
+            st = f.stats()
+            assert st['errors'] == 0, st
+            if st['games'] >= games:
+                break
+        return st
+    net = HashNetTorch(f.P)
+    for rnd in range(max_iter):
+        f.select()
+        pi, vv = net.predict_batch(f.leaf_states.view((T,) + shape), f.leaf_valid.bool())
+        f.expand_backup(pi, vv)
+        f.selfplay_advance()
+        if rnd % chunk == chunk - 1:
+            st = f.stats()
+            assert st['errors'] == 0, st
+            if st['games'] >= games:
+                break
+    return f.stats()
+
+
+
+_ASYNC_GAMES = ('splendor2', 'splendor4', 'santorini1', 'azul')     # games with a descent kernel in the pipeline
+
+
 @pytest.mark.parametrize('variant,prob_full', [('splendor2', 1.0), ('splendor2', 0.5), ('splendor4', 1.0), ('santorini1', 1.0),
                                                 ('santorini11', 1.0), ('azul', 1.0), ('abalone', 1.0), ('akropolis', 1.0), ('akropolis3', 1.0), ('akropolis4', 1.0), ('smallworld', 1.0), ('smallworld3', 1.0), ('smallworld4', 1.0)])
 def test_selfplay_first_games_vs_oracle(variant, prob_full):
+    _first_games_vs_oracle(variant, prob_full, 'rounds')
+
+
+@pytest.mark.parametrize('variant,prob_full', [('splendor2', 1.0), ('splendor2', 0.5), ('splendor4', 1.0), ('santorini1', 1.0), ('azul', 1.0)])
+def test_async_pipeline_first_games_vs_oracle(variant, prob_full):
+    """the PIPELINE itself (not its two-kernel twin) against the oracle's episodes: persistent descent kernel, the hash-net evaluated inside
+    the pipeline's persistent evaluator kernel, moves / examples / restarts / clean-ups in-kernel (Coach.py:37-84,117-144)"""
+    _first_games_vs_oracle(variant, prob_full, 'async')
+
+
+def _first_games_vs_oracle(variant, prob_full, mode):
     import torch
     import azg_oracle as O
     from azg_amd import games
@@ -39,19 +86,8 @@ def test_selfplay_first_games_vs_oracle(variant, prob_full):
                 tempThreshold=6, **kw)
     f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=2048, max_examples=T * 1200, rng_seed=seed,
                stream0=stream0)
-    net = HashNetTorch(g.P)
     f.selfplay_start()
-    shape = f.board_shape()
-    for rnd in range(200000):
-        f.select()
-        pi, vv = net.predict_batch(f.leaf_states.view((T,) + shape), f.leaf_valid.bool())
-        f.expand_backup(pi, vv)
-        f.selfplay_advance()
-        if rnd % 256 == 255:
-            st = f.stats()
-            assert st['errors'] == 0
-            if st['games'] >= 2 * T:
-                break
+    _play_until(f, T, 2 * T, mode)
     boards, pis, zs, valids, qs, meta = [x.cpu().numpy() for x in f.drain_examples()]
     assert len(boards) > 0
     for t in range(T):
@@ -71,10 +107,12 @@ def test_selfplay_first_games_vs_oracle(variant, prob_full):
     f.close()
 
 
+@pytest.mark.parametrize('mode', ['rounds', 'async'])
 @pytest.mark.parametrize('variant,cap', [('splendor2', 400), ('azul', 900), ('santorini1', 700)])
-def test_selfplay_gc_keeps_results(tmp_path, variant, cap):
+def test_selfplay_gc_keeps_results(tmp_path, variant, cap, mode):
     """A node arena too small for a whole game forces the clean-up many times (free-id stack, record free lists / id-indexed
-    record slots, table rebuild); results must not change and the structure must stay valid."""
+    record slots, table rebuild); results must not change and the structure must stay valid -- in the host-driven rounds and inside the
+    asynchronous pipeline's descent kernel."""
     import torch
     import azg_oracle as O
     from azg_amd import games
@@ -88,19 +126,9 @@ def test_selfplay_gc_keeps_results(tmp_path, variant, cap):
     args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1.0, 1.0, 1.0],
                 tempThreshold=6, **kw)
     f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=cap, max_examples=T * 1200, rng_seed=seed, stream0=stream0)
-    net = HashNetTorch(g.P)
     f.selfplay_start()
-    for rnd in range(200000):
-        f.select()
-        pi, vv = net.predict_batch(f.leaf_states.view((T,) + f.board_shape()), f.leaf_valid.bool())
-        f.expand_backup(pi, vv)
-        f.selfplay_advance()
-        if rnd % 256 == 255:
-            st = f.stats()
-            assert st['errors'] == 0, st
-            if st['games'] >= 3 * T:           # every tree has finished its first game by then
-                break
-    st = f.stats()
+    st = _play_until(f, T, 3 * T, mode)          # every tree has finished its first game by then
+    # (mode 'async': the clean-up runs INSIDE the pipeline's descent kernel, on the one wave that found the search finished -- gc_scan<G, true>)
     assert st['gc_runs'] > 0
     assert f.validate() == 0
     boards, pis, zs, valids, qs, meta = [x.cpu().numpy() for x in f.drain_examples()]
@@ -380,8 +408,18 @@ _EP_CASES = sorted(_os.path.basename(p)[len('episode_'):-len('.npz')]
                    for p in _glob.glob(_os.path.join(_os.path.dirname(__file__), 'golden', 'episode_*.npz')))
 
 
+@pytest.mark.parametrize('case', [c for c in _EP_CASES if c.split('_')[0] in _ASYNC_GAMES])
+def test_async_pipeline_vs_reference_executeEpisode(case, golden_dir):
+    """the PIPELINE itself against the episodes the reference's own Coach.executeEpisode played (see below)"""
+    _vs_reference_episode(case, golden_dir, 'async')
+
+
 @pytest.mark.parametrize('case', _EP_CASES)
 def test_selfplay_vs_reference_executeEpisode(case, golden_dir):
+    _vs_reference_episode(case, golden_dir, 'rounds')
+
+
+def _vs_reference_episode(case, golden_dir, mode):
     """Device-resident self-play against an episode the REFERENCE's own Coach.executeEpisode played (Coach.py:37-84; fixture from
     tools/gen_golden_episode.py): same init board, same counter stream -> the recorded plies (canonical board, pi,
     q, player), z = roll(r, -player), and the symmetry-expanded example list in the reference's order."""
@@ -398,20 +436,9 @@ def test_selfplay_vs_reference_executeEpisode(case, golden_dir):
                 fpu=float(d['fpu']), universes=int(d['universes']), forced_playouts=bool(d['forced']))
     f = Forest(g.GAME_ID, g.variant, T, args, node_capacity=4096, max_examples=T * 1200, rng_seed=int(d['seed']),
                stream0=int(d['stream']))
-    net = HashNetTorch(g.P)
     ib = torch.from_numpy(np.stack([d['init_board'], d['init_board']])).cuda()
     f.selfplay_start(init_boards=ib)
-    shape = f.board_shape()
-    for rnd in range(400000):
-        f.select()
-        pi, vv = net.predict_batch(f.leaf_states.view((T,) + shape), f.leaf_valid.bool())
-        f.expand_backup(pi, vv)
-        f.selfplay_advance()
-        if rnd % 256 == 255:
-            st = f.stats()
-            assert st['errors'] == 0
-            if st['games'] >= 2 * T:
-                break
+    _play_until(f, T, 2 * T, mode, max_iter=400000)
     boards, pis, zs, valids, qs, meta = f.drain_examples()
     m = meta.cpu().numpy()
     sel = np.flatnonzero((m[:, 0] == int(d['stream'])) & (m[:, 1] == 0))
@@ -756,3 +783,58 @@ def test_full_size_properties_other_configs(game_key, sims, cap):
         eng.close()
         del eng
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('variant,T,sims,alpha', [('splendor2', 48, 24, 0.3), ('azul', 40, 30, 0.0)])
+def test_async_pipeline_shared_budget_plays_the_same_games(variant, T, sims, alpha):
+    """The mode bench.py times: SelfPlayEngine's default for the pipeline is the WORK-SHARING budget (run(rounds) = rounds x T calls for the
+    trees together; a tree is stopped wherever it is when the budget is spent and goes on in the next launch).  How far each game gets
+    per launch depends on timing -- what is played must not: two whole games per tree (episode quota 2 T) over launches of odd lengths,
+    then EVERY drained record, keyed (stream, game, ply), equals the per-tree-budget run's (which test_async_pipeline_first_games_vs_oracle
+    ties to the oracle).  Root noise on for Splendor: the in-kernel sampler is keyed by the tree's simulation counter."""
+    from azg_amd import games
+    from azg_amd.selfplay import SelfPlayEngine
+    from hashnet import HashNetPipeline
+    g = games.SplendorGame(2) if variant == 'splendor2' else games.AzulGame()
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=alpha, temperature=[1.25, 0.8, 1.0], tempThreshold=6,
+                **{**MCTS_ARGS[variant], 'forced_playouts': False})
+    res = []
+    for shared, lengths in ((True, (37, 91, 13, 255, 64, 7)), (False, (64,))):
+        e = SelfPlayEngine(g, HashNetPipeline(g.P), args, T, node_capacity=2048, max_examples=T * 800, rng_seed=21, stream0=300,
+                           async_pipe=True, async_cfg=dict(shared_budget=shared))
+        assert e.async_pipe and e.groups[0].async_cfg['shared_budget'] is shared
+        e.start(episode_quota=2 * T)
+        for k in range(4000):
+            e.run(lengths[k % len(lengths)])
+            st = e.stats()
+            assert st['errors'] == 0, st
+            if st['active'] == 0:
+                break
+        assert st['games'] == 2 * T and st['active'] == 0
+        assert e.forest.validate() == 0
+        ex = [x.cpu().numpy() for x in e.drain_examples()]
+        meta = ex[5]
+        order = np.lexsort((meta[:, 2], meta[:, 1], meta[:, 0]))
+        res.append([x[order] for x in ex])
+        e.close()
+    assert len(res[0][0]) > 2 * T
+    for a, b in zip(res[0], res[1]):
+        assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_selfplay_engine_default_mode_and_deterministic_switch():
+    """the pipeline's default is the work-sharing budget; deterministic=True / AZG_DETERMINISTIC=1 selects the per-tree budget"""
+    from azg_amd import games
+    from azg_amd.selfplay import SelfPlayEngine
+    from hashnet import HashNetPipeline
+    g = games.SplendorGame(2)
+    args = Args(numMCTSSims=16, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0, temperature=[1.0, 1.0, 1.0], tempThreshold=6,
+                **{**MCTS_ARGS['splendor2'], 'forced_playouts': False})
+    for det in (None, True):
+        e = SelfPlayEngine(g, HashNetPipeline(2), args, 32, node_capacity=1024, max_examples=32 * 400, deterministic=det)
+        assert e.async_pipe and e.groups[0].async_cfg['shared_budget'] is (not det)
+        e.start()
+        e.run(200)
+        st = e.stats()
+        assert st['errors'] == 0 and st['plies'] > 0 and e.forest.validate() == 0
+        e.close()
