@@ -105,21 +105,31 @@ __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)"
 // 59 flat_store in k_async_select<SplendorDev<2>>: 64-bit VALU address arithmetic per access, no scalar-base addressing, and a wait on
 // BOTH counters -- vmcnt and lgkmcnt -- at every use, which ties the level loop's memory round trip to its LDS traffic).  A round trip
 // through the global address space tells it what a by-value kernel argument would have: the same accesses are global_load / global_store.
-#ifndef AZG_ASYNC_NO_GLOBALIZE
+// Which pointers: the gain is the level loop's and the edge resolution's (heap, node states, hash table, node headers, path, free lists);
+// the per-game trait picks the set -- for the multi-class forests (Santorini, Azul) a GLOBAL record heap makes the register allocator spill
+// vector registers inside the level loop (k_async_select<SantoriniDev<1>>: scratch instructions 70 -> 185 with the heap alone, 203 with
+// everything; measured: a descent 33 -> 47 us, Azul 38 -> 50 us); every other pointer leaves the spill count as it is but gains nothing
+// (Santorini 34.1 -> 36.0 us per descent, Azul 36.8 -> 36.4): those two kernels keep their generic pointers.
 template <class T>
 __device__ __forceinline__ T* as_global(T* p) { return (T*)(T __attribute__((address_space(1)))*)(uintptr_t)p; }
-#else
-template <class T>
-__device__ __forceinline__ T* as_global(T* p) { return p; }
+enum : uint32_t { AG_HEAP = 1, AG_STATE = 2, AG_HTAB = 4, AG_NHDR = 8, AG_HDR = 16, AG_ALLOC = 32, AG_PATH = 64, AG_ROOT = 128, AG_IO = 256, AG_ALL = 511 };
+#ifndef AZG_AG_DEFAULT
+#define AZG_AG_DEFAULT AG_ALL
 #endif
+#ifndef AZG_AG_MULTI
+#define AZG_AG_MULTI 0                      /* multi-class forests: nothing (measured, see above) */
+#endif
+template <class G> struct AsyncGlobalMask { static constexpr uint32_t value = Forest<G>::ONE_CLASS ? (uint32_t)(AZG_AG_DEFAULT) : (uint32_t)(AZG_AG_MULTI); };
+template <uint32_t M>
 __device__ __forceinline__ ForestDev forest_as_global(ForestDev F) {
-    F.hdr = as_global(F.hdr); F.node_hdr = as_global(F.node_hdr); F.node_state = as_global(F.node_state); F.heap = as_global(F.heap);
-    F.htab = as_global(F.htab); F.free_ids = as_global(F.free_ids); F.rec_free = as_global(F.rec_free); F.path = as_global(F.path);
-    F.root_state = as_global(F.root_state); F.board = as_global(F.board);
-    F.rec_board = as_global(F.rec_board); F.rec_pi = as_global(F.rec_pi); F.rec_valid = as_global(F.rec_valid); F.rec_q = as_global(F.rec_q);
-    F.rec_player = as_global(F.rec_player); F.rec_ply = as_global(F.rec_ply);
-    F.ex_board = as_global(F.ex_board); F.ex_pi = as_global(F.ex_pi); F.ex_z = as_global(F.ex_z); F.ex_valid = as_global(F.ex_valid);
-    F.ex_q = as_global(F.ex_q); F.ex_meta = as_global(F.ex_meta); F.ex_count = as_global(F.ex_count);
+    if (M & AG_HEAP) F.heap = as_global(F.heap);
+    if (M & AG_STATE) F.node_state = as_global(F.node_state);
+    if (M & AG_HTAB) F.htab = as_global(F.htab);
+    if (M & AG_NHDR) F.node_hdr = as_global(F.node_hdr);
+    if (M & AG_HDR) F.hdr = as_global(F.hdr);
+    if (M & AG_ALLOC) { F.free_ids = as_global(F.free_ids); F.rec_free = as_global(F.rec_free); }
+    if (M & AG_PATH) F.path = as_global(F.path);
+    if (M & AG_ROOT) { F.root_state = as_global(F.root_state); F.board = as_global(F.board); }
     return F;
 }
 // LDS control block of a select workgroup
@@ -352,11 +362,15 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                 const AsyncArgs* a = args;
                 asm volatile("" : "+s"(a));                                 // (opaque per call: nothing of a descent is kept live across the loop)
                 const AsyncArgsC A = (AsyncArgsC)(uintptr_t)a;
-                const ForestDev F = forest_as_global(load_const(&A->F));
+                constexpr uint32_t AGM = AsyncGlobalMask<G>::value;
+                const ForestDev F = forest_as_global<AGM>(load_const(&A->F));
                 const uint32_t c0t = wall32();
                 const uint32_t y0t = (uint32_t)clock64();
-                r = select_tree<G, true>(F, t, sm, dense, as_global(A->aleaf), as_global(A->leaf_valid), as_global(A->needs_eval), A->noise,
-                                         as_global(A->pi), as_global(A->v), A->noise);
+                if constexpr (AGM & AG_IO)
+                    r = select_tree<G, true>(F, t, sm, dense, as_global(A->aleaf), as_global(A->leaf_valid), as_global(A->needs_eval), A->noise,
+                                             as_global(A->pi), as_global(A->v), A->noise);
+                else
+                    r = select_tree<G, true>(F, t, sm, dense, A->aleaf, A->leaf_valid, A->needs_eval, A->noise, A->pi, A->v, A->noise);
                 if (l == 0) {
                     atomicAdd(&C->prof[0], 1ull); atomicAdd(&C->prof[1], (unsigned long long)(wall32() - c0t));
                     atomicAdd(&C->prof[4], (unsigned long long)((uint32_t)clock64() - y0t));
@@ -708,6 +722,10 @@ static int async_launch_select(const azg::AsyncArgs* devbuf, int n_sel, hipStrea
 }
 // net_kind: 0 = Splendor 2 players (V80), 1 = Santorini no-gods (V89), 2 / 3 = Splendor 3 / 4 players, 4 = Azul (MobileNet-1d), 5 = Santorini with gods
 int azg_async_launch_select(int net_kind, const azg::AsyncArgs* devbuf, int n_sel, hipStream_t s) {
+#ifdef AZG_ASYNC_ONLY_KIND      /* code-generation experiments: one game's kernel only */
+    if (net_kind != AZG_ASYNC_ONLY_KIND) return -1;
+    return async_launch_select<AZG_ASYNC_ONLY_GAME>(devbuf, n_sel, s);
+#else
     switch (net_kind) {
         case 0: return async_launch_select<azg::SplendorDev<2>>(devbuf, n_sel, s);
         case 1: return async_launch_select<azg::SantoriniDev<1>>(devbuf, n_sel, s);
@@ -719,6 +737,7 @@ int azg_async_launch_select(int net_kind, const azg::AsyncArgs* devbuf, int n_se
 #endif
         default: return -1;
     }
+#endif
 }
 #endif  // AZG_ASYNC_PART_SELECT
 
@@ -849,9 +868,10 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
         // default split of the CUs.  V80: measured at 4096 x 800 (round 6, descent 19.9 us: see DESIGN.md 3.6); V89: a forward of 8 leaves
         // costs ~80 us of a CU, a descent ~33 us of a sixteenth of one: 13 / 16 for the net (measured: 208 + 48 -> 28.8 k env-steps/s, 216 + 40
         // 24.5 k, 204 + 52 28.7 k, 200 + 56 28.3 k; two kernels 26.5 k); Splendor 3 / 4 players (forward 55-59 us per 8 leaves, descent 27 us):
-        // 25 / 32 for the net (4 players: 200 + 56 -> 35.8 k, 208 + 48 33.1 k, 192 + 64 34.6 k); Azul (descent-heavy, forward 29 us per 16):
+        // round 5 25 / 32 for the net (4 players: 200 + 56 -> 35.8 k, 208 + 48 33.1 k, 192 + 64 34.6 k), round 6 with the descent at 22 us
+        // 13 / 16 (200 + 56 -> 38.8 k, 208 + 48 40.1 k, 216 + 40 36.1 k); Azul (descent-heavy, forward 29 us per 16):
         // 3 / 8 (96 + 160 -> 70.4 k; 112 + 144 68.6 k, 88 + 168 66.3 k).  The hash-net costs next to nothing: a sixteenth.
-        n_net = hash ? (n_cu / 16 > 0 ? n_cu / 16 : 1) : kind == 0 ? n_cu * AZG_V80_NET_SHARE_256 / 256 : kind == 4 ? n_cu * 3 / 8 : (kind == 2 || kind == 3) ? n_cu * 25 / 32 : n_cu * 13 / 16;
+        n_net = hash ? (n_cu / 16 > 0 ? n_cu / 16 : 1) : kind == 0 ? n_cu * AZG_V80_NET_SHARE_256 / 256 : kind == 4 ? n_cu * 3 / 8 : (kind == 2 || kind == 3) ? n_cu * 13 / 16 : n_cu * 13 / 16;
         n_sel = n_cu - n_net;
     }
     if (n_sel > T) n_sel = T;
