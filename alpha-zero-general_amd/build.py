@@ -65,13 +65,17 @@ def build(force=False, verbose=False):
     import tempfile
     cache = None
     if not force:
-        key = hashlib.sha1(' '.join(FLAGS + [str(u) for u in UNITS]).encode()).hexdigest()[:12]
-        cache = os.path.join(os.environ.get('AZG_OBJ_DIR') or os.path.join(HERE, '..', 'build_ab', 'obj'), key)
-        os.makedirs(cache, exist_ok=True)
-    tmp = cache or tempfile.mkdtemp(prefix='azg_build_')
+        cache = os.environ.get('AZG_OBJ_DIR') or os.path.join(HERE, '..', 'build_ab', 'obj')
+    tmp = None if cache else tempfile.mkdtemp(prefix='azg_build_')
     objs, procs = [], []
     for src, extra in UNITS:                       # the units compile concurrently
-        obj = os.path.join(tmp, src.replace('.hip', '.o'))
+        if cache:                                  # one cache directory per (common flags, this unit's flags): an A/B variant of one
+            key = hashlib.sha1(' '.join(FLAGS + [src] + extra).encode()).hexdigest()[:12]     # unit re-uses the other units' objects
+            udir = os.path.join(cache, key)
+            os.makedirs(udir, exist_ok=True)
+        else:
+            udir = tmp
+        obj = os.path.join(udir, src.replace('.hip', '.o'))
         dep = obj + '.d'
         objs.append(obj)
         if cache and not _unit_stale(obj, dep):

@@ -325,6 +325,7 @@ extern "C" int azg_forest_create(const azg_forest_cfg* cfg, azg_forest** out) {
     if (cfg->n_trees <= 0 || cfg->node_capacity < 16) { delete f; return fail("bad n_trees / node_capacity"); }
     if (cfg->node_capacity > (1 << AZG_IDX_BITS) - 2) { delete f; return fail("node_capacity too large"); }
     if (cfg->universes < 0 || cfg->universes > AZG_MAX_UNIVERSES) { delete f; return fail("universes out of range"); }
+    if (cfg->numMCTSSims <= 0 || cfg->numMCTSSims >= (1 << 24)) { delete f; return fail("numMCTSSims must be in 1 .. 2^24 - 1"); }   // (kernels.hip.h: the forced-playout test)
     ForestDev& D = f->dev;
     memset(&D, 0, sizeof(D));
     D.T = cfg->n_trees;
@@ -776,7 +777,7 @@ extern "C" int azg_selfplay_drain_examples(azg_forest* f, int max_records, int8_
 // arguments: HIP graphs that captured this forest's launches must be captured again.  Searches in flight keep their n_sims.
 extern "C" int azg_forest_set_search_params(azg_forest* f, int numMCTSSims, double prob_fullMCTS) {
     if (!f) return fail("null forest");
-    if (numMCTSSims <= 0 || !(prob_fullMCTS >= 0.0 && prob_fullMCTS <= 1.0)) return fail("azg_forest_set_search_params: bad argument");
+    if (numMCTSSims <= 0 || numMCTSSims >= (1 << 24) || !(prob_fullMCTS >= 0.0 && prob_fullMCTS <= 1.0)) return fail("azg_forest_set_search_params: bad argument");
     f->dev.numMCTSSims = numMCTSSims;
     f->dev.prob_fullMCTS = prob_fullMCTS;
     return 0;

@@ -785,8 +785,20 @@ __device__ __forceinline__ int select_tree(const ForestDev& F, const int t, type
                         idv = FR::IDB == 1 ? (uint32_t)*(const uint8_t*)(rp + id_off(j2)) : (uint32_t)*(const uint16_t*)(rp + id_off(j2));
                     }
                     if (forced) {                                                 // :218-220 first deficient action wins
+                        // The reference's test is  Nsa < int(sqrt(0.5 * P * n_iter))  -- an f64 square root per lane and simulation (a ~35-
+                        // instruction software sequence, v_rsq_f64 at a quarter of the rate).  It is decided without one: for an integer
+                        // n >= 0,  n < trunc(RN(sqrt(x)))  <=>  m = n + 1 <= RN(sqrt(x))  <=>  m * m <= x.  (<=) sqrt(x) >= m and rounding is
+                        // monotone.  (=>) otherwise sqrt(x) < m rounds UP to m, i.e. m - sqrt(x) <= m 2^-53 and m^2 - x <= m^2 2^-52; but
+                        // x = 0.5 * p * k is exact (24 + 24 bits) and a multiple of q = 2^(e - 24) for p in [2^e, 2^(e + 1)), so is m^2
+                        // (e <= 0), hence m^2 - x >= q, while m^2 < 2 x = p k < 2^(e + 1) k gives m^2 2^-52 < 2^(e - 51) k <= q for
+                        // k < 2^24 (azg_forest_create checks numMCTSSims): a contradiction.  m * m is exact (m <= 2^24).
+#ifndef AZG_FORCED_SQRT
+                        const double mm = (double)(n + 1u);
+                        const uint64_t def = __ballot(a_ok && (mm * mm <= 0.5 * (double)p * (double)H.sim_idx));
+#else
                         const double thr = sqrt(0.5 * (double)p * (double)H.sim_idx);
                         const uint64_t def = __ballot(a_ok && ((long long)n < (long long)thr));
+#endif
                         if (def) {
                             const int src = first_lane(def);
                             j = base + src;

@@ -442,7 +442,15 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
     s1 = eng.stats()
     dt = t1 - t0
     rdev = dev if (not use_dist or dist.get_backend() == 'nccl') else 'cpu'          # (gloo: the small reductions on host tensors)
+    per_rank = None
     if use_dist:
+        # what every rank saw, side by side (stragglers and the memory margin beside the forest + the communicator's buffers are visible in
+        # the rank-reduced line): its own wall time of the timed region, its plies, its free HBM after the run
+        free_b, total_b = torch.cuda.mem_get_info()
+        mine = torch.tensor([t1 - t0, float(s1['plies'] - s0['plies']), float(free_b), float(total_b)], dtype=torch.float64, device=rdev)
+        allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allv, mine)
+        per_rank = [[float(x) for x in v.tolist()] for v in allv]
         tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -469,7 +477,9 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
         # it, the record count every rank contributed (from the count all_gather), the bytes rank 0 received, the wall time of the exchange
         res.update(rccl_world=dist.get_world_size(), rccl_backend=dist.get_backend(), examples_per_rank=ginfo.get('counts'),
                    gather_ms=ginfo.get('ms'), gather_bytes_received_rank0=ginfo.get('bytes_received'), gather_mode=ginfo.get('mode'),
-                   gather_row_bytes=ginfo.get('row_bytes'))
+                   gather_row_bytes=ginfo.get('row_bytes'),
+                   value_per_rank=[round(v[1] / v[0], 1) for v in per_rank], ms_per_step_per_rank=[round(v[0] / steps * 1e3, 3) for v in per_rank],
+                   free_hbm_bytes_per_rank=[int(v[2]) for v in per_rank], total_hbm_bytes_per_rank=[int(v[3]) for v in per_rank])
     res['roofline'] = measure_roofline(a, eng, T) if roofline and a.roofline_rounds > 0 else None
     eng._last_roofline = res['roofline']
     res['percu'] = bool(getattr(eng, 'percu', False)) and not getattr(eng, 'async_pipe', False)
@@ -583,7 +593,8 @@ def main():
               'engine_errors', 'forest_bytes_per_gpu', 'node_capacity', 'max_live_after_gc', 'max_live_frac', 'max_nodes_per_tree', 'gc_runs',
               'rounds_timed', 'ms_per_round', 'preroll_plies', 'work_budget', 'advance_every', 'percu', 'async_pipe'):
         out[k] = r[k]
-    for k in ('rccl_world', 'rccl_backend', 'examples_per_rank', 'gather_ms', 'gather_bytes_received_rank0', 'gather_mode', 'gather_row_bytes'):
+    for k in ('rccl_world', 'rccl_backend', 'examples_per_rank', 'gather_ms', 'gather_bytes_received_rank0', 'gather_mode', 'gather_row_bytes',
+              'value_per_rank', 'ms_per_step_per_rank', 'free_hbm_bytes_per_rank', 'total_hbm_bytes_per_rank'):
         if k in r:
             out[k] = r[k]
     out['config']['preroll'] = ('%d plies of fast searches (numMCTSSims // ratio_fullMCTS, MCTS.py:58-59) before the warm-up, untimed: games end '

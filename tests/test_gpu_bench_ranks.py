@@ -32,6 +32,10 @@ def test_bench_multi_rank_flow_world2():
     assert r['plies_completed'] > 2 * 64 * 20 and r['value'] > 0                      # both ranks' plies are in the whole-job figure
     assert abs(r['value'] * r['ms_per_step'] * r['steps'] / 1e3 - r['plies_completed']) < 1.0
     assert r['config']['games_per_gpu'] == 64
+    # every rank's own rate, wall time and HBM margin are in the line (a straggler or a nearly full GPU shows up in SCALE_rNN.json)
+    assert len(r['value_per_rank']) == 2 and all(v > 0 for v in r['value_per_rank'])
+    assert abs(sum(r['value_per_rank']) - r['value']) / r['value'] < 0.2 and max(r['ms_per_step_per_rank']) <= r['ms_per_step'] * 1.001
+    assert all(0 < f <= t for f, t in zip(r['free_hbm_bytes_per_rank'], r['total_hbm_bytes_per_rank']))
 
 
 def test_bench_multi_rank_flow_fails_loudly():
