@@ -13,6 +13,7 @@
 #define AZG_WAVE_LOCAL_SYNC 1
 #define AZG_FUSED_DEVICE_ONLY 1
 #define AZG_NN_KERNEL static
+#define AZG_NN_OPAQUE_TID 1        /* nn_kernels.hip.h nn_tid(): nothing thread-derived is hoisted out of the persistent net kernel's loop */
 #include "../../include/azg.h"
 #include "../../include/azg_testaids.h"
 #include "azg_host.h"

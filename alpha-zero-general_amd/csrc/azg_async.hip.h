@@ -865,13 +865,14 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
     const int n_cu = D.n_cu;
     const int T = dev->T;
     if (n_net <= 0 || n_sel <= 0) {
-        // default split of the CUs.  V80: measured at 4096 x 800 (round 6, descent 19.9 us: see DESIGN.md 3.6); V89: a forward of 8 leaves
-        // costs ~80 us of a CU, a descent ~33 us of a sixteenth of one: 13 / 16 for the net (measured: 208 + 48 -> 28.8 k env-steps/s, 216 + 40
-        // 24.5 k, 204 + 52 28.7 k, 200 + 56 28.3 k; two kernels 26.5 k); Splendor 3 / 4 players (forward 55-59 us per 8 leaves, descent 27 us):
+        // default split of the CUs.  V80: measured at 4096 x 800 (round 6, descent 19.9 us: see DESIGN.md 3.6); V89: round 5 a forward of 8
+        // leaves cost ~75 us of a CU, a descent ~33 us of a sixteenth of one: 13 / 16 for the net (208 + 48 -> 28.8 k env-steps/s, 216 + 40
+        // 24.5 k, 204 + 52 28.7 k, 200 + 56 28.3 k; two kernels 26.5 k); round 6 with the forward at 63-70 us (nn_tid): 3 / 4 (208 + 48 -> 26.8 k,
+        // 200 + 56 30.5 k, 192 + 64 32.4 k, 184 + 72 31.7 k, 176 + 80 30.7 k); Splendor 3 / 4 players (forward 55-59 us per 8 leaves, descent 27 us):
         // round 5 25 / 32 for the net (4 players: 200 + 56 -> 35.8 k, 208 + 48 33.1 k, 192 + 64 34.6 k), round 6 with the descent at 22 us
         // 13 / 16 (200 + 56 -> 38.8 k, 208 + 48 40.1 k, 216 + 40 36.1 k); Azul (descent-heavy, forward 29 us per 16):
         // 3 / 8 (96 + 160 -> 70.4 k; 112 + 144 68.6 k, 88 + 168 66.3 k).  The hash-net costs next to nothing: a sixteenth.
-        n_net = hash ? (n_cu / 16 > 0 ? n_cu / 16 : 1) : kind == 0 ? n_cu * AZG_V80_NET_SHARE_256 / 256 : kind == 4 ? n_cu * 3 / 8 : (kind == 2 || kind == 3) ? n_cu * 13 / 16 : n_cu * 13 / 16;
+        n_net = hash ? (n_cu / 16 > 0 ? n_cu / 16 : 1) : kind == 0 ? n_cu * AZG_V80_NET_SHARE_256 / 256 : kind == 4 ? n_cu * 3 / 8 : (kind == 2 || kind == 3) ? n_cu * 13 / 16 : n_cu * 3 / 4;
         n_sel = n_cu - n_net;
     }
     if (n_sel > T) n_sel = T;

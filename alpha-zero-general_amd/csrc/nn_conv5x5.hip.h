@@ -141,7 +141,7 @@ template <int KC, int NS, bool RELU = true>
 __device__ __forceinline__ void conv3x3_tile(const float* __restrict__ Wfrag, const float* __restrict__ bias,
                                              const float* IN, float* OUT, const float* RES) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, KCH = 9 * KC, RG = 3, MAXT = (RT + RG - 1) / RG;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int tidx_ = nn_tid(), lane = tidx_ & 63, wave = tidx_ >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
     // this lane's cell of each of the wave's tiles: row index, and which of the 9 taps stay on the board
     int row[MAXT];
@@ -233,7 +233,7 @@ template <int NS, bool RELU = true, int NPL = 3>
 __device__ __forceinline__ void conv3x3_first_split(const float* __restrict__ Wfrag, const float* __restrict__ bias,
                                                     const float* IN, uint8_t* OUT) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 2) * 128;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int tidx_ = nn_tid(), lane = tidx_ & 63, wave = tidx_ >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
     float4 w[9];
 #pragma unroll
@@ -286,7 +286,7 @@ __device__ __forceinline__ void conv3x3_first_h2(const float* __restrict__ Wfrag
                                                  const float* IN, uint8_t* OUT, Prefetch prefetch = Prefetch()) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, CS = 68, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 2) * 128;
     constexpr float WS = 256.f;                             // weight scale (|w| < 255 keeps the hi half finite)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int tidx_ = nn_tid(), lane = tidx_ & 63, wave = tidx_ >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
     uint4 wh, wl;
     C5F_PH(0);
@@ -343,7 +343,7 @@ __device__ __forceinline__ void heads1x1_h2(const float* __restrict__ Wp, const 
                                             const float* __restrict__ bv, const uint8_t* IN, float* HP, float* HV) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, PB = (ROWS + 2) * 128;
     constexpr float WS = 256.f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int tidx_ = nn_tid(), lane = tidx_ & 63, wave = tidx_ >> 6, g = lane >> 4, r16 = lane & 15;
     uint4 wh[2], wl[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -394,7 +394,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
                                               const uint4* __restrict__ WNEXT = nullptr, uint4 (*wio)[6][3] = nullptr) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 2) * 128, KCH = 18;
     static_assert(MAXT == 5 && RT - RG * (MAXT - 1) == 1, "step schedule: two tile pairs per wave + one odd tile in the first row group");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int tidx_ = nn_tid(), lane = tidx_ & 63, wave = tidx_ >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
     C5_PH(24);
     static_assert(!CM || NS == 8, "cell-major tiles: two cells of eight samples per 16-row tile");
@@ -632,7 +632,7 @@ __device__ __forceinline__ void conv3x3_split(const uint4* __restrict__ Wfrag, c
 // (NPL = 2: f16 x 2 operands, [4 ct][2 chunks][2 planes]; w[c * 3 + plane], the third slot unused)
 template <int NPL = 3>
 __device__ __forceinline__ void gemm64_wload(const uint4* __restrict__ Wfrag, uint4 (&w)[6]) {
-    const int lane = threadIdx.x & 63, ct = (threadIdx.x >> 6) & 3;
+    const int tidx_ = nn_tid(), lane = tidx_ & 63, ct = (tidx_ >> 6) & 3;
 #pragma unroll
     for (int c = 0; c < 2; c++)
 #pragma unroll
@@ -642,7 +642,7 @@ template <int NS, int NPL = 3>
 __device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t* IN, f32x4 (&acc)[(NS * 25 + 15) / 16 / 3 + 1]) {
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 2) * 128;
     static_assert(MAXT == RT / 3 + 1 && RT - RG * (MAXT - 1) == 1, "tile schedule: MAXT - 1 tiles per wave + one odd tile in the first row group");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    const int tidx_ = nn_tid(), lane = tidx_ & 63, wave = tidx_ >> 6, g = lane >> 4, r16 = lane & 15;
     const int rg = wave >> 2;
 #pragma unroll
     for (int i = 0; i < MAXT; i++) {

@@ -26,6 +26,23 @@
 
 namespace azg {
 
+// The thread index as the net kernels' helper functions see it.  In the translation unit of the pipeline's PERSISTENT net kernel
+// (azg_async.hip defines AZG_NN_OPAQUE_TID) it is laundered through an empty asm at every use: the forward runs inside one long loop there,
+// everything derived from the raw threadIdx.x is loop-invariant, and the compiler hoisted ~50 per-lane operand addresses of the Santorini
+// forward to the kernel's entry and SPILLED them (k_async_net<NetC5>: 196 B of scratch, one scratch reload per basic block of the
+// forward, each waiting with vmcnt(0) behind the weight prefetch; the stand-alone kernel has no scratch).  Opaque, they are recomputed
+// where they are used -- a handful of VALU instructions per helper call.
+__device__ __forceinline__ int nn_tid() {
+#ifdef AZG_NN_OPAQUE_TID
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+#else
+    return (int)threadIdx.x;
+#endif
+}
+
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));     // v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 operands
 
