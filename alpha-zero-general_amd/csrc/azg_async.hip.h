@@ -575,19 +575,24 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
     constexpr int BS = NET::BS;
     constexpr uint32_t FULL = (1u << BS) - 1u;
     int* const sidx = (int*)(lds + NET::LDS);
-    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t t_begin = wall32();
     unsigned long long* const P = (unsigned long long*)(lds + NET::LDS + 160);   // batches, leaves, busy, idle, leaf wait (LDS: nothing live across the forward)
     unsigned long long* const smask = (unsigned long long*)(sidx + H2_IND_MASK);
-    if (tid < 6) P[tid] = 0ull;
+    if ((int)threadIdx.x < 6) P[threadIdx.x] = 0ull;
     // the workgroup's TICKET RANGE: sixteen consecutive leaf tickets taken with one returning atomic add (a claim that has to look at
     // head and tail and compare-and-swap costs several memory round trips and serialises the 150 workgroups: measured 285 us of leaf
     // wait).  The range is consumed in one batch when its sixteen leaves are there, in several when the producers are slow; sidx[34] =
     // first ticket, sidx[35] = bit mask of the tickets already consumed, sidx[36] = 1 when the range is valid.
-    if (tid == 0) sidx[36] = 0;
+    if (threadIdx.x == 0) sidx[36] = 0;
     __syncthreads();
 #pragma unroll 1
     for (;;) {
+        // (the thread index is opaque per batch: what the claim and the hand-back derive from it -- LDS addresses of the batch descriptor, lane
+        // masks -- was otherwise computed at kernel entry, kept across the forward that fills the register file, i.e. SPILLED, and
+        // reloaded from scratch with a vmcnt(0) wait in front of the claim's and the hand-back's first use: on the hand-over path)
+        int tid_ = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid_));
+        const int tid = tid_, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         if (wave == 0) {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
             AsyncCtl* const ctl = A->ctl;
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
         }
         // (no barrier here: between the barrier above and the next claim only wave 0 touches the batch descriptor, in program order)
     }
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
         unsigned long long* prof = A->prof;
         atomicAdd(prof + 3, P[0]); atomicAdd(prof + 4, P[1]); atomicAdd(prof + 5, P[2]); atomicAdd(prof + 6, P[3]);
