@@ -97,6 +97,13 @@ typedef const AsyncArgs __attribute__((address_space(4))) * AsyncArgsC;
 __device__ __forceinline__ uint32_t aload(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void astore(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t wall32() { return (uint32_t)wall_clock64(); }
+// a wave-uniform 64-bit value (an LDS word every lane loaded from the same address) moved to a SCALAR register pair: the claim loop's
+// tree masks then live, and are combined, on the scalar unit -- as vector pairs the allocator spilled them to scratch around the inlined
+// descent (k_async_select<SplendorDev<2>>: ~12 scratch loads / stores on the claim path, each a vmcnt(0) round trip through the CU's busy
+// memory queue between "a tree is ready" and "a wave works on it")
+__device__ __forceinline__ unsigned long long uni_u64(unsigned long long v) {
+    return ((unsigned long long)uni_u32((uint32_t)(v >> 32)) << 32) | (unsigned long long)uni_u32((uint32_t)v);
+}
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 #ifdef AZG_ASYNC_PART_SELECT     /* the descent kernel: azg_async_sel.hip */
@@ -243,23 +250,31 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
 #define AZG_LDS_LD32(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #pragma unroll 1
     for (;;) {
-        const int l = lane_id();
+        // (the lane id is taken afresh -- lane_id() is opaque in this translation unit -- wherever it is used: as ONE value for the whole
+        // iteration it was live across the inlined descent, the allocator spilled it at the top of the loop and re-loaded it from scratch in
+        // front of every use on the claim path: six vmcnt(0) round trips through the CU's busy memory queue between "a tree is ready"
+        // and "a wave works on it")
+#define AZG_L lane_id()
         if (AZG_LDS_LD32(&C->retired) >= (uint32_t)n_g) break;
         // ---- look for a ready tree of this workgroup that no wave is handling: in the LDS copy of the ready words first ----
-        unsigned long long c0 = AZG_LDS_LD64(&C->seen[0]) & ~AZG_LDS_LD64(&C->claimed[0]);
-        unsigned long long c1 = AZG_LDS_LD64(&C->seen[1]) & ~AZG_LDS_LD64(&C->claimed[1]);
+        unsigned long long c0 = uni_u64(AZG_LDS_LD64(&C->seen[0]) & ~AZG_LDS_LD64(&C->claimed[0]));
+        unsigned long long c1 = uni_u64(AZG_LDS_LD64(&C->seen[1]) & ~AZG_LDS_LD64(&C->claimed[1]));
         if (!(c0 | c1)) {
             // nothing known to be ready: ONE wave of the workgroup (the scout) polls the ready words in HBM, the others sleep on the LDS copy
             uint32_t got = 0u;
-            if (l == 0) {
-                if (AZG_ASYNC_SCOUTS == 1) got = __hip_atomic_exchange(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u ? 1u : 0u;
+            if (AZG_L == 0) {
+                // (the constant comes out of an opaque scalar: the compiler otherwise keeps ONE vector register holding 1 for the whole kernel,
+                // spills it around the descent and re-loads it from scratch here, in front of every poll)
+                uint32_t one;
+                asm volatile("s_mov_b32 %0, 1" : "=s"(one));
+                if (AZG_ASYNC_SCOUTS == 1) got = __hip_atomic_exchange(&C->scout, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u ? 1u : 0u;
                 else {          // up to AZG_ASYNC_SCOUTS polls in flight: a poll's answer is ~2 us old, a second one started meanwhile halves the gap
                     got = __hip_atomic_fetch_add(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)AZG_ASYNC_SCOUTS ? 1u : 0u;
                     if (!got) __hip_atomic_fetch_sub(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             if (!uni_u32(got)) {                        // (the clock is read on passes that found nothing only: never in front of a claim)
-                if (l == 0) {
+                if (AZG_L == 0) {
                     const uint32_t now = wall32(), d = now - C->idle_last[wave];
                     C->idle_acc[wave] += d < ASYNC_IDLE_STEP_CAP ? d : ASYNC_IDLE_STEP_CAP;
                     C->idle_last[wave] = now;
@@ -267,37 +282,37 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                 __builtin_amdgcn_s_sleep(AZG_IDLE_SLEEP);
                 continue;
             }
-            const uint32_t v0 = l < n_g ? aload(my_ready + l) : 0u;
-            const uint32_t v1 = l + 64 < n_g ? aload(my_ready + 64 + l) : 0u;
+            const uint32_t v0 = AZG_L < n_g ? aload(my_ready + AZG_L) : 0u;
+            const uint32_t v1 = AZG_L + 64 < n_g ? aload(my_ready + 64 + AZG_L) : 0u;
             {
                 const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
                 const uint32_t* my_ts = A->ts_ready + (size_t)g * ASYNC_RS;
-                const uint32_t s0 = l < n_g ? aload(my_ts + l) : 0u, s1 = l + 64 < n_g ? aload(my_ts + 64 + l) : 0u;
-                __hip_atomic_store(&C->rts[l], s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&C->rts[64 + l], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t s0 = AZG_L < n_g ? aload(my_ts + AZG_L) : 0u, s1 = AZG_L + 64 < n_g ? aload(my_ts + 64 + AZG_L) : 0u;
+                __hip_atomic_store(&C->rts[AZG_L], s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&C->rts[64 + AZG_L], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (A->total_calls) {
                     const uint32_t st = uni_u32(aload(&A->ctl->stop));
-                    if (st && l == 0) __hip_atomic_store(&C->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (st && AZG_L == 0) __hip_atomic_store(&C->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             // current = smaller than the word this workgroup consumed last for the tree (a tree's ready words decrease over a launch)
-            const unsigned long long r0 = __ballot(v0 != 0u && v0 < AZG_LDS_LD32(&C->last[l]));
-            const unsigned long long r1 = __ballot(v1 != 0u && v1 < AZG_LDS_LD32(&C->last[64 + l]));
-            __hip_atomic_store(&C->rw[l], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&C->rw[64 + l], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long r0 = __ballot(v0 != 0u && v0 < AZG_LDS_LD32(&C->last[AZG_L]));
+            const unsigned long long r1 = __ballot(v1 != 0u && v1 < AZG_LDS_LD32(&C->last[64 + AZG_L]));
+            __hip_atomic_store(&C->rw[AZG_L], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&C->rw[64 + AZG_L], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             wave_sync();
-            if (l == 0) {
+            if (AZG_L == 0) {
                 __hip_atomic_store(&C->seen[0], r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_store(&C->seen[1], r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            c0 = r0 & ~AZG_LDS_LD64(&C->claimed[0]);
-            c1 = r1 & ~AZG_LDS_LD64(&C->claimed[1]);
+            c0 = r0 & ~uni_u64(AZG_LDS_LD64(&C->claimed[0]));
+            c1 = r1 & ~uni_u64(AZG_LDS_LD64(&C->claimed[1]));
             bool leave = false;
             if (!(c0 | c1)) {
                 const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
                 const uint32_t now = wall32();
                 uint32_t acc = 0u;
-                if (l == 0) {
+                if (AZG_L == 0) {
                     const uint32_t d = now - C->idle_last[wave];
                     acc = C->idle_acc[wave] + (d < ASYNC_IDLE_STEP_CAP ? d : ASYNC_IDLE_STEP_CAP);
                     C->idle_acc[wave] = acc; C->idle_last[wave] = now;
@@ -305,13 +320,13 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                 acc = uni_u32(acc);
                 if (uni_u32(aload(&A->ctl->abort))) leave = true;
                 else if (acc > (uint32_t)timeout) {                        // (this wave has looked for work for that long and found none)
-                    if (l == 0) { astore(&A->ctl->abort, 1u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT); }
+                    if (AZG_L == 0) { astore(&A->ctl->abort, 1u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT); }
                     leave = true;
                 }
-                if (leave && l == 0) __hip_atomic_store(&C->retired, 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // everyone out
+                if (leave && AZG_L == 0) __hip_atomic_store(&C->retired, 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // everyone out
                 if (!leave) __builtin_amdgcn_s_sleep(AZG_SCOUT_SLEEP);
             }
-            if (l == 0) {
+            if (AZG_L == 0) {
                 if (AZG_ASYNC_SCOUTS == 1) __hip_atomic_store(&C->scout, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else __hip_atomic_fetch_sub(&C->scout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
             if (!(c0 | c1)) continue;
         }
         // the first candidate at or after the rotating cursor
-        const uint32_t cur = AZG_LDS_LD32(&C->cursor) & 127u;
+        const uint32_t cur = uni_u32(AZG_LDS_LD32(&C->cursor)) & 127u;
         const unsigned long long m0 = cur < 64u ? c0 & (~0ull << cur) : 0ull, m1 = cur < 64u ? c1 : c1 & (~0ull << (cur - 64u));
         int i;
         if (m0) i = __builtin_ctzll(m0);
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         else i = 64 + __builtin_ctzll(c1);
         const unsigned long long bit = 1ull << (i & 63);
         unsigned long long old = 0ull;
-        if (l == 0) {
+        if (AZG_L == 0) {
             old = __hip_atomic_fetch_or(&C->claimed[i >> 6], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&C->cursor, (uint32_t)i + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -336,9 +351,9 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         // the claim is ours.  Is the snapshot current?  (A wave that handled the tree since the poll recorded the word it consumed BEFORE it
         // released the claim.)
         const uint32_t word = uni_u32(AZG_LDS_LD32(&C->rw[i]));
-        if (l == 0) __hip_atomic_fetch_and(&C->seen[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // taken: ready again only by a later poll
+        if (AZG_L == 0) __hip_atomic_fetch_and(&C->seen[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // taken: ready again only by a later poll
         if (word == 0u || word >= uni_u32(AZG_LDS_LD32(&C->last[i]))) {
-            if (l == 0) __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (AZG_L == 0) __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             continue;
         }
         int t;
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
             t = g + i * A->n_sel;
             const uint32_t now = wall32();
             const uint32_t w = now - uni_u32(AZG_LDS_LD32(&C->rts[i]));
-            if (l == 0) {
+            if (AZG_L == 0) {
                 atomicAdd(&C->prof[2], (unsigned long long)(now - idle_since));
                 atomicAdd(&C->prof[3], (unsigned long long)w);
                 atomicAdd(&C->hist[(w / 100u) < 31u ? (w / 100u) : 31u], 1u);
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                                              as_global(A->pi), as_global(A->v), A->noise);
                 else
                     r = select_tree<G, true>(F, t, sm, dense, A->aleaf, A->leaf_valid, A->needs_eval, A->noise, A->pi, A->v, A->noise);
-                if (l == 0) {
+                if (AZG_L == 0) {
                     atomicAdd(&C->prof[0], 1ull); atomicAdd(&C->prof[1], (unsigned long long)(wall32() - c0t));
                     atomicAdd(&C->prof[4], (unsigned long long)((uint32_t)clock64() - y0t));
                 }
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                 const unsigned long long total = A->total_calls;
                 if (total) {
                     uint32_t stop = 0u;
-                    if (l == 0) {
+                    if (AZG_L == 0) {
                         const uint32_t c = __hip_atomic_fetch_add(&C->calls, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
                         if ((c & 31u) == 0u) {
                             const unsigned long long g0 = atomicAdd(&A->ctl->calls, 32ull) + 32ull;
@@ -402,7 +417,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
             if (r == 0) {
                 drain_vmem();
                 const bool on = async_between_calls<G>(args, t, mine);
-                if (l == 0) atomicAdd(&C->prof[5], 1ull);
+                if (AZG_L == 0) atomicAdd(&C->prof[5], 1ull);
                 if (!on) { left = 0u; break; }                              // idle (episode quota), parked with an error: done with this launch
             }
         }
@@ -416,32 +431,32 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         uint32_t pv0, pv1, ps0, ps1;
         {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
-            if (need && l == 0) tk = atomicAdd(&A->ctl->leaf_tail, 1u);
+            if (need && AZG_L == 0) tk = atomicAdd(&A->ctl->leaf_tail, 1u);
             const uint32_t* my_ts = A->ts_ready + (size_t)g * ASYNC_RS;
-            pv0 = l < n_g ? aload(my_ready + l) : 0u; pv1 = l + 64 < n_g ? aload(my_ready + 64 + l) : 0u;
-            ps0 = l < n_g ? aload(my_ts + l) : 0u; ps1 = l + 64 < n_g ? aload(my_ts + 64 + l) : 0u;
+            pv0 = AZG_L < n_g ? aload(my_ready + AZG_L) : 0u; pv1 = AZG_L + 64 < n_g ? aload(my_ready + 64 + AZG_L) : 0u;
+            ps0 = AZG_L < n_g ? aload(my_ts + AZG_L) : 0u; ps1 = AZG_L + 64 < n_g ? aload(my_ts + 64 + AZG_L) : 0u;
         }
-        if (l == 0) __hip_atomic_store(&C->last[i], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (AZG_L == 0) __hip_atomic_store(&C->last[i], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         drain_vmem();
         {
             // publish the snapshot (as a scout would; several waves may do so at once: every value is checked against `last` when it is claimed)
             wave_sync();
-            const unsigned long long r0 = __ballot(pv0 != 0u && pv0 < AZG_LDS_LD32(&C->last[l]));
-            const unsigned long long r1 = __ballot(pv1 != 0u && pv1 < AZG_LDS_LD32(&C->last[64 + l]));
-            __hip_atomic_store(&C->rw[l], pv0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&C->rw[64 + l], pv1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&C->rts[l], ps0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&C->rts[64 + l], ps1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long r0 = __ballot(pv0 != 0u && pv0 < AZG_LDS_LD32(&C->last[AZG_L]));
+            const unsigned long long r1 = __ballot(pv1 != 0u && pv1 < AZG_LDS_LD32(&C->last[64 + AZG_L]));
+            __hip_atomic_store(&C->rw[AZG_L], pv0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&C->rw[64 + AZG_L], pv1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&C->rts[AZG_L], ps0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&C->rts[64 + AZG_L], ps1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             wave_sync();
-            if (l == 0) {
+            if (AZG_L == 0) {
                 __hip_atomic_store(&C->seen[0], r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_store(&C->seen[1], r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        if (l == 0) __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (AZG_L == 0) __hip_atomic_fetch_and(&C->claimed[i >> 6], ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
-            if (l == 0) {
+            if (AZG_L == 0) {
                 if (need) {
                     const uint32_t rb = (uint32_t)A->ring_bits;
                     // ring entry: tree [19:0] | time stamp (100 MHz clock >> 4, 12 bits: profile only) [31:20] | calls left [55:32] | lap tag [63:60]
@@ -458,6 +473,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         idle_since = wall32();
         if (lane_id() == 0) { C->idle_acc[wave] = 0u; C->idle_last[wave] = idle_since; }
     }
+#undef AZG_L
     if (lane_id() == 0) atomicAdd(&C->prof[2], (unsigned long long)(wall32() - idle_since));
     __syncthreads();
     {
@@ -873,11 +889,12 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
         // default split of the CUs.  V80: measured at 4096 x 800 (round 6, descent 19.9 us: see DESIGN.md 3.6); V89: round 5 a forward of 8
         // leaves cost ~75 us of a CU, a descent ~33 us of a sixteenth of one: 13 / 16 for the net (208 + 48 -> 28.8 k env-steps/s, 216 + 40
         // 24.5 k, 204 + 52 28.7 k, 200 + 56 28.3 k; two kernels 26.5 k); round 6 with the forward at 63-70 us (nn_tid): 3 / 4 (208 + 48 -> 26.8 k,
-        // 200 + 56 30.5 k, 192 + 64 32.4 k, 184 + 72 31.7 k, 176 + 80 30.7 k); Splendor 3 / 4 players (forward 55-59 us per 8 leaves, descent 27 us):
+        // 200 + 56 30.5 k, 192 + 64 32.4 k, 184 + 72 31.7 k, 176 + 80 30.7 k; with the claim path off scratch 192 + 64 33.2 k, 196 + 60 33.9 k,
+        // 200 + 56 33.6 k: 49 / 64); Splendor 3 / 4 players (forward 55-59 us per 8 leaves, descent 27 us):
         // round 5 25 / 32 for the net (4 players: 200 + 56 -> 35.8 k, 208 + 48 33.1 k, 192 + 64 34.6 k), round 6 with the descent at 22 us
         // 13 / 16 (200 + 56 -> 38.8 k, 208 + 48 40.1 k, 216 + 40 36.1 k); Azul (descent-heavy, forward 29 us per 16):
-        // 3 / 8 (96 + 160 -> 70.4 k; 112 + 144 68.6 k, 88 + 168 66.3 k).  The hash-net costs next to nothing: a sixteenth.
-        n_net = hash ? (n_cu / 16 > 0 ? n_cu / 16 : 1) : kind == 0 ? n_cu * AZG_V80_NET_SHARE_256 / 256 : kind == 4 ? n_cu * 3 / 8 : (kind == 2 || kind == 3) ? n_cu * 13 / 16 : n_cu * 3 / 4;
+        // round 5 3 / 8 (96 + 160 -> 70.4 k; 112 + 144 68.6 k, 88 + 168 66.3 k), round 6 13 / 32 (96 + 160 69.9 k, 104 + 152 72.3 k).  The hash-net costs next to nothing: a sixteenth.
+        n_net = hash ? (n_cu / 16 > 0 ? n_cu / 16 : 1) : kind == 0 ? n_cu * AZG_V80_NET_SHARE_256 / 256 : kind == 4 ? n_cu * 13 / 32 : (kind == 2 || kind == 3) ? n_cu * 13 / 16 : n_cu * 49 / 64;
         n_sel = n_cu - n_net;
     }
     if (n_sel > T) n_sel = T;

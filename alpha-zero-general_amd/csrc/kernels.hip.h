@@ -852,8 +852,22 @@ __device__ __forceinline__ int select_tree(const ForestDev& F, const int t, type
                 const int a = a_sel;
                 bool is_new = false;
                 const long long t_e = AZG_CLK();
-                child = uni_u32(resolve_edge<G, SelState, ASYNC>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es,
-                                                          srng, spec_now, ps0, ps1, ps2));
+#ifndef AZG_SEARCH_OWN_RNG
+#define AZG_SEARCH_OWN_RNG 0
+#endif
+                if constexpr (G::STOCHASTIC || !AZG_SEARCH_OWN_RNG)
+                    child = uni_u32(resolve_edge<G, SelState, ASYNC>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es,
+                                                              srng, spec_now, ps0, ps1, ps2));
+                else {
+                    // (AZG_SEARCH_OWN_RNG, measured and off: a search's env step never draws from the tree's stream unless the game says so --
+                    // random_seed is a magic seed or -1, MCTS.py:63, never the 0 that means "true random" -- so a stream of its own here would
+                    // keep the tree's 64-bit counter out of the descent's registers; but at the 128-register cap the allocation of
+                    // k_async_select<SplendorDev<2>> came out WORSE with it -- a register that carries spilled scalars was itself spilled:
+                    // scratch instructions 17 -> 93, a descent 20.3 -> 21.6 us)
+                    Rng none{0ull, 0ull, 0ull};
+                    child = uni_u32(resolve_edge<G, SelState, ASYNC>(F, t, H, sm, rh.node_id, a, seed, leaf_states, leaf_valid, &is_new, &leaf_terminal, es,
+                                                              none, spec_now, ps0, ps1, ps2));
+                }
                 cyc_edge += AZG_CLK() - t_e;
                 if (child == AZG_NONE) { H.sim_idx = H.n_sims; break; }
                 // memoise: this universe's slot -- or every slot when the env step of `a` cannot depend on the seed (the
