@@ -73,6 +73,7 @@ struct AsyncCtl {                              // zeroed by the host before ever
 //  7 sum of (leaf claimed - leaf pushed)            8 sum of (tree claimed - tree marked ready)
 //  9 launches           10 select workgroup-ticks resident   11 net workgroup-ticks resident
 // 12 n_sel  13 n_net (filled by the host)   14 shader-clock cycles inside the forwards   15 inside the descents   16 plies advanced in-kernel
+// 17 / 18 launches that ended because a descent wave / a net workgroup gave up (time-out)
 // 32..63 histogram of the leaf wait in us (last bucket: >= 31)    64..95 histogram of the ready wait
 struct AsyncArgs {
     ForestDev F;
@@ -484,9 +485,14 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
             atomicAdd(prof + 0, C->prof[0]); atomicAdd(prof + 1, C->prof[1]); atomicAdd(prof + 2, C->prof[2]); atomicAdd(prof + 8, C->prof[3]);
             atomicAdd(prof + 15, C->prof[4]); atomicAdd(prof + 16, C->prof[5]);
             unsigned long long* wi = A->wginfo + (size_t)g * 4;
-            wi[0] = where_am_i(); wi[1] = 1ull; wi[2] += C->prof[0]; wi[3] += C->prof[4];
+            wi[0] = where_am_i(); wi[1] = 1ull; wi[2] += C->prof[0]; wi[3] += C->prof[4];   // role | ticks this workgroup stayed << 8
             atomicAdd(prof + 10, (unsigned long long)(wall32() - t_begin));
             if (g == 0) atomicAdd(prof + 9, 1ull);
+            // (sticky: launches that ended because a descent wave / a net workgroup gave up -- the error bit on tree 0 can be overwritten by
+            // that tree's own header write-back.  Anything more elaborate in the time-out branch itself changes the register allocation of the
+            // whole kernel: a post-mortem dump there took the scratch instructions of the Azul / Santorini / Splendor descents from 45 / 61 / 17
+            // to 175 / 194 / 75 and Azul at 1600 simulations from 35 to 25.5 k env-steps/s)
+            if (g == 0) { const uint32_t ab = aload(&A->ctl->abort); if (ab == 1u || ab == 2u) atomicAdd(prof + 16 + ab, 1ull); }
         }
         if (i < 32 && C->hist[i]) atomicAdd(prof + 64 + i, (unsigned long long)C->hist[i]);
     }
@@ -718,7 +724,7 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
         atomicAdd(prof + 3, P[0]); atomicAdd(prof + 4, P[1]); atomicAdd(prof + 5, P[2]); atomicAdd(prof + 6, P[3]);
         atomicAdd(prof + 7, P[4]); atomicAdd(prof + 11, (unsigned long long)(wall32() - t_begin)); atomicAdd(prof + 14, P[5]);
         unsigned long long* wi = A->wginfo + (size_t)(A->n_sel + (int)blockIdx.x) * 4;
-        wi[0] = where_am_i(); wi[1] = 2ull; wi[2] += P[0]; wi[3] += P[5];
+        wi[0] = where_am_i(); wi[1] = 2ull | ((unsigned long long)(wall32() - t_begin) << 8); wi[2] += P[0]; wi[3] += P[5];
     }
 }
 

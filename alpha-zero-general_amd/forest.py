@@ -164,6 +164,7 @@ class Forest:
         d['select_wave_busy'] = o[1] / max(o[1] + o[2], 1)          # share of a descent wave's life inside select_tree
         d['net_wg_busy'] = o[5] / max(o[11], 1)                     # share of a net workgroup's life inside the forward
         d['n_sel'], d['n_net'] = int(o[12]), int(o[13])
+        d['timeouts'] = dict(select=int(o[17]), net=int(o[18]))        # launches that ended in a time-out (sticky until the counters are reset)
         d['ctl'] = dict(leaf_tail=int(o[20]), leaf_head=int(o[21]), retired=int(o[22]), abort=int(o[23]), calls=int(o[24]), stop=int(o[25]))
         d['forward_cycles'] = o[14] / max(o[3], 1)                   # shader-clock cycles of a forward / a descent, and the clock they imply
         d['descent_cycles'] = o[15] / max(o[0], 1)
@@ -176,13 +177,14 @@ class Forest:
         return d
 
     def async_wginfo(self, reset=True):
-        """per workgroup of the pipeline: (xcc, cu, se, sh, role 1 descent / 2 net, calls, shader cycles per call)"""
+        """per workgroup of the pipeline: (xcc, cu, se, sh, role 1 descent / 2 net, calls, shader cycles per call, us resident in the last launch)"""
         buf = (C.c_uint64 * (4 * 1024))()
         n = check(lib().azg_forest_async_wginfo(self.h, buf, 1024, int(reset)))
         out = []
         for k in range(n):
             w, role, calls, cyc = buf[4 * k], buf[4 * k + 1], buf[4 * k + 2], buf[4 * k + 3]
-            out.append((int(w & 0xF), int((w >> 8) & 0xF), int((w >> 16) & 0x7), int((w >> 24) & 1), int(role), int(calls), cyc / max(calls, 1)))
+            out.append((int(w & 0xF), int((w >> 8) & 0xF), int((w >> 16) & 0x7), int((w >> 24) & 1), int(role & 0xFF), int(calls), cyc / max(calls, 1),
+                        int(role >> 8) / 100.0))          # ... and how long the workgroup stayed in the last launch (us)
         return out
 
     def rounds_profile(self, reset=True):

@@ -480,6 +480,12 @@ def run_workload(a, game_key, T, steps, warmup, rank, world, dev, use_dist, roof
                    gather_row_bytes=ginfo.get('row_bytes'),
                    value_per_rank=[round(v[1] / v[0], 1) for v in per_rank], ms_per_step_per_rank=[round(v[0] / steps * 1e3, 3) for v in per_rank],
                    free_hbm_bytes_per_rank=[int(v[2]) for v in per_rank], total_hbm_bytes_per_rank=[int(v[3]) for v in per_rank])
+    if getattr(eng, 'async_pipe', False):
+        # time-outs of the pipeline since the engine was made (sticky counters of the kernels: a launch that gave up sets error bit 128)
+        try:
+            res['pipeline_timeouts'] = eng.forest.async_profile(reset=False)['timeouts']
+        except Exception as ex_:
+            res['pipeline_timeouts'] = repr(ex_)
     res['roofline'] = measure_roofline(a, eng, T) if roofline and a.roofline_rounds > 0 else None
     eng._last_roofline = res['roofline']
     res['percu'] = bool(getattr(eng, 'percu', False)) and not getattr(eng, 'async_pipe', False)
@@ -593,6 +599,8 @@ def main():
               'engine_errors', 'forest_bytes_per_gpu', 'node_capacity', 'max_live_after_gc', 'max_live_frac', 'max_nodes_per_tree', 'gc_runs',
               'rounds_timed', 'ms_per_round', 'preroll_plies', 'work_budget', 'advance_every', 'percu', 'async_pipe'):
         out[k] = r[k]
+    if 'pipeline_timeouts' in r:
+        out['pipeline_timeouts'] = r['pipeline_timeouts']
     for k in ('rccl_world', 'rccl_backend', 'examples_per_rank', 'gather_ms', 'gather_bytes_received_rank0', 'gather_mode', 'gather_row_bytes',
               'value_per_rank', 'ms_per_step_per_rank', 'free_hbm_bytes_per_rank', 'total_hbm_bytes_per_rank'):
         if k in r:
