@@ -103,6 +103,8 @@ def lib():
             L.azg_forest_async_rounds_hashnet.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         L.azg_forest_async_profile.argtypes = [vp, C.POINTER(C.c_double), i]
         L.azg_forest_async_wginfo.argtypes = [vp, vp, i, i]
+        if hasattr(L, 'azg_forest_async_debug'):
+            L.azg_forest_async_debug.argtypes = [vp, vp, vp, i, vp, i]
     L.azg_stream_create_xcd.argtypes = [i, i, C.POINTER(vp)]
     L.azg_stream_destroy.argtypes = [vp]
     L.azg_debug_placement.argtypes = [i, vp, vp]

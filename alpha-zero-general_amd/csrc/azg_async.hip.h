@@ -31,6 +31,19 @@
 //   Every spin loop is bounded: a wave that finds nothing to do for `timeout_ticks` of the 100 MHz wall clock sets ctl->abort (everyone
 //   leaves) and error bit ERR_ASYNC_TIMEOUT on tree 0 -- a pipeline that cannot make progress (a workgroup not resident) fails loudly
 //   instead of hanging.
+//
+// Recovery (round 6).  The two kernels depend on every workgroup running.  On the MI355X boxes of this project a launch is, about once per 45 s
+// of pipeline time, hit by an event that freezes the whole chip for ~1 ms and after which a few workgroups (seen: three net workgroups) do
+// not run again until other workgroups leave (tools/dbg_async_stall.py: their batch counters stop, they still hold the ticket ranges they
+// had claimed, they resume the moment the launch winds down) -- a preemption by the platform, not something the kernels do.  The leaves queued
+// into those ranges are never evaluated, their trees never come back, the launch cannot end: rounds 5 and 6 saw it as the 20 s "time-out"
+// (error bit 128).  With the work-sharing budget (the engine's default) such a launch now ENDS EARLY AND SAFELY instead: a wave that finds
+// nothing to do for `timeout_ticks` (50 ms) raises the abort flag, everyone leaves, and nothing is lost -- every tree records whether the leaf
+// it queued last has been evaluated (`evald`: cleared by the descent wave in front of the ticket, set by the net workgroup with the hand-back),
+// and the next launch re-queues a tree that is still owed its evaluation (the leaf record is still in the pipeline's leaf array) instead of
+// expanding it with a policy that never arrived.  Eight launches in a row that end this way set the error bit after all (a pipeline that
+// really cannot run -- a workgroup that never becomes resident -- still fails loudly).  With per-tree budgets (shared_budget == 0: "exactly
+// `rounds` calls per tree") an early end would change what a launch means, so there the time-out stays an error.
 #pragma once
 #include "azg_fused.hip.h"
 #include "selfplay.hip.h"
@@ -38,7 +51,6 @@
 namespace azg {
 
 constexpr uint32_t ERR_ASYNC_TIMEOUT = 128;
-constexpr uint32_t ERR_ASYNC_OVERRUN = 256;   // a leaf-ring entry was overwritten by a later lap before its net workgroup took it (abort code 3)
 constexpr int ASYNC_RING_LAPS = 8;            // ring slots = pow2 >= ASYNC_RING_LAPS x T: see the ring entry in k_async_select
 #ifndef AZG_ASYNC_SEL_WAVES
 #define AZG_ASYNC_SEL_WAVES 16                /* waves of a descent workgroup: 16 (<= 128 VGPRs each) fills a CU; 12 (<= 168 VGPRs) measured in round 5 */
@@ -73,7 +85,8 @@ struct AsyncCtl {                              // zeroed by the host before ever
 //  7 sum of (leaf claimed - leaf pushed)            8 sum of (tree claimed - tree marked ready)
 //  9 launches           10 select workgroup-ticks resident   11 net workgroup-ticks resident
 // 12 n_sel  13 n_net (filled by the host)   14 shader-clock cycles inside the forwards   15 inside the descents   16 plies advanced in-kernel
-// 17 / 18 launches that ended because a descent wave / a net workgroup gave up (time-out)
+// 17 / 18 launches that ended early because a descent wave / a net workgroup gave up (time-out); 19 such launches in a row;
+// 26 ticket ranges a net workgroup abandoned because the ring had lapped it
 // 32..63 histogram of the leaf wait in us (last bucket: >= 31)    64..95 histogram of the ready wait
 struct AsyncArgs {
     ForestDev F;
@@ -83,6 +96,7 @@ struct AsyncArgs {
     int8_t* aleaf; uint8_t* leaf_valid; uint8_t* needs_eval; float* pi; float* v;
     AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts_ready;
     unsigned long long* prof;
+    uint32_t* evald;                           // [T]: 1 = the leaf the tree queued last has been evaluated (its pi / v are in place); 0 = still owed (see "Recovery")
     unsigned long long* wginfo;                // [n_sel + n_net][4]: where the workgroup ran (XCC | cu << 8 | se << 16 | sh << 24), role, calls, busy shader cycles
     int noise, rounds, n_sel, ring_bits, batch_wait, timeout_ticks;
     unsigned long long total_calls;            // != 0: the launch ends when the trees TOGETHER have had this many calls (whichever tree is fast
@@ -321,7 +335,12 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                 acc = uni_u32(acc);
                 if (uni_u32(aload(&A->ctl->abort))) leave = true;
                 else if (acc > (uint32_t)timeout) {                        // (this wave has looked for work for that long and found none)
-                    if (AZG_L == 0) { astore(&A->ctl->abort, 1u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT); }
+                    // work-sharing budget: the launch ends early and the next one carries on (see "Recovery"); eight such launches in a row, or
+                    // per-tree budgets: an error
+                    if (AZG_L == 0) {
+                        astore(&A->ctl->abort, 1u);
+                        if (!A->total_calls || atomicAdd(A->prof + 19, 1ull) >= 7ull) atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT);
+                    }
                     leave = true;
                 }
                 if (leave && AZG_L == 0) __hip_atomic_store(&C->retired, 0x7FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // everyone out
@@ -372,7 +391,15 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         bool need = false;
         uint32_t left = word - 1u;                                          // calls of this tree still to run in this launch
         if (AZG_LDS_LD32(&C->stop)) left = 0u;                              // the launch's shared budget is spent: the tree retires as it is
-        while (left > 0u) {
+        // Recovery: the first time the tree is handled in this launch -- was the leaf it queued in an EARLIER launch ever evaluated?  (Only a launch
+        // that ended early leaves such trees behind.)  If not, its leaf record goes back on the ring as it is; no call is spent.
+        if (uni_u32(AZG_LDS_LD32(&C->last[i])) == 0xFFFFFFFFu) {
+            const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+            // (the hand-back word must be SMALLER than the word consumed here -- that is how the workgroup tells a fresh hand-back from a stale
+            // one -- so the re-queue costs the tree one call of the launch's budget)
+            if (uni_u32(aload(A->evald + t)) == 0u && uni_u32(aload(&A->F.hdr[t].status)) == ST_WAIT_NN) { need = true; left = word >= 2u ? word - 2u : 0u; }
+        }
+        while (left > 0u && !need) {
             int r;
             {
                 const AsyncArgs* a = args;
@@ -432,7 +459,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         uint32_t pv0, pv1, ps0, ps1;
         {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
-            if (need && AZG_L == 0) tk = atomicAdd(&A->ctl->leaf_tail, 1u);
+            if (need && AZG_L == 0) { astore(A->evald + t, 0u); tk = atomicAdd(&A->ctl->leaf_tail, 1u); }     // (owed from here on: drained with the leaf record, before the ring entry)
             const uint32_t* my_ts = A->ts_ready + (size_t)g * ASYNC_RS;
             pv0 = AZG_L < n_g ? aload(my_ready + AZG_L) : 0u; pv1 = AZG_L + 64 < n_g ? aload(my_ready + 64 + AZG_L) : 0u;
             ps0 = AZG_L < n_g ? aload(my_ts + AZG_L) : 0u; ps1 = AZG_L + 64 < n_g ? aload(my_ts + 64 + AZG_L) : 0u;
@@ -492,7 +519,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
             // that tree's own header write-back.  Anything more elaborate in the time-out branch itself changes the register allocation of the
             // whole kernel: a post-mortem dump there took the scratch instructions of the Azul / Santorini / Splendor descents from 45 / 61 / 17
             // to 175 / 194 / 75 and Azul at 1600 simulations from 35 to 25.5 k env-steps/s)
-            if (g == 0) { const uint32_t ab = aload(&A->ctl->abort); if (ab == 1u || ab == 2u) atomicAdd(prof + 16 + ab, 1ull); }
+            if (g == 0) { const uint32_t ab = aload(&A->ctl->abort); if (ab == 1u || ab == 2u) atomicAdd(prof + 16 + ab, 1ull); else if (ab == 0u) prof[19] = 0ull; }
         }
         if (i < 32 && C->hist[i]) atomicAdd(prof + 64 + i, (unsigned long long)C->hist[i]);
     }
@@ -628,34 +655,54 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
                 if (lane == 0) b = atomicAdd(&ctl->leaf_head, (uint32_t)BS);
                 base = uni_u32(b); taken = 0u;
             }
-            const uint32_t tk = base + (uint32_t)(lane % BS);
-            const uint32_t tag = ((tk >> rb) & 7u) + 1u;
+            uint32_t tk = base + (uint32_t)(lane % BS);
+            uint32_t tag = ((tk >> rb) & 7u) + 1u;
             uint32_t first_seen = 0u;
             unsigned long long e = 0ull;
             bool seen = false;
             int n = 0;
             uint32_t take = 0u;
             unsigned spins = 0u;
+            bool dumped = false; (void)dumped;
             for (;;) {
                 e = lane < BS ? __hip_atomic_load(A->ring + (tk & rmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                 const uint32_t filled = (uint32_t)__ballot(lane < BS && (uint32_t)(e >> 60) == tag) & ~taken;
                 // a slot of this range that already carries the NEXT lap's tag before its ticket was taken here: the producers lapped this
-                // workgroup (it was held up for several whole cycles of every other tree -- the ring has ASYNC_RING_LAPS x T slots and no
-                // back-pressure: a producer's check of the slot would cost every hand-over a dependent memory round trip) and the entry is
-                // lost.  Fail at once, with a code of its own, instead of waiting 20 s for a tag that cannot come.
+                // workgroup -- it did not run for a whole lap of the ring (ASYNC_RING_LAPS x T tickets: the platform froze it, see "Recovery") and
+                // what was queued into the rest of its range has been overwritten.  It ABANDONS the range and takes a fresh one; the trees whose
+                // leaves were lost are still marked as owed their evaluation (`evald`) and are re-queued by the next launch, which this
+                // launch's end -- those trees never come back, a wave runs into the time-out -- brings about.
                 if ((uint32_t)__ballot(lane < BS && (uint32_t)(e >> 60) == ((((tk >> rb) + 1u) & 7u) + 1u)) & ~taken) {
-                    if (lane == 0) { astore(&ctl->abort, 3u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_OVERRUN); }
-                    n = -1;
-                    break;
+                    uint32_t b = 0u;
+                    if (lane == 0) { b = atomicAdd(&ctl->leaf_head, (uint32_t)BS); atomicAdd(A->prof + 26, 1ull); }
+                    base = uni_u32(b); taken = 0u;
+                    tk = base + (uint32_t)(lane % BS); tag = ((tk >> rb) & 7u) + 1u;
+                    seen = false;
+                    continue;
                 }
                 const uint32_t now = wall32();
                 { const uint32_t d = now - idle_last; idle_acc += d < ASYNC_IDLE_STEP_CAP ? d : ASYNC_IDLE_STEP_CAP; idle_last = now; }
+#ifdef AZG_ASYNC_POSTMORTEM   /* debug: this range has shown nothing for 1 ms although every ticket of it has been issued -- what do the slots hold? */
+                if (!filled && !dumped && (now - idle0) > 100000u) {
+                    const uint32_t tl = uni_u32(__hip_atomic_fetch_add(&ctl->leaf_tail, uni_u32(0u) * (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if ((int32_t)(tl - (base + (uint32_t)BS)) > 0) {
+                        dumped = true;
+                        unsigned long long* dd = A->wginfo + (size_t)4 * 1024 + 280 + 512 + 40 * (size_t)(blockIdx.x < 104 ? blockIdx.x : 103);
+                        if (lane < BS) { dd[8 + lane] = e; dd[24 + lane] = __hip_atomic_fetch_add(A->ring + (tk & rmask), (unsigned long long)(uni_u32(0u) * (uint32_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        if (lane == 0) { dd[0] = (unsigned long long)base | ((unsigned long long)taken << 32); dd[1] = (unsigned long long)tl | ((unsigned long long)aload(&ctl->leaf_head) << 32);
+                                         dd[2] = (unsigned long long)(now - t_begin); dd[3] = (unsigned long long)tag | ((unsigned long long)rb << 8) | ((unsigned long long)P[0] << 16); }
+                    }
+                }
+#endif
                 if (filled && !seen) { seen = true; first_seen = now; }
                 if (filled && ((filled | taken) == FULL || (int)(now - first_seen) >= wait_ticks)) { take = filled; n = __popc(filled); break; }
                 if (!filled && (++spins & 7u) == 0u) {
                     if (uni_u32(aload(&ctl->retired)) >= (uint32_t)T || uni_u32(aload(&ctl->abort))) { n = -1; break; }
                     if (idle_acc > (uint32_t)timeout) {                              // (no leaf for that long)
-                        if (lane == 0) { astore(&ctl->abort, 2u); atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT); }
+                        if (lane == 0) {
+                            astore(&ctl->abort, 2u);
+                            if (!A->total_calls || atomicAdd(A->prof + 19, 1ull) >= 7ull) atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT);
+                        }
                         n = -1;
                         break;
                     }
@@ -700,6 +747,17 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
         uint32_t next_base = 0u;
         const bool need_range = wave == 0 && !sidx[36];
         if (need_range && lane == 0) next_base = atomicAdd(&((AsyncArgsC)(uintptr_t)args)->ctl->leaf_head, (uint32_t)BS);
+#ifdef AZG_ASYNC_POSTMORTEM   /* debug: is the range this workgroup was just given plausible?  (head can be at most ~T + ranges behind / ahead of the tail) */
+        if (need_range && lane == 0) {
+            const AsyncArgsC A_ = (AsyncArgsC)(uintptr_t)args;
+            const uint32_t tl = __hip_atomic_fetch_add(&A_->ctl->leaf_tail, (uint32_t)(clock64() >> 62), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int32_t)(tl - next_base) > 16384 || (int32_t)(next_base - tl) > 16384) {
+                unsigned long long* dd = A_->wginfo + (size_t)4 * 1024 + 280 + 512 + 40 * (size_t)(blockIdx.x < 104 ? blockIdx.x : 103);
+                if (dd[4] == 0ull) { dd[4] = (unsigned long long)next_base | ((unsigned long long)tl << 32); dd[5] = (unsigned long long)(uint32_t)sidx[34] | ((unsigned long long)(wall32() - t_begin) << 32);
+                                     dd[6] = (unsigned long long)__hip_atomic_fetch_add(&A_->ctl->leaf_head, (uint32_t)(clock64() >> 62), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | ((unsigned long long)P[0] << 32); }
+            }
+        }
+#endif
         drain_vmem();                                   // EVERY wave: its write-through pi / v rows have left
         __syncthreads();
         {
@@ -708,6 +766,7 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
             if (tid < 16 && sidx[tid] >= 0) {
                 const int t = sidx[tid], ns = A->n_sel;
                 const int gi = t % ns, ii = t / ns;
+                astore(A->evald + t, 1u);                                       // (read by the NEXT launch only: see "Recovery")
                 astore(A->ts_ready + (size_t)gi * ASYNC_RS + ii, wall32());     // (profile only: not ordered against the ready word)
                 astore(A->ready + (size_t)gi * ASYNC_RS + ii, (uint32_t)sidx[16 + tid] + 1u);
             }
@@ -725,6 +784,10 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
         atomicAdd(prof + 7, P[4]); atomicAdd(prof + 11, (unsigned long long)(wall32() - t_begin)); atomicAdd(prof + 14, P[5]);
         unsigned long long* wi = A->wginfo + (size_t)(A->n_sel + (int)blockIdx.x) * 4;
         wi[0] = where_am_i(); wi[1] = 2ull | ((unsigned long long)(wall32() - t_begin) << 8); wi[2] += P[0]; wi[3] += P[5];
+        // (post-mortems: the ticket range this workgroup held when it left -- first ticket | tickets taken << 32, valid | last batch size << 32)
+        unsigned long long* dn = A->wginfo + (size_t)4 * 1024 + 280 + 2 * (size_t)blockIdx.x;
+        dn[0] = (unsigned long long)(uint32_t)sidx[34] | ((unsigned long long)(uint32_t)sidx[35] << 32);
+        dn[1] = (unsigned long long)(uint32_t)sidx[36] | ((unsigned long long)(uint32_t)sidx[32] << 32);
     }
 }
 
@@ -773,7 +836,7 @@ int azg_async_launch_select(int net_kind, const azg::AsyncArgs* devbuf, int n_se
 // ---- host side ----
 struct AsyncSlot {
     AsyncArgs host; AsyncArgs* devbuf;
-    int8_t* aleaf; AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts; unsigned long long* prof; unsigned long long* wginfo;
+    int8_t* aleaf; AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts; uint32_t* evald; unsigned long long* prof; unsigned long long* wginfo;
     hipEvent_t fork, join, join_net;
     int n_sel, n_net, ring_bits;
     int device, n_cu, leaf_stride, T;          // what the buffers were sized for (checked on every reuse)
@@ -781,7 +844,7 @@ struct AsyncSlot {
 static void async_slot_free(void* p) {
     AsyncSlot* s = (AsyncSlot*)p;
     (void)hipFree(s->devbuf); (void)hipFree(s->aleaf); (void)hipFree(s->ctl); (void)hipFree(s->ring); (void)hipFree(s->ready);
-    (void)hipFree(s->ts); (void)hipFree(s->prof); (void)hipFree(s->wginfo);
+    (void)hipFree(s->ts); (void)hipFree(s->evald); (void)hipFree(s->prof); (void)hipFree(s->wginfo);
     if (s->fork) (void)hipEventDestroy(s->fork);
     if (s->join) (void)hipEventDestroy(s->join);
     if (s->join_net) (void)hipEventDestroy(s->join_net);
@@ -836,6 +899,20 @@ extern "C" int azg_forest_async_wginfo(azg_forest* f, unsigned long long* out /*
     HIPCHK(hipMemcpy(out, sl->wginfo, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost));
     if (reset) HIPCHK(hipMemset(sl->wginfo, 0, sizeof(unsigned long long) * 4 * n));
     return n;
+}
+
+// include/azg_testaids.h: post-mortem of a pipeline time-out: the debug area behind the workgroup table, the ready words and the leaf ring as they
+// are in MEMORY after the launch
+extern "C" int azg_forest_async_debug(azg_forest* f, unsigned long long* out /* host [792 + 104 * 40] */, uint32_t* ready_out /* host [128 * max_wg] or null */, int max_wg,
+                                      unsigned long long* ring_out /* host [ring slots] or null */, int max_ring) {
+    if (!f || !out) return fail("azg_forest_async_debug: null argument");
+    AsyncSlot* sl = (AsyncSlot*)azg_forest_attached(f, "async_v80");
+    if (!sl) return 0;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, sl->wginfo + (size_t)4 * 1024, sizeof(unsigned long long) * (280 + 512 + 104 * 40), hipMemcpyDeviceToHost));
+    if (ready_out) HIPCHK(hipMemcpy(ready_out, sl->ready, sizeof(uint32_t) * ASYNC_RS * (size_t)(max_wg < sl->n_cu ? max_wg : sl->n_cu), hipMemcpyDeviceToHost));
+    if (ring_out) HIPCHK(hipMemcpy(ring_out, sl->ring, sizeof(unsigned long long) * (size_t)(max_ring < (1 << sl->ring_bits) ? max_ring : (1 << sl->ring_bits)), hipMemcpyDeviceToHost));
+    return sl->ring_bits;
 }
 
 // One launch of the pipeline.  kind = which game's descent kernel (and, hash == 0, which net): 0 Splendor 2 players + V80 (w = 43 pointers,
@@ -925,10 +1002,12 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
             hipMalloc(&n->devbuf, sizeof(AsyncArgs)) == hipSuccess && hipMalloc(&n->aleaf, (size_t)T * leaf_stride) == hipSuccess &&
             hipMalloc(&n->ctl, sizeof(AsyncCtl)) == hipSuccess && hipMalloc(&n->ring, sizeof(unsigned long long) << rb) == hipSuccess &&
             hipMalloc(&n->ready, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess &&           // (sized for any split: it may change from launch to launch)
-            hipMalloc(&n->ts, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess && hipMalloc(&n->prof, sizeof(unsigned long long) * ASYNC_NPROF) == hipSuccess &&
-            hipMalloc(&n->wginfo, sizeof(unsigned long long) * 4 * n_cu) == hipSuccess &&
+            hipMalloc(&n->ts, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess && hipMalloc(&n->evald, sizeof(uint32_t) * (size_t)T) == hipSuccess &&
+            hipMemset(n->evald, 1, sizeof(uint32_t) * (size_t)T) == hipSuccess &&       // (non-zero: whatever a tree is waiting for when the pipeline first sees it has been evaluated)
+            hipMalloc(&n->prof, sizeof(unsigned long long) * ASYNC_NPROF) == hipSuccess &&
+            hipMalloc(&n->wginfo, sizeof(unsigned long long) * (4 * 1024 + 280 + 512 + 104 * 40)) == hipSuccess &&
             hipMemset(n->prof, 0, sizeof(unsigned long long) * ASYNC_NPROF) == hipSuccess &&
-            hipMemset(n->wginfo, 0, sizeof(unsigned long long) * 4 * n_cu) == hipSuccess && hipMemset(n->aleaf, 0, (size_t)T * leaf_stride) == hipSuccess &&
+            hipMemset(n->wginfo, 0, sizeof(unsigned long long) * (4 * 1024 + 280 + 512 + 104 * 40)) == hipSuccess && hipMemset(n->aleaf, 0, (size_t)T * leaf_stride) == hipSuccess &&
             hipMemset(n->ts, 0, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess &&
             hipEventCreateWithFlags(&n->fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&n->join, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&n->join_net, hipEventDisableTiming) == hipSuccess;
@@ -966,7 +1045,7 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
         want.c5_descale = descale[0];
     }
     want.aleaf = sl->aleaf; want.leaf_valid = leaf_valid; want.needs_eval = needs_eval; want.pi = pi; want.v = v;
-    want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_ready = sl->ts; want.prof = sl->prof; want.wginfo = sl->wginfo;
+    want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_ready = sl->ts; want.evald = sl->evald; want.prof = sl->prof; want.wginfo = sl->wginfo;
     want.noise = (alpha != 0.0 && noise_stride == -2) ? 1 : 0;
     want.rounds = rounds; want.n_sel = n_sel; want.ring_bits = sl->ring_bits;
     if (shared_budget) {                              // `rounds` x T calls for the trees together; no tree is held back by a share of its own
@@ -974,7 +1053,15 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
         want.rounds = (1 << 24) - 2;
     }
     want.batch_wait = batch_wait_ticks >= 0 ? batch_wait_ticks : 150;
-    { const char* e = getenv("AZG_ASYNC_TIMEOUT_MS"); int ms = e ? atoi(e) : 20000; ms = ms < 1 ? 1 : (ms > 20000 ? 20000 : ms); want.timeout_ticks = ms * 100000; }   // (32-bit ticks of 10 ns: <= 20 s)
+    // (work-sharing budget: a launch that stalls ends early and the next one carries on -- 50 ms; per-tree budgets: the time-out is an error -- 20 s)
+    { const char* e = getenv("AZG_ASYNC_TIMEOUT_MS"); int ms = e ? atoi(e) : (shared_budget ? 50 : 20000); ms = ms < 1 ? 1 : (ms > 20000 ? 20000 : ms); want.timeout_ticks = ms * 100000; }   // (32-bit ticks of 10 ns: <= 20 s)
+    // test hook (tests/test_gpu_selfplay.py): AZG_ASYNC_TEST_STALL=k cuts the k-th launch of the process short -- its time-out is 20 us, so the first
+    // wave that idles ends it -- to exercise the recovery path without waiting for the platform to freeze a workgroup
+    {
+        static int n_launch = 0;
+        const char* e = getenv("AZG_ASYNC_TEST_STALL");
+        if (e && shared_budget) { if (++n_launch == atoi(e)) want.timeout_ticks = 2000; } else n_launch = 0;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (memcmp(&sl->host, &want, sizeof(want)) != 0) {
         sl->host = want;

@@ -33,6 +33,13 @@ int azg_forest_async_rounds_hashnet(azg_forest* f, uint8_t* leaf_valid_dev, uint
    << 8 | se_id << 16 | sh_id << 24), role (1 descent, 2 net), calls (descents / forwards) and the shader cycles spent in them since
    the last reset.  Returns the number of rows written (<= max_wg). */
 int azg_forest_async_wginfo(azg_forest* f, unsigned long long* out_host, int max_wg, int reset);
+/* post-mortem of a pipeline time-out (error bit 128).  out280: what the descent wave that gave up saw of its workgroup (libraries built with
+   -DAZG_ASYNC_POSTMORTEM only, zeros otherwise): [0] claimed mask (trees 0..63), [1] seen mask, [2] stop | scout << 32, [3] workgroup | wave << 16 |
+   trees << 24 | retired << 32, [4 + k] snapshot ready word | last consumed word << 32 of its tree k (k < 128), [132 + k] ready word as the kernel
+   read it | (status | err << 8) << 32; [280 + 2 b], [281 + 2 b]: the ticket range net workgroup b held when it left (first ticket | taken mask << 32,
+   valid | last batch size << 32).  ready_out (or null): the ready words [workgroup][128] as they are in memory after the launch; ring_out (or
+   null): the leaf ring.  Returns the ring's log2 size (0: the forest never ran the pipeline). */
+int azg_forest_async_debug(azg_forest* f, unsigned long long* out792_host, uint32_t* ready_out_host, int max_wg, unsigned long long* ring_out_host, int max_ring);
 
 #ifdef __cplusplus
 }

@@ -838,3 +838,44 @@ def test_selfplay_engine_default_mode_and_deterministic_switch():
         st = e.stats()
         assert st['errors'] == 0 and st['plies'] > 0 and e.forest.validate() == 0
         e.close()
+
+
+def test_async_pipeline_recovers_from_a_launch_that_ends_early(monkeypatch):
+    """A launch of the pipeline that stalls (on this hardware: the platform freezes a few workgroups about once per 45 s of pipeline time,
+    csrc/azg_async.hip.h "Recovery") ends early instead of hanging: a wave that idles past the time-out raises the abort flag, everyone leaves,
+    and the NEXT launch re-queues the leaves that were never evaluated.  AZG_ASYNC_TEST_STALL cuts the 3rd launch short (time-out 20 us):
+    the games played are still exactly the per-tree-budget run's, no error flag, and the early end is counted."""
+    from azg_amd import games
+    from azg_amd.selfplay import SelfPlayEngine
+    from hashnet import HashNetPipeline
+    g = games.SplendorGame(2)
+    T, sims = 48, 24
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0], tempThreshold=6,
+                **{**MCTS_ARGS['splendor2'], 'forced_playouts': False})
+    res, early = [], 0
+    for shared in (True, False):
+        if shared:
+            monkeypatch.setenv('AZG_ASYNC_TEST_STALL', '3')
+        else:
+            monkeypatch.delenv('AZG_ASYNC_TEST_STALL', raising=False)
+        e = SelfPlayEngine(g, HashNetPipeline(2), args, T, node_capacity=2048, max_examples=T * 800, rng_seed=77, stream0=900,
+                           async_pipe=True, async_cfg=dict(shared_budget=shared))
+        e.start(episode_quota=2 * T)
+        for k in range(4000):
+            e.run(97)
+            st = e.stats()
+            assert st['errors'] == 0, st
+            if st['active'] == 0:
+                break
+        assert st['games'] == 2 * T and e.forest.validate() == 0
+        if shared:
+            to = e.forest.async_profile(reset=False)['timeouts']
+            early = to['select'] + to['net']
+        ex = [x.cpu().numpy() for x in e.drain_examples()]
+        meta = ex[5]
+        order = np.lexsort((meta[:, 2], meta[:, 1], meta[:, 0]))
+        res.append([x[order] for x in ex])
+        e.close()
+    assert early >= 1                                     # the third launch did end early ...
+    for a, b in zip(res[0], res[1]):                      # ... and nothing was lost or played differently
+        assert a.shape == b.shape and np.array_equal(a, b)
