@@ -40,8 +40,8 @@
 // (error bit 128).  With the work-sharing budget (the engine's default) such a launch now ENDS EARLY AND SAFELY instead: a wave that finds
 // nothing to do for `timeout_ticks` (50 ms) raises the abort flag, everyone leaves, and nothing is lost -- every tree records whether the leaf
 // it queued last has been evaluated (`evald`: cleared by the descent wave in front of the ticket, set by the net workgroup with the hand-back),
-// and the next launch re-queues a tree that is still owed its evaluation (the leaf record is still in the pipeline's leaf array) instead of
-// expanding it with a policy that never arrived.  Eight launches in a row that end this way set the error bit after all (a pipeline that
+// and the next launch begins with a small kernel (k_async_requeue) that puts the leaf of every tree still owed its evaluation back on the ring (the
+// leaf record is still in the pipeline's leaf array) and starts that tree as "in the net" instead of expanding it with a policy that never arrived.  Eight launches in a row that end this way set the error bit after all (a pipeline that
 // really cannot run -- a workgroup that never becomes resident -- still fails loudly).  With per-tree budgets (shared_budget == 0: "exactly
 // `rounds` calls per tree") an early end would change what a launch means, so there the time-out stays an error.
 #pragma once
@@ -86,7 +86,7 @@ struct AsyncCtl {                              // zeroed by the host before ever
 //  9 launches           10 select workgroup-ticks resident   11 net workgroup-ticks resident
 // 12 n_sel  13 n_net (filled by the host)   14 shader-clock cycles inside the forwards   15 inside the descents   16 plies advanced in-kernel
 // 17 / 18 launches that ended early because a descent wave / a net workgroup gave up (time-out); 19 such launches in a row;
-// 26 ticket ranges a net workgroup abandoned because the ring had lapped it
+// 26 ticket ranges a net workgroup abandoned because the ring had lapped it; 27 leaves re-queued at the start of a launch (owed by one that ended early)
 // 32..63 histogram of the leaf wait in us (last bucket: >= 31)    64..95 histogram of the ready wait
 struct AsyncArgs {
     ForestDev F;
@@ -97,6 +97,7 @@ struct AsyncArgs {
     AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts_ready;
     unsigned long long* prof;
     uint32_t* evald;                           // [T]: 1 = the leaf the tree queued last has been evaluated (its pi / v are in place); 0 = still owed (see "Recovery")
+    uint8_t* pending;                          // [T]: 1 = k_async_requeue put the tree's owed leaf back on the ring: it starts this launch waiting for the net
     unsigned long long* wginfo;                // [n_sel + n_net][4]: where the workgroup ran (XCC | cu << 8 | se << 16 | sh << 24), role, calls, busy shader cycles
     int noise, rounds, n_sel, ring_bits, batch_wait, timeout_ticks;
     unsigned long long total_calls;            // != 0: the launch ends when the trees TOGETHER have had this many calls (whichever tree is fast
@@ -235,18 +236,23 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         my_ready = A->ready + (size_t)g * ASYNC_RS;
         // every tree of this workgroup starts the launch ready, with `rounds` calls to go (ready word = calls left + 1)
         const int i = (int)threadIdx.x;
+        // (a tree whose owed leaf k_async_requeue has put back on the ring starts the launch waiting for the net: see "Recovery")
+        unsigned long long start0 = 0ull, start1 = 0ull;
         if (i < ASYNC_RS) {
-            const uint32_t w0 = i < n_g ? (uint32_t)rounds + 1u : 0u;
+            const bool here = i < n_g && !A->pending[g + i * n_sel];
+            const uint32_t w0 = here ? (uint32_t)rounds + 1u : 0u;
             astore(my_ready + i, w0);
             C->rw[i] = w0; C->last[i] = 0xFFFFFFFFu;
+            const unsigned long long bal = __ballot(here);
+            if (i < 64) start0 = bal; else start1 = bal;
         }
         if (i < ASYNC_RS) { astore(A->ts_ready + (size_t)g * ASYNC_RS + i, t_begin); C->rts[i] = t_begin; }
         if (i == 0) {
             C->claimed[0] = C->claimed[1] = 0ull; C->retired = 0u; C->cursor = 0u; C->scout = 0u; C->calls = 0u; C->stop = 0u;
             for (int k = 0; k < 6; k++) C->prof[k] = 0ull;
-            C->seen[0] = n_g >= 64 ? ~0ull : (1ull << n_g) - 1ull;             // every tree starts ready
-            C->seen[1] = n_g >= 128 ? ~0ull : n_g > 64 ? (1ull << (n_g - 64)) - 1ull : 0ull;
+            C->seen[0] = start0;                                               // every tree starts ready (but those waiting for the net)
         }
+        if (i == 64) C->seen[1] = start1;
         if (i < 32) C->hist[i] = 0u;
         drain_vmem();
     }
@@ -391,15 +397,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         bool need = false;
         uint32_t left = word - 1u;                                          // calls of this tree still to run in this launch
         if (AZG_LDS_LD32(&C->stop)) left = 0u;                              // the launch's shared budget is spent: the tree retires as it is
-        // Recovery: the first time the tree is handled in this launch -- was the leaf it queued in an EARLIER launch ever evaluated?  (Only a launch
-        // that ended early leaves such trees behind.)  If not, its leaf record goes back on the ring as it is; no call is spent.
-        if (uni_u32(AZG_LDS_LD32(&C->last[i])) == 0xFFFFFFFFu) {
-            const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
-            // (the hand-back word must be SMALLER than the word consumed here -- that is how the workgroup tells a fresh hand-back from a stale
-            // one -- so the re-queue costs the tree one call of the launch's budget)
-            if (uni_u32(aload(A->evald + t)) == 0u && uni_u32(aload(&A->F.hdr[t].status)) == ST_WAIT_NN) { need = true; left = word >= 2u ? word - 2u : 0u; }
-        }
-        while (left > 0u && !need) {
+        while (left > 0u) {
             int r;
             {
                 const AsyncArgs* a = args;
@@ -836,7 +834,7 @@ int azg_async_launch_select(int net_kind, const azg::AsyncArgs* devbuf, int n_se
 // ---- host side ----
 struct AsyncSlot {
     AsyncArgs host; AsyncArgs* devbuf;
-    int8_t* aleaf; AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts; uint32_t* evald; unsigned long long* prof; unsigned long long* wginfo;
+    int8_t* aleaf; AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts; uint32_t* evald; uint8_t* pending; unsigned long long* prof; unsigned long long* wginfo;
     hipEvent_t fork, join, join_net;
     int n_sel, n_net, ring_bits;
     int device, n_cu, leaf_stride, T;          // what the buffers were sized for (checked on every reuse)
@@ -844,7 +842,7 @@ struct AsyncSlot {
 static void async_slot_free(void* p) {
     AsyncSlot* s = (AsyncSlot*)p;
     (void)hipFree(s->devbuf); (void)hipFree(s->aleaf); (void)hipFree(s->ctl); (void)hipFree(s->ring); (void)hipFree(s->ready);
-    (void)hipFree(s->ts); (void)hipFree(s->evald); (void)hipFree(s->prof); (void)hipFree(s->wginfo);
+    (void)hipFree(s->ts); (void)hipFree(s->evald); (void)hipFree(s->pending); (void)hipFree(s->prof); (void)hipFree(s->wginfo);
     if (s->fork) (void)hipEventDestroy(s->fork);
     if (s->join) (void)hipEventDestroy(s->join);
     if (s->join_net) (void)hipEventDestroy(s->join_net);
@@ -918,6 +916,25 @@ extern "C" int azg_forest_async_debug(azg_forest* f, unsigned long long* out /* 
 // One launch of the pipeline.  kind = which game's descent kernel (and, hash == 0, which net): 0 Splendor 2 players + V80 (w = 43 pointers,
 // descale = 16 host floats); 1 Santorini no-gods + V89 (w = 14 pointers, descale = 1 host float); 2 / 3 Splendor 3 / 4 players, 4 Azul
 // (MobileNet-1d: 43 pointers + 16 factors); 5 Santorini with gods (hash-net only so far).  hash != 0: the integer hash-net as the evaluator.
+// Recovery, first half: in front of the two persistent kernels, every tree that is still owed the evaluation of the leaf it queued in an
+// earlier launch (status ST_WAIT_NN, `evald` clear: that launch ended early) gets its leaf record -- still in the pipeline's leaf array --
+// back on the ring and is flagged `pending`: its descent workgroup starts it as "in the net".  Costs one tiny launch; in the common case
+// (the previous launch ended normally) it finds nothing.
+__global__ __launch_bounds__(256) void k_async_requeue(const AsyncArgs* args) {
+    const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= A->F.T) return;
+    const bool owed = aload(A->evald + t) == 0u && aload(&A->F.hdr[t].status) == ST_WAIT_NN && !aload(&A->F.hdr[t].err);
+    A->pending[t] = owed ? (uint8_t)1 : (uint8_t)0;
+    if (owed) {
+        const uint32_t rb = (uint32_t)A->ring_bits, tk = atomicAdd(&A->ctl->leaf_tail, 1u);
+        // (calls left = the launch's `rounds`: the hand-back word rounds + 1 is below the 0xFFFFFFFF the workgroup starts its bookkeeping from)
+        A->ring[tk & ((1u << rb) - 1u)] = (unsigned long long)((uint32_t)t | (((wall32() >> 4) & 0xFFFu) << 20)) | ((unsigned long long)(uint32_t)A->rounds << 32) |
+                                           ((unsigned long long)(((tk >> rb) & 7u) + 1u) << 60);
+        atomicAdd(A->prof + 27, 1ull);
+    }
+}
+
 template <class NET>
 static int async_launch_net(const AsyncArgs* devbuf, int n_net, hipStream_t s) {
     k_async_net<NET><<<dim3(n_net), dim3(768), NET::LDS + ASYNC_DESC_BYTES, s>>>(devbuf);
@@ -1003,7 +1020,7 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
             hipMalloc(&n->ctl, sizeof(AsyncCtl)) == hipSuccess && hipMalloc(&n->ring, sizeof(unsigned long long) << rb) == hipSuccess &&
             hipMalloc(&n->ready, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess &&           // (sized for any split: it may change from launch to launch)
             hipMalloc(&n->ts, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess && hipMalloc(&n->evald, sizeof(uint32_t) * (size_t)T) == hipSuccess &&
-            hipMemset(n->evald, 1, sizeof(uint32_t) * (size_t)T) == hipSuccess &&       // (non-zero: whatever a tree is waiting for when the pipeline first sees it has been evaluated)
+            hipMemset(n->evald, 1, sizeof(uint32_t) * (size_t)T) == hipSuccess && hipMalloc(&n->pending, (size_t)T) == hipSuccess && hipMemset(n->pending, 0, (size_t)T) == hipSuccess &&       // (non-zero: whatever a tree is waiting for when the pipeline first sees it has been evaluated)
             hipMalloc(&n->prof, sizeof(unsigned long long) * ASYNC_NPROF) == hipSuccess &&
             hipMalloc(&n->wginfo, sizeof(unsigned long long) * (4 * 1024 + 280 + 512 + 104 * 40)) == hipSuccess &&
             hipMemset(n->prof, 0, sizeof(unsigned long long) * ASYNC_NPROF) == hipSuccess &&
@@ -1045,7 +1062,7 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
         want.c5_descale = descale[0];
     }
     want.aleaf = sl->aleaf; want.leaf_valid = leaf_valid; want.needs_eval = needs_eval; want.pi = pi; want.v = v;
-    want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_ready = sl->ts; want.evald = sl->evald; want.prof = sl->prof; want.wginfo = sl->wginfo;
+    want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_ready = sl->ts; want.evald = sl->evald; want.pending = sl->pending; want.prof = sl->prof; want.wginfo = sl->wginfo;
     want.noise = (alpha != 0.0 && noise_stride == -2) ? 1 : 0;
     want.rounds = rounds; want.n_sel = n_sel; want.ring_bits = sl->ring_bits;
     if (shared_budget) {                              // `rounds` x T calls for the trees together; no tree is held back by a share of its own
@@ -1069,6 +1086,8 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
     }
     HIPCHK(hipMemsetAsync(sl->ctl, 0, sizeof(AsyncCtl), s));
     HIPCHK(hipMemsetAsync(sl->ring, 0, sizeof(unsigned long long) << sl->ring_bits, s));
+    k_async_requeue<<<dim3((T + 255) / 256), dim3(256), 0, s>>>(sl->devbuf);       // (see "Recovery"; in stream order behind the resets above)
+    HIPCHK(hipGetLastError());
     // fork from the caller's stream into the two private streams, join both before returning
     HIPCHK(hipEventRecord(sl->fork, s));
     HIPCHK(hipStreamWaitEvent(D.net_stream, sl->fork, 0));

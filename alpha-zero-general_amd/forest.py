@@ -164,7 +164,7 @@ class Forest:
         d['select_wave_busy'] = o[1] / max(o[1] + o[2], 1)          # share of a descent wave's life inside select_tree
         d['net_wg_busy'] = o[5] / max(o[11], 1)                     # share of a net workgroup's life inside the forward
         d['n_sel'], d['n_net'] = int(o[12]), int(o[13])
-        d['timeouts'] = dict(select=int(o[17]), net=int(o[18]), ranges_abandoned=int(o[26]))        # launches that ended early in a time-out (sticky until the counters are reset)
+        d['timeouts'] = dict(select=int(o[17]), net=int(o[18]), ranges_abandoned=int(o[26]), leaves_requeued=int(o[27]))        # launches that ended early in a time-out (sticky until the counters are reset)
         d['ctl'] = dict(leaf_tail=int(o[20]), leaf_head=int(o[21]), retired=int(o[22]), abort=int(o[23]), calls=int(o[24]), stop=int(o[25]))
         d['forward_cycles'] = o[14] / max(o[3], 1)                   # shader-clock cycles of a forward / a descent, and the clock they imply
         d['descent_cycles'] = o[15] / max(o[0], 1)
