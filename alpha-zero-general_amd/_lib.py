@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# AZG_LIB: A/B-test another build of the same library (tools/ab_bench.sh); never a different implementation
+# AZG_LIB: A/B-test another build of the same library (tools/archive/ab_bench.sh); never a different implementation
 LIB_PATH = os.environ.get('AZG_LIB') or os.path.join(HERE, 'libazg_hip.so')
 
 SPLENDOR, SANTORINI, AZUL, MINIVILLES, ABALONE, TLP, BOTANIK, AKROPOLIS, SMALLWORLD = 0, 1, 2, 3, 4, 5, 6, 7, 8

@@ -920,7 +920,7 @@ __device__ __forceinline__ int select_tree(const ForestDev& F, const int t, type
         stat_add(&Hp->c_term, c_term);
 #ifdef AZG_CYC_COUNTERS
 #ifndef AZG_WALL_CAL
-        Hp->pad0_ += edges_this_launch;      // debug: frontier-edge resolutions of this tree (tools/dbg_tail.py)
+        Hp->pad0_ += edges_this_launch;      // debug: frontier-edge resolutions of this tree (tools/archive/dbg_tail.py)
 #endif
 #ifdef AZG_WALL_CAL
         Hp->pad0_ = w_first; Hp->pad1_ = (uint32_t)wall_clock64(); (void)w_start;   // absolute 100 MHz stamps: wave start / end

@@ -9,7 +9,7 @@ numMCTSSims of its time -- in exchange for one launch less per round; per-tree r
 `work_budget` caps the work of a tree in one select launch (a launch lasts as long as its slowest tree): near the end of a
 game most simulations end on terminal nodes and would otherwise all run inside one launch (measured: 0.65 ms rounds).
 Whole-game sweep at 4096 x 800 sims (env-steps/s), round 1: budget 0 -> 21.3 k, 96 -> 30.9 k, 48 -> 33.8 k, 32 -> 35.1 k, 20 -> 37.2 k;
-advance every 4 / 8 / 16 / 32 rounds -> 32.5 / 33.8 / 34.4 / 34.7 k.  Round 3 (tools/sweep_budget_games.sh): Splendor 10 / 48 -> 68.1 k
+advance every 4 / 8 / 16 / 32 rounds -> 32.5 / 33.8 / 34.4 / 34.7 k.  Round 3 (tools/archive/sweep_budget_games.sh): Splendor 10 / 48 -> 68.1 k
 against 63.0 k for 20 / 16; Azul and Santorini keep 20 / 16 -- the defaults below are per game family.
 
 GROUPS (round 4, measured, NOT the default).  Both kernels of a round are latency chains -- a select launch lasts as long as the
@@ -18,9 +18,9 @@ neither can share a CU with the other (a net workgroup takes 504 of a SIMD's 512
 > 1 splits the games into independent forests, each with its own stream, leaf / pi / v buffers and captured graph of K fused rounds;
 nothing synchronises the groups.  The streams ask for a CU mask of one XCD each (azg_stream_create_xcd) -- but on this MI355X (one
 partition over 8 XCDs) the hardware deals a queue's workgroups round-robin over ALL XCDs and the mask is not honoured
-(tools/dbg_placement.py: every masked stream ran on the 256 CUs of all 8 XCDs), so the groups share every CU: a net workgroup then
+(tools/archive/dbg_placement.py: every masked stream ran on the 256 CUs of all 8 XCDs), so the groups share every CU: a net workgroup then
 waits for a whole CU to drain while the other groups' descents keep landing on it.  Driver flags, one MI355X: 1 group 72.6 k
-env-steps/s, 2 groups 72.3 k, 4 groups 40.5 k, 8 groups 27.4 k (profiles/r04_round_structure.md).  Per-tree results do not depend on
+env-steps/s, 2 groups 72.3 k, 4 groups 40.5 k, 8 groups 27.4 k (profiles/archive/r04_round_structure.md).  Per-tree results do not depend on
 the grouping (global game streams stream0 + index; tested)."""
 import ctypes as C
 
@@ -100,7 +100,7 @@ class SelfPlayEngine:
         assert n_games % groups == 0
         self.T, self.G = n_games, groups
         self.fused = bool(fused)
-        # defaults per game family, from whole-game sweeps at 4096 games x 800 sims (tools/sweep_budget_games.sh; the timings repeat to
+        # defaults per game family, from whole-game sweeps at 4096 games x 800 sims (tools/archive/sweep_budget_games.sh; the timings repeat to
         # 0.1 % since k_select stopped reading the dispatch packet): Splendor 2p / 4p prefer short launches and a rarer advance (work
         # budget 10, every 48 rounds: +8 % / +3 % over 20 / 16), Azul and Santorini the opposite (20 / 16: 42.5 k vs 35.5 k, 21.6 k vs 20.9 k)
         from . import _lib
@@ -195,7 +195,7 @@ class SelfPlayEngine:
             self.split_log = []
             self.use_graph = False          # two launches per K rounds: nothing to amortise
         # one stream per pipeline; pinned to an XCD (or an equal share of the 8 XCDs) unless pin_xcd=False
-        # (default off: on this MI355X a stream's CU mask is not honoured, profiles/r04_placement.txt, and azg_stream_create_xcd refuses
+        # (default off: on this MI355X a stream's CU mask is not honoured, profiles/archive/r04_placement.txt, and azg_stream_create_xcd refuses
         # devices whose CU count is not a multiple of 8)
         self.pin_xcd = False if pin_xcd is None else bool(pin_xcd)
         self._raw_streams = []

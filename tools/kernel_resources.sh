@@ -1,13 +1,16 @@
 #!/bin/bash
-# Register / LDS / scratch use of the kernels in a compiled unit (object file or libazg_hip.so), from the code object's metadata notes.
-#   tools/kernel_resources.sh <file.o|.so> [grep -E pattern on the mangled name]
+# Register / LDS / scratch use of the kernels in a compiled unit (object file or libazg_hip.so: every code object bundled into it), from the
+# code objects' metadata notes (the same reader as tests/test_kernel_resources.py).
+#   tools/kernel_resources.sh <file.o|.so> [grep -E pattern on the demangled name]
 set -e
-T=$(mktemp -d)
-/opt/rocm/lib/llvm/bin/llvm-objcopy --dump-section .hip_fatbin=$T/fat.bin "$1" /dev/null
-/opt/rocm/lib/llvm/bin/clang-offload-bundler --type=o --input=$T/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$T/dev.co --unbundle
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes $T/dev.co | awk '
-  /\.group_segment_fixed_size:/{lds=$2} /\.name:/{name=$2} /\.private_segment_fixed_size:/{scr=$2}
-  /\.sgpr_count:/{sg=$2} /\.sgpr_spill_count:/{ss=$2} /\.vgpr_count:/{vg=$2}
-  /\.vgpr_spill_count:/{vs=$2; printf "vgpr %-4s sgpr %-4s sgpr_spill %-4s vgpr_spill %-4s scratch %-6s lds %-7s %s\n", vg, sg, ss, vs, scr, lds, name}' \
-  | (if [ -n "$2" ]; then grep -E "$2"; else cat; fi) | c++filt | cut -c1-200
-rm -rf $T
+R=$(cd "$(dirname "$0")/.." && pwd)
+python - "$1" "$2" <<PY
+import sys, re
+sys.path.insert(0, '$R/tests')
+from test_kernel_resources import kernel_notes
+pat = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] else None
+for name, v in sorted(kernel_notes(sys.argv[1]).items()):
+    if pat and not re.search(pat, name):
+        continue
+    print('vgpr %-4d sgpr %-4d sgpr_spill %-4d vgpr_spill %-4d scratch %-6d lds %-7d %s' % (v['vgpr'], v['sgpr'], v['sgpr_spill'], v['vgpr_spill'], v['scratch'], v['lds'], name[:160]))
+PY

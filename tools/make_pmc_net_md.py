@@ -1,4 +1,4 @@
-"""profiles/r03_pmc_net.md from the two raw SQ passes (tools/refresh_profiles_r03.sh): python tools/make_pmc_net_md.py profiles/r03"""
+"""profiles/archive/r03_pmc_net.md from the two raw SQ passes (tools/archive/refresh_profiles_r03.sh): python tools/make_pmc_net_md.py profiles/r03"""
 import re
 import sys
 

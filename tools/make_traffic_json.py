@@ -33,7 +33,7 @@ def main():
     corrected = (2.0 * sum(f.values()) + sum(w.values())) * 1024.0
     out = {'games': games, 'sims': sims, 'source': '%s + %s' % (fetch_db, write_db),
            'note': 'per lock-step round (one k_select launch with the expansion + backup in its prologue); FETCH_SIZE x 2 and WRITE_SIZE x 1: '
-                   'calibrated in round 4 on tools/ubench/calib.hip (profiles/r04_pmc_calib.json) -- FETCH_SIZE counts 64 B per read REQUEST, '
+                   'calibrated in round 4 on tools/ubench/calib.hip (profiles/archive/r04_pmc_calib.json) -- FETCH_SIZE counts 64 B per read REQUEST, '
                    'whatever its size: a wave instruction that touches >= 128 contiguous bytes (a record\'s hot run, a child-slot run, the '
                    'action ids, a state chunk) is counted at half its bytes, a 64-B request exactly, a 32-B record header at twice its '
                    'bytes (64 B are fetched); WRITE_SIZE is exact for full lines and counts 32 B for a 16-B store.  x 2 on all fetches is '

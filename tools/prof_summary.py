@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 rocpd sqlite database (kernel trace, optional PMC counters) into markdown.
-    python tools/prof_summary.py gpurun_out/prof_r1/r1_results.db > profiles/r01_kernel_stats.md"""
+    python tools/prof_summary.py gpurun_out/prof_r1/r1_results.db > profiles/archive/r01_kernel_stats.md"""
 import sqlite3
 import sys
 
