@@ -1,6 +1,6 @@
 """HBM traffic per lock-step round from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as the MI355X guide
 prescribes) -> profiles/<tag>_traffic.json, read by bench.py for roofline.traffic.
-    python tools/make_traffic_json.py fetch.db write.db profiles/r01c_traffic.json [games sims [bench_line.json [kernel]]]
+    python tools/make_traffic_json.py fetch.db write.db profiles/archive/r01c_traffic.json [games sims [bench_line.json [kernel]]]
 bench_line.json = the JSON line the profiled command printed (same run as the FETCH_SIZE pass): its roofline block gives the
 algorithmic bytes of THAT run (d, v, e, sims per launch), so that traffic / algorithmic has one denominator.
 Units: the counters report KiB-ish "KB" per dispatch slice; FETCH_SIZE is doubled (gfx950 correction of
