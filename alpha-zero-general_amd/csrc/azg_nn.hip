@@ -398,6 +398,17 @@ static int s78_launch(const int8_t* boards, const uint8_t* valid, const float* c
         k_s78_net<10, 1782, 2><<<dim3((B + 3) / 4), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
     }
     HIPCHK(hipGetLastError());
+    if (split == 2) {                       // (the policy FC on f16 x 2 operands as well: w[11] then holds its hi / lo fragments + the descale)
+        constexpr size_t lds_h2 = (size_t)(16 * (160 + 4) + 16 * (112 * 16 + 4)) * sizeof(float);
+        static bool attr_h2 = false;
+        if (!attr_h2) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_s78_policy_h2<1782, 132>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h2));
+            attr_h2 = true;
+        }
+        k_s78_policy_h2<1782, 132><<<dim3((B + 15) / 16), dim3(768), lds_h2, (hipStream_t)stream>>>((const uint4*)N.Wfp, N.bfp, valid, B, pi);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     constexpr size_t lds_pi = (size_t)(16 * (144 + 4) + 16 * (112 * 16 + 4)) * sizeof(float);
     static bool attr_pi = false;
     if (!attr_pi) {

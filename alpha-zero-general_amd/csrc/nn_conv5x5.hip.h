@@ -1008,6 +1008,113 @@ __device__ __forceinline__ void s78_heads(const S78NetW& N, const float* X, cons
     }
 }
 
+// The same heads for the 8-sample kernels (round 6): the form above reads every weight from global memory inside its dot products (the
+// 1x1 convolutions two loads per term, fc1 one) and ran 31 k of the trunk kernel's 360 k cycles (tools/dbg_nn_phases_s78.py).  Here the
+// head weights are staged ONCE in LDS (WL: the X planes' region, dead after the f32 rebuild -- the caller has a barrier between), a
+// thread of the 1x1 convolutions owns (row, two output channels: uniform per wave) and reads its weights as broadcast float2, fc1 keeps
+// four partial sums, fc2 splits its K over four lanes; the weights are requested before the rebuild (s78_heads_prefetch).  WL: (64 * 6 + 8 + 82 * 64 + 64 + 64 * P + P) floats.
+struct S78HeadPf { float wf1[7], w6, b6, bf1, wf2, bf2; };      // a thread's share of the head weights, requested ahead (s78_heads_prefetch)
+template <int P>
+__device__ __forceinline__ void s78_heads_prefetch(const S78NetW& N, S78HeadPf& pf) {
+    constexpr int CPI = 4, CV = 2, FV = CV * 25 + 32;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 7; q++) pf.wf1[q] = tid + 768 * q < FV * 64 ? N.Wf1[tid + 768 * q] : 0.f;
+    const int k = tid / 6, c = tid - 6 * k;
+    pf.w6 = tid < 64 * 6 ? (c < CPI ? N.Whp[k * CPI + c] : N.Whv[k * CV + (c - CPI)]) : 0.f;
+    pf.b6 = tid < 6 ? (tid < CPI ? N.bhp[tid] : N.bhv[tid - CPI]) : 0.f;
+    pf.bf1 = tid < 64 ? N.bf1[tid] : 0.f;
+    pf.wf2 = tid < 64 * P ? N.Wf2[tid] : 0.f;
+    pf.bf2 = tid < P ? N.bf2[tid] : 0.f;
+}
+template <int NS, int A, int P>
+__device__ __forceinline__ void s78_heads_lds(const S78HeadPf& pf, const float* X, const float* META, float* SCR, float* WL, int b0, int nb,
+                                              float* __restrict__ pi_out, float* __restrict__ v_out) {
+    constexpr int CS = 68, CPI = 4, CV = 2, FP = CPI * 25 + 32, FV = CV * 25 + 32, ROWS = NS * 25;
+    static_assert(ROWS <= 256 && NS * 64 <= 768 && NS * P * 4 <= 64 && FV * 64 <= 7 * 768, "thread maps");
+    const int tid = threadIdx.x;
+    float* FEAT_P = SCR;                    // [NS][FP]
+    float* FEAT_V = FEAT_P + NS * FP;       // [NS][FV]
+    float* H1 = FEAT_V + NS * FV;           // [NS][64]
+    float* W6 = WL;                         // [64][6]: policy channels 0..3, value channels 0..1
+    float* B6 = W6 + 64 * 6;                // [6] (+ 2)
+    float* WF1 = B6 + 8;                    // [FV][64]
+    float* BF1 = WF1 + FV * 64;             // [64]
+    float* WF2 = BF1 + 64;                  // [64][P]
+    float* BF2 = WF2 + 64 * P;              // [P]
+#pragma unroll
+    for (int q = 0; q < 7; q++)
+        if (tid + 768 * q < FV * 64) WF1[tid + 768 * q] = pf.wf1[q];
+    if (tid < 64 * 6) W6[tid] = pf.w6;
+    if (tid < 6) B6[tid] = pf.b6;
+    if (tid < 64) BF1[tid] = pf.bf1;
+    if (tid < 64 * P) WF2[tid] = pf.wf2;
+    if (tid < P) BF2[tid] = pf.bf2;
+    for (int i = tid; i < NS * 32; i += 768) {
+        const int s = i >> 5, j = i & 31;
+        FEAT_P[s * FP + CPI * 25 + j] = META[i];
+        FEAT_V[s * FV + CV * 25 + j] = META[i];
+    }
+    C5_PH(14);
+    __syncthreads();
+    C5_PH(15);
+    {                                       // 1x1 convolutions + ReLU: a wave's output pair is uniform (waves 0-3 / 4-7 / 8-11), a lane = a row
+        const int og = __builtin_amdgcn_readfirstlane(tid >> 8), r = tid & 255;
+        if (r < ROWS) {
+            const float* xr = X + r * CS;
+            const float* wg = W6 + 2 * og;  // (the same address in every lane: broadcast reads, requested in one batch)
+            float a0 = B6[2 * og], a1 = B6[2 * og + 1], c0 = 0.f, c1 = 0.f;
+#pragma unroll 1
+            for (int kc = 0; kc < 64; kc += 16) {       // (16 terms per batch of reads: all 64 weight pairs at once were 128 registers -- spilled)
+                float2 w[16];
+                float4 x[4];
+#pragma unroll
+                for (int k = 0; k < 16; k++) w[k] = *(const float2*)(wg + 6 * (kc + k));
+#pragma unroll
+                for (int k = 0; k < 4; k++) x[k] = *(const float4*)(xr + kc + 4 * k);
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {
+                    a0 += x[k].x * w[4 * k].x; a1 += x[k].x * w[4 * k].y; c0 += x[k + 1].x * w[4 * k + 4].x; c1 += x[k + 1].x * w[4 * k + 4].y;
+                    a0 += x[k].y * w[4 * k + 1].x; a1 += x[k].y * w[4 * k + 1].y; c0 += x[k + 1].y * w[4 * k + 5].x; c1 += x[k + 1].y * w[4 * k + 5].y;
+                    a0 += x[k].z * w[4 * k + 2].x; a1 += x[k].z * w[4 * k + 2].y; c0 += x[k + 1].z * w[4 * k + 6].x; c1 += x[k + 1].z * w[4 * k + 6].y;
+                    a0 += x[k].w * w[4 * k + 3].x; a1 += x[k].w * w[4 * k + 3].y; c0 += x[k + 1].w * w[4 * k + 7].x; c1 += x[k + 1].w * w[4 * k + 7].y;
+                }
+            }
+            a0 = fmaxf(a0 + c0, 0.f); a1 = fmaxf(a1 + c1, 0.f);
+            const int s = r / 25, cell = r - 25 * s;
+            if (og < 2) { FEAT_P[s * FP + (2 * og) * 25 + cell] = a0; FEAT_P[s * FP + (2 * og + 1) * 25 + cell] = a1; }
+            else { FEAT_V[s * FV + cell] = a0; FEAT_V[s * FV + 25 + cell] = a1; }
+        }
+    }
+    C5_PH(16);
+    __syncthreads();
+    C5_PH(17);
+    for (int i = tid; i < nb * FP; i += 768) {                 // the policy features go to the head of the sample's pi row (k_s78_policy)
+        const int s = i / FP, k = i - s * FP;
+        pi_out[(size_t)(b0 + s) * A + k] = FEAT_P[s * FP + k];
+    }
+    if (tid < NS * 64) {
+        const int s = tid >> 6, j = tid & 63;
+        const float* fv = FEAT_V + s * FV;
+        float acc[4] = {BF1[j], 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < FV; k++) acc[k & 3] += fv[k] * WF1[k * 64 + j];
+        H1[s * 64 + j] = fmaxf((acc[0] + acc[1]) + (acc[2] + acc[3]), 0.f);
+    }
+    C5_PH(18);
+    __syncthreads();
+    C5_PH(19);
+    if (tid < NS * P * 4) {                 // fc2 + tanh: (sample, player) x four lanes over K
+        const int q = tid & 3, sp = tid >> 2, s = sp / P, p = sp - s * P;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc += H1[s * 64 + 16 * q + j] * WF2[(16 * q + j) * P + p];
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (q == 0 && s < nb) v_out[(size_t)(b0 + s) * P + p] = tanhf(acc + BF2[p]);
+    }
+}
+
 template <int NB, int A, int P>
 __global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid,
                                                  int B, float* __restrict__ pi_out, float* __restrict__ v_out) {
@@ -1103,10 +1210,10 @@ __global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __rest
 // product).  N.We / N.Wp point to the split fragments [NB][3 thirds][4 ct][2 chunks][3 planes][64 lanes][8] bf16.
 // NPL = 2: f16 x 2 operands (hi + lo, three MFMAs per product, two planes per tile holding 64 * x; N.We / N.Wp then hold
 // [NB][3 thirds][4 ct][2 chunks][2 planes][64 lanes][8] f16 of W * 2^k, ds_e / ds_p = 2^-k / 64 of the two matrix families)
-template <int NB, int A, int P, int NPL = 3>
+template <int NB, int A, int P, int NPL = 3, int NS = 8>
 __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid,
                                                        int B, float* __restrict__ pi_out, float* __restrict__ v_out, float ds_e, float ds_p) {
-    constexpr int NS = 8, ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, CS = 68, E = 192;
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, CS = 68, E = 192;
     // (the f32 staging / head tile [ROWS][CS] + head buffers live in the H region: it keeps the size of three planes)
     constexpr int PLANE_B = (ROWS + 2) * 128, TILE_B = NPL * PLANE_B, HREG_B = 3 * PLANE_B;
     constexpr size_t G64_U4 = (size_t)4 * 2 * NPL * 64;        // uint4 per 64 x 64 matrix
@@ -1119,6 +1226,7 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
     const int ct = wave & 3, rg = wave >> 2;
     const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
+    C5_PH(8);
     for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(STG + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < NPL * 64) ((uint32_t*)(XP + (tid >> 6) * PLANE_B + ROWS * 128))[tid & 63] = 0u;      // X's zero row
     __syncthreads();
@@ -1136,9 +1244,11 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     __shared__ float zero_bias[64];
     if (tid < 64) zero_bias[tid] = 0.f;
     __syncthreads();
+    C5_PH(9);
     if (NPL == 2) conv3x3_first_h2<NS, false>(N.W0, zero_bias, STG, XP);
     else conv3x3_first_split<NS, false, NPL>(N.W0, zero_bias, STG, XP);
     __syncthreads();
+    C5_PH(10);
     if (tid < NPL * 64) ((uint32_t*)(HP + (tid >> 6) * PLANE_B + ROWS * 128))[tid & 63] = 0u;      // H's zero row (the staging tile is dead)
 #pragma unroll 1
     for (int blk = 0; blk < NB; blk++) {
@@ -1148,6 +1258,10 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
 #pragma unroll 1
         for (int t = 0; t < 3; t++) {
             // ---- 1x1 expand (channels 64 t .. 64 t + 63) + BN + ReLU -> H ----
+#define S78_PH(k) do { if (blk == 5 && t == 1) C5_PH(k); } while (0)
+            S78_PH(0);
+            f32x2 dw_w[9], dw_b;
+            uint4 wp[6];
             {
                 f32x4 e[MAXT];
 #pragma unroll
@@ -1155,6 +1269,16 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
                 uint4 we[6];
                 gemm64_wload<NPL>((const uint4*)N.We + (size_t)(blk * 3 + t) * G64_U4, we);
                 gemm64_split<NS, NPL>(we, XP, e);
+                // (measured and dropped, round 6: the GEMMs' weight fragments requested a phase ahead -- the project's under the depthwise
+                // convolution: wave 0's project phase 1.7 k -> 1.0 k cycles, the forward 367 -> 379 us; the expand's under the project
+                // GEMM of the pass before: nothing, that phase is bound by the MFMA pipe, its LDS operand reads and its epilogue)
+                if constexpr (NPL == 2) {                 // the depthwise weights of this thread's channel pair: requested here, used behind the barrier
+                    const int ec = blk * E + t * 64 + 2 * (tid & 31);
+                    const float* wd = N.Wd + (size_t)ec * 9;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) dw_w[k] = f32x2{wd[k], wd[9 + k]};
+                    dw_b = f32x2{N.bd[ec], N.bd[ec + 1]};
+                }
                 const float4 b = *(const float4*)(N.be + blk * E + t * 64 + ct * 16 + 4 * g);
 #pragma unroll
                 for (int i = 0; i < MAXT; i++) {
@@ -1169,13 +1293,73 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
                                                                                fmaxf(e[i][2] + b.z, 0.f), fmaxf(e[i][3] + b.w, 0.f)));
                 }
             }
+            S78_PH(1);
             __syncthreads();
+            S78_PH(2);
             // ---- depthwise 3x3 + BN + ReLU in place: one thread = the 5x5 plane of one (sample, channel) ----
             // (round 4, f16 x 2 kernel, measured and dropped: one thread per channel PAIR -- dword accesses to the planes, packed f32
             // multiply-adds, 256 threads instead of 512 -- 415 -> 419 us per 4096 leaves; the GEMM phases' weight fragments and biases
             // requested one phase ahead -- 411-419 -> 408-415 us, 48 B of spills: neither the 16-bit LDS accesses nor the 60 weight
             // round trips are what this kernel waits for)
-            if (tid < NS * 64) {
+            if constexpr (NPL == 2) {
+                // One thread = a PAIR of channels (one dword of a plane row: packed f32 multiply-adds, half the LDS accesses) x a group of
+                // output rows (0-1 / 2-3 / 4; wave-uniform), holding the <= 4 input rows it needs: 3 x NS x 32 threads, i.e. every wave of an
+                // 8-sample workgroup -- the form with one thread per plane ran 650 vector instructions on 8 of the 12 waves (5.1 k of a
+                // pass's 11 k cycles, tools/dbg_nn_phases_s78.py).  The planes hold 64 x: with the bias scaled the sums come out as 64 x too.
+                // Row r0 + cell of sample s sits in swizzle class (s + cell) & 7 (25 = 1 mod 8): eight base addresses per thread, the cell
+                // itself is an immediate offset.  In place: every read is done before the first write (the barrier in the middle).
+                constexpr int PT = NS * 32;
+                const int part = tid / PT, s_ = (tid >> 5) % NS, pr = tid & 31;
+                int base[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) base[j] = s_ * 25 * 128 + (((pr >> 2) ^ ((s_ + j) & 7)) << 4) + ((pr & 3) << 2);
+                f32x2 out[10];
+                const f32x2 bias = dw_b * H2_AS;
+                const f32x2 (&w)[9] = dw_w;
+                auto rows = [&](auto y0c, auto nyc) {
+                    constexpr int Y0 = decltype(y0c)::value, NY = decltype(nyc)::value, I0 = Y0 > 0 ? Y0 - 1 : 0, I1 = Y0 + NY < 5 ? Y0 + NY : 4;
+                    f32x2 in[(I1 - I0 + 1) * 5];
+#pragma unroll
+                    for (int k = I0 * 5; k < (I1 + 1) * 5; k++) {
+                        const uint8_t* src = HP + base[k & 7] + k * 128;
+                        in[k - I0 * 5] = h2_join2(*(const uint32_t*)src, *(const uint32_t*)(src + PLANE_B));
+                    }
+                    // (taps outside, outputs inside: ten independent accumulators between two uses of one -- a dependent packed
+                    // multiply-add needs a wait state, and output by output the compiler emitted one s_nop per multiply-add)
+#pragma unroll
+                    for (int o = 0; o < NY * 5; o++) out[o] = bias;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+                            for (int y = Y0; y < Y0 + NY; y++)
+#pragma unroll
+                                for (int x = 0; x < 5; x++) {
+                                    const int yy = y + ky - 1, xx = x + kx - 1;
+                                    if (yy >= 0 && yy < 5 && xx >= 0 && xx < 5) out[(y - Y0) * 5 + x] += w[ky * 3 + kx] * in[(yy - I0) * 5 + xx];
+                                }
+#pragma unroll
+                    for (int o = 0; o < NY * 5; o++) out[o] = f32x2{fmaxf(out[o].x, 0.f), fmaxf(out[o].y, 0.f)};
+                };
+                if (part == 0) rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+                else if (part == 1) rows(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+                else if (part == 2) rows(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+                __syncthreads();
+                auto put = [&](auto y0c, auto nyc) {
+                    constexpr int Y0 = decltype(y0c)::value, NY = decltype(nyc)::value;
+#pragma unroll
+                    for (int k = 0; k < NY * 5; k++) {
+                        uint32_t h, l;
+                        h2_split2(out[k].x, out[k].y, h, l);
+                        uint8_t* dst = HP + base[(Y0 * 5 + k) & 7] + (Y0 * 5 + k) * 128;
+                        *(uint32_t*)dst = h; *(uint32_t*)(dst + PLANE_B) = l;
+                    }
+                };
+                if (part == 0) put(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+                else if (part == 1) put(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+                else if (part == 2) put(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+            } else if (tid < NS * 64) {
                 const int s = tid >> 6, c = tid & 63, ec = blk * E + t * 64 + c;
                 float in[25], w[9];
                 const int q = c >> 3, cb = (c & 7) << 1, r0 = s * 25;
@@ -1229,14 +1413,15 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
                     }
                 }
             }
+            S78_PH(3);
             __syncthreads();
+            S78_PH(4);
             // ---- 1x1 project, K = this third of the expanded channels ----
-            {
-                uint4 wp[6];
-                gemm64_wload<NPL>((const uint4*)N.Wp + (size_t)(blk * 3 + t) * G64_U4, wp);
-                gemm64_split<NS, NPL>(wp, HP, pacc);
-            }
+            gemm64_wload<NPL>((const uint4*)N.Wp + (size_t)(blk * 3 + t) * G64_U4, wp);
+            gemm64_split<NS, NPL>(wp, HP, pacc);
+            S78_PH(5);
             __syncthreads();
+            S78_PH(6);
         }
         // ---- + BN bias + residual -> X, in place (a lane reads and writes its own elements) ----
         const float4 b = *(const float4*)(N.bp + blk * 64 + ct * 16 + 4 * g);
@@ -1254,6 +1439,9 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
         }
         __syncthreads();
     }
+    C5_PH(11);
+    S78HeadPf hpf;
+    s78_heads_prefetch<P>(N, hpf);           // (lands under the rebuild and its barrier)
     // ---- the heads read f32: rebuild the trunk output as [ROWS][CS] f32 over the H region ----
     for (int i = tid; i < ROWS * 16; i += 768) {
         const int r = i >> 4, c4 = (i & 15) * 4;
@@ -1261,7 +1449,10 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
         else *(float4*)(STG + r * CS + c4) = load_split4(XP, PLANE_B, r, c4);
     }
     __syncthreads();
-    s78_heads<NS, A, P>(N, STG, META, STG + ROWS * CS, b0, nb, pi_out, v_out);
+    C5_PH(12);
+    static_assert((size_t)(64 * 6 + 8 + 82 * 64 + 64 + 64 * P + P) * 4 <= (size_t)TILE_B, "the head weights fit the X planes' region");
+    s78_heads_lds<NS, A, P>(hpf, STG, META, STG + ROWS * CS, (float*)XP, b0, nb, pi_out, v_out);
+    C5_PH(13);
 }
 
 // Policy FC + masked softmax of the with-gods net for 16 samples per workgroup: logits[s][a] = bfp[a] + sum_k feat[s][k] Wfp[k][a]
@@ -1315,6 +1506,85 @@ __global__ __launch_bounds__(768) void k_s78_policy(const float* __restrict__ Wf
     }
     __syncthreads();
     for (int s = wave; s < nb; s += NW) {                      // masked softmax, one wave per sample
+        const int b = b0 + s;
+        constexpr int NK = (A + 63) / 64;
+        float x[NK];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const int ai = lane + 64 * k;
+            x[k] = -INFINITY;
+            if (ai < A) x[k] = valid[(size_t)b * A + ai] ? LG[s * LS + ai] : -1e8f;
+            mx = fmaxf(mx, x[k]);
+        }
+        mx = nn_wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; k++) { x[k] = (lane + 64 * k < A) ? expf(x[k] - mx) : 0.f; sum += x[k]; }
+        sum = nn_wave_sum(sum);
+#pragma unroll
+        for (int k = 0; k < NK; k++)
+            if (lane + 64 * k < A) pi[(size_t)b * A + lane + 64 * k] = x[k] / sum;
+    }
+}
+
+// The same FC on f16 x 2 split-precision operands (azg_nn_s78_forward_h2, round 6): the f32-input MFMA runs at 1/16 of the 16-bit rate
+// and the FC was bound by it (112 column tiles x 36 v_mfma_f32_16x16x4f32 per 16 samples); here a column tile is 5 K chunks of 32 x three
+// v_mfma_f32_16x16x32_f16 (lo*hi, hi*lo, hi*hi: h2_mma).  Wfrag: [112 ct][5 chunks][2 planes hi, lo][64 lanes][8] f16 of Wfp * 2^k
+// (K 132 -> 160, N 1782 -> 1792, zero padded; element = W_plane[32*chunk + 8*(lane>>4) + j][16*ct + (lane&15)]) followed by ONE float:
+// the descale 2^-k / 64 (the feature operand holds 64 * x like every activation plane).  The 16 samples' feature fragments stay in
+// registers, a wave streams the fragments of its column tiles two tiles ahead of the MFMAs.
+template <int A, int FP>
+__global__ __launch_bounds__(768) void k_s78_policy_h2(const uint4* __restrict__ Wfrag, const float* __restrict__ bias,
+                                                       const uint8_t* __restrict__ valid, int B, float* __restrict__ pi) {
+    constexpr int KCH = (FP + 31) / 32, KP = KCH * 32, FS = KP + 4, NT = (A + 15) / 16, LS = NT * 16 + 4, NW = 12;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* FEAT = smem;                     // [16][FS]
+    float* LG = FEAT + 16 * FS;             // [16][LS]
+    h2_fp16_saturate_mode();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const int b0 = blockIdx.x * 16, nb = min(16, B - b0);
+    const float descale = *(const float*)(Wfrag + (size_t)NT * KCH * 2 * 64);
+    auto wload = [&](int ct, uint4* w) {
+#pragma unroll
+        for (int c = 0; c < 2 * KCH; c++) w[c] = Wfrag[((size_t)(ct < NT ? ct : 0) * (2 * KCH) + c) * 64 + lane];
+    };
+    uint4 w0[2 * KCH], w1[2 * KCH];
+    wload(wave, w0);                        // (under the feature staging)
+    wload(wave + NW, w1);
+    for (int i = tid; i < 16 * FS; i += 768) {
+        const int s = i / FS, k = i - s * FS;
+        FEAT[i] = (s < nb && k < FP) ? pi[(size_t)(b0 + s) * A + k] : 0.f;
+    }
+    __syncthreads();
+    uint4 ah[KCH], al[KCH];                 // sample r16, k = 32 c + 8 g .. + 7
+#pragma unroll
+    for (int c = 0; c < KCH; c++) {
+        const float4 x0 = *(const float4*)(FEAT + r16 * FS + 32 * c + 8 * g), x1 = *(const float4*)(FEAT + r16 * FS + 32 * c + 8 * g + 4);
+        h2_split2(x0.x * H2_AS, x0.y * H2_AS, ah[c].x, al[c].x);
+        h2_split2(x0.z * H2_AS, x0.w * H2_AS, ah[c].y, al[c].y);
+        h2_split2(x1.x * H2_AS, x1.y * H2_AS, ah[c].z, al[c].z);
+        h2_split2(x1.z * H2_AS, x1.w * H2_AS, ah[c].w, al[c].w);
+    }
+    auto tile = [&](int ct, const uint4* w) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KCH; c++) acc = h2_mma(w[2 * c], w[2 * c + 1], ah[c], al[c], acc);
+        const float4 b = *(const float4*)(bias + ct * 16 + 4 * g);
+        *(float4*)(LG + r16 * LS + ct * 16 + 4 * g) =
+            make_float4(acc[0] * descale + b.x, acc[1] * descale + b.y, acc[2] * descale + b.z, acc[3] * descale + b.w);
+    };
+#pragma unroll 1
+    for (int ct = wave; ct < NT; ct += 2 * NW) {
+        tile(ct, w0);
+        wload(ct + 2 * NW, w0);
+        if (ct + NW < NT) {
+            tile(ct + NW, w1);
+            wload(ct + 3 * NW, w1);
+        }
+    }
+    __syncthreads();
+    for (int s = wave; s < nb; s += NW) {                      // masked softmax, one wave per sample (as k_s78_policy)
         const int b = b0 + s;
         constexpr int NK = (A + 63) / 64;
         float x[NK];

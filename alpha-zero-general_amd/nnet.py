@@ -968,6 +968,17 @@ class SantoriniV78Hip(SantoriniV89Hip):
         wfp[:132, :1782] = base.fc_pi[0]
         bfp = torch.zeros(1792, dtype=torch.float32, device=d)
         bfp[:1782] = base.fc_pi[1]
+        if self.h2:                        # the policy FC on f16 x 2 operands too (k_s78_policy_h2): K 132 -> 160, hi / lo fragments + the descale
+            kf = 12 - int(math.ceil(math.log2(max(1e-30, float(base.fc_pi[0].abs().max())))))
+            m = torch.zeros((160, 1792), dtype=torch.float32, device=d)
+            m[:132, :1782] = base.fc_pi[0]
+            m *= 2.0 ** kf
+            hi = m.to(torch.float16)
+            lo = (m - hi.float()).to(torch.float16)
+            pl = torch.stack([hi, lo]).view(2, 5, 4, 8, 112, 16)                          # plane, chunk, g, j, ct, r
+            fr = pl.permute(4, 1, 0, 2, 5, 3).contiguous().view(-1).view(torch.uint8)     # ct, chunk, plane, g, r, j
+            tail = torch.tensor([(2.0 ** -kf) / 64.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=d).view(torch.uint8)
+            wfp_h2 = torch.cat([fr, tail]).contiguous()
         keep = [frag(m0.reshape(144, 64).contiguous()),
                 (thirds([we.reshape(192, 64).t() for (we, _), _, _ in base.blocks], False) if self.split else
                  cat([frag(we.reshape(192, 64).t().contiguous()) for (we, _), _, _ in base.blocks])), cat([be for (_, be), _, _ in base.blocks]),
@@ -975,7 +986,7 @@ class SantoriniV78Hip(SantoriniV89Hip):
                 (thirds([wp.reshape(64, 192).t() for _, _, (wp, _) in base.blocks], True) if self.split else
                  cat([frag(wp.reshape(64, 192).t().contiguous()) for _, _, (wp, _) in base.blocks])), cat([bp for _, _, (_, bp) in base.blocks]),
                 base.meta[0].contiguous(), base.meta[1].contiguous(),
-                base.hp[0].reshape(4, 64).t().contiguous(), base.hp[1].contiguous(), frag(wfp), bfp,
+                base.hp[0].reshape(4, 64).t().contiguous(), base.hp[1].contiguous(), (wfp_h2 if self.h2 else frag(wfp)), bfp,
                 base.hv[0].reshape(2, 64).t().contiguous(), base.hv[1].contiguous(), base.fc_v1[0].contiguous(), base.fc_v1[1].contiguous(),
                 base.fc_v2[0].contiguous(), base.fc_v2[1].contiguous()]
         assert len(keep) == 19 and tuple(base.fc_pi[0].shape) == (132, 1782) and tuple(base.fc_v1[0].shape) == (82, 64)
