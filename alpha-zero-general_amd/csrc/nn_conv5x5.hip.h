@@ -1250,194 +1250,210 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     __syncthreads();
     C5_PH(10);
     if (tid < NPL * 64) ((uint32_t*)(HP + (tid >> 6) * PLANE_B + ROWS * 128))[tid & 63] = 0u;      // H's zero row (the staging tile is dead)
-#pragma unroll 1
-    for (int blk = 0; blk < NB; blk++) {
-        f32x4 pacc[MAXT];
-#pragma unroll
-        for (int i = 0; i < MAXT; i++) pacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int t = 0; t < 3; t++) {
-            // ---- 1x1 expand (channels 64 t .. 64 t + 63) + BN + ReLU -> H ----
+    // The phases of a pass (third t of block blk), as functions of the H buffer they work on:
+    f32x2 dw_w[9], dw_b;                    // (NPL = 2) the depthwise weights of this thread's channel pair, requested a phase ahead
+    f32x4 pacc[MAXT];
 #define S78_PH(k) do { if (blk == 5 && t == 1) C5_PH(k); } while (0)
-            S78_PH(0);
-            f32x2 dw_w[9], dw_b;
-            uint4 wp[6];
-            {
-                f32x4 e[MAXT];
+    // ---- 1x1 expand (channels 64 t .. 64 t + 63) + BN + ReLU -> Hc ----
+    auto expand = [&](int blk, int t, uint8_t* Hc) {
+        f32x4 e[MAXT];
 #pragma unroll
-                for (int i = 0; i < MAXT; i++) e[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                uint4 we[6];
-                gemm64_wload<NPL>((const uint4*)N.We + (size_t)(blk * 3 + t) * G64_U4, we);
-                gemm64_split<NS, NPL>(we, XP, e);
-                // (measured and dropped, round 6: the GEMMs' weight fragments requested a phase ahead -- the project's under the depthwise
-                // convolution: wave 0's project phase 1.7 k -> 1.0 k cycles, the forward 367 -> 379 us; the expand's under the project
-                // GEMM of the pass before: nothing, that phase is bound by the MFMA pipe, its LDS operand reads and its epilogue)
-                if constexpr (NPL == 2) {                 // the depthwise weights of this thread's channel pair: requested here, used behind the barrier
-                    const int ec = blk * E + t * 64 + 2 * (tid & 31);
-                    const float* wd = N.Wd + (size_t)ec * 9;
+        for (int i = 0; i < MAXT; i++) e[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        uint4 we[6];
+        gemm64_wload<NPL>((const uint4*)N.We + (size_t)(blk * 3 + t) * G64_U4, we);
+        gemm64_split<NS, NPL>(we, XP, e);
+        // (measured and dropped, round 6: the GEMMs' weight fragments requested a phase ahead -- the project's under the depthwise
+        // convolution: wave 0's project phase 1.7 k -> 1.0 k cycles, the forward 367 -> 379 us; the expand's under the project
+        // GEMM of the pass before: nothing, that phase is bound by the MFMA pipe, its LDS operand reads and its epilogue)
+        if constexpr (NPL == 2) {           // the depthwise weights: requested here, used behind the barrier
+            const int ec = blk * E + t * 64 + 2 * (tid & 31);
+            const float* wd = N.Wd + (size_t)ec * 9;
 #pragma unroll
-                    for (int k = 0; k < 9; k++) dw_w[k] = f32x2{wd[k], wd[9 + k]};
-                    dw_b = f32x2{N.bd[ec], N.bd[ec + 1]};
-                }
-                const float4 b = *(const float4*)(N.be + blk * E + t * 64 + ct * 16 + 4 * g);
-#pragma unroll
-                for (int i = 0; i < MAXT; i++) {
-                    const int r = (rg + RG * i) * 16 + r16;
-                    if (rg + RG * i >= RT || r >= ROWS) continue;
-                    if (NPL == 2) {
-                        const f32x4 o = e[i] * ds_e + f32x4{b.x, b.y, b.z, b.w};
-                        h2_store4(HP, PLANE_B, 128, r, ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});
-                        continue;
-                    }
-                    store_split4(HP, PLANE_B, r, ct * 16 + 4 * g, make_float4(fmaxf(e[i][0] + b.x, 0.f), fmaxf(e[i][1] + b.y, 0.f),
-                                                                               fmaxf(e[i][2] + b.z, 0.f), fmaxf(e[i][3] + b.w, 0.f)));
-                }
-            }
-            S78_PH(1);
-            __syncthreads();
-            S78_PH(2);
-            // ---- depthwise 3x3 + BN + ReLU in place: one thread = the 5x5 plane of one (sample, channel) ----
-            // (round 4, f16 x 2 kernel, measured and dropped: one thread per channel PAIR -- dword accesses to the planes, packed f32
-            // multiply-adds, 256 threads instead of 512 -- 415 -> 419 us per 4096 leaves; the GEMM phases' weight fragments and biases
-            // requested one phase ahead -- 411-419 -> 408-415 us, 48 B of spills: neither the 16-bit LDS accesses nor the 60 weight
-            // round trips are what this kernel waits for)
-            if constexpr (NPL == 2) {
-                // One thread = a PAIR of channels (one dword of a plane row: packed f32 multiply-adds, half the LDS accesses) x a group of
-                // output rows (0-1 / 2-3 / 4; wave-uniform), holding the <= 4 input rows it needs: 3 x NS x 32 threads, i.e. every wave of an
-                // 8-sample workgroup -- the form with one thread per plane ran 650 vector instructions on 8 of the 12 waves (5.1 k of a
-                // pass's 11 k cycles, tools/dbg_nn_phases_s78.py).  The planes hold 64 x: with the bias scaled the sums come out as 64 x too.
-                // Row r0 + cell of sample s sits in swizzle class (s + cell) & 7 (25 = 1 mod 8): eight base addresses per thread, the cell
-                // itself is an immediate offset.  In place: every read is done before the first write (the barrier in the middle).
-                constexpr int PT = NS * 32;
-                const int part = tid / PT, s_ = (tid >> 5) % NS, pr = tid & 31;
-                int base[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) base[j] = s_ * 25 * 128 + (((pr >> 2) ^ ((s_ + j) & 7)) << 4) + ((pr & 3) << 2);
-                f32x2 out[10];
-                const f32x2 bias = dw_b * H2_AS;
-                const f32x2 (&w)[9] = dw_w;
-                auto rows = [&](auto y0c, auto nyc) {
-                    constexpr int Y0 = decltype(y0c)::value, NY = decltype(nyc)::value, I0 = Y0 > 0 ? Y0 - 1 : 0, I1 = Y0 + NY < 5 ? Y0 + NY : 4;
-                    f32x2 in[(I1 - I0 + 1) * 5];
-#pragma unroll
-                    for (int k = I0 * 5; k < (I1 + 1) * 5; k++) {
-                        const uint8_t* src = HP + base[k & 7] + k * 128;
-                        in[k - I0 * 5] = h2_join2(*(const uint32_t*)src, *(const uint32_t*)(src + PLANE_B));
-                    }
-                    // (taps outside, outputs inside: ten independent accumulators between two uses of one -- a dependent packed
-                    // multiply-add needs a wait state, and output by output the compiler emitted one s_nop per multiply-add)
-#pragma unroll
-                    for (int o = 0; o < NY * 5; o++) out[o] = bias;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                        for (int kx = 0; kx < 3; kx++)
-#pragma unroll
-                            for (int y = Y0; y < Y0 + NY; y++)
-#pragma unroll
-                                for (int x = 0; x < 5; x++) {
-                                    const int yy = y + ky - 1, xx = x + kx - 1;
-                                    if (yy >= 0 && yy < 5 && xx >= 0 && xx < 5) out[(y - Y0) * 5 + x] += w[ky * 3 + kx] * in[(yy - I0) * 5 + xx];
-                                }
-#pragma unroll
-                    for (int o = 0; o < NY * 5; o++) out[o] = f32x2{fmaxf(out[o].x, 0.f), fmaxf(out[o].y, 0.f)};
-                };
-                if (part == 0) rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-                else if (part == 1) rows(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
-                else if (part == 2) rows(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
-                __syncthreads();
-                auto put = [&](auto y0c, auto nyc) {
-                    constexpr int Y0 = decltype(y0c)::value, NY = decltype(nyc)::value;
-#pragma unroll
-                    for (int k = 0; k < NY * 5; k++) {
-                        uint32_t h, l;
-                        h2_split2(out[k].x, out[k].y, h, l);
-                        uint8_t* dst = HP + base[(Y0 * 5 + k) & 7] + (Y0 * 5 + k) * 128;
-                        *(uint32_t*)dst = h; *(uint32_t*)(dst + PLANE_B) = l;
-                    }
-                };
-                if (part == 0) put(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-                else if (part == 1) put(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
-                else if (part == 2) put(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
-            } else if (tid < NS * 64) {
-                const int s = tid >> 6, c = tid & 63, ec = blk * E + t * 64 + c;
-                float in[25], w[9];
-                const int q = c >> 3, cb = (c & 7) << 1, r0 = s * 25;
-                auto off = [&](int k) { return (r0 + k) * 128 + ((q ^ ((r0 + k) & 7)) << 4) + cb; };
-#pragma unroll
-                for (int k = 0; k < 25; k++) {
-                    const uint8_t* src = HP + off(k);
-                    if (NPL == 2) in[k] = ((float)*(const _Float16*)src + (float)*(const _Float16*)(src + PLANE_B)) * H2_IAS;
-                    else in[k] = (bf16_lo_f32(*(const uint16_t*)src) + bf16_lo_f32(*(const uint16_t*)(src + PLANE_B))) +
-                                 bf16_lo_f32(*(const uint16_t*)(src + 2 * PLANE_B));
-                }
-#pragma unroll
-                for (int k = 0; k < 9; k++) w[k] = N.Wd[(size_t)ec * 9 + k];
-                const float bias = N.bd[ec];
-                float out[26];
-#pragma unroll
-                for (int y = 0; y < 5; y++)
-#pragma unroll
-                    for (int x = 0; x < 5; x++) {
-                        float a = bias;
-#pragma unroll
-                        for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                            for (int kx = 0; kx < 3; kx++) {
-                                const int yy = y + ky - 1, xx = x + kx - 1;
-                                if (yy >= 0 && yy < 5 && xx >= 0 && xx < 5) a += w[ky * 3 + kx] * in[yy * 5 + xx];
-                            }
-                        out[y * 5 + x] = fmaxf(a, 0.f);
-                    }
-                out[25] = 0.f;
-#pragma unroll
-                for (int k = 0; k < 26; k += 2) {                  // two cells per conversion
-                    uint32_t h, m, l;
-                    if (NPL == 2) {
-                        h2_split2(out[k] * H2_AS, out[k + 1] * H2_AS, h, m);
-                        uint8_t* e0 = HP + off(k);
-                        *(uint16_t*)e0 = (uint16_t)h; *(uint16_t*)(e0 + PLANE_B) = (uint16_t)m;
-                        if (k + 1 < 25) {
-                            uint8_t* e1 = HP + off(k + 1);
-                            *(uint16_t*)e1 = (uint16_t)(h >> 16); *(uint16_t*)(e1 + PLANE_B) = (uint16_t)(m >> 16);
-                        }
-                        continue;
-                    }
-                    split3x2(out[k], out[k + 1], h, m, l);
-                    uint8_t* d0 = HP + off(k);
-                    *(uint16_t*)d0 = (uint16_t)h; *(uint16_t*)(d0 + PLANE_B) = (uint16_t)m; *(uint16_t*)(d0 + 2 * PLANE_B) = (uint16_t)l;
-                    if (k + 1 < 25) {
-                        uint8_t* d1 = HP + off(k + 1);
-                        *(uint16_t*)d1 = (uint16_t)(h >> 16); *(uint16_t*)(d1 + PLANE_B) = (uint16_t)(m >> 16);
-                        *(uint16_t*)(d1 + 2 * PLANE_B) = (uint16_t)(l >> 16);
-                    }
-                }
-            }
-            S78_PH(3);
-            __syncthreads();
-            S78_PH(4);
-            // ---- 1x1 project, K = this third of the expanded channels ----
-            gemm64_wload<NPL>((const uint4*)N.Wp + (size_t)(blk * 3 + t) * G64_U4, wp);
-            gemm64_split<NS, NPL>(wp, HP, pacc);
-            S78_PH(5);
-            __syncthreads();
-            S78_PH(6);
+            for (int k = 0; k < 9; k++) dw_w[k] = f32x2{wd[k], wd[9 + k]};
+            dw_b = f32x2{N.bd[ec], N.bd[ec + 1]};
         }
-        // ---- + BN bias + residual -> X, in place (a lane reads and writes its own elements) ----
-        const float4 b = *(const float4*)(N.bp + blk * 64 + ct * 16 + 4 * g);
+        const float4 b = *(const float4*)(N.be + blk * E + t * 64 + ct * 16 + 4 * g);
 #pragma unroll
         for (int i = 0; i < MAXT; i++) {
             const int r = (rg + RG * i) * 16 + r16;
             if (rg + RG * i >= RT || r >= ROWS) continue;
             if (NPL == 2) {
-                h2_store4(XP, PLANE_B, 128, r, ct * 16 + 4 * g, pacc[i] * ds_p + f32x4{b.x, b.y, b.z, b.w} + h2_load4(XP, PLANE_B, 128, r, ct * 16 + 4 * g));
+                const f32x4 o = e[i] * ds_e + f32x4{b.x, b.y, b.z, b.w};
+                h2_store4(Hc, PLANE_B, 128, r, ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});
                 continue;
             }
-            const float4 x = load_split4(XP, PLANE_B, r, ct * 16 + 4 * g);
-            store_split4(XP, PLANE_B, r, ct * 16 + 4 * g, make_float4(pacc[i][0] + b.x + x.x, pacc[i][1] + b.y + x.y,
-                                                                       pacc[i][2] + b.z + x.z, pacc[i][3] + b.w + x.w));
+            store_split4(Hc, PLANE_B, r, ct * 16 + 4 * g, make_float4(fmaxf(e[i][0] + b.x, 0.f), fmaxf(e[i][1] + b.y, 0.f),
+                                                                       fmaxf(e[i][2] + b.z, 0.f), fmaxf(e[i][3] + b.w, 0.f)));
         }
-        __syncthreads();
+    };
+    auto depthwise = [&](int blk, int t, uint8_t* Hc) {
+        (void)blk; (void)t;
+        // ---- depthwise 3x3 + BN + ReLU in place: one thread = the 5x5 plane of one (sample, channel) ----
+        // (round 4, f16 x 2 kernel, measured and dropped: one thread per channel PAIR -- dword accesses to the planes, packed f32
+        // multiply-adds, 256 threads instead of 512 -- 415 -> 419 us per 4096 leaves; the GEMM phases' weight fragments and biases
+        // requested one phase ahead -- 411-419 -> 408-415 us, 48 B of spills: neither the 16-bit LDS accesses nor the 60 weight
+        // round trips are what this kernel waits for)
+        if constexpr (NPL == 2) {
+            // One thread = a PAIR of channels (one dword of a plane row: packed f32 multiply-adds, half the LDS accesses) x a group of
+            // output rows (0-1 / 2-3 / 4; wave-uniform), holding the <= 4 input rows it needs: 3 x NS x 32 threads, i.e. every wave of an
+            // 8-sample workgroup -- the form with one thread per plane ran 650 vector instructions on 8 of the 12 waves (5.1 k of a
+            // pass's 11 k cycles, tools/dbg_nn_phases_s78.py).  The planes hold 64 x: with the bias scaled the sums come out as 64 x too.
+            // Row r0 + cell of sample s sits in swizzle class (s + cell) & 7 (25 = 1 mod 8): eight base addresses per thread, the cell
+            // itself is an immediate offset.  In place: every read is done before the first write (the barrier in the middle).
+            constexpr int PT = NS * 32;
+            const int part = tid / PT, s_ = (tid >> 5) % NS, pr = tid & 31;
+            int base[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) base[j] = s_ * 25 * 128 + (((pr >> 2) ^ ((s_ + j) & 7)) << 4) + ((pr & 3) << 2);
+            f32x2 out[10];
+            const f32x2 bias = dw_b * H2_AS;
+            const f32x2 (&w)[9] = dw_w;
+            auto rows = [&](auto y0c, auto nyc) {
+                constexpr int Y0 = decltype(y0c)::value, NY = decltype(nyc)::value, I0 = Y0 > 0 ? Y0 - 1 : 0, I1 = Y0 + NY < 5 ? Y0 + NY : 4;
+                f32x2 in[(I1 - I0 + 1) * 5];
+#pragma unroll
+                for (int k = I0 * 5; k < (I1 + 1) * 5; k++) {
+                    const uint8_t* src = Hc + base[k & 7] + k * 128;
+                    in[k - I0 * 5] = h2_join2(*(const uint32_t*)src, *(const uint32_t*)(src + PLANE_B));
+                }
+                // (taps outside, outputs inside: ten independent accumulators between two uses of one -- a dependent packed
+                // multiply-add needs a wait state, and output by output the compiler emitted one s_nop per multiply-add)
+#pragma unroll
+                for (int o = 0; o < NY * 5; o++) out[o] = bias;
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+                        for (int y = Y0; y < Y0 + NY; y++)
+#pragma unroll
+                            for (int x = 0; x < 5; x++) {
+                                const int yy = y + ky - 1, xx = x + kx - 1;
+                                if (yy >= 0 && yy < 5 && xx >= 0 && xx < 5) out[(y - Y0) * 5 + x] += w[ky * 3 + kx] * in[(yy - I0) * 5 + xx];
+                            }
+#pragma unroll
+                for (int o = 0; o < NY * 5; o++) out[o] = f32x2{fmaxf(out[o].x, 0.f), fmaxf(out[o].y, 0.f)};
+            };
+            if (part == 0) rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            else if (part == 1) rows(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+            else if (part == 2) rows(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+            __syncthreads();
+            auto put = [&](auto y0c, auto nyc) {
+                constexpr int Y0 = decltype(y0c)::value, NY = decltype(nyc)::value;
+#pragma unroll
+                for (int k = 0; k < NY * 5; k++) {
+                    uint32_t h, l;
+                    h2_split2(out[k].x, out[k].y, h, l);
+                    uint8_t* dst = Hc + base[(Y0 * 5 + k) & 7] + (Y0 * 5 + k) * 128;
+                    *(uint32_t*)dst = h; *(uint32_t*)(dst + PLANE_B) = l;
+                }
+            };
+            if (part == 0) put(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            else if (part == 1) put(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+            else if (part == 2) put(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+        } else if (tid < NS * 64) {
+            const int s = tid >> 6, c = tid & 63, ec = blk * E + t * 64 + c;
+            float in[25], w[9];
+            const int q = c >> 3, cb = (c & 7) << 1, r0 = s * 25;
+            auto off = [&](int k) { return (r0 + k) * 128 + ((q ^ ((r0 + k) & 7)) << 4) + cb; };
+#pragma unroll
+            for (int k = 0; k < 25; k++) {
+                const uint8_t* src = Hc + off(k);
+                if (NPL == 2) in[k] = ((float)*(const _Float16*)src + (float)*(const _Float16*)(src + PLANE_B)) * H2_IAS;
+                else in[k] = (bf16_lo_f32(*(const uint16_t*)src) + bf16_lo_f32(*(const uint16_t*)(src + PLANE_B))) +
+                             bf16_lo_f32(*(const uint16_t*)(src + 2 * PLANE_B));
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) w[k] = N.Wd[(size_t)ec * 9 + k];
+            const float bias = N.bd[ec];
+            float out[26];
+#pragma unroll
+            for (int y = 0; y < 5; y++)
+#pragma unroll
+                for (int x = 0; x < 5; x++) {
+                    float a = bias;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            const int yy = y + ky - 1, xx = x + kx - 1;
+                            if (yy >= 0 && yy < 5 && xx >= 0 && xx < 5) a += w[ky * 3 + kx] * in[yy * 5 + xx];
+                        }
+                    out[y * 5 + x] = fmaxf(a, 0.f);
+                }
+            out[25] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 26; k += 2) {                  // two cells per conversion
+                uint32_t h, m, l;
+                if (NPL == 2) {
+                    h2_split2(out[k] * H2_AS, out[k + 1] * H2_AS, h, m);
+                    uint8_t* e0 = Hc + off(k);
+                    *(uint16_t*)e0 = (uint16_t)h; *(uint16_t*)(e0 + PLANE_B) = (uint16_t)m;
+                    if (k + 1 < 25) {
+                        uint8_t* e1 = Hc + off(k + 1);
+                        *(uint16_t*)e1 = (uint16_t)(h >> 16); *(uint16_t*)(e1 + PLANE_B) = (uint16_t)(m >> 16);
+                    }
+                    continue;
+                }
+                split3x2(out[k], out[k + 1], h, m, l);
+                uint8_t* d0 = Hc + off(k);
+                *(uint16_t*)d0 = (uint16_t)h; *(uint16_t*)(d0 + PLANE_B) = (uint16_t)m; *(uint16_t*)(d0 + 2 * PLANE_B) = (uint16_t)l;
+                if (k + 1 < 25) {
+                    uint8_t* d1 = Hc + off(k + 1);
+                    *(uint16_t*)d1 = (uint16_t)(h >> 16); *(uint16_t*)(d1 + PLANE_B) = (uint16_t)(m >> 16);
+                    *(uint16_t*)(d1 + 2 * PLANE_B) = (uint16_t)(l >> 16);
+                }
+            }
+        }
+    };
+    // ---- 1x1 project, K = this third of the expanded channels ----
+    auto project = [&](int blk, int t, const uint8_t* Hc) {
+        uint4 wp[6];
+        gemm64_wload<NPL>((const uint4*)N.Wp + (size_t)(blk * 3 + t) * G64_U4, wp);
+        gemm64_split<NS, NPL>(wp, Hc, pacc);
+    };
+    auto residual = [&](int blk) {
+    // ---- + BN bias + residual -> X, in place (a lane reads and writes its own elements) ----
+    const float4 b = *(const float4*)(N.bp + blk * 64 + ct * 16 + 4 * g);
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) {
+        const int r = (rg + RG * i) * 16 + r16;
+        if (rg + RG * i >= RT || r >= ROWS) continue;
+        if (NPL == 2) {
+            h2_store4(XP, PLANE_B, 128, r, ct * 16 + 4 * g, pacc[i] * ds_p + f32x4{b.x, b.y, b.z, b.w} + h2_load4(XP, PLANE_B, 128, r, ct * 16 + 4 * g));
+            continue;
+        }
+        const float4 x = load_split4(XP, PLANE_B, r, ct * 16 + 4 * g);
+        store_split4(XP, PLANE_B, r, ct * 16 + 4 * g, make_float4(pacc[i][0] + b.x + x.x, pacc[i][1] + b.y + x.y,
+                                                                   pacc[i][2] + b.z + x.z, pacc[i][3] + b.w + x.w));
+    }
+    };
+#pragma unroll 1
+    for (int blk = 0; blk < NB; blk++) {
+#pragma unroll
+        for (int i = 0; i < MAXT; i++) pacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (measured and dropped, round 6: two H buffers -- the project GEMM of third t and the expand GEMM of third t + 1 as ONE phase, seven
+        // barriers per block instead of ten: 333 -> 341-345 us per 4096 leaves on the same box, 17 spilled registers)
+        {
+#pragma unroll 1
+            for (int t = 0; t < 3; t++) {
+                S78_PH(0);
+                expand(blk, t, HP);
+                S78_PH(1);
+                __syncthreads();
+                S78_PH(2);
+                depthwise(blk, t, HP);
+                S78_PH(3);
+                __syncthreads();
+                S78_PH(4);
+                project(blk, t, HP);
+                S78_PH(5);
+                __syncthreads();
+                S78_PH(6);
+            }
+            residual(blk);
+            __syncthreads();
+        }
     }
     C5_PH(11);
     S78HeadPf hpf;
