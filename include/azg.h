@@ -186,13 +186,23 @@ int azg_forest_rounds_profile(azg_forest* f, double* out4, int reset);
    be resident; <= 0: a default split); the split may change from call to call.  Per-tree results are identical bit for bit to
    `rounds` x (azg_forest_select_fused -> azg_selfplay_advance -> azg_nn_v80_forward_h2) with shared_budget == 0 (tests/test_gpu_selfplay.py).
    leaf_valid_dev u8[T][A], needs_eval_dev u8[T], pi_dev f32[T][A], v_dev f32[T][P]: as for azg_forest_select_fused (the leaf states
-   travel through a buffer the forest owns).  A pipeline that stops making progress for AZG_ASYNC_TIMEOUT_MS (20000; at most 20000) sets error bit 128
-   (azg_selfplay_stats.errors) and ends the kernels. */
+   travel through a buffer the forest owns).
+   Determinism: with shared_budget != 0 the GAMES played are the same as with per-tree budgets (a tree's sequence of calls is its own),
+   but how many of them are finished after N launches depends on GPU timing; callers that need "the examples after N runs" to be a function
+   of the seed use shared_budget == 0 (Python: SelfPlayEngine(deterministic=True) or AZG_DETERMINISTIC=1; 3-4 % slower).
+   Exclusive use: every workgroup of both kernels must be resident, so the device's CUs must not be held by other kernels for long (two
+   engines on one GPU split the CUs with n_net / n_sel).
+   Time-outs and recovery (csrc/azg_async.hip.h "Recovery"): a wave that finds nothing to do for AZG_ASYNC_TIMEOUT_MS (default 50 with a
+   shared budget, 20000 with per-tree budgets) ends the launch.  With a shared budget that is a launch that ENDS EARLY, not an error: on
+   this platform a few workgroups are occasionally not scheduled for about a second; the leaves they held are re-queued by the next
+   launch (a small kernel in front of it), nothing is evaluated twice or lost, and the early end is counted (azg_forest_async_profile
+   out[17] / [18]: ended by a descent / a net wave, [26] ticket ranges abandoned, [27] leaves re-queued).  Eight early ends in a row, or
+   any time-out with per-tree budgets, set error bit 128 (azg_selfplay_stats.errors): a pipeline that cannot make progress fails loudly. */
 int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev,
                                    int noise_stride, const void* const* w, const float* descale_host, int rounds, int n_net, int n_sel,
                                    int batch_wait_ticks, int shared_budget, void* stream);
 /* The same pipeline for a Santorini no-gods forest with the V89 net: w = the 14 device pointers and descale of azg_nn_conv5_forward_h2, 8
-   leaves per forward; default split 13 / 16 of the CUs for the net.  Everything else as above. */
+   leaves per forward; default split 49 / 64 of the CUs for the net.  Everything else as above. */
 int azg_forest_async_rounds_conv5_h2(azg_forest* f, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev,
                                      int noise_stride, const float* const* w, float descale, int rounds, int n_net, int n_sel,
                                      int batch_wait_ticks, int shared_budget, void* stream);
@@ -205,7 +215,8 @@ int azg_forest_async_rounds_mb1d_h2(azg_forest* f, int geometry, uint8_t* leaf_v
    out[0] descents (select_tree calls), [1] ticks inside them, [2] ticks descent waves spent looking for a ready tree, [3] net batches,
    [4] leaves in them, [5] ticks inside the forward, [6] ticks net workgroups waited for leaves, [7] sum over leaves of (claimed by a net
    workgroup - queued), [8] sum over descents of (tree claimed - tree handed back by the net), [9] launches, [10] / [11] resident ticks
-   summed over the select / net workgroups, [12] n_sel, [13] n_net, [32..63] histogram of [7]'s waits in microseconds (last bucket: >= 31), [64..95] of [8]'s. */
+   summed over the select / net workgroups, [12] n_sel, [13] n_net, [17] / [18] launches ended early by a descent / net wave's time-out,
+   [26] ticket ranges abandoned, [27] leaves re-queued at the start of a launch, [32..63] histogram of [7]'s waits in microseconds (last bucket: >= 31), [64..95] of [8]'s. */
 #define AZG_ASYNC_NPROF 96
 int azg_forest_async_profile(azg_forest* f, double* out96, int reset);
 
@@ -414,7 +425,10 @@ int azg_nn_s78_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev,
                              int B, float* pi_dev, float* v_dev, void* stream);
 /* The same with the trunk's 1x1 convolutions and the depthwise pass on f16 x 2 split-precision operands (hi + lo, three
    v_mfma_f32_16x16x32_f16 per product, two planes per tile holding 64 * x): We / Wp = [n_blocks][3 thirds][4 ct][2 chunks]
-   [2 planes hi, lo][64 lanes][8] f16 of W * 2^k (one k per family), ds_e / ds_p = 2^-k / 64.  Same 1e-5 contract. */
+   [2 planes hi, lo][64 lanes][8] f16 of W * 2^k (one k per family), ds_e / ds_p = 2^-k / 64.  The policy FC runs on the same operands
+   (k_s78_policy_h2): w[11] = [112 column tiles][5 K chunks of 32][2 planes hi, lo][64 lanes][8] f16 of Wfp * 2^k (K 132 -> 160,
+   N 1782 -> 1792, zero padded; element = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)]) followed by ONE float, its descale
+   2^-k / 64 (the 16-byte tail of the buffer).  Same 1e-5 contract. */
 int azg_nn_s78_forward_h2(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, float ds_e, float ds_p, int n_blocks,
                           int A, int P, int B, float* pi_dev, float* v_dev, void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */

@@ -1,9 +1,9 @@
-# round-5 evidence: run on the GPU box (gpurun), outputs under gpurun_out/r06p/ -> copied to profiles/r06_* afterwards
-# usage: bash tools/refresh_profiles_r06.sh [part ...]   parts: tests bench prof sant games variants phases (default: all)
+# round-6 evidence: run on the GPU box (gpurun), outputs under gpurun_out/r06prof/ -> copied to profiles/r06_* afterwards
+# usage: bash tools/refresh_profiles_r06.sh [part ...]   parts: tests bench prof sant sant11 games variants phases v78 (default: all)
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r06prof; mkdir -p $O
-PARTS=${@:-tests bench prof sant sant11 games variants phases}
+PARTS=${@:-tests bench prof sant sant11 games variants phases v78}
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 cd $R
 if has tests; then python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -40 > $O/pytest_tail.txt; tail -3 $O/pytest_tail.txt > $O/pytest.txt; fi
@@ -73,5 +73,9 @@ if has phases; then
   AZG_ASYNC=1 python tools/dbg_async_placement.py 2>&1 | grep -v amdgpu.ids > $O/placement_pipeline.txt
   [ -f build_ab/libazg_cyc.so ] && AZG_LIB=$R/build_ab/libazg_cyc.so python tools/dbg_cycles.py 2>&1 | grep -v amdgpu.ids > $O/cycles_pipeline.txt
   [ -f build_ab/libazg_cyc.so ] && AZG_ASYNC=0 AZG_LIB=$R/build_ab/libazg_cyc.so python tools/dbg_cycles.py 2>&1 | grep -v amdgpu.ids > $O/cycles_two_kernel.txt
+fi
+if has v78; then
+  python tools/time_v78.py 2>&1 | grep -v amdgpu.ids | tail -1 > $O/v78_forward.txt
+  [ -f build_ab/libazg_ph.so ] && AZG_LIB=$R/build_ab/libazg_ph.so python tools/dbg_nn_phases_s78.py 2>&1 | grep -v amdgpu.ids >> $O/v78_forward.txt
 fi
 ls -la $O | tail -50
