@@ -397,6 +397,9 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         bool need = false;
         uint32_t left = word - 1u;                                          // calls of this tree still to run in this launch
         if (AZG_LDS_LD32(&C->stop)) left = 0u;                              // the launch's shared budget is spent: the tree retires as it is
+#ifdef AZG_ASYNC_EXP_ACQUIRE   /* experiment (profiles/r06_pooling.md): the L1 invalidate a wave would need after claiming a tree that another CU of its XCD may have worked on */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
         while (left > 0u) {
             int r;
             {
