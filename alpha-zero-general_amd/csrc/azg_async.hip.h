@@ -37,13 +37,16 @@
 // not run again until other workgroups leave (tools/dbg_async_stall.py: their batch counters stop, they still hold the ticket ranges they
 // had claimed, they resume the moment the launch winds down) -- a preemption by the platform, not something the kernels do.  The leaves queued
 // into those ranges are never evaluated, their trees never come back, the launch cannot end: rounds 5 and 6 saw it as the 20 s "time-out"
-// (error bit 128).  With the work-sharing budget (the engine's default) such a launch now ENDS EARLY AND SAFELY instead: a wave that finds
+// (error bit 128).  Such a launch now ENDS EARLY AND SAFELY instead: a wave that finds
 // nothing to do for `timeout_ticks` (50 ms) raises the abort flag, everyone leaves, and nothing is lost -- every tree records whether the leaf
 // it queued last has been evaluated (`evald`: cleared by the descent wave in front of the ticket, set by the net workgroup with the hand-back),
 // and the next launch begins with a small kernel (k_async_requeue) that puts the leaf of every tree still owed its evaluation back on the ring (the
 // leaf record is still in the pipeline's leaf array) and starts that tree as "in the net" instead of expanding it with a policy that never arrived.  Eight launches in a row that end this way set the error bit after all (a pipeline that
-// really cannot run -- a workgroup that never becomes resident -- still fails loudly).  With per-tree budgets (shared_budget == 0: "exactly
-// `rounds` calls per tree") an early end would change what a launch means, so there the time-out stays an error.
+// really cannot run -- a workgroup that never becomes resident -- still fails loudly).  With the work-sharing budget that is all: an early end
+// is a launch that did fewer calls.  With per-tree budgets (shared_budget == 0: "exactly `rounds` calls per tree") every tree also keeps
+// the calls it has not run (`carry`: rounds + carry at the start of a launch, the calls left at every hand-over, 0 when the tree retires), and the
+// entry point launches the pipeline twice -- the second launch grants nothing, it runs what the first left over -- so the contract holds at
+// every return.
 #pragma once
 #include "azg_fused.hip.h"
 #include "selfplay.hip.h"
@@ -98,6 +101,7 @@ struct AsyncArgs {
     unsigned long long* prof;
     uint32_t* evald;                           // [T]: 1 = the leaf the tree queued last has been evaluated (its pi / v are in place); 0 = still owed (see "Recovery")
     uint8_t* pending;                          // [T]: 1 = k_async_requeue put the tree's owed leaf back on the ring: it starts this launch waiting for the net
+    uint32_t* carry;                           // [T] (per-tree budgets): the calls the tree still has to run -- what a launch that ended early left over is added to the next launch's `rounds`
     unsigned long long* wginfo;                // [n_sel + n_net][4]: where the workgroup ran (XCC | cu << 8 | se << 16 | sh << 24), role, calls, busy shader cycles
     int noise, rounds, n_sel, ring_bits, batch_wait, timeout_ticks;
     unsigned long long total_calls;            // != 0: the launch ends when the trees TOGETHER have had this many calls (whichever tree is fast
@@ -240,7 +244,10 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         unsigned long long start0 = 0ull, start1 = 0ull;
         if (i < ASYNC_RS) {
             const bool here = i < n_g && !A->pending[g + i * n_sel];
-            const uint32_t w0 = here ? (uint32_t)rounds + 1u : 0u;
+            // (per-tree budgets: what an earlier launch that ended early left of the tree's calls is run now, see "Recovery")
+            const uint32_t calls = (uint32_t)rounds + ((i < n_g && !A->total_calls) ? A->carry[g + i * n_sel] : 0u);
+            if (here && !A->total_calls) A->carry[g + i * n_sel] = calls;
+            const uint32_t w0 = here ? calls + 1u : 0u;
             astore(my_ready + i, w0);
             C->rw[i] = w0; C->last[i] = 0xFFFFFFFFu;
             const unsigned long long bal = __ballot(here);
@@ -341,11 +348,10 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
                 acc = uni_u32(acc);
                 if (uni_u32(aload(&A->ctl->abort))) leave = true;
                 else if (acc > (uint32_t)timeout) {                        // (this wave has looked for work for that long and found none)
-                    // work-sharing budget: the launch ends early and the next one carries on (see "Recovery"); eight such launches in a row, or
-                    // per-tree budgets: an error
+                    // the launch ends early and the next one carries on (see "Recovery"); eight such launches in a row: an error
                     if (AZG_L == 0) {
                         astore(&A->ctl->abort, 1u);
-                        if (!A->total_calls || atomicAdd(A->prof + 19, 1ull) >= 7ull) atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT);
+                        if (atomicAdd(A->prof + 19, 1ull) >= 7ull) atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT);
                     }
                     leave = true;
                 }
@@ -486,6 +492,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
         {
             const AsyncArgsC A = (AsyncArgsC)(uintptr_t)args;
             if (AZG_L == 0) {
+                if (!A->total_calls) A->carry[t] = left;                    // (per-tree budgets: the calls still to run, should this launch end early)
                 if (need) {
                     const uint32_t rb = (uint32_t)A->ring_bits;
                     // ring entry: tree [19:0] | time stamp (100 MHz clock >> 4, 12 bits: profile only) [31:20] | calls left [55:32] | lap tag [63:60]
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
             unsigned long long* wi = A->wginfo + (size_t)g * 4;
             wi[0] = where_am_i(); wi[1] = 1ull; wi[2] += C->prof[0]; wi[3] += C->prof[4];   // role | ticks this workgroup stayed << 8
             atomicAdd(prof + 10, (unsigned long long)(wall32() - t_begin));
-            if (g == 0) atomicAdd(prof + 9, 1ull);
+            if (g == 0 && A->rounds > 0) atomicAdd(prof + 9, 1ull);            // (launches; not the catch-up launch of a per-tree budget)
             // (sticky: launches that ended because a descent wave / a net workgroup gave up -- the error bit on tree 0 can be overwritten by
             // that tree's own header write-back.  Anything more elaborate in the time-out branch itself changes the register allocation of the
             // whole kernel: a post-mortem dump there took the scratch instructions of the Azul / Santorini / Splendor descents from 45 / 61 / 17
@@ -702,7 +709,7 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
                     if (idle_acc > (uint32_t)timeout) {                              // (no leaf for that long)
                         if (lane == 0) {
                             astore(&ctl->abort, 2u);
-                            if (!A->total_calls || atomicAdd(A->prof + 19, 1ull) >= 7ull) atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT);
+                            if (atomicAdd(A->prof + 19, 1ull) >= 7ull) atomicOr(&A->F.hdr[0].err, ERR_ASYNC_TIMEOUT);
                         }
                         n = -1;
                         break;
@@ -837,7 +844,7 @@ int azg_async_launch_select(int net_kind, const azg::AsyncArgs* devbuf, int n_se
 // ---- host side ----
 struct AsyncSlot {
     AsyncArgs host; AsyncArgs* devbuf;
-    int8_t* aleaf; AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts; uint32_t* evald; uint8_t* pending; unsigned long long* prof; unsigned long long* wginfo;
+    int8_t* aleaf; AsyncCtl* ctl; unsigned long long* ring; uint32_t* ready; uint32_t* ts; uint32_t* evald; uint8_t* pending; uint32_t* carry; unsigned long long* prof; unsigned long long* wginfo;
     hipEvent_t fork, join, join_net;
     int n_sel, n_net, ring_bits;
     int device, n_cu, leaf_stride, T;          // what the buffers were sized for (checked on every reuse)
@@ -845,7 +852,7 @@ struct AsyncSlot {
 static void async_slot_free(void* p) {
     AsyncSlot* s = (AsyncSlot*)p;
     (void)hipFree(s->devbuf); (void)hipFree(s->aleaf); (void)hipFree(s->ctl); (void)hipFree(s->ring); (void)hipFree(s->ready);
-    (void)hipFree(s->ts); (void)hipFree(s->evald); (void)hipFree(s->pending); (void)hipFree(s->prof); (void)hipFree(s->wginfo);
+    (void)hipFree(s->ts); (void)hipFree(s->evald); (void)hipFree(s->pending); (void)hipFree(s->carry); (void)hipFree(s->prof); (void)hipFree(s->wginfo);
     if (s->fork) (void)hipEventDestroy(s->fork);
     if (s->join) (void)hipEventDestroy(s->join);
     if (s->join_net) (void)hipEventDestroy(s->join_net);
@@ -931,8 +938,10 @@ __global__ __launch_bounds__(256) void k_async_requeue(const AsyncArgs* args) {
     A->pending[t] = owed ? (uint8_t)1 : (uint8_t)0;
     if (owed) {
         const uint32_t rb = (uint32_t)A->ring_bits, tk = atomicAdd(&A->ctl->leaf_tail, 1u);
+        const uint32_t calls = (uint32_t)A->rounds + (A->total_calls ? 0u : A->carry[t]);   // (per-tree budgets: + what the tree was left owing)
+        if (!A->total_calls) A->carry[t] = calls;
         // (calls left = the launch's `rounds`: the hand-back word rounds + 1 is below the 0xFFFFFFFF the workgroup starts its bookkeeping from)
-        A->ring[tk & ((1u << rb) - 1u)] = (unsigned long long)((uint32_t)t | (((wall32() >> 4) & 0xFFFu) << 20)) | ((unsigned long long)(uint32_t)A->rounds << 32) |
+        A->ring[tk & ((1u << rb) - 1u)] = (unsigned long long)((uint32_t)t | (((wall32() >> 4) & 0xFFFu) << 20)) | ((unsigned long long)calls << 32) |
                                            ((unsigned long long)(((tk >> rb) & 7u) + 1u) << 60);
         atomicAdd(A->prof + 27, 1ull);
     }
@@ -1023,7 +1032,8 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
             hipMalloc(&n->ctl, sizeof(AsyncCtl)) == hipSuccess && hipMalloc(&n->ring, sizeof(unsigned long long) << rb) == hipSuccess &&
             hipMalloc(&n->ready, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess &&           // (sized for any split: it may change from launch to launch)
             hipMalloc(&n->ts, sizeof(uint32_t) * ASYNC_RS * n_cu) == hipSuccess && hipMalloc(&n->evald, sizeof(uint32_t) * (size_t)T) == hipSuccess &&
-            hipMemset(n->evald, 1, sizeof(uint32_t) * (size_t)T) == hipSuccess && hipMalloc(&n->pending, (size_t)T) == hipSuccess && hipMemset(n->pending, 0, (size_t)T) == hipSuccess &&       // (non-zero: whatever a tree is waiting for when the pipeline first sees it has been evaluated)
+            hipMemset(n->evald, 1, sizeof(uint32_t) * (size_t)T) == hipSuccess && hipMalloc(&n->pending, (size_t)T) == hipSuccess && hipMemset(n->pending, 0, (size_t)T) == hipSuccess &&
+            hipMalloc(&n->carry, sizeof(uint32_t) * (size_t)T) == hipSuccess && hipMemset(n->carry, 0, sizeof(uint32_t) * (size_t)T) == hipSuccess &&       // (non-zero: whatever a tree is waiting for when the pipeline first sees it has been evaluated)
             hipMalloc(&n->prof, sizeof(unsigned long long) * ASYNC_NPROF) == hipSuccess &&
             hipMalloc(&n->wginfo, sizeof(unsigned long long) * (4 * 1024 + 280 + 512 + 104 * 40)) == hipSuccess &&
             hipMemset(n->prof, 0, sizeof(unsigned long long) * ASYNC_NPROF) == hipSuccess &&
@@ -1065,24 +1075,31 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
         want.c5_descale = descale[0];
     }
     want.aleaf = sl->aleaf; want.leaf_valid = leaf_valid; want.needs_eval = needs_eval; want.pi = pi; want.v = v;
-    want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_ready = sl->ts; want.evald = sl->evald; want.pending = sl->pending; want.prof = sl->prof; want.wginfo = sl->wginfo;
+    want.ctl = sl->ctl; want.ring = sl->ring; want.ready = sl->ready; want.ts_ready = sl->ts; want.evald = sl->evald; want.pending = sl->pending; want.carry = sl->carry; want.prof = sl->prof; want.wginfo = sl->wginfo;
     want.noise = (alpha != 0.0 && noise_stride == -2) ? 1 : 0;
-    want.rounds = rounds; want.n_sel = n_sel; want.ring_bits = sl->ring_bits;
+    want.n_sel = n_sel; want.ring_bits = sl->ring_bits;
+    hipStream_t s = (hipStream_t)stream;
+    if (shared_budget) HIPCHK(hipMemsetAsync(sl->carry, 0, sizeof(uint32_t) * (size_t)T, s));      // (per-tree balances mean nothing to a shared budget)
+    else if (rounds >= (1 << 22)) return fail(me + ": at most 2^22 - 1 rounds per launch with per-tree budgets");
+    // One launch of the two kernels.  Per-tree budgets: TWO -- the second grants no calls, it only runs what the first left over if it ended early
+    // (the platform froze a workgroup, "Recovery"): after it every tree has had its `rounds` calls again, without the host looking at the
+    // outcome of the first.  (Nothing left over: every tree is claimed once and retires -- ~30 us.)
+    auto launch_once = [&](int rounds) -> int {
+    want.rounds = rounds;
     if (shared_budget) {                              // `rounds` x T calls for the trees together; no tree is held back by a share of its own
         want.total_calls = (unsigned long long)rounds * (unsigned long long)T;
         want.rounds = (1 << 24) - 2;
     }
     want.batch_wait = batch_wait_ticks >= 0 ? batch_wait_ticks : 150;
-    // (work-sharing budget: a launch that stalls ends early and the next one carries on -- 50 ms; per-tree budgets: the time-out is an error -- 20 s)
-    { const char* e = getenv("AZG_ASYNC_TIMEOUT_MS"); int ms = e ? atoi(e) : (shared_budget ? 50 : 20000); ms = ms < 1 ? 1 : (ms > 20000 ? 20000 : ms); want.timeout_ticks = ms * 100000; }   // (32-bit ticks of 10 ns: <= 20 s)
+    // (a launch that stalls ends early and the next one carries on: 50 ms of a wave's own idling)
+    { const char* e = getenv("AZG_ASYNC_TIMEOUT_MS"); int ms = e ? atoi(e) : 50; ms = ms < 1 ? 1 : (ms > 20000 ? 20000 : ms); want.timeout_ticks = ms * 100000; }   // (32-bit ticks of 10 ns: <= 20 s)
     // test hook (tests/test_gpu_selfplay.py): AZG_ASYNC_TEST_STALL=k cuts the k-th launch of the process short -- its time-out is 20 us, so the first
     // wave that idles ends it -- to exercise the recovery path without waiting for the platform to freeze a workgroup
     {
         static int n_launch = 0;
         const char* e = getenv("AZG_ASYNC_TEST_STALL");
-        if (e && shared_budget) { if (++n_launch == atoi(e)) want.timeout_ticks = 2000; } else n_launch = 0;
+        if (e) { if (++n_launch == atoi(e)) want.timeout_ticks = 2000; } else n_launch = 0;
     }
-    hipStream_t s = (hipStream_t)stream;
     if (memcmp(&sl->host, &want, sizeof(want)) != 0) {
         sl->host = want;
         HIPCHK(hipMemcpyAsync(sl->devbuf, &sl->host, sizeof(AsyncArgs), hipMemcpyHostToDevice, s));
@@ -1124,6 +1141,10 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
     HIPCHK(hipEventRecord(sl->join, D.sel_stream));
     HIPCHK(hipStreamWaitEvent(s, sl->join_net, 0));
     HIPCHK(hipStreamWaitEvent(s, sl->join, 0));
+    return 0;
+    };
+    if (launch_once(rounds)) return -1;
+    if (!shared_budget && launch_once(0)) return -1;
     return 0;
 }
 

@@ -192,12 +192,14 @@ int azg_forest_rounds_profile(azg_forest* f, double* out4, int reset);
    of the seed use shared_budget == 0 (Python: SelfPlayEngine(deterministic=True) or AZG_DETERMINISTIC=1; 3-4 % slower).
    Exclusive use: every workgroup of both kernels must be resident, so the device's CUs must not be held by other kernels for long (two
    engines on one GPU split the CUs with n_net / n_sel).
-   Time-outs and recovery (csrc/azg_async.hip.h "Recovery"): a wave that finds nothing to do for AZG_ASYNC_TIMEOUT_MS (default 50 with a
-   shared budget, 20000 with per-tree budgets) ends the launch.  With a shared budget that is a launch that ENDS EARLY, not an error: on
-   this platform a few workgroups are occasionally not scheduled for about a second; the leaves they held are re-queued by the next
-   launch (a small kernel in front of it), nothing is evaluated twice or lost, and the early end is counted (azg_forest_async_profile
-   out[17] / [18]: ended by a descent / a net wave, [26] ticket ranges abandoned, [27] leaves re-queued).  Eight early ends in a row, or
-   any time-out with per-tree budgets, set error bit 128 (azg_selfplay_stats.errors): a pipeline that cannot make progress fails loudly. */
+   Time-outs and recovery (csrc/azg_async.hip.h "Recovery"): a wave that finds nothing to do for AZG_ASYNC_TIMEOUT_MS (default 50) ends
+   the launch.  That is a launch that ENDS EARLY, not an error: on this platform a few workgroups are occasionally not scheduled for
+   about a second; the leaves they held are re-queued by the next launch (a small kernel in front of it), nothing is evaluated twice or
+   lost, and the early end is counted (azg_forest_async_profile out[17] / [18]: ended by a descent / a net wave, [26] ticket ranges
+   abandoned, [27] leaves re-queued).  With per-tree budgets every tree keeps the calls it has not run yet and a call of this function
+   launches the pipeline TWICE -- the second launch grants nothing and only runs what the first left over -- so the "exactly `rounds` calls
+   per tree" contract holds at every return whether or not the first launch ended early (both ending early: the next call catches up).
+   Eight early ends in a row set error bit 128 (azg_selfplay_stats.errors): a pipeline that cannot make progress fails loudly. */
 int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev,
                                    int noise_stride, const void* const* w, const float* descale_host, int rounds, int n_net, int n_sel,
                                    int batch_wait_ticks, int shared_budget, void* stream);

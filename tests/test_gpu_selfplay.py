@@ -879,3 +879,47 @@ def test_async_pipeline_recovers_from_a_launch_that_ends_early(monkeypatch):
     assert early >= 1                                     # the third launch did end early ...
     for a, b in zip(res[0], res[1]):                      # ... and nothing was lost or played differently
         assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_async_pipeline_per_tree_budget_survives_an_early_end(monkeypatch):
+    """Per-tree budgets (SelfPlayEngine(deterministic=True)): a launch that ends early leaves every tree its unfinished calls (`carry`,
+    csrc/azg_async.hip.h "Recovery") and the catch-up launch that follows every per-tree launch runs them -- so after each run() every tree
+    has had exactly `rounds` calls again, stall or no stall.  AZG_ASYNC_TEST_STALL cuts the 3rd and the 7th launch of the process short
+    (= the main launches of the 2nd and 4th run()): the engine's state after EVERY run() -- statistics counters, root statistics -- and the
+    examples equal an undisturbed engine's."""
+    from azg_amd import games
+    from azg_amd.selfplay import SelfPlayEngine
+    from hashnet import HashNetPipeline
+    g = games.SplendorGame(2)
+    T, sims = 48, 24
+    args = Args(numMCTSSims=sims, prob_fullMCTS=1.0, ratio_fullMCTS=5, dirichletAlpha=0.3, temperature=[1.25, 0.8, 1.0], tempThreshold=6,
+                **{**MCTS_ARGS['splendor2'], 'forced_playouts': False})
+    runs = []
+    for stall in ('3', None):
+        if stall:
+            monkeypatch.setenv('AZG_ASYNC_TEST_STALL', stall)
+        else:
+            monkeypatch.delenv('AZG_ASYNC_TEST_STALL', raising=False)
+        e = SelfPlayEngine(g, HashNetPipeline(2), args, T, node_capacity=2048, max_examples=T * 800, rng_seed=78, stream0=1200,
+                           async_pipe=True, deterministic=True)
+        e.start(episode_quota=T)
+        trace = []
+        for k in range(40):
+            e.run(61)
+            st = e.stats()
+            assert st['errors'] == 0, st
+            trace.append((st['games'], st['plies'], st['sims'], st['active']) + tuple(int(x) for x in e.forest.root_stats()['Ns'].cpu().numpy()))
+            if k == 1 and stall:
+                monkeypatch.setenv('AZG_ASYNC_TEST_STALL', '0')          # (the launch counter restarts: no further stall)
+        to = e.forest.async_profile(reset=False)['timeouts']
+        ex = [x.cpu().numpy() for x in e.drain_examples()]
+        meta = ex[5]
+        order = np.lexsort((meta[:, 2], meta[:, 1], meta[:, 0]))
+        runs.append((trace, [x[order] for x in ex], to['select'] + to['net']))
+        assert e.forest.validate() == 0
+        e.close()
+    assert runs[0][2] >= 1 and runs[1][2] == 0                     # the stalled engine did end a launch early
+    assert runs[0][0] == runs[1][0]                                # ... and was where the undisturbed one was after every run()
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert a.shape == b.shape and np.array_equal(a, b)
