@@ -382,7 +382,7 @@ def measure_net(a, eng, T, game_key, net_kind):
         dt = 'f16' if h2 else 'f32'
         flops_leaf = NET_MFLOP_PER_LEAF[game_key] * 1e6
         ach = flops_leaf * ap['leaves'] / max(ap['launch_us'] * ap['launches'], 1e-9) / 1e6
-        return dict(bound='mfma', kernel='k_async_net (persistent: the forward of %s on batches of queued leaves)' % ('k_v80_net_h2<12>' if game_key == 'splendor2' else 'k_conv5_net<5, 162, 2, 2>'),
+        return dict(bound='mfma', kernel='k_async_net (persistent: the forward of %s on batches of queued leaves)' % ({'splendor2': 'k_v80_net_h2<12>', 'santorini1': 'k_conv5_net<5, 162, 2, 2>'}.get(game_key, 'k_mb1d_net<Cfg, true>')),
                     achieved=ach, peak=MFMA_PEAK_TFLOPS[dt], unit='TFLOP/s', frac=ach / MFMA_PEAK_TFLOPS[dt], traffic=None, mfma_input_dtype=dt,
                     frac_of_peak_of_its_cus=ach / (MFMA_PEAK_TFLOPS[dt] * ap['n_net'] / max(1, ap['n_net'] + ap['n_sel'])),
                     note='fp32-accurate (<= 1e-5 of the reference outputs): every f32 operand is a hi + lo pair of f16 numbers, one algorithmic product = 3 '
