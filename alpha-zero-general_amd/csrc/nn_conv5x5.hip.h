@@ -668,6 +668,39 @@ __device__ __forceinline__ void gemm64_split(const uint4 (&w)[6], const uint8_t*
 }
 #undef AZG_BF
 
+// The same GEMM phase with TWO column tiles per wave (f16 x 2 only; the with-gods trunk, round 6): 12 waves = 2 column-tile pairs x 6 row
+// groups, a wave's row tiles rt = rg + 6 i.  A wave reads each activation tile once for its two column tiles: 104 instead of 208 16-byte
+// operand reads per GEMM over the workgroup -- the phase was bound by them (1.9 k cycles of LDS bandwidth against 1.4 k of the MFMA pipe).
+// w[ctl * 4 + c * 2 + plane]; acc[i * 2 + ctl].
+__device__ __forceinline__ void gemm64_wload2(const uint4* __restrict__ Wfrag, uint4 (&w)[8]) {
+    const int tidx_ = nn_tid(), lane = tidx_ & 63, ctp = (tidx_ >> 6) & 1;
+#pragma unroll
+    for (int ctl = 0; ctl < 2; ctl++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) w[ctl * 4 + c * 2 + p] = Wfrag[(((size_t)(2 * ctp + ctl) * 2 + c) * 2 + p) * 64 + lane];
+}
+template <int NS>
+__device__ __forceinline__ void gemm64_split2(const uint4 (&w)[8], const uint8_t* IN, f32x4 (&acc)[((NS * 25 + 15) / 16 / 6 + 1) * 2]) {
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 6, MAXT = (RT + RG - 1) / RG, PB = (ROWS + 2) * 128;
+    static_assert(MAXT == RT / RG + 1 && RT - RG * (MAXT - 1) == 1, "tile schedule: MAXT - 1 tiles per wave + one odd tile in the first row group");
+    const int tidx_ = nn_tid(), lane = tidx_ & 63, wave = tidx_ >> 6, g = lane >> 4, r16 = lane & 15;
+    const int rg = wave >> 1;
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) {
+        if (i == MAXT - 1 && rg != 0) continue;             // (wave-uniform)
+        const int r = (rg + RG * i) * 16 + r16;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint8_t* src = IN + pl_off_z<ROWS>(r, 4 * c + g, r < ROWS);
+            const uint4 ah = *(const uint4*)src, al = *(const uint4*)(src + PB);
+            acc[i * 2] = h2_mma(w[c * 2], w[c * 2 + 1], ah, al, acc[i * 2]);
+            acc[i * 2 + 1] = h2_mma(w[4 + c * 2], w[4 + c * 2 + 1], ah, al, acc[i * 2 + 1]);
+        }
+    }
+}
+
 // IND (the asynchronous pipeline, azg_async.hip.h): sample s of the workgroup is tree sidx[s] (LDS; < 0 = no sample); `boards` and `valid`
 // are then both the pipeline's leaf-record array (kernels.hip.h AsyncLeaf<SantoriniDev<1>>: int8 state [80] + valid bit mask u64[3], stride
 // 112), read past the L1; the samples' masks are fetched with the boards into `smask` (LDS u64 [8][3]); pi / v rows are written
@@ -1210,10 +1243,14 @@ __global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __rest
 // product).  N.We / N.Wp point to the split fragments [NB][3 thirds][4 ct][2 chunks][3 planes][64 lanes][8] bf16.
 // NPL = 2: f16 x 2 operands (hi + lo, three MFMAs per product, two planes per tile holding 64 * x; N.We / N.Wp then hold
 // [NB][3 thirds][4 ct][2 chunks][2 planes][64 lanes][8] f16 of W * 2^k, ds_e / ds_p = 2^-k / 64 of the two matrix families)
+#ifndef AZG_S78_W2
+#define AZG_S78_W2 1                        /* 0: one column tile per wave (4 x 3), the form of rounds 2-5 */
+#endif
 template <int NB, int A, int P, int NPL = 3, int NS = 8>
 __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* __restrict__ boards, const uint8_t* __restrict__ valid,
                                                        int B, float* __restrict__ pi_out, float* __restrict__ v_out, float ds_e, float ds_p) {
-    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = 3, MAXT = (RT + RG - 1) / RG, CS = 68, E = 192;
+    constexpr bool W2 = NPL == 2 && AZG_S78_W2;            // two column tiles per wave (gemm64_split2): 2 column-tile pairs x 6 row groups
+    constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = W2 ? 6 : 3, MAXT = (RT + RG - 1) / RG, CTW = W2 ? 2 : 1, CS = 68, E = 192;
     // (the f32 staging / head tile [ROWS][CS] + head buffers live in the H region: it keeps the size of three planes)
     constexpr int PLANE_B = (ROWS + 2) * 128, TILE_B = NPL * PLANE_B, HREG_B = 3 * PLANE_B;
     constexpr size_t G64_U4 = (size_t)4 * 2 * NPL * 64;        // uint4 per 64 x 64 matrix
@@ -1224,7 +1261,7 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     float* META = (float*)(HP + HREG_B);                        // [NS][32]
     float* STG = (float*)HP;                                    // f32 [ROWS][CS]: the board staging tile, later the trunk output for the heads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
-    const int ct = wave & 3, rg = wave >> 2;
+    const int ct = W2 ? 2 * (wave & 1) : (wave & 3), rg = W2 ? (wave >> 1) : (wave >> 2);        // (W2: the first of the wave's two column tiles)
     const int b0 = blockIdx.x * NS, nb = min(NS, B - b0);
     C5_PH(8);
     for (int i = tid; i < ROWS * 4; i += 768) *(float4*)(STG + (i >> 2) * CS + 4 * (i & 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1252,16 +1289,22 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     if (tid < NPL * 64) ((uint32_t*)(HP + (tid >> 6) * PLANE_B + ROWS * 128))[tid & 63] = 0u;      // H's zero row (the staging tile is dead)
     // The phases of a pass (third t of block blk), as functions of the H buffer they work on:
     f32x2 dw_w[9], dw_b;                    // (NPL = 2) the depthwise weights of this thread's channel pair, requested a phase ahead
-    f32x4 pacc[MAXT];
+    f32x4 pacc[MAXT * CTW];
 #define S78_PH(k) do { if (blk == 5 && t == 1) C5_PH(k); } while (0)
     // ---- 1x1 expand (channels 64 t .. 64 t + 63) + BN + ReLU -> Hc ----
     auto expand = [&](int blk, int t, uint8_t* Hc) {
-        f32x4 e[MAXT];
+        f32x4 e[MAXT * CTW];
 #pragma unroll
-        for (int i = 0; i < MAXT; i++) e[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        uint4 we[6];
-        gemm64_wload<NPL>((const uint4*)N.We + (size_t)(blk * 3 + t) * G64_U4, we);
-        gemm64_split<NS, NPL>(we, XP, e);
+        for (int i = 0; i < MAXT * CTW; i++) e[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (W2) {
+            uint4 we[8];
+            gemm64_wload2((const uint4*)N.We + (size_t)(blk * 3 + t) * G64_U4, we);
+            gemm64_split2<NS>(we, XP, e);
+        } else {
+            uint4 we[6];
+            gemm64_wload<NPL>((const uint4*)N.We + (size_t)(blk * 3 + t) * G64_U4, we);
+            gemm64_split<NS, NPL>(we, XP, e);
+        }
         // (measured and dropped, round 6: the GEMMs' weight fragments requested a phase ahead -- the project's under the depthwise
         // convolution: wave 0's project phase 1.7 k -> 1.0 k cycles, the forward 367 -> 379 us; the expand's under the project
         // GEMM of the pass before: nothing, that phase is bound by the MFMA pipe, its LDS operand reads and its epilogue)
@@ -1273,13 +1316,17 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
             dw_b = f32x2{N.bd[ec], N.bd[ec + 1]};
         }
         const float4 b = *(const float4*)(N.be + blk * E + t * 64 + ct * 16 + 4 * g);
+        float4 b2 = b;
+        if (W2) b2 = *(const float4*)(N.be + blk * E + t * 64 + (ct + 1) * 16 + 4 * g);
 #pragma unroll
         for (int i = 0; i < MAXT; i++) {
             const int r = (rg + RG * i) * 16 + r16;
             if (rg + RG * i >= RT || r >= ROWS) continue;
             if (NPL == 2) {
-                const f32x4 o = e[i] * ds_e + f32x4{b.x, b.y, b.z, b.w};
+                const f32x4 o = e[i * CTW] * ds_e + f32x4{b.x, b.y, b.z, b.w};
                 h2_store4(Hc, PLANE_B, 128, r, ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});
+                const f32x4 o2 = e[i * CTW + CTW - 1] * ds_e + f32x4{b2.x, b2.y, b2.z, b2.w};
+                h2_store4(Hc, PLANE_B, 128, r, (ct + 1) * 16 + 4 * g, f32x4{fmaxf(o2[0], 0.f), fmaxf(o2[1], 0.f), fmaxf(o2[2], 0.f), fmaxf(o2[3], 0.f)});
                 continue;
             }
             store_split4(Hc, PLANE_B, r, ct * 16 + 4 * g, make_float4(fmaxf(e[i][0] + b.x, 0.f), fmaxf(e[i][1] + b.y, 0.f),
@@ -1408,19 +1455,29 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     };
     // ---- 1x1 project, K = this third of the expanded channels ----
     auto project = [&](int blk, int t, const uint8_t* Hc) {
-        uint4 wp[6];
-        gemm64_wload<NPL>((const uint4*)N.Wp + (size_t)(blk * 3 + t) * G64_U4, wp);
-        gemm64_split<NS, NPL>(wp, Hc, pacc);
+        if constexpr (W2) {
+            uint4 wp[8];
+            gemm64_wload2((const uint4*)N.Wp + (size_t)(blk * 3 + t) * G64_U4, wp);
+            gemm64_split2<NS>(wp, Hc, pacc);
+        } else {
+            uint4 wp[6];
+            gemm64_wload<NPL>((const uint4*)N.Wp + (size_t)(blk * 3 + t) * G64_U4, wp);
+            gemm64_split<NS, NPL>(wp, Hc, pacc);
+        }
     };
     auto residual = [&](int blk) {
     // ---- + BN bias + residual -> X, in place (a lane reads and writes its own elements) ----
     const float4 b = *(const float4*)(N.bp + blk * 64 + ct * 16 + 4 * g);
+    float4 b2 = b;
+    if (W2) b2 = *(const float4*)(N.bp + blk * 64 + (ct + 1) * 16 + 4 * g);
 #pragma unroll
     for (int i = 0; i < MAXT; i++) {
         const int r = (rg + RG * i) * 16 + r16;
         if (rg + RG * i >= RT || r >= ROWS) continue;
         if (NPL == 2) {
-            h2_store4(XP, PLANE_B, 128, r, ct * 16 + 4 * g, pacc[i] * ds_p + f32x4{b.x, b.y, b.z, b.w} + h2_load4(XP, PLANE_B, 128, r, ct * 16 + 4 * g));
+            h2_store4(XP, PLANE_B, 128, r, ct * 16 + 4 * g, pacc[i * CTW] * ds_p + f32x4{b.x, b.y, b.z, b.w} + h2_load4(XP, PLANE_B, 128, r, ct * 16 + 4 * g));
+            h2_store4(XP, PLANE_B, 128, r, (ct + 1) * 16 + 4 * g,
+                      pacc[i * CTW + CTW - 1] * ds_p + f32x4{b2.x, b2.y, b2.z, b2.w} + h2_load4(XP, PLANE_B, 128, r, (ct + 1) * 16 + 4 * g));
             continue;
         }
         const float4 x = load_split4(XP, PLANE_B, r, ct * 16 + 4 * g);
@@ -1431,7 +1488,7 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
 #pragma unroll 1
     for (int blk = 0; blk < NB; blk++) {
 #pragma unroll
-        for (int i = 0; i < MAXT; i++) pacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MAXT * CTW; i++) pacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         // (measured and dropped, round 6: two H buffers -- the project GEMM of third t and the expand GEMM of third t + 1 as ONE phase, seven
         // barriers per block instead of ten: 333 -> 341-345 us per 4096 leaves on the same box, 17 spilled registers)
         {
