@@ -97,7 +97,7 @@ def main():
         dt = time.perf_counter() - t0
         s1 = eng.stats()
         sims, plies = s1['sims'] - s0['sims'], s1['plies'] - s0['plies']
-        bad = sum(grp.f.validate() for grp in eng.groups) if T <= 1024 else -1
+        bad = sum(grp.f.validate(verbose=False) for grp in eng.groups)
         if a.md:
             print('| %s | %d | %d | %d | %d | %s | %.0f | %.2f | %.3f | %.2f | %.1f | %d | %d | %.1f |' % (
                 name, g.P, g.S, g.A, T, a.net, plies / dt, sims / dt / 1e6, dt / (a.plies * a.sims) * 1e3, (s1['levels'] - s0['levels']) / max(sims, 1),

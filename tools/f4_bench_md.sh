@@ -1,5 +1,5 @@
-# profiles/r05_f4_bench.md: the six f4 plugins with their evaluators (run on the GPU box)
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/r05; mkdir -p $O
+# profiles/r06_f4_bench.md: the six f4 plugins with their evaluators (run on the GPU box)
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/r06f4; mkdir -p $O
 {
 echo '# f4 game plugins on one MI355X (`tools/bench_f4.py --md --net <evaluator>`: batched self-play, 200 simulations per move, 20 timed ply waves after 2 of warm-up, HIP-graph rounds)'
 echo
@@ -20,7 +20,7 @@ echo '## `k_select` at 1024 trees (rocprofv3 --kernel-trace, `tools/f4prof.sh <g
 echo
 for g in smallworld botanik minivilles thelittleprince abalone akropolis; do
   bash tools/f4prof.sh $g > /dev/null 2>&1
-  grep "k_select<" gpurun_out/r05p/f4prof_$g.txt | head -1 | awk -F'|' -v g=$g '{printf "* %s: `k_select` %s us average over %s launches (min %s, max %s); VGPRs %s, scratch %s B\n", g, $5, $3, $6, $7, $9, $12}'
+  grep "k_select<" gpurun_out/r06p/f4prof_$g.txt | head -1 | awk -F'|' -v g=$g '{printf "* %s: `k_select` %s us average over %s launches (min %s, max %s); VGPRs %s, scratch %s B\n", g, $5, $3, $6, $7, $9, $12}'
 done
 echo
 echo '(Akropolis runs without policy-target pruning: with ~250 valid placements and 200 simulations the pruned counts are all <= 1, which the engine reports as error bit 64 -- the reference divides 0 / 0 there.)'
