@@ -52,6 +52,13 @@ class HashNetHip:
         self.P = P
         self._out = {}
 
+    def bind_outputs(self, T, A, P, device):
+        """the engine announces the batch it will evaluate: fixed output buffers `pi` / `v`, which selfplay._Group then hands to the
+        expansion as they are (no copy per round: two 7-us copy kernels per 50-us round in tools/bench_f4.py --net hashhip)"""
+        self.pi = torch.empty((T, A), dtype=torch.float32, device=device)
+        self.v = torch.empty((T, P), dtype=torch.float32, device=device)
+        self._out[(T, A, torch.device(device))] = (self.pi, self.v)
+
     def predict_batch(self, boards, valids):
         import ctypes as C
         from azg_amd import _lib

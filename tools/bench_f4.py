@@ -84,6 +84,7 @@ def main():
             net = TorchModuleEvaluator(MlpNet(int(g.S), g.A, g.P), g)
         elif a.net == 'hashhip':
             net = HashNetHip(g.P)
+            net.bind_outputs(T, g.A, g.P, g.device)          # fixed output buffers: the engine's expansion reads them in place (no copy kernels per round)
         else:
             net = HashNetTorch(g.P)
         eng = SelfPlayEngine(g, net, args, n_games=T, node_capacity=max(2048, capf * a.sims), max_examples=T * 256)
