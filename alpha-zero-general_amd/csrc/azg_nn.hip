@@ -398,6 +398,32 @@ static int s78_launch(const int8_t* boards, const uint8_t* valid, const float* c
         k_s78_net<10, 1782, 2><<<dim3((B + 3) / 4), dim3(768), lds, (hipStream_t)stream>>>(N, boards, valid, B, pi, v);
     }
     HIPCHK(hipGetLastError());
+    static const int pol2 = getenv("AZG_S78_POLICY2") ? atoi(getenv("AZG_S78_POLICY2")) : 1;    // (0: the one-launch form, k_s78_policy_h2)
+    if (split == 2 && pol2) {               // policy FC in two launches: 64 samples x a quarter of the columns per workgroup, then the softmax
+        // workspace for the raw logits [B][1792] (the pi rows hold the policy features until every column quarter has read them): kept per
+        // device, grown on demand (the first call of a size happens in the warm-up rounds, before any graph capture)
+        static float* ws[64];
+        static size_t ws_rows[64];
+        int dv = 0;
+        HIPCHK(hipGetDevice(&dv));
+        if (dv < 0 || dv >= 64) return fail("azg_nn_s78_forward_h2: device index");
+        if (ws_rows[dv] < (size_t)B) {
+            if (ws[dv]) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(ws[dv]); ws[dv] = nullptr; ws_rows[dv] = 0; }
+            HIPCHK(hipMalloc(&ws[dv], (size_t)B * 1792 * sizeof(float)));
+            ws_rows[dv] = (size_t)B;
+        }
+        constexpr size_t lds_g = (size_t)2 * 64 * (160 * 2 + 16);
+        static bool attr_g = false;
+        if (!attr_g) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_s78_policy_gemm_h2<1782, 132>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
+            attr_g = true;
+        }
+        k_s78_policy_gemm_h2<1782, 132><<<dim3((B + 63) / 64, 4), dim3(768), lds_g, (hipStream_t)stream>>>((const uint4*)N.Wfp, N.bfp, B, pi, ws[dv]);
+        HIPCHK(hipGetLastError());
+        k_s78_policy_softmax<1782><<<dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(ws[dv], valid, B, pi);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (split == 2) {                       // (the policy FC on f16 x 2 operands as well: w[11] then holds its hi / lo fragments + the descale)
         constexpr size_t lds_h2 = (size_t)(16 * (160 + 4) + 16 * (112 * 16 + 4)) * sizeof(float);
         static bool attr_h2 = false;

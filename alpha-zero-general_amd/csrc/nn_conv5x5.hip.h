@@ -1680,6 +1680,105 @@ __global__ __launch_bounds__(768) void k_s78_policy_h2(const uint4* __restrict__
     }
 }
 
+// ... and in two launches (round 6, the default of azg_nn_s78_forward_h2): k_s78_policy_h2 streams the FC's 1.15 MB of weight fragments
+// once per 16 samples -- 294 MB per 4096 leaves, 8.9 TB/s out of the L2s: that stream is what bounds it (34 us).  Here a workgroup owns
+// 64 samples x a QUARTER of the column tiles (28 of 112): every fragment it loads serves four sample groups (74 MB per 4096 leaves), the
+// features of its 64 samples sit in LDS as f16 hi / lo planes (row stride 336 B: conflict-free 16-byte operand reads), raw logits go to a
+// workspace [B][1792] (the pi rows still hold the FEATURES the other three quarters of the same samples read), and k_s78_policy_softmax
+// normalises them into pi, one wave per sample.
+template <int A, int FP>
+__global__ __launch_bounds__(768) void k_s78_policy_gemm_h2(const uint4* __restrict__ Wfrag, const float* __restrict__ bias, int B,
+                                                            const float* __restrict__ pi_feat, float* __restrict__ logits) {
+    constexpr int KCH = (FP + 31) / 32, KP = KCH * 32, NT = (A + 15) / 16, NQ = 4, TQ = NT / NQ, LROW = NT * 16, NW = 12, NSG = 4, RS = KP * 2 + 16;
+    static_assert(NT % NQ == 0, "column tiles divide into quarters");
+    extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+    uint8_t* FH = fsm;                      // [64][RS] f16 hi plane of 64 * x
+    uint8_t* FL = FH + 64 * RS;             // lo plane
+    h2_fp16_saturate_mode();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const int b0 = (int)blockIdx.x * 64, nb = min(64, B - b0), cq = (int)blockIdx.y;
+    const float descale = *(const float*)(Wfrag + (size_t)NT * KCH * 2 * 64);
+    auto wload = [&](int ctl, uint4* w) {                         // column tile cq * TQ + ctl of this quarter
+        const int ct = cq * TQ + (ctl < TQ ? ctl : 0);
+#pragma unroll
+        for (int c = 0; c < 2 * KCH; c++) w[c] = Wfrag[((size_t)ct * (2 * KCH) + c) * 64 + lane];
+    };
+    uint4 w0[2 * KCH], w1[2 * KCH];
+    wload(wave, w0);                        // (under the feature staging)
+    wload(wave + NW, w1);
+    for (int i = tid; i < 64 * (KP / 2); i += 768) {
+        const int s = i / (KP / 2), k = 2 * (i - s * (KP / 2));
+        const float x0 = (s < nb && k < FP) ? pi_feat[(size_t)(b0 + s) * A + k] : 0.f;
+        const float x1 = (s < nb && k + 1 < FP) ? pi_feat[(size_t)(b0 + s) * A + k + 1] : 0.f;
+        uint32_t h, l;
+        h2_split2(x0 * H2_AS, x1 * H2_AS, h, l);
+        *(uint32_t*)(FH + s * RS + 2 * k) = h;
+        *(uint32_t*)(FL + s * RS + 2 * k) = l;
+    }
+    __syncthreads();
+    auto tile = [&](int ctl, const uint4* w) {
+        const int col = (cq * TQ + ctl) * 16 + 4 * g;
+        const float4 b = *(const float4*)(bias + col);
+#pragma unroll 2                             /* (fully unrolled, the four groups' 40 operand reads were hoisted together: 118 spilled registers) */
+        for (int sg = 0; sg < NSG; sg++) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < KCH; c++) {
+                const int off = (16 * sg + r16) * RS + 64 * c + 16 * g;
+                acc = h2_mma(w[2 * c], w[2 * c + 1], *(const uint4*)(FH + off), *(const uint4*)(FL + off), acc);
+            }
+            const int s = 16 * sg + r16;
+            if (s < nb)
+                *(float4*)(logits + (size_t)(b0 + s) * LROW + col) =
+                    make_float4(acc[0] * descale + b.x, acc[1] * descale + b.y, acc[2] * descale + b.z, acc[3] * descale + b.w);
+        }
+    };
+#pragma unroll 1
+    for (int ctl = wave; ctl < TQ; ctl += 2 * NW) {
+        tile(ctl, w0);
+        wload(ctl + 2 * NW, w0);
+        if (ctl + NW < TQ) {
+            tile(ctl + NW, w1);
+            wload(ctl + 3 * NW, w1);
+        }
+    }
+}
+template <int A>
+__global__ __launch_bounds__(256) void k_s78_policy_softmax(const float* __restrict__ logits, const uint8_t* __restrict__ valid, int B,
+                                                            float* __restrict__ pi) {
+    // one wave per sample, a lane owns PAIRS of neighbouring actions (A is even: the valid bytes of a pair are one aligned 16-bit load,
+    // logits and probabilities 8-byte accesses)
+    static_assert(A % 2 == 0, "pairs of actions");
+    constexpr int LROW = (A + 15) / 16 * 16, NK = (A / 2 + 63) / 64;
+    const int lane = threadIdx.x & 63, b = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (b >= B) return;
+    float2 x[NK];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int ai = 2 * (lane + 64 * k);
+        x[k] = make_float2(-INFINITY, -INFINITY);
+        if (ai < A) {
+            const uint32_t vb = *(const uint16_t*)(valid + (size_t)b * A + ai);
+            const float2 lg = *(const float2*)(logits + (size_t)b * LROW + ai);
+            x[k] = make_float2((vb & 0xFFu) ? lg.x : -1e8f, (vb >> 8) ? lg.y : -1e8f);
+        }
+        mx = fmaxf(mx, fmaxf(x[k].x, x[k].y));
+    }
+    mx = nn_wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const bool on = 2 * (lane + 64 * k) < A;
+        x[k] = on ? make_float2(expf(x[k].x - mx), expf(x[k].y - mx)) : make_float2(0.f, 0.f);
+        sum += x[k].x; sum += x[k].y;
+    }
+    sum = nn_wave_sum(sum);
+#pragma unroll
+    for (int k = 0; k < NK; k++)
+        if (2 * (lane + 64 * k) < A) *(float2*)(pi + (size_t)b * A + 2 * (lane + 64 * k)) = make_float2(x[k].x / sum, x[k].y / sum);
+}
+
 #pragma clang fp contract(off)
 
 }  // namespace azg

@@ -430,7 +430,10 @@ int azg_nn_s78_forward_split(const int8_t* boards_dev, const uint8_t* valid_dev,
    [2 planes hi, lo][64 lanes][8] f16 of W * 2^k (one k per family), ds_e / ds_p = 2^-k / 64.  The policy FC runs on the same operands
    (k_s78_policy_h2): w[11] = [112 column tiles][5 K chunks of 32][2 planes hi, lo][64 lanes][8] f16 of Wfp * 2^k (K 132 -> 160,
    N 1782 -> 1792, zero padded; element = W_plane[32*chunk + 8*(lane>>4) + j][16*tile + (lane&15)]) followed by ONE float, its descale
-   2^-k / 64 (the 16-byte tail of the buffer).  Same 1e-5 contract. */
+   2^-k / 64 (the 16-byte tail of the buffer).  Three launches: trunk + value head; the FC as a GEMM (a workgroup = 64 samples x a quarter
+   of the column tiles: every weight fragment serves four sample groups; raw logits go to a per-device workspace of B x 1792 floats that
+   the library keeps and grows on demand); masked softmax into pi.  AZG_S78_POLICY2=0: FC + softmax in one launch (k_s78_policy_h2,
+   16 samples per workgroup, no workspace).  Same 1e-5 contract. */
 int azg_nn_s78_forward_h2(const int8_t* boards_dev, const uint8_t* valid_dev, const float* const* w, float ds_e, float ds_p, int n_blocks,
                           int A, int P, int B, float* pi_dev, float* v_dev, void* stream);
 /* boards int8 [B][C][7] (reference board layout) -> x f32 [B][7][C] */
