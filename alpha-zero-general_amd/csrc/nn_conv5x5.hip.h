@@ -1323,10 +1323,17 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
             const int r = (rg + RG * i) * 16 + r16;
             if (rg + RG * i >= RT || r >= ROWS) continue;
             if (NPL == 2) {
-                const f32x4 o = e[i * CTW] * ds_e + f32x4{b.x, b.y, b.z, b.w};
-                h2_store4(Hc, PLANE_B, 128, r, ct * 16 + 4 * g, f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)});
-                const f32x4 o2 = e[i * CTW + CTW - 1] * ds_e + f32x4{b2.x, b2.y, b2.z, b2.w};
-                h2_store4(Hc, PLANE_B, 128, r, (ct + 1) * 16 + 4 * g, f32x4{fmaxf(o2[0], 0.f), fmaxf(o2[1], 0.f), fmaxf(o2[2], 0.f), fmaxf(o2[3], 0.f)});
+                // (the expanded tile goes to the depthwise pass as F32 -- [row][64 channels], 16-byte chunks swizzled by the row, in the planes'
+                // units 64 * x -- over the same bytes the two f16 planes take afterwards: the depthwise pass reads all of it before it writes
+                // the planes.  Splitting here and joining there again was 10 of this epilogue's 14 and 40 of that pass's 165 vector instructions.)
+                const float se = ds_e * H2_AS;
+                const f32x4 o = e[i * CTW] * se + f32x4{b.x, b.y, b.z, b.w} * H2_AS;
+                *(float4*)(Hc + r * 256 + (((4 * ct + g) ^ (r & 7)) << 4)) = make_float4(fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f));
+                if (W2) {
+                    const f32x4 o2 = e[i * CTW + CTW - 1] * se + f32x4{b2.x, b2.y, b2.z, b2.w} * H2_AS;
+                    *(float4*)(Hc + r * 256 + (((4 * (ct + 1) + g) ^ (r & 7)) << 4)) =
+                        make_float4(fmaxf(o2[0], 0.f), fmaxf(o2[1], 0.f), fmaxf(o2[2], 0.f), fmaxf(o2[3], 0.f));
+                }
                 continue;
             }
             store_split4(Hc, PLANE_B, r, ct * 16 + 4 * g, make_float4(fmaxf(e[i][0] + b.x, 0.f), fmaxf(e[i][1] + b.y, 0.f),
@@ -1349,9 +1356,9 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
             // itself is an immediate offset.  In place: every read is done before the first write (the barrier in the middle).
             constexpr int PT = NS * 32;
             const int part = tid / PT, s_ = (tid >> 5) % NS, pr = tid & 31;
-            int base[8];
+            int fbase[8];                    // f32 tile (read) and planes (written, below): both swizzled by the row class (s + cell) & 7
 #pragma unroll
-            for (int j = 0; j < 8; j++) base[j] = s_ * 25 * 128 + (((pr >> 2) ^ ((s_ + j) & 7)) << 4) + ((pr & 3) << 2);
+            for (int j = 0; j < 8; j++) fbase[j] = s_ * 25 * 256 + (((pr >> 1) ^ ((s_ + j) & 7)) << 4) + ((pr & 1) << 3);
             f32x2 out[10];
             const f32x2 bias = dw_b * H2_AS;
             const f32x2 (&w)[9] = dw_w;
@@ -1360,8 +1367,7 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
                 f32x2 in[(I1 - I0 + 1) * 5];
 #pragma unroll
                 for (int k = I0 * 5; k < (I1 + 1) * 5; k++) {
-                    const uint8_t* src = Hc + base[k & 7] + k * 128;
-                    in[k - I0 * 5] = h2_join2(*(const uint32_t*)src, *(const uint32_t*)(src + PLANE_B));
+                    in[k - I0 * 5] = *(const f32x2*)(Hc + fbase[k & 7] + k * 256);
                 }
                 // (taps outside, outputs inside: ten independent accumulators between two uses of one -- a dependent packed
                 // multiply-add needs a wait state, and output by output the compiler emitted one s_nop per multiply-add)
@@ -1385,6 +1391,10 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
             else if (part == 1) rows(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
             else if (part == 2) rows(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
             __syncthreads();
+            if (tid < 32) ((uint32_t*)(Hc + ROWS * 128))[tid] = 0u;     // the hi plane's zero row lies inside the f32 tile (row ROWS / 2): zero again
+            int base[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) base[j] = s_ * 25 * 128 + (((pr >> 2) ^ ((s_ + j) & 7)) << 4) + ((pr & 3) << 2);
             auto put = [&](auto y0c, auto nyc) {
                 constexpr int Y0 = decltype(y0c)::value, NY = decltype(nyc)::value;
 #pragma unroll
