@@ -373,7 +373,7 @@ static int s78_launch(const int8_t* boards, const uint8_t* valid, const float* c
     if (n_blocks != 10 || A != 1782 || P != 2) return fail("azg_nn_s78_forward: built for 10 blocks, A = 1782, P = 2");
     S78NetW N{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15], w[16], w[17], w[18]};
     if (split == 2) {
-        constexpr size_t lds = (size_t)(2 + 3) * 202 * 128 + 8 * 32 * sizeof(float);      // X: two f16 planes; the H region keeps three planes' room
+        constexpr size_t lds = (size_t)(2 + 4) * 202 * 128 + 8 * 32 * sizeof(float);      // X: two f16 planes; H: the f32 expanded tile + two f16 planes behind it
         static bool attr = false;
         if (!attr) {
             HIPCHK(hipFuncSetAttribute((const void*)k_s78_net_split<10, 1782, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1252,7 +1252,8 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     constexpr bool W2 = NPL == 2 && AZG_S78_W2;            // two column tiles per wave (gemm64_split2): 2 column-tile pairs x 6 row groups
     constexpr int ROWS = NS * 25, RT = (ROWS + 15) / 16, RG = W2 ? 6 : 3, MAXT = (RT + RG - 1) / RG, CTW = W2 ? 2 : 1, CS = 68, E = 192;
     // (the f32 staging / head tile [ROWS][CS] + head buffers live in the H region: it keeps the size of three planes)
-    constexpr int PLANE_B = (ROWS + 2) * 128, TILE_B = NPL * PLANE_B, HREG_B = 3 * PLANE_B;
+    // (NPL = 2: the H region holds the f32 expanded tile AND, behind it, the two f16 planes the depthwise pass writes for the project GEMM)
+    constexpr int PLANE_B = (ROWS + 2) * 128, TILE_B = NPL * PLANE_B, HREG_B = NPL == 2 ? 2 * TILE_B : 3 * PLANE_B;
     constexpr size_t G64_U4 = (size_t)4 * 2 * NPL * 64;        // uint4 per 64 x 64 matrix
     extern __shared__ __attribute__((aligned(256))) float smem[];
     if (NPL == 2) h2_fp16_saturate_mode();
@@ -1286,7 +1287,8 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
     else conv3x3_first_split<NS, false, NPL>(N.W0, zero_bias, STG, XP);
     __syncthreads();
     C5_PH(10);
-    if (tid < NPL * 64) ((uint32_t*)(HP + (tid >> 6) * PLANE_B + ROWS * 128))[tid & 63] = 0u;      // H's zero row (the staging tile is dead)
+    uint8_t* const HPL = NPL == 2 ? HP + TILE_B : HP;           // the planes the project GEMM reads (NPL = 2: a buffer of their own)
+    if (tid < NPL * 64) ((uint32_t*)(HPL + (tid >> 6) * PLANE_B + ROWS * 128))[tid & 63] = 0u;      // H's zero row (the staging tile is dead)
     // The phases of a pass (third t of block blk), as functions of the H buffer they work on:
     f32x2 dw_w[9], dw_b;                    // (NPL = 2) the depthwise weights of this thread's channel pair, requested a phase ahead
     f32x4 pacc[MAXT * CTW];
@@ -1340,8 +1342,8 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
                                                                        fmaxf(e[i][2] + b.z, 0.f), fmaxf(e[i][3] + b.w, 0.f)));
         }
     };
-    auto depthwise = [&](int blk, int t, uint8_t* Hc) {
-        (void)blk; (void)t;
+    auto depthwise = [&](int blk, int t, uint8_t* Hc, uint8_t* Hd) {       // (Hd: where the planes go; NPL = 3: Hd == Hc, in place)
+        (void)blk; (void)t; (void)Hd;
         // ---- depthwise 3x3 + BN + ReLU in place: one thread = the 5x5 plane of one (sample, channel) ----
         // (round 4, f16 x 2 kernel, measured and dropped: one thread per channel PAIR -- dword accesses to the planes, packed f32
         // multiply-adds, 256 threads instead of 512 -- 415 -> 419 us per 4096 leaves; the GEMM phases' weight fragments and biases
@@ -1390,9 +1392,7 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
             if (part == 0) rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
             else if (part == 1) rows(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
             else if (part == 2) rows(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
-            __syncthreads();
-            if (tid < 32) ((uint32_t*)(Hc + ROWS * 128))[tid] = 0u;     // the hi plane's zero row lies inside the f32 tile (row ROWS / 2): zero again
-            int base[8];
+            int base[8];                     // (the planes are a buffer of their own: no barrier between the reads above and the writes below)
 #pragma unroll
             for (int j = 0; j < 8; j++) base[j] = s_ * 25 * 128 + (((pr >> 2) ^ ((s_ + j) & 7)) << 4) + ((pr & 3) << 2);
             auto put = [&](auto y0c, auto nyc) {
@@ -1401,7 +1401,7 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
                 for (int k = 0; k < NY * 5; k++) {
                     uint32_t h, l;
                     h2_split2(out[k].x, out[k].y, h, l);
-                    uint8_t* dst = Hc + base[(Y0 * 5 + k) & 7] + (Y0 * 5 + k) * 128;
+                    uint8_t* dst = Hd + base[(Y0 * 5 + k) & 7] + (Y0 * 5 + k) * 128;
                     *(uint32_t*)dst = h; *(uint32_t*)(dst + PLANE_B) = l;
                 }
             };
@@ -1509,15 +1509,18 @@ __global__ __launch_bounds__(768) void k_s78_net_split(S78NetW N, const int8_t* 
                 S78_PH(1);
                 __syncthreads();
                 S78_PH(2);
-                depthwise(blk, t, HP);
+                depthwise(blk, t, HP, HPL);
                 S78_PH(3);
                 __syncthreads();
                 S78_PH(4);
-                project(blk, t, HP);
+                project(blk, t, HPL);
                 S78_PH(5);
-                __syncthreads();
+                // (NPL = 2: no barrier here -- the next expand writes the f32 tile and reads X, the project GEMM read the planes; the next
+                // depthwise pass, which overwrites the planes, starts behind the barrier that follows that expand)
+                if (NPL != 2) __syncthreads();
                 S78_PH(6);
             }
+            // (X is rewritten below, each lane its own elements: the block's last expand, which read all of X, ran before the depthwise barrier)
             residual(blk);
             __syncthreads();
         }
