@@ -1242,7 +1242,11 @@ __global__ __launch_bounds__(768) void k_s78_net(S78NetW N, const int8_t* __rest
 // with the project accumulators kept in registers across the passes; every GEMM is the 64 x 64 gemm64_split (six bf16 MFMAs per
 // product).  N.We / N.Wp point to the split fragments [NB][3 thirds][4 ct][2 chunks][3 planes][64 lanes][8] bf16.
 // NPL = 2: f16 x 2 operands (hi + lo, three MFMAs per product, two planes per tile holding 64 * x; N.We / N.Wp then hold
-// [NB][3 thirds][4 ct][2 chunks][2 planes][64 lanes][8] f16 of W * 2^k, ds_e / ds_p = 2^-k / 64 of the two matrix families)
+// [NB][3 thirds][4 ct][2 chunks][2 planes][64 lanes][8] f16 of W * 2^k, ds_e / ds_p = 2^-k / 64 of the two matrix families).
+// NPL = 2 since round 6: LDS = X planes (52 KB) | the expanded third as an F32 tile [200][64], 16-byte chunks swizzled by the row (51 KB) |
+// the two f16 planes of the depthwise pass's output (52 KB) | meta features.  A pass: expand GEMM (two column tiles per wave,
+// gemm64_split2) -> f32 tile; barrier; depthwise 3x3 (a thread = a channel pair x a group of output rows; reads the f32 tile, writes the
+// planes); barrier; project GEMM from the planes -- and straight on into the next pass's expand, which touches neither: 7 barriers per block.
 #ifndef AZG_S78_W2
 #define AZG_S78_W2 1                        /* 0: one column tile per wave (4 x 3), the form of rounds 2-5 */
 #endif
