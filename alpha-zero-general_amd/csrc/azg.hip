@@ -29,7 +29,7 @@ static thread_local std::string g_err;
 int azg_fail(const std::string& m) { g_err = m; return -1; }
 
 extern "C" const char* azg_last_error(void) { return g_err.c_str(); }
-extern "C" const char* azg_version(void) { return "azg-hip r5 (gfx950)"; }
+extern "C" const char* azg_version(void) { return "azg-hip r6 (gfx950)"; }
 extern "C" int azg_forest_cfg_size(void) { return (int)sizeof(azg_forest_cfg); }      // ABI check of a binding against this build
 extern "C" int azg_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 extern "C" int azg_set_device(int d) { HIPCHK(hipSetDevice(d)); return 0; }
