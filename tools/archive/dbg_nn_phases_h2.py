@@ -1,6 +1,6 @@
 """debug build only (AZG_DEFINES=AZG_NN_PHASE_TIMES, AZG_LIB=that library): clock64 stamps of workgroup 7 / thread 0 of k_v80_net_h2"""
 import os, sys, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT]
 import torch
 from azg_amd import _lib
