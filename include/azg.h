@@ -199,7 +199,8 @@ int azg_forest_rounds_profile(azg_forest* f, double* out4, int reset);
    abandoned, [27] leaves re-queued).  With per-tree budgets every tree keeps the calls it has not run yet and a call of this function
    launches the pipeline TWICE -- the second launch grants nothing and only runs what the first left over -- so the "exactly `rounds` calls
    per tree" contract holds at every return whether or not the first launch ended early (both ending early: the next call catches up).
-   Eight early ends in a row set error bit 128 (azg_selfplay_stats.errors): a pipeline that cannot make progress fails loudly. */
+   Eight early ends in a row set error bit 128 (azg_selfplay_stats.errors): a pipeline that cannot make progress fails loudly.
+   rounds: 1 .. 2^24 - 1 with a shared budget, 1 .. 2^22 - 1 with per-tree budgets (<= 0: the call does nothing). */
 int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev,
                                    int noise_stride, const void* const* w, const float* descale_host, int rounds, int n_net, int n_sel,
                                    int batch_wait_ticks, int shared_budget, void* stream);
