@@ -523,11 +523,11 @@ __global__ __launch_bounds__(ASYNC_SEL_WAVES * 64) void k_async_select(const Asy
             wi[0] = where_am_i(); wi[1] = 1ull; wi[2] += C->prof[0]; wi[3] += C->prof[4];   // role | ticks this workgroup stayed << 8
             atomicAdd(prof + 10, (unsigned long long)(wall32() - t_begin));
             if (g == 0 && A->rounds > 0) atomicAdd(prof + 9, 1ull);            // (launches; not the catch-up launch of a per-tree budget)
-            // (sticky: launches that ended because a descent wave / a net workgroup gave up -- the error bit on tree 0 can be overwritten by
-            // that tree's own header write-back.  Anything more elaborate in the time-out branch itself changes the register allocation of the
-            // whole kernel: a post-mortem dump there took the scratch instructions of the Azul / Santorini / Splendor descents from 45 / 61 / 17
-            // to 175 / 194 / 75 and Azul at 1600 simulations from 35 to 25.5 k env-steps/s)
-            if (g == 0) { const uint32_t ab = aload(&A->ctl->abort); if (ab == 1u || ab == 2u) atomicAdd(prof + 16 + ab, 1ull); else if (ab == 0u) prof[19] = 0ull; }
+            // (Launches that ended early are counted by the NET kernel's workgroup 0: a net workgroup leaves only when the launch is over --
+            // a descent workgroup leaves when ITS trees are done, with per-tree budgets long before another one's wave may run into the
+            // time-out.  Anything more elaborate in the time-out branch itself changes the register allocation of the whole kernel: a
+            // post-mortem dump there took the scratch instructions of the Azul / Santorini / Splendor descents from 45 / 61 / 17 to
+            // 175 / 194 / 75 and Azul at 1600 simulations from 35 to 25.5 k env-steps/s.)
         }
         if (i < 32 && C->hist[i]) atomicAdd(prof + 64 + i, (unsigned long long)C->hist[i]);
     }
@@ -792,6 +792,8 @@ __global__ __launch_bounds__(768) void k_async_net(const AsyncArgs* args) {
         atomicAdd(prof + 7, P[4]); atomicAdd(prof + 11, (unsigned long long)(wall32() - t_begin)); atomicAdd(prof + 14, P[5]);
         unsigned long long* wi = A->wginfo + (size_t)(A->n_sel + (int)blockIdx.x) * 4;
         wi[0] = where_am_i(); wi[1] = 2ull | ((unsigned long long)(wall32() - t_begin) << 8); wi[2] += P[0]; wi[3] += P[5];
+        // sticky: launches that ended because a descent wave (17) / a net workgroup (18) gave up; 19 = such launches in a row (eight: an error)
+        if (blockIdx.x == 0) { const uint32_t ab = aload(&A->ctl->abort); if (ab == 1u || ab == 2u) atomicAdd(prof + 16 + ab, 1ull); else if (ab == 0u) prof[19] = 0ull; }
         // (post-mortems: the ticket range this workgroup held when it left -- first ticket | tickets taken << 32, valid | last batch size << 32)
         unsigned long long* dn = A->wginfo + (size_t)4 * 1024 + 280 + 2 * (size_t)blockIdx.x;
         dn[0] = (unsigned long long)(uint32_t)sidx[34] | ((unsigned long long)(uint32_t)sidx[35] << 32);
@@ -963,7 +965,7 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
                              int shared_budget, void* stream) {
     const std::string me(who);
     if (!f || !leaf_valid || !needs_eval || !pi || !v || (!hash && (!w || !descale))) return fail(me + ": null argument");
-    if (rounds <= 0) return 0;
+    if (rounds < 0 || (rounds == 0 && shared_budget)) return 0;       // (per-tree budgets: rounds == 0 = only what earlier launches left over)
     if (rounds >= (1 << 24)) return fail(me + ": at most 2^24 - 1 rounds per launch");
     if (noise_stride != 0 && noise_stride != -2) return fail(me + ": noise_stride must be 0 or -2");
     int game = 0, variant = 0;
@@ -1143,7 +1145,7 @@ static int async_rounds_impl(const char* who, int kind, int hash, azg_forest* f,
     HIPCHK(hipStreamWaitEvent(s, sl->join, 0));
     return 0;
     };
-    if (launch_once(rounds)) return -1;
+    if (rounds > 0 && launch_once(rounds)) return -1;
     if (!shared_budget && launch_once(0)) return -1;
     return 0;
 }

@@ -185,6 +185,8 @@ class SelfPlayEngine:
             if deterministic is None:
                 deterministic = os.environ.get('AZG_DETERMINISTIC', '0') == '1'
             cfg.setdefault('shared_budget', not deterministic)
+            self.deterministic = not cfg['shared_budget']
+            self._early_seen = 0
             self.groups[0].async_cfg = cfg
             # adaptive split (opt-in, AZG_ASYNC_ADAPT=1; only with the work-sharing budget -- with per-tree budgets the results must not
             # depend on anything measured): round 5 measured it and it LOSES to the fixed half-and-half split -- every chunk boundary is a
@@ -299,6 +301,18 @@ class SelfPlayEngine:
             grp = self.groups[0]
             if not self.adaptive:
                 grp.rounds(rounds, self.fused, self.percu)
+                if getattr(self, 'deterministic', False):
+                    # Per-tree budgets: the entry point follows its launch with a catch-up launch (what a launch that ended early -- the
+                    # platform froze a workgroup, csrc/azg_async.hip.h "Recovery" -- left over); should that one have ended early as well,
+                    # further catch-up launches (rounds = 0) follow here, so that "every tree has had exactly its calls" holds when run()
+                    # returns.  (Reads the pipeline's counters: a device synchronisation per run(), in this mode only.)
+                    for _ in range(16):
+                        to = self.forest.async_profile(reset=False)['timeouts']
+                        n = to['select'] + to['net']
+                        if n == self._early_seen:
+                            break
+                        self._early_seen = n
+                        grp.rounds(0, self.fused, self.percu)
             else:
                 # ADAPTIVE CU SPLIT: which side is the bottleneck changes with the phase of the games (late game: many simulations end on
                 # terminal nodes and need no forward -> the descents are; opening / middle game: every simulation needs one -> the net is,

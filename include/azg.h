@@ -200,7 +200,9 @@ int azg_forest_rounds_profile(azg_forest* f, double* out4, int reset);
    launches the pipeline TWICE -- the second launch grants nothing and only runs what the first left over -- so the "exactly `rounds` calls
    per tree" contract holds at every return whether or not the first launch ended early (both ending early: the next call catches up).
    Eight early ends in a row set error bit 128 (azg_selfplay_stats.errors): a pipeline that cannot make progress fails loudly.
-   rounds: 1 .. 2^24 - 1 with a shared budget, 1 .. 2^22 - 1 with per-tree budgets (<= 0: the call does nothing). */
+   rounds: 1 .. 2^24 - 1 with a shared budget, 1 .. 2^22 - 1 with per-tree budgets; rounds == 0 with per-tree budgets: a catch-up launch only
+   (Python's SelfPlayEngine(deterministic=True).run() issues these until the early-end counters [17] / [18] stop moving); < 0, or 0 with
+   a shared budget: the call does nothing.  Early ends are counted by the net kernel's workgroup 0, which leaves only when the launch is over. */
 int azg_forest_async_rounds_v80_h2(azg_forest* f, uint8_t* leaf_valid_dev, uint8_t* needs_eval_dev, float* pi_dev, float* v_dev,
                                    int noise_stride, const void* const* w, const float* descale_host, int rounds, int n_net, int n_sel,
                                    int batch_wait_ticks, int shared_budget, void* stream);
