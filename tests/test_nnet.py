@@ -304,6 +304,35 @@ def test_santorini_v78_one_launch_gpu(split):
 
 
 @pytest.mark.gpu
+def test_santorini_v78_policy_in_one_launch_gpu():
+    """AZG_S78_POLICY2=0: the with-gods net's policy FC + softmax as ONE launch (k_s78_policy_h2, 16 samples per workgroup, no workspace) instead
+    of the default GEMM + softmax pair -- the switch is read once per process, hence the subprocess: same outputs within 1e-5 of the f64
+    evaluation, exact zeros on invalid actions, on a ragged batch."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from azg_amd import nnet
+root = %r
+w = os.path.join(root, 'weights_santorini11_v78.npz')
+net = nnet.SantoriniV78Hip(nnet.SantoriniV78.from_npz(w, device='cuda:0'), max_batch=64)
+ref = nnet.SantoriniV78.from_npz(w, device='cuda:0', dtype=torch.float64)
+g = torch.Generator().manual_seed(5)
+boards = torch.randint(-2, 5, (203, 75), generator=g, dtype=torch.int8).to('cuda:0')
+rm = (torch.rand((203, 1782), generator=g) < 0.05).to('cuda:0'); rm[:, 7] = True
+pi, v = net.predict_batch(boards, rm)
+pr, vr = ref.predict_batch(boards.reshape(203, 5, 5, 3), rm)
+assert float((pi - pr).abs().max()) < 1e-5 and float((v - vr).abs().max()) < 1e-5
+assert float(pi[~rm].abs().max()) == 0.0
+print('ok')
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    env = dict(os.environ, AZG_S78_POLICY2='0')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('tag', ['splendor2_v80', 'splendor4_v80', 'azul_v84', 'santorini1_v89', 'santorini11_v78', 'minivilles2_v82', 'tlp3_v83'])
 def test_net_kernels_do_not_depend_on_stale_onchip_memory(tag):
     """every one-launch net kernel gives bit-identical outputs whatever the LDS of the CUs and the scratch memory of the queue held
